@@ -1,0 +1,41 @@
+"""In-tree build of libd2p_hip.so with hipcc for gfx950 (no JIT cache, no cmake)."""
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+SOURCES = ['api.hip', 'gemm.hip', 'conv.hip', 'bn.hip', 'lstm.hip', 'xent.hip', 'misc.hip',
+           'adam.hip']
+HEADERS = ['common.h', 'gemm_core.h', os.path.join('..', '..', 'include', 'd2p.h')]
+OUT = os.path.join(CSRC, 'libd2p_hip.so')
+
+
+def _stale():
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    for f in SOURCES + HEADERS:
+        if os.path.getmtime(os.path.join(CSRC, f)) > t:
+            return True
+    return False
+
+
+def build_library(force=False, verbose=False):
+    """Compile every HIP source into csrc/libd2p_hip.so.  hipcc cross-compiles for gfx950
+    without a GPU present."""
+    if not force and not _stale():
+        return OUT
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    if not os.path.exists(hipcc):
+        hipcc = 'hipcc'
+    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+           '-Wno-unused-result'] + SOURCES + ['-o', OUT + '.tmp']
+    if verbose:
+        print(' '.join(cmd))
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    os.replace(OUT + '.tmp', OUT)
+    return OUT
+
+
+if __name__ == '__main__':
+    print(build_library(force=True, verbose=True))

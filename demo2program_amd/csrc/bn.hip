@@ -1,0 +1,283 @@
+// K2: training-mode batch norm over row groups, forward and backward (include/d2p.h).
+// Replaces tf.contrib.layers.batch_norm(is_training=True) at models/ops.py:20-23.
+//
+// x is [R, C] row-major; group(r) = (r / inner) % G.  The reference runs the encoder once
+// per demonstration index (models/model_full.py:373-379), so the batched product path
+// needs one set of statistics per index: G = k, inner = rows per (program, demo).
+// Reductions are two-stage and deterministic: (G x S) workgroups write fp64 partial sums,
+// a finalize kernel folds them in a fixed order.  fp64 accumulation makes
+// E[x^2] - E[x]^2 safe for the un-normalised 0..255 ViZDoom activations.
+#include "common.h"
+
+#define BN_EPS 1e-3   // [TF-1.3] contrib.layers.batch_norm default epsilon
+
+struct BnPlan {
+    int lanes_c;    // threads along channels
+    int row_lanes;  // threads along rows
+    int S;          // row splits per group
+};
+
+static inline BnPlan bn_plan(int R, int C, int G) {
+    BnPlan p;
+    p.lanes_c = C < 256 ? C : 256;
+    p.row_lanes = 256 / p.lanes_c;
+    const int n = G > 0 ? R / G : 0;                      // rows per group
+    int s = 1024 / (G > 0 ? G : 1);
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    int cap = (n + p.row_lanes * 8 - 1) / (p.row_lanes * 8);
+    if (cap < 1) cap = 1;
+    if (s > cap) s = cap;
+    p.S = s;
+    return p;
+}
+
+extern "C" size_t d2p_bn_ws_bytes(int R, int C, int G) {
+    if (R <= 0 || C <= 0 || G <= 0) return 0;
+    BnPlan p = bn_plan(R, C, G);
+    return (size_t)G * p.S * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(float);
+}
+
+// partial[((g*S + s)*C + c)*2 + {0,1}] = sum over this block's rows of (a, b) where
+//   MODE 0 (fwd):  a = x,   b = x*x
+//   MODE 1 (bwd):  a = dy,  b = dy * xhat
+template <int MODE>
+__global__ void __launch_bounds__(256)
+bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, const float* x,
+                  const float* dy, const float* mean, const float* rstd, double* partial) {
+    __shared__ double red[2][256];
+    const int g = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const int tid = threadIdx.x;
+    const int cl = tid % lanes_c, rl = tid / lanes_c;
+    const bool active = rl < row_lanes;
+    for (int c0 = 0; c0 < C; c0 += lanes_c) {
+        const int c = c0 + cl;
+        double a = 0.0, b = 0.0;
+        if (active && c < C) {
+            float mu = 0.f, rs = 0.f;
+            if (MODE == 1) { mu = mean[g * C + c]; rs = rstd[g * C + c]; }
+            for (int j = s * row_lanes + rl; j < n; j += S * row_lanes) {
+                const int o = j / inner, ii = j - o * inner;
+                const long r = ((long)o * G + g) * inner + ii;
+                const float xv = x[r * C + c];
+                if (MODE == 0) {
+                    a += (double)xv;
+                    b += (double)xv * (double)xv;
+                } else {
+                    const float d = dy[r * C + c];
+                    a += (double)d;
+                    b += (double)d * (double)((xv - mu) * rs);
+                }
+            }
+        }
+        red[0][tid] = a;
+        red[1][tid] = b;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            for (int q = 1; q < row_lanes; ++q) {
+                a += red[0][q * lanes_c + cl];
+                b += red[1][q * lanes_c + cl];
+            }
+            double* out = partial + (((long)g * S + s) * C + c) * 2;
+            out[0] = a;
+            out[1] = b;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bn_finalize_fwd_kernel(int n, int C, int G, int S, const double* partial, float* mean, float* rstd,
+                       float* var_out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= G * C) return;
+    const int g = idx / C, c = idx - g * C;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double* p = partial + (((long)g * S + s) * C + c) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    const double mu = a / n;
+    double var = b / n - mu * mu;   // biased variance
+    if (var < 0.0) var = 0.0;
+    mean[idx] = (float)mu;
+    rstd[idx] = (float)(1.0 / sqrt(var + BN_EPS));
+    if (var_out) var_out[idx] = (float)var;
+}
+
+// m12[(g*C+c)*2 + {0,1}] = (mean_g(dy), mean_g(dy*xhat)); dgamma/dbeta summed over groups.
+__global__ void __launch_bounds__(256)
+bn_finalize_bwd_kernel(int n, int C, int G, int S, const double* partial, float* m12,
+                       float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double sg = 0.0, sb = 0.0;
+    for (int g = 0; g < G; ++g) {
+        double a = 0.0, b = 0.0;
+        for (int s = 0; s < S; ++s) {
+            const double* p = partial + (((long)g * S + s) * C + c) * 2;
+            a += p[0];
+            b += p[1];
+        }
+        m12[((long)g * C + c) * 2 + 0] = (float)(a / n);
+        m12[((long)g * C + c) * 2 + 1] = (float)(b / n);
+        sb += a;
+        sg += b;
+    }
+    if (dgamma) dgamma[c] = (float)sg;
+    if (dbeta) dbeta[c] = (float)sb;
+}
+
+__global__ void __launch_bounds__(256)
+bn_apply_fwd_kernel(long R, int C, int G, int inner, const float* x, const float* gamma,
+                    const float* beta, const float* mean, const float* rstd, float* y) {
+    const long total = R * C;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const long r = idx / C;
+        const int c = (int)(idx - r * C);
+        const int g = (int)((r / inner) % G);
+        y[idx] = gamma[c] * (x[idx] - mean[g * C + c]) * rstd[g * C + c] + beta[c];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bn_apply_fwd_vec4_kernel(long R, int C, int G, int inner, const float* x, const float* gamma,
+                         const float* beta, const float* mean, const float* rstd, float* y) {
+    const int C4 = C >> 2;
+    const long total = R * C4;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const long r = idx / C4;
+        const int c = (int)(idx - r * C4) * 4;
+        const int g = (int)((r / inner) % G);
+        const float4 xv = *reinterpret_cast<const float4*>(x + r * C + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        const float4 mu = *reinterpret_cast<const float4*>(mean + g * C + c);
+        const float4 rs = *reinterpret_cast<const float4*>(rstd + g * C + c);
+        float4 o;
+        o.x = ga.x * (xv.x - mu.x) * rs.x + be.x;
+        o.y = ga.y * (xv.y - mu.y) * rs.y + be.y;
+        o.z = ga.z * (xv.z - mu.z) * rs.z + be.z;
+        o.w = ga.w * (xv.w - mu.w) * rs.w + be.w;
+        *reinterpret_cast<float4*>(y + r * C + c) = o;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+bn_apply_bwd_kernel(long R, int C, int G, int inner, const float* x, const float* dy,
+                    const float* gamma, const float* mean, const float* rstd, const float* m12,
+                    int act_bwd, float* dx) {
+    const long total = R * C;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const long r = idx / C;
+        const int c = (int)(idx - r * C);
+        const int g = (int)((r / inner) % G);
+        const float xv = x[idx];
+        const float rs = rstd[g * C + c];
+        const float xhat = (xv - mean[g * C + c]) * rs;
+        const float m1 = m12[((long)g * C + c) * 2], m2 = m12[((long)g * C + c) * 2 + 1];
+        float d = gamma[c] * rs * (dy[idx] - m1 - xhat * m2);
+        if (act_bwd) d *= d2p_lrelu_grad_from_out(xv);
+        dx[idx] = d;
+    }
+}
+
+static int bn_check(int R, int C, int G, int inner) {
+    D2P_REQUIRE(R >= 0 && C > 0 && G > 0 && inner > 0, D2P_EINVAL,
+                "bn: bad sizes R=%d C=%d G=%d inner=%d", R, C, G, inner);
+    D2P_REQUIRE(R % (G * inner) == 0, D2P_EINVAL,
+                "bn: R=%d is not a multiple of G*inner=%d", R, G * inner);
+    return D2P_OK;
+}
+
+static inline int ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    if (b > 2048) b = 2048;   // 256 CUs x 8 blocks, grid-stride the rest
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, const float* gamma,
+                                const float* beta, float* y, float* mean, float* rstd,
+                                float* var_out, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    int rc = bn_check(R, C, G, inner);
+    if (rc) return rc;
+    if (R == 0) return D2P_OK;
+    D2P_REQUIRE(x && gamma && beta && y && mean && rstd, D2P_EINVAL, "bn fwd: null pointer");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_bn_ws_bytes(R, C, G), D2P_EWS,
+                "bn fwd: workspace too small (%zu < %zu)", ws_bytes, d2p_bn_ws_bytes(R, C, G));
+    hipStream_t st = as_stream(stream);
+    BnPlan p = bn_plan(R, C, G);
+    const int n = R / G;
+    double* partial = (double*)ws;
+    hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
+                       p.lanes_c, p.row_lanes, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, partial);
+    D2P_LAUNCH_CHECK("bn_partial_fwd");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(G * C, 256)), dim3(256), 0, st, n, C, G,
+                       p.S, partial, mean, rstd, var_out);
+    D2P_LAUNCH_CHECK("bn_finalize_fwd");
+    const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma |
+                                        (uintptr_t)beta | (uintptr_t)mean | (uintptr_t)rstd) & 15) == 0);
+    if (vec) {
+        hipLaunchKernelGGL(bn_apply_fwd_vec4_kernel, dim3(ew_blocks((long)R * C / 4)), dim3(256), 0,
+                           st, (long)R, C, G, inner, x, gamma, beta, mean, rstd, y);
+    } else {
+        hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks((long)R * C)), dim3(256), 0, st,
+                           (long)R, C, G, inner, x, gamma, beta, mean, rstd, y);
+    }
+    D2P_LAUNCH_CHECK("bn_apply_fwd");
+    return D2P_OK;
+}
+
+extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float* dy,
+                                const float* gamma, const float* mean, const float* rstd,
+                                int act_bwd, float* dx, float* dgamma, float* dbeta, void* ws,
+                                size_t ws_bytes, d2p_stream_t stream) {
+    int rc = bn_check(R, C, G, inner);
+    if (rc) return rc;
+    if (R == 0) return D2P_OK;
+    D2P_REQUIRE(x && dy && gamma && mean && rstd && dx, D2P_EINVAL, "bn bwd: null pointer");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_bn_ws_bytes(R, C, G), D2P_EWS,
+                "bn bwd: workspace too small (%zu < %zu)", ws_bytes, d2p_bn_ws_bytes(R, C, G));
+    hipStream_t st = as_stream(stream);
+    BnPlan p = bn_plan(R, C, G);
+    const int n = R / G;
+    double* partial = (double*)ws;
+    float* m12 = (float*)((char*)ws + (size_t)G * p.S * C * 2 * sizeof(double));
+    hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
+                       p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial);
+    D2P_LAUNCH_CHECK("bn_partial_bwd");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, n, C, G,
+                       p.S, partial, m12, dgamma, dbeta);
+    D2P_LAUNCH_CHECK("bn_finalize_bwd");
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks((long)R * C)), dim3(256), 0, st, (long)R,
+                       C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx);
+    D2P_LAUNCH_CHECK("bn_apply_bwd");
+    return D2P_OK;
+}
+
+__global__ void __launch_bounds__(256)
+bn_update_moving_kernel(int C, int G, float decay, const float* mean, const float* var,
+                        float* mm, float* mv) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = mm[c], b = mv[c];
+    for (int g = 0; g < G; ++g) {   // one update per Demo_Encoder call, in call order
+        a = decay * a + (1.f - decay) * mean[g * C + c];
+        b = decay * b + (1.f - decay) * var[g * C + c];
+    }
+    mm[c] = a;
+    mv[c] = b;
+}
+
+extern "C" int d2p_bn_update_moving(int C, int G, float decay, const float* mean, const float* var,
+                                    float* moving_mean, float* moving_var, d2p_stream_t stream) {
+    D2P_REQUIRE(C > 0 && G > 0, D2P_EINVAL, "bn moving: bad sizes C=%d G=%d", C, G);
+    D2P_REQUIRE(mean && var && moving_mean && moving_var, D2P_EINVAL, "bn moving: null pointer");
+    hipLaunchKernelGGL(bn_update_moving_kernel, dim3(ceil_div(C, 256)), dim3(256), 0,
+                       as_stream(stream), C, G, decay, mean, var, moving_mean, moving_var);
+    D2P_LAUNCH_CHECK("bn_update_moving");
+    return D2P_OK;
+}

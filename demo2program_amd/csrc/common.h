@@ -1,0 +1,72 @@
+// Shared helpers for the gfx950 kernels behind include/d2p.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/d2p.h"
+
+// ---- error reporting (thread-local string, include/d2p.h conventions) -------------
+void d2p_set_error(const char* fmt, ...);
+
+#define D2P_REQUIRE(cond, code, ...)                 \
+    do {                                             \
+        if (!(cond)) {                               \
+            d2p_set_error(__VA_ARGS__);              \
+            return (code);                           \
+        }                                            \
+    } while (0)
+
+#define D2P_HIP(expr)                                                              \
+    do {                                                                           \
+        hipError_t e__ = (expr);                                                   \
+        if (e__ != hipSuccess) {                                                   \
+            d2p_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__),  \
+                          __FILE__, __LINE__);                                     \
+            return (int)e__;                                                       \
+        }                                                                          \
+    } while (0)
+
+#define D2P_LAUNCH_CHECK(name)                                                     \
+    do {                                                                           \
+        hipError_t e__ = hipGetLastError();                                        \
+        if (e__ != hipSuccess) {                                                   \
+            d2p_set_error("launch of %s failed: %s", name, hipGetErrorString(e__)); \
+            return (int)e__;                                                       \
+        }                                                                          \
+    } while (0)
+
+static inline hipStream_t as_stream(d2p_stream_t s) { return (hipStream_t)s; }
+
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long ceil_divl(long a, long b) { return (a + b - 1) / b; }
+
+// ---- device helpers ------------------------------------------------------------------
+#define D2P_WAVE 64
+
+__device__ __forceinline__ float d2p_lrelu(float x) {
+    // models/ops.py:7-11: 0.6*x + 0.4*|x|
+    return 0.6f * x + 0.4f * fabsf(x);
+}
+__device__ __forceinline__ float d2p_lrelu_grad_from_out(float a) {
+    // sign(lrelu(x)) == sign(x); TF: d|x|/dx at 0 is 0 -> slope 0.6 there.
+    return a > 0.f ? 1.0f : (a < 0.f ? 0.2f : 0.6f);
+}
+// Accurate (ocml) exp/tanh: the gate kernels are HBM/latency-bound, so the few extra
+// VALU ops are free, and they keep logits within the 1e-4 parity budget over 50 steps.
+__device__ __forceinline__ float d2p_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float d2p_tanh(float x) { return tanhf(x); }
+
+template <typename T>
+__device__ __forceinline__ T wave_reduce_sum(T v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_reduce_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}

@@ -1,0 +1,104 @@
+// K5: dense fp32 MFMA GEMM entry points + column sum (include/d2p.h).
+#include "gemm_core.h"
+
+static inline int vec_ok(const float* p, long ld) {
+    return (((uintptr_t)p & 15) == 0 && (ld % 4) == 0) ? 1 : 0;
+}
+
+static int check_gemm_args(int M, int N, int K, const float* A, const float* B, float* C,
+                           int act) {
+    D2P_REQUIRE(M >= 0 && N >= 0 && K >= 0, D2P_EINVAL, "gemm: negative dimension M=%d N=%d K=%d", M, N, K);
+    D2P_REQUIRE(act == 0 || act == 1, D2P_EINVAL, "gemm: unknown act %d", act);
+    if (M == 0 || N == 0) return D2P_OK;
+    D2P_REQUIRE(C != nullptr, D2P_EINVAL, "gemm: C is null");
+    D2P_REQUIRE(K == 0 || (A != nullptr && B != nullptr), D2P_EINVAL, "gemm: A or B is null");
+    return D2P_OK;
+}
+
+extern "C" size_t d2p_gemm_ws_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    return d2p_plan_ws_bytes(M, N, K);
+}
+
+extern "C" int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, const float* B,
+                               long ldb, float* C, long ldc, const float* bias, int act,
+                               int accumulate, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    int rc = check_gemm_args(M, N, K, A, B, C, act);
+    if (rc) return rc;
+    DenseKC al{A, lda, M, vec_ok(A, lda)};
+    DenseXC bl{B, ldb, N, vec_ok(B, ldb)};
+    EpiDense ep{C, ldc, bias, act, accumulate};
+    return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_nn");
+}
+
+extern "C" int d2p_gemm_f32_nt(int M, int N, int K, const float* A, long lda, const float* B,
+                               long ldb, float* C, long ldc, const float* bias, int act,
+                               int accumulate, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    int rc = check_gemm_args(M, N, K, A, B, C, act);
+    if (rc) return rc;
+    DenseKC al{A, lda, M, vec_ok(A, lda)};
+    DenseKC bl{B, ldb, N, vec_ok(B, ldb)};   // B is [N,K]: K contiguous
+    EpiDense ep{C, ldc, bias, act, accumulate};
+    return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_nt");
+}
+
+extern "C" int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, const float* B,
+                               long ldb, float* C, long ldc, const float* bias, int act,
+                               int accumulate, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    int rc = check_gemm_args(M, N, K, A, B, C, act);
+    if (rc) return rc;
+    DenseXC al{A, lda, M, vec_ok(A, lda)};   // A is [K,M]: M contiguous
+    DenseXC bl{B, ldb, N, vec_ok(B, ldb)};
+    EpiDense ep{C, ldc, bias, act, accumulate};
+    return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_tn");
+}
+
+// ---- column sum (bias gradients): two-stage, deterministic --------------------------
+// stage 1: block (cb, s) sums rows r = s, s+S, ... of 64 columns; stage 2 sums the S partials.
+#define COLSUM_S 64
+
+__global__ void __launch_bounds__(256)
+colsum_stage1(int rows, int cols, const float* X, long ld, float* part) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) s += X[(long)r * ld + c];
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        part[(long)blockIdx.y * cols + c] = s;
+    }
+}
+__global__ void __launch_bounds__(256) colsum_stage2(int cols, int S, const float* part, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < S; ++i) s += part[(long)i * cols + c];
+    out[c] = s;
+}
+
+extern "C" size_t d2p_colsum_ws_bytes(int rows, int cols) {
+    (void)rows;
+    return cols > 0 ? (size_t)COLSUM_S * cols * sizeof(float) : 0;
+}
+
+extern "C" int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float* out, void* ws,
+                              size_t ws_bytes, d2p_stream_t stream) {
+    D2P_REQUIRE(rows >= 0 && cols >= 0, D2P_EINVAL, "colsum: negative size");
+    if (cols == 0) return D2P_OK;
+    D2P_REQUIRE(out && (rows == 0 || X), D2P_EINVAL, "colsum: null pointer");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_colsum_ws_bytes(rows, cols), D2P_EWS,
+                "colsum: workspace too small (%zu < %zu)", ws_bytes, d2p_colsum_ws_bytes(rows, cols));
+    hipStream_t st = as_stream(stream);
+    float* part = (float*)ws;
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 64), COLSUM_S), dim3(256), 0, st, rows,
+                       cols, X, ld, part);
+    D2P_LAUNCH_CHECK("colsum_stage1");
+    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 256)), dim3(256), 0, st, cols, COLSUM_S,
+                       part, out);
+    D2P_LAUNCH_CHECK("colsum_stage2");
+    return D2P_OK;
+}

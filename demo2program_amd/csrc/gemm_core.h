@@ -1,0 +1,313 @@
+// fp32 MFMA GEMM core for gfx950: C[M,N] = A[M,K] * B[K,N] with pluggable operand
+// loaders (dense / implicit im2col) and epilogues.
+//
+// Machine mapping (MI355X_MICROARCH.md, cdna_hip_programming.md §3):
+//  - v_mfma_f32_32x32x2_f32: per wave a 32x32 fp32 tile, K=2 per instruction, exact
+//    f32 (bitwise an fmaf chain), 64 cycles/SIMD -> 157 TF chip peak.
+//    A operand: lane l holds A[i=l&31][k=l>>5]; B: lane l holds B[k=l>>5][j=l&31];
+//    C/D: 16 regs/lane, col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+//  - 256-thread workgroups = 4 waves (one per SIMD) arranged 2x2 over a BMxBN tile,
+//    each wave owning TMxTN MFMA tiles (TM=BM/64, TN=BN/64).
+//  - K is consumed in BK=16 slabs staged through double-buffered LDS; one barrier per
+//    slab; the next slab's global loads are issued before the MFMAs of the current one.
+//  - An operand whose K index is contiguous in memory ("KCONTIG", e.g. row-major A) is
+//    stored in LDS as [x][BK+4] and read with one ds_read_b128 per 4 MFMAs: lanes 0-31
+//    take k..k+3, lanes 32-63 take k+4..k+7, and the j-th MFMA of the group consumes
+//    component j from every lane (any pairing of k indices is valid as long as A and B
+//    agree).  Row stride 20 floats = 5 sixteen-byte slots (odd) -> conflict-free b128.
+//  - An operand whose x index is contiguous ("XCONTIG", e.g. row-major B) is stored as
+//    [BK][BX] and read with ds_read_b32: lanes 0-31 consecutive floats -> conflict-free.
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define D2P_GEMM_BK 16
+
+// ------------------------------------------------------------------------------------
+// Loaders.  load4(x, k, klim, v):
+//   KCONTIG:  v[j] = elem(x, k+j)  for k+j < klim, x < X, else 0
+//   XCONTIG:  v[j] = elem(x+j, k)  for x+j < X, k < klim, else 0
+// ------------------------------------------------------------------------------------
+struct DenseKC {  // elem(x,k) = p[x*ld + k]
+    static constexpr bool KCONTIG = true;
+    const float* p;
+    long ld;
+    int X;
+    int vec;  // ld % 4 == 0 and p 16-byte aligned
+    __device__ __forceinline__ void load4(int x, int k, int klim, float (&v)[4]) const {
+        if (x >= X) {
+            v[0] = v[1] = v[2] = v[3] = 0.f;
+            return;
+        }
+        const float* q = p + (long)x * ld + k;
+        if (vec && k + 3 < klim) {
+            float4 t = *reinterpret_cast<const float4*>(q);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (k + j < klim) ? q[j] : 0.f;
+        }
+    }
+};
+
+struct DenseXC {  // elem(x,k) = p[k*ld + x]
+    static constexpr bool KCONTIG = false;
+    const float* p;
+    long ld;
+    int X;
+    int vec;
+    __device__ __forceinline__ void load4(int x, int k, int klim, float (&v)[4]) const {
+        if (k >= klim) {
+            v[0] = v[1] = v[2] = v[3] = 0.f;
+            return;
+        }
+        const float* q = p + (long)k * ld + x;
+        if (vec && x + 3 < X) {
+            float4 t = *reinterpret_cast<const float4*>(q);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (x + j < X) ? q[j] : 0.f;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// Epilogues.  operator()(row, col, value): called once per in-range output element.
+// ------------------------------------------------------------------------------------
+struct EpiDense {
+    float* C;
+    long ldc;
+    const float* bias;  // [N] or null
+    int act;            // 0 none, 1 lrelu(0.2)
+    int accumulate;     // C = act(v + C_old + bias)
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        float* c = C + (long)row * ldc + col;
+        if (accumulate) v += *c;
+        if (bias) v += bias[col];
+        if (act == 1) v = d2p_lrelu(v);
+        *c = v;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, class AL, class BL, class EP>
+__global__ void __launch_bounds__(256)
+gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial) {
+    constexpr int BK = D2P_GEMM_BK;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int A_LD = AL::KCONTIG ? (BK + 4) : BM;
+    constexpr int B_LD = BL::KCONTIG ? (BK + 4) : BN;
+    constexpr int A_SZ = AL::KCONTIG ? BM * (BK + 4) : BK * BM;
+    constexpr int B_SZ = BL::KCONTIG ? BN * (BK + 4) : BK * BN;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nbn = (N + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+    const int kbeg = blockIdx.z * k_per_split;
+    const int kend = min(K, kbeg + k_per_split);
+    const int nk = (kend - kbeg + BK - 1) / BK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float ra[TM][4], rb[TN][4];
+
+    auto gload = [&](int kt) {
+        const int k0 = kbeg + kt * BK;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int q = tid + i * 256;
+            if (AL::KCONTIG) al.load4(m0 + (q >> 2), k0 + (q & 3) * 4, kend, ra[i]);
+            else al.load4(m0 + (q % (BM / 4)) * 4, k0 + q / (BM / 4), kend, ra[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int q = tid + i * 256;
+            if (BL::KCONTIG) bl.load4(n0 + (q >> 2), k0 + (q & 3) * 4, kend, rb[i]);
+            else bl.load4(n0 + (q % (BN / 4)) * 4, k0 + q / (BN / 4), kend, rb[i]);
+        }
+    };
+    auto sstore = [&](int buf) {
+        float* As = smem + buf * (A_SZ + B_SZ);
+        float* Bs = As + A_SZ;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int q = tid + i * 256;
+            float4 t = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
+            if (AL::KCONTIG) *reinterpret_cast<float4*>(&As[(q >> 2) * A_LD + (q & 3) * 4]) = t;
+            else *reinterpret_cast<float4*>(&As[(q / (BM / 4)) * A_LD + (q % (BM / 4)) * 4]) = t;
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int q = tid + i * 256;
+            float4 t = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
+            if (BL::KCONTIG) *reinterpret_cast<float4*>(&Bs[(q >> 2) * B_LD + (q & 3) * 4]) = t;
+            else *reinterpret_cast<float4*>(&Bs[(q / (BN / 4)) * B_LD + (q % (BN / 4)) * 4]) = t;
+        }
+    };
+    auto compute = [&](int buf) {
+        const float* As = smem + buf * (A_SZ + B_SZ);
+        const float* Bs = As + A_SZ;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float fa[TM][4], fb[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int x = wm * (BM / 2) + i * 32 + l32;
+                if (AL::KCONTIG) {
+                    float4 t = *reinterpret_cast<const float4*>(&As[x * A_LD + kk * 8 + 4 * hi]);
+                    fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[i][j] = As[(kk * 8 + 4 * hi + j) * A_LD + x];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int x = wn * (BN / 2) + i * 32 + l32;
+                if (BL::KCONTIG) {
+                    float4 t = *reinterpret_cast<const float4*>(&Bs[x * B_LD + kk * 8 + 4 * hi]);
+                    fb[i][0] = t.x; fb[i][1] = t.y; fb[i][2] = t.z; fb[i][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[i][j] = Bs[(kk * 8 + 4 * hi + j) * B_LD + x];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < TN; ++jj)
+                        acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[jj][j],
+                                                                          acc[i][jj], 0, 0, 0);
+        }
+    };
+
+    if (nk > 0) {
+        gload(0);
+        sstore(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1 < nk);
+            if (more) gload(kt + 1);
+            compute(buf);
+            if (more) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+
+    const bool split = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int col = n0 + wn * (BN / 2) + j * 32 + l32;
+                if (row < M && col < N) {
+                    if (split) partial[((long)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+                    else ep(row, col, acc[i][j][r]);
+                }
+            }
+}
+
+// Deterministic split-K combine: sums the nz partial slabs in slab order, then applies EP.
+template <class EP>
+__global__ void __launch_bounds__(256)
+gemm_splitk_reduce_kernel(EP ep, const float* partial, int M, int N, int nz) {
+    const long total = (long)M * N;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        float s = 0.f;
+        for (int z = 0; z < nz; ++z) s += partial[(long)z * total + idx];
+        ep((int)(idx / N), (int)(idx % N), s);
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Host-side launch policy shared by gemm.hip and conv.hip.
+// ------------------------------------------------------------------------------------
+struct GemmPlan {
+    int big;      // 1: 128x128 tiles, 0: 64x64
+    int splits;   // grid.z
+    int k_per_split;
+};
+
+static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
+    GemmPlan p;
+    const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    const long t64 = (long)ceil_div(M, 64) * ceil_div(N, 64);
+    p.big = (t128 >= 512) ? 1 : 0;   // >= 2 full rounds of 256 CUs at the large tile
+    p.splits = 1;
+    p.k_per_split = K;
+    const long tiles = p.big ? t128 : t64;
+    if (allow_split && tiles < 128 && K >= 1024) {
+        long want = (512 + tiles - 1) / tiles;           // aim at ~512 workgroups
+        long maxs = K / 256;                             // keep >= 256 of K per split
+        long s = want < maxs ? want : maxs;
+        if (s > 1) {
+            int kps = (int)((K + s - 1) / s);
+            kps = (kps + D2P_GEMM_BK - 1) / D2P_GEMM_BK * D2P_GEMM_BK;
+            p.k_per_split = kps;
+            p.splits = (K + kps - 1) / kps;
+        }
+    }
+    return p;
+}
+
+static inline size_t d2p_plan_ws_bytes(int M, int N, int K) {
+    GemmPlan p = d2p_plan_gemm(M, N, K, true);
+    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+}
+
+template <class AL, class BL, class EP>
+static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
+                           void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+    if (M <= 0 || N <= 0) return D2P_OK;
+    GemmPlan p = d2p_plan_gemm(M, N, K, ws != nullptr);
+    float* partial = nullptr;
+    if (p.splits > 1) {
+        const size_t need = (size_t)p.splits * M * N * sizeof(float);
+        if (ws_bytes < need) {   // not enough scratch: fall back to a single pass
+            p.splits = 1;
+            p.k_per_split = K;
+        } else {
+            partial = (float*)ws;
+        }
+    }
+    if (p.big) {
+        dim3 grid(ceil_div(M, 128) * ceil_div(N, 128), 1, p.splits);
+        hipLaunchKernelGGL((gemm_mfma_kernel<128, 128, AL, BL, EP>), grid, dim3(256), 0, st,
+                           al, bl, ep, M, N, K, p.k_per_split, partial);
+    } else {
+        dim3 grid(ceil_div(M, 64) * ceil_div(N, 64), 1, p.splits);
+        hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, AL, BL, EP>), grid, dim3(256), 0, st,
+                           al, bl, ep, M, N, K, p.k_per_split, partial);
+    }
+    D2P_LAUNCH_CHECK(name);
+    if (p.splits > 1) {
+        const long total = (long)M * N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EP>), dim3(blocks), dim3(256), 0, st, ep,
+                           partial, M, N, p.splits);
+        D2P_LAUNCH_CHECK("gemm_splitk_reduce");
+    }
+    return D2P_OK;
+}

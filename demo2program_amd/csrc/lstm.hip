@@ -1,0 +1,264 @@
+// K3/K4 + sequence drivers: BasicLSTMCell gates and the recurrent loop (include/d2p.h).
+// Replaces rnn.BasicLSTMCell + tf.nn.dynamic_rnn (models/model_full.py:244-256,265-276)
+// and the BasicDecoder/TrainingHelper loop (models/model_full.py:413,465-471).
+//
+// [TF-1.3] BasicLSTMCell: z = [x,h]·W + b split as i, j, f, o;
+//   c' = c*sigmoid(f + 1.0) + sigmoid(i)*tanh(j);  h' = tanh(c')*sigmoid(o).
+// dynamic_rnn(sequence_length): for t >= len the emitted output is 0 and (c,h) copy through.
+//
+// The input projection x·Wx + b is hoisted out of the loop by the caller (one large GEMM
+// over all steps); per step only the recurrent h·Wh GEMM (accumulating into the stored
+// pre-activations) and the pointwise gate kernel run.  The pre-activations are kept for
+// backward; activations are recomputed there (saves 3/4 of the saved-state traffic).
+#include "common.h"
+
+#define FORGET_BIAS 1.0f
+
+struct f4 { float v[4]; };
+__device__ __forceinline__ f4 ldf4(const float* p) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    f4 r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
+}
+__device__ __forceinline__ void stf4(float* p, const f4& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+__device__ __forceinline__ f4 zero4() { f4 r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f; return r; }
+
+__global__ void __launch_bounds__(256)
+lstm_gate_fwd_kernel(int M, int U, const float* __restrict__ z, long zrs,
+                     const float* __restrict__ c_prev, const float* __restrict__ h_prev,
+                     const int* __restrict__ lens, int t, float* __restrict__ c_out,
+                     float* __restrict__ hs_out, float* __restrict__ h_out) {
+    const int U4 = U >> 2;
+    const long total = (long)M * U4;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int r = (int)(idx / U4);
+        const int u = (int)(idx - (long)r * U4) * 4;
+        const long o = (long)r * U + u;
+        const bool active = lens ? (t < lens[r]) : true;
+        f4 cp = c_prev ? ldf4(c_prev + o) : zero4();
+        if (active) {
+            const float* zr = z + (long)r * zrs + u;
+            const f4 zi = ldf4(zr), zj = ldf4(zr + U), zf = ldf4(zr + 2 * U), zo = ldf4(zr + 3 * U);
+            f4 cn, hn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float c1 = cp.v[q] * d2p_sigmoid(zf.v[q] + FORGET_BIAS) +
+                                 d2p_sigmoid(zi.v[q]) * d2p_tanh(zj.v[q]);
+                cn.v[q] = c1;
+                hn.v[q] = d2p_tanh(c1) * d2p_sigmoid(zo.v[q]);
+            }
+            stf4(c_out + o, cn);
+            if (hs_out) stf4(hs_out + o, hn);
+            stf4(h_out + o, hn);
+        } else {
+            stf4(c_out + o, cp);
+            if (hs_out) stf4(hs_out + o, h_prev ? ldf4(h_prev + o) : zero4());
+            stf4(h_out + o, zero4());
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+lstm_gate_bwd_kernel(int M, int U, const float* __restrict__ z, long zrs,
+                     const float* __restrict__ c_prev, const float* __restrict__ c,
+                     const float* __restrict__ dh_in, const float* __restrict__ dh_out_grad,
+                     const int* __restrict__ lens, int t, float* __restrict__ dc,
+                     float* __restrict__ dz, long dzrs, float* __restrict__ dh_pass) {
+    const int U4 = U >> 2;
+    const long total = (long)M * U4;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int r = (int)(idx / U4);
+        const int u = (int)(idx - (long)r * U4) * 4;
+        const long o = (long)r * U + u;
+        const bool active = lens ? (t < lens[r]) : true;
+        float* dzr = dz + (long)r * dzrs + u;
+        if (active) {
+            const float* zr = z + (long)r * zrs + u;
+            const f4 zi = ldf4(zr), zj = ldf4(zr + U), zf = ldf4(zr + 2 * U), zo = ldf4(zr + 3 * U);
+            const f4 cp = c_prev ? ldf4(c_prev + o) : zero4();
+            const f4 cc = ldf4(c + o);
+            f4 dh = dh_in ? ldf4(dh_in + o) : zero4();
+            if (dh_out_grad) {
+                const f4 e = ldf4(dh_out_grad + o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dh.v[q] += e.v[q];
+            }
+            f4 dcv = ldf4(dc + o);
+            f4 gi, gj, gf, go, dcn;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float i = d2p_sigmoid(zi.v[q]);
+                const float j = d2p_tanh(zj.v[q]);
+                const float f = d2p_sigmoid(zf.v[q] + FORGET_BIAS);
+                const float og = d2p_sigmoid(zo.v[q]);
+                const float tc = d2p_tanh(cc.v[q]);
+                const float d_o = dh.v[q] * tc;
+                const float dct = dcv.v[q] + dh.v[q] * og * (1.f - tc * tc);
+                gi.v[q] = dct * j * i * (1.f - i);
+                gj.v[q] = dct * i * (1.f - j * j);
+                gf.v[q] = dct * cp.v[q] * f * (1.f - f);
+                go.v[q] = d_o * og * (1.f - og);
+                dcn.v[q] = dct * f;
+            }
+            stf4(dzr, gi);
+            stf4(dzr + U, gj);
+            stf4(dzr + 2 * U, gf);
+            stf4(dzr + 3 * U, go);
+            stf4(dc + o, dcn);
+            if (dh_pass) stf4(dh_pass + o, zero4());
+        } else {
+            const f4 zz = zero4();
+            stf4(dzr, zz);
+            stf4(dzr + U, zz);
+            stf4(dzr + 2 * U, zz);
+            stf4(dzr + 3 * U, zz);
+            if (dh_pass) stf4(dh_pass + o, dh_in ? ldf4(dh_in + o) : zero4());
+        }
+    }
+}
+
+static inline int gate_blocks(long total) {
+    long b = (total + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+static int gate_check(int M, int U, long zrs, const void* z) {
+    D2P_REQUIRE(M >= 0 && U > 0, D2P_EINVAL, "lstm gate: bad sizes M=%d U=%d", M, U);
+    D2P_REQUIRE(U % 4 == 0 && zrs % 4 == 0 && (((uintptr_t)z & 15) == 0), D2P_EALIGN,
+                "lstm gate: needs U %% 4 == 0, row stride %% 4 == 0 and 16-byte aligned z");
+    return D2P_OK;
+}
+
+extern "C" int d2p_lstm_gate_fwd(int M, int U, const float* z, long z_row_stride,
+                                 const float* c_prev, const float* h_prev, const int* lens, int t,
+                                 float* c_out, float* h_state_out, float* h_out,
+                                 d2p_stream_t stream) {
+    int rc = gate_check(M, U, z_row_stride, z);
+    if (rc) return rc;
+    if (M == 0) return D2P_OK;
+    D2P_REQUIRE(z && c_out && h_out, D2P_EINVAL, "lstm gate fwd: null pointer");
+    hipLaunchKernelGGL(lstm_gate_fwd_kernel, dim3(gate_blocks((long)M * U / 4)), dim3(256), 0,
+                       as_stream(stream), M, U, z, z_row_stride, c_prev, h_prev, lens, t, c_out,
+                       h_state_out, h_out);
+    D2P_LAUNCH_CHECK("lstm_gate_fwd");
+    return D2P_OK;
+}
+
+extern "C" int d2p_lstm_gate_bwd(int M, int U, const float* z, long z_row_stride,
+                                 const float* c_prev, const float* c, const float* dh_in,
+                                 const float* dh_out_grad, const int* lens, int t, float* dc,
+                                 float* dz, long dz_row_stride, float* dh_pass,
+                                 d2p_stream_t stream) {
+    int rc = gate_check(M, U, z_row_stride, z);
+    if (rc) return rc;
+    if (M == 0) return D2P_OK;
+    D2P_REQUIRE(z && c && dc && dz, D2P_EINVAL, "lstm gate bwd: null pointer");
+    D2P_REQUIRE(dz_row_stride % 4 == 0 && (((uintptr_t)dz & 15) == 0), D2P_EALIGN,
+                "lstm gate bwd: dz must be 16-byte aligned with row stride %% 4 == 0");
+    hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(gate_blocks((long)M * U / 4)), dim3(256), 0,
+                       as_stream(stream), M, U, z, z_row_stride, c_prev, c, dh_in, dh_out_grad, lens,
+                       t, dc, dz, dz_row_stride, dh_pass);
+    D2P_LAUNCH_CHECK("lstm_gate_bwd");
+    return D2P_OK;
+}
+
+// ---- sequence drivers ------------------------------------------------------------------
+
+extern "C" size_t d2p_lstm_ws_bytes(int M, int U) {
+    if (M <= 0 || U <= 0) return 0;
+    return (size_t)3 * M * U * sizeof(float);
+}
+
+static int copy_or_zero(float* dst, const float* src, size_t n, hipStream_t st) {
+    if (!dst) return D2P_OK;
+    if (src) {
+        if (src != dst) D2P_HIP(hipMemcpyAsync(dst, src, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+    } else {
+        D2P_HIP(hipMemsetAsync(dst, 0, n * sizeof(float), st));
+    }
+    return D2P_OK;
+}
+
+extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_stride,
+                                long z_t_stride, const float* Wh, const float* h0, const float* c0,
+                                const int* lens, float* hout, float* cs, float* h_final,
+                                float* c_final, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    D2P_REQUIRE(M >= 0 && U > 0 && n_steps >= 0, D2P_EINVAL, "lstm seq fwd: bad sizes");
+    hipStream_t st = as_stream(stream);
+    const size_t MU = (size_t)M * U;
+    if (M == 0) return D2P_OK;
+    D2P_REQUIRE(n_steps == 0 || (z && Wh && hout && cs), D2P_EINVAL, "lstm seq fwd: null pointer");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_lstm_ws_bytes(M, U), D2P_EWS,
+                "lstm seq fwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
+    float* hs[2] = {(float*)ws, (float*)ws + MU};
+    const float* h_prev = h0;
+    const float* c_prev = c0;
+    for (int t = 0; t < n_steps; ++t) {
+        float* zt = z + (long)t * z_t_stride;
+        if (h_prev) {
+            int rc = d2p_gemm_f32_nn(M, 4 * U, U, h_prev, U, Wh, 4L * U, zt, z_row_stride, nullptr,
+                                     0, /*accumulate=*/1, nullptr, 0, stream);
+            if (rc) return rc;
+        }
+        float* hs_out = lens ? hs[t & 1] : nullptr;
+        int rc = d2p_lstm_gate_fwd(M, U, zt, z_row_stride, c_prev, h_prev, lens, t, cs + t * MU,
+                                   hs_out, hout + t * MU, stream);
+        if (rc) return rc;
+        h_prev = lens ? hs_out : hout + t * MU;
+        c_prev = cs + t * MU;
+    }
+    int rc = copy_or_zero(h_final, h_prev, MU, st);
+    if (rc) return rc;
+    return copy_or_zero(c_final, c_prev, MU, st);
+}
+
+extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long z_row_stride,
+                                long z_t_stride, const float* Wh, const float* c0, const int* lens,
+                                const float* cs, const float* dhout, const float* dh_final,
+                                const float* dc_final, float* dz, float* dh0, float* dc0, void* ws,
+                                size_t ws_bytes, d2p_stream_t stream) {
+    D2P_REQUIRE(M >= 0 && U > 0 && n_steps >= 0, D2P_EINVAL, "lstm seq bwd: bad sizes");
+    hipStream_t st = as_stream(stream);
+    const size_t MU = (size_t)M * U;
+    if (M == 0) return D2P_OK;
+    D2P_REQUIRE(n_steps == 0 || (z && Wh && cs && dz), D2P_EINVAL, "lstm seq bwd: null pointer");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_lstm_ws_bytes(M, U), D2P_EWS,
+                "lstm seq bwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
+    float* dHbuf[2] = {(float*)ws, (float*)ws + MU};
+    float* dC = (float*)ws + 2 * MU;
+    int rc = copy_or_zero(dC, dc_final, MU, st);
+    if (rc) return rc;
+    const float* dh_in = dh_final;   // may be null (= 0)
+    for (int t = n_steps - 1; t >= 0; --t) {
+        const float* c_prev = t ? cs + (size_t)(t - 1) * MU : c0;
+        const bool last = (t == 0);
+        if (last && !dh0) {
+            // caller does not need dh0: still need dz[0] and dc0
+            rc = d2p_lstm_gate_bwd(M, U, z + (long)t * z_t_stride, z_row_stride, c_prev, cs + t * MU,
+                                   dh_in, dhout ? dhout + t * MU : nullptr, lens, t, dC,
+                                   dz + (long)t * z_t_stride, z_row_stride, nullptr, stream);
+            if (rc) return rc;
+            dh_in = nullptr;
+            break;
+        }
+        float* target = last ? dh0 : dHbuf[t & 1];
+        rc = d2p_lstm_gate_bwd(M, U, z + (long)t * z_t_stride, z_row_stride, c_prev, cs + t * MU,
+                               dh_in, dhout ? dhout + t * MU : nullptr, lens, t, dC,
+                               dz + (long)t * z_t_stride, z_row_stride, lens ? target : nullptr,
+                               stream);
+        if (rc) return rc;
+        // dh_prev = dz[t] · Wh^T (+ pass-through of masked rows)
+        rc = d2p_gemm_f32_nt(M, U, 4 * U, dz + (long)t * z_t_stride, z_row_stride, Wh, 4L * U, target,
+                             U, nullptr, 0, /*accumulate=*/lens ? 1 : 0, nullptr, 0, stream);
+        if (rc) return rc;
+        dh_in = target;
+    }
+    if (n_steps == 0) {
+        rc = copy_or_zero(dh0, dh_final, MU, st);
+        if (rc) return rc;
+    }
+    return copy_or_zero(dc0, dC, MU, st);
+}

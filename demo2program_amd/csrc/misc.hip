@@ -1,0 +1,298 @@
+// K6 (embedding), summarizer glue and small layout helpers (include/d2p.h).
+// All HBM-bound elementwise / small-reduction kernels: 16-byte accesses along the feature
+// axis, grid-stride loops capped at 2048 workgroups (256 CUs x 8).
+#include "common.h"
+
+static inline int ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ---- decoder input ids: <s> then the ground truth shifted right, time-major --------------
+// models/model_full.py:447-450
+__global__ void shift_tokens_tm_kernel(int R, int T, const int* tokens, int start_id, int* ids) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= R * T) return;
+    const int t = idx / R, r = idx - t * R;
+    ids[idx] = (t == 0) ? start_id : tokens[(long)r * T + t - 1];
+}
+
+extern "C" int d2p_shift_tokens_tm(int R, int T, const int* tokens, int start_id, int* ids,
+                                   d2p_stream_t stream) {
+    D2P_REQUIRE(R >= 0 && T >= 0, D2P_EINVAL, "shift_tokens: negative size");
+    if (R == 0 || T == 0) return D2P_OK;
+    D2P_REQUIRE(tokens && ids, D2P_EINVAL, "shift_tokens: null pointer");
+    hipLaunchKernelGGL(shift_tokens_tm_kernel, dim3(ceil_div(R * T, 256)), dim3(256), 0,
+                       as_stream(stream), R, T, tokens, start_id, ids);
+    D2P_LAUNCH_CHECK("shift_tokens_tm");
+    return D2P_OK;
+}
+
+// ---- embedding gather, out-of-range id -> zero row (TF-GPU gather semantics) -------------
+// models/model_full.py:294 with the <s> id of :448-450
+__global__ void __launch_bounds__(256)
+embedding_gather_kernel(long n, int rows, int E4, const int* ids, const float4* table, float4* out) {
+    const long total = n * E4;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const long i = idx / E4;
+        const int e = (int)(idx - i * E4);
+        const int id = ids[i];
+        out[idx] = (id >= 0 && id < rows) ? table[(long)id * E4 + e] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+extern "C" int d2p_embedding_gather_oob0(int n, int rows, int E, const int* ids, const float* table,
+                                         float* out, d2p_stream_t stream) {
+    D2P_REQUIRE(n >= 0 && rows > 0 && E > 0, D2P_EINVAL, "embedding gather: bad sizes");
+    if (n == 0) return D2P_OK;
+    D2P_REQUIRE(ids && table && out, D2P_EINVAL, "embedding gather: null pointer");
+    D2P_REQUIRE(E % 4 == 0 && ((((uintptr_t)table | (uintptr_t)out) & 15) == 0), D2P_EALIGN,
+                "embedding gather: needs E %% 4 == 0 and 16-byte aligned buffers");
+    hipLaunchKernelGGL(embedding_gather_kernel, dim3(ew_blocks((long)n * E / 4)), dim3(256), 0,
+                       as_stream(stream), (long)n, rows, E / 4, ids, (const float4*)table, (float4*)out);
+    D2P_LAUNCH_CHECK("embedding_gather");
+    return D2P_OK;
+}
+
+// Scatter-add gradient, deterministic: one workgroup per (table row, 256-column slab) walks
+// the id list in order and sums the matching dout rows (table has <= 51 rows, n <= 6400).
+__global__ void __launch_bounds__(256)
+embedding_scatter_kernel(int n, int E, const int* ids, const float* dout, float* dtable) {
+    const int row = blockIdx.x;
+    const int e = blockIdx.y * 256 + threadIdx.x;
+    __shared__ int sid[256];
+    float acc = 0.f;
+    for (int base = 0; base < n; base += 256) {
+        const int i = base + threadIdx.x;
+        sid[threadIdx.x] = (i < n) ? ids[i] : -1;
+        __syncthreads();
+        const int lim = min(256, n - base);
+        if (e < E)
+            for (int q = 0; q < lim; ++q)
+                if (sid[q] == row) acc += dout[(long)(base + q) * E + e];
+        __syncthreads();
+    }
+    if (e < E) dtable[(long)row * E + e] = acc;
+}
+
+extern "C" int d2p_embedding_scatter_add_oob0(int n, int rows, int E, const int* ids,
+                                              const float* dout, float* dtable,
+                                              d2p_stream_t stream) {
+    D2P_REQUIRE(n >= 0 && rows > 0 && E > 0, D2P_EINVAL, "embedding scatter: bad sizes");
+    D2P_REQUIRE(dtable && (n == 0 || (ids && dout)), D2P_EINVAL, "embedding scatter: null pointer");
+    hipLaunchKernelGGL(embedding_scatter_kernel, dim3(rows, ceil_div(E, 256)), dim3(256), 0,
+                       as_stream(stream), n, E, ids, dout, dtable);
+    D2P_LAUNCH_CHECK("embedding_scatter");
+    return D2P_OK;
+}
+
+// ---- SummarizeFeature('avgpool'): mean over the k demonstrations -------------------------
+// models/model_full.py:351-356,380-385
+__global__ void __launch_bounds__(256)
+group_mean_kernel(int B, int k, int U, const float* x, float* out, float* bcast) {
+    const long total = (long)B * U;
+    const float inv = 1.f / (float)k;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int b = (int)(idx / U), u = (int)(idx - (long)b * U);
+        float s = 0.f;
+        for (int i = 0; i < k; ++i) s += x[((long)b * k + i) * U + u];
+        s *= inv;
+        out[idx] = s;
+        if (bcast)
+            for (int i = 0; i < k; ++i) bcast[((long)b * k + i) * U + u] = s;
+    }
+}
+
+extern "C" int d2p_group_mean(int B, int k, int U, const float* x, float* out, float* bcast,
+                              d2p_stream_t stream) {
+    D2P_REQUIRE(B >= 0 && k > 0 && U > 0, D2P_EINVAL, "group_mean: bad sizes");
+    if (B == 0) return D2P_OK;
+    D2P_REQUIRE(x && out, D2P_EINVAL, "group_mean: null pointer");
+    hipLaunchKernelGGL(group_mean_kernel, dim3(ew_blocks((long)B * U)), dim3(256), 0,
+                       as_stream(stream), B, k, U, x, out, bcast);
+    D2P_LAUNCH_CHECK("group_mean");
+    return D2P_OK;
+}
+
+__global__ void __launch_bounds__(256)
+group_mean_bwd_kernel(int B, int k, int U, const float* dout, const float* dbcast, float* dx,
+                      int accumulate) {
+    const long total = (long)B * U;
+    const float inv = 1.f / (float)k;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int b = (int)(idx / U), u = (int)(idx - (long)b * U);
+        float s = dout ? dout[idx] : 0.f;
+        if (dbcast)
+            for (int i = 0; i < k; ++i) s += dbcast[((long)b * k + i) * U + u];
+        s *= inv;
+        for (int i = 0; i < k; ++i) {
+            float* p = dx + ((long)b * k + i) * U + u;
+            *p = accumulate ? (*p + s) : s;
+        }
+    }
+}
+
+extern "C" int d2p_group_mean_bwd(int B, int k, int U, const float* dout, const float* dbcast,
+                                  float* dx, int accumulate, d2p_stream_t stream) {
+    D2P_REQUIRE(B >= 0 && k > 0 && U > 0, D2P_EINVAL, "group_mean_bwd: bad sizes");
+    if (B == 0) return D2P_OK;
+    D2P_REQUIRE(dx, D2P_EINVAL, "group_mean_bwd: null pointer");
+    hipLaunchKernelGGL(group_mean_bwd_kernel, dim3(ew_blocks((long)B * U)), dim3(256), 0,
+                       as_stream(stream), B, k, U, dout, dbcast, dx, accumulate);
+    D2P_LAUNCH_CHECK("group_mean_bwd");
+    return D2P_OK;
+}
+
+// ---- rn_pool first layer, pairs never materialised ---------------------------------------
+// models/model_full.py:333-343: row (b, a, c) of the pair matrix is [feat[b,c] || feat[b,a]],
+// so fc1(row) = feat[b,c]·W1[:U] + feat[b,a]·W1[U:] + bias = P[b,c] + Q[b,a] + bias.
+__global__ void __launch_bounds__(256)
+rn_pair_fwd_kernel(int B, int k, int U4, const float4* P, const float4* Q, const float4* bias,
+                   float4* y) {
+    const long total = (long)B * k * k * U4;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int u = (int)(idx % U4);
+        long row = idx / U4;
+        const int c = (int)(row % k); row /= k;
+        const int a = (int)(row % k);
+        const int b = (int)(row / k);
+        const float4 p = P[((long)b * k + c) * U4 + u], q = Q[((long)b * k + a) * U4 + u], bb = bias[u];
+        float4 o;
+        o.x = d2p_lrelu(p.x + q.x + bb.x);
+        o.y = d2p_lrelu(p.y + q.y + bb.y);
+        o.z = d2p_lrelu(p.z + q.z + bb.z);
+        o.w = d2p_lrelu(p.w + q.w + bb.w);
+        y[idx] = o;
+    }
+}
+
+extern "C" int d2p_rn_pair_fwd(int B, int k, int U, const float* P, const float* Q,
+                               const float* bias, float* y, d2p_stream_t stream) {
+    D2P_REQUIRE(B >= 0 && k > 0 && U > 0 && U % 4 == 0, D2P_EINVAL, "rn_pair_fwd: bad sizes");
+    if (B == 0) return D2P_OK;
+    D2P_REQUIRE(P && Q && bias && y, D2P_EINVAL, "rn_pair_fwd: null pointer");
+    hipLaunchKernelGGL(rn_pair_fwd_kernel, dim3(ew_blocks((long)B * k * k * U / 4)), dim3(256), 0,
+                       as_stream(stream), B, k, U / 4, (const float4*)P, (const float4*)Q,
+                       (const float4*)bias, (float4*)y);
+    D2P_LAUNCH_CHECK("rn_pair_fwd");
+    return D2P_OK;
+}
+
+// dP[b,c] = sum_a dy[b,a,c], dQ[b,a] = sum_c dy[b,a,c]
+__global__ void __launch_bounds__(256)
+rn_pair_bwd_kernel(int B, int k, int U, const float* dy, float* dP, float* dQ) {
+    const long total = (long)B * k * U;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int u = (int)(idx % U);
+        const long bi = idx / U;
+        const int i = (int)(bi % k);
+        const int b = (int)(bi / k);
+        float sp = 0.f, sq = 0.f;
+        for (int o = 0; o < k; ++o) {
+            sp += dy[(((long)b * k + o) * k + i) * U + u];   // a = o, c = i
+            sq += dy[(((long)b * k + i) * k + o) * U + u];   // a = i, c = o
+        }
+        dP[idx] = sp;
+        dQ[idx] = sq;
+    }
+}
+
+extern "C" int d2p_rn_pair_bwd(int B, int k, int U, const float* dy, float* dP, float* dQ,
+                               d2p_stream_t stream) {
+    D2P_REQUIRE(B >= 0 && k > 0 && U > 0, D2P_EINVAL, "rn_pair_bwd: bad sizes");
+    if (B == 0) return D2P_OK;
+    D2P_REQUIRE(dy && dP && dQ, D2P_EINVAL, "rn_pair_bwd: null pointer");
+    hipLaunchKernelGGL(rn_pair_bwd_kernel, dim3(ew_blocks((long)B * k * U)), dim3(256), 0,
+                       as_stream(stream), B, k, U, dy, dP, dQ);
+    D2P_LAUNCH_CHECK("rn_pair_bwd");
+    return D2P_OK;
+}
+
+// out[b] = mean over the kk pair rows + base[b]   (models/model_full.py:346-348,358-359)
+__global__ void __launch_bounds__(256)
+pair_mean_fwd_kernel(int B, int kk, int U, const float* y, const float* base, float* out) {
+    const long total = (long)B * U;
+    const float inv = 1.f / (float)kk;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int b = (int)(idx / U), u = (int)(idx - (long)b * U);
+        float s = 0.f;
+        for (int j = 0; j < kk; ++j) s += y[((long)b * kk + j) * U + u];
+        out[idx] = s * inv + (base ? base[idx] : 0.f);
+    }
+}
+
+extern "C" int d2p_pair_mean_fwd(int B, int kk, int U, const float* y, const float* base, float* out,
+                                 d2p_stream_t stream) {
+    D2P_REQUIRE(B >= 0 && kk > 0 && U > 0, D2P_EINVAL, "pair_mean_fwd: bad sizes");
+    if (B == 0) return D2P_OK;
+    D2P_REQUIRE(y && out, D2P_EINVAL, "pair_mean_fwd: null pointer");
+    hipLaunchKernelGGL(pair_mean_fwd_kernel, dim3(ew_blocks((long)B * U)), dim3(256), 0,
+                       as_stream(stream), B, kk, U, y, base, out);
+    D2P_LAUNCH_CHECK("pair_mean_fwd");
+    return D2P_OK;
+}
+
+__global__ void __launch_bounds__(256)
+pair_mean_bwd_kernel(int B, int kk, int U, const float* dout, float* dy) {
+    const long total = (long)B * kk * U;
+    const float inv = 1.f / (float)kk;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int u = (int)(idx % U);
+        const int b = (int)(idx / ((long)kk * U));
+        dy[idx] = dout[(long)b * U + u] * inv;
+    }
+}
+
+extern "C" int d2p_pair_mean_bwd(int B, int kk, int U, const float* dout, float* dy,
+                                 d2p_stream_t stream) {
+    D2P_REQUIRE(B >= 0 && kk > 0 && U > 0, D2P_EINVAL, "pair_mean_bwd: bad sizes");
+    if (B == 0) return D2P_OK;
+    D2P_REQUIRE(dout && dy, D2P_EINVAL, "pair_mean_bwd: null pointer");
+    hipLaunchKernelGGL(pair_mean_bwd_kernel, dim3(ew_blocks((long)B * kk * U)), dim3(256), 0,
+                       as_stream(stream), B, kk, U, dout, dy);
+    D2P_LAUNCH_CHECK("pair_mean_bwd");
+    return D2P_OK;
+}
+
+// ---- y (=|+=) a*x --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+axpy_kernel(size_t n, float a, const float* x, float* y, int accumulate) {
+    for (size_t idx = blockIdx.x * 256UL + threadIdx.x; idx < n; idx += (size_t)gridDim.x * 256UL)
+        y[idx] = accumulate ? (y[idx] + a * x[idx]) : a * x[idx];
+}
+
+extern "C" int d2p_axpy(size_t n, float a, const float* x, float* y, int accumulate,
+                        d2p_stream_t stream) {
+    if (n == 0) return D2P_OK;
+    D2P_REQUIRE(x && y, D2P_EINVAL, "axpy: null pointer");
+    hipLaunchKernelGGL(axpy_kernel, dim3(ew_blocks((long)n)), dim3(256), 0, as_stream(stream), n, a,
+                       x, y, accumulate);
+    D2P_LAUNCH_CHECK("axpy");
+    return D2P_OK;
+}
+
+// ---- out[t, r, :] = in[r, t, :] -------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+transpose_rt_kernel(int R, int T, int C, const float* in, float* out) {
+    const long total = (long)R * T * C;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int c = (int)(idx % C);
+        const long tr = idx / C;
+        const int r = (int)(tr % R);
+        const int t = (int)(tr / R);
+        out[idx] = in[((long)r * T + t) * C + c];
+    }
+}
+
+extern "C" int d2p_transpose_rt(int R, int T, int C, const float* in, float* out,
+                                d2p_stream_t stream) {
+    D2P_REQUIRE(R >= 0 && T >= 0 && C > 0, D2P_EINVAL, "transpose_rt: bad sizes");
+    if (R == 0 || T == 0) return D2P_OK;
+    D2P_REQUIRE(in && out, D2P_EINVAL, "transpose_rt: null pointer");
+    hipLaunchKernelGGL(transpose_rt_kernel, dim3(ew_blocks((long)R * T * C)), dim3(256), 0,
+                       as_stream(stream), R, T, C, in, out);
+    D2P_LAUNCH_CHECK("transpose_rt");
+    return D2P_OK;
+}

@@ -1,0 +1,269 @@
+// K7: masked, mask-count-normalised sequence cross-entropies (include/d2p.h).
+// Replaces Sequence_Loss at models/model_full.py:620-657 and the loss sum at :918-932,
+// :1014-1038, :1061-1079.
+//
+// One wavefront per (t, r) logits row: V (50 / 42 program tokens, 6 / 12 actions, 5 / 6
+// perception bits) fits the 64 lanes, so max / sum-exp / dot products are pure cross-lane
+// reductions with no LDS.  Per-group numerators / denominators are reduced in two
+// deterministic stages (fixed partial order), never with float atomics.
+#include "common.h"
+
+#define XENT_S 64   // row splits per group in the forward reduction
+
+extern "C" size_t d2p_xent_ws_bytes(int G) {
+    return G > 0 ? (size_t)G * XENT_S * 2 * sizeof(float) : 0;
+}
+
+struct LabelView {
+    const float* p;
+    long rs, ts, vs;
+    __device__ __forceinline__ float at(int r, int t, int v) const {
+        return p[(long)r * rs + (long)t * ts + (long)v * vs];
+    }
+};
+
+// MODE 0: softmax CE = lse*sum(lab) - sum(lab*x);  MODE 1: mean_v sigmoid CE.
+template <int MODE>
+__device__ __forceinline__ float row_loss(const float* x, bool have_logits, const LabelView& lab,
+                                          int r, int t, int V, int lane) {
+    if (MODE == 0) {
+        float mx = -INFINITY;
+        for (int v = lane; v < V; v += 64) mx = fmaxf(mx, have_logits ? x[v] : 0.f);
+        mx = wave_reduce_max(mx);
+        float se = 0.f, sl = 0.f, slx = 0.f;
+        for (int v = lane; v < V; v += 64) {
+            const float xv = have_logits ? x[v] : 0.f;
+            const float lv = lab.at(r, t, v);
+            se += expf(xv - mx);
+            sl += lv;
+            slx += lv * xv;
+        }
+        se = wave_reduce_sum(se);
+        sl = wave_reduce_sum(sl);
+        slx = wave_reduce_sum(slx);
+        return (mx + logf(se)) * sl - slx;
+    } else {
+        float s = 0.f;
+        for (int v = lane; v < V; v += 64) {
+            const float xv = have_logits ? x[v] : 0.f;
+            const float lv = lab.at(r, t, v);
+            // [TF-1.3] max(x,0) - x*z + log(1 + exp(-|x|))
+            s += fmaxf(xv, 0.f) - xv * lv + log1pf(expf(-fabsf(xv)));
+        }
+        return wave_reduce_sum(s) / (float)V;
+    }
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+xent_fwd_partial_kernel(int T, int R, int V, int G, int n_steps, const float* logits,
+                        LabelView lab, const int* lens, float* partial) {
+    __shared__ float red[2][4];
+    const int g = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rg = R / G;               // rows per group per time step
+    const int n = T * rg;
+    float num = 0.f, den = 0.f;
+    for (int j = s * 4 + wave; j < n; j += S * 4) {
+        const int t = j / rg, r = (j - t * rg) * G + g;
+        if (t < lens[r]) {              // tf.sequence_mask(len, maxlen=T)
+            num += row_loss<MODE>(logits + ((long)t * R + r) * V, t < n_steps, lab, r, t, V, lane);
+            den += 1.f;
+        }
+    }
+    if (lane == 0) { red[0][wave] = num; red[1][wave] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partial[((long)g * S + s) * 2 + 0] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        partial[((long)g * S + s) * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+__global__ void xent_fwd_final_kernel(int G, int S, const float* partial, float* num, float* den) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    float a = 0.f, b = 0.f;
+    for (int s = 0; s < S; ++s) {
+        a += partial[((long)g * S + s) * 2 + 0];
+        b += partial[((long)g * S + s) * 2 + 1];
+    }
+    num[g] = a;
+    den[g] = b;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+xent_bwd_kernel(int R, int V, int G, int n_steps, const float* logits, LabelView lab,
+                const int* lens, const float* den, float scale, float* dlogits) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nrows = (long)n_steps * R;
+    for (long row = blockIdx.x * 4L + wave; row < nrows; row += (long)gridDim.x * 4L) {
+        const int t = (int)(row / R), r = (int)(row - (long)t * R);
+        const float* x = logits + row * V;
+        float* dx = dlogits + row * V;
+        if (t >= lens[r]) {
+            for (int v = lane; v < V; v += 64) dx[v] = 0.f;
+            continue;
+        }
+        const float w = scale / ((float)G * den[r % G]);
+        if (MODE == 0) {
+            float mx = -INFINITY;
+            for (int v = lane; v < V; v += 64) mx = fmaxf(mx, x[v]);
+            mx = wave_reduce_max(mx);
+            float se = 0.f;
+            for (int v = lane; v < V; v += 64) se += expf(x[v] - mx);
+            se = wave_reduce_sum(se);
+            const float inv = 1.f / se;
+            // [TF-1.3] SoftmaxCrossEntropyWithLogits backprop = softmax - labels
+            for (int v = lane; v < V; v += 64) dx[v] = w * (expf(x[v] - mx) * inv - lab.at(r, t, v));
+        } else {
+            const float wv = w / (float)V;
+            for (int v = lane; v < V; v += 64) dx[v] = wv * (d2p_sigmoid(x[v]) - lab.at(r, t, v));
+        }
+    }
+}
+
+static int xent_check(int T, int R, int V, int G, int n_steps) {
+    D2P_REQUIRE(T >= 0 && R >= 0 && V > 0 && G > 0 && n_steps >= 0 && n_steps <= T, D2P_EINVAL,
+                "xent: bad sizes T=%d R=%d V=%d G=%d n_steps=%d", T, R, V, G, n_steps);
+    D2P_REQUIRE(R % G == 0, D2P_EINVAL, "xent: R=%d not a multiple of G=%d", R, G);
+    return D2P_OK;
+}
+
+template <int MODE>
+static int xent_fwd(int T, int R, int V, int G, int n_steps, const float* logits,
+                    const float* labels, long lrs, long lts, long lvs, const int* lens,
+                    float* num, float* den, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    int rc = xent_check(T, R, V, G, n_steps);
+    if (rc) return rc;
+    D2P_REQUIRE(num && den && lens && labels && (n_steps == 0 || logits), D2P_EINVAL,
+                "xent fwd: null pointer");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_xent_ws_bytes(G), D2P_EWS, "xent fwd: workspace too small");
+    hipStream_t st = as_stream(stream);
+    LabelView lab{labels, lrs, lts, lvs};
+    float* partial = (float*)ws;
+    hipLaunchKernelGGL((xent_fwd_partial_kernel<MODE>), dim3(G, XENT_S), dim3(256), 0, st, T, R, V, G,
+                       n_steps, logits, lab, lens, partial);
+    D2P_LAUNCH_CHECK("xent_fwd_partial");
+    hipLaunchKernelGGL(xent_fwd_final_kernel, dim3(ceil_div(G, 64)), dim3(64), 0, st, G, XENT_S,
+                       partial, num, den);
+    D2P_LAUNCH_CHECK("xent_fwd_final");
+    return D2P_OK;
+}
+
+template <int MODE>
+static int xent_bwd(int T, int R, int V, int G, int n_steps, const float* logits,
+                    const float* labels, long lrs, long lts, long lvs, const int* lens,
+                    const float* den, float scale, float* dlogits, d2p_stream_t stream) {
+    int rc = xent_check(T, R, V, G, n_steps);
+    if (rc) return rc;
+    if (n_steps == 0 || R == 0) return D2P_OK;
+    D2P_REQUIRE(logits && labels && lens && den && dlogits, D2P_EINVAL, "xent bwd: null pointer");
+    LabelView lab{labels, lrs, lts, lvs};
+    long blocks = ((long)n_steps * R + 3) / 4;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL((xent_bwd_kernel<MODE>), dim3((int)blocks), dim3(256), 0, as_stream(stream), R,
+                       V, G, n_steps, logits, lab, lens, den, scale, dlogits);
+    D2P_LAUNCH_CHECK("xent_bwd");
+    return D2P_OK;
+}
+
+extern "C" int d2p_softmax_xent_masked_fwd(int T, int R, int V, int G, int n_steps,
+                                           const float* logits, const float* labels, long lrs,
+                                           long lts, long lvs, const int* lens, float* loss_num,
+                                           float* loss_den, void* ws, size_t ws_bytes,
+                                           d2p_stream_t stream) {
+    return xent_fwd<0>(T, R, V, G, n_steps, logits, labels, lrs, lts, lvs, lens, loss_num, loss_den,
+                       ws, ws_bytes, stream);
+}
+extern "C" int d2p_sigmoid_xent_masked_fwd(int T, int R, int V, int G, int n_steps,
+                                           const float* logits, const float* labels, long lrs,
+                                           long lts, long lvs, const int* lens, float* loss_num,
+                                           float* loss_den, void* ws, size_t ws_bytes,
+                                           d2p_stream_t stream) {
+    return xent_fwd<1>(T, R, V, G, n_steps, logits, labels, lrs, lts, lvs, lens, loss_num, loss_den,
+                       ws, ws_bytes, stream);
+}
+extern "C" int d2p_softmax_xent_masked_bwd(int T, int R, int V, int G, int n_steps,
+                                           const float* logits, const float* labels, long lrs,
+                                           long lts, long lvs, const int* lens,
+                                           const float* loss_den, float scale, float* dlogits,
+                                           d2p_stream_t stream) {
+    return xent_bwd<0>(T, R, V, G, n_steps, logits, labels, lrs, lts, lvs, lens, loss_den, scale,
+                       dlogits, stream);
+}
+extern "C" int d2p_sigmoid_xent_masked_bwd(int T, int R, int V, int G, int n_steps,
+                                           const float* logits, const float* labels, long lrs,
+                                           long lts, long lvs, const int* lens,
+                                           const float* loss_den, float scale, float* dlogits,
+                                           d2p_stream_t stream) {
+    return xent_bwd<1>(T, R, V, G, n_steps, logits, labels, lrs, lts, lvs, lens, loss_den, scale,
+                       dlogits, stream);
+}
+
+// loss = sum_terms (1/G_j) sum_g num/den   (models/model_full.py:932,1035-1038,1078-1079)
+struct TermGroups { int n; int g[8]; };
+
+__global__ void loss_assemble_kernel(TermGroups tg, const float* nums, const float* dens,
+                                     float* loss, float* term_losses) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float total = 0.f;
+    int off = 0;
+    for (int j = 0; j < tg.n; ++j) {
+        float s = 0.f;
+        for (int g = 0; g < tg.g[j]; ++g) s += nums[off + g] / dens[off + g];
+        s /= (float)tg.g[j];
+        if (term_losses) term_losses[j] = s;
+        total += s;
+        off += tg.g[j];
+    }
+    loss[0] = total;
+}
+
+extern "C" int d2p_loss_assemble(int n_terms, const int* groups, const float* nums,
+                                 const float* dens, float* loss, float* term_losses,
+                                 d2p_stream_t stream) {
+    D2P_REQUIRE(n_terms > 0 && n_terms <= 8 && groups && nums && dens && loss, D2P_EINVAL,
+                "loss_assemble: bad arguments (n_terms=%d)", n_terms);
+    TermGroups tg;
+    tg.n = n_terms;
+    for (int i = 0; i < 8; ++i) tg.g[i] = i < n_terms ? groups[i] : 0;
+    for (int i = 0; i < n_terms; ++i)
+        D2P_REQUIRE(groups[i] > 0, D2P_EINVAL, "loss_assemble: groups[%d]=%d", i, groups[i]);
+    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(64), 0, as_stream(stream), tg, nums, dens,
+                       loss, term_losses);
+    D2P_LAUNCH_CHECK("loss_assemble");
+    return D2P_OK;
+}
+
+// zero logits rows (t, r) with t >= min(T, max_{r' % G == r % G} lens[r'])
+// (dynamic_decode stops at the longest sequence of that call; models/model_full.py:476-484)
+__global__ void __launch_bounds__(256)
+zero_past_group_steps_kernel(int T, int R, int V, int G, const int* lens, float* logits) {
+    extern __shared__ int gmax[];
+    for (int g = threadIdx.x; g < G; g += 256) {
+        int m = 0;
+        for (int r = g; r < R; r += G) m = max(m, lens[r]);
+        gmax[g] = min(m, T);
+    }
+    __syncthreads();
+    const long total = (long)T * R * V;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const long row = idx / V;
+        const int t = (int)(row / R), r = (int)(row - (long)t * R);
+        if (t >= gmax[r % G]) logits[idx] = 0.f;
+    }
+}
+
+extern "C" int d2p_zero_past_group_steps(int T, int R, int V, int G, const int* lens, float* logits,
+                                         d2p_stream_t stream) {
+    D2P_REQUIRE(T >= 0 && R >= 0 && V > 0 && G > 0 && G <= 4096, D2P_EINVAL, "zero_past: bad sizes");
+    if (T == 0 || R == 0) return D2P_OK;
+    D2P_REQUIRE(lens && logits, D2P_EINVAL, "zero_past: null pointer");
+    long blocks = ((long)T * R * V + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(zero_past_group_steps_kernel, dim3((int)blocks), dim3(256), G * sizeof(int),
+                       as_stream(stream), T, R, V, G, lens, logits);
+    D2P_LAUNCH_CHECK("zero_past_group_steps");
+    return D2P_OK;
+}

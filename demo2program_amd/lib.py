@@ -1,0 +1,125 @@
+"""ctypes binding of libd2p_hip.so (C ABI: include/d2p.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``demo2program_amd.build.build_library()`` with
+``hipcc --offload-arch=gfx950``.  There is NO fallback: if the library is missing
+or a call fails, a RuntimeError is raised -- the product path never routes through
+a CPU implementation.
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_float, c_int, c_long, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libd2p_hip.so')
+
+P = c_void_p      # device (or host, where noted in d2p.h) pointer
+S = c_void_p      # hipStream_t
+
+# name -> (restype, argtypes).  Mirrors include/d2p.h one to one; tests/test_abi.py checks
+# that every prototype in the header is listed here and exported by the .so.
+SIGNATURES = {
+    'd2p_version': (c_int, []),
+    'd2p_last_error': (c_char_p, []),
+    'd2p_device_info': (c_int, [c_int, P, c_int, P, P, P]),
+    'd2p_gemm_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'd2p_gemm_f32_nn': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
+    'd2p_gemm_f32_nt': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
+    'd2p_gemm_f32_tn': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
+    'd2p_colsum_ws_bytes': (c_size_t, [c_int, c_int]),
+    'd2p_colsum_f32': (c_int, [c_int, c_int, P, c_long, P, P, c_size_t, S]),
+    'd2p_conv_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    'd2p_conv2d_nhwc_s2_same_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, P, S]),
+    'd2p_conv2d_nhwc_s2_same_dgrad': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, S]),
+    'd2p_conv2d_nhwc_s2_same_wgrad': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_size_t, S]),
+    'd2p_bn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'd2p_bn_group_fwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, c_size_t, S]),
+    'd2p_bn_group_bwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, c_size_t, S]),
+    'd2p_bn_update_moving': (c_int, [c_int, c_int, c_float, P, P, P, P, S]),
+    'd2p_lstm_gate_fwd': (c_int, [c_int, c_int, P, c_long, P, P, P, c_int, P, P, P, S]),
+    'd2p_lstm_gate_bwd': (c_int, [c_int, c_int, P, c_long, P, P, P, P, P, c_int, P, P, c_long, P, S]),
+    'd2p_lstm_ws_bytes': (c_size_t, [c_int, c_int]),
+    'd2p_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, c_long, c_long, P, P, P, P, P, P, P, P, P, c_size_t, S]),
+    'd2p_lstm_seq_bwd': (c_int, [c_int, c_int, c_int, P, c_long, c_long, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
+    'd2p_shift_tokens_tm': (c_int, [c_int, c_int, P, c_int, P, S]),
+    'd2p_embedding_gather_oob0': (c_int, [c_int, c_int, c_int, P, P, P, S]),
+    'd2p_embedding_scatter_add_oob0': (c_int, [c_int, c_int, c_int, P, P, P, S]),
+    'd2p_xent_ws_bytes': (c_size_t, [c_int]),
+    'd2p_softmax_xent_masked_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, P, P, c_size_t, S]),
+    'd2p_softmax_xent_masked_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, c_float, P, S]),
+    'd2p_sigmoid_xent_masked_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, P, P, c_size_t, S]),
+    'd2p_sigmoid_xent_masked_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, c_float, P, S]),
+    'd2p_loss_assemble': (c_int, [c_int, P, P, P, P, P, S]),
+    'd2p_group_mean': (c_int, [c_int, c_int, c_int, P, P, P, S]),
+    'd2p_group_mean_bwd': (c_int, [c_int, c_int, c_int, P, P, P, c_int, S]),
+    'd2p_rn_pair_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, S]),
+    'd2p_rn_pair_bwd': (c_int, [c_int, c_int, c_int, P, P, P, S]),
+    'd2p_pair_mean_fwd': (c_int, [c_int, c_int, c_int, P, P, P, S]),
+    'd2p_pair_mean_bwd': (c_int, [c_int, c_int, c_int, P, P, S]),
+    'd2p_axpy': (c_int, [c_size_t, c_float, P, P, c_int, S]),
+    'd2p_transpose_rt': (c_int, [c_int, c_int, c_int, P, P, S]),
+    'd2p_zero_past_group_steps': (c_int, [c_int, c_int, c_int, c_int, P, P, S]),
+    'd2p_l2norm_ws_bytes': (c_size_t, [c_size_t]),
+    'd2p_l2norm_flat': (c_int, [c_size_t, P, c_float, P, P, c_size_t, S]),
+    'd2p_adam_clip_flat': (c_int, [c_size_t, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, S]),
+}
+
+_lib = None
+
+
+class D2PError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and declare every prototype.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise D2PError(
+            'libd2p_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; '
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(name, rc):
+    if rc != 0:
+        msg = load().d2p_last_error()
+        raise D2PError('%s failed (code %d): %s' % (name, rc, msg.decode() if msg else ''))
+
+
+class _Caller(object):
+    """``call.d2p_xxx(...)`` -> invokes the C function, raises D2PError on a non-zero
+    return code for int-returning entry points."""
+
+    def __getattr__(self, name):
+        lib = load()
+        fn = getattr(lib, name)
+        res = SIGNATURES[name][0]
+        if res is c_int and name != 'd2p_version':
+            def wrapped(*args):
+                _check(name, fn(*args))
+        else:
+            wrapped = fn
+        setattr(self, name, wrapped)
+        return wrapped
+
+
+call = _Caller()
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

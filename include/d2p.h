@@ -1,0 +1,248 @@
+/*
+ * d2p.h -- C ABI of libd2p_hip.so: the MI355X (gfx950) kernels under the
+ * demo2program full-model training step.
+ *
+ * The reference (shaohua0116/demo2program) has no FFI / plugin interface: its hot
+ * path sits behind Python classes (models/model_full.py, trainer.py) and the
+ * arithmetic is whatever TensorFlow 1.3 dispatches.  Each entry point below
+ * therefore cites the reference call site (file:line under /root/reference) whose
+ * TF-1.3 op it replaces.  The Python surface that mirrors the reference classes is
+ * demo2program_amd/{models/model_full.py,trainer.py}; it reaches these functions
+ * through ctypes (demo2program_amd/lib.py).  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless noted;
+ *    fp32 / int32, contiguous unless a stride argument says otherwise;
+ *  - the caller owns every buffer, including scratch (`ws`); the library allocates
+ *    nothing and keeps no global mutable state except a thread-local error string;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs
+ *    no device synchronisation, and is hipGraph-capturable;
+ *  - return 0 on success, a negative D2P_E* code for argument errors, or a positive
+ *    hipError_t; never throws / aborts.  d2p_last_error() describes the failure.
+ *  - activations are row-major [rows, features]; images NHWC; conv weights
+ *    [3,3,Cin,Cout] (TF HWIO); LSTM kernel [(I+U), 4U] with gate order i, j, f, o.
+ */
+#ifndef D2P_H
+#define D2P_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define D2P_OK 0
+#define D2P_EINVAL (-1)  /* bad argument (null pointer, negative size, bad enum) */
+#define D2P_EWS (-2)     /* workspace too small */
+#define D2P_EALIGN (-3)  /* pointer / stride alignment requirement violated */
+
+typedef void* d2p_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------ */
+int d2p_version(void);                 /* ABI version, currently 1 */
+const char* d2p_last_error(void);      /* thread-local, never NULL */
+/* Fills: name (<=255 chars), number of CUs, wavefront size, HBM bytes.  HOST pointers. */
+int d2p_device_info(int device, char* name, int name_len, int* cus, int* wave, size_t* hbm_bytes);
+
+/* ---- K5: fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32, LDS-tiled) ---------------------
+ * Replaces the cuBLAS/Eigen matmuls TF dispatches for slim.fully_connected
+ * (models/ops.py:152), BasicLSTMCell's [x,h]·W (models/model_full.py:244-246),
+ * layers_core.Dense (models/model_full.py:463-464) and their gradients.
+ *   nn: C[M,N] (=|+=) A[M,K]·B[K,N]      nt: A[M,K]·B[N,K]^T      tn: A[K,M]^T·B[K,N]
+ * lda/ldb/ldc are row strides in floats.  bias: [N] or NULL.  act: 0 none, 1 lrelu(0.2).
+ * accumulate != 0 adds the previous contents of C (before bias/act are applied:
+ * C = act(A·B + C_old + bias)).
+ * ws: scratch for split-K, at least d2p_gemm_ws_bytes(M,N,K) bytes (may be NULL if 0). */
+size_t d2p_gemm_ws_bytes(int M, int N, int K);
+int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                    float* C, long ldc, const float* bias, int act, int accumulate,
+                    void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_gemm_f32_nt(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                    float* C, long ldc, const float* bias, int act, int accumulate,
+                    void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                    float* C, long ldc, const float* bias, int act, int accumulate,
+                    void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* out[c] = sum_r X[r*ld + c]  (bias gradients).  ws >= d2p_colsum_ws_bytes. */
+size_t d2p_colsum_ws_bytes(int rows, int cols);
+int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float* out,
+                   void* ws, size_t ws_bytes, d2p_stream_t stream);
+
+/* ---- K1: NHWC 3x3 stride-2 TF-SAME convolution as implicit-im2col MFMA GEMM -------
+ * Replaces slim.conv2d(3x3, stride 2, SAME) (models/ops.py:30, called from
+ * State_Encoder, models/model_full.py:219-229) and its cuDNN gradients.
+ * x: [N,H,W,Cin] (fp32, or uint8 when x_is_u8 != 0 -- widened on load);
+ * w: [3,3,Cin,Cout]; y: [N,Ho,Wo,Cout], Ho=ceil(H/2), Wo=ceil(W/2).
+ * SAME padding is asymmetric: even sizes pad (0 before, 1 after); odd sizes (1,1).
+ * fwd applies  y = act(conv(x,w) + bias), act: 0 none / 1 lrelu(0.2). */
+size_t d2p_conv_ws_bytes(int N, int H, int W, int Cin, int Cout);
+int d2p_conv2d_nhwc_s2_same_fwd(int N, int H, int W, int Cin, int Cout,
+                                const void* x, int x_is_u8, const float* w, const float* bias,
+                                int act, float* y, d2p_stream_t stream);
+/* dx[N,H,W,Cin] = conv_transpose(dy[N,Ho,Wo,Cout], w) */
+int d2p_conv2d_nhwc_s2_same_dgrad(int N, int H, int W, int Cin, int Cout,
+                                  const float* dy, const float* w, float* dx, d2p_stream_t stream);
+/* dw[3,3,Cin,Cout] = im2col(x)^T · dy  (split-K over the N*Ho*Wo rows; deterministic) */
+int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int Cout,
+                                  const void* x, int x_is_u8, const float* dy, float* dw,
+                                  void* ws, size_t ws_bytes, d2p_stream_t stream);
+
+/* ---- K2: training-mode batch norm over row groups (+ fused lrelu backward) ---------
+ * Replaces tf.contrib.layers.batch_norm(is_training=True, decay=0.9,
+ * updates_collections=None) (models/ops.py:20-23).  The reference calls the encoder
+ * once per demonstration index (models/model_full.py:373-379), so statistics are per
+ * GROUP: x is [R, C]; group(r) = (r / inner) % G; G = 1 is an ordinary batch norm.
+ * Statistics: per (group, channel) mean and BIASED variance, eps = 1e-3, accumulated
+ * in fp64.  mean/rstd: [G, C] outputs (kept for backward).
+ * y = gamma*(x-mean)*rstd + beta.   var_out ([G,C] or NULL) receives the biased variance.
+ * bwd: given dy, the forward input x and saved mean/rstd, writes
+ *   dx = gamma*rstd*(dy - mean_g(dy) - xhat*mean_g(dy*xhat)) [* lrelu'(x) if act_bwd]
+ *   dgamma[c] = sum_all dy*xhat,  dbeta[c] = sum_all dy.
+ * act_bwd = 1: x is the lrelu OUTPUT feeding BN (conv/fc -> lrelu -> BN order,
+ * models/ops.py:14-24), and dx is additionally multiplied by lrelu'(pre-activation),
+ * whose sign equals sign(x): 1 (x>0), 0.2 (x<0), 0.6 (x==0, TF's abs'(0)=0). */
+size_t d2p_bn_ws_bytes(int R, int C, int G);
+int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, const float* gamma,
+                     const float* beta, float* y, float* mean, float* rstd, float* var_out,
+                     void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float* dy,
+                     const float* gamma, const float* mean, const float* rstd, int act_bwd,
+                     float* dx, float* dgamma, float* dbeta,
+                     void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* moving <- decay*moving + (1-decay)*batch, applied G times in group order (the
+ * reference updates once per Demo_Encoder call).  moving_mean/var: [C]. */
+int d2p_bn_update_moving(int C, int G, float decay, const float* mean, const float* var,
+                         float* moving_mean, float* moving_var, d2p_stream_t stream);
+
+/* ---- K3/K4: LSTM gate pointwise, standalone ----------------------------------------
+ * Replaces the elementwise tail of rnn.BasicLSTMCell.call (models/model_full.py:244-246):
+ *   z = [i, j, f, o] pre-activations (row r at z + r*z_row_stride, 4U floats);
+ *   c' = c*sigmoid(f+1) + sigmoid(i)*tanh(j);  h' = tanh(c')*sigmoid(o).
+ * lens/t implement tf.nn.dynamic_rnn(sequence_length) (models/model_full.py:254-256):
+ * rows with t >= lens[r] copy (c,h) through and emit h_out = 0.  lens == NULL: no masking.
+ * Algorithmic bytes/row: fwd 14336 (U=512), bwd 26624. */
+int d2p_lstm_gate_fwd(int M, int U, const float* z, long z_row_stride, const float* c_prev,
+                      const float* h_prev, const int* lens, int t,
+                      float* c_out, float* h_state_out, float* h_out, d2p_stream_t stream);
+/* dh_in: gradient wrt the state h after this step ([M,U], may be NULL = 0);
+ * dh_out_grad: gradient wrt the emitted output row ([M,U], may be NULL);
+ * dc: in/out gradient wrt state c ([M,U]); dz: out [M rows, stride dz_row_stride, 4U].
+ * For masked rows dz = 0, dc unchanged and dh_pass (if non-NULL) receives dh_in
+ * (else 0), so that dh_prev = dz·Wh^T + dh_pass. */
+int d2p_lstm_gate_bwd(int M, int U, const float* z, long z_row_stride, const float* c_prev,
+                      const float* c, const float* dh_in, const float* dh_out_grad,
+                      const int* lens, int t, float* dc, float* dz, long dz_row_stride,
+                      float* dh_pass, d2p_stream_t stream);
+
+/* ---- LSTM over a sequence (recurrent GEMM + gate per step) --------------------------
+ * Replaces tf.nn.dynamic_rnn(BasicLSTMCell) (models/model_full.py:254-256,274-276) and
+ * the BasicDecoder/TrainingHelper loop (models/model_full.py:413,465-471).
+ * z: in = hoisted input projection x·Wx + b for every step; out = full pre-activations
+ *    (element (row r, step t) at z + r*z_row_stride + t*z_t_stride, 4U floats).
+ * Wh: [U, 4U] recurrent rows of the LSTM kernel.  h0/c0: [M,U] or NULL (zeros).
+ * lens: [M] int32 or NULL.  hout: [n_steps, M, U] emitted outputs (0 past len).
+ * cs: [n_steps, M, U] cell state after each step.  h_final/c_final: [M,U].
+ * ws: >= d2p_lstm_ws_bytes(M,U). */
+size_t d2p_lstm_ws_bytes(int M, int U);
+int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_stride, long z_t_stride,
+                     const float* Wh, const float* h0, const float* c0, const int* lens,
+                     float* hout, float* cs, float* h_final, float* c_final,
+                     void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* Backward through the sequence.  dhout: [n_steps,M,U] or NULL; dh_final/dc_final: [M,U]
+ * or NULL.  dz: out, same addressing as z.  dh0/dc0: out [M,U] (may be NULL). */
+int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long z_row_stride, long z_t_stride,
+                     const float* Wh, const float* c0, const int* lens,
+                     const float* cs, const float* dhout, const float* dh_final,
+                     const float* dc_final, float* dz, float* dh0, float* dc0,
+                     void* ws, size_t ws_bytes, d2p_stream_t stream);
+
+/* ---- K6: embedding gather with out-of-range -> 0, and its scatter-add gradient ------
+ * Replaces tf.nn.embedding_lookup (models/model_full.py:294); the reference's <s> id is
+ * token_dim+1, out of range for the [token_dim+1, E] table, which TF-GPU gathers as zeros
+ * (models/model_full.py:288-291,448-450).
+ * d2p_shift_tokens_tm builds the decoder input ids time-major:
+ *   ids[t*R + r] = (t == 0) ? start_id : tokens[r*T + t-1]      (models/model_full.py:447-450) */
+int d2p_shift_tokens_tm(int R, int T, const int* tokens, int start_id, int* ids, d2p_stream_t stream);
+int d2p_embedding_gather_oob0(int n, int rows, int E, const int* ids, const float* table,
+                              float* out, d2p_stream_t stream);
+int d2p_embedding_scatter_add_oob0(int n, int rows, int E, const int* ids, const float* dout,
+                                   float* dtable, d2p_stream_t stream);
+
+/* ---- K7: masked, count-normalised sequence cross-entropies --------------------------
+ * Replaces Sequence_Loss (models/model_full.py:620-657): softmax_/sigmoid_cross_entropy_
+ * with_logits, tf.sequence_mask and the sum(ce*mask)/sum(mask) normalisation.
+ * logits: time-major [T, R, V] (row (t,r) at (t*R+r)*V).  labels: element (r,t,v) at
+ * labels[r*lab_r_stride + t*lab_t_stride + v*lab_v_stride] (so both the reference's
+ * [B,V,L] one-hot `program` and its [B,k,T,A] `a_h` are read in place).
+ * lens: [R].  group(r) = r % G (G = k for action/per: one loss per demonstration index,
+ * models/model_full.py:1018-1038; G = 1 for the program).  Rows with t >= n_steps have
+ * logits treated as 0 (the reference zero-pads past max(len), models/model_full.py:476-484).
+ * fwd: loss_num[g] = sum ce*mask, loss_den[g] = sum mask (fp32 outputs [G] each); two-stage
+ *      deterministic reduction through ws (>= d2p_xent_ws_bytes(G)).
+ * bwd: dlogits[(t,r),v] = scale/(G*den[g]) * mask * (softmax - labels)      (softmax)
+ *                       = scale/(G*den[g]) * mask * (sigmoid - labels)/V    (sigmoid),
+ *      written for t < n_steps only. */
+size_t d2p_xent_ws_bytes(int G);
+int d2p_softmax_xent_masked_fwd(int T, int R, int V, int G, int n_steps, const float* logits,
+                                const float* labels, long lab_r_stride, long lab_t_stride,
+                                long lab_v_stride, const int* lens, float* loss_num,
+                                float* loss_den, void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_softmax_xent_masked_bwd(int T, int R, int V, int G, int n_steps, const float* logits,
+                                const float* labels, long lab_r_stride, long lab_t_stride,
+                                long lab_v_stride, const int* lens, const float* loss_den,
+                                float scale, float* dlogits, d2p_stream_t stream);
+int d2p_sigmoid_xent_masked_fwd(int T, int R, int V, int G, int n_steps, const float* logits,
+                                const float* labels, long lab_r_stride, long lab_t_stride,
+                                long lab_v_stride, const int* lens, float* loss_num,
+                                float* loss_den, void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_sigmoid_xent_masked_bwd(int T, int R, int V, int G, int n_steps, const float* logits,
+                                const float* labels, long lab_r_stride, long lab_t_stride,
+                                long lab_v_stride, const int* lens, const float* loss_den,
+                                float scale, float* dlogits, d2p_stream_t stream);
+/* loss[0] = sum_terms (1/G_j) * sum_g num_j[g]/den_j[g]   (models/model_full.py:932,1035-1038,
+ * 1078-1079).  nums/dens: concatenated [G_0 + G_1 + ...]; groups: HOST array of n_terms ints. */
+int d2p_loss_assemble(int n_terms, const int* groups, const float* nums, const float* dens,
+                      float* loss, float* term_losses, d2p_stream_t stream);
+
+/* ---- summarizer glue (models/model_full.py:333-362,380-404) -------------------------- */
+/* mean over k: out[b,:] = mean_i x[b,i,:]; if bcast != NULL also bcast[b,i,:] = out[b,:]. */
+int d2p_group_mean(int B, int k, int U, const float* x, float* out, float* bcast, d2p_stream_t stream);
+/* dx[b,i,:] (=|+=) (dout[b,:] + sum_i dbcast[b,i,:]) / k   (dbcast may be NULL) */
+int d2p_group_mean_bwd(int B, int k, int U, const float* dout, const float* dbcast, float* dx,
+                       int accumulate, d2p_stream_t stream);
+/* rn_pool first layer without materialising pairs:
+ *   y[b,a,c,:] = lrelu(P[b,c,:] + Q[b,a,:] + bias)   with P = feat·W1[:U], Q = feat·W1[U:] */
+int d2p_rn_pair_fwd(int B, int k, int U, const float* P, const float* Q, const float* bias,
+                    float* y, d2p_stream_t stream);
+/* dP[b,c,:] = sum_a dy[b,a,c,:], dQ[b,a,:] = sum_c dy[b,a,c,:]   (dy already wrt pre-activation) */
+int d2p_rn_pair_bwd(int B, int k, int U, const float* dy, float* dP, float* dQ, d2p_stream_t stream);
+/* out[b,:] = mean_{a,c} y[b,a,c,:] + base[b,:]  and its backward dy[b,a,c,:] = dout[b,:]/k^2 */
+int d2p_pair_mean_fwd(int B, int kk, int U, const float* y, const float* base, float* out, d2p_stream_t stream);
+int d2p_pair_mean_bwd(int B, int kk, int U, const float* dout, float* dy, d2p_stream_t stream);
+/* small elementwise helpers: y (=|+=) a*x ; transposes used to re-lay host batches */
+int d2p_axpy(size_t n, float a, const float* x, float* y, int accumulate, d2p_stream_t stream);
+/* out[t, r, :] = in[r, t, :]  (R x T x C -> T x R x C) */
+int d2p_transpose_rt(int R, int T, int C, const float* in, float* out, d2p_stream_t stream);
+/* zero logits rows (t, r) with t >= nsteps_g[r % G]  (per-demo dynamic padding,
+ * models/model_full.py:476-484); nsteps_g[g] = min(T, max_{r%G==g} lens[r]) computed on device. */
+int d2p_zero_past_group_steps(int T, int R, int V, int G, const int* lens, float* logits, d2p_stream_t stream);
+
+/* ---- K8: global-norm clip + Adam over one flat buffer -------------------------------
+ * Replaces tf.contrib.layers.optimize_loss(clip_gradients=20.0, AdamOptimizer)
+ * (trainer.py:102-109): clip_by_global_norm then Adam (beta1 .9, beta2 .999, eps 1e-8,
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) supplied by the caller as lr_t).
+ * d2p_l2norm_flat writes sum(g^2)*prescale^2 as fp64 to sumsq[0]; d2p_adam_clip_flat reads it
+ * on device (no host sync): scale = prescale * clip / max(sqrt(sumsq), clip).
+ * prescale = 1/world_size folds the data-parallel gradient average in. */
+size_t d2p_l2norm_ws_bytes(size_t n);
+int d2p_l2norm_flat(size_t n, const float* g, float prescale, double* sumsq,
+                    void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_adam_clip_flat(size_t n, float* p, const float* g, float* m, float* v,
+                       const double* sumsq, float prescale, float clip, float lr_t,
+                       float beta1, float beta2, float eps, d2p_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* D2P_H */
