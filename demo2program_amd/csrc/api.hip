@@ -28,3 +28,79 @@ extern "C" int d2p_device_info(int device, char* name, int name_len, int* cus, i
     if (hbm_bytes) *hbm_bytes = prop.totalGlobalMem;
     return D2P_OK;
 }
+
+// ---- optional HIP-event profiling (prof.h) ------------------------------------------------
+#include <vector>
+
+#include "prof.h"
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int key;
+    double work;
+};
+static bool g_prof_enabled = false;
+static thread_local int g_prof_tag = 0;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+
+bool d2p_prof_on() { return g_prof_enabled; }
+int d2p_prof_tag() { return g_prof_tag; }
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void d2p_prof_begin(hipStream_t st, int family, double work) {
+    ProfRec r;
+    r.a = prof_event();
+    r.b = prof_event();
+    r.key = family * 8 + (g_prof_tag & 7);
+    r.work = work;
+    (void)hipEventRecord(r.a, st);
+    g_prof_recs.push_back(r);
+}
+
+void d2p_prof_end(hipStream_t st) {
+    if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().b, st);
+}
+
+extern "C" int d2p_prof_enable(int on) {
+    for (auto& r : g_prof_recs) {
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.clear();
+    g_prof_enabled = on != 0;
+    return D2P_OK;
+}
+
+extern "C" int d2p_prof_set_tag(int tag) {
+    g_prof_tag = tag;
+    return D2P_OK;
+}
+
+extern "C" int d2p_prof_read(int key, int* count, double* total_ms, double* total_work) {
+    int n = 0;
+    double ms = 0.0, work = 0.0;
+    for (auto& r : g_prof_recs) {
+        if (r.key != key) continue;
+        D2P_HIP(hipEventSynchronize(r.b));
+        float t = 0.f;
+        D2P_HIP(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t;
+        work += r.work;
+        ++n;
+    }
+    if (count) *count = n;
+    if (total_ms) *total_ms = ms;
+    if (total_work) *total_work = work;
+    return D2P_OK;
+}

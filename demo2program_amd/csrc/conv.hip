@@ -170,10 +170,10 @@ extern "C" int d2p_conv2d_nhwc_s2_same_fwd(int N, int H, int W, int Cin, int Cou
     EpiDense ep{y, Cout, bias, act, 0};
     if (x_is_u8) {
         Im2colKC<uint8_t> al{{(const uint8_t*)x, g, (Cin % 4 == 0) && (((uintptr_t)x & 3) == 0)}, M};
-        return d2p_launch_gemm(al, bl, ep, M, Cout, K, nullptr, 0, as_stream(stream), "conv_fwd_u8");
+        return d2p_launch_gemm(al, bl, ep, M, Cout, K, nullptr, 0, as_stream(stream), "conv_fwd_u8", D2P_PROF_CONV);
     }
     Im2colKC<float> al{{(const float*)x, g, vecx}, M};
-    return d2p_launch_gemm(al, bl, ep, M, Cout, K, nullptr, 0, as_stream(stream), "conv_fwd");
+    return d2p_launch_gemm(al, bl, ep, M, Cout, K, nullptr, 0, as_stream(stream), "conv_fwd", D2P_PROF_CONV);
 }
 
 extern "C" int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int Cout, const void* x,
@@ -189,10 +189,10 @@ extern "C" int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int C
     EpiDense ep{dw, Cout, nullptr, 0, 0};
     if (x_is_u8) {
         Im2colXC<uint8_t> al{{(const uint8_t*)x, g, (Cin % 4 == 0) && (((uintptr_t)x & 3) == 0)}, KK};
-        return d2p_launch_gemm(al, bl, ep, KK, Cout, Mred, ws, ws_bytes, as_stream(stream), "conv_wgrad_u8");
+        return d2p_launch_gemm(al, bl, ep, KK, Cout, Mred, ws, ws_bytes, as_stream(stream), "conv_wgrad_u8", D2P_PROF_CONV);
     }
     Im2colXC<float> al{{(const float*)x, g, vecx}, KK};
-    return d2p_launch_gemm(al, bl, ep, KK, Cout, Mred, ws, ws_bytes, as_stream(stream), "conv_wgrad");
+    return d2p_launch_gemm(al, bl, ep, KK, Cout, Mred, ws, ws_bytes, as_stream(stream), "conv_wgrad", D2P_PROF_CONV);
 }
 
 extern "C" int d2p_conv2d_nhwc_s2_same_dgrad(int N, int H, int W, int Cin, int Cout,
@@ -209,5 +209,5 @@ extern "C" int d2p_conv2d_nhwc_s2_same_dgrad(int N, int H, int W, int Cin, int C
     ColTKC al{dy, g, P};
     WDgradKC bl{w, Cin, Cout};
     EpiDense ep{dx, Cin, nullptr, 0, 0};
-    return d2p_launch_gemm(al, bl, ep, P, Cin, K, nullptr, 0, as_stream(stream), "conv_dgrad");
+    return d2p_launch_gemm(al, bl, ep, P, Cin, K, nullptr, 0, as_stream(stream), "conv_dgrad", D2P_PROF_CONV);
 }

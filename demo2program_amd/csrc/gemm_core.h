@@ -19,6 +19,7 @@
 //    [BK][BX] and read with ds_read_b32: lanes 0-31 consecutive floats -> conflict-free.
 #pragma once
 #include "common.h"
+#include "prof.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -278,8 +279,10 @@ static inline size_t d2p_plan_ws_bytes(int M, int N, int K) {
 
 template <class AL, class BL, class EP>
 static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
-                           void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+                           void* ws, size_t ws_bytes, hipStream_t st, const char* name,
+                           int prof_family = D2P_PROF_GEMM) {
     if (M <= 0 || N <= 0) return D2P_OK;
+    D2pProfScope prof(st, prof_family, 2.0 * M * N * K);
     GemmPlan p = d2p_plan_gemm(M, N, K, ws != nullptr);
     float* partial = nullptr;
     if (p.splits > 1) {

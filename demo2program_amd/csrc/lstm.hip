@@ -11,6 +11,7 @@
 // pre-activations) and the pointwise gate kernel run.  The pre-activations are kept for
 // backward; activations are recomputed there (saves 3/4 of the saved-state traffic).
 #include "common.h"
+#include "prof.h"
 
 #define FORGET_BIAS 1.0f
 
@@ -140,6 +141,8 @@ extern "C" int d2p_lstm_gate_fwd(int M, int U, const float* z, long z_row_stride
     if (rc) return rc;
     if (M == 0) return D2P_OK;
     D2P_REQUIRE(z && c_out && h_out, D2P_EINVAL, "lstm gate fwd: null pointer");
+    // algorithmic bytes/row: read 4U pre-activations + U c_prev, write U c + U h
+    D2pProfScope prof(as_stream(stream), D2P_PROF_GATE_FWD, 7.0 * U * 4.0 * M);
     hipLaunchKernelGGL(lstm_gate_fwd_kernel, dim3(gate_blocks((long)M * U / 4)), dim3(256), 0,
                        as_stream(stream), M, U, z, z_row_stride, c_prev, h_prev, lens, t, c_out,
                        h_state_out, h_out);
@@ -158,6 +161,8 @@ extern "C" int d2p_lstm_gate_bwd(int M, int U, const float* z, long z_row_stride
     D2P_REQUIRE(z && c && dc && dz, D2P_EINVAL, "lstm gate bwd: null pointer");
     D2P_REQUIRE(dz_row_stride % 4 == 0 && (((uintptr_t)dz & 15) == 0), D2P_EALIGN,
                 "lstm gate bwd: dz must be 16-byte aligned with row stride %% 4 == 0");
+    // algorithmic bytes/row: read dh, dc, 4U pre-activations, c_prev, c (8U); write 4U dz + U dc
+    D2pProfScope prof(as_stream(stream), D2P_PROF_GATE_BWD, 13.0 * U * 4.0 * M);
     hipLaunchKernelGGL(lstm_gate_bwd_kernel, dim3(gate_blocks((long)M * U / 4)), dim3(256), 0,
                        as_stream(stream), M, U, z, z_row_stride, c_prev, c, dh_in, dh_out_grad, lens,
                        t, dc, dz, dz_row_stride, dh_pass);
@@ -196,6 +201,7 @@ extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_
     float* hs[2] = {(float*)ws, (float*)ws + MU};
     const float* h_prev = h0;
     const float* c_prev = c0;
+    d2p_prof_set_tag(1);   // sub-tag 1 = launches inside the recurrence
     for (int t = 0; t < n_steps; ++t) {
         float* zt = z + (long)t * z_t_stride;
         if (h_prev) {
@@ -210,6 +216,7 @@ extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_
         h_prev = lens ? hs_out : hout + t * MU;
         c_prev = cs + t * MU;
     }
+    d2p_prof_set_tag(0);
     int rc = copy_or_zero(h_final, h_prev, MU, st);
     if (rc) return rc;
     return copy_or_zero(c_final, c_prev, MU, st);
@@ -232,6 +239,7 @@ extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long 
     int rc = copy_or_zero(dC, dc_final, MU, st);
     if (rc) return rc;
     const float* dh_in = dh_final;   // may be null (= 0)
+    d2p_prof_set_tag(1);
     for (int t = n_steps - 1; t >= 0; --t) {
         const float* c_prev = t ? cs + (size_t)(t - 1) * MU : c0;
         const bool last = (t == 0);
@@ -256,6 +264,7 @@ extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long 
         if (rc) return rc;
         dh_in = target;
     }
+    d2p_prof_set_tag(0);
     if (n_steps == 0) {
         rc = copy_or_zero(dh0, dh_final, MU, st);
         if (rc) return rc;

@@ -1,0 +1,95 @@
+"""Data parallelism over the batch (program) axis: one process per GPU, RCCL over xGMI.
+
+The reference is single-GPU (trainer.py:134-138) and defines no multi-GPU behaviour; this is
+the one exchange step the sharded path needs:
+
+  * each rank trains on B/N programs with ALL k demonstrations of each program (the
+    summarizer mixes across k inside a program, never across programs);
+  * after backward, ONE all-reduce(SUM, fp32) over the flat gradient buffer (~45 MB);
+    xGMI is point-to-point, so a ring all-reduce is per-link bound and one large message
+    is the efficient shape (2*(N-1)/N*45 MB / 153 GB/s ~= 0.5 ms at N=8);
+  * the 1/N of the average is folded into the clip+Adam kernel's ``prescale`` -- the
+    averaged gradient is never written back to HBM;
+  * clip-by-global-norm runs AFTER the reduce, on every rank, as trainer.py:107 implies;
+  * batch-norm statistics and the loss denominators stay per rank (no sync-BN): N ranks x
+    B/N programs == N independent reference steps with averaged gradients.
+
+``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used for the CPU tests.
+"""
+import os
+
+import torch
+
+
+class DataParallel(object):
+
+    def __init__(self, rank=0, world_size=1, initialized=False):
+        self.rank = rank
+        self.world_size = world_size
+        self.initialized = initialized
+
+    @classmethod
+    def from_env(cls, backend=None):
+        """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run)."""
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        rank = int(os.environ.get('RANK', '0'))
+        local = int(os.environ.get('LOCAL_RANK', str(rank)))
+        if world <= 1:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(0)
+            return cls(0, 1, False)
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        use_cuda = torch.cuda.is_available()
+        if use_cuda:
+            torch.cuda.set_device(local % torch.cuda.device_count())
+        if backend is None:
+            backend = 'nccl' if use_cuda else 'gloo'
+        if not dist.is_initialized():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        return cls(rank, world, True)
+
+    @property
+    def prescale(self):
+        return 1.0 / self.world_size
+
+    def all_reduce_grads(self, flat_grad):
+        """SUM the flat gradient buffer across ranks, in place (no-op for one rank)."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+        return flat_grad
+
+    def broadcast_params(self, flat_params, src=0):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(flat_params, src=src)
+        return flat_params
+
+    def shard(self, ids):
+        """Per-rank id shard: ids[rank::N] (after the reference's seeded shuffle,
+        karel_env/dataset_karel.py:156)."""
+        return list(ids)[self.rank::self.world_size]
+
+    def barrier(self):
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    def max_over_ranks(self, value):
+        """max of a python float across ranks (bench timing)."""
+        if self.world_size <= 1:
+            return value
+        import torch.distributed as dist
+        dev = 'cuda' if torch.cuda.is_available() and dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([value], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def shutdown(self):
+        if self.initialized:
+            import torch.distributed as dist
+            if dist.is_initialized():
+                dist.destroy_process_group()

@@ -1,0 +1,320 @@
+"""Tensor-level wrappers over the C ABI (include/d2p.h).
+
+torch is used here only for device memory (``torch.empty``), the current stream and
+views; every arithmetic operation is a call into libd2p_hip.so.  All tensors must be
+CUDA (ROCm) fp32 / int32 and contiguous unless a stride is passed explicitly.
+"""
+import torch
+
+from .lib import call, current_stream, ptr
+
+
+def _require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError('demo2program_amd kernels need CUDA/ROCm tensors; got a %s tensor. '
+                               'There is no CPU fallback.' % t.device)
+
+
+class Scratch(object):
+    """One growing device scratch buffer.  Every kernel is launched on the same stream, so
+    successive ops may reuse it (stream order serialises their accesses)."""
+
+    def __init__(self):
+        self.buf = None
+
+    def get(self, nbytes):
+        nbytes = int(nbytes)
+        if nbytes == 0:
+            return None, 0
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device='cuda')
+        return self.buf.data_ptr(), self.buf.numel()
+
+    def reserve(self, nbytes):
+        self.get(nbytes)
+
+
+SCRATCH = Scratch()
+
+
+# ---------------------------------------------------------------- GEMM
+def gemm_raw(kind, M, N, K, A, lda, B, ldb, C, ldc, bias=None, act=0, accumulate=False,
+             allow_split=True):
+    """kind in {'nn','nt','tn'}; A/B/C are data pointers (ints) or tensors."""
+    ws, wsb = (None, 0)
+    if allow_split:
+        ws, wsb = SCRATCH.get(call.d2p_gemm_ws_bytes(M, N, K))
+    fn = getattr(call, 'd2p_gemm_f32_' + kind)
+    fn(M, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias), act, 1 if accumulate else 0,
+       ws, wsb, current_stream())
+
+
+def _p(x):
+    if x is None or isinstance(x, int):
+        return x
+    return x.data_ptr()
+
+
+def matmul_nn(A, B, out=None, bias=None, act=0, accumulate=False):
+    """out[M,N] = A[M,K] @ B[K,N] (+bias, act)."""
+    _require_gpu(A, B)
+    M, K = A.shape
+    K2, N = B.shape
+    assert K == K2
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    gemm_raw('nn', M, N, K, A, A.stride(0), B, B.stride(0), out, out.stride(0), bias, act, accumulate)
+    return out
+
+
+def matmul_nt(A, B, out=None, accumulate=False):
+    """out[M,N] = A[M,K] @ B[N,K]^T."""
+    _require_gpu(A, B)
+    M, K = A.shape
+    N, K2 = B.shape
+    assert K == K2
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    gemm_raw('nt', M, N, K, A, A.stride(0), B, B.stride(0), out, out.stride(0), None, 0, accumulate)
+    return out
+
+
+def matmul_tn(A, B, out=None, accumulate=False):
+    """out[M,N] = A[K,M]^T @ B[K,N]."""
+    _require_gpu(A, B)
+    K, M = A.shape
+    K2, N = B.shape
+    assert K == K2
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    gemm_raw('tn', M, N, K, A, A.stride(0), B, B.stride(0), out, out.stride(0), None, 0, accumulate)
+    return out
+
+
+def colsum(X, out=None, rows=None):
+    _require_gpu(X)
+    R, C = X.shape
+    if rows is not None:
+        R = rows
+    if out is None:
+        out = torch.empty(C, dtype=torch.float32, device=X.device)
+    ws, wsb = SCRATCH.get(call.d2p_colsum_ws_bytes(R, C))
+    call.d2p_colsum_f32(R, C, ptr(X), X.stride(0), ptr(out), ws, wsb, current_stream())
+    return out
+
+
+# ---------------------------------------------------------------- conv
+def conv_out_hw(H, W):
+    return (H + 1) // 2, (W + 1) // 2
+
+
+def conv_fwd(x, w, bias, act=1, out=None):
+    """x [N,H,W,Cin] fp32 or uint8; w [3,3,Cin,Cout]; returns act(conv+bias) [N,Ho,Wo,Cout]."""
+    _require_gpu(x, w)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    Ho, Wo = conv_out_hw(H, W)
+    if out is None:
+        out = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    call.d2p_conv2d_nhwc_s2_same_fwd(N, H, W, Cin, Cout, ptr(x), 1 if x.dtype == torch.uint8 else 0,
+                                     ptr(w), ptr(bias), act, ptr(out), current_stream())
+    return out
+
+
+def conv_wgrad(x, dy, dw):
+    _require_gpu(x, dy, dw)
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    ws, wsb = SCRATCH.get(call.d2p_conv_ws_bytes(N, H, W, Cin, Cout))
+    call.d2p_conv2d_nhwc_s2_same_wgrad(N, H, W, Cin, Cout, ptr(x), 1 if x.dtype == torch.uint8 else 0,
+                                       ptr(dy), ptr(dw), ws, wsb, current_stream())
+    return dw
+
+
+def conv_dgrad(dy, w, x_shape, dx=None):
+    _require_gpu(dy, w)
+    N, H, W, Cin = x_shape
+    Cout = w.shape[3]
+    if dx is None:
+        dx = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dy.device)
+    call.d2p_conv2d_nhwc_s2_same_dgrad(N, H, W, Cin, Cout, ptr(dy), ptr(w), ptr(dx), current_stream())
+    return dx
+
+
+# ---------------------------------------------------------------- batch norm
+def bn_fwd(x2d, gamma, beta, G, inner, y=None, mean=None, rstd=None, var=None):
+    """x2d [R,C]; returns (y, mean[G,C], rstd[G,C], var) -- var only if a buffer is passed."""
+    _require_gpu(x2d)
+    R, C = x2d.shape
+    if y is None:
+        y = torch.empty_like(x2d)
+    if mean is None:
+        mean = torch.empty(G, C, dtype=torch.float32, device=x2d.device)
+    if rstd is None:
+        rstd = torch.empty(G, C, dtype=torch.float32, device=x2d.device)
+    ws, wsb = SCRATCH.get(call.d2p_bn_ws_bytes(R, C, G))
+    call.d2p_bn_group_fwd(R, C, G, inner, ptr(x2d), ptr(gamma), ptr(beta), ptr(y), ptr(mean),
+                          ptr(rstd), ptr(var), ws, wsb, current_stream())
+    return y, mean, rstd, var
+
+
+def bn_bwd(x2d, dy, gamma, mean, rstd, G, inner, act_bwd, dgamma, dbeta, dx=None):
+    _require_gpu(x2d, dy)
+    R, C = x2d.shape
+    if dx is None:
+        dx = torch.empty_like(x2d)
+    ws, wsb = SCRATCH.get(call.d2p_bn_ws_bytes(R, C, G))
+    call.d2p_bn_group_bwd(R, C, G, inner, ptr(x2d), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd),
+                          1 if act_bwd else 0, ptr(dx), ptr(dgamma), ptr(dbeta), ws, wsb,
+                          current_stream())
+    return dx
+
+
+def bn_update_moving(mean, var, moving_mean, moving_var, decay=0.9):
+    G, C = mean.shape
+    call.d2p_bn_update_moving(C, G, decay, ptr(mean), ptr(var), ptr(moving_mean), ptr(moving_var),
+                              current_stream())
+
+
+# ---------------------------------------------------------------- LSTM
+def lstm_seq_fwd(z, z_row_stride, z_t_stride, M, U, n_steps, Wh, h0, c0, lens, hout, cs,
+                 h_final, c_final):
+    ws, wsb = SCRATCH.get(call.d2p_lstm_ws_bytes(M, U))
+    call.d2p_lstm_seq_fwd(M, U, n_steps, ptr(z), z_row_stride, z_t_stride, ptr(Wh), ptr(h0), ptr(c0),
+                          ptr(lens), ptr(hout), ptr(cs), ptr(h_final), ptr(c_final), ws, wsb,
+                          current_stream())
+
+
+def lstm_seq_bwd(z, z_row_stride, z_t_stride, M, U, n_steps, Wh, c0, lens, cs, dhout, dh_final,
+                 dc_final, dz, dh0, dc0):
+    ws, wsb = SCRATCH.get(call.d2p_lstm_ws_bytes(M, U))
+    call.d2p_lstm_seq_bwd(M, U, n_steps, ptr(z), z_row_stride, z_t_stride, ptr(Wh), ptr(c0),
+                          ptr(lens), ptr(cs), ptr(dhout), ptr(dh_final), ptr(dc_final), ptr(dz),
+                          ptr(dh0), ptr(dc0), ws, wsb, current_stream())
+
+
+def lstm_gate_fwd(z, c_prev, h_prev, lens, t, c_out, hs_out, h_out):
+    M = c_out.shape[0]
+    U = c_out.shape[1]
+    call.d2p_lstm_gate_fwd(M, U, ptr(z), z.stride(0), ptr(c_prev), ptr(h_prev), ptr(lens), t,
+                           ptr(c_out), ptr(hs_out), ptr(h_out), current_stream())
+
+
+def lstm_gate_bwd(z, c_prev, c, dh_in, dh_out_grad, lens, t, dc, dz, dh_pass):
+    M, U = c.shape
+    call.d2p_lstm_gate_bwd(M, U, ptr(z), z.stride(0), ptr(c_prev), ptr(c), ptr(dh_in),
+                           ptr(dh_out_grad), ptr(lens), t, ptr(dc), ptr(dz), dz.stride(0),
+                           ptr(dh_pass), current_stream())
+
+
+# ---------------------------------------------------------------- embedding
+def shift_tokens_tm(tokens, start_id, out=None):
+    """tokens [R,T] int32 -> ids [T,R] int32 with <s> first."""
+    R, T = tokens.shape
+    if out is None:
+        out = torch.empty(T, R, dtype=torch.int32, device=tokens.device)
+    call.d2p_shift_tokens_tm(R, T, ptr(tokens), start_id, ptr(out), current_stream())
+    return out
+
+
+def embedding_gather(ids, table, out=None, n=None):
+    rows, E = table.shape
+    if n is None:
+        n = ids.numel()
+    if out is None:
+        out = torch.empty(ids.numel(), E, dtype=torch.float32, device=table.device)
+    call.d2p_embedding_gather_oob0(n, rows, E, ptr(ids), ptr(table), ptr(out), current_stream())
+    return out
+
+
+def embedding_scatter_add(ids, dout, dtable, n=None):
+    rows, E = dtable.shape
+    if n is None:
+        n = ids.numel()
+    call.d2p_embedding_scatter_add_oob0(n, rows, E, ptr(ids), ptr(dout), ptr(dtable), current_stream())
+    return dtable
+
+
+# ---------------------------------------------------------------- losses
+def _lab_strides(kind, V, T):
+    # program labels [B,V,L]; action/per labels [B,k,T,V] flattened to rows r=(b,i)
+    if kind == 'bvl':
+        return V * T, 1, T
+    return T * V, V, 1
+
+
+def xent_fwd(mode, logits, labels, lab_kind, lens, T, R, V, G, n_steps, num, den):
+    ws, wsb = SCRATCH.get(call.d2p_xent_ws_bytes(G))
+    rs, ts, vs = _lab_strides(lab_kind, V, T)
+    fn = call.d2p_softmax_xent_masked_fwd if mode == 'softmax' else call.d2p_sigmoid_xent_masked_fwd
+    fn(T, R, V, G, n_steps, ptr(logits), ptr(labels), rs, ts, vs, ptr(lens), ptr(num), ptr(den),
+       ws, wsb, current_stream())
+
+
+def xent_bwd(mode, logits, labels, lab_kind, lens, T, R, V, G, n_steps, den, scale, dlogits):
+    rs, ts, vs = _lab_strides(lab_kind, V, T)
+    fn = call.d2p_softmax_xent_masked_bwd if mode == 'softmax' else call.d2p_sigmoid_xent_masked_bwd
+    fn(T, R, V, G, n_steps, ptr(logits), ptr(labels), rs, ts, vs, ptr(lens), ptr(den), scale,
+       ptr(dlogits), current_stream())
+
+
+def loss_assemble(groups, nums, dens, loss, term_losses):
+    import ctypes
+    arr = (ctypes.c_int * len(groups))(*groups)
+    call.d2p_loss_assemble(len(groups), ctypes.cast(arr, ctypes.c_void_p), ptr(nums), ptr(dens),
+                           ptr(loss), ptr(term_losses), current_stream())
+
+
+def zero_past_group_steps(logits, lens, T, R, V, G):
+    call.d2p_zero_past_group_steps(T, R, V, G, ptr(lens), ptr(logits), current_stream())
+
+
+# ---------------------------------------------------------------- summarizer glue
+def group_mean(x, B, k, U, out, bcast=None):
+    call.d2p_group_mean(B, k, U, ptr(x), ptr(out), ptr(bcast), current_stream())
+
+
+def group_mean_bwd(dout, dbcast, dx, B, k, U, accumulate):
+    call.d2p_group_mean_bwd(B, k, U, ptr(dout), ptr(dbcast), ptr(dx), 1 if accumulate else 0,
+                            current_stream())
+
+
+def rn_pair_fwd(P, Q, bias, y, B, k, U):
+    call.d2p_rn_pair_fwd(B, k, U, ptr(P), ptr(Q), ptr(bias), ptr(y), current_stream())
+
+
+def rn_pair_bwd(dy, dP, dQ, B, k, U):
+    call.d2p_rn_pair_bwd(B, k, U, ptr(dy), ptr(dP), ptr(dQ), current_stream())
+
+
+def pair_mean_fwd(y, base, out, B, kk, U):
+    call.d2p_pair_mean_fwd(B, kk, U, ptr(y), ptr(base), ptr(out), current_stream())
+
+
+def pair_mean_bwd(dout, dy, B, kk, U):
+    call.d2p_pair_mean_bwd(B, kk, U, ptr(dout), ptr(dy), current_stream())
+
+
+def axpy(a, x, y, accumulate=True, n=None):
+    if n is None:
+        n = x.numel()
+    call.d2p_axpy(n, a, ptr(x), ptr(y), 1 if accumulate else 0, current_stream())
+
+
+def transpose_rt(x, R, T, C, out=None):
+    if out is None:
+        out = torch.empty(T, R, C, dtype=torch.float32, device=x.device)
+    call.d2p_transpose_rt(R, T, C, ptr(x), ptr(out), current_stream())
+    return out
+
+
+# ---------------------------------------------------------------- optimizer
+def l2norm_flat(g, prescale, sumsq):
+    ws, wsb = SCRATCH.get(call.d2p_l2norm_ws_bytes(g.numel()))
+    call.d2p_l2norm_flat(g.numel(), ptr(g), prescale, ptr(sumsq), ws, wsb, current_stream())
+
+
+def adam_clip_flat(p, g, m, v, sumsq, prescale, clip, lr_t, b1=0.9, b2=0.999, eps=1e-8):
+    call.d2p_adam_clip_flat(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(sumsq), prescale, clip,
+                            lr_t, b1, b2, eps, current_stream())

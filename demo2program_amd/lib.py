@@ -61,6 +61,9 @@ SIGNATURES = {
     'd2p_zero_past_group_steps': (c_int, [c_int, c_int, c_int, c_int, P, P, S]),
     'd2p_l2norm_ws_bytes': (c_size_t, [c_size_t]),
     'd2p_l2norm_flat': (c_int, [c_size_t, P, c_float, P, P, c_size_t, S]),
+    'd2p_prof_enable': (c_int, [c_int]),
+    'd2p_prof_set_tag': (c_int, [c_int]),
+    'd2p_prof_read': (c_int, [c_int, P, P, P]),
     'd2p_adam_clip_flat': (c_int, [c_size_t, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, S]),
 }
 

@@ -1,0 +1,492 @@
+"""Full model (demonstration encoder -> summarizer -> program / action / perception decoders)
+on MI355X, behind the reference's ``Model`` surface.
+
+Mirrors ``models/model_full.py:22-1132`` of shaohua0116/demo2program: same constructor,
+``get_feed_dict(batch_chunk)``, ``loss``, ``output``, ``pred_program`` ... attributes.  The
+TF-1.3 graph is replaced by explicit ``forward`` / ``backward`` schedules of calls into
+libd2p_hip.so (include/d2p.h).  PyTorch provides device memory, the stream and views only.
+
+What is batched differently from the reference (results are identical):
+  * the reference builds k copies of the Demo encoder, SecondPath encoder and the action /
+    perception decoders, one per demonstration index (:373-398, :530-599).  Here all
+    M = B*k sequences run as one batch; per-index batch-norm statistics are kept
+    by the grouped BN kernel (group = demonstration index), per-index loss normalisation by
+    the grouped cross-entropy kernels.
+  * the LSTM input projections x·Wx + b are hoisted out of the recurrence (one GEMM over all
+    steps); only h·Wh + gates run per step.
+  * rn_pool's first layer is factorised, fc1([f_c || f_a]) = f_c·W1[:U] + f_a·W1[U:], so the
+    [B*k*k, 2U] pair matrix (:335-341) is never materialised.
+Row order everywhere: sequences m = b*k + i; recurrent tensors are time-major [T, M, *].
+"""
+import numpy as np
+import torch
+
+from .. import kernels as K
+from ..config import conv_shapes, feature_dim, n_conv
+from ..params import FlatParams
+
+
+class Model(object):
+
+    def __init__(self, config, debug_information=False, is_train=True, global_step=None,
+                 params=None, seed=123):
+        self.debug = debug_information
+        self.global_step = global_step
+        self.config = config
+        self.is_train = is_train
+        self.dataset_type = config.dataset_type
+        self.scheduled_sampling = getattr(config, 'scheduled_sampling', False) or False
+        self.scheduled_sampling_decay_steps = \
+            getattr(config, 'scheduled_sampling_decay_steps', 5000) or 5000
+        self.batch_size = config.batch_size
+        self.encoder_rnn_type = config.encoder_rnn_type
+        self.num_lstm_cell_units = config.num_lstm_cell_units
+        self.demo_aggregation = config.demo_aggregation    # parsed, ignored (as the reference)
+        self.dim_program_token = config.dim_program_token
+        self.max_program_len = config.max_program_len
+        self.max_demo_len = config.max_demo_len
+        self.max_action_len = self.max_demo_len
+        self.k = config.k
+        self.test_k = getattr(config, 'test_k', 5)
+        self.h, self.w, self.depth = config.h, config.w, config.depth
+        self.action_space = config.action_space
+        self.per_dim = config.per_dim
+
+        if self.scheduled_sampling:
+            if global_step is None:
+                raise ValueError('scheduled sampling requires global_step')   # model_full.py:59-61
+            raise NotImplementedError(
+                'scheduled sampling (models/model_full.py:414-423) is not on the parity path '
+                '(categorical sampling; SURVEY F13) and is not built yet')
+        if self.encoder_rnn_type != 'lstm':
+            # the reference reads cell_state.h/.c (models/model_full.py:258), which only an
+            # LSTMStateTuple has: 'rnn' / 'gru' cannot work there either
+            raise ValueError('Unknown encoder rnn type')
+        if not is_train:
+            raise NotImplementedError('is_train=False (moving-average BN, evaler.py:61) is not built yet')
+        if not torch.cuda.is_available():
+            raise RuntimeError('demo2program_amd.Model needs an MI355X (torch.cuda unavailable); '
+                               'there is no CPU fallback')
+
+        self.params = FlatParams(config, values=params, seed=seed)
+        self._bufs = {}
+        self._feed = None
+        self._ctx = None
+        self._conv = conv_shapes(config)
+        self.feature_dim = feature_dim(config)
+        # non-trainable BN moving statistics (updated inline, once per reference call)
+        self.moving = {}
+        for l, (_, _, _, cout, _, _) in enumerate(self._conv, start=1):
+            self._init_moving('conv%d' % l, cout)
+        U = self.num_lstm_cell_units
+        for s in ('rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2', 'per/fc'):
+            self._init_moving(s, U)
+        self.track_moving = True
+        self._reserve_scratch()
+
+    # ------------------------------------------------------------------ plumbing
+    def _init_moving(self, name, C):
+        self.moving[name] = (torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'))
+
+    def _buf(self, name, shape, dtype=torch.float32, zero=False):
+        t = self._bufs.get(name)
+        shape = tuple(int(s) for s in shape)
+        if t is None or tuple(t.shape) != shape or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device='cuda')
+            self._bufs[name] = t
+        return t
+
+    def _reserve_scratch(self):
+        from ..lib import call
+        c = self.config
+        B, k, T, U = c.batch_size, c.k, c.max_demo_len, c.num_lstm_cell_units
+        M = B * k
+        need = [call.d2p_lstm_ws_bytes(M, U), call.d2p_xent_ws_bytes(k),
+                call.d2p_l2norm_ws_bytes(self.params.size),
+                call.d2p_bn_ws_bytes(B * k * k, U, 1), call.d2p_bn_ws_bytes(T * M, U, k),
+                call.d2p_colsum_ws_bytes(T * M, 4 * U)]
+        for (h, w, cin, cout, ho, wo) in self._conv:
+            need.append(call.d2p_conv_ws_bytes(M * T, h, w, cin, cout))
+            need.append(call.d2p_bn_ws_bytes(M * T * ho * wo, cout, k))
+        K.SCRATCH.reserve(max(need))
+
+    # ------------------------------------------------------------------ feed
+    def get_feed_dict(self, batch_chunk, step=None, is_training=True):
+        """batch_chunk (numpy arrays or torch tensors, keys of models/model_full.py:185-206)
+        -> device-resident feed.  Lengths arrive as float32 and are cast to int32 exactly as the
+        reference does (:155-171).  test_* / init_pos* entries are only read by metric
+        py_funcs in the reference and stay on the host."""
+        c = self.config
+        B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len
+
+        def dev(x, dtype):
+            t = torch.as_tensor(x) if not torch.is_tensor(x) else x
+            if t.dtype != dtype:
+                t = t.to(dtype)
+            return t.to('cuda', non_blocking=True).contiguous()
+
+        def host_np(x):
+            return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+        s_h = batch_chunk['s_h']
+        s_dtype = torch.uint8 if getattr(s_h, 'dtype', None) in (np.uint8, torch.uint8) else torch.float32
+        feed = {
+            's_h': dev(s_h, s_dtype).view(B * k * T, c.h, c.w, c.depth),
+            'program': dev(batch_chunk['program'], torch.float32),
+            'program_tokens': dev(batch_chunk['program_tokens'], torch.int32),
+            'a_h': dev(batch_chunk['a_h'], torch.float32),
+            'a_h_tokens': dev(batch_chunk['a_h_tokens'], torch.int32).view(B * k, T),
+            'per': dev(batch_chunk['per'], torch.float32),
+        }
+        plen = host_np(batch_chunk['program_len']).astype(np.int32).reshape(B)
+        dlen = host_np(batch_chunk['demo_len']).astype(np.int32).reshape(B * k)
+        feed['program_len'] = dev(plen, torch.int32)
+        feed['demo_len'] = dev(dlen, torch.int32)
+        # dynamic_decode runs until the longest sequence of the batch
+        feed['n_prog'] = int(min(int(plen.max()) if B else 0, L))
+        feed['n_demo'] = int(min(int(dlen.max()) if B * k else 0, T))
+        feed['id'] = batch_chunk.get('id') if hasattr(batch_chunk, 'get') else None
+        feed['host'] = {n: batch_chunk[n] for n in ('test_s_h', 'test_demo_len', 'test_per')
+                        if n in batch_chunk}
+        return feed
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, feed):
+        c, p = self.config, self.params.p
+        B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len
+        U, V, A, P = c.num_lstm_cell_units, c.dim_program_token, c.action_space, c.per_dim
+        M, NF, F = B * k, B * k * T, self.feature_dim
+        ctx = {'feed': feed}
+        lens_d, lens_p = feed['demo_len'], feed['program_len']
+        n_p, n_d = feed['n_prog'], feed['n_demo']
+
+        # ---- State_Encoder: conv -> +bias -> lrelu -> BN(train), per demo-index statistics
+        x = feed['s_h']
+        ctx['conv'] = []
+        for l, (h, w, cin, cout, ho, wo) in enumerate(self._conv, start=1):
+            a = K.conv_fwd(x, p['conv%d/W' % l], p['conv%d/b' % l], act=1,
+                           out=self._buf('conv%d/a' % l, (NF, ho, wo, cout)))
+            y, mean, rstd = self._bn_fwd('conv%d' % l, a.view(NF * ho * wo, cout),
+                                         p['conv%d/gamma' % l], p['conv%d/beta' % l], k, T * ho * wo)
+            ctx['conv'].append((x, a, mean, rstd))
+            x = y.view(NF, ho, wo, cout)
+        feats = x.view(M, T, F)
+        feats_tm = K.transpose_rt(feats, M, T, F, out=self._buf('feats_tm', (T, M, F)))
+
+        # ---- Demo_Encoder LSTM (zero initial state, length-masked)
+        e1 = self._lstm_fwd('demo_lstm', feats_tm.view(T * M, F), F, M, T, T, None, None, lens_d,
+                            want_final=True)
+        # ---- summary = mean over k; broadcast as SecondPath initial state
+        sum_h, h0_2 = self._buf('sum_h', (B, U)), self._buf('h0_2', (M, U))
+        sum_c, c0_2 = self._buf('sum_c', (B, U)), self._buf('c0_2', (M, U))
+        K.group_mean(e1['h_final'], B, k, U, sum_h, h0_2)
+        K.group_mean(e1['c_final'], B, k, U, sum_c, c0_2)
+        # ---- SecondPathEncoder over the step-1 outputs (zeros past len)
+        e2 = self._lstm_fwd('second_lstm', e1['hout'].view(T * M, U), U, M, T, T, h0_2, c0_2, lens_d,
+                            want_final=True)
+        demo_h, demo_c = e2['h_final'], e2['c_final']
+        # ---- SummarizeFeature('rn') = mean_k + rn_pool
+        rn_h = self._rn_fwd('rn_h', demo_h, B, k, U)
+        rn_c = self._rn_fwd('rn_c', demo_c, B, k, U)
+
+        # ---- Program decoder (teacher forcing; <s> = out-of-range id -> zero vector)
+        ids_p = K.shift_tokens_tm(feed['program_tokens'], V + 1, out=self._buf('ids_p', (L, B), torch.int32))
+        emb_p = K.embedding_gather(ids_p, p['prog/embedding'], out=self._buf('emb_p', (L * B, U)), n=n_p * B)
+        dp = self._decoder_fwd('prog', emb_p, U, B, L, n_p, rn_h['out'], rn_c['out'], V)
+        # ---- Action decoders (all k in one batch)
+        ids_a = K.shift_tokens_tm(feed['a_h_tokens'], A + 1, out=self._buf('ids_a', (T, M), torch.int32))
+        emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)), n=n_d * M)
+        da = self._decoder_fwd('act', emb_a, U, M, T, n_d, demo_h, demo_c, A)
+        # ---- Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
+        per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
+        pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
+                           bias=p['per/fc/b'], act=0)
+        pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
+        dq = self._decoder_fwd('per', pe, U, M, T, n_d, demo_h, demo_c, P)
+
+        # ---- losses: program + mean_k action + mean_k perception, each mask-count normalised
+        nums = self._buf('loss_nums', (1 + 2 * k,))
+        dens = self._buf('loss_dens', (1 + 2 * k,))
+        K.xent_fwd('softmax', dp['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
+                   nums[0:1], dens[0:1])
+        K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                   nums[1:1 + k], dens[1:1 + k])
+        K.xent_fwd('sigmoid', dq['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                   nums[1 + k:], dens[1 + k:])
+        loss = self._buf('loss', (1,))
+        terms = self._buf('loss_terms', (3,))
+        K.loss_assemble([1, k, k], nums, dens, loss, terms)
+
+        ctx.update(e1=e1, e2=e2, rn_h=rn_h, rn_c=rn_c, dp=dp, da=da, dq=dq, feats_tm=feats_tm,
+                   ids_p=ids_p, ids_a=ids_a, emb_p=emb_p, emb_a=emb_a, per_tm=per_tm, pe_a=pe_a,
+                   pe=pe, pe_mean=pe_mean, pe_rstd=pe_rstd, dens=dens, h0_2=h0_2, c0_2=c0_2,
+                   demo_h=demo_h, demo_c=demo_c)
+        self._ctx = ctx
+        self._feed = feed
+        self._loss, self._terms = loss, terms
+        return loss
+
+    def _bn_fwd(self, name, x2d, gamma, beta, G, inner):
+        R, C = x2d.shape
+        y = self._buf(name + '/bn_y', (R, C))
+        mean = self._buf(name + '/bn_mean', (G, C))
+        rstd = self._buf(name + '/bn_rstd', (G, C))
+        var = self._buf(name + '/bn_var', (G, C)) if self.track_moving else None
+        K.bn_fwd(x2d, gamma, beta, G, inner, y=y, mean=mean, rstd=rstd, var=var)
+        if self.track_moving:
+            mm, mv = self.moving[name]
+            K.bn_update_moving(mean, var, mm, mv)       # G sequential updates
+        return y, mean, rstd
+
+    def _lstm_fwd(self, name, x2d, I, M, T, n_steps, h0, c0, lens, want_final):
+        """x2d: [T*M, I] time-major inputs.  Returns saved tensors for backward."""
+        p = self.params.p
+        U = self.num_lstm_cell_units
+        kernel, bias = p[name + '/kernel'], p[name + '/bias']
+        Wx, Wh = kernel[:I], kernel[I:]
+        z = self._buf(name + '/z', (T * M, 4 * U))
+        if n_steps > 0:
+            K.gemm_raw('nn', n_steps * M, 4 * U, I, x2d, x2d.stride(0), Wx, 4 * U, z, 4 * U, bias=bias)
+        hout = self._buf(name + '/hout', (T, M, U))
+        cs = self._buf(name + '/cs', (T, M, U))
+        hf = self._buf(name + '/h_final', (M, U)) if want_final else None
+        cf = self._buf(name + '/c_final', (M, U)) if want_final else None
+        K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, n_steps, Wh, h0, c0, lens, hout, cs, hf, cf)
+        return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
+                    hout=hout, cs=cs, h_final=hf, c_final=cf, Wx=Wx, Wh=Wh)
+
+    def _decoder_fwd(self, scope, x2d, I, R, T, n_steps, h0, c0, token_dim):
+        """BasicDecoder + TrainingHelper + Dense(no bias): models/model_full.py:440-490."""
+        p = self.params.p
+        U = self.num_lstm_cell_units
+        e = self._lstm_fwd(scope + '/lstm', x2d, I, R, T, n_steps, h0, c0, None, want_final=False)
+        logits = self._buf(scope + '/logits', (T, R, token_dim), zero=True)
+        if n_steps > 0:
+            K.gemm_raw('nn', n_steps * R, token_dim, U, e['hout'], U, p[scope + '/proj'], token_dim,
+                       logits, token_dim)
+        if n_steps < T:
+            logits[n_steps:].zero_()        # dynamic zero padding (:476-484); memset, no arithmetic
+        e['logits'] = logits
+        e['token_dim'] = token_dim
+        e['scope'] = scope
+        return e
+
+    def _rn_fwd(self, scope, feat, B, k, U):
+        """SummarizeFeature('rn'): mean over k + rn_pool (models/model_full.py:333-362)."""
+        p = self.params.p
+        W1, W2 = p[scope + '/fc1/W'], p[scope + '/fc2/W']
+        Pm = K.matmul_nn(feat, W1[:U], out=self._buf(scope + '/P', (B * k, U)))
+        Qm = K.matmul_nn(feat, W1[U:], out=self._buf(scope + '/Q', (B * k, U)))
+        y1a = self._buf(scope + '/y1a', (B * k * k, U))
+        K.rn_pair_fwd(Pm, Qm, p[scope + '/fc1/b'], y1a, B, k, U)
+        y1, m1, r1 = self._bn_fwd(scope + '/fc1', y1a, p[scope + '/fc1/gamma'], p[scope + '/fc1/beta'], 1, 1)
+        y2a = K.matmul_nn(y1, W2, out=self._buf(scope + '/y2a', (B * k * k, U)),
+                          bias=p[scope + '/fc2/b'], act=1)
+        y2, m2, r2 = self._bn_fwd(scope + '/fc2', y2a, p[scope + '/fc2/gamma'], p[scope + '/fc2/beta'], 1, 1)
+        base = self._buf(scope + '/base', (B, U))
+        K.group_mean(feat, B, k, U, base, None)
+        out = self._buf(scope + '/out', (B, U))
+        K.pair_mean_fwd(y2, base, out, B, k * k, U)
+        return dict(scope=scope, feat=feat, y1a=y1a, y1=y1, m1=m1, r1=r1, y2a=y2a, m2=m2, r2=r2, out=out)
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, loss_scale=1.0):
+        """Hand-written reverse schedule; writes every entry of params.grad exactly once."""
+        ctx, c, p, g = self._ctx, self.config, self.params.p, self.params.g
+        feed = ctx['feed']
+        B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len
+        U, V, A, P = c.num_lstm_cell_units, c.dim_program_token, c.action_space, c.per_dim
+        M, NF, F = B * k, B * k * T, self.feature_dim
+        lens_d, lens_p = feed['demo_len'], feed['program_len']
+        n_p, n_d = feed['n_prog'], feed['n_demo']
+        dens = ctx['dens']
+
+        # ---- losses -> dlogits (time-major, first n_steps*R rows)
+        dl_p = self._buf('prog/dlogits', (L * B, V))
+        dl_a = self._buf('act/dlogits', (T * M, A))
+        dl_q = self._buf('per/dlogits', (T * M, P))
+        K.xent_bwd('softmax', ctx['dp']['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
+                   dens[0:1], loss_scale, dl_p)
+        K.xent_bwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                   dens[1:1 + k], loss_scale, dl_a)
+        K.xent_bwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                   dens[1 + k:], loss_scale, dl_q)
+
+        d_demo_h, d_demo_c = self._buf('d_demo_h', (M, U)), self._buf('d_demo_c', (M, U))
+        tmp_h, tmp_c = self._buf('tmp_dh', (M, U)), self._buf('tmp_dc', (M, U))
+        d_rn_h, d_rn_c = self._buf('d_rn_h', (B, U)), self._buf('d_rn_c', (B, U))
+
+        # ---- program decoder: grads of embedding / lstm / proj, and of the rn summaries
+        dx_p = self._decoder_bwd(ctx['dp'], dl_p, d_rn_h, d_rn_c, want_dx=True)
+        K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
+        # ---- action decoder: initial-state grads start d_demo_{h,c}
+        dx_a = self._decoder_bwd(ctx['da'], dl_a, d_demo_h, d_demo_c, want_dx=True)
+        K.embedding_scatter_add(ctx['ids_a'], dx_a, g['act/embedding'], n=n_d * M)
+        # ---- perception decoder
+        dx_q = self._decoder_bwd(ctx['dq'], dl_q, tmp_h, tmp_c, want_dx=True)
+        K.axpy(1.0, tmp_h, d_demo_h)
+        K.axpy(1.0, tmp_c, d_demo_c)
+        if n_d < T:
+            dx_q[n_d * M:].zero_()
+        d_pe_a = K.bn_bwd(ctx['pe_a'], dx_q, p['per/fc/gamma'], ctx['pe_mean'], ctx['pe_rstd'], k, 1,
+                          False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)))
+        K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
+        K.colsum(d_pe_a, out=g['per/fc/b'])
+
+        # ---- SummarizeFeature('rn') backward (adds into d_demo_{h,c})
+        self._rn_bwd(ctx['rn_h'], d_rn_h, d_demo_h, B, k, U)
+        self._rn_bwd(ctx['rn_c'], d_rn_c, d_demo_c, B, k, U)
+
+        # ---- SecondPathEncoder backward: only the final states carry gradient
+        e2 = ctx['e2']
+        dh0_2, dc0_2 = self._buf('dh0_2', (M, U)), self._buf('dc0_2', (M, U))
+        d_hout1 = self._lstm_bwd(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2, want_dx=True)
+        # summary = mean_k(step-1 final states), broadcast to every demo of the program
+        d_h1f, d_c1f = self._buf('d_h1f', (M, U)), self._buf('d_c1f', (M, U))
+        K.group_mean_bwd(None, dh0_2, d_h1f, B, k, U, False)
+        K.group_mean_bwd(None, dc0_2, d_c1f, B, k, U, False)
+        # ---- Demo_Encoder LSTM backward
+        d_feats_tm = self._lstm_bwd(ctx['e1'], d_hout1, d_h1f, d_c1f, None, None, want_dx=True)
+        d_feats = K.transpose_rt(d_feats_tm.view(T, M, F), T, M, F, out=self._buf('d_feats', (M, T, F)))
+
+        # ---- State_Encoder backward
+        dy = d_feats
+        for l in range(len(self._conv), 0, -1):
+            (h, w, cin, cout, ho, wo) = self._conv[l - 1]
+            x_in, a, mean, rstd = ctx['conv'][l - 1]
+            da_ = K.bn_bwd(a.view(NF * ho * wo, cout), dy.view(NF * ho * wo, cout), p['conv%d/gamma' % l],
+                           mean, rstd, k, T * ho * wo, True, g['conv%d/gamma' % l], g['conv%d/beta' % l],
+                           dx=self._buf('conv%d/da' % l, (NF * ho * wo, cout)))
+            K.colsum(da_, out=g['conv%d/b' % l])
+            K.conv_wgrad(x_in, da_.view(NF, ho, wo, cout), g['conv%d/W' % l])
+            if l > 1:
+                dy = K.conv_dgrad(da_.view(NF, ho, wo, cout), p['conv%d/W' % l], (NF, h, w, cin),
+                                  dx=self._buf('conv%d/dx' % l, (NF, h, w, cin)))
+        return self.params.grad
+
+    def _lstm_bwd(self, e, dhout, dh_final, dc_final, dh0, dc0, want_dx):
+        """Backward of _lstm_fwd.  Writes the kernel / bias gradients; returns dX [n*M, I]."""
+        g = self.params.g
+        name, M, T, n, I = e['name'], e['M'], e['T'], e['n'], e['I']
+        U = self.num_lstm_cell_units
+        gk, gb = g[name + '/kernel'], g[name + '/bias']
+        dz = self._buf(name + '/dz', (T * M, 4 * U))
+        K.lstm_seq_bwd(e['z'], 4 * U, M * 4 * U, M, U, n, e['Wh'], e['c0'], e['lens'], e['cs'],
+                       dhout, dh_final, dc_final, dz, dh0, dc0)
+        rows = n * M
+        dz_n = dz[:rows] if rows > 0 else dz[:0]
+        # dWx = X^T dZ ; db = colsum(dZ)
+        K.gemm_raw('tn', I, 4 * U, rows, e['x'], e['x'].stride(0), dz_n, 4 * U, gk[:I], 4 * U)
+        K.colsum(dz_n, out=gb, rows=rows) if rows > 0 else gb.zero_()
+        # dWh = sum_t h_{t-1}^T dZ_t : h_{-1} = h0 (skipped when zero), then hout[t-1]
+        hout2d = e['hout'].view(T * M, U)
+        if e['h0'] is not None and n > 0:
+            K.gemm_raw('tn', U, 4 * U, M, e['h0'], U, dz, 4 * U, gk[I:], 4 * U)
+            if n > 1:
+                K.gemm_raw('tn', U, 4 * U, (n - 1) * M, hout2d, U, dz[M:], 4 * U, gk[I:], 4 * U,
+                           accumulate=True)
+        elif n > 1:
+            K.gemm_raw('tn', U, 4 * U, (n - 1) * M, hout2d, U, dz[M:], 4 * U, gk[I:], 4 * U)
+        else:
+            gk[I:].zero_()
+        if not want_dx:
+            return None
+        dx = self._buf(name + '/dx', (T * M, I))
+        if rows > 0:
+            K.gemm_raw('nt', rows, I, 4 * U, dz_n, 4 * U, e['Wx'], 4 * U, dx, I)
+        return dx
+
+    def _decoder_bwd(self, e, dlogits, dh0, dc0, want_dx):
+        p, g = self.params.p, self.params.g
+        scope, R, T, n, V = e['scope'], e['M'], e['T'], e['n'], e['token_dim']
+        U = self.num_lstm_cell_units
+        rows = n * R
+        hout2d = e['hout'].view(T * R, U)
+        dhout = self._buf(scope + '/dhout', (T * R, U))
+        if rows > 0:
+            K.gemm_raw('tn', U, V, rows, hout2d, U, dlogits, V, g[scope + '/proj'], V)
+            K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
+        else:
+            g[scope + '/proj'].zero_()
+        return self._lstm_bwd(e, dhout, None, None, dh0, dc0, want_dx)
+
+    def _rn_bwd(self, r, d_out, d_feat, B, k, U):
+        """d_out: [B,U] gradient of mean_k(feat) + rn_pool(feat); accumulates into d_feat [M,U]."""
+        p, g = self.params.p, self.params.g
+        s = r['scope']
+        W1, W2 = p[s + '/fc1/W'], p[s + '/fc2/W']
+        K.group_mean_bwd(d_out, None, d_feat, B, k, U, True)                 # the avg-pool branch
+        dy2 = self._buf(s + '/dy2', (B * k * k, U))
+        K.pair_mean_bwd(d_out, dy2, B, k * k, U)
+        dy2a = K.bn_bwd(r['y2a'], dy2, p[s + '/fc2/gamma'], r['m2'], r['r2'], 1, 1, True,
+                        g[s + '/fc2/gamma'], g[s + '/fc2/beta'], dx=self._buf(s + '/dy2a', (B * k * k, U)))
+        K.matmul_tn(r['y1'], dy2a, out=g[s + '/fc2/W'])
+        K.colsum(dy2a, out=g[s + '/fc2/b'])
+        dy1 = K.matmul_nt(dy2a, W2, out=self._buf(s + '/dy1', (B * k * k, U)))
+        dy1a = K.bn_bwd(r['y1a'], dy1, p[s + '/fc1/gamma'], r['m1'], r['r1'], 1, 1, True,
+                        g[s + '/fc1/gamma'], g[s + '/fc1/beta'], dx=self._buf(s + '/dy1a', (B * k * k, U)))
+        K.colsum(dy1a, out=g[s + '/fc1/b'])
+        dP, dQ = self._buf(s + '/dP', (B * k, U)), self._buf(s + '/dQ', (B * k, U))
+        K.rn_pair_bwd(dy1a, dP, dQ, B, k, U)
+        gW1 = g[s + '/fc1/W']
+        K.matmul_tn(r['feat'], dP, out=gW1[:U])
+        K.matmul_tn(r['feat'], dQ, out=gW1[U:])
+        K.matmul_nt(dP, W1[:U], out=d_feat, accumulate=True)
+        K.matmul_nt(dQ, W1[U:], out=d_feat, accumulate=True)
+
+    # ------------------------------------------------------------------ reference attributes
+    @property
+    def loss(self):
+        return self._loss
+
+    @property
+    def report_loss(self):
+        t = self._terms
+        return {'program_loss': t[0], 'avg_action_loss': t[1], 'avg_per_loss': t[2]}
+
+    @property
+    def pred_program(self):
+        """[B, dim_program_token, max_program_len] logits, zero past max(program_len)."""
+        return self._ctx['dp']['logits'].permute(1, 2, 0)
+
+    @property
+    def ground_truth_program(self):
+        return self._feed['program']
+
+    @property
+    def program_len(self):
+        return self._feed['program_len'].view(-1, 1)
+
+    def _per_demo_logits(self, e, token_dim):
+        c = self.config
+        B, k, T = c.batch_size, c.k, c.max_demo_len
+        M = B * k
+        out = e['logits'].clone()
+        K.zero_past_group_steps(out, self._feed['demo_len'], T, M, token_dim, k)   # per-call padding
+        return out.view(T, B, k, token_dim).permute(1, 2, 0, 3)                  # [B,k,T,token_dim]
+
+    @property
+    def pred_action(self):
+        """[B, k, T, action_space] (models/model_full.py:559-560)."""
+        return self._per_demo_logits(self._ctx['da'], self.action_space)
+
+    @property
+    def pred_per(self):
+        return self._per_demo_logits(self._ctx['dq'], self.per_dim)
+
+    @property
+    def output(self):
+        """[gt, pred] pairs: program, then per demo action, then per demo perception
+        (models/model_full.py:919-933,1034,1077)."""
+        f = self._feed
+        c = self.config
+        B, k, T = c.batch_size, c.k, c.max_demo_len
+        out = [f['program'], self.pred_program]
+        pa, pq = self.pred_action, self.pred_per
+        gt_a = f['a_h'].view(B, k, T, self.action_space)
+        gt_q = f['per'].view(B, k, T, self.per_dim)
+        for i in range(k):
+            out.extend([gt_a[:, i].permute(0, 2, 1), pa[:, i].permute(0, 2, 1)])
+        for i in range(k):
+            out.extend([gt_q[:, i].permute(0, 2, 1), pq[:, i].permute(0, 2, 1)])
+        return out

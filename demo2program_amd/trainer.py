@@ -1,0 +1,236 @@
+"""Training driver behind the reference's ``Trainer`` surface (trainer.py:16-240 of
+shaohua0116/demo2program): same constructor, ``train`` / ``run_single_step`` / ``run_test`` /
+``log_step_message``, the same CLI flags and log line.
+
+The TF session + queue runners are replaced by: a host batch source -> ``Model.get_feed_dict``
+(H2D) -> ``Model.forward`` / ``Model.backward`` (HIP kernels) -> optional RCCL all-reduce of
+the flat gradient buffer -> fused global-norm-clip + Adam kernel (trainer.py:102-109).
+One process per GPU; ``torch.distributed`` (backend "nccl" == RCCL) is used only for that
+all-reduce.
+"""
+import argparse
+import math
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import kernels as K
+from .config import make_config
+from .dist import DataParallel
+from .synthetic import make_batch
+
+CLIP_GRADIENTS = 20.0        # trainer.py:107
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-8   # [TF-1.3] AdamOptimizer defaults
+
+
+def learning_rate_at(config, step):
+    """trainer.py:82-93: constant, or exponential_decay(0.5 / 10000 steps, staircase)."""
+    if getattr(config, 'lr_weight_decay', False):
+        return config.learning_rate * 0.5 ** (step // 10000)
+    return config.learning_rate
+
+
+class SyntheticBatches(object):
+    """Stand-in for create_input_ops (karel_env/input_ops_karel.py:24-125) when no HDF5
+    dataset is present: an endless stream of seeded synthetic batch_chunks."""
+
+    def __init__(self, config, seed=123, n_distinct=8, rank=0):
+        self.batches = [make_batch(config, seed=seed + 7919 * rank + i) for i in range(n_distinct)]
+        self.i = 0
+
+    def next(self):
+        b = self.batches[self.i % len(self.batches)]
+        self.i += 1
+        return b
+
+
+class Trainer(object):
+
+    @staticmethod
+    def get_model_class(model_name):
+        """trainer.py:18-30.  Only the full model is on the hot path; the baselines are a
+        strict subset of its kernels and are not built."""
+        if model_name == 'full':
+            from .models.model_full import Model
+        elif model_name in ('synthesis_baseline', 'induction_baseline', 'summarizer'):
+            raise NotImplementedError('%s is outside the MI355X hot path (only --model full)' % model_name)
+        else:
+            raise ValueError(model_name)
+        return Model
+
+    def __init__(self, config, dataset=None, dataset_test=None, make_train_dir=True, dp=None):
+        self.config = config
+        hyper_parameter_str = 'bs_{}_lr_{}_{}_cell_{}'.format(
+            config.batch_size, config.learning_rate, config.encoder_rnn_type,
+            config.num_lstm_cell_units)
+        if config.scheduled_sampling:
+            hyper_parameter_str += '_sd_{}'.format(config.scheduled_sampling_decay_steps)
+        hyper_parameter_str += '_k_{}'.format(config.num_k)
+        self.train_dir = './train_dir/%s-%s-%s-%s-%s-%s' % (
+            config.dataset_type, '_'.join(config.dataset_path.split('/')), config.model,
+            config.prefix, hyper_parameter_str, time.strftime("%Y%m%d-%H%M%S"))
+        if make_train_dir and not os.path.exists(self.train_dir):
+            os.makedirs(self.train_dir)
+
+        self.batch_size = config.batch_size
+        self.dp = dp if dp is not None else DataParallel()
+        self.batch_train = dataset if dataset is not None else SyntheticBatches(config, 123, rank=self.dp.rank)
+        self.batch_test = dataset_test if dataset_test is not None else SyntheticBatches(config, 321, 2, rank=self.dp.rank)
+
+        self.global_step = 0
+        Model = self.get_model_class(config.model)
+        self.model = Model(config, debug_information=config.debug, global_step=self.global_step)
+        self.dp.broadcast_params(self.model.params.flat)
+
+        self.log_step = config.log_step
+        self.test_sample_step = config.test_sample_step
+        self.write_summary_step = config.write_summary_step
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device='cuda')
+
+        if config.checkpoint is not None:
+            self.load_checkpoint(config.checkpoint)
+
+    # ------------------------------------------------------------------ one optimizer step
+    def train_step(self, feed):
+        """forward + backward + (all-reduce) + clip + Adam on a device-resident feed.
+        Asynchronous: returns the device loss tensor without synchronising."""
+        m = self.model
+        loss = m.forward(feed)
+        m.backward()
+        P = m.params
+        self.dp.all_reduce_grads(P.grad)            # SUM over ranks; mean folded into prescale
+        pre = self.dp.prescale
+        K.l2norm_flat(P.grad, pre, self._sumsq)
+        t = self.global_step + 1
+        lr = learning_rate_at(self.config, self.global_step)
+        lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+        K.adam_clip_flat(P.flat, P.grad, P.m, P.v, self._sumsq, pre, CLIP_GRADIENTS, lr_t,
+                         ADAM_B1, ADAM_B2, ADAM_EPS)
+        self.global_step = t
+        return loss
+
+    def run_single_step(self, batch, step=None, is_train=True):
+        """trainer.py:186-205: step_time spans batch fetch + feed + run."""
+        _start_time = time.time()
+        batch_chunk = batch.next()
+        feed = self.model.get_feed_dict(batch_chunk, step=step, is_training=is_train)
+        loss = self.train_step(feed)
+        loss_value = float(loss.item())             # the reference fetches the loss every step
+        _end_time = time.time()
+        return self.global_step, None, loss_value, None, (_end_time - _start_time)
+
+    def run_test(self, batch):
+        """trainer.py:207-225: the training-mode graph on a test batch, no update."""
+        _start_time = time.time()
+        batch_chunk = batch.next()
+        feed = self.model.get_feed_dict(batch_chunk, is_training=False)
+        track = self.model.track_moving
+        self.model.track_moving = False
+        loss = self.model.forward(feed)
+        self.model.track_moving = track
+        loss_value = float(loss.item())
+        _end_time = time.time()
+        return self.global_step, None, loss_value, None, (_end_time - _start_time)
+
+    def train(self, max_steps=1000000):
+        ckpt_save_step = 1000
+        for s in range(max_steps):
+            step, train_summary, loss, output, step_time = \
+                self.run_single_step(self.batch_train, step=s, is_train=True)
+            if s % self.log_step == 0:
+                self.log_step_message(step, loss, step_time)
+            if s % self.test_sample_step == 0:
+                test_step, _, test_loss, _, test_step_time = self.run_test(self.batch_test)
+                self.log_step_message(step, test_loss, test_step_time, is_train=False)
+            if s % ckpt_save_step == 0 and self.dp.rank == 0:
+                self.save_checkpoint(os.path.join(self.train_dir, 'model-%d.npz' % step))
+
+    def log_step_message(self, step, loss, step_time, is_train=True):
+        """The reference's log line, verbatim (trainer.py:227-240)."""
+        if step_time == 0:
+            step_time = 0.001
+        if self.dp.rank != 0:
+            return
+        print((" [{split_mode:5s} step {step:4d}] " +
+               "Loss: {loss:.5f} " +
+               "({sec_per_batch:.3f} sec/batch, {instance_per_sec:.3f} " +
+               "instances/sec) "
+               ).format(split_mode=(is_train and 'train' or 'val'),
+                        step=step, loss=loss, sec_per_batch=step_time,
+                        instance_per_sec=self.batch_size * self.dp.world_size / step_time))
+
+    # ------------------------------------------------------------------ checkpoints (own format)
+    def save_checkpoint(self, path):
+        P = self.model.params
+        blob = {'p/' + n: v for n, v in P.to_numpy('p').items()}
+        blob.update({'m/' + n: v for n, v in P.to_numpy('m').items()})
+        blob.update({'v/' + n: v for n, v in P.to_numpy('v').items()})
+        for n, (mm, mv) in self.model.moving.items():
+            blob['moving_mean/' + n] = mm.cpu().numpy()
+            blob['moving_var/' + n] = mv.cpu().numpy()
+        blob['global_step'] = np.asarray(self.global_step)
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        np.savez(path, **blob)
+
+    def load_checkpoint(self, path):
+        z = np.load(path)
+        P = self.model.params
+        P.load({n: z['p/' + n] for n in P.shapes})
+        if 'm/' + next(iter(P.shapes)) in z:
+            for which, buf in (('m', P.m), ('v', P.v)):
+                host = np.zeros(P.size, np.float32)
+                for n in P.shapes:
+                    a = z[which + '/' + n].reshape(-1)
+                    host[P.offsets[n]:P.offsets[n] + a.size] = a
+                buf.copy_(torch.from_numpy(host))
+        for n in self.model.moving:
+            if 'moving_mean/' + n in z:
+                self.model.moving[n][0].copy_(torch.from_numpy(z['moving_mean/' + n]))
+                self.model.moving[n][1].copy_(torch.from_numpy(z['moving_var/' + n]))
+        if 'global_step' in z:
+            self.global_step = int(z['global_step'])
+
+
+def build_arg_parser():
+    """The reference's flags and defaults, verbatim (trainer.py:245-289), plus build-only
+    --max_steps / --synthetic (trainer.py:153 hard-codes 1000000 steps)."""
+    parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    parser.add_argument('--debug', action='store_true', default=False)
+    parser.add_argument('--prefix', type=str, default='default')
+    parser.add_argument('--model', type=str, default='full',
+                        choices=['synthesis_baseline', 'induction_baseline', 'summarizer', 'full'])
+    parser.add_argument('--dataset_type', type=str, default='karel', choices=['karel', 'vizdoom'])
+    parser.add_argument('--dataset_path', type=str, default='datasets/karel_dataset')
+    parser.add_argument('--checkpoint', type=str, default=None)
+    parser.add_argument('--log_step', type=int, default=10)
+    parser.add_argument('--write_summary_step', type=int, default=100)
+    parser.add_argument('--test_sample_step', type=int, default=100)
+    parser.add_argument('--num_k', type=int, default=10)
+    parser.add_argument('--batch_size', type=int, default=32)
+    parser.add_argument('--learning_rate', type=float, default=0.001)
+    parser.add_argument('--lr_weight_decay', action='store_true', default=False)
+    parser.add_argument('--scheduled_sampling', action='store_true', default=False)
+    parser.add_argument('--scheduled_sampling_decay_steps', type=int, default=20000)
+    parser.add_argument('--encoder_rnn_type', default='lstm', choices=['lstm', 'rnn', 'gru'])
+    parser.add_argument('--num_lstm_cell_units', type=int, default=512)
+    parser.add_argument('--demo_aggregation', type=str, default='avgpool',
+                        choices=['concat', 'avgpool', 'maxpool'])
+    parser.add_argument('--max_steps', type=int, default=1000000, help='(build-only)')
+    return parser
+
+
+def main(argv=None):
+    args = build_arg_parser().parse_args(argv)
+    preset = 'karel' if args.dataset_type == 'karel' else 'vizdoom'
+    flags = {k: v for k, v in vars(args).items() if k != 'max_steps'}
+    flags['k'] = args.num_k
+    config = make_config(preset, **flags)
+    dp = DataParallel.from_env()
+    trainer = Trainer(config, dp=dp)
+    trainer.train(max_steps=args.max_steps)
+
+
+if __name__ == '__main__':
+    main()

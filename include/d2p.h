@@ -242,6 +242,18 @@ int d2p_adam_clip_flat(size_t n, float* p, const float* g, float* m, float* v,
                        const double* sumsq, float prescale, float clip, float lr_t,
                        float beta1, float beta2, float eps, d2p_stream_t stream);
 
+/* ---- optional per-launch HIP-event timing (used by bench.py's roofline leg) -------------
+ * When enabled, every GEMM / conv / LSTM-gate launch is bracketed by hipEvents recorded on
+ * the launch stream.  key = family*8 + tag; families: 1 dense GEMM (work = FLOP),
+ * 2 conv (FLOP), 3 LSTM gate fwd (algorithmic bytes), 4 LSTM gate bwd (bytes);
+ * tag 1 = launched from inside the recurrence (d2p_lstm_seq_*), 0 otherwise.
+ * d2p_prof_enable(on) clears all records.  d2p_prof_read synchronises on the recorded
+ * events and returns launch count, summed milliseconds and summed work for one key
+ * (HOST pointers).  Not hipGraph-capturable; off by default. */
+int d2p_prof_enable(int on);
+int d2p_prof_set_tag(int tag);
+int d2p_prof_read(int key, int* count, double* total_ms, double* total_work);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,55 @@
+"""Shared helpers for the parity tests: build matching (product config, oracle config,
+params, batch) tuples."""
+import numpy as np
+import torch
+
+import oracle
+from demo2program_amd.config import make_config
+from demo2program_amd.params import init_params
+from demo2program_amd.synthetic import make_batch, to_torch
+
+
+def oracle_config(cfg):
+    return oracle.OracleConfig(
+        batch_size=cfg.batch_size, k=cfg.k, max_demo_len=cfg.max_demo_len,
+        max_program_len=cfg.max_program_len, h=cfg.h, w=cfg.w, depth=cfg.depth,
+        dim_program_token=cfg.dim_program_token, action_space=cfg.action_space,
+        per_dim=cfg.per_dim, num_lstm_cell_units=cfg.num_lstm_cell_units,
+        dataset_type=cfg.dataset_type)
+
+
+def perturbed_params(cfg, seed):
+    """Initialiser values with the zero biases / unit gammas replaced by random ones, so
+    that every parameter's role is exercised by the parity check."""
+    p = init_params(cfg, seed)
+    rs = np.random.RandomState(seed + 1)
+    for n in p:
+        leaf = n.split('/')[-1]
+        if leaf in ('b', 'bias', 'beta'):
+            p[n] = rs.uniform(-0.1, 0.1, p[n].shape).astype(np.float32)
+        elif leaf == 'gamma':
+            p[n] = rs.uniform(0.5, 1.5, p[n].shape).astype(np.float32)
+        elif leaf == 'embedding':
+            p[n] = rs.uniform(-0.5, 0.5, p[n].shape).astype(np.float32)
+    return p
+
+
+def small_case(kind='karel', seed=7, **over):
+    if kind == 'karel':
+        base = dict(batch_size=3, k=3, max_demo_len=6, max_program_len=9, num_lstm_cell_units=64)
+        base.update(over)
+        cfg = make_config('karel', **base)
+    else:
+        base = dict(batch_size=2, k=3, max_demo_len=5, max_program_len=8, num_lstm_cell_units=64,
+                    h=20, w=20)
+        base.update(over)
+        cfg = make_config('vizdoom', **base)
+    params = perturbed_params(cfg, seed)
+    batch = make_batch(cfg, seed=seed)
+    return cfg, params, batch
+
+
+def run_oracle(cfg, params, batch, dtype=torch.float64):
+    tb = to_torch(batch)
+    tp = {n: torch.from_numpy(v) for n, v in params.items()}
+    return oracle.loss_and_grads(tp, tb, oracle_config(cfg), dtype=dtype)

@@ -1,0 +1,451 @@
+"""Per-kernel parity: every C-ABI entry point (called through ctypes on a real MI355X) against
+the CPU oracle / fp64 torch-CPU restatements of the same TF-1.3 semantics."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    assert torch.cuda.is_available(), 'GPU tests need a real MI355X (run through gpurun)'
+    from demo2program_amd import build, kernels
+    build.build_library()
+    return kernels
+
+
+def dev(t, dtype=torch.float32):
+    return t.to(dtype).cuda().contiguous()
+
+
+def close(a, b, atol=1e-4, rtol=1e-4):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    tol = atol + rtol * b.abs().max().item() if b.numel() else atol
+    assert err <= tol, 'max abs err %.3e > tol %.3e' % (err, tol)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('M,N,K_', [(64, 64, 16), (70, 50, 37), (320, 2048, 512), (6400, 6, 512),
+                                    (33, 512, 5), (1, 1, 1), (130, 260, 1030), (144, 16, 20480),
+                                    (1024, 1024, 64)])
+def test_gemm_nn_nt_tn(K, M, N, K_):
+    A = rnd(M, K_, seed=1)
+    B = rnd(K_, N, seed=2)
+    ref = A @ B
+    tol = dict(atol=2e-6 * K_ + 1e-5, rtol=1e-5)
+    close(K.matmul_nn(dev(A), dev(B)), ref, **tol)
+    close(K.matmul_nt(dev(A), dev(B.t().contiguous())), ref, **tol)
+    close(K.matmul_tn(dev(A.t().contiguous()), dev(B)), ref, **tol)
+
+
+def test_gemm_epilogue_bias_lrelu_accumulate_and_strides(K):
+    M, N, K_ = 100, 72, 48
+    A, B, bias, C0 = rnd(M, K_, seed=3), rnd(K_, N, seed=4), rnd(N, seed=5), rnd(M, N, seed=6)
+    out = K.matmul_nn(dev(A), dev(B), bias=dev(bias), act=1)
+    close(out, oracle.lrelu(A @ B + bias), atol=1e-4)
+    c = dev(C0)
+    K.matmul_nn(dev(A), dev(B), out=c, accumulate=True)
+    close(c, A @ B + C0, atol=1e-4)
+    # strided C and A (LSTM layout: rows with stride T*4U, offset t*4U)
+    big = torch.zeros(M, 3 * N, device='cuda')
+    view = big[:, N:2 * N]
+    K.gemm_raw('nn', M, N, K_, dev(A), K_, dev(B), N, view.data_ptr(), 3 * N)
+    close(big[:, N:2 * N], A @ B, atol=1e-4)
+    assert big[:, :N].abs().max().item() == 0 and big[:, 2 * N:].abs().max().item() == 0
+
+
+def test_gemm_is_transpose_detecting(K):
+    # A = I with an asymmetric B catches a swapped C layout (cdna guide §3)
+    n = 96
+    B = torch.arange(n * n, dtype=torch.float64).reshape(n, n)
+    close(K.matmul_nn(dev(torch.eye(n, dtype=torch.float64)), dev(B)), B, atol=0, rtol=0)
+
+
+def test_colsum(K):
+    X = rnd(777, 130, seed=7)
+    close(K.colsum(dev(X)), X.sum(0), atol=1e-4)
+
+
+# ------------------------------------------------------------------ conv
+def _conv_ref(x, w, b):
+    N, H, W, C = x.shape
+    pt, pb = oracle.same_pad_s2k3(H)
+    pl, pr = oracle.same_pad_s2k3(W)
+    xn = F.pad(x.permute(0, 3, 1, 2), (pl, pr, pt, pb))
+    y = F.conv2d(xn, w.permute(3, 2, 0, 1), bias=b, stride=2)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(40, 8, 8, 16, 16), (40, 4, 4, 16, 32), (40, 2, 2, 32, 48),
+                                            (6, 80, 80, 3, 16), (7, 5, 5, 48, 48), (9, 3, 3, 48, 48),
+                                            (3, 10, 10, 48, 48), (5, 7, 9, 4, 8)])
+def test_conv_fwd_dgrad_wgrad(K, N, H, W, Cin, Cout):
+    x = rnd(N, H, W, Cin, seed=1).requires_grad_(True)
+    w = rnd(3, 3, Cin, Cout, seed=2, scale=0.3).requires_grad_(True)
+    b = rnd(Cout, seed=3)
+    y = _conv_ref(x, w, b)
+    dy = rnd(*y.shape, seed=4)
+    y.backward(dy)
+    out = K.conv_fwd(dev(x), dev(w), dev(b), act=0)
+    close(out, y, atol=1e-4)
+    close(K.conv_fwd(dev(x), dev(w), dev(b), act=1), oracle.lrelu(y), atol=1e-4)
+    dw = torch.empty(3, 3, Cin, Cout, device='cuda')
+    K.conv_wgrad(dev(x), dev(dy), dw)
+    close(dw, w.grad, atol=1e-5 * N * H * W + 1e-4, rtol=1e-5)
+    if Cout % 4 == 0:
+        close(K.conv_dgrad(dev(dy), dev(w), (N, H, W, Cin)), x.grad, atol=1e-4)
+
+
+def test_conv_same_padding_is_asymmetric(K):
+    # 4x4 ramp, all-ones kernel -> (0,1) padding, not (1,1)
+    x = torch.arange(16, dtype=torch.float64).reshape(1, 4, 4, 1)
+    w = torch.ones(3, 3, 1, 1, dtype=torch.float64)
+    out = K.conv_fwd(dev(x), dev(w), dev(torch.zeros(1)), act=0).cpu().reshape(2, 2)
+    # top-left window covers rows 0..2, cols 0..2 of the unpadded image
+    assert out[0, 0].item() == float(x[0, 0:3, 0:3, 0].sum())
+    assert out[1, 1].item() == float(x[0, 2:4, 2:4, 0].sum())
+
+
+def test_conv_uint8_input(K):
+    g = torch.Generator().manual_seed(0)
+    xu = torch.randint(0, 256, (4, 80, 80, 3), generator=g, dtype=torch.uint8)
+    w = rnd(3, 3, 3, 16, seed=2, scale=0.05)
+    b = rnd(16, seed=3)
+    ref = _conv_ref(xu.double(), w, b)
+    out = K.conv_fwd(xu.cuda(), dev(w), dev(b), act=0)
+    close(out, ref, atol=2e-3, rtol=1e-5)
+    dy = rnd(*ref.shape, seed=5)
+    dw = torch.empty(3, 3, 3, 16, device='cuda')
+    K.conv_wgrad(xu.cuda(), dev(dy), dw)
+    dwf = torch.empty(3, 3, 3, 16, device='cuda')
+    K.conv_wgrad(dev(xu.double()), dev(dy), dwf)
+    close(dw, dwf, atol=1e-2, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ batch norm
+@pytest.mark.parametrize('B,k,inner,C,act', [(3, 4, 20, 16, True), (2, 10, 8, 48, True),
+                                             (5, 1, 7, 512, True), (4, 3, 1, 512, False)])
+def test_bn_group_fwd_bwd(K, B, k, inner, C, act):
+    R = B * k * inner
+    x = rnd(R, C, seed=1, scale=3.0)
+    x[0, :] = 0.0                                    # exercises lrelu'(0) = 0.6
+    pre = x.clone().requires_grad_(True)             # pre-activation
+    gamma = (rnd(C, seed=2) + 1.5).requires_grad_(True)
+    beta = rnd(C, seed=3).requires_grad_(True)
+    a = oracle.lrelu(pre) if act else pre
+    a4 = a.reshape(B, k, inner, C)
+    ys, means, vars_ = [], [], []
+    for i in range(k):                               # one BN call per demo index
+        y, m, v = oracle.batch_norm_train(a4[:, i], beta, gamma)
+        ys.append(y); means.append(m); vars_.append(v)
+    yref = torch.stack(ys, dim=1).reshape(R, C)
+    dy = rnd(R, C, seed=4)
+    yref.backward(dy)
+    a_dev = dev(a)
+    var = torch.empty(k, C, device='cuda')
+    y, mean, rstd, var = K.bn_fwd(a_dev, dev(gamma), dev(beta), k, inner, var=var)
+    close(y, yref, atol=1e-4)
+    close(mean, torch.stack(means), atol=1e-5)
+    close(var, torch.stack(vars_), atol=1e-5)
+    dgamma = torch.empty(C, device='cuda')
+    dbeta = torch.empty(C, device='cuda')
+    dx = K.bn_bwd(a_dev, dev(dy), dev(gamma), mean, rstd, k, inner, act, dgamma, dbeta)
+    close(dx, pre.grad, atol=1e-4)
+    close(dgamma, gamma.grad, atol=1e-3, rtol=1e-4)
+    close(dbeta, beta.grad, atol=1e-3, rtol=1e-4)
+
+
+def test_bn_moving_average_k_updates(K):
+    mean, var = rnd(5, 8, seed=1), rnd(5, 8, seed=2).abs()
+    mm, mv = torch.zeros(8, dtype=torch.float64), torch.ones(8, dtype=torch.float64)
+    mmd, mvd = dev(mm), dev(mv)
+    K.bn_update_moving(dev(mean), dev(var), mmd, mvd)
+    for g in range(5):
+        mm = 0.9 * mm + 0.1 * mean[g]
+        mv = 0.9 * mv + 0.1 * var[g]
+    close(mmd, mm, atol=1e-6)
+    close(mvd, mv, atol=1e-6)
+
+
+# ------------------------------------------------------------------ LSTM
+def _lstm_case(K, M, T, I, U, masked, with_init, strided):
+    x = rnd(M, T, I, seed=1).requires_grad_(True)
+    kernel = rnd(I + U, 4 * U, seed=2, scale=0.3).requires_grad_(True)
+    bias = rnd(4 * U, seed=3, scale=0.3).requires_grad_(True)
+    h0 = rnd(M, U, seed=4).requires_grad_(True) if with_init else None
+    c0 = rnd(M, U, seed=5).requires_grad_(True) if with_init else None
+    g = torch.Generator().manual_seed(6)
+    lens = torch.randint(0 if masked else 1, T + 1, (M,), generator=g)
+    lens[0] = T
+    if masked:
+        outs, h, c = oracle.dynamic_rnn(x, lens, kernel, bias, c0=c0, h0=h0)
+        n_steps = T
+    else:                                           # decoder: no masking, n_steps = max(len)
+        n_steps = T - 1
+        cc = c0 if with_init else torch.zeros(M, U, dtype=torch.float64)
+        hh = h0 if with_init else torch.zeros(M, U, dtype=torch.float64)
+        outl = []
+        for t in range(n_steps):
+            cc, hh = oracle.basic_lstm_cell(x[:, t], cc, hh, kernel, bias)
+            outl.append(hh)
+        outs, h, c = torch.stack(outl, dim=1), hh, cc
+    douts = rnd(*outs.shape, seed=7)
+    dh, dc = rnd(M, U, seed=8), rnd(M, U, seed=9)
+    (outs * douts).sum().backward(retain_graph=True)
+    ((h * dh).sum() + (c * dc).sum()).backward()
+
+    Wx, Wh = dev(kernel[:I]), dev(kernel[I:])
+    # hoisted input projection in the chosen layout
+    if strided:    # (m, t)-ordered rows: row stride T*4U, t stride 4U
+        z = K.matmul_nn(dev(x.reshape(M * T, I)), Wx, bias=dev(bias))
+        zrs, zts = T * 4 * U, 4 * U
+    else:          # time-major
+        z = K.matmul_nn(dev(x.transpose(0, 1).reshape(T * M, I)), Wx, bias=dev(bias))
+        zrs, zts = 4 * U, M * 4 * U
+    hout = torch.empty(n_steps, M, U, device='cuda')
+    cs = torch.empty(n_steps, M, U, device='cuda')
+    hf, cf = torch.empty(M, U, device='cuda'), torch.empty(M, U, device='cuda')
+    lens_d = lens.to(torch.int32).cuda() if masked else None
+    K.lstm_seq_fwd(z, zrs, zts, M, U, n_steps, Wh, dev(h0) if with_init else None,
+                   dev(c0) if with_init else None, lens_d, hout, cs, hf, cf)
+    close(hout.transpose(0, 1), outs, atol=2e-5)
+    close(hf, h, atol=2e-5)
+    close(cf, c, atol=2e-5)
+    dz = torch.zeros_like(z)
+    dh0, dc0 = torch.empty(M, U, device='cuda'), torch.empty(M, U, device='cuda')
+    K.lstm_seq_bwd(z, zrs, zts, M, U, n_steps, Wh, dev(c0) if with_init else None, lens_d, cs,
+                   dev(douts.transpose(0, 1)), dev(dh), dev(dc), dz, dh0, dc0)
+    # parameter / input grads from dz
+    if strided:
+        dz2 = dz.reshape(M * T, 4 * U)
+        x2 = dev(x.reshape(M * T, I))
+        hprev = torch.cat([dev(h0).unsqueeze(0) if with_init else torch.zeros(1, M, U, device='cuda'),
+                           hout[:-1]], 0)
+        dzt = dz.reshape(M, T, 4 * U).transpose(0, 1).contiguous()[:n_steps]
+        dx = K.matmul_nt(dz2, Wx).reshape(M, T, I)
+    else:
+        dz2 = dz[:n_steps * M]
+        x2 = dev(x.transpose(0, 1).reshape(T * M, I))[:n_steps * M]
+        hprev = torch.cat([dev(h0).unsqueeze(0) if with_init else torch.zeros(1, M, U, device='cuda'),
+                           hout[:-1]], 0)
+        dzt = dz2.reshape(n_steps, M, 4 * U)
+        dx = torch.zeros(T, M, I, device='cuda')
+        dx[:n_steps] = K.matmul_nt(dz2, Wx).reshape(n_steps, M, I)
+        dx = dx.transpose(0, 1)
+    dWx = K.matmul_tn(x2, dz2.reshape(x2.shape[0], 4 * U))
+    dWh = K.matmul_tn(hprev.reshape(n_steps * M, U), dzt.reshape(n_steps * M, 4 * U))
+    db = K.colsum(dz2.reshape(-1, 4 * U))
+    tol = dict(atol=3e-4, rtol=1e-4)
+    close(dx, x.grad, **tol)
+    close(dWx, kernel.grad[:I], **tol)
+    close(dWh, kernel.grad[I:], **tol)
+    close(db, bias.grad, **tol)
+    if with_init:
+        close(dh0, h0.grad, **tol)
+        close(dc0, c0.grad, **tol)
+
+
+@pytest.mark.parametrize('masked,with_init,strided', [(True, False, True), (True, True, False),
+                                                      (False, True, False), (False, False, False)])
+def test_lstm_seq_fwd_bwd(K, masked, with_init, strided):
+    _lstm_case(K, M=12, T=6, I=20, U=64, masked=masked, with_init=with_init, strided=strided)
+
+
+def test_lstm_known_answer_scalar_cell(K):
+    # U=1-like check of gate order i,j,f,o and forget bias 1.0 (U padded to 4)
+    U = 4
+    z = torch.tensor([[0.5] * U + [-0.3] * U + [0.2] * U + [1.0] * U], dtype=torch.float64)
+    c_prev = torch.full((1, U), 0.7, dtype=torch.float64)
+    i, j, f, o = 0.5, -0.3, 0.2, 1.0
+    sig = lambda v: 1 / (1 + math.exp(-v))
+    c1 = 0.7 * sig(f + 1.0) + sig(i) * math.tanh(j)
+    h1 = math.tanh(c1) * sig(o)
+    c_out, h_out = torch.empty(1, U, device='cuda'), torch.empty(1, U, device='cuda')
+    K.lstm_gate_fwd(dev(z), dev(c_prev), None, None, 0, c_out, None, h_out)
+    assert abs(c_out[0, 0].item() - c1) < 1e-6 and abs(h_out[0, 0].item() - h1) < 1e-6
+
+
+# ------------------------------------------------------------------ embedding
+def test_embedding_gather_scatter_and_shift(K):
+    V, E, R, T = 50, 64, 7, 5
+    table = rnd(V + 1, E, seed=1)
+    g = torch.Generator().manual_seed(2)
+    tokens = torch.randint(0, V, (R, T), generator=g, dtype=torch.int32)
+    ids = K.shift_tokens_tm(tokens.cuda(), V + 1)
+    ref_ids = torch.cat([torch.full((R, 1), V + 1, dtype=torch.int32), tokens[:, :-1]], 1).t()
+    assert torch.equal(ids.cpu(), ref_ids)
+    out = K.embedding_gather(ids, dev(table))
+    ref = oracle.model_full.embedding_lookup_oob0(table.float(), ref_ids.reshape(-1).long())
+    close(out, ref.float(), atol=0, rtol=0)
+    assert out[:R].abs().max().item() == 0          # <s> rows are zero vectors
+    dout = rnd(T * R, E, seed=3)
+    dtable = torch.empty(V + 1, E, device='cuda')
+    K.embedding_scatter_add(ids, dev(dout), dtable)
+    dref = torch.zeros(V + 1, E, dtype=torch.float64)
+    flat = ref_ids.reshape(-1).long()
+    ok = flat <= V
+    dref.index_add_(0, flat[ok], dout[ok])
+    close(dtable, dref, atol=1e-5)
+
+
+# ------------------------------------------------------------------ losses
+@pytest.mark.parametrize('mode,V,G', [('softmax', 50, 1), ('softmax', 6, 3), ('sigmoid', 5, 3)])
+def test_xent_fwd_bwd(K, mode, V, G):
+    B, T = 4, 9
+    R = B * G
+    g = torch.Generator().manual_seed(1)
+    lens = torch.randint(1, T + 1, (R,), generator=g)
+    n_steps = int(lens.max())
+    logits = rnd(T, R, V, seed=2, scale=3.0)
+    logits[n_steps:] = 0
+    logits = logits.requires_grad_(True)
+    if mode == 'softmax':
+        lab = F.one_hot(torch.randint(0, V, (R, T), generator=g), V).double()
+    else:
+        lab = torch.randint(0, 2, (R, T, V), generator=g).double()
+    lab = lab * (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)   # zero rows past len
+    # oracle: one Sequence_Loss per group (demo index), mean over groups
+    pred = logits.permute(1, 2, 0)                  # [R, V, T]
+    gt = lab.permute(0, 2, 1)
+    losses = []
+    for gi in range(G):
+        idx = torch.arange(gi, R, G)
+        losses.append(oracle.sequence_loss(pred[idx], gt[idx], lens[idx], T, V,
+                                           'program' if mode == 'softmax' else 'per'))
+    loss = sum(losses) / G
+    loss.backward()
+    num, den = torch.empty(G, device='cuda'), torch.empty(G, device='cuda')
+    K.xent_fwd(mode, dev(logits), dev(lab), 'rtv', lens.int().cuda(), T, R, V, G, n_steps, num, den)
+    out = torch.empty(1, device='cuda')
+    terms = torch.empty(1, device='cuda')
+    K.loss_assemble([G], num, den, out, terms)
+    close(out, loss.reshape(1), atol=1e-5)
+    dl = torch.zeros(T, R, V, device='cuda')
+    K.xent_bwd(mode, dev(logits), dev(lab), 'rtv', lens.int().cuda(), T, R, V, G, n_steps, den, 1.0, dl)
+    close(dl, logits.grad, atol=1e-6)
+
+
+def test_xent_program_label_layout_bvl(K):
+    B, V, L = 3, 50, 8
+    g = torch.Generator().manual_seed(3)
+    lens = torch.tensor([8, 3, 5])
+    toks = torch.randint(0, V, (B, L), generator=g)
+    program = F.one_hot(toks, V).double().permute(0, 2, 1).contiguous()          # [B,V,L]
+    program = program * (torch.arange(L) < lens.unsqueeze(1)).unsqueeze(1)
+    logits = rnd(L, B, V, seed=4)
+    ref = oracle.sequence_loss(logits.permute(1, 2, 0), program, lens, L, V, 'program')
+    num, den = torch.empty(1, device='cuda'), torch.empty(1, device='cuda')
+    K.xent_fwd('softmax', dev(logits), dev(program), 'bvl', lens.int().cuda(), L, B, V, 1, L, num, den)
+    close(num / den, ref.reshape(1), atol=1e-5)
+
+
+def test_zero_past_group_steps(K):
+    T, B, G, V = 6, 3, 2, 4
+    R = B * G
+    lens = torch.tensor([2, 5, 3, 1, 1, 4])
+    x = torch.ones(T, R, V, device='cuda')
+    K.zero_past_group_steps(x, lens.int().cuda(), T, R, V, G)
+    nst = [int(lens[0::2].max()), int(lens[1::2].max())]
+    for t in range(T):
+        for r in range(R):
+            assert x[t, r, 0].item() == (1.0 if t < nst[r % G] else 0.0)
+
+
+# ------------------------------------------------------------------ summarizer glue
+def test_summarizer_glue(K):
+    B, k, U = 3, 4, 8
+    x = rnd(B, k, U, seed=1)
+    out, bc = torch.empty(B, U, device='cuda'), torch.empty(B, k, U, device='cuda')
+    K.group_mean(dev(x), B, k, U, out, bc)
+    close(out, x.mean(1), atol=1e-6)
+    close(bc, x.mean(1, keepdim=True).expand(B, k, U), atol=1e-6)
+    dout, dbc = rnd(B, U, seed=2), rnd(B, k, U, seed=3)
+    dx = dev(torch.ones(B, k, U, dtype=torch.float64))
+    K.group_mean_bwd(dev(dout), dev(dbc), dx, B, k, U, True)
+    close(dx, 1 + ((dout + dbc.sum(1)) / k).unsqueeze(1).expand(B, k, U), atol=1e-6)
+    # rn pair: y[b,a,c] = lrelu(P[b,c] + Q[b,a] + bias)
+    Pm, Qm, bias = rnd(B, k, U, seed=4), rnd(B, k, U, seed=5), rnd(U, seed=6)
+    y = torch.empty(B, k, k, U, device='cuda')
+    K.rn_pair_fwd(dev(Pm), dev(Qm), dev(bias), y, B, k, U)
+    ref = oracle.lrelu(Pm.unsqueeze(1) + Qm.unsqueeze(2) + bias)
+    close(y, ref, atol=1e-6)
+    dy = rnd(B, k, k, U, seed=7)
+    dP, dQ = torch.empty(B, k, U, device='cuda'), torch.empty(B, k, U, device='cuda')
+    K.rn_pair_bwd(dev(dy), dP, dQ, B, k, U)
+    close(dP, dy.sum(1), atol=1e-6)
+    close(dQ, dy.sum(2), atol=1e-6)
+    base = rnd(B, U, seed=8)
+    o2 = torch.empty(B, U, device='cuda')
+    K.pair_mean_fwd(dev(dy.reshape(B, k * k, U)), dev(base), o2, B, k * k, U)
+    close(o2, dy.reshape(B, k * k, U).mean(1) + base, atol=1e-6)
+    d2 = torch.empty(B, k * k, U, device='cuda')
+    K.pair_mean_bwd(dev(dout), d2, B, k * k, U)
+    close(d2, (dout / (k * k)).unsqueeze(1).expand(B, k * k, U), atol=1e-7)
+    tr = K.transpose_rt(dev(x), B, k, U)
+    close(tr, x.float().transpose(0, 1), atol=0, rtol=0)
+
+
+def test_rn_factorisation_equals_concat_fc(K):
+    # P + Q + b must equal fc1([feat_c || feat_a]) of models/model_full.py:335-343
+    B, k, U = 2, 3, 16
+    feat = rnd(B, k, U, seed=1)
+    W1, b1 = rnd(2 * U, U, seed=2, scale=0.3), rnd(U, seed=3)
+    tile1 = feat.unsqueeze(1).expand(B, k, k, U)
+    tile2 = feat.unsqueeze(2).expand(B, k, k, U)
+    ref = oracle.lrelu(torch.cat([tile1, tile2], 3).reshape(-1, 2 * U) @ W1 + b1)
+    f2 = dev(feat.reshape(B * k, U))
+    W1d = dev(W1)
+    Pm = K.matmul_nn(f2, W1d[:U])
+    Qm = K.matmul_nn(f2, W1d[U:])
+    y = torch.empty(B * k * k, U, device='cuda')
+    K.rn_pair_fwd(Pm, Qm, dev(b1), y, B, k, U)
+    close(y, ref, atol=1e-5)
+
+
+# ------------------------------------------------------------------ optimizer
+@pytest.mark.parametrize('gscale', [0.01, 50.0])
+def test_adam_clip_matches_oracle(K, gscale):
+    n = 1003
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2, scale=gscale)
+    params, grads = {'w': p0.clone()}, {'w': g0.clone()}
+    m, v = {'w': torch.zeros(n, dtype=torch.float64)}, {'w': torch.zeros(n, dtype=torch.float64)}
+    pd, md, vd = dev(p0), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    sumsq = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for step in (1, 2, 3):
+        norm = oracle.adam_clip_step(params, grads, m, v, step, 1e-3)
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        K.l2norm_flat(dev(g0), 1.0, sumsq)
+        assert abs(math.sqrt(sumsq.item()) - norm) < 1e-4 * max(1.0, norm)
+        K.adam_clip_flat(pd, dev(g0), md, vd, sumsq, 1.0, 20.0, lr_t)
+    close(pd, params['w'], atol=1e-6)
+    close(md, m['w'], atol=1e-6, rtol=1e-5)
+
+
+def test_adam_prescale_is_gradient_average(K):
+    n = 256
+    g = rnd(n, seed=3, scale=5.0)
+    p1, p2 = dev(torch.zeros(n)), dev(torch.zeros(n))
+    s = torch.zeros(1, dtype=torch.float64, device='cuda')
+    for p, gg, pre in ((p1, g * 4, 0.25), (p2, g, 1.0)):
+        m, v = torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+        K.l2norm_flat(dev(gg), pre, s)
+        K.adam_clip_flat(p, dev(gg), m, v, s, pre, 20.0, 1e-3)
+    close(p1, p2, atol=1e-7)
+
+
+def test_missing_gpu_tensor_fails_loudly(K):
+    with pytest.raises(RuntimeError):
+        K.matmul_nn(torch.zeros(4, 4), torch.zeros(4, 4))

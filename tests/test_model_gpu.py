@@ -1,0 +1,196 @@
+"""Whole-path parity on a real MI355X: Model.forward / backward / Trainer.train_step (HIP
+kernels through the C ABI) against the CPU oracle on the same seeded inputs and weights.
+
+Tolerances (north_star): fp32 logits within 1e-4 absolute of the oracle; loss within 1e-5
+relative; gradients within 2e-4 of each tensor's max |g| (fp32 accumulation over
+thousands of terms vs the fp64 oracle)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from helpers import oracle_config, run_oracle, small_case
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _gpu():
+    assert torch.cuda.is_available(), 'GPU tests need a real MI355X (run through gpurun)'
+    from demo2program_amd import build
+    build.build_library()
+
+
+def _maxerr(a, b):
+    return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
+
+
+def _check_against_oracle(cfg, params, batch, out, grads, logit_tol=1e-4):
+    from demo2program_amd.models.model_full import Model
+    model = Model(cfg, params=params)
+    feed = model.get_feed_dict(batch)
+    loss = model.forward(feed)
+    model.backward()
+    torch.cuda.synchronize()
+    ref_loss = float(out['loss'])
+    assert abs(float(loss.item()) - ref_loss) <= 1e-5 * abs(ref_loss) + 1e-6, (float(loss.item()), ref_loss)
+    rl = model.report_loss
+    assert abs(float(rl['program_loss'].item()) - float(out['program_loss'])) < 1e-4
+    assert abs(float(rl['avg_action_loss'].item()) - float(out['avg_action_loss'])) < 1e-4
+    assert abs(float(rl['avg_per_loss'].item()) - float(out['avg_per_loss'])) < 1e-4
+    # logits: [B,V,L], [B,k,T,A] (oracle: [B,k,A,T]), [B,k,T,P]
+    assert _maxerr(model.pred_program, out['pred_program']) <= logit_tol
+    assert _maxerr(model.pred_action, out['pred_action'].permute(0, 1, 3, 2)) <= logit_tol
+    assert _maxerr(model.pred_per, out['pred_per'].permute(0, 1, 3, 2)) <= logit_tol
+    g = model.params.to_numpy('g')
+    worst = []
+    for n, ref in grads.items():
+        ref = ref.double().numpy()
+        err = np.abs(g[n].astype(np.float64) - ref).max()
+        scale = np.abs(ref).max()
+        worst.append((err / (scale + 1e-12), n, err, scale))
+        assert err <= 2e-4 * scale + 1e-6, 'grad %s: err %.3e vs max|g| %.3e' % (n, err, scale)
+    return model, sorted(worst)[-3:]
+
+
+@pytest.mark.parametrize('kind', ['karel', 'vizdoom'])
+def test_forward_backward_matches_oracle_small(kind):
+    cfg, params, batch = small_case(kind)
+    out, grads = run_oracle(cfg, params, batch, dtype=torch.float64)
+    _check_against_oracle(cfg, params, batch, out, grads)
+
+
+def test_forward_backward_matches_oracle_u512_karel():
+    # full-width cells (U=512, the shipped configuration) on a small batch
+    cfg, params, batch = small_case('karel', seed=11, batch_size=2, k=2, max_demo_len=8,
+                                    max_program_len=12, num_lstm_cell_units=512)
+    out, grads = run_oracle(cfg, params, batch, dtype=torch.float64)
+    _check_against_oracle(cfg, params, batch, out, grads)
+
+
+def test_matches_committed_golden_fixture():
+    """tests/golden/karel_small.npz was produced by tests/golden/make_golden.py (fp32 oracle)."""
+    z = np.load(os.path.join(GOLDEN, 'karel_small.npz'))
+    cfg, params, batch = small_case('karel', seed=int(z['seed']))
+    for n in params:
+        assert np.array_equal(params[n], z['param/' + n]), n
+    for n, v in batch.items():
+        if v.dtype.kind not in 'US':
+            assert np.array_equal(v, z['batch/' + n]), n
+    from demo2program_amd.models.model_full import Model
+    model = Model(cfg, params=params)
+    loss = model.forward(model.get_feed_dict(batch))
+    model.backward()
+    assert abs(float(loss.item()) - float(z['loss'])) <= 1e-5 * abs(float(z['loss']))
+    assert np.abs(model.pred_program.cpu().numpy() - z['pred_program']).max() <= 1e-4
+    assert np.abs(model.pred_action.cpu().numpy() - z['pred_action']).max() <= 1e-4
+    assert np.abs(model.pred_per.cpu().numpy() - z['pred_per']).max() <= 1e-4
+    g = model.params.to_numpy('g')
+    for n in params:
+        ref = z['grad/' + n]
+        assert np.abs(g[n] - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-6, n
+
+
+def test_output_list_and_dynamic_padding():
+    cfg, params, batch = small_case('karel', seed=5)
+    # shorten every program / demo so that dynamic_decode stops early
+    batch['program_len'][:] = np.minimum(batch['program_len'], 4)
+    batch['demo_len'][:] = np.minimum(batch['demo_len'], 3)
+    for b in range(cfg.batch_size):
+        batch['program'][b, :, int(batch['program_len'][b, 0]):] = 0
+    from demo2program_amd.models.model_full import Model
+    model = Model(cfg, params=params)
+    model.forward(model.get_feed_dict(batch))
+    pp = model.pred_program.cpu()
+    n = int(batch['program_len'].max())
+    assert pp[:, :, n:].abs().max().item() == 0 and pp[:, :, :n].abs().max().item() > 0
+    # rows shorter than the longest keep producing non-zero logits (impute_finished=False)
+    short = int(np.argmin(batch['program_len'][:, 0]))
+    if batch['program_len'][short, 0] < n:
+        assert pp[short, :, n - 1].abs().max().item() > 0
+    out = model.output
+    assert len(out) == 2 + 2 * cfg.k + 2 * cfg.k
+    assert tuple(out[1].shape) == (cfg.batch_size, cfg.dim_program_token, cfg.max_program_len)
+    assert tuple(out[3].shape) == (cfg.batch_size, cfg.action_space, cfg.max_demo_len)
+    out2, _ = run_oracle(cfg, params, batch, dtype=torch.float64)
+    assert _maxerr(model.pred_action, out2['pred_action'].permute(0, 1, 3, 2)) <= 1e-4
+
+
+def test_trainer_steps_match_oracle_adam():
+    """Three optimizer steps (clip 20 + Adam) against the oracle's optimizer, and the loss
+    goes down on a repeated batch."""
+    from demo2program_amd.trainer import Trainer, SyntheticBatches
+    cfg, params, batch = small_case('karel', seed=3)
+
+    class One(object):
+        def next(self):
+            return batch
+
+    tr = Trainer(cfg, dataset=One(), dataset_test=One(), make_train_dir=False)
+    tr.model.params.load(params)
+    p = {n: torch.from_numpy(v).double() for n, v in params.items()}
+    m = {n: torch.zeros_like(v) for n, v in p.items()}
+    v = {n: torch.zeros_like(v_) for n, v_ in p.items()}
+    losses = []
+    for step in (1, 2, 3):
+        out, grads = run_oracle(cfg, {n: t.numpy() for n, t in p.items()}, batch)
+        oracle.adam_clip_step(p, grads, m, v, step, cfg.learning_rate)
+        _, _, loss, _, _ = tr.run_single_step(One())
+        losses.append(loss)
+        assert abs(loss - float(out['loss'])) <= 2e-4 * abs(float(out['loss']))
+    got = tr.model.params.to_numpy('p')
+    # Adam's update is sign-like (m/sqrt(v)): an element whose gradient is at fp32-noise level
+    # can move +-lr in either direction, so compare the bulk, not the max (the Adam kernel
+    # itself is checked exactly against the oracle in test_kernels_gpu.py).
+    for n in p:
+        diff = np.abs(got[n] - p[n].numpy())
+        assert (diff <= 2e-4).mean() >= 0.98, (n, float((diff <= 2e-4).mean()))
+        assert diff.max() <= 3 * 1.01e-3 * 2, n
+    assert losses[2] < losses[0]
+    assert tr.global_step == 3
+
+
+def test_bn_moving_statistics_follow_reference_updates():
+    cfg, params, batch = small_case('karel', seed=9)
+    from demo2program_amd.models.model_full import Model
+    model = Model(cfg, params=params)
+    model.forward(model.get_feed_dict(batch))
+    out, _ = run_oracle(cfg, params, batch, dtype=torch.float64)
+    mm, mv = torch.zeros(16, dtype=torch.float64), torch.ones(16, dtype=torch.float64)
+    for (mean, var) in out['bn_stats']['conv1']:        # k calls -> k updates
+        mm = 0.9 * mm + 0.1 * mean
+        mv = 0.9 * mv + 0.1 * var
+    assert _maxerr(model.moving['conv1'][0], mm) < 1e-5
+    assert _maxerr(model.moving['conv1'][1], mv) < 1e-5
+
+
+def test_headline_config_properties():
+    """BASELINE config 2 (Karel, B=32, k=10): too slow for a per-element oracle comparison in a
+    unit test budget, so check size-independent properties: finite loss near the
+    uniform-prediction value, determinism across two runs, zero-padded logits, gradient norm
+    finite, and per-term losses summing to the total."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.synthetic import make_batch
+    cfg = make_config('karel')
+    batch = make_batch(cfg, seed=123)
+    model = Model(cfg, seed=123)
+    feed = model.get_feed_dict(batch)
+    l1 = float(model.forward(feed).item())
+    model.backward()
+    g1 = model.params.grad.clone()
+    l2 = float(model.forward(feed).item())
+    model.backward()
+    assert l1 == l2 and torch.equal(g1, model.params.grad)          # deterministic reductions
+    assert abs(l1 - (math.log(50) + math.log(6) + math.log(2))) < 0.5
+    t = model.report_loss
+    s = sum(float(t[n].item()) for n in ('program_loss', 'avg_action_loss', 'avg_per_loss'))
+    assert abs(s - l1) < 1e-5
+    assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+    n = feed['n_prog']
+    assert model.pred_program[:, :, n:].abs().max().item() == 0 if n < cfg.max_program_len else True
