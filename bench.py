@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""Headline benchmark: training throughput of the full model on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one complete optimizer step of the reference's trainer (trainer.py:186-205):
+forward + backward + [RCCL all-reduce of the flat gradient buffer] + global-norm clip +
+Adam, on one synthetic Karel batch that is ALREADY RESIDENT IN HBM.  Workload (weak
+scaling): BASELINE.json config 2 per GPU -- Karel full model, k=10, 8x8x16 frames, T=20,
+L=50, batch 32 programs per GPU.  value = programs (instances) per second over the whole
+job; an instance = one program with its k demonstrations (trainer.py:238).
+
+Besides the contract fields the JSON line carries
+  roofline     -- the dominant kernel family of the step, timed live with HIP events on the
+                  launch stream in an instrumented pass right after the timed region
+  cpu_baseline -- the CPU oracle (torch-CPU restatement, NOT TF1) timed on this box's host
+                  cores on the same batch (rank 0, N=1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0          # HBM3E spec (6290 GB/s measured copy)
+
+PROF_FAMILIES = {
+    1: ('gemm_mfma_kernel (dense fp32 MFMA GEMM)', 'mfma'),
+    2: ('gemm_mfma_kernel<Im2col> (conv implicit GEMM)', 'mfma'),
+    3: ('lstm_gate_fwd_kernel', 'hbm'),
+    4: ('lstm_gate_bwd_kernel', 'hbm'),
+    7: ('lstm_step_fwd_kernel (fused recurrent GEMM + gates)', 'mfma'),
+    8: ('lstm_step_bwd_kernel (fused recurrent GEMM + gate backward)', 'mfma'),
+}
+
+
+def roofline_leg(trainer, feeds, steps=2):
+    """Re-runs `steps` training steps with per-launch HIP events enabled inside the library
+    and reports the family/tag with the largest summed device time."""
+    from demo2program_amd.lib import load
+    lib = load()
+    torch.cuda.synchronize()
+    lib.d2p_prof_enable(1)
+    for i in range(steps):
+        trainer.train_step(feeds[i % len(feeds)])
+    torch.cuda.synchronize()
+    rows = []
+    for fam, (name, bound) in PROF_FAMILIES.items():
+        for tag in (0, 1):
+            cnt, ms, work = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
+            lib.d2p_prof_read(fam * 8 + tag, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(work))
+            if cnt.value:
+                rows.append(dict(family=fam, tag=tag, name=name, bound=bound, launches=cnt.value,
+                                 total_ms=ms.value, work=work.value))
+    lib.d2p_prof_enable(0)
+    if not rows:
+        return None, []
+    rows.sort(key=lambda r: -r['total_ms'])
+    top = rows[0]
+    sec = top['total_ms'] / 1e3
+    if top['bound'] == 'mfma':
+        achieved, peak, unit = top['work'] / sec / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
+    else:
+        achieved, peak, unit = top['work'] / sec / 1e9, PEAK_HBM_GBS, 'GB/s'
+    roof = {
+        'kernel': top['name'] + (' [inside the recurrence]' if top['tag'] == 1 else ''),
+        'bound': top['bound'], 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
+        'frac': round(achieved / peak, 4), 'traffic': None,
+        'launches_per_step': top['launches'] / steps,
+        'avg_launch_us': round(top['total_ms'] * 1e3 / top['launches'], 3),
+        'work_per_launch': top['work'] / top['launches'],
+        'share_of_instrumented_ms': round(top['total_ms'] / sum(r['total_ms'] for r in rows), 3),
+    }
+    table = [dict(kernel=r['name'], tag=r['tag'], launches_per_step=r['launches'] / steps,
+                  ms_per_step=round(r['total_ms'] / steps, 4),
+                  rate=round(r['work'] / (r['total_ms'] / 1e3) / (1e12 if r['bound'] == 'mfma' else 1e9), 2),
+                  unit='TFLOP/s' if r['bound'] == 'mfma' else 'GB/s') for r in rows]
+    return roof, table
+
+
+def cpu_baseline_leg(config, batch, params, steps=2):
+    """The CPU oracle (torch-CPU fp32 restatement of the TF-1.3 graph + torch autograd) on the
+    host cores of this box, same batch, same weights.  Reported, never the target."""
+    import oracle
+    from demo2program_amd.synthetic import to_torch
+    # many small ops: more than ~16 threads only adds fork/join overhead (256-core host: >10x slower)
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    ocfg = oracle.OracleConfig(
+        batch_size=config.batch_size, k=config.k, max_demo_len=config.max_demo_len,
+        max_program_len=config.max_program_len, h=config.h, w=config.w, depth=config.depth,
+        dim_program_token=config.dim_program_token, action_space=config.action_space,
+        per_dim=config.per_dim, num_lstm_cell_units=config.num_lstm_cell_units,
+        dataset_type=config.dataset_type)
+    tb = to_torch(batch)
+    tp = {n: torch.from_numpy(v) for n, v in params.items()}
+    oracle.loss_and_grads(tp, tb, ocfg, dtype=torch.float32)       # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        oracle.loss_and_grads(tp, tb, ocfg, dtype=torch.float32)
+    dt = (time.time() - t0) / steps
+    model = ''
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                model = line.split(':', 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {'value': round(config.batch_size / dt, 3), 'unit': 'instances/s',
+            'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d full forward+backward steps (no optimizer) of the torch-CPU oracle on the '
+                      'same batch of %d programs x %d demos, fp32, %.2f s/step; CPU restatement, '
+                      'not TF1 (TensorFlow 1.3 is not installable here)' %
+                      (steps, config.batch_size, config.k, dt),
+            'cpu_model': model}
+
+
+def log(msg):
+    if os.environ.get('RANK', '0') == '0':
+        sys.stderr.write('[bench %.1fs] %s\n' % (time.time() - _T0, msg))
+        sys.stderr.flush()
+
+
+_T0 = time.time()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--preset', default='karel', help='karel | vizdoom | vizdoom_k25 | karel_tiny')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--h2d', action='store_true', help='also report the host-batch (PCIe-inclusive) rate')
+    args = ap.parse_args()
+
+    from demo2program_amd import build
+    from demo2program_amd.config import make_config
+    from demo2program_amd.dist import DataParallel
+    from demo2program_amd.synthetic import make_batch
+    from demo2program_amd.trainer import Trainer
+
+    dp = DataParallel.from_env()
+    if dp.world_size != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run '
+                         '--nproc-per-node %d' % (args.gpus, dp.world_size, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
+    if dp.rank == 0:
+        build.build_library()
+    dp.barrier()
+
+    config = make_config(args.preset)
+    log('building trainer')
+    trainer = Trainer(config, make_train_dir=False, dp=dp)
+    log('trainer ready; making batches')
+    # distinct per-rank synthetic batches, made resident in HBM before the timed region
+    host_batches = [make_batch(config, seed=123 + 7919 * dp.rank + i) for i in range(4)]
+    feeds = [trainer.model.get_feed_dict(b) for b in host_batches]
+    torch.cuda.synchronize()
+    log('feeds resident; warmup')
+
+    for i in range(args.warmup):
+        trainer.train_step(feeds[i % len(feeds)])
+    torch.cuda.synchronize()
+    log('warmup done; timing %d steps' % args.steps)
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = trainer.train_step(feeds[i % len(feeds)])
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+    final_loss = float(loss.item())
+    log('timed region done: %.3f s' % elapsed)
+
+    global_batch = config.batch_size * dp.world_size
+    value = global_batch * args.steps / elapsed
+    out = {
+        'metric': 'train instances/sec (batch x k demos) Karel full model' if args.preset == 'karel'
+                  else 'train instances/sec (batch x k demos) %s full model' % args.preset,
+        'value': round(value, 3), 'unit': 'instances/s', 'n_gpus': dp.world_size,
+        'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {
+            'workload': '%s full model, k=%d, %dx%dx%d frames, T=%d, L=%d, batch=%d programs per GPU; '
+                        'one step = forward + backward + grad all-reduce + clip(20) + Adam; '
+                        'inputs resident in HBM' %
+                        (args.preset, config.k, config.h, config.w, config.depth, config.max_demo_len,
+                         config.max_program_len, config.batch_size),
+            'global_batch': global_batch, 'parallelism': 'dp%d' % dp.world_size,
+            'lstm_units': config.num_lstm_cell_units,
+        },
+        'demo_instances_per_sec': round(value * config.k, 1),
+        'final_loss': round(final_loss, 5),
+    }
+
+    if args.h2d:
+        # PCIe-inclusive rate: host numpy batch -> H2D -> step (never `value`)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n = max(5, args.steps // 5)
+        for i in range(n):
+            trainer.train_step(trainer.model.get_feed_dict(host_batches[i % len(host_batches)]))
+        torch.cuda.synchronize()
+        out['value_incl_h2d'] = round(global_batch * n / dp.max_over_ranks(time.perf_counter() - t1), 3)
+
+    if not args.no_roofline:
+        log('roofline leg')
+        roof, table = roofline_leg(trainer, feeds)
+        out['roofline'] = roof
+        out['kernel_table'] = table
+    if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:
+        from demo2program_amd.params import init_params
+        log('cpu baseline leg (%d host cores)' % (os.cpu_count() or 1))
+        out['cpu_baseline'] = cpu_baseline_leg(config, host_batches[0], init_params(config, 123))
+    if dp.rank == 0:
+        print(json.dumps(out))
+    dp.shutdown()
+
+
+if __name__ == '__main__':
+    main()

@@ -13,17 +13,7 @@
 #include "common.h"
 #include "prof.h"
 
-#define FORGET_BIAS 1.0f
-
-struct f4 { float v[4]; };
-__device__ __forceinline__ f4 ldf4(const float* p) {
-    float4 t = *reinterpret_cast<const float4*>(p);
-    f4 r; r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w; return r;
-}
-__device__ __forceinline__ void stf4(float* p, const f4& a) {
-    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
-}
-__device__ __forceinline__ f4 zero4() { f4 r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f; return r; }
+#include "lstm_math.h"
 
 __global__ void __launch_bounds__(256)
 lstm_gate_fwd_kernel(int M, int U, const float* __restrict__ z, long zrs,
@@ -42,13 +32,7 @@ lstm_gate_fwd_kernel(int M, int U, const float* __restrict__ z, long zrs,
             const float* zr = z + (long)r * zrs + u;
             const f4 zi = ldf4(zr), zj = ldf4(zr + U), zf = ldf4(zr + 2 * U), zo = ldf4(zr + 3 * U);
             f4 cn, hn;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float c1 = cp.v[q] * d2p_sigmoid(zf.v[q] + FORGET_BIAS) +
-                                 d2p_sigmoid(zi.v[q]) * d2p_tanh(zj.v[q]);
-                cn.v[q] = c1;
-                hn.v[q] = d2p_tanh(c1) * d2p_sigmoid(zo.v[q]);
-            }
+            lstm_gate_fwd4(zi, zj, zf, zo, cp, cn, hn);
             stf4(c_out + o, cn);
             if (hs_out) stf4(hs_out + o, hn);
             stf4(h_out + o, hn);
@@ -87,21 +71,7 @@ lstm_gate_bwd_kernel(int M, int U, const float* __restrict__ z, long zrs,
             }
             f4 dcv = ldf4(dc + o);
             f4 gi, gj, gf, go, dcn;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float i = d2p_sigmoid(zi.v[q]);
-                const float j = d2p_tanh(zj.v[q]);
-                const float f = d2p_sigmoid(zf.v[q] + FORGET_BIAS);
-                const float og = d2p_sigmoid(zo.v[q]);
-                const float tc = d2p_tanh(cc.v[q]);
-                const float d_o = dh.v[q] * tc;
-                const float dct = dcv.v[q] + dh.v[q] * og * (1.f - tc * tc);
-                gi.v[q] = dct * j * i * (1.f - i);
-                gj.v[q] = dct * i * (1.f - j * j);
-                gf.v[q] = dct * cp.v[q] * f * (1.f - f);
-                go.v[q] = d_o * og * (1.f - og);
-                dcn.v[q] = dct * f;
-            }
+            lstm_gate_bwd4(zi, zj, zf, zo, cp, cc, dh, dcv, gi, gj, gf, go, dcn);
             stf4(dzr, gi);
             stf4(dzr + U, gj);
             stf4(dzr + 2 * U, gf);
@@ -171,10 +141,40 @@ extern "C" int d2p_lstm_gate_bwd(int M, int U, const float* z, long z_row_stride
 }
 
 // ---- sequence drivers ------------------------------------------------------------------
+// Fused recurrent-step path (lstm_step.hip); the unfused path below (generic GEMM + gate
+// kernel per step) remains as the reference implementation and for unsupported sizes.
+bool d2p_lstm_fused_eligible(int M, int U);
+size_t d2p_lstm_fused_ws_bytes(int M, int U);
+int d2p_lstm_fused_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, const float* Wh,
+                       const float* h0, const float* c0, const int* lens, float* hout, float* cs,
+                       float* h_final, float* c_final, float* ws, hipStream_t st);
+int d2p_lstm_fused_bwd(int M, int U, int n_steps, const float* z, long zrs, long zts, const float* Wh,
+                       const float* c0, const int* lens, const float* cs, const float* dhout,
+                       const float* dh_final, const float* dc_final, float* dz, float* dh0,
+                       float* dc0, float* ws, hipStream_t st);
+
+static int g_lstm_fused = 1;
+
+extern "C" int d2p_lstm_set_fused(int on) {
+    g_lstm_fused = on ? 1 : 0;
+    return D2P_OK;
+}
+
+static size_t unfused_ws_bytes(int M, int U) { return (size_t)3 * M * U * sizeof(float); }
 
 extern "C" size_t d2p_lstm_ws_bytes(int M, int U) {
     if (M <= 0 || U <= 0) return 0;
-    return (size_t)3 * M * U * sizeof(float);
+    size_t a = unfused_ws_bytes(M, U);
+    if (d2p_lstm_fused_eligible(M, U)) {
+        const size_t b = d2p_lstm_fused_ws_bytes(M, U);
+        if (b > a) a = b;
+    }
+    return a;
+}
+
+static bool use_fused(int M, int U, long zrs, const void* z, size_t ws_bytes) {
+    return g_lstm_fused && d2p_lstm_fused_eligible(M, U) && ws_bytes >= d2p_lstm_fused_ws_bytes(M, U) &&
+           (zrs % 4 == 0) && (((uintptr_t)z & 15) == 0);
 }
 
 static int copy_or_zero(float* dst, const float* src, size_t n, hipStream_t st) {
@@ -196,8 +196,11 @@ extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_
     const size_t MU = (size_t)M * U;
     if (M == 0) return D2P_OK;
     D2P_REQUIRE(n_steps == 0 || (z && Wh && hout && cs), D2P_EINVAL, "lstm seq fwd: null pointer");
-    D2P_REQUIRE(ws && ws_bytes >= d2p_lstm_ws_bytes(M, U), D2P_EWS,
+    D2P_REQUIRE(ws && ws_bytes >= unfused_ws_bytes(M, U), D2P_EWS,
                 "lstm seq fwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
+    if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes))
+        return d2p_lstm_fused_fwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, h0, c0, lens, hout,
+                                  cs, h_final, c_final, (float*)ws, st);
     float* hs[2] = {(float*)ws, (float*)ws + MU};
     const float* h_prev = h0;
     const float* c_prev = c0;
@@ -232,8 +235,11 @@ extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long 
     const size_t MU = (size_t)M * U;
     if (M == 0) return D2P_OK;
     D2P_REQUIRE(n_steps == 0 || (z && Wh && cs && dz), D2P_EINVAL, "lstm seq bwd: null pointer");
-    D2P_REQUIRE(ws && ws_bytes >= d2p_lstm_ws_bytes(M, U), D2P_EWS,
+    D2P_REQUIRE(ws && ws_bytes >= unfused_ws_bytes(M, U), D2P_EWS,
                 "lstm seq bwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
+    if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && (((uintptr_t)dz & 15) == 0))
+        return d2p_lstm_fused_bwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
+                                  dh_final, dc_final, dz, dh0, dc0, (float*)ws, st);
     float* dHbuf[2] = {(float*)ws, (float*)ws + MU};
     float* dC = (float*)ws + 2 * MU;
     int rc = copy_or_zero(dC, dc_final, MU, st);

@@ -1,0 +1,556 @@
+// Fused recurrent-step kernels: per timestep ONE launch computes h·Wh (fp32 MFMA), adds the
+// hoisted input projection, applies the BasicLSTMCell gates and the dynamic_rnn length mask
+// (forward), or computes dz[t+1]·Wh^T and the gate backward of step t (backward).
+// Replaces the per-step matmul + 5 elementwise TF ops inside tf.nn.dynamic_rnn /
+// seq2seq.dynamic_decode (models/model_full.py:254-256,274-276,469-471).
+//
+// Why this shape (MI355X_MICROARCH.md price list): every step needs ALL of h, so the step
+// boundary is an all-to-all seam; a kernel boundary (~1.5 us) is cheaper than a grid barrier
+// (4-7 us), so the loop stays one launch per step.  Inside a launch the problem
+// ([320 x 512] x [512 x 2048], 0.67 GFLOP = 4.3 us at fp32-MFMA peak) is latency-bound, so:
+//   * 256 workgroups (one per CU), each owning a [~80 rows] x [8 units x 4 gates] output tile;
+//     block -> tile mapping keeps a tile column's row-tiles on one XCD (shared L2 slice of Wh);
+//   * the 4 waves of a workgroup split K (no operand is shared between waves, so nothing is
+//     staged through LDS); each wave issues ALL loads of its K slice up front (<= 56 x 1 KiB
+//     in flight per wave) and then runs its v_mfma_f32_16x16x4_f32 chain;
+//   * operands are stored "fragment-major": a [16 rows x 16 k] block is 64 lanes x 4 floats
+//     laid out so that lane l's float4 is (row l&15, k = 4*(l>>4)..+3).  A wave loads a block
+//     with one perfectly coalesced dwordx4 (1 KiB) and uses component j in the j-th of 4
+//     MFMAs (A and B agree on the k permutation).  Wh is packed once per sequence call; h / dz
+//     are emitted in this layout by the previous step's epilogue;
+//   * the 4 K-partials are combined through LDS (row stride 36 floats: conflict-free b32
+//     writes, 16-byte aligned b128 reads) and the epilogue handles (row, 4 units) per thread
+//     with 16-byte global accesses.
+#include "common.h"
+#include "lstm_math.h"
+#include "prof.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define FWD_RSMAX 5     // row sub-tiles (16 rows) per workgroup, forward
+#define BWD_RSMAX 4     // backward
+#define P_LD 36         // LDS partial-tile row stride (floats)
+
+// ---------------------------------------------------------------------------------------
+// Packing kernels (HBM-bound copies, once per sequence call / per initial state)
+// ---------------------------------------------------------------------------------------
+// Forward B operand: Wf[((ct*KC + kc)*2 + cs)*64 + lane] (float4), ct = 8-unit column tile,
+// local column j = cs*16 + (lane&15) -> gate j>>3, unit ct*8 + (j&7); k = kc*16 + 4*(lane>>4)+jj
+__global__ void __launch_bounds__(256)
+pack_w_fwd_kernel(int U, const float* __restrict__ Wh, float4* __restrict__ Wf) {
+    const int KC = U >> 4;
+    const long total = (long)(U >> 3) * KC * 2 * 64;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int lane = (int)(idx & 63);
+        const int cs = (int)((idx >> 6) & 1);
+        const long r = idx >> 7;
+        const int kc = (int)(r % KC), ct = (int)(r / KC);
+        const int j = cs * 16 + (lane & 15);
+        const long col = (long)(j >> 3) * U + ct * 8 + (j & 7);
+        const int k = kc * 16 + 4 * (lane >> 4);
+        const long ld = 4L * U;
+        Wf[idx] = make_float4(Wh[(k + 0) * ld + col], Wh[(k + 1) * ld + col], Wh[(k + 2) * ld + col],
+                              Wh[(k + 3) * ld + col]);
+    }
+}
+// Backward B operand (Wh^T): Wb[(nt*KC4 + kc)*64 + lane], n = nt*16 + (lane&15) (unit),
+// k = kc*16 + 4*(lane>>4) (gate column): value Wh[n][k..k+3] -- a straight float4 copy.
+__global__ void __launch_bounds__(256)
+pack_w_bwd_kernel(int U, const float* __restrict__ Wh, float4* __restrict__ Wb) {
+    const int KC4 = U >> 2;
+    const long total = (long)(U >> 4) * KC4 * 64;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int lane = (int)(idx & 63);
+        const long r = idx >> 6;
+        const int kc = (int)(r % KC4), nt = (int)(r / KC4);
+        const int n = nt * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4);
+        Wb[idx] = *reinterpret_cast<const float4*>(Wh + (long)n * 4 * U + k);
+    }
+}
+// A operand from a row-major [M, K] matrix: Af[(rs*KCx + kc)*64 + lane], row = rs*16+(lane&15)
+__global__ void __launch_bounds__(256)
+pack_rows_kernel(int M, int K, int total_rs, const float* __restrict__ X, float4* __restrict__ Af) {
+    const int KCx = K >> 4;
+    const long total = (long)total_rs * KCx * 64;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int lane = (int)(idx & 63);
+        const long r = idx >> 6;
+        const int kc = (int)(r % KCx), rs = (int)(r / KCx);
+        const int row = rs * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4);
+        Af[idx] = row < M ? *reinterpret_cast<const float4*>(X + (long)row * K + k)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+
+static inline int pack_blocks(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+// fragment-major offset (in floats) of (row, k..k+3), k % 4 == 0, for a matrix with KCx chunks
+__device__ __forceinline__ long frag_off(int row, int k, int KCx) {
+    return ((((long)(row >> 4) * KCx + (k >> 4)) * 64) + (((k & 15) >> 2) << 4) + (row & 15)) * 4;
+}
+
+// row sub-tile range of row tile rt when total_rs sub-tiles are spread over RT tiles
+__device__ __forceinline__ void rt_range(int rt, int total_rs, int RT, int& rs0, int& nrs) {
+    const int base = total_rs / RT, rem = total_rs % RT;
+    rs0 = rt * base + min(rt, rem);
+    nrs = base + (rt < rem ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------
+// Forward step
+// ---------------------------------------------------------------------------------------
+struct StepFwdArgs {
+    int M, U, total_rs, RT, t, has_h;
+    const float4* hfrag_in;    // A operand: state h before this step (fragment-major)
+    const float4* Wf;          // packed Wh (forward layout)
+    float* z; long zrs;        // in: x·Wx + b ; out: full pre-activations (row stride zrs)
+    const float* c_prev;       // [M,U] or null (zeros)
+    const float* hs_prev;      // [M,U] state h (row-major), only read for masked rows; may be null
+    const int* lens;           // [M] or null
+    float* c_out;              // [M,U]
+    float* hout;               // [M,U] emitted output (0 for masked rows)
+    float* hs_out;             // [M,U] state h (row-major) or null when lens == null
+    float* hfrag_out;          // state h after this step, fragment-major
+};
+
+// K-slice GEMM of one wave: NRS row sub-tiles x 2 column sub-tiles, all loads issued up
+// front, K-partials written to LDS.
+template <int CPW, int NRS>
+__device__ __forceinline__ void fwd_gemm(const f32x4* __restrict__ Af, const f32x4* __restrict__ Bf,
+                                         int rs0, int ct, int wave, int lane,
+                                         float (*P)[FWD_RSMAX * 16][P_LD]) {
+    constexpr int KC = 4 * CPW;
+    f32x4 acc[NRS][2];
+#pragma unroll
+    for (int i = 0; i < NRS; ++i) {
+        acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 av[CPW][NRS], bv[CPW][2];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) {
+        const int kc = wave * CPW + c;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) bv[c][s] = Bf[(((long)ct * KC + kc) * 2 + s) * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < NRS; ++i) av[c][i] = Af[((long)(rs0 + i) * KC + kc) * 64 + lane];
+    }
+    // keep every load above the MFMA chain: hipcc's occupancy-driven scheduler otherwise sinks
+    // each load next to its first use (58 VGPRs, one load in flight at a time)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < NRS; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i][jj], bv[c][0][jj], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][i][jj], bv[c][1][jj], acc[i][1], 0, 0, 0);
+            }
+    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int i = 0; i < NRS; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                P[wave][i * 16 + (lane >> 4) * 4 + r][s * 16 + (lane & 15)] = acc[i][s][r];
+}
+
+template <int CPW>   // 16-wide k chunks per wave; U = 64*CPW
+__global__ void __launch_bounds__(256, 1) lstm_step_fwd_kernel(StepFwdArgs a) {
+    constexpr int KC = 4 * CPW;
+    __shared__ __attribute__((aligned(16))) float P[4][FWD_RSMAX * 16][P_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int U = a.U;
+    // block -> (ct, rt): all row tiles of a column tile on one XCD (block b runs on XCD b % 8)
+    const int nct = U >> 3;
+    int ct, rt;
+    {
+        const int b = blockIdx.x;
+        if ((nct & 7) == 0) {
+            const int per_xcd = nct >> 3, xcd = b & 7, slot = b >> 3;
+            ct = xcd * per_xcd + slot / a.RT;
+            rt = slot % a.RT;
+        } else {
+            ct = b / a.RT;
+            rt = b % a.RT;
+        }
+    }
+    int rs0, nrs;
+    rt_range(rt, a.total_rs, a.RT, rs0, nrs);
+
+    if (a.has_h) {
+        const f32x4* Af = reinterpret_cast<const f32x4*>(a.hfrag_in);
+        const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wf);
+        // the row sub-tile count is a compile-time constant inside each case: runtime
+        // predicates around the MFMAs force accumulator shuffles and serialise the chain
+        switch (nrs) {
+            case 1: fwd_gemm<CPW, 1>(Af, Bf, rs0, ct, wave, lane, P); break;
+            case 2: fwd_gemm<CPW, 2>(Af, Bf, rs0, ct, wave, lane, P); break;
+            case 3: fwd_gemm<CPW, 3>(Af, Bf, rs0, ct, wave, lane, P); break;
+            case 4: fwd_gemm<CPW, 4>(Af, Bf, rs0, ct, wave, lane, P); break;
+            default: fwd_gemm<CPW, 5>(Af, Bf, rs0, ct, wave, lane, P); break;
+        }
+    }
+    __syncthreads();
+
+    // epilogue: one (row, 4 units) item per thread; local columns g*8 + q*4 .. +3
+    const int nrows = nrs * 16;
+    for (int item = tid; item < nrows * 2; item += 256) {
+        const int r = item >> 1, q = item & 1;
+        const int row = rs0 * 16 + r;
+        if (row >= a.M) continue;
+        const int u = ct * 8 + q * 4;
+        const long o = (long)row * U + u;
+        const bool active = a.lens ? (a.t < a.lens[row]) : true;
+        const f4 cp = a.c_prev ? ldf4(a.c_prev + o) : zero4();
+        f4 hstate;
+        if (active) {
+            f4 zz[4];
+            float* zr = a.z + (long)row * a.zrs + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f4 s = ldf4(zr + (long)g * U);
+                if (a.has_h) {
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        const f4 p = ldf4(&P[w][r][g * 8 + q * 4]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s.v[e] += p.v[e];
+                    }
+                    stf4(zr + (long)g * U, s);      // full pre-activation, kept for backward
+                }
+                zz[g] = s;
+            }
+            f4 cn, hn;
+            lstm_gate_fwd4(zz[0], zz[1], zz[2], zz[3], cp, cn, hn);
+            stf4(a.c_out + o, cn);
+            stf4(a.hout + o, hn);
+            hstate = hn;
+        } else {
+            stf4(a.c_out + o, cp);
+            stf4(a.hout + o, zero4());
+            hstate = a.hs_prev ? ldf4(a.hs_prev + o) : zero4();
+        }
+        if (a.hs_out) stf4(a.hs_out + o, hstate);
+        stf4(a.hfrag_out + frag_off(row, u, U >> 4), hstate);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Backward step:  G = dz[t+1]·Wh^T (skipped when has_gemm == 0), then
+//   mode 0: gate backward of step t -> dz[t] (row-major + fragment-major), dC in place
+//   mode 1: final call: dh0 = G + pass-through
+// ---------------------------------------------------------------------------------------
+struct StepBwdArgs {
+    int M, U, total_rs, RT, t, n_steps, has_gemm, mode;
+    const float4* dzfrag_in;   // A operand: dz[t+1], fragment-major over K = 4U
+    const float4* Wb;          // packed Wh^T
+    const float* z; long zrs;  // pre-activations of step t
+    const float* c_prev;       // c before step t, or null
+    const float* c;            // c after step t
+    const float* dhout;        // gradient wrt emitted output of step t, or null
+    const float* dh_final;     // [M,U] or null
+    const int* lens;
+    float* dC;                 // [M,U] in/out
+    float* dz; long dzrs;      // out: dz[t] row-major
+    float* dzfrag_out;         // out: dz[t] fragment-major
+    float* dh0;                // mode 1 output
+};
+
+#define BWD_CB 4   // chunks per software-pipeline stage
+
+// K-slice GEMM of one wave for NRS row sub-tiles x 1 column sub-tile; two register stages of
+// BWD_CB chunks each are kept in flight (manual double buffering with static names).
+template <int NRS>
+__device__ __forceinline__ void bwd_gemm(const f32x4* __restrict__ Af, const f32x4* __restrict__ Bf,
+                                         int rs0, int KC4, int cpw, int wave, int lane,
+                                         float (*P)[BWD_RSMAX * 16][P_LD]) {
+    f32x4 acc[NRS];
+#pragma unroll
+    for (int i = 0; i < NRS; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 a0[BWD_CB][NRS], b0[BWD_CB], a1[BWD_CB][NRS], b1[BWD_CB];
+    const int kbeg = wave * cpw;
+    const int NB = cpw / BWD_CB;
+#define BWD_LOAD(AV, BV, nb)                                                               \
+    {                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < BWD_CB; ++c) {                               \
+            const int kc = kbeg + (nb) * BWD_CB + c;                                       \
+            BV[c] = Bf[(long)kc * 64 + lane];                                              \
+            _Pragma("unroll") for (int i = 0; i < NRS; ++i)                                \
+                AV[c][i] = Af[((long)(rs0 + i) * KC4 + kc) * 64 + lane];                   \
+        }                                                                                  \
+    }
+#define BWD_COMPUTE(AV, BV)                                                                \
+    {                                                                                      \
+        _Pragma("unroll") for (int c = 0; c < BWD_CB; ++c)                                 \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                   \
+        _Pragma("unroll") for (int i = 0; i < NRS; ++i)                                    \
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[c][i][jj], BV[c][jj], acc[i], 0, 0, 0); \
+    }
+    // Steady state has UNCONDITIONAL prefetches: a conditional load makes hipcc merge the
+    // vmcnt state at the join conservatively (vmcnt(0) before every compute stage, i.e. no
+    // overlap).  The tail is peeled instead.
+    BWD_LOAD(a0, b0, 0)
+    int nb = 0;
+    for (; nb + 2 < NB; nb += 2) {
+        BWD_LOAD(a1, b1, nb + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        BWD_COMPUTE(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        BWD_LOAD(a0, b0, nb + 2)
+        __builtin_amdgcn_sched_barrier(0);
+        BWD_COMPUTE(a1, b1)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (nb + 1 < NB) {
+        BWD_LOAD(a1, b1, nb + 1)
+        __builtin_amdgcn_sched_barrier(0);
+        BWD_COMPUTE(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        BWD_COMPUTE(a1, b1)
+    } else {
+        BWD_COMPUTE(a0, b0)
+    }
+#undef BWD_LOAD
+#undef BWD_COMPUTE
+#pragma unroll
+    for (int i = 0; i < NRS; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) P[wave][i * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[i][r];
+}
+
+template <int DUMMY>
+__global__ void __launch_bounds__(256, 1) lstm_step_bwd_kernel(StepBwdArgs a) {
+    __shared__ __attribute__((aligned(16))) float P[4][BWD_RSMAX * 16][P_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int U = a.U;
+    const int KC4 = U >> 2;                 // 16-wide chunks over K = 4U
+    const int cpw = KC4 >> 2;               // chunks per wave (U % 64 == 0 -> multiple of 4)
+    const int nnt = U >> 4;
+    int nt, rt;
+    {
+        const int b = blockIdx.x;
+        if ((nnt & 7) == 0) {
+            const int per_xcd = nnt >> 3, xcd = b & 7, slot = b >> 3;
+            nt = xcd * per_xcd + slot / a.RT;
+            rt = slot % a.RT;
+        } else {
+            nt = b / a.RT;
+            rt = b % a.RT;
+        }
+    }
+    int rs0, nrs;
+    rt_range(rt, a.total_rs, a.RT, rs0, nrs);
+
+    if (a.has_gemm) {
+        const f32x4* Af = reinterpret_cast<const f32x4*>(a.dzfrag_in);
+        const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wb) + (long)nt * KC4 * 64;
+        switch (nrs) {
+            case 1: bwd_gemm<1>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
+            case 2: bwd_gemm<2>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
+            case 3: bwd_gemm<3>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
+            default: bwd_gemm<4>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
+        }
+    }
+    __syncthreads();
+
+    const int nrows = nrs * 16;
+    for (int item = tid; item < nrows * 4; item += 256) {
+        const int r = item >> 2, q = item & 3;
+        const int row = rs0 * 16 + r;
+        if (row >= a.M) continue;
+        const int u = nt * 16 + q * 4;
+        const long o = (long)row * U + u;
+        // dH_t = dz[t+1]·Wh^T, or dh_final for rows that are not active at t+1
+        f4 dH = zero4();
+        if (a.has_gemm) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const f4 p = ldf4(&P[w][r][q * 4]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dH.v[e] += p.v[e];
+            }
+        }
+        const int len = a.lens ? a.lens[row] : a.n_steps;
+        const bool next_active = (a.t + 1 < a.n_steps) && (a.t + 1 < len);
+        if (!next_active && a.dh_final) {
+            const f4 e4 = ldf4(a.dh_final + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dH.v[e] += e4.v[e];
+        }
+        if (a.mode == 1) {
+            stf4(a.dh0 + o, dH);
+            continue;
+        }
+        float* dzr = a.dz + (long)row * a.dzrs + u;
+        const int KCx = U >> 2;
+        if (a.t < len) {
+            const float* zr = a.z + (long)row * a.zrs + u;
+            const f4 zi = ldf4(zr), zj = ldf4(zr + U), zf = ldf4(zr + 2L * U), zo = ldf4(zr + 3L * U);
+            const f4 cp = a.c_prev ? ldf4(a.c_prev + o) : zero4();
+            const f4 cc = ldf4(a.c + o);
+            if (a.dhout) {
+                const f4 e4 = ldf4(a.dhout + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dH.v[e] += e4.v[e];
+            }
+            const f4 dcv = ldf4(a.dC + o);
+            f4 g[4], dcn;
+            lstm_gate_bwd4(zi, zj, zf, zo, cp, cc, dH, dcv, g[0], g[1], g[2], g[3], dcn);
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                stf4(dzr + (long)gg * U, g[gg]);
+                stf4(a.dzfrag_out + frag_off(row, gg * U + u, KCx), g[gg]);
+            }
+            stf4(a.dC + o, dcn);
+        } else {
+            const f4 zz = zero4();
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                stf4(dzr + (long)gg * U, zz);
+                stf4(a.dzfrag_out + frag_off(row, gg * U + u, KCx), zz);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Host drivers (called from d2p_lstm_seq_fwd / d2p_lstm_seq_bwd in lstm.hip)
+// ---------------------------------------------------------------------------------------
+static inline int pick_rt(int total_rs, int col_tiles, int rsmax) {
+    int rt = (256 + col_tiles / 2) / col_tiles;           // aim at one workgroup per CU
+    if (rt < 1) rt = 1;
+    const int need = (total_rs + rsmax - 1) / rsmax;      // keep tiles within the register budget
+    if (rt < need) rt = need;
+    if (rt > total_rs) rt = total_rs;
+    return rt;
+}
+
+bool d2p_lstm_fused_eligible(int M, int U) {
+    return M > 0 && (U == 64 || U == 128 || U == 256 || U == 512);
+}
+
+size_t d2p_lstm_fused_ws_bytes(int M, int U) {
+    const size_t Mp = (size_t)((M + 15) / 16) * 16;
+    // max over forward (Wf + 2 hfrag + 2 hs) and backward (Wb + 2 dzfrag + dC)
+    const size_t fwd = (size_t)4 * U * U + 2 * Mp * U + 2 * (size_t)M * U;
+    const size_t bwd = (size_t)4 * U * U + 2 * Mp * 4 * U + (size_t)M * U;
+    return (fwd > bwd ? fwd : bwd) * sizeof(float);
+}
+
+template <int CPW>
+static void launch_fwd(const StepFwdArgs& a, int blocks, hipStream_t st) {
+    hipLaunchKernelGGL((lstm_step_fwd_kernel<CPW>), dim3(blocks), dim3(256), 0, st, a);
+}
+
+int d2p_lstm_fused_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, const float* Wh,
+                       const float* h0, const float* c0, const int* lens, float* hout, float* cs,
+                       float* h_final, float* c_final, float* ws, hipStream_t st) {
+    const size_t MU = (size_t)M * U;
+    const int total_rs = (M + 15) / 16;
+    const size_t Mp = (size_t)total_rs * 16;
+    float* Wf = ws;
+    float* hfrag[2] = {Wf + (size_t)4 * U * U, Wf + (size_t)4 * U * U + Mp * U};
+    float* hs[2] = {hfrag[1] + Mp * U, hfrag[1] + Mp * U + MU};
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(pack_blocks((long)U * U / 4)), dim3(256), 0, st, U, Wh,
+                       (float4*)Wf);
+    D2P_LAUNCH_CHECK("pack_w_fwd");
+    if (h0) {
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(pack_blocks((long)Mp * U / 4)), dim3(256), 0, st, M, U,
+                           total_rs, h0, (float4*)hfrag[0]);
+        D2P_LAUNCH_CHECK("pack_rows(h0)");
+    }
+    const int nct = U / 8;
+    const int RT = pick_rt(total_rs, nct, FWD_RSMAX);
+    const int blocks = nct * RT;
+    const float* h_prev = h0;
+    const float* c_prev = c0;
+    for (int t = 0; t < n_steps; ++t) {
+        StepFwdArgs a;
+        a.M = M; a.U = U; a.total_rs = total_rs; a.RT = RT; a.t = t;
+        a.has_h = (t > 0 || h0) ? 1 : 0;
+        a.hfrag_in = (const float4*)hfrag[t & 1];
+        a.Wf = (const float4*)Wf;
+        a.z = z + (long)t * zts; a.zrs = zrs;
+        a.c_prev = c_prev;
+        a.hs_prev = lens ? h_prev : nullptr;
+        a.lens = lens;
+        a.c_out = cs + t * MU;
+        a.hout = hout + t * MU;
+        a.hs_out = lens ? hs[t & 1] : nullptr;
+        a.hfrag_out = hfrag[(t + 1) & 1];
+        {
+            D2pProfScope prof(st, D2P_PROF_LSTM_STEP_FWD, 2.0 * M * 4.0 * U * U);
+            switch (U) {
+                case 64: launch_fwd<1>(a, blocks, st); break;
+                case 128: launch_fwd<2>(a, blocks, st); break;
+                case 256: launch_fwd<4>(a, blocks, st); break;
+                default: launch_fwd<8>(a, blocks, st); break;
+            }
+        }
+        D2P_LAUNCH_CHECK("lstm_step_fwd");
+        h_prev = lens ? hs[t & 1] : hout + t * MU;
+        c_prev = cs + t * MU;
+    }
+    if (h_final) {
+        if (h_prev) D2P_HIP(hipMemcpyAsync(h_final, h_prev, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
+        else D2P_HIP(hipMemsetAsync(h_final, 0, MU * sizeof(float), st));
+    }
+    if (c_final) {
+        if (c_prev) D2P_HIP(hipMemcpyAsync(c_final, c_prev, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
+        else D2P_HIP(hipMemsetAsync(c_final, 0, MU * sizeof(float), st));
+    }
+    return D2P_OK;
+}
+
+int d2p_lstm_fused_bwd(int M, int U, int n_steps, const float* z, long zrs, long zts, const float* Wh,
+                       const float* c0, const int* lens, const float* cs, const float* dhout,
+                       const float* dh_final, const float* dc_final, float* dz, float* dh0,
+                       float* dc0, float* ws, hipStream_t st) {
+    const size_t MU = (size_t)M * U;
+    const int total_rs = (M + 15) / 16;
+    const size_t Mp = (size_t)total_rs * 16;
+    float* Wb = ws;
+    float* dzfrag[2] = {Wb + (size_t)4 * U * U, Wb + (size_t)4 * U * U + Mp * 4 * U};
+    float* dC = dzfrag[1] + Mp * 4 * U;
+    hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(pack_blocks((long)U * U / 4)), dim3(256), 0, st, U, Wh,
+                       (float4*)Wb);
+    D2P_LAUNCH_CHECK("pack_w_bwd");
+    if (dc_final) D2P_HIP(hipMemcpyAsync(dC, dc_final, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else D2P_HIP(hipMemsetAsync(dC, 0, MU * sizeof(float), st));
+    const int nnt = U / 16;
+    const int RT = pick_rt(total_rs, nnt, BWD_RSMAX);
+    const int blocks = nnt * RT;
+    // steps n-1 .. 0 (mode 0), then the final dh0 GEMM (mode 1, t = -1)
+    for (int t = n_steps - 1; t >= -1; --t) {
+        if (t < 0 && !dh0) break;
+        StepBwdArgs a;
+        a.M = M; a.U = U; a.total_rs = total_rs; a.RT = RT; a.t = t; a.n_steps = n_steps;
+        a.has_gemm = (t + 1 < n_steps) ? 1 : 0;
+        a.mode = t < 0 ? 1 : 0;
+        a.dzfrag_in = (const float4*)dzfrag[(t + 1) & 1];
+        a.Wb = (const float4*)Wb;
+        a.z = t >= 0 ? z + (long)t * zts : nullptr; a.zrs = zrs;
+        a.c_prev = t > 0 ? cs + (size_t)(t - 1) * MU : c0;
+        a.c = t >= 0 ? cs + (size_t)t * MU : nullptr;
+        a.dhout = (dhout && t >= 0) ? dhout + (size_t)t * MU : nullptr;
+        a.dh_final = dh_final;
+        a.lens = lens;
+        a.dC = dC;
+        a.dz = t >= 0 ? dz + (long)t * zts : nullptr; a.dzrs = zrs;
+        a.dzfrag_out = dzfrag[t & 1];
+        a.dh0 = dh0;
+        {
+            D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, a.has_gemm ? 2.0 * M * 4.0 * U * U : 0.0);
+            hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), dim3(blocks), dim3(256), 0, st, a);
+        }
+        D2P_LAUNCH_CHECK("lstm_step_bwd");
+    }
+    if (dc0) D2P_HIP(hipMemcpyAsync(dc0, dC, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return D2P_OK;
+}

@@ -178,6 +178,11 @@ def bn_update_moving(mean, var, moving_mean, moving_var, decay=0.9):
 
 
 # ---------------------------------------------------------------- LSTM
+def set_lstm_fused(on):
+    """Process-global knob: fused recurrent-step kernels (default) vs GEMM + gate per step."""
+    call.d2p_lstm_set_fused(1 if on else 0)
+
+
 def lstm_seq_fwd(z, z_row_stride, z_t_stride, M, U, n_steps, Wh, h0, c0, lens, hout, cs,
                  h_final, c_final):
     ws, wsb = SCRATCH.get(call.d2p_lstm_ws_bytes(M, U))

@@ -145,6 +145,10 @@ int d2p_lstm_gate_bwd(int M, int U, const float* z, long z_row_stride, const flo
  * cs: [n_steps, M, U] cell state after each step.  h_final/c_final: [M,U].
  * ws: >= d2p_lstm_ws_bytes(M,U). */
 size_t d2p_lstm_ws_bytes(int M, int U);
+/* Tuning knob (process-global): 1 (default) = fused recurrent-step kernels (one launch per
+ * step: h·Wh MFMA + gates) when U in {64,128,256,512} and ws >= d2p_lstm_ws_bytes;
+ * 0 = generic GEMM + gate kernel per step.  Both produce the same results (tests compare). */
+int d2p_lstm_set_fused(int on);
 int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_stride, long z_t_stride,
                      const float* Wh, const float* h0, const float* c0, const int* lens,
                      float* hout, float* cs, float* h_final, float* c_final,

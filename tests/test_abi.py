@@ -36,7 +36,7 @@ def test_library_loads_and_exports_everything(d2p_lib):
 
 
 def test_workspace_queries_need_no_gpu(d2p_lib):
-    assert d2p_lib.d2p_lstm_ws_bytes(320, 512) == 3 * 320 * 512 * 4
+    assert d2p_lib.d2p_lstm_ws_bytes(320, 512) >= 3 * 320 * 512 * 4
     assert d2p_lib.d2p_gemm_ws_bytes(144, 16, 102400) > 0      # conv1 wgrad needs split-K
     assert d2p_lib.d2p_gemm_ws_bytes(6400, 2048, 512) == 0
     assert d2p_lib.d2p_bn_ws_bytes(6400 * 16, 16, 10) > 0

@@ -258,10 +258,55 @@ def _lstm_case(K, M, T, I, U, masked, with_init, strided):
         close(dc0, c0.grad, **tol)
 
 
+@pytest.mark.parametrize('fused', [True, False])
 @pytest.mark.parametrize('masked,with_init,strided', [(True, False, True), (True, True, False),
                                                       (False, True, False), (False, False, False)])
-def test_lstm_seq_fwd_bwd(K, masked, with_init, strided):
-    _lstm_case(K, M=12, T=6, I=20, U=64, masked=masked, with_init=with_init, strided=strided)
+def test_lstm_seq_fwd_bwd(K, masked, with_init, strided, fused):
+    K.set_lstm_fused(fused)
+    try:
+        _lstm_case(K, M=12, T=6, I=20, U=64, masked=masked, with_init=with_init, strided=strided)
+    finally:
+        K.set_lstm_fused(True)
+
+
+@pytest.mark.parametrize('M,U', [(35, 128), (80, 256), (48, 512)])
+def test_lstm_seq_fused_other_widths(K, M, U):
+    _lstm_case(K, M=M, T=4, I=12, U=U, masked=True, with_init=True, strided=False)
+    _lstm_case(K, M=M, T=4, I=12, U=U, masked=False, with_init=False, strided=False)
+
+
+@pytest.mark.parametrize('M,masked', [(320, True), (320, False), (32, False), (400, True)])
+def test_lstm_fused_equals_unfused_at_full_size(K, M, masked):
+    """BASELINE config sizes (M = B*k = 320 rows, U = 512; M = 32 program rows; M = 400 for
+    k=25): the fused recurrent-step path must reproduce the GEMM + gate-kernel path."""
+    T, U = 7, 512
+    g = torch.Generator().manual_seed(5)
+    z0 = (torch.rand(T * M, 4 * U, generator=g) * 2 - 1).cuda()
+    Wh = ((torch.rand(U, 4 * U, generator=g) * 2 - 1) * 0.05).cuda()
+    h0 = (torch.rand(M, U, generator=g) * 2 - 1).cuda()
+    c0 = (torch.rand(M, U, generator=g) * 2 - 1).cuda()
+    lens = torch.randint(0, T + 1, (M,), generator=g).int().cuda() if masked else None
+    dhout = (torch.rand(T, M, U, generator=g) * 2 - 1).cuda()
+    dhf = (torch.rand(M, U, generator=g) * 2 - 1).cuda()
+    dcf = (torch.rand(M, U, generator=g) * 2 - 1).cuda()
+    res = []
+    for fused in (True, False):
+        K.set_lstm_fused(fused)
+        z = z0.clone()
+        hout, cs = torch.empty(T, M, U, device='cuda'), torch.empty(T, M, U, device='cuda')
+        hf, cf = torch.empty(M, U, device='cuda'), torch.empty(M, U, device='cuda')
+        K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, T, Wh, h0, c0, lens, hout, cs, hf, cf)
+        dz = torch.zeros_like(z)
+        dh0, dc0 = torch.empty(M, U, device='cuda'), torch.empty(M, U, device='cuda')
+        K.lstm_seq_bwd(z, 4 * U, M * 4 * U, M, U, T, Wh, c0, lens, cs, dhout, dhf, dcf, dz, dh0, dc0)
+        res.append((hout, cs, hf, cf, dz, dh0, dc0, z))
+    K.set_lstm_fused(True)
+    names = ('hout', 'cs', 'h_final', 'c_final', 'dz', 'dh0', 'dc0', 'z')
+    for n, a, b in zip(names, res[0], res[1]):
+        if masked and n == 'z':
+            continue          # masked rows: the unfused path still accumulates h·Wh into unused z rows
+        err = (a - b).abs().max().item()
+        assert err <= 2e-5 * max(1.0, b.abs().max().item()), (n, err)
 
 
 def test_lstm_known_answer_scalar_cell(K):

@@ -149,7 +149,7 @@ def test_trainer_steps_match_oracle_adam():
     # itself is checked exactly against the oracle in test_kernels_gpu.py).
     for n in p:
         diff = np.abs(got[n] - p[n].numpy())
-        assert (diff <= 2e-4).mean() >= 0.98, (n, float((diff <= 2e-4).mean()))
+        assert (diff > 2e-4).sum() <= max(2, 0.02 * diff.size), (n, int((diff > 2e-4).sum()), diff.size)
         assert diff.max() <= 3 * 1.01e-3 * 2, n
     assert losses[2] < losses[0]
     assert tr.global_step == 3
