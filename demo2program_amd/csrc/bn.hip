@@ -35,7 +35,8 @@ static inline BnPlan bn_plan(int R, int C, int G) {
 extern "C" size_t d2p_bn_ws_bytes(int R, int C, int G) {
     if (R <= 0 || C <= 0 || G <= 0) return 0;
     BnPlan p = bn_plan(R, C, G);
-    return (size_t)G * p.S * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(float);
+    return (size_t)G * p.S * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(double) +
+           (size_t)G * C * 2 * sizeof(float);
 }
 
 // partial[((g*S + s)*C + c)*2 + {0,1}] = sum over this block's rows of (a, b) where
@@ -86,44 +87,64 @@ bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, co
     }
 }
 
+// One wavefront per (group, channel): lanes stride over the S partials, wave-reduce in fp64.
 __global__ void __launch_bounds__(256)
 bn_finalize_fwd_kernel(int n, int C, int G, int S, const double* partial, float* mean, float* rstd,
                        float* var_out) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (idx >= G * C) return;
     const int g = idx / C, c = idx - g * C;
     double a = 0.0, b = 0.0;
-    for (int s = 0; s < S; ++s) {
+    for (int s = lane; s < S; s += 64) {
         const double* p = partial + (((long)g * S + s) * C + c) * 2;
         a += p[0];
         b += p[1];
     }
-    const double mu = a / n;
-    double var = b / n - mu * mu;   // biased variance
-    if (var < 0.0) var = 0.0;
-    mean[idx] = (float)mu;
-    rstd[idx] = (float)(1.0 / sqrt(var + BN_EPS));
-    if (var_out) var_out[idx] = (float)var;
+    a = wave_reduce_sum(a);
+    b = wave_reduce_sum(b);
+    if (lane == 0) {
+        const double mu = a / n;
+        double var = b / n - mu * mu;   // biased variance
+        if (var < 0.0) var = 0.0;
+        mean[idx] = (float)mu;
+        rstd[idx] = (float)(1.0 / sqrt(var + BN_EPS));
+        if (var_out) var_out[idx] = (float)var;
+    }
 }
 
-// m12[(g*C+c)*2 + {0,1}] = (mean_g(dy), mean_g(dy*xhat)); dgamma/dbeta summed over groups.
+// m12[(g*C+c)*2 + {0,1}] = (mean_g(dy), mean_g(dy*xhat)); gsum[(g*C+c)*2 + {0,1}] = raw sums
 __global__ void __launch_bounds__(256)
-bn_finalize_bwd_kernel(int n, int C, int G, int S, const double* partial, float* m12,
-                       float* dgamma, float* dbeta) {
+bn_finalize_bwd_kernel(int n, int C, int G, int S, const double* partial, float* m12, double* gsum) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (idx >= G * C) return;
+    const int g = idx / C, c = idx - g * C;
+    double a = 0.0, b = 0.0;
+    for (int s = lane; s < S; s += 64) {
+        const double* p = partial + (((long)g * S + s) * C + c) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    a = wave_reduce_sum(a);
+    b = wave_reduce_sum(b);
+    if (lane == 0) {
+        m12[(long)idx * 2 + 0] = (float)(a / n);
+        m12[(long)idx * 2 + 1] = (float)(b / n);
+        gsum[(long)idx * 2 + 0] = a;
+        gsum[(long)idx * 2 + 1] = b;
+    }
+}
+
+// dgamma / dbeta: sum over the groups in group order (gamma, beta are shared by all groups)
+__global__ void __launch_bounds__(256)
+bn_dparam_kernel(int C, int G, const double* gsum, float* dgamma, float* dbeta) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    double sg = 0.0, sb = 0.0;
+    double sb = 0.0, sg = 0.0;
     for (int g = 0; g < G; ++g) {
-        double a = 0.0, b = 0.0;
-        for (int s = 0; s < S; ++s) {
-            const double* p = partial + (((long)g * S + s) * C + c) * 2;
-            a += p[0];
-            b += p[1];
-        }
-        m12[((long)g * C + c) * 2 + 0] = (float)(a / n);
-        m12[((long)g * C + c) * 2 + 1] = (float)(b / n);
-        sb += a;
-        sg += b;
+        sb += gsum[((long)g * C + c) * 2 + 0];
+        sg += gsum[((long)g * C + c) * 2 + 1];
     }
     if (dgamma) dgamma[c] = (float)sg;
     if (dbeta) dbeta[c] = (float)sb;
@@ -215,7 +236,7 @@ extern "C" int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, 
                        p.lanes_c, p.row_lanes, x, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, partial);
     D2P_LAUNCH_CHECK("bn_partial_fwd");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(G * C, 256)), dim3(256), 0, st, n, C, G,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, st, n, C, G,
                        p.S, partial, mean, rstd, var_out);
     D2P_LAUNCH_CHECK("bn_finalize_fwd");
     const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma |
@@ -245,13 +266,17 @@ extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, 
     BnPlan p = bn_plan(R, C, G);
     const int n = R / G;
     double* partial = (double*)ws;
-    float* m12 = (float*)((char*)ws + (size_t)G * p.S * C * 2 * sizeof(double));
+    double* gsum = partial + (size_t)G * p.S * C * 2;
+    float* m12 = (float*)(gsum + (size_t)G * C * 2);
     hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
                        p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial);
     D2P_LAUNCH_CHECK("bn_partial_bwd");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, n, C, G,
-                       p.S, partial, m12, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, st, n, C, G,
+                       p.S, partial, m12, gsum);
     D2P_LAUNCH_CHECK("bn_finalize_bwd");
+    hipLaunchKernelGGL(bn_dparam_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, G, gsum, dgamma,
+                       dbeta);
+    D2P_LAUNCH_CHECK("bn_dparam");
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks((long)R * C)), dim3(256), 0, st, (long)R,
                        C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx);
     D2P_LAUNCH_CHECK("bn_apply_bwd");

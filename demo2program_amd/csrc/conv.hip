@@ -48,6 +48,19 @@ struct Im2colElem {
     const T* x;
     ConvGeom g;
     int vec;   // Cin % 4 == 0 and base aligned
+    // branch-free variant (vec path only): clamped address + select
+    __device__ __forceinline__ bool gather4_fast(int m, int kk, bool ok, float (&v)[4]) const {
+        const int howo = g.Ho * g.Wo;
+        const int n = m / howo;
+        const int rem = m - n * howo;
+        const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+        const int tap = kk / g.Cin, c = kk - tap * g.Cin;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = oy * 2 - g.pt + ky, ix = ox * 2 - g.pl + kx;
+        ok = ok & (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.W);
+        ld4(x + (ok ? (((long)n * g.H + iy) * g.W + ix) * g.Cin + c : 0L), v);
+        return ok;
+    }
     __device__ __forceinline__ void gather4(int m, int kk, int kklim, float (&v)[4]) const {
         // 4 consecutive kk for one m
         const int howo = g.Ho * g.Wo;
@@ -86,9 +99,13 @@ struct Im2colKC {   // fwd A operand: x = m (rows), k = kk
     static constexpr bool KCONTIG = true;
     Im2colElem<T> e;
     int Mrows;
-    __device__ __forceinline__ void load4(int x, int k, int klim, float (&v)[4]) const {
-        if (x >= Mrows) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
+    bool fast_ok(int K) const { return e.vec && Mrows > 0 && K >= 4; }
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
+        if (FAST) return e.gather4_fast(x, k, (x < Mrows) & (k < klim), v);
+        if (x >= Mrows) { v[0] = v[1] = v[2] = v[3] = 0.f; return true; }
         e.gather4(x, k, klim, v);
+        return true;
     }
 };
 
@@ -97,9 +114,13 @@ struct Im2colXC {   // wgrad A operand (A^T·B form): x = kk (output rows), k = 
     static constexpr bool KCONTIG = false;
     Im2colElem<T> e;
     int KK;         // 9*Cin
-    __device__ __forceinline__ void load4(int x, int k, int klim, float (&v)[4]) const {
-        if (k >= klim) { v[0] = v[1] = v[2] = v[3] = 0.f; return; }
+    bool fast_ok(int K) const { return e.vec && K > 0; }
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
+        if (FAST) return e.gather4_fast(k, x, (x < KK) & (k < klim), v);
+        if (k >= klim) { v[0] = v[1] = v[2] = v[3] = 0.f; return true; }
         e.gather4(k, x, KK, v);
+        return true;
     }
 };
 
@@ -110,9 +131,11 @@ struct ColTKC {
     const float* dy;
     ConvGeom g;
     int Prows;
-    __device__ __forceinline__ void load4(int x, int k, int klim, float (&v)[4]) const {
+    bool fast_ok(int K) const { return false; }   // parity test keeps this one on the guarded path
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
         v[0] = v[1] = v[2] = v[3] = 0.f;
-        if (x >= Prows || k >= klim) return;
+        if (x >= Prows || k >= klim) return true;
         const int hw = g.H * g.W;
         const int n = x / hw;
         const int rem = x - n * hw;
@@ -121,10 +144,11 @@ struct ColTKC {
         const int tap = k / g.Cout, co = k - tap * g.Cout;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int ty = iy + g.pt - ky, tx = ix + g.pl - kx;
-        if (ty < 0 || tx < 0 || (ty & 1) || (tx & 1)) return;
+        if (ty < 0 || tx < 0 || (ty & 1) || (tx & 1)) return true;
         const int oy = ty >> 1, ox = tx >> 1;
-        if (oy >= g.Ho || ox >= g.Wo) return;
+        if (oy >= g.Ho || ox >= g.Wo) return true;
         ld4(dy + (((long)n * g.Ho + oy) * g.Wo + ox) * g.Cout + co, v);
+        return true;
     }
 };
 
@@ -133,11 +157,14 @@ struct WDgradKC {
     static constexpr bool KCONTIG = true;
     const float* w;
     int Cin, Cout;
-    __device__ __forceinline__ void load4(int x, int k, int klim, float (&v)[4]) const {
+    bool fast_ok(int K) const { return false; }
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
         v[0] = v[1] = v[2] = v[3] = 0.f;
-        if (x >= Cin || k >= klim) return;
+        if (x >= Cin || k >= klim) return true;
         const int tap = k / Cout, co = k - tap * Cout;
         ld4(w + ((long)tap * Cin + x) * Cout + co, v);
+        return true;
     }
 };
 

@@ -102,3 +102,39 @@ extern "C" int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float
     D2P_LAUNCH_CHECK("colsum_stage2");
     return D2P_OK;
 }
+
+// ---- K6 backward: embedding scatter-add as a one-hot TN GEMM ---------------------------
+// dtable[v, e] = sum_i [ids[i] == v] * dout[i, e]  =  OneHot^T · dout.
+// Replaces the IndexedSlices gradient of tf.nn.embedding_lookup (models/model_full.py:294).
+// Out-of-range ids (the <s> id token_dim+1) match no row -> no gradient, as in TF.
+// The products are 1.0*x (exact) and the sum runs on the MFMA pipe with split-K over the id
+// list, combined in a fixed order: deterministic, unlike float atomics.
+struct OneHotXC {   // A operand, A^T·B form: x = table row v, k = id position i
+    static constexpr bool KCONTIG = false;
+    const int* ids;
+    int rows;
+    bool fast_ok(int K) const { return false; }
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
+        const int id = (k < klim) ? ids[k] : -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (x + j < rows && id == x + j) ? 1.f : 0.f;
+        return true;
+    }
+};
+
+extern "C" size_t d2p_embedding_scatter_ws_bytes(int n, int rows, int E) {
+    if (n <= 0 || rows <= 0 || E <= 0) return 0;
+    return d2p_plan_ws_bytes(rows, E, n);
+}
+
+extern "C" int d2p_embedding_scatter_add_oob0(int n, int rows, int E, const int* ids,
+                                              const float* dout, float* dtable, void* ws,
+                                              size_t ws_bytes, d2p_stream_t stream) {
+    D2P_REQUIRE(n >= 0 && rows > 0 && E > 0, D2P_EINVAL, "embedding scatter: bad sizes");
+    D2P_REQUIRE(dtable && (n == 0 || (ids && dout)), D2P_EINVAL, "embedding scatter: null pointer");
+    OneHotXC al{ids, rows};
+    DenseXC bl{dout, E, E, vec_ok(dout, E)};
+    EpiDense ep{dtable, E, nullptr, 0, 0};
+    return d2p_launch_gemm(al, bl, ep, rows, E, n, ws, ws_bytes, as_stream(stream), "embedding_scatter");
+}

@@ -36,10 +36,22 @@ struct DenseKC {  // elem(x,k) = p[x*ld + k]
     long ld;
     int X;
     int vec;  // ld % 4 == 0 and p 16-byte aligned
-    __device__ __forceinline__ void load4(int x, int k, int klim, float (&v)[4]) const {
+    // FAST: vec && K % 4 == 0: one unconditional 16-byte load from a clamped address, then a
+    // select -- no control flow, so hipcc keeps counted vmcnt waits across the K loop.
+    bool fast_ok(int K) const { return vec && K >= 4 && (K % 4) == 0 && X > 0; }
+    // Returns false when the caller must treat v as zeros (FAST defers the select to the
+    // LDS-store point so that nothing consumes the load result early).
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
+        if (FAST) {
+            const bool ok = (x < X) & (k < klim);
+            const float4 t = *reinterpret_cast<const float4*>(p + (ok ? (long)x * ld + k : 0L));
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            return ok;
+        }
         if (x >= X) {
             v[0] = v[1] = v[2] = v[3] = 0.f;
-            return;
+            return true;
         }
         const float* q = p + (long)x * ld + k;
         if (vec && k + 3 < klim) {
@@ -49,6 +61,7 @@ struct DenseKC {  // elem(x,k) = p[x*ld + k]
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = (k + j < klim) ? q[j] : 0.f;
         }
+        return true;
     }
 };
 
@@ -58,10 +71,18 @@ struct DenseXC {  // elem(x,k) = p[k*ld + x]
     long ld;
     int X;
     int vec;
-    __device__ __forceinline__ void load4(int x, int k, int klim, float (&v)[4]) const {
+    bool fast_ok(int K) const { return vec && X >= 4 && (X % 4) == 0 && K > 0; }
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
+        if (FAST) {
+            const bool ok = (x < X) & (k < klim);
+            const float4 t = *reinterpret_cast<const float4*>(p + (ok ? (long)k * ld + x : 0L));
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            return ok;
+        }
         if (k >= klim) {
             v[0] = v[1] = v[2] = v[3] = 0.f;
-            return;
+            return true;
         }
         const float* q = p + (long)k * ld + x;
         if (vec && x + 3 < X) {
@@ -71,6 +92,7 @@ struct DenseXC {  // elem(x,k) = p[k*ld + x]
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = (x + j < X) ? q[j] : 0.f;
         }
+        return true;
     }
 };
 
@@ -93,7 +115,7 @@ struct EpiDense {
 };
 
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, class AL, class BL, class EP>
+template <int BM, int BN, bool FAST, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial) {
     constexpr int BK = D2P_GEMM_BK;
@@ -124,41 +146,43 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float ra[TM][4], rb[TN][4];
+    // Two register staging sets: the loads of K-slab kt+2 are issued before the MFMAs of slab
+    // kt and only written to LDS after the MFMAs of slab kt+1, so each global load has two
+    // slabs of MFMA time (plus whatever other resident workgroups contribute) to land.
+    float ra0[TM][4], rb0[TN][4], ra1[TM][4], rb1[TN][4];
+    bool oa0[TM], ob0[TN], oa1[TM], ob1[TN];
 
-    auto gload = [&](int kt) {
-        const int k0 = kbeg + kt * BK;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int q = tid + i * 256;
-            if (AL::KCONTIG) al.load4(m0 + (q >> 2), k0 + (q & 3) * 4, kend, ra[i]);
-            else al.load4(m0 + (q % (BM / 4)) * 4, k0 + q / (BM / 4), kend, ra[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int q = tid + i * 256;
-            if (BL::KCONTIG) bl.load4(n0 + (q >> 2), k0 + (q & 3) * 4, kend, rb[i]);
-            else bl.load4(n0 + (q % (BN / 4)) * 4, k0 + q / (BN / 4), kend, rb[i]);
-        }
-    };
-    auto sstore = [&](int buf) {
-        float* As = smem + buf * (A_SZ + B_SZ);
-        float* Bs = As + A_SZ;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int q = tid + i * 256;
-            float4 t = make_float4(ra[i][0], ra[i][1], ra[i][2], ra[i][3]);
-            if (AL::KCONTIG) *reinterpret_cast<float4*>(&As[(q >> 2) * A_LD + (q & 3) * 4]) = t;
-            else *reinterpret_cast<float4*>(&As[(q / (BM / 4)) * A_LD + (q % (BM / 4)) * 4]) = t;
-        }
-#pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int q = tid + i * 256;
-            float4 t = make_float4(rb[i][0], rb[i][1], rb[i][2], rb[i][3]);
-            if (BL::KCONTIG) *reinterpret_cast<float4*>(&Bs[(q >> 2) * B_LD + (q & 3) * 4]) = t;
-            else *reinterpret_cast<float4*>(&Bs[(q / (BN / 4)) * B_LD + (q % (BN / 4)) * 4]) = t;
-        }
-    };
+#define D2P_GLOAD(RA, RB, OA, OB, kt)                                                                   \
+    {                                                                                           \
+        const int k0 = kbeg + (kt) * BK;                                                        \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+            const int q = tid + i * 256;                                                        \
+            if (AL::KCONTIG) OA[i] = al.template load4<FAST>(m0 + (q >> 2), k0 + (q & 3) * 4, kend, RA[i]);            \
+            else OA[i] = al.template load4<FAST>(m0 + (q % (BM / 4)) * 4, k0 + q / (BM / 4), kend, RA[i]);             \
+        }                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                        \
+            const int q = tid + i * 256;                                                        \
+            if (BL::KCONTIG) OB[i] = bl.template load4<FAST>(n0 + (q >> 2), k0 + (q & 3) * 4, kend, RB[i]);            \
+            else OB[i] = bl.template load4<FAST>(n0 + (q % (BN / 4)) * 4, k0 + q / (BN / 4), kend, RB[i]);             \
+        }                                                                                       \
+    }
+#define D2P_SSTORE(RA, RB, OA, OB, buf)                                                                 \
+    {                                                                                           \
+        float* As = smem + (buf) * (A_SZ + B_SZ);                                               \
+        float* Bs = As + A_SZ;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
+            const int q = tid + i * 256;                                                        \
+            float4 t = make_float4(OA[i] ? RA[i][0] : 0.f, OA[i] ? RA[i][1] : 0.f, OA[i] ? RA[i][2] : 0.f, OA[i] ? RA[i][3] : 0.f);                     \
+            if (AL::KCONTIG) *reinterpret_cast<float4*>(&As[(q >> 2) * A_LD + (q & 3) * 4]) = t; \
+            else *reinterpret_cast<float4*>(&As[(q / (BM / 4)) * A_LD + (q % (BM / 4)) * 4]) = t; \
+        }                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                        \
+            const int q = tid + i * 256;                                                        \
+            float4 t = make_float4(OB[i] ? RB[i][0] : 0.f, OB[i] ? RB[i][1] : 0.f, OB[i] ? RB[i][2] : 0.f, OB[i] ? RB[i][3] : 0.f);                     \
+            if (BL::KCONTIG) *reinterpret_cast<float4*>(&Bs[(q >> 2) * B_LD + (q & 3) * 4]) = t; \
+            else *reinterpret_cast<float4*>(&Bs[(q / (BN / 4)) * B_LD + (q % (BN / 4)) * 4]) = t; \
+        }                                                                                       \
+    }
     auto compute = [&](int buf) {
         const float* As = smem + buf * (A_SZ + B_SZ);
         const float* Bs = As + A_SZ;
@@ -198,20 +222,28 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         }
     };
 
+    // loads past the end of K return zeros (klim checks), so the steady-state loop prefetches
+    // unconditionally; slabs nk and nk+1 are never stored.
     if (nk > 0) {
-        gload(0);
-        sstore(0);
+        D2P_GLOAD(ra0, rb0, oa0, ob0, 0)
+        D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
+        D2P_GLOAD(ra1, rb1, oa1, ob1, 1)
         __syncthreads();
-        int buf = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            const bool more = (kt + 1 < nk);
-            if (more) gload(kt + 1);
-            compute(buf);
-            if (more) sstore(buf ^ 1);
+        for (int kt = 0; kt < nk; kt += 2) {
+            D2P_GLOAD(ra0, rb0, oa0, ob0, kt + 2)  // in flight during compute(kt) and compute(kt+1)
+            compute(0);
+            if (kt + 1 < nk) D2P_SSTORE(ra1, rb1, oa1, ob1, 1)
             __syncthreads();
-            buf ^= 1;
+            if (kt + 1 < nk) {
+                D2P_GLOAD(ra1, rb1, oa1, ob1, kt + 3)
+                compute(1);
+                if (kt + 2 < nk) D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
+                __syncthreads();
+            }
         }
     }
+#undef D2P_GLOAD
+#undef D2P_SSTORE
 
     const bool split = gridDim.z > 1;
 #pragma unroll
@@ -258,9 +290,9 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
     p.splits = 1;
     p.k_per_split = K;
     const long tiles = p.big ? t128 : t64;
-    if (allow_split && tiles < 128 && K >= 1024) {
-        long want = (512 + tiles - 1) / tiles;           // aim at ~512 workgroups
-        long maxs = K / 256;                             // keep >= 256 of K per split
+    if (allow_split && tiles <= 512 && K >= 1024) {
+        long want = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
+        long maxs = K / 512;                             // keep >= 512 of K per split
         long s = want < maxs ? want : maxs;
         if (s > 1) {
             int kps = (int)((K + s - 1) / s);
@@ -294,14 +326,23 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
             partial = (float*)ws;
         }
     }
+    const bool fast = al.fast_ok(K) && bl.fast_ok(K);
     if (p.big) {
         dim3 grid(ceil_div(M, 128) * ceil_div(N, 128), 1, p.splits);
-        hipLaunchKernelGGL((gemm_mfma_kernel<128, 128, AL, BL, EP>), grid, dim3(256), 0, st,
-                           al, bl, ep, M, N, K, p.k_per_split, partial);
+        if (fast)
+            hipLaunchKernelGGL((gemm_mfma_kernel<128, 128, true, AL, BL, EP>), grid, dim3(256), 0, st,
+                               al, bl, ep, M, N, K, p.k_per_split, partial);
+        else
+            hipLaunchKernelGGL((gemm_mfma_kernel<128, 128, false, AL, BL, EP>), grid, dim3(256), 0, st,
+                               al, bl, ep, M, N, K, p.k_per_split, partial);
     } else {
         dim3 grid(ceil_div(M, 64) * ceil_div(N, 64), 1, p.splits);
-        hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, AL, BL, EP>), grid, dim3(256), 0, st,
-                           al, bl, ep, M, N, K, p.k_per_split, partial);
+        if (fast)
+            hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, true, AL, BL, EP>), grid, dim3(256), 0, st,
+                               al, bl, ep, M, N, K, p.k_per_split, partial);
+        else
+            hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, false, AL, BL, EP>), grid, dim3(256), 0, st,
+                               al, bl, ep, M, N, K, p.k_per_split, partial);
     }
     D2P_LAUNCH_CHECK(name);
     if (p.splits > 1) {

@@ -56,38 +56,6 @@ extern "C" int d2p_embedding_gather_oob0(int n, int rows, int E, const int* ids,
     return D2P_OK;
 }
 
-// Scatter-add gradient, deterministic: one workgroup per (table row, 256-column slab) walks
-// the id list in order and sums the matching dout rows (table has <= 51 rows, n <= 6400).
-__global__ void __launch_bounds__(256)
-embedding_scatter_kernel(int n, int E, const int* ids, const float* dout, float* dtable) {
-    const int row = blockIdx.x;
-    const int e = blockIdx.y * 256 + threadIdx.x;
-    __shared__ int sid[256];
-    float acc = 0.f;
-    for (int base = 0; base < n; base += 256) {
-        const int i = base + threadIdx.x;
-        sid[threadIdx.x] = (i < n) ? ids[i] : -1;
-        __syncthreads();
-        const int lim = min(256, n - base);
-        if (e < E)
-            for (int q = 0; q < lim; ++q)
-                if (sid[q] == row) acc += dout[(long)(base + q) * E + e];
-        __syncthreads();
-    }
-    if (e < E) dtable[(long)row * E + e] = acc;
-}
-
-extern "C" int d2p_embedding_scatter_add_oob0(int n, int rows, int E, const int* ids,
-                                              const float* dout, float* dtable,
-                                              d2p_stream_t stream) {
-    D2P_REQUIRE(n >= 0 && rows > 0 && E > 0, D2P_EINVAL, "embedding scatter: bad sizes");
-    D2P_REQUIRE(dtable && (n == 0 || (ids && dout)), D2P_EINVAL, "embedding scatter: null pointer");
-    hipLaunchKernelGGL(embedding_scatter_kernel, dim3(rows, ceil_div(E, 256)), dim3(256), 0,
-                       as_stream(stream), n, E, ids, dout, dtable);
-    D2P_LAUNCH_CHECK("embedding_scatter");
-    return D2P_OK;
-}
-
 // ---- SummarizeFeature('avgpool'): mean over the k demonstrations -------------------------
 // models/model_full.py:351-356,380-385
 __global__ void __launch_bounds__(256)

@@ -237,7 +237,9 @@ def embedding_scatter_add(ids, dout, dtable, n=None):
     rows, E = dtable.shape
     if n is None:
         n = ids.numel()
-    call.d2p_embedding_scatter_add_oob0(n, rows, E, ptr(ids), ptr(dout), ptr(dtable), current_stream())
+    ws, wsb = SCRATCH.get(call.d2p_embedding_scatter_ws_bytes(n, rows, E))
+    call.d2p_embedding_scatter_add_oob0(n, rows, E, ptr(ids), ptr(dout), ptr(dtable), ws, wsb,
+                                        current_stream())
     return dtable
 
 

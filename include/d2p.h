@@ -170,8 +170,12 @@ int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long z_row_strid
 int d2p_shift_tokens_tm(int R, int T, const int* tokens, int start_id, int* ids, d2p_stream_t stream);
 int d2p_embedding_gather_oob0(int n, int rows, int E, const int* ids, const float* table,
                               float* out, d2p_stream_t stream);
+/* dtable[v,:] = sum_{i: ids[i]==v} dout[i,:]  (overwrites dtable).  Runs as a one-hot TN GEMM on
+ * the MFMA pipe, split over the id list and combined in a fixed order (deterministic).
+ * ws >= d2p_embedding_scatter_ws_bytes(n, rows, E). */
+size_t d2p_embedding_scatter_ws_bytes(int n, int rows, int E);
 int d2p_embedding_scatter_add_oob0(int n, int rows, int E, const int* ids, const float* dout,
-                                   float* dtable, d2p_stream_t stream);
+                                   float* dtable, void* ws, size_t ws_bytes, d2p_stream_t stream);
 
 /* ---- K7: masked, count-normalised sequence cross-entropies --------------------------
  * Replaces Sequence_Loss (models/model_full.py:620-657): softmax_/sigmoid_cross_entropy_
