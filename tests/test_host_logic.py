@@ -1,0 +1,98 @@
+"""Host-side logic that needs no GPU: config presets, synthetic batch contract, trainer CLI,
+learning-rate schedule, and that the product refuses to run without its HIP path."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from demo2program_amd.config import conv_shapes, feature_dim, make_config
+from demo2program_amd.synthetic import make_batch
+
+
+def test_presets_match_baseline_configs():
+    c2 = make_config('karel')
+    assert (c2.batch_size, c2.k, c2.max_demo_len, c2.max_program_len) == (32, 10, 20, 50)
+    assert (c2.h, c2.w, c2.depth, c2.dim_program_token, c2.action_space, c2.per_dim) == (8, 8, 16, 50, 6, 5)
+    assert feature_dim(c2) == 48
+    c4 = make_config('vizdoom')
+    assert (c4.h, c4.w, c4.depth, c4.dim_program_token, c4.action_space, c4.per_dim) == (80, 80, 3, 42, 12, 6)
+    assert feature_dim(c4) == 432
+    assert [s[4] for s in conv_shapes(c4)] == [40, 20, 10, 5, 3]
+    c5 = make_config('vizdoom_k25')
+    assert (c5.batch_size, c5.k) == (16, 25)
+
+
+def test_synthetic_batch_follows_the_reference_padding_rules():
+    cfg = make_config('karel', batch_size=5, k=3)
+    b = make_batch(cfg, seed=1)
+    B, k, T, L, V, A, P = 5, 3, cfg.max_demo_len, cfg.max_program_len, 50, 6, 5
+    assert b['s_h'].shape == (B, k, T, 8, 8, 16) and b['s_h'].dtype == np.float32
+    assert b['program'].shape == (B, V, L) and b['program_tokens'].shape == (B, L)
+    assert b['a_h'].shape == (B, k, T, A) and b['a_h_tokens'].dtype == np.int32
+    assert b['program_len'].shape == (B, 1) and b['program_len'].dtype == np.float32
+    assert b['demo_len'].shape == (B, k) and b['test_s_h'].shape[1] == cfg.test_k
+    for bi in range(B):
+        n = int(b['program_len'][bi, 0])
+        assert b['program'][bi, :, :n].sum() == n and b['program'][bi, :, n:].sum() == 0
+        assert list(b['program_tokens'][bi, :3]) == [0, 1, 2] and b['program_tokens'][bi, n - 1] == 3
+        assert np.array_equal(b['program'][bi].argmax(0)[:n], b['program_tokens'][bi, :n])
+        for i in range(k):
+            m = int(b['demo_len'][bi, i])
+            assert b['s_h'][bi, i, m:].sum() == 0 and b['s_h'][bi, i, :m].sum() > 0
+            assert b['a_h_tokens'][bi, i, m - 1] == A - 1                 # <e> closes the demo
+            assert b['a_h'][bi, i, :m].sum() == m and b['a_h'][bi, i, m:].sum() == 0
+            assert b['per'][bi, i, m:].sum() == 0
+    assert set(np.unique(b['s_h'])) <= {0.0, 1.0}
+    again = make_batch(cfg, seed=1)
+    assert all(np.array_equal(b[n], again[n]) for n in b)
+
+
+def test_vizdoom_frames_are_unnormalised_bytes():
+    cfg = make_config('vizdoom', batch_size=1, k=2, h=8, w=8)
+    b = make_batch(cfg, seed=2)
+    assert b['s_h'].max() > 200 and b['s_h'].min() == 0 and b['s_h'].dtype == np.float32
+
+
+def test_cli_flags_and_defaults_match_the_reference():
+    from demo2program_amd.trainer import build_arg_parser, learning_rate_at
+    a = build_arg_parser().parse_args([])
+    assert (a.model, a.dataset_type, a.num_k, a.batch_size, a.learning_rate) == ('full', 'karel', 10, 32, 0.001)
+    assert (a.log_step, a.write_summary_step, a.test_sample_step) == (10, 100, 100)
+    assert a.encoder_rnn_type == 'lstm' and a.num_lstm_cell_units == 512
+    assert a.scheduled_sampling is False and a.scheduled_sampling_decay_steps == 20000
+    assert a.demo_aggregation == 'avgpool' and a.lr_weight_decay is False
+    with pytest.raises(SystemExit):
+        build_arg_parser().parse_args(['--model', 'nope'])
+    cfg = make_config('karel', lr_weight_decay=True)
+    assert learning_rate_at(cfg, 9999) == 1e-3 and learning_rate_at(cfg, 10000) == 5e-4
+    assert learning_rate_at(make_config('karel'), 50000) == 1e-3
+
+
+def test_model_class_lookup_and_errors():
+    from demo2program_amd.trainer import Trainer
+    with pytest.raises(ValueError):
+        Trainer.get_model_class('bogus')
+    with pytest.raises(NotImplementedError):
+        Trainer.get_model_class('summarizer')
+    assert Trainer.get_model_class('full').__name__ == 'Model'
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')
+def test_product_fails_loudly_without_a_gpu():
+    from demo2program_amd import kernels
+    from demo2program_amd.models.model_full import Model
+    with pytest.raises(RuntimeError):
+        Model(make_config('karel_tiny'))
+    with pytest.raises(RuntimeError):
+        kernels.matmul_nn(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_product_never_imports_the_oracle():
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'demo2program_amd')
+    for d, _, files in os.walk(root):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(d, f)).read()
+                assert 'import oracle' not in src and 'from oracle' not in src, f
