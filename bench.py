@@ -51,6 +51,7 @@ def roofline_leg(trainer, feeds, steps=2):
     lib = load()
     torch.cuda.synchronize()
     lib.d2p_prof_enable(1)
+    lib._d2p_prof_on = True          # Trainer.train_step takes the eager (un-graphed) path
     for i in range(steps):
         trainer.train_step(feeds[i % len(feeds)])
     torch.cuda.synchronize()
@@ -63,6 +64,7 @@ def roofline_leg(trainer, feeds, steps=2):
                 rows.append(dict(family=fam, tag=tag, name=name, bound=bound, launches=cnt.value,
                                  total_ms=ms.value, work=work.value))
     lib.d2p_prof_enable(0)
+    lib._d2p_prof_on = False
     if not rows:
         return None, []
     rows.sort(key=lambda r: -r['total_ms'])

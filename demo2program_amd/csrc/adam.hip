@@ -64,7 +64,9 @@ extern "C" int d2p_l2norm_flat(size_t n, const float* g, float prescale, double*
 
 __global__ void __launch_bounds__(256)
 adam_clip_kernel(size_t n, float* p, const float* g, float* m, float* v, const double* sumsq,
-                 float prescale, float clip, float lr_t, float b1, float b2, float eps) {
+                 float prescale, float clip, float lr_t_host, const float* lr_t_dev, float b1,
+                 float b2, float eps) {
+    const float lr_t = lr_t_dev ? lr_t_dev[0] : lr_t_host;
     const double norm = sqrt(sumsq[0]);
     // [TF-1.3] clip_by_global_norm: g * clip / max(norm, clip)
     const float scale = prescale * (float)((double)clip / (norm > (double)clip ? norm : (double)clip));
@@ -98,7 +100,8 @@ adam_clip_kernel(size_t n, float* p, const float* g, float* m, float* v, const d
 
 extern "C" int d2p_adam_clip_flat(size_t n, float* p, const float* g, float* m, float* v,
                                   const double* sumsq, float prescale, float clip, float lr_t,
-                                  float beta1, float beta2, float eps, d2p_stream_t stream) {
+                                  const float* lr_t_dev, float beta1, float beta2, float eps,
+                                  d2p_stream_t stream) {
     if (n == 0) return D2P_OK;
     D2P_REQUIRE(p && g && m && v && sumsq, D2P_EINVAL, "adam: null pointer");
     D2P_REQUIRE(((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0), D2P_EALIGN,
@@ -106,7 +109,7 @@ extern "C" int d2p_adam_clip_flat(size_t n, float* p, const float* g, float* m, 
     size_t want = (n / 4 + 255) / 256;
     int nb = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     hipLaunchKernelGGL(adam_clip_kernel, dim3(nb), dim3(256), 0, as_stream(stream), n, p, g, m, v,
-                       sumsq, prescale, clip, lr_t, beta1, beta2, eps);
+                       sumsq, prescale, clip, lr_t, lr_t_dev, beta1, beta2, eps);
     D2P_LAUNCH_CHECK("adam_clip");
     return D2P_OK;
 }

@@ -54,35 +54,58 @@ extern "C" int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, co
 }
 
 // ---- column sum (bias gradients): two-stage, deterministic --------------------------
-// stage 1: block (cb, s) sums rows r = s, s+S, ... of 64 columns; stage 2 sums the S partials.
-#define COLSUM_S 64
+// stage 1: block (cb, s) sums rows r = s*4+rl, step S*4, of 64 columns -> part[s][c];
+// stage 2: block per 64 columns, 4 lanes per column over the S partials, fixed-order tree.
+// S adapts so that ~2048 workgroups stream the matrix (HBM-bound: rows*cols*4 bytes).
+static inline int colsum_S(int rows, int cols) {
+    const int cb = ceil_div(cols, 64);
+    int S = 2048 / cb;
+    const int cap = ceil_div(rows, 32);          // >= 8 rows per thread
+    if (S > cap) S = cap;
+    if (S > 256) S = 256;
+    if (S < 1) S = 1;
+    return S;
+}
 
 __global__ void __launch_bounds__(256)
 colsum_stage1(int rows, int cols, const float* X, long ld, float* part) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
-    float s = 0.f;
-    if (c < cols)
-        for (int r = blockIdx.y * 4 + rl; r < rows; r += gridDim.y * 4) s += X[(long)r * ld + c];
-    red[rl][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (rl == 0 && c < cols) {
-        s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
-        part[(long)blockIdx.y * cols + c] = s;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < cols) {
+        const int step = gridDim.y * 4;
+        int r = blockIdx.y * 4 + rl;
+        for (; r + 3 * step < rows; r += 4 * step) {      // 4 independent loads in flight
+            s0 += X[(long)r * ld + c];
+            s1 += X[(long)(r + step) * ld + c];
+            s2 += X[(long)(r + 2 * step) * ld + c];
+            s3 += X[(long)(r + 3 * step) * ld + c];
+        }
+        for (; r < rows; r += step) s0 += X[(long)r * ld + c];
     }
+    red[rl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl == 0 && c < cols)
+        part[(long)blockIdx.y * cols + c] =
+            (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 __global__ void __launch_bounds__(256) colsum_stage2(int cols, int S, const float* part, float* out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sl = threadIdx.x >> 6;
     float s = 0.f;
-    for (int i = 0; i < S; ++i) s += part[(long)i * cols + c];
-    out[c] = s;
+    if (c < cols)
+        for (int i = sl; i < S; i += 4) s += part[(long)i * cols + c];
+    red[sl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (sl == 0 && c < cols)
+        out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 extern "C" size_t d2p_colsum_ws_bytes(int rows, int cols) {
     (void)rows;
-    return cols > 0 ? (size_t)COLSUM_S * cols * sizeof(float) : 0;
+    return cols > 0 ? (size_t)256 * cols * sizeof(float) : 0;
 }
 
 extern "C" int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float* out, void* ws,
@@ -94,11 +117,11 @@ extern "C" int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float
                 "colsum: workspace too small (%zu < %zu)", ws_bytes, d2p_colsum_ws_bytes(rows, cols));
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 64), COLSUM_S), dim3(256), 0, st, rows,
-                       cols, X, ld, part);
+    const int S = colsum_S(rows, cols);
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 64), S), dim3(256), 0, st, rows, cols, X,
+                       ld, part);
     D2P_LAUNCH_CHECK("colsum_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 256)), dim3(256), 0, st, cols, COLSUM_S,
-                       part, out);
+    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 64)), dim3(256), 0, st, cols, S, part, out);
     D2P_LAUNCH_CHECK("colsum_stage2");
     return D2P_OK;
 }

@@ -183,6 +183,31 @@ __global__ void __launch_bounds__(256, 1) lstm_step_fwd_kernel(StepFwdArgs a) {
     int rs0, nrs;
     rt_range(rt, a.total_rs, a.RT, rs0, nrs);
 
+    // Epilogue operands of this thread's (row, 4 units) item are requested BEFORE the GEMM so
+    // that their latency hides under the MFMA chain (one item per thread: <= 160 items).
+    const int nrows = nrs * 16;
+    const int item = tid;
+    const bool has_item = item < nrows * 2 && (rs0 * 16 + (item >> 1)) < a.M;
+    const int r = item >> 1, q = item & 1;
+    const int row = rs0 * 16 + r;
+    const int u = ct * 8 + q * 4;
+    const long o = (long)row * U + u;
+    bool active = false;
+    f4 cp = zero4(), zz[4], hprev = zero4();
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zz[g] = zero4();
+    if (has_item) {
+        active = a.lens ? (a.t < a.lens[row]) : true;
+        if (a.c_prev) cp = ldf4(a.c_prev + o);
+        if (active) {
+            const float* zr = a.z + (long)row * a.zrs + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) zz[g] = ldf4(zr + (long)g * U);
+        } else if (a.hs_prev) {
+            hprev = ldf4(a.hs_prev + o);
+        }
+    }
+
     if (a.has_h) {
         const f32x4* Af = reinterpret_cast<const f32x4*>(a.hfrag_in);
         const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wf);
@@ -198,33 +223,21 @@ __global__ void __launch_bounds__(256, 1) lstm_step_fwd_kernel(StepFwdArgs a) {
     }
     __syncthreads();
 
-    // epilogue: one (row, 4 units) item per thread; local columns g*8 + q*4 .. +3
-    const int nrows = nrs * 16;
-    for (int item = tid; item < nrows * 2; item += 256) {
-        const int r = item >> 1, q = item & 1;
-        const int row = rs0 * 16 + r;
-        if (row >= a.M) continue;
-        const int u = ct * 8 + q * 4;
-        const long o = (long)row * U + u;
-        const bool active = a.lens ? (a.t < a.lens[row]) : true;
-        const f4 cp = a.c_prev ? ldf4(a.c_prev + o) : zero4();
+    if (has_item) {
         f4 hstate;
         if (active) {
-            f4 zz[4];
-            float* zr = a.z + (long)row * a.zrs + u;
+            if (a.has_h) {
+                float* zr = a.z + (long)row * a.zrs + u;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f4 s = ldf4(zr + (long)g * U);
-                if (a.has_h) {
+                for (int g = 0; g < 4; ++g) {
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
                         const f4 p = ldf4(&P[w][r][g * 8 + q * 4]);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) s.v[e] += p.v[e];
+                        for (int e = 0; e < 4; ++e) zz[g].v[e] += p.v[e];
                     }
-                    stf4(zr + (long)g * U, s);      // full pre-activation, kept for backward
+                    stf4(zr + (long)g * U, zz[g]);      // full pre-activation, kept for backward
                 }
-                zz[g] = s;
             }
             f4 cn, hn;
             lstm_gate_fwd4(zz[0], zz[1], zz[2], zz[3], cp, cn, hn);
@@ -234,7 +247,7 @@ __global__ void __launch_bounds__(256, 1) lstm_step_fwd_kernel(StepFwdArgs a) {
         } else {
             stf4(a.c_out + o, cp);
             stf4(a.hout + o, zero4());
-            hstate = a.hs_prev ? ldf4(a.hs_prev + o) : zero4();
+            hstate = hprev;
         }
         if (a.hs_out) stf4(a.hs_out + o, hstate);
         stf4(a.hfrag_out + frag_off(row, u, U >> 4), hstate);
@@ -347,6 +360,37 @@ __global__ void __launch_bounds__(256, 1) lstm_step_bwd_kernel(StepBwdArgs a) {
     int rs0, nrs;
     rt_range(rt, a.total_rs, a.RT, rs0, nrs);
 
+    // One (row, 4 units) epilogue item per thread (<= 64 rows x 4 quads); its operands are
+    // requested before the GEMM so their latency hides under the MFMA chain.
+    const int nrows = nrs * 16;
+    const int r = tid >> 2, q = tid & 3;
+    const int row = rs0 * 16 + r;
+    const bool has_item = tid < nrows * 4 && row < a.M;
+    const int u = nt * 16 + q * 4;
+    const long o = (long)row * U + u;
+    int len = a.n_steps;
+    bool cur_active = false, next_active = false;
+    f4 zi = zero4(), zj = zero4(), zf = zero4(), zo = zero4(), cp = zero4(), cc = zero4();
+    f4 dhx = zero4(), dcv = zero4();           // dhx = dh_final pass-through + dhout[t]
+    if (has_item) {
+        if (a.lens) len = a.lens[row];
+        next_active = (a.t + 1 < a.n_steps) && (a.t + 1 < len);
+        cur_active = (a.mode == 0) && (a.t < len);
+        if (!next_active && a.dh_final) dhx = ldf4(a.dh_final + o);
+        if (cur_active) {
+            const float* zr = a.z + (long)row * a.zrs + u;
+            zi = ldf4(zr); zj = ldf4(zr + U); zf = ldf4(zr + 2L * U); zo = ldf4(zr + 3L * U);
+            if (a.c_prev) cp = ldf4(a.c_prev + o);
+            cc = ldf4(a.c + o);
+            dcv = ldf4(a.dC + o);
+            if (a.dhout) {
+                const f4 e4 = ldf4(a.dhout + o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dhx.v[e] += e4.v[e];
+            }
+        }
+    }
+
     if (a.has_gemm) {
         const f32x4* Af = reinterpret_cast<const f32x4*>(a.dzfrag_in);
         const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wb) + (long)nt * KC4 * 64;
@@ -359,15 +403,9 @@ __global__ void __launch_bounds__(256, 1) lstm_step_bwd_kernel(StepBwdArgs a) {
     }
     __syncthreads();
 
-    const int nrows = nrs * 16;
-    for (int item = tid; item < nrows * 4; item += 256) {
-        const int r = item >> 2, q = item & 3;
-        const int row = rs0 * 16 + r;
-        if (row >= a.M) continue;
-        const int u = nt * 16 + q * 4;
-        const long o = (long)row * U + u;
-        // dH_t = dz[t+1]·Wh^T, or dh_final for rows that are not active at t+1
-        f4 dH = zero4();
+    if (has_item) {
+        // dH_t = dz[t+1]·Wh^T (+ dh_final for rows that are not active at t+1) (+ dhout[t])
+        f4 dH = dhx;
         if (a.has_gemm) {
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
@@ -376,44 +414,27 @@ __global__ void __launch_bounds__(256, 1) lstm_step_bwd_kernel(StepBwdArgs a) {
                 for (int e = 0; e < 4; ++e) dH.v[e] += p.v[e];
             }
         }
-        const int len = a.lens ? a.lens[row] : a.n_steps;
-        const bool next_active = (a.t + 1 < a.n_steps) && (a.t + 1 < len);
-        if (!next_active && a.dh_final) {
-            const f4 e4 = ldf4(a.dh_final + o);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) dH.v[e] += e4.v[e];
-        }
         if (a.mode == 1) {
             stf4(a.dh0 + o, dH);
-            continue;
-        }
-        float* dzr = a.dz + (long)row * a.dzrs + u;
-        const int KCx = U >> 2;
-        if (a.t < len) {
-            const float* zr = a.z + (long)row * a.zrs + u;
-            const f4 zi = ldf4(zr), zj = ldf4(zr + U), zf = ldf4(zr + 2L * U), zo = ldf4(zr + 3L * U);
-            const f4 cp = a.c_prev ? ldf4(a.c_prev + o) : zero4();
-            const f4 cc = ldf4(a.c + o);
-            if (a.dhout) {
-                const f4 e4 = ldf4(a.dhout + o);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) dH.v[e] += e4.v[e];
-            }
-            const f4 dcv = ldf4(a.dC + o);
-            f4 g[4], dcn;
-            lstm_gate_bwd4(zi, zj, zf, zo, cp, cc, dH, dcv, g[0], g[1], g[2], g[3], dcn);
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                stf4(dzr + (long)gg * U, g[gg]);
-                stf4(a.dzfrag_out + frag_off(row, gg * U + u, KCx), g[gg]);
-            }
-            stf4(a.dC + o, dcn);
         } else {
-            const f4 zz = zero4();
+            float* dzr = a.dz + (long)row * a.dzrs + u;
+            const int KCx = U >> 2;
+            if (cur_active) {
+                f4 g[4], dcn;
+                lstm_gate_bwd4(zi, zj, zf, zo, cp, cc, dH, dcv, g[0], g[1], g[2], g[3], dcn);
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                stf4(dzr + (long)gg * U, zz);
-                stf4(a.dzfrag_out + frag_off(row, gg * U + u, KCx), zz);
+                for (int gg = 0; gg < 4; ++gg) {
+                    stf4(dzr + (long)gg * U, g[gg]);
+                    stf4(a.dzfrag_out + frag_off(row, gg * U + u, KCx), g[gg]);
+                }
+                stf4(a.dC + o, dcn);
+            } else {
+                const f4 z0 = zero4();
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    stf4(dzr + (long)gg * U, z0);
+                    stf4(a.dzfrag_out + frag_off(row, gg * U + u, KCx), z0);
+                }
             }
         }
     }

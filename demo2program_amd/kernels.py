@@ -35,7 +35,28 @@ class Scratch(object):
         self.get(nbytes)
 
 
-SCRATCH = Scratch()
+class _ScratchByStream(object):
+    """A Scratch per stream: ops issued on different streams may run concurrently and must
+    not share scratch memory (ops on one stream are serialised by stream order)."""
+
+    def __init__(self):
+        self.by_stream = {}
+
+    def _cur(self):
+        key = torch.cuda.current_stream().cuda_stream
+        s = self.by_stream.get(key)
+        if s is None:
+            s = self.by_stream[key] = Scratch()
+        return s
+
+    def get(self, nbytes):
+        return self._cur().get(nbytes)
+
+    def reserve(self, nbytes):
+        self._cur().reserve(nbytes)
+
+
+SCRATCH = _ScratchByStream()
 
 
 # ---------------------------------------------------------------- GEMM
@@ -322,6 +343,6 @@ def l2norm_flat(g, prescale, sumsq):
     call.d2p_l2norm_flat(g.numel(), ptr(g), prescale, ptr(sumsq), ws, wsb, current_stream())
 
 
-def adam_clip_flat(p, g, m, v, sumsq, prescale, clip, lr_t, b1=0.9, b2=0.999, eps=1e-8):
+def adam_clip_flat(p, g, m, v, sumsq, prescale, clip, lr_t, b1=0.9, b2=0.999, eps=1e-8, lr_t_dev=None):
     call.d2p_adam_clip_flat(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(sumsq), prescale, clip,
-                            lr_t, b1, b2, eps, current_stream())
+                            lr_t, ptr(lr_t_dev), b1, b2, eps, current_stream())

@@ -66,7 +66,7 @@ SIGNATURES = {
     'd2p_prof_enable': (c_int, [c_int]),
     'd2p_prof_set_tag': (c_int, [c_int]),
     'd2p_prof_read': (c_int, [c_int, P, P, P]),
-    'd2p_adam_clip_flat': (c_int, [c_size_t, P, P, P, P, P, c_float, c_float, c_float, c_float, c_float, c_float, S]),
+    'd2p_adam_clip_flat': (c_int, [c_size_t, P, P, P, P, P, c_float, c_float, c_float, P, c_float, c_float, c_float, S]),
 }
 
 _lib = None

@@ -60,8 +60,14 @@ class Trainer(object):
             raise ValueError(model_name)
         return Model
 
-    def __init__(self, config, dataset=None, dataset_test=None, make_train_dir=True, dp=None):
+    def __init__(self, config, dataset=None, dataset_test=None, make_train_dir=True, dp=None,
+                 use_graph=None):
         self.config = config
+        if use_graph is None:
+            use_graph = os.environ.get('D2P_NO_GRAPH', '0') != '1'
+        self.use_graph = bool(use_graph)
+        self._graphs = {}
+        self._static_feed = None
         hyper_parameter_str = 'bs_{}_lr_{}_{}_cell_{}'.format(
             config.batch_size, config.learning_rate, config.encoder_rnn_type,
             config.num_lstm_cell_units)
@@ -88,6 +94,7 @@ class Trainer(object):
         self.test_sample_step = config.test_sample_step
         self.write_summary_step = config.write_summary_step
         self._sumsq = torch.zeros(1, dtype=torch.float64, device='cuda')
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device='cuda')
 
         if config.checkpoint is not None:
             self.load_checkpoint(config.checkpoint)
@@ -95,10 +102,19 @@ class Trainer(object):
     # ------------------------------------------------------------------ one optimizer step
     def train_step(self, feed):
         """forward + backward + (all-reduce) + clip + Adam on a device-resident feed.
-        Asynchronous: returns the device loss tensor without synchronising."""
+        Asynchronous: returns the device loss tensor without synchronising.
+
+        With use_graph (default) forward+backward are captured once per (n_prog, n_demo) --
+        the two batch-dependent step counts of dynamic_decode -- into a hipGraph reading a
+        static copy of the feed, and replayed: ~500 launches per step collapse into one
+        graph launch.  The all-reduce, norm and Adam stay outside the graph (RCCL call; the
+        Adam rate changes per step and is read from device memory)."""
         m = self.model
-        loss = m.forward(feed)
-        m.backward()
+        if self.use_graph and not self._profiling():
+            loss = self._graphed_forward_backward(feed)
+        else:
+            loss = m.forward(feed)
+            m.backward()
         P = m.params
         self.dp.all_reduce_grads(P.grad)            # SUM over ranks; mean folded into prescale
         pre = self.dp.prescale
@@ -110,6 +126,48 @@ class Trainer(object):
                          ADAM_B1, ADAM_B2, ADAM_EPS)
         self.global_step = t
         return loss
+
+    @staticmethod
+    def _profiling():
+        from .lib import load
+        return bool(getattr(load(), '_d2p_prof_on', False))
+
+    _STATIC_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'program_len',
+                    'demo_len')
+
+    def _graphed_forward_backward(self, feed):
+        m = self.model
+        if self._static_feed is None:
+            self._static_feed = {k: torch.empty_like(feed[k]) for k in self._STATIC_KEYS}
+        sf = self._static_feed
+        for k in self._STATIC_KEYS:
+            if sf[k].dtype != feed[k].dtype:         # e.g. uint8 frames after float32 frames
+                sf[k] = torch.empty_like(feed[k])
+                self._graphs.clear()
+            sf[k].copy_(feed[k], non_blocking=True)
+        key = (feed['n_prog'], feed['n_demo'])
+        static = dict(sf, n_prog=key[0], n_demo=key[1], id=feed.get('id'), host=feed.get('host'))
+        g = self._graphs.get(key)
+        if g is None:
+            # one eager pass sizes every buffer / scratch, then capture the same schedule; the
+            # BN moving statistics are restored so the warm-up does not count as a step
+            saved = {n: (a.clone(), b.clone()) for n, (a, b) in m.moving.items()}
+            m.forward(static)
+            m.backward()
+            for n, (a, b) in saved.items():
+                m.moving[n][0].copy_(a)
+                m.moving[n][1].copy_(b)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                m.forward(static)
+                m.backward()
+            self._graphs[key] = g
+        else:
+            m._ctx['feed'] = static
+            m._feed = static
+        g.replay()
+        return m.loss
 
     def run_single_step(self, batch, step=None, is_train=True):
         """trainer.py:186-205: step_time spans batch fetch + feed + run."""

@@ -246,9 +246,12 @@ int d2p_zero_past_group_steps(int T, int R, int V, int G, const int* lens, float
 size_t d2p_l2norm_ws_bytes(size_t n);
 int d2p_l2norm_flat(size_t n, const float* g, float prescale, double* sumsq,
                     void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* lr_t_dev: optional DEVICE pointer to one float; when non-NULL it overrides lr_t, so the
+ * launch can sit inside a replayed hipGraph while the bias-corrected rate changes per step. */
 int d2p_adam_clip_flat(size_t n, float* p, const float* g, float* m, float* v,
                        const double* sumsq, float prescale, float clip, float lr_t,
-                       float beta1, float beta2, float eps, d2p_stream_t stream);
+                       const float* lr_t_dev, float beta1, float beta2, float eps,
+                       d2p_stream_t stream);
 
 /* ---- optional per-launch HIP-event timing (used by bench.py's roofline leg) -------------
  * When enabled, every GEMM / conv / LSTM-gate launch is bracketed by hipEvents recorded on
