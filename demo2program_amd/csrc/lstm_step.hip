@@ -28,7 +28,10 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define FWD_RSMAX 5     // row sub-tiles (16 rows) per workgroup, forward
-#define BWD_RSMAX 4     // backward
+#define BWD_RSMAX 3     // backward
+// Both kernels are held under 256 registers (VGPR+AGPR) so that TWO workgroups are
+// resident per CU: one workgroup's load / LDS-combine / epilogue phases then overlap the
+// other's MFMA chain (a single resident workgroup leaves the matrix pipe idle ~60 % of a step).
 #define P_LD 36         // LDS partial-tile row stride (floats)
 
 // ---------------------------------------------------------------------------------------
@@ -103,7 +106,7 @@ __device__ __forceinline__ void rt_range(int rt, int total_rs, int RT, int& rs0,
 // Forward step
 // ---------------------------------------------------------------------------------------
 struct StepFwdArgs {
-    int M, U, total_rs, RT, t, has_h;
+    int M, U, total_rs, RT, t, has_h, skip_epi;
     const float4* hfrag_in;    // A operand: state h before this step (fragment-major)
     const float4* Wf;          // packed Wh (forward layout)
     float* z; long zrs;        // in: x·Wx + b ; out: full pre-activations (row stride zrs)
@@ -160,8 +163,73 @@ __device__ __forceinline__ void fwd_gemm(const f32x4* __restrict__ Af, const f32
                 P[wave][i * 16 + (lane >> 4) * 4 + r][s * 16 + (lane & 15)] = acc[i][s][r];
 }
 
-template <int CPW>   // 16-wide k chunks per wave; U = 64*CPW
-__global__ void __launch_bounds__(256, 1) lstm_step_fwd_kernel(StepFwdArgs a) {
+// Register-lean variant: two stages of FWD_CB chunks in flight (<= 256 registers, so two
+// workgroups -- e.g. of two independent LSTMs on different streams -- can share a CU).
+#define FWD_CB 2
+template <int CPW, int NRS>
+__device__ __forceinline__ void fwd_gemm_pipe(const f32x4* __restrict__ Af, const f32x4* __restrict__ Bf,
+                                              int rs0, int ct, int wave, int lane,
+                                              float (*P)[FWD_RSMAX * 16][P_LD]) {
+    constexpr int KC = 4 * CPW;
+    constexpr int CB = CPW < FWD_CB ? CPW : FWD_CB;
+    constexpr int NB = CPW / CB;
+    f32x4 acc[NRS][2];
+#pragma unroll
+    for (int i = 0; i < NRS; ++i) {
+        acc[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 a0[CB][NRS], b0[CB][2], a1[CB][NRS], b1[CB][2];
+#define FWD_LOAD(AV, BV, nb)                                                                  \
+    {                                                                                         \
+        _Pragma("unroll") for (int c = 0; c < CB; ++c) {                                      \
+            const int kc = wave * CPW + (nb) * CB + c;                                        \
+            _Pragma("unroll") for (int s = 0; s < 2; ++s)                                     \
+                BV[c][s] = Bf[(((long)ct * KC + kc) * 2 + s) * 64 + lane];                    \
+            _Pragma("unroll") for (int i = 0; i < NRS; ++i)                                   \
+                AV[c][i] = Af[((long)(rs0 + i) * KC + kc) * 64 + lane];                       \
+        }                                                                                     \
+    }
+#define FWD_COMPUTE(AV, BV)                                                                   \
+    {                                                                                         \
+        _Pragma("unroll") for (int c = 0; c < CB; ++c)                                        \
+        _Pragma("unroll") for (int jj = 0; jj < 4; ++jj)                                      \
+        _Pragma("unroll") for (int i = 0; i < NRS; ++i) {                                     \
+            acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[c][i][jj], BV[c][0][jj], acc[i][0], 0, 0, 0); \
+            acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(AV[c][i][jj], BV[c][1][jj], acc[i][1], 0, 0, 0); \
+        }                                                                                     \
+    }
+    FWD_LOAD(a0, b0, 0)
+#pragma unroll
+    for (int nb = 0; nb < NB; nb += 2) {
+        if (nb + 1 < NB) {
+            FWD_LOAD(a1, b1, nb + 1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        FWD_COMPUTE(a0, b0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (nb + 1 < NB) {
+            if (nb + 2 < NB) {
+                FWD_LOAD(a0, b0, nb + 2)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            FWD_COMPUTE(a1, b1)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#undef FWD_LOAD
+#undef FWD_COMPUTE
+#pragma unroll
+    for (int i = 0; i < NRS; ++i)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                P[wave][i * 16 + (lane >> 4) * 4 + r][s * 16 + (lane & 15)] = acc[i][s][r];
+}
+
+template <int CPW, bool PIPE>   // 16-wide k chunks per wave; U = 64*CPW
+__global__ void __launch_bounds__(256, PIPE ? 2 : 1) lstm_step_fwd_kernel(StepFwdArgs a) {
     constexpr int KC = 4 * CPW;
     __shared__ __attribute__((aligned(16))) float P[4][FWD_RSMAX * 16][P_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -187,7 +255,7 @@ __global__ void __launch_bounds__(256, 1) lstm_step_fwd_kernel(StepFwdArgs a) {
     // that their latency hides under the MFMA chain (one item per thread: <= 160 items).
     const int nrows = nrs * 16;
     const int item = tid;
-    const bool has_item = item < nrows * 2 && (rs0 * 16 + (item >> 1)) < a.M;
+    const bool has_item = item < nrows * 2 && (rs0 * 16 + (item >> 1)) < a.M && !a.skip_epi;
     const int r = item >> 1, q = item & 1;
     const int row = rs0 * 16 + r;
     const int u = ct * 8 + q * 4;
@@ -213,12 +281,22 @@ __global__ void __launch_bounds__(256, 1) lstm_step_fwd_kernel(StepFwdArgs a) {
         const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wf);
         // the row sub-tile count is a compile-time constant inside each case: runtime
         // predicates around the MFMAs force accumulator shuffles and serialise the chain
-        switch (nrs) {
-            case 1: fwd_gemm<CPW, 1>(Af, Bf, rs0, ct, wave, lane, P); break;
-            case 2: fwd_gemm<CPW, 2>(Af, Bf, rs0, ct, wave, lane, P); break;
-            case 3: fwd_gemm<CPW, 3>(Af, Bf, rs0, ct, wave, lane, P); break;
-            case 4: fwd_gemm<CPW, 4>(Af, Bf, rs0, ct, wave, lane, P); break;
-            default: fwd_gemm<CPW, 5>(Af, Bf, rs0, ct, wave, lane, P); break;
+        if (PIPE) {
+            switch (nrs) {
+                case 1: fwd_gemm_pipe<CPW, 1>(Af, Bf, rs0, ct, wave, lane, P); break;
+                case 2: fwd_gemm_pipe<CPW, 2>(Af, Bf, rs0, ct, wave, lane, P); break;
+                case 3: fwd_gemm_pipe<CPW, 3>(Af, Bf, rs0, ct, wave, lane, P); break;
+                case 4: fwd_gemm_pipe<CPW, 4>(Af, Bf, rs0, ct, wave, lane, P); break;
+                default: fwd_gemm_pipe<CPW, 5>(Af, Bf, rs0, ct, wave, lane, P); break;
+            }
+        } else {
+            switch (nrs) {
+                case 1: fwd_gemm<CPW, 1>(Af, Bf, rs0, ct, wave, lane, P); break;
+                case 2: fwd_gemm<CPW, 2>(Af, Bf, rs0, ct, wave, lane, P); break;
+                case 3: fwd_gemm<CPW, 3>(Af, Bf, rs0, ct, wave, lane, P); break;
+                case 4: fwd_gemm<CPW, 4>(Af, Bf, rs0, ct, wave, lane, P); break;
+                default: fwd_gemm<CPW, 5>(Af, Bf, rs0, ct, wave, lane, P); break;
+            }
         }
     }
     __syncthreads();
@@ -260,7 +338,7 @@ __global__ void __launch_bounds__(256, 1) lstm_step_fwd_kernel(StepFwdArgs a) {
 //   mode 1: final call: dh0 = G + pass-through
 // ---------------------------------------------------------------------------------------
 struct StepBwdArgs {
-    int M, U, total_rs, RT, t, n_steps, has_gemm, mode;
+    int M, U, total_rs, RT, t, n_steps, has_gemm, mode, skip_epi;
     const float4* dzfrag_in;   // A operand: dz[t+1], fragment-major over K = 4U
     const float4* Wb;          // packed Wh^T
     const float* z; long zrs;  // pre-activations of step t
@@ -338,7 +416,7 @@ __device__ __forceinline__ void bwd_gemm(const f32x4* __restrict__ Af, const f32
 }
 
 template <int DUMMY>
-__global__ void __launch_bounds__(256, 1) lstm_step_bwd_kernel(StepBwdArgs a) {
+__global__ void __launch_bounds__(256, 2) lstm_step_bwd_kernel(StepBwdArgs a) {
     __shared__ __attribute__((aligned(16))) float P[4][BWD_RSMAX * 16][P_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int U = a.U;
@@ -365,7 +443,7 @@ __global__ void __launch_bounds__(256, 1) lstm_step_bwd_kernel(StepBwdArgs a) {
     const int nrows = nrs * 16;
     const int r = tid >> 2, q = tid & 3;
     const int row = rs0 * 16 + r;
-    const bool has_item = tid < nrows * 4 && row < a.M;
+    const bool has_item = tid < nrows * 4 && row < a.M && !a.skip_epi;
     const int u = nt * 16 + q * 4;
     const long o = (long)row * U + u;
     int len = a.n_steps;
@@ -397,8 +475,7 @@ __global__ void __launch_bounds__(256, 1) lstm_step_bwd_kernel(StepBwdArgs a) {
         switch (nrs) {
             case 1: bwd_gemm<1>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
             case 2: bwd_gemm<2>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
-            case 3: bwd_gemm<3>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
-            default: bwd_gemm<4>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
+            default: bwd_gemm<3>(Af, Bf, rs0, KC4, cpw, wave, lane, P); break;
         }
     }
     __syncthreads();
@@ -443,8 +520,25 @@ __global__ void __launch_bounds__(256, 1) lstm_step_bwd_kernel(StepBwdArgs a) {
 // ---------------------------------------------------------------------------------------
 // Host drivers (called from d2p_lstm_seq_fwd / d2p_lstm_seq_bwd in lstm.hip)
 // ---------------------------------------------------------------------------------------
-static inline int pick_rt(int total_rs, int col_tiles, int rsmax) {
-    int rt = (256 + col_tiles / 2) / col_tiles;           // aim at one workgroup per CU
+// Ablation knobs for tools/bench_lstm_step.py (results are WRONG when set): bit 0 skips the
+// MFMA part, bit 1 skips the epilogue.  Runtime flags, so nothing is dead-code eliminated.
+static int g_step_debug = 0;
+extern "C" int d2p_lstm_debug_flags(int flags) {
+    g_step_debug = flags & 3;
+    return D2P_OK;
+}
+
+static int g_fwd_pipe = 1;    // 1: register-lean pipelined forward kernel (2 workgroups per CU)
+static int g_fwd_wgs = 256, g_bwd_wgs = 256;   // workgroups per launch aimed at (256 CUs)
+extern "C" int d2p_lstm_set_tiling(int fwd_wgs, int bwd_wgs, int fwd_pipelined) {
+    if (fwd_wgs > 0) g_fwd_wgs = fwd_wgs;
+    if (bwd_wgs > 0) g_bwd_wgs = bwd_wgs;
+    if (fwd_pipelined >= 0) g_fwd_pipe = fwd_pipelined ? 1 : 0;
+    return D2P_OK;
+}
+
+static inline int pick_rt(int total_rs, int col_tiles, int rsmax, int target_wgs) {
+    int rt = (target_wgs + col_tiles / 2) / col_tiles;
     if (rt < 1) rt = 1;
     const int need = (total_rs + rsmax - 1) / rsmax;      // keep tiles within the register budget
     if (rt < need) rt = need;
@@ -466,7 +560,10 @@ size_t d2p_lstm_fused_ws_bytes(int M, int U) {
 
 template <int CPW>
 static void launch_fwd(const StepFwdArgs& a, int blocks, hipStream_t st) {
-    hipLaunchKernelGGL((lstm_step_fwd_kernel<CPW>), dim3(blocks), dim3(256), 0, st, a);
+    if (g_fwd_pipe)
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<CPW, true>), dim3(blocks), dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<CPW, false>), dim3(blocks), dim3(256), 0, st, a);
 }
 
 int d2p_lstm_fused_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, const float* Wh,
@@ -487,7 +584,7 @@ int d2p_lstm_fused_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, 
         D2P_LAUNCH_CHECK("pack_rows(h0)");
     }
     const int nct = U / 8;
-    const int RT = pick_rt(total_rs, nct, FWD_RSMAX);
+    const int RT = pick_rt(total_rs, nct, FWD_RSMAX, g_fwd_wgs);
     const int blocks = nct * RT;
     const float* h_prev = h0;
     const float* c_prev = c0;
@@ -495,6 +592,8 @@ int d2p_lstm_fused_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, 
         StepFwdArgs a;
         a.M = M; a.U = U; a.total_rs = total_rs; a.RT = RT; a.t = t;
         a.has_h = (t > 0 || h0) ? 1 : 0;
+        if (g_step_debug & 1) a.has_h = 0;
+        a.skip_epi = (g_step_debug & 2) ? 1 : 0;
         a.hfrag_in = (const float4*)hfrag[t & 1];
         a.Wf = (const float4*)Wf;
         a.z = z + (long)t * zts; a.zrs = zrs;
@@ -545,7 +644,7 @@ int d2p_lstm_fused_bwd(int M, int U, int n_steps, const float* z, long zrs, long
     if (dc_final) D2P_HIP(hipMemcpyAsync(dC, dc_final, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
     else D2P_HIP(hipMemsetAsync(dC, 0, MU * sizeof(float), st));
     const int nnt = U / 16;
-    const int RT = pick_rt(total_rs, nnt, BWD_RSMAX);
+    const int RT = pick_rt(total_rs, nnt, BWD_RSMAX, g_bwd_wgs);
     const int blocks = nnt * RT;
     // steps n-1 .. 0 (mode 0), then the final dh0 GEMM (mode 1, t = -1)
     for (int t = n_steps - 1; t >= -1; --t) {
@@ -553,6 +652,8 @@ int d2p_lstm_fused_bwd(int M, int U, int n_steps, const float* z, long zrs, long
         StepBwdArgs a;
         a.M = M; a.U = U; a.total_rs = total_rs; a.RT = RT; a.t = t; a.n_steps = n_steps;
         a.has_gemm = (t + 1 < n_steps) ? 1 : 0;
+        if (g_step_debug & 1) a.has_gemm = 0;
+        a.skip_epi = (g_step_debug & 2) ? 1 : 0;
         a.mode = t < 0 ? 1 : 0;
         a.dzfrag_in = (const float4*)dzfrag[(t + 1) & 1];
         a.Wb = (const float4*)Wb;

@@ -149,6 +149,13 @@ size_t d2p_lstm_ws_bytes(int M, int U);
  * step: h·Wh MFMA + gates) when U in {64,128,256,512} and ws >= d2p_lstm_ws_bytes;
  * 0 = generic GEMM + gate kernel per step.  Both produce the same results (tests compare). */
 int d2p_lstm_set_fused(int on);
+/* Ablation knobs for tools/bench_lstm_step.py only (results are wrong when non-zero):
+ * bit 0 skips the MFMA part of the fused step kernels, bit 1 skips their epilogue. */
+int d2p_lstm_debug_flags(int flags);
+/* Tuning knobs: workgroups per launch the fused step kernels aim at (0 keeps the current value);
+ * fwd_pipelined 1 selects the register-lean forward kernel (2 workgroups/CU), 0 the all-loads-
+ * up-front one, -1 keeps the current choice. */
+int d2p_lstm_set_tiling(int fwd_wgs, int bwd_wgs, int fwd_pipelined);
 int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_stride, long z_t_stride,
                      const float* Wh, const float* h0, const float* c0, const int* lens,
                      float* hout, float* cs, float* h_final, float* c_final,
