@@ -124,47 +124,71 @@ struct Im2colXC {   // wgrad A operand (A^T·B form): x = kk (output rows), k = 
     }
 };
 
-// dgrad A operand: rows p = (n, iy, ix) input pixels; k = (tap, co).
-// value = dY[n, oy, ox, co] where oy*2 + ky - pt == iy (needs parity match and range).
-struct ColTKC {
+// ---- dgrad by output-parity classes -----------------------------------------------------
+// With stride 2 an input pixel (iy, ix) only receives taps whose parity matches:
+// ky == (iy + pt) mod 2, so rows with (iy+pt) even see ky in {0, 2}, odd rows ky = 1 (same in
+// x).  The 4 classes (qy, qx) have 4 / 2 / 2 / 1 valid taps: 2.25 per pixel instead of 9.
+// Each class is its own exact GEMM: rows m = (n, j, i) with iy = iy0 + 2j, ix = ix0 + 2i;
+// k = (t, co), t = ty*ntx + tx, ky = qy + 2*ty, kx = qx + 2*tx; oy = j + (iy0+pt-ky)/2.
+struct DgradClass {
+    int qy, qx, nty, ntx, iy0, ix0, Hc, Wc;
+};
+
+struct DgradAKC {   // A operand: colT(dY) restricted to one parity class
     static constexpr bool KCONTIG = true;
     const float* dy;
     ConvGeom g;
-    int Prows;
-    bool fast_ok(int K) const { return false; }   // parity test keeps this one on the guarded path
+    DgradClass c;
+    int Mrows;
+    int vec;
+    bool fast_ok(int K) const { return vec && Mrows > 0 && K >= 4; }
     template <bool FAST>
     __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
-        v[0] = v[1] = v[2] = v[3] = 0.f;
-        if (x >= Prows || k >= klim) return true;
-        const int hw = g.H * g.W;
+        bool ok = (x < Mrows) & (k < klim);
+        const int hw = c.Hc * c.Wc;
         const int n = x / hw;
         const int rem = x - n * hw;
-        const int iy = rem / g.W, ix = rem - iy * g.W;
-        // Cout % 4 == 0 is required by the entry point, so 4 consecutive k share a tap
-        const int tap = k / g.Cout, co = k - tap * g.Cout;
-        const int ky = tap / 3, kx = tap - ky * 3;
-        const int ty = iy + g.pt - ky, tx = ix + g.pl - kx;
-        if (ty < 0 || tx < 0 || (ty & 1) || (tx & 1)) return true;
-        const int oy = ty >> 1, ox = tx >> 1;
-        if (oy >= g.Ho || ox >= g.Wo) return true;
-        ld4(dy + (((long)n * g.Ho + oy) * g.Wo + ox) * g.Cout + co, v);
-        return true;
+        const int j = rem / c.Wc, i = rem - j * c.Wc;
+        const int t = k / g.Cout, co = k - t * g.Cout;
+        const int ty = t / c.ntx, tx = t - ty * c.ntx;
+        const int oy = j + ((c.iy0 + g.pt - (c.qy + 2 * ty)) >> 1);
+        const int ox = i + ((c.ix0 + g.pl - (c.qx + 2 * tx)) >> 1);
+        ok = ok & (oy >= 0) & (oy < g.Ho) & (ox >= 0) & (ox < g.Wo);
+        ld4(dy + (ok ? (((long)n * g.Ho + oy) * g.Wo + ox) * g.Cout + co : 0L), v);
+        if (!FAST && !ok) v[0] = v[1] = v[2] = v[3] = 0.f;
+        return FAST ? ok : true;
     }
 };
 
-// dgrad B operand: columns x = c (input channel), k = (tap, co): W[tap, c, co]
-struct WDgradKC {
+struct DgradBKC {   // B operand: columns x = c (input channel), k = (t, co): W[ky, kx, c, co]
     static constexpr bool KCONTIG = true;
     const float* w;
     int Cin, Cout;
-    bool fast_ok(int K) const { return false; }
+    DgradClass c;
+    int vec;
+    bool fast_ok(int K) const { return vec && Cin > 0 && K >= 4; }
     template <bool FAST>
     __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
-        v[0] = v[1] = v[2] = v[3] = 0.f;
-        if (x >= Cin || k >= klim) return true;
-        const int tap = k / Cout, co = k - tap * Cout;
-        ld4(w + ((long)tap * Cin + x) * Cout + co, v);
-        return true;
+        const bool ok = (x < Cin) & (k < klim);
+        const int t = k / Cout, co = k - t * Cout;
+        const int ty = t / c.ntx, tx = t - ty * c.ntx;
+        const int tap = (c.qy + 2 * ty) * 3 + (c.qx + 2 * tx);
+        ld4(w + (ok ? ((long)tap * Cin + x) * Cout + co : 0L), v);
+        if (!FAST && !ok) v[0] = v[1] = v[2] = v[3] = 0.f;
+        return FAST ? ok : true;
+    }
+};
+
+struct EpiDgrad {   // scatter the class rows back to their stride-2 pixel positions
+    float* dx;
+    int H, W, Cin;
+    DgradClass c;
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        const int hw = c.Hc * c.Wc;
+        const int n = row / hw;
+        const int rem = row - n * hw;
+        const int j = rem / c.Wc, i = rem - j * c.Wc;
+        dx[(((long)n * H + c.iy0 + 2 * j) * W + c.ix0 + 2 * i) * Cin + col] = v;
     }
 };
 
@@ -232,9 +256,24 @@ extern "C" int d2p_conv2d_nhwc_s2_same_dgrad(int N, int H, int W, int Cin, int C
     D2P_REQUIRE(Cout % 4 == 0 && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)w & 15) == 0), D2P_EALIGN,
                 "conv dgrad: needs Cout %% 4 == 0 and 16-byte aligned dy/w (Cout=%d)", Cout);
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
-    const int P = N * H * W, K = 9 * Cout;
-    ColTKC al{dy, g, P};
-    WDgradKC bl{w, Cin, Cout};
-    EpiDense ep{dx, Cin, nullptr, 0, 0};
-    return d2p_launch_gemm(al, bl, ep, P, Cin, K, nullptr, 0, as_stream(stream), "conv_dgrad", D2P_PROF_CONV);
+    for (int qy = 0; qy < 2; ++qy)
+        for (int qx = 0; qx < 2; ++qx) {
+            DgradClass c;
+            c.qy = qy; c.qx = qx;
+            c.nty = qy == 0 ? 2 : 1;
+            c.ntx = qx == 0 ? 2 : 1;
+            c.iy0 = qy ^ (g.pt & 1);             // (iy + pt) & 1 == qy
+            c.ix0 = qx ^ (g.pl & 1);
+            c.Hc = (H - c.iy0 + 1) / 2;
+            c.Wc = (W - c.ix0 + 1) / 2;
+            if (c.Hc <= 0 || c.Wc <= 0) continue;
+            const int Mc = N * c.Hc * c.Wc, K = c.nty * c.ntx * Cout;
+            DgradAKC al{dy, g, c, Mc, 1};
+            DgradBKC bl{w, Cin, Cout, c, 1};
+            EpiDgrad ep{dx, H, W, Cin, c};
+            rc = d2p_launch_gemm(al, bl, ep, Mc, Cin, K, nullptr, 0, as_stream(stream), "conv_dgrad",
+                                 D2P_PROF_CONV);
+            if (rc) return rc;
+        }
+    return D2P_OK;
 }

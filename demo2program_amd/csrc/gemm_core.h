@@ -115,21 +115,32 @@ struct EpiDense {
 };
 
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, bool FAST, class AL, class BL, class EP>
+// Tile shapes: BM x BN block tile, waves arranged WM x WN (WM*WN = 4), each wave owning
+// TM x TN MFMA tiles of 32x32 (TM = BM/WM/32, TN = BN/WN/32):
+//   64x64  (2x2, 1x1)  default for small problems
+//   128x128 (2x2, 2x2) large dense GEMMs
+//   128x32 (4x1, 1x1)  skinny N (conv Cout / Cin = 16..32): no wasted MFMA columns
+//   256x32 (4x1, 2x1)  very tall skinny N
+// ------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, bool FAST, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
     constexpr int BK = D2P_GEMM_BK;
-    constexpr int TM = BM / 64, TN = BN / 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
     constexpr int A_LD = AL::KCONTIG ? (BK + 4) : BM;
     constexpr int B_LD = BL::KCONTIG ? (BK + 4) : BN;
     constexpr int A_SZ = AL::KCONTIG ? BM * (BK + 4) : BK * BM;
     constexpr int B_SZ = BL::KCONTIG ? BN * (BK + 4) : BK * BN;
+    constexpr int CA = BM * BK / 4, CB = BN * BK / 4;           // float4 slots per slab
+    constexpr int IA = (CA + 255) / 256, IB = (CB + 255) / 256; // per-thread staging loads
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, hi = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     const int nbn = (N + BN - 1) / BN;
     const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
@@ -149,39 +160,49 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     // Two register staging sets: the loads of K-slab kt+2 are issued before the MFMAs of slab
     // kt and only written to LDS after the MFMAs of slab kt+1, so each global load has two
     // slabs of MFMA time (plus whatever other resident workgroups contribute) to land.
-    float ra0[TM][4], rb0[TN][4], ra1[TM][4], rb1[TN][4];
-    bool oa0[TM], ob0[TN], oa1[TM], ob1[TN];
+    float ra0[IA][4], rb0[IB][4], ra1[IA][4], rb1[IB][4];
+    bool oa0[IA], ob0[IB], oa1[IA], ob1[IB];
 
-#define D2P_GLOAD(RA, RB, OA, OB, kt)                                                                   \
-    {                                                                                           \
-        const int k0 = kbeg + (kt) * BK;                                                        \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
-            const int q = tid + i * 256;                                                        \
-            if (AL::KCONTIG) OA[i] = al.template load4<FAST>(m0 + (q >> 2), k0 + (q & 3) * 4, kend, RA[i]);            \
-            else OA[i] = al.template load4<FAST>(m0 + (q % (BM / 4)) * 4, k0 + q / (BM / 4), kend, RA[i]);             \
-        }                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                        \
-            const int q = tid + i * 256;                                                        \
-            if (BL::KCONTIG) OB[i] = bl.template load4<FAST>(n0 + (q >> 2), k0 + (q & 3) * 4, kend, RB[i]);            \
-            else OB[i] = bl.template load4<FAST>(n0 + (q % (BN / 4)) * 4, k0 + q / (BN / 4), kend, RB[i]);             \
-        }                                                                                       \
+#define D2P_GLOAD(RA, RB, OA, OB, kt)                                                              \
+    {                                                                                              \
+        const int k0 = kbeg + (kt) * BK;                                                           \
+        _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
+            const int q = tid + i * 256;                                                           \
+            if (CA % 256 == 0 || q < CA) {                                                         \
+                if (AL::KCONTIG) OA[i] = al.template load4<FAST>(m0 + (q >> 2), k0 + (q & 3) * 4, kend, RA[i]); \
+                else OA[i] = al.template load4<FAST>(m0 + (q % (BM / 4)) * 4, k0 + q / (BM / 4), kend, RA[i]); \
+            }                                                                                      \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < IB; ++i) {                                           \
+            const int q = tid + i * 256;                                                           \
+            if (CB % 256 == 0 || q < CB) {                                                         \
+                if (BL::KCONTIG) OB[i] = bl.template load4<FAST>(n0 + (q >> 2), k0 + (q & 3) * 4, kend, RB[i]); \
+                else OB[i] = bl.template load4<FAST>(n0 + (q % (BN / 4)) * 4, k0 + q / (BN / 4), kend, RB[i]); \
+            }                                                                                      \
+        }                                                                                          \
     }
-#define D2P_SSTORE(RA, RB, OA, OB, buf)                                                                 \
-    {                                                                                           \
-        float* As = smem + (buf) * (A_SZ + B_SZ);                                               \
-        float* Bs = As + A_SZ;                                                                  \
-        _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                        \
-            const int q = tid + i * 256;                                                        \
-            float4 t = make_float4(OA[i] ? RA[i][0] : 0.f, OA[i] ? RA[i][1] : 0.f, OA[i] ? RA[i][2] : 0.f, OA[i] ? RA[i][3] : 0.f);                     \
-            if (AL::KCONTIG) *reinterpret_cast<float4*>(&As[(q >> 2) * A_LD + (q & 3) * 4]) = t; \
-            else *reinterpret_cast<float4*>(&As[(q / (BM / 4)) * A_LD + (q % (BM / 4)) * 4]) = t; \
-        }                                                                                       \
-        _Pragma("unroll") for (int i = 0; i < TN; ++i) {                                        \
-            const int q = tid + i * 256;                                                        \
-            float4 t = make_float4(OB[i] ? RB[i][0] : 0.f, OB[i] ? RB[i][1] : 0.f, OB[i] ? RB[i][2] : 0.f, OB[i] ? RB[i][3] : 0.f);                     \
-            if (BL::KCONTIG) *reinterpret_cast<float4*>(&Bs[(q >> 2) * B_LD + (q & 3) * 4]) = t; \
-            else *reinterpret_cast<float4*>(&Bs[(q / (BN / 4)) * B_LD + (q % (BN / 4)) * 4]) = t; \
-        }                                                                                       \
+#define D2P_SSTORE(RA, RB, OA, OB, buf)                                                            \
+    {                                                                                              \
+        float* As = smem + (buf) * (A_SZ + B_SZ);                                                  \
+        float* Bs = As + A_SZ;                                                                     \
+        _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
+            const int q = tid + i * 256;                                                           \
+            if (CA % 256 == 0 || q < CA) {                                                         \
+                float4 t = make_float4(OA[i] ? RA[i][0] : 0.f, OA[i] ? RA[i][1] : 0.f,             \
+                                       OA[i] ? RA[i][2] : 0.f, OA[i] ? RA[i][3] : 0.f);            \
+                if (AL::KCONTIG) *reinterpret_cast<float4*>(&As[(q >> 2) * A_LD + (q & 3) * 4]) = t; \
+                else *reinterpret_cast<float4*>(&As[(q / (BM / 4)) * A_LD + (q % (BM / 4)) * 4]) = t; \
+            }                                                                                      \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < IB; ++i) {                                           \
+            const int q = tid + i * 256;                                                           \
+            if (CB % 256 == 0 || q < CB) {                                                         \
+                float4 t = make_float4(OB[i] ? RB[i][0] : 0.f, OB[i] ? RB[i][1] : 0.f,             \
+                                       OB[i] ? RB[i][2] : 0.f, OB[i] ? RB[i][3] : 0.f);            \
+                if (BL::KCONTIG) *reinterpret_cast<float4*>(&Bs[(q >> 2) * B_LD + (q & 3) * 4]) = t; \
+                else *reinterpret_cast<float4*>(&Bs[(q / (BN / 4)) * B_LD + (q % (BN / 4)) * 4]) = t; \
+            }                                                                                      \
+        }                                                                                          \
     }
     auto compute = [&](int buf) {
         const float* As = smem + buf * (A_SZ + B_SZ);
@@ -191,7 +212,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             float fa[TM][4], fb[TN][4];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const int x = wm * (BM / 2) + i * 32 + l32;
+                const int x = wm * (BM / WM) + i * 32 + l32;
                 if (AL::KCONTIG) {
                     float4 t = *reinterpret_cast<const float4*>(&As[x * A_LD + kk * 8 + 4 * hi]);
                     fa[i][0] = t.x; fa[i][1] = t.y; fa[i][2] = t.z; fa[i][3] = t.w;
@@ -202,7 +223,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                const int x = wn * (BN / 2) + i * 32 + l32;
+                const int x = wn * (BN / WN) + i * 32 + l32;
                 if (BL::KCONTIG) {
                     float4 t = *reinterpret_cast<const float4*>(&Bs[x * B_LD + kk * 8 + 4 * hi]);
                     fb[i][0] = t.x; fb[i][1] = t.y; fb[i][2] = t.z; fb[i][3] = t.w;
@@ -252,8 +273,8 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int col = n0 + wn * (BN / 2) + j * 32 + l32;
+                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int col = n0 + wn * (BN / WN) + j * 32 + l32;
                 if (row < M && col < N) {
                     if (split) partial[((long)blockIdx.z * M + row) * N + col] = acc[i][j][r];
                     else ep(row, col, acc[i][j][r]);
@@ -276,8 +297,11 @@ gemm_splitk_reduce_kernel(EP ep, const float* partial, int M, int N, int nz) {
 // ------------------------------------------------------------------------------------
 // Host-side launch policy shared by gemm.hip and conv.hip.
 // ------------------------------------------------------------------------------------
+enum GemmTile { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x32 = 2, TILE_256x32 = 3 };
+
 struct GemmPlan {
-    int big;      // 1: 128x128 tiles, 0: 64x64
+    int tile;     // GemmTile
+    int bm, bn;
     int splits;   // grid.z
     int k_per_split;
 };
@@ -285,11 +309,18 @@ struct GemmPlan {
 static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
     GemmPlan p;
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
-    const long t64 = (long)ceil_div(M, 64) * ceil_div(N, 64);
-    p.big = (t128 >= 512) ? 1 : 0;   // >= 2 full rounds of 256 CUs at the large tile
+    if (N <= 32) {                       // skinny outputs: keep every MFMA column useful
+        const long t256 = (long)ceil_div(M, 256);
+        if (t256 >= 1024) { p.tile = TILE_256x32; p.bm = 256; p.bn = 32; }
+        else { p.tile = TILE_128x32; p.bm = 128; p.bn = 32; }
+    } else if (t128 >= 512) {            // >= 2 full rounds of 256 CUs at the large tile
+        p.tile = TILE_128x128; p.bm = 128; p.bn = 128;
+    } else {
+        p.tile = TILE_64x64; p.bm = 64; p.bn = 64;
+    }
     p.splits = 1;
     p.k_per_split = K;
-    const long tiles = p.big ? t128 : t64;
+    const long tiles = (long)ceil_div(M, p.bm) * ceil_div(N, p.bn);
     if (allow_split && tiles <= 512 && K >= 1024) {
         long want = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
         long maxs = K / 512;                             // keep >= 512 of K per split
@@ -307,6 +338,18 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
 static inline size_t d2p_plan_ws_bytes(int M, int N, int K) {
     GemmPlan p = d2p_plan_gemm(M, N, K, true);
     return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+}
+
+template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
+                            const GemmPlan& p, bool fast, float* partial, hipStream_t st) {
+    dim3 grid(ceil_div(M, BM) * ceil_div(N, BN), 1, p.splits);
+    if (fast)
+        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, true, AL, BL, EP>), grid, dim3(256), 0, st,
+                           al, bl, ep, M, N, K, p.k_per_split, partial);
+    else
+        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, false, AL, BL, EP>), grid, dim3(256), 0, st,
+                           al, bl, ep, M, N, K, p.k_per_split, partial);
 }
 
 template <class AL, class BL, class EP>
@@ -327,22 +370,11 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         }
     }
     const bool fast = al.fast_ok(K) && bl.fast_ok(K);
-    if (p.big) {
-        dim3 grid(ceil_div(M, 128) * ceil_div(N, 128), 1, p.splits);
-        if (fast)
-            hipLaunchKernelGGL((gemm_mfma_kernel<128, 128, true, AL, BL, EP>), grid, dim3(256), 0, st,
-                               al, bl, ep, M, N, K, p.k_per_split, partial);
-        else
-            hipLaunchKernelGGL((gemm_mfma_kernel<128, 128, false, AL, BL, EP>), grid, dim3(256), 0, st,
-                               al, bl, ep, M, N, K, p.k_per_split, partial);
-    } else {
-        dim3 grid(ceil_div(M, 64) * ceil_div(N, 64), 1, p.splits);
-        if (fast)
-            hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, true, AL, BL, EP>), grid, dim3(256), 0, st,
-                               al, bl, ep, M, N, K, p.k_per_split, partial);
-        else
-            hipLaunchKernelGGL((gemm_mfma_kernel<64, 64, false, AL, BL, EP>), grid, dim3(256), 0, st,
-                               al, bl, ep, M, N, K, p.k_per_split, partial);
+    switch (p.tile) {
+        case TILE_128x128: d2p_launch_tile<128, 128, 2, 2>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_128x32: d2p_launch_tile<128, 32, 4, 1>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_256x32: d2p_launch_tile<256, 32, 4, 1>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        default: d2p_launch_tile<64, 64, 2, 2>(al, bl, ep, M, N, K, p, fast, partial, st); break;
     }
     D2P_LAUNCH_CHECK(name);
     if (p.splits > 1) {

@@ -264,3 +264,49 @@ extern "C" int d2p_transpose_rt(int R, int T, int C, const float* in, float* out
     D2P_LAUNCH_CHECK("transpose_rt");
     return D2P_OK;
 }
+
+// ---- pad / unpad one axis with zeros: out[o, c, i] = c < C ? in[o, c, i] : 0 ----------------
+// Used to bring 3-channel ViZDoom frames (and conv1's [3,3,3,16] weights) to 4 channels so that
+// the implicit-im2col loaders gather 16 bytes (or one packed uint8x4 pixel) per tap.
+template <typename T>
+__global__ void __launch_bounds__(256)
+pad_axis_kernel(long outer, int C, int Cp, int inner, const T* in, T* out) {
+    const long total = outer * Cp * inner;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int i = (int)(idx % inner);
+        const long oc = idx / inner;
+        const int c = (int)(oc % Cp);
+        const long o = oc / Cp;
+        out[idx] = c < C ? in[(o * C + c) * inner + i] : (T)0;
+    }
+}
+template <typename T>
+__global__ void __launch_bounds__(256)
+unpad_axis_kernel(long outer, int C, int Cp, int inner, const T* in, T* out) {
+    const long total = outer * C * inner;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int i = (int)(idx % inner);
+        const long oc = idx / inner;
+        const int c = (int)(oc % C);
+        const long o = oc / C;
+        out[idx] = in[(o * Cp + c) * inner + i];
+    }
+}
+
+extern "C" int d2p_pad_axis(long outer, int C, int Cp, int inner, const void* in, void* out,
+                            int is_u8, int unpad, d2p_stream_t stream) {
+    D2P_REQUIRE(outer >= 0 && C > 0 && Cp >= C && inner > 0, D2P_EINVAL, "pad_axis: bad sizes");
+    if (outer == 0) return D2P_OK;
+    D2P_REQUIRE(in && out, D2P_EINVAL, "pad_axis: null pointer");
+    hipStream_t st = as_stream(stream);
+    const int blocks = ew_blocks(outer * (unpad ? C : Cp) * inner);
+    if (is_u8) {
+        if (unpad) hipLaunchKernelGGL((unpad_axis_kernel<uint8_t>), dim3(blocks), dim3(256), 0, st, outer, C, Cp, inner, (const uint8_t*)in, (uint8_t*)out);
+        else hipLaunchKernelGGL((pad_axis_kernel<uint8_t>), dim3(blocks), dim3(256), 0, st, outer, C, Cp, inner, (const uint8_t*)in, (uint8_t*)out);
+    } else {
+        if (unpad) hipLaunchKernelGGL((unpad_axis_kernel<float>), dim3(blocks), dim3(256), 0, st, outer, C, Cp, inner, (const float*)in, (float*)out);
+        else hipLaunchKernelGGL((pad_axis_kernel<float>), dim3(blocks), dim3(256), 0, st, outer, C, Cp, inner, (const float*)in, (float*)out);
+    }
+    D2P_LAUNCH_CHECK("pad_axis");
+    return D2P_OK;
+}

@@ -337,6 +337,13 @@ def transpose_rt(x, R, T, C, out=None):
     return out
 
 
+def pad_axis(x, outer, C, Cp, inner, out, unpad=False):
+    """out[o,c,i] = x[o,c,i] (c < C) else 0 over [outer,Cp,inner]; unpad=True slices back."""
+    call.d2p_pad_axis(outer, C, Cp, inner, ptr(x), ptr(out), 1 if x.dtype == torch.uint8 else 0,
+                      1 if unpad else 0, current_stream())
+    return out
+
+
 # ---------------------------------------------------------------- optimizer
 def l2norm_flat(g, prescale, sumsq):
     ws, wsb = SCRATCH.get(call.d2p_l2norm_ws_bytes(g.numel()))

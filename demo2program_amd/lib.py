@@ -62,6 +62,7 @@ SIGNATURES = {
     'd2p_pair_mean_bwd': (c_int, [c_int, c_int, c_int, P, P, S]),
     'd2p_axpy': (c_int, [c_size_t, c_float, P, P, c_int, S]),
     'd2p_transpose_rt': (c_int, [c_int, c_int, c_int, P, P, S]),
+    'd2p_pad_axis': (c_int, [c_long, c_int, c_int, c_int, P, P, c_int, c_int, S]),
     'd2p_zero_past_group_steps': (c_int, [c_int, c_int, c_int, c_int, P, P, S]),
     'd2p_l2norm_ws_bytes': (c_size_t, [c_size_t]),
     'd2p_l2norm_flat': (c_int, [c_size_t, P, c_float, P, P, c_size_t, S]),

@@ -164,7 +164,15 @@ class Model(object):
         x = feed['s_h']
         ctx['conv'] = []
         for l, (h, w, cin, cout, ho, wo) in enumerate(self._conv, start=1):
-            a = K.conv_fwd(x, p['conv%d/W' % l], p['conv%d/b' % l], act=1,
+            Wl = p['conv%d/W' % l]
+            if l == 1 and cin % 4 != 0:
+                # 3-channel (ViZDoom) frames: zero-pad frames and weights to 4 channels so every
+                # tap is one 16-byte (uint8x4: 4-byte) gather; the extra channel contributes 0
+                cp = (cin + 3) // 4 * 4
+                x = K.pad_axis(x, NF * h * w, cin, cp, 1,
+                               self._buf('conv1/xpad', (NF, h, w, cp), x.dtype))
+                Wl = K.pad_axis(Wl, 9, cin, cp, cout, self._buf('conv1/Wpad', (3, 3, cp, cout)))
+            a = K.conv_fwd(x, Wl, p['conv%d/b' % l], act=1,
                            out=self._buf('conv%d/a' % l, (NF, ho, wo, cout)))
             y, mean, rstd = self._bn_fwd('conv%d' % l, a.view(NF * ho * wo, cout),
                                          p['conv%d/gamma' % l], p['conv%d/beta' % l], k, T * ho * wo)
@@ -358,7 +366,13 @@ class Model(object):
                            mean, rstd, k, T * ho * wo, True, g['conv%d/gamma' % l], g['conv%d/beta' % l],
                            dx=self._buf('conv%d/da' % l, (NF * ho * wo, cout)))
             K.colsum(da_, out=g['conv%d/b' % l])
-            K.conv_wgrad(x_in, da_.view(NF, ho, wo, cout), g['conv%d/W' % l])
+            if x_in.shape[3] != cin:            # channel-padded conv1 input: unpad the gradient
+                cp = x_in.shape[3]
+                gpad = K.conv_wgrad(x_in, da_.view(NF, ho, wo, cout),
+                                    self._buf('conv1/gWpad', (3, 3, cp, cout)))
+                K.pad_axis(gpad, 9, cin, cp, cout, g['conv%d/W' % l], unpad=True)
+            else:
+                K.conv_wgrad(x_in, da_.view(NF, ho, wo, cout), g['conv%d/W' % l])
             if l > 1:
                 dy = K.conv_dgrad(da_.view(NF, ho, wo, cout), p['conv%d/W' % l], (NF, h, w, cin),
                                   dx=self._buf('conv%d/dx' % l, (NF, h, w, cin)))

@@ -239,6 +239,11 @@ int d2p_pair_mean_bwd(int B, int kk, int U, const float* dout, float* dy, d2p_st
 int d2p_axpy(size_t n, float a, const float* x, float* y, int accumulate, d2p_stream_t stream);
 /* out[t, r, :] = in[r, t, :]  (R x T x C -> T x R x C) */
 int d2p_transpose_rt(int R, int T, int C, const float* in, float* out, d2p_stream_t stream);
+/* out[o, c, i] = c < C ? in[o, c, i] : 0 over [outer, Cp, inner] (unpad = 0), or the inverse
+ * slice out[o, c, i] = in[o, c, i], c < C, over [outer, C, inner] (unpad = 1).  fp32 or uint8.
+ * Brings 3-channel frames / conv1 weights to 4 channels for 16-byte (uint8x4) tap gathers. */
+int d2p_pad_axis(long outer, int C, int Cp, int inner, const void* in, void* out, int is_u8,
+                 int unpad, d2p_stream_t stream);
 /* zero logits rows (t, r) with t >= nsteps_g[r % G]  (per-demo dynamic padding,
  * models/model_full.py:476-484); nsteps_g[g] = min(T, max_{r%G==g} lens[r]) computed on device. */
 int d2p_zero_past_group_steps(int T, int R, int V, int G, const int* lens, float* logits, d2p_stream_t stream);

@@ -96,6 +96,27 @@ def test_matches_committed_golden_fixture():
         assert np.abs(g[n] - ref).max() <= 5e-4 * np.abs(ref).max() + 1e-6, n
 
 
+def test_uint8_frames_give_the_same_result_as_float_frames():
+    """ViZDoom frames are bytes 0..255 (vizdoom_env/generator.py:184): feeding them as uint8
+    (widened inside the conv loader, 4x less H2D traffic) must not change anything; also
+    exercises the 3 -> 4 channel padding of conv1."""
+    from demo2program_amd.models.model_full import Model
+    for kind in ('vizdoom', 'karel'):
+        cfg, params, batch = small_case(kind, seed=13)
+        m1 = Model(cfg, params=params)
+        l1 = float(m1.forward(m1.get_feed_dict(batch)).item())
+        m1.backward()
+        g1 = m1.params.grad.clone()
+        b8 = dict(batch)
+        b8['s_h'] = batch['s_h'].astype(np.uint8)
+        assert np.array_equal(b8['s_h'].astype(np.float32), batch['s_h'])
+        m2 = Model(cfg, params=params)
+        l2 = float(m2.forward(m2.get_feed_dict(b8)).item())
+        m2.backward()
+        assert abs(l1 - l2) <= 1e-6 * abs(l1), (kind, l1, l2)
+        assert (g1 - m2.params.grad).abs().max().item() <= 1e-5 * g1.abs().max().item()
+
+
 def test_output_list_and_dynamic_padding():
     cfg, params, batch = small_case('karel', seed=5)
     # shorten every program / demo so that dynamic_decode stops early (SURVEY D8)
