@@ -17,9 +17,12 @@ struct BnPlan {
     int S;          // row splits per group
 };
 
+// With C % 4 == 0 each thread owns 4 consecutive channels (one 16-byte load per row), so the
+// "channel lanes" count is C/4; otherwise one channel per thread.
 static inline BnPlan bn_plan(int R, int C, int G) {
     BnPlan p;
-    p.lanes_c = C < 256 ? C : 256;
+    const int cl = (C % 4 == 0) ? C / 4 : C;
+    p.lanes_c = cl < 256 ? cl : 256;
     p.row_lanes = 256 / p.lanes_c;
     const int n = G > 0 ? R / G : 0;                      // rows per group
     int s = 1024 / (G > 0 ? G : 1);
@@ -42,46 +45,74 @@ extern "C" size_t d2p_bn_ws_bytes(int R, int C, int G) {
 // partial[((g*S + s)*C + c)*2 + {0,1}] = sum over this block's rows of (a, b) where
 //   MODE 0 (fwd):  a = x,   b = x*x
 //   MODE 1 (bwd):  a = dy,  b = dy * xhat
-template <int MODE>
+// VEC = 4: thread owns channels 4*cl .. 4*cl+3 (16-byte loads); VEC = 1: one channel.
+template <int MODE, int VEC>
 __global__ void __launch_bounds__(256)
 bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, const float* x,
                   const float* dy, const float* mean, const float* rstd, double* partial) {
-    __shared__ double red[2][256];
+    __shared__ double red[2][VEC][256];
     const int g = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     const int tid = threadIdx.x;
     const int cl = tid % lanes_c, rl = tid / lanes_c;
     const bool active = rl < row_lanes;
-    for (int c0 = 0; c0 < C; c0 += lanes_c) {
-        const int c = c0 + cl;
-        double a = 0.0, b = 0.0;
+    const int CL = C / VEC;                       // channel lanes in total
+    for (int c0 = 0; c0 < CL; c0 += lanes_c) {
+        const int c = (c0 + cl) * VEC;
+        double a[VEC], b[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) a[e] = b[e] = 0.0;
         if (active && c < C) {
-            float mu = 0.f, rs = 0.f;
-            if (MODE == 1) { mu = mean[g * C + c]; rs = rstd[g * C + c]; }
+            float mu[VEC], rs[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                mu[e] = MODE == 1 ? mean[g * C + c + e] : 0.f;
+                rs[e] = MODE == 1 ? rstd[g * C + c + e] : 0.f;
+            }
             for (int j = s * row_lanes + rl; j < n; j += S * row_lanes) {
                 const int o = j / inner, ii = j - o * inner;
                 const long r = ((long)o * G + g) * inner + ii;
-                const float xv = x[r * C + c];
-                if (MODE == 0) {
-                    a += (double)xv;
-                    b += (double)xv * (double)xv;
+                float xv[VEC], dv[VEC];
+                if (VEC == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(x + r * C + c);
+                    xv[0] = t.x; xv[1 % VEC] = t.y; xv[2 % VEC] = t.z; xv[3 % VEC] = t.w;
+                    if (MODE == 1) {
+                        const float4 d = *reinterpret_cast<const float4*>(dy + r * C + c);
+                        dv[0] = d.x; dv[1 % VEC] = d.y; dv[2 % VEC] = d.z; dv[3 % VEC] = d.w;
+                    }
                 } else {
-                    const float d = dy[r * C + c];
-                    a += (double)d;
-                    b += (double)d * (double)((xv - mu) * rs);
+                    xv[0] = x[r * C + c];
+                    if (MODE == 1) dv[0] = dy[r * C + c];
+                }
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    if (MODE == 0) {
+                        a[e] += (double)xv[e];
+                        b[e] += (double)xv[e] * (double)xv[e];
+                    } else {
+                        a[e] += (double)dv[e];
+                        b[e] += (double)dv[e] * (double)((xv[e] - mu[e]) * rs[e]);
+                    }
                 }
             }
         }
-        red[0][tid] = a;
-        red[1][tid] = b;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            red[0][e][tid] = a[e];
+            red[1][e][tid] = b[e];
+        }
         __syncthreads();
         if (rl == 0 && c < C) {
-            for (int q = 1; q < row_lanes; ++q) {
-                a += red[0][q * lanes_c + cl];
-                b += red[1][q * lanes_c + cl];
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                double aa = a[e], bb = b[e];
+                for (int q = 1; q < row_lanes; ++q) {
+                    aa += red[0][e][q * lanes_c + cl];
+                    bb += red[1][e][q * lanes_c + cl];
+                }
+                double* out = partial + (((long)g * S + s) * C + c + e) * 2;
+                out[0] = aa;
+                out[1] = bb;
             }
-            double* out = partial + (((long)g * S + s) * C + c) * 2;
-            out[0] = a;
-            out[1] = b;
         }
         __syncthreads();
     }
@@ -232,9 +263,15 @@ extern "C" int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, 
     BnPlan p = bn_plan(R, C, G);
     const int n = R / G;
     double* partial = (double*)ws;
-    hipLaunchKernelGGL((bn_partial_kernel<0>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
-                       p.lanes_c, p.row_lanes, x, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, partial);
+    const bool vec4 = (C % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    if (vec4)
+        hipLaunchKernelGGL((bn_partial_kernel<0, 4>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
+                           p.lanes_c, p.row_lanes, x, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, partial);
+    else
+        hipLaunchKernelGGL((bn_partial_kernel<0, 1>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
+                           (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, partial);
     D2P_LAUNCH_CHECK("bn_partial_fwd");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, st, n, C, G,
                        p.S, partial, mean, rstd, var_out);
@@ -268,8 +305,13 @@ extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, 
     double* partial = (double*)ws;
     double* gsum = partial + (size_t)G * p.S * C * 2;
     float* m12 = (float*)(gsum + (size_t)G * C * 2);
-    hipLaunchKernelGGL((bn_partial_kernel<1>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
-                       p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial);
+    const bool vec4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
+    if (vec4)
+        hipLaunchKernelGGL((bn_partial_kernel<1, 4>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
+                           p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial);
+    else
+        hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
+                           (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, dy, mean, rstd, partial);
     D2P_LAUNCH_CHECK("bn_partial_bwd");
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, st, n, C, G,
                        p.S, partial, m12, gsum);

@@ -90,13 +90,17 @@ colsum_stage1(int rows, int cols, const float* X, long ld, float* part) {
         part[(long)blockIdx.y * cols + c] =
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ void __launch_bounds__(256) colsum_stage2(int cols, int S, const float* part, float* out) {
+// fold > 1: the matrix was viewed as [rows/fold, cols*fold]; out[c] = sum_g colsum[g*cols + c]
+__global__ void __launch_bounds__(256)
+colsum_stage2(int cols, int fold, int S, const float* part, float* out) {
     __shared__ float red[4][64];
+    const int wc = cols * fold;                       // width of the partial rows
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int sl = threadIdx.x >> 6;
     float s = 0.f;
     if (c < cols)
-        for (int i = sl; i < S; i += 4) s += part[(long)i * cols + c];
+        for (int i = sl; i < S; i += 4)
+            for (int g = 0; g < fold; ++g) s += part[(long)i * wc + g * cols + c];
     red[sl][threadIdx.x & 63] = s;
     __syncthreads();
     if (sl == 0 && c < cols)
@@ -117,11 +121,17 @@ extern "C" int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float
                 "colsum: workspace too small (%zu < %zu)", ws_bytes, d2p_colsum_ws_bytes(rows, cols));
     hipStream_t st = as_stream(stream);
     float* part = (float*)ws;
-    const int S = colsum_S(rows, cols);
-    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(cols, 64), S), dim3(256), 0, st, rows, cols, X,
-                       ld, part);
+    // narrow contiguous matrices (conv channels 16/32): view [rows, cols] as
+    // [rows/fold, cols*fold] so that all 64 lanes of a wave read one contiguous 256 B row
+    int fold = 1;
+    if (cols < 64 && 64 % cols == 0 && ld == cols && rows % (64 / cols) == 0) fold = 64 / cols;
+    const int vrows = rows / fold, vcols = cols * fold;
+    const int S = colsum_S(vrows, vcols);
+    hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(vcols, 64), S), dim3(256), 0, st, vrows, vcols, X,
+                       (long)(fold > 1 ? vcols : ld), part);
     D2P_LAUNCH_CHECK("colsum_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 64)), dim3(256), 0, st, cols, S, part, out);
+    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 64)), dim3(256), 0, st, cols, fold, S, part,
+                       out);
     D2P_LAUNCH_CHECK("colsum_stage2");
     return D2P_OK;
 }

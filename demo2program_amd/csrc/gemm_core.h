@@ -282,10 +282,30 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             }
 }
 
-// Deterministic split-K combine: sums the nz partial slabs in slab order, then applies EP.
+// Deterministic split-K combine: 16 lanes per output element each sum slabs z = l, l+16, ...
+// then a fixed-order xor-shuffle tree combines them; EP is applied by lane 0 of the group.
 template <class EP>
 __global__ void __launch_bounds__(256)
 gemm_splitk_reduce_kernel(EP ep, const float* partial, int M, int N, int nz) {
+    const long total = (long)M * N;
+    const int sub = threadIdx.x & 15;
+    for (long base = (blockIdx.x * 256L + threadIdx.x) >> 4; base < ((total + 15) & ~15L);
+         base += ((long)gridDim.x * 256L) >> 4) {
+        float s = 0.f;
+        if (base < total)
+            for (int z = sub; z < nz; z += 16) s += partial[(long)z * total + base];
+        s += __shfl_xor(s, 8, 64);
+        s += __shfl_xor(s, 4, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 1, 64);
+        if (sub == 0 && base < total) ep((int)(base / N), (int)(base % N), s);
+    }
+}
+
+// Few slabs (weight gradients with 4-8 splits over a large output): one thread per element.
+template <class EP>
+__global__ void __launch_bounds__(256)
+gemm_splitk_reduce_flat_kernel(EP ep, const float* partial, int M, int N, int nz) {
     const long total = (long)M * N;
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
         float s = 0.f;
@@ -297,7 +317,7 @@ gemm_splitk_reduce_kernel(EP ep, const float* partial, int M, int N, int nz) {
 // ------------------------------------------------------------------------------------
 // Host-side launch policy shared by gemm.hip and conv.hip.
 // ------------------------------------------------------------------------------------
-enum GemmTile { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x32 = 2, TILE_256x32 = 3 };
+enum GemmTile { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x32 = 2, TILE_256x32 = 3, TILE_128x64 = 4 };
 
 struct GemmPlan {
     int tile;     // GemmTile
@@ -313,6 +333,8 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
         const long t256 = (long)ceil_div(M, 256);
         if (t256 >= 1024) { p.tile = TILE_256x32; p.bm = 256; p.bn = 32; }
         else { p.tile = TILE_128x32; p.bm = 128; p.bn = 32; }
+    } else if (N <= 64 && (long)ceil_div(M, 128) >= 512) {   // e.g. conv Cout = 48
+        p.tile = TILE_128x64; p.bm = 128; p.bn = 64;
     } else if (t128 >= 512) {            // >= 2 full rounds of 256 CUs at the large tile
         p.tile = TILE_128x128; p.bm = 128; p.bn = 128;
     } else {
@@ -325,6 +347,7 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
         long want = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
         long maxs = K / 512;                             // keep >= 512 of K per split
         long s = want < maxs ? want : maxs;
+        if (s > 256) s = 256;                            // bound the combine pass
         if (s > 1) {
             int kps = (int)((K + s - 1) / s);
             kps = (kps + D2P_GEMM_BK - 1) / D2P_GEMM_BK * D2P_GEMM_BK;
@@ -374,15 +397,23 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         case TILE_128x128: d2p_launch_tile<128, 128, 2, 2>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         case TILE_128x32: d2p_launch_tile<128, 32, 4, 1>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         case TILE_256x32: d2p_launch_tile<256, 32, 4, 1>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_128x64: d2p_launch_tile<128, 64, 2, 2>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         default: d2p_launch_tile<64, 64, 2, 2>(al, bl, ep, M, N, K, p, fast, partial, st); break;
     }
     D2P_LAUNCH_CHECK(name);
     if (p.splits > 1) {
         const long total = (long)M * N;
-        int blocks = (int)((total + 255) / 256);
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EP>), dim3(blocks), dim3(256), 0, st, ep,
-                           partial, M, N, p.splits);
+        if (p.splits <= 16) {
+            int blocks = (int)((total + 255) / 256);
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL((gemm_splitk_reduce_flat_kernel<EP>), dim3(blocks), dim3(256), 0, st, ep,
+                               partial, M, N, p.splits);
+        } else {
+            int blocks = (int)((total * 16 + 255) / 256);
+            if (blocks > 4096) blocks = 4096;
+            hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EP>), dim3(blocks), dim3(256), 0, st, ep,
+                               partial, M, N, p.splits);
+        }
         D2P_LAUNCH_CHECK("gemm_splitk_reduce");
     }
     return D2P_OK;
