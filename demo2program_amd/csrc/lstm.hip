@@ -159,6 +159,7 @@ extern "C" int d2p_lstm_set_fused(int on) {
     g_lstm_fused = on ? 1 : 0;
     return D2P_OK;
 }
+int d2p_lstm_is_fused_enabled() { return g_lstm_fused; }
 
 static size_t unfused_ws_bytes(int M, int U) { return (size_t)3 * M * U * sizeof(float); }
 

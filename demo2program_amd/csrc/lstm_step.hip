@@ -228,17 +228,32 @@ __device__ __forceinline__ void fwd_gemm_pipe(const f32x4* __restrict__ Af, cons
                 P[wave][i * 16 + (lane >> 4) * 4 + r][s * 16 + (lane & 15)] = acc[i][s][r];
 }
 
+// Up to D2P_MAX_SEQ independent LSTMs (same U) advance one step in ONE launch ("horizontal
+// fusion": e.g. the action, perception and program decoders).  Workgroups [0, nb[0]) serve
+// sequence 0, the next nb[1] sequence 1, ...  Fewer launches, and workgroups of different
+// LSTMs share a CU (<= 256 registers each), overlapping each other's memory and MFMA phases
+// without any extra operand traffic.
+#define D2P_MAX_SEQ 3
+struct StepFwdMulti {
+    StepFwdArgs s[D2P_MAX_SEQ];
+    int nb[D2P_MAX_SEQ];
+};
+
 template <int CPW, bool PIPE>   // 16-wide k chunks per wave; U = 64*CPW
-__global__ void __launch_bounds__(256, PIPE ? 2 : 1) lstm_step_fwd_kernel(StepFwdArgs a) {
+__global__ void __launch_bounds__(256, PIPE ? 2 : 1) lstm_step_fwd_kernel(StepFwdMulti mm) {
     constexpr int KC = 4 * CPW;
     __shared__ __attribute__((aligned(16))) float P[4][FWD_RSMAX * 16][P_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x, si = 0;
+    if (bid >= mm.nb[0]) { bid -= mm.nb[0]; si = 1; if (bid >= mm.nb[1]) { bid -= mm.nb[1]; si = 2; } }
+    const StepFwdArgs& a = mm.s[si];
     const int U = a.U;
-    // block -> (ct, rt): all row tiles of a column tile on one XCD (block b runs on XCD b % 8)
+    // block -> (ct, rt): all row tiles of a column tile on one XCD (block b runs on XCD b % 8;
+    // every nb[] is a multiple of 8, so bid % 8 == blockIdx.x % 8)
     const int nct = U >> 3;
     int ct, rt;
     {
-        const int b = blockIdx.x;
+        const int b = bid;
         if ((nct & 7) == 0) {
             const int per_xcd = nct >> 3, xcd = b & 7, slot = b >> 3;
             ct = xcd * per_xcd + slot / a.RT;
@@ -415,17 +430,25 @@ __device__ __forceinline__ void bwd_gemm(const f32x4* __restrict__ Af, const f32
         for (int r = 0; r < 4; ++r) P[wave][i * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[i][r];
 }
 
+struct StepBwdMulti {
+    StepBwdArgs s[D2P_MAX_SEQ];
+    int nb[D2P_MAX_SEQ];
+};
+
 template <int DUMMY>
-__global__ void __launch_bounds__(256, 2) lstm_step_bwd_kernel(StepBwdArgs a) {
+__global__ void __launch_bounds__(256, 2) lstm_step_bwd_kernel(StepBwdMulti mm) {
     __shared__ __attribute__((aligned(16))) float P[4][BWD_RSMAX * 16][P_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x, si = 0;
+    if (bid >= mm.nb[0]) { bid -= mm.nb[0]; si = 1; if (bid >= mm.nb[1]) { bid -= mm.nb[1]; si = 2; } }
+    const StepBwdArgs& a = mm.s[si];
     const int U = a.U;
     const int KC4 = U >> 2;                 // 16-wide chunks over K = 4U
     const int cpw = KC4 >> 2;               // chunks per wave (U % 64 == 0 -> multiple of 4)
     const int nnt = U >> 4;
     int nt, rt;
     {
-        const int b = blockIdx.x;
+        const int b = bid;
         if ((nnt & 7) == 0) {
             const int per_xcd = nnt >> 3, xcd = b & 7, slot = b >> 3;
             nt = xcd * per_xcd + slot / a.RT;
@@ -559,72 +582,220 @@ size_t d2p_lstm_fused_ws_bytes(int M, int U) {
 }
 
 template <int CPW>
-static void launch_fwd(const StepFwdArgs& a, int blocks, hipStream_t st) {
+static void launch_fwd(const StepFwdMulti& m, int blocks, hipStream_t st) {
     if (g_fwd_pipe)
-        hipLaunchKernelGGL((lstm_step_fwd_kernel<CPW, true>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<CPW, true>), dim3(blocks), dim3(256), 0, st, m);
     else
-        hipLaunchKernelGGL((lstm_step_fwd_kernel<CPW, false>), dim3(blocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((lstm_step_fwd_kernel<CPW, false>), dim3(blocks), dim3(256), 0, st, m);
+}
+
+// ---- forward ---------------------------------------------------------------------------
+struct FwdSeq {
+    int M, U, n_steps, total_rs, RT, blocks;
+    size_t MU;
+    float* z; long zrs, zts;
+    const float *Wh, *h0, *c0; const int* lens;
+    float *hout, *cs, *h_final, *c_final;
+    float *Wf, *hfrag[2], *hs[2];
+    const float *h_prev, *c_prev;
+};
+
+static int fwd_prepare(FwdSeq& q, float* ws, hipStream_t st) {
+    q.MU = (size_t)q.M * q.U;
+    q.total_rs = (q.M + 15) / 16;
+    const size_t Mp = (size_t)q.total_rs * 16;
+    const int U = q.U;
+    q.Wf = ws;
+    q.hfrag[0] = q.Wf + (size_t)4 * U * U;
+    q.hfrag[1] = q.hfrag[0] + Mp * U;
+    q.hs[0] = q.hfrag[1] + Mp * U;
+    q.hs[1] = q.hs[0] + q.MU;
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(pack_blocks((long)U * U / 4)), dim3(256), 0, st, U, q.Wh,
+                       (float4*)q.Wf);
+    D2P_LAUNCH_CHECK("pack_w_fwd");
+    if (q.h0) {
+        hipLaunchKernelGGL(pack_rows_kernel, dim3(pack_blocks((long)Mp * U / 4)), dim3(256), 0, st, q.M, U,
+                           q.total_rs, q.h0, (float4*)q.hfrag[0]);
+        D2P_LAUNCH_CHECK("pack_rows(h0)");
+    }
+    const int nct = U / 8;
+    q.RT = pick_rt(q.total_rs, nct, FWD_RSMAX, g_fwd_wgs);
+    q.blocks = nct * q.RT;
+    q.h_prev = q.h0;
+    q.c_prev = q.c0;
+    return D2P_OK;
+}
+
+static StepFwdArgs fwd_args(FwdSeq& q, int t) {
+    StepFwdArgs a;
+    a.M = q.M; a.U = q.U; a.total_rs = q.total_rs; a.RT = q.RT; a.t = t;
+    a.has_h = (t > 0 || q.h0) ? 1 : 0;
+    if (g_step_debug & 1) a.has_h = 0;
+    a.skip_epi = (g_step_debug & 2) ? 1 : 0;
+    a.hfrag_in = (const float4*)q.hfrag[t & 1];
+    a.Wf = (const float4*)q.Wf;
+    a.z = q.z + (long)t * q.zts; a.zrs = q.zrs;
+    a.c_prev = q.c_prev;
+    a.hs_prev = q.lens ? q.h_prev : nullptr;
+    a.lens = q.lens;
+    a.c_out = q.cs + t * q.MU;
+    a.hout = q.hout + t * q.MU;
+    a.hs_out = q.lens ? q.hs[t & 1] : nullptr;
+    a.hfrag_out = q.hfrag[(t + 1) & 1];
+    q.h_prev = q.lens ? q.hs[t & 1] : q.hout + t * q.MU;
+    q.c_prev = q.cs + t * q.MU;
+    return a;
+}
+
+static int fwd_finish(FwdSeq& q, hipStream_t st) {
+    if (q.h_final) {
+        if (q.h_prev) D2P_HIP(hipMemcpyAsync(q.h_final, q.h_prev, q.MU * sizeof(float), hipMemcpyDeviceToDevice, st));
+        else D2P_HIP(hipMemsetAsync(q.h_final, 0, q.MU * sizeof(float), st));
+    }
+    if (q.c_final) {
+        if (q.c_prev) D2P_HIP(hipMemcpyAsync(q.c_final, q.c_prev, q.MU * sizeof(float), hipMemcpyDeviceToDevice, st));
+        else D2P_HIP(hipMemsetAsync(q.c_final, 0, q.MU * sizeof(float), st));
+    }
+    return D2P_OK;
+}
+
+// All sequences must share U.  Launch j serves step j of every sequence that still has one.
+int d2p_lstm_fused_fwd_multi(int nseq, FwdSeq* seqs, float** ws, hipStream_t st) {
+    int max_n = 0;
+    for (int i = 0; i < nseq; ++i) {
+        int rc = fwd_prepare(seqs[i], ws[i], st);
+        if (rc) return rc;
+        if (seqs[i].n_steps > max_n) max_n = seqs[i].n_steps;
+    }
+    const int U = seqs[0].U;
+    for (int t = 0; t < max_n; ++t) {
+        StepFwdMulti m;
+        int blocks = 0, slot = 0;
+        double work = 0.0;
+        for (int i = 0; i < D2P_MAX_SEQ; ++i) m.nb[i] = 0;
+        for (int i = 0; i < nseq; ++i) {
+            if (t >= seqs[i].n_steps) continue;
+            m.s[slot] = fwd_args(seqs[i], t);
+            m.nb[slot] = seqs[i].blocks;
+            blocks += seqs[i].blocks;
+            work += 2.0 * seqs[i].M * 4.0 * U * U;
+            ++slot;
+        }
+        for (int i = slot; i < D2P_MAX_SEQ; ++i) m.s[i] = m.s[0];
+        {
+            D2pProfScope prof(st, D2P_PROF_LSTM_STEP_FWD, work);
+            switch (U) {
+                case 64: launch_fwd<1>(m, blocks, st); break;
+                case 128: launch_fwd<2>(m, blocks, st); break;
+                case 256: launch_fwd<4>(m, blocks, st); break;
+                default: launch_fwd<8>(m, blocks, st); break;
+            }
+        }
+        D2P_LAUNCH_CHECK("lstm_step_fwd");
+    }
+    for (int i = 0; i < nseq; ++i) {
+        int rc = fwd_finish(seqs[i], st);
+        if (rc) return rc;
+    }
+    return D2P_OK;
 }
 
 int d2p_lstm_fused_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, const float* Wh,
                        const float* h0, const float* c0, const int* lens, float* hout, float* cs,
                        float* h_final, float* c_final, float* ws, hipStream_t st) {
-    const size_t MU = (size_t)M * U;
-    const int total_rs = (M + 15) / 16;
-    const size_t Mp = (size_t)total_rs * 16;
-    float* Wf = ws;
-    float* hfrag[2] = {Wf + (size_t)4 * U * U, Wf + (size_t)4 * U * U + Mp * U};
-    float* hs[2] = {hfrag[1] + Mp * U, hfrag[1] + Mp * U + MU};
-    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(pack_blocks((long)U * U / 4)), dim3(256), 0, st, U, Wh,
-                       (float4*)Wf);
-    D2P_LAUNCH_CHECK("pack_w_fwd");
-    if (h0) {
-        hipLaunchKernelGGL(pack_rows_kernel, dim3(pack_blocks((long)Mp * U / 4)), dim3(256), 0, st, M, U,
-                           total_rs, h0, (float4*)hfrag[0]);
-        D2P_LAUNCH_CHECK("pack_rows(h0)");
+    FwdSeq q;
+    q.M = M; q.U = U; q.n_steps = n_steps; q.z = z; q.zrs = zrs; q.zts = zts; q.Wh = Wh; q.h0 = h0;
+    q.c0 = c0; q.lens = lens; q.hout = hout; q.cs = cs; q.h_final = h_final; q.c_final = c_final;
+    return d2p_lstm_fused_fwd_multi(1, &q, &ws, st);
+}
+
+// ---- backward --------------------------------------------------------------------------
+struct BwdSeq {
+    int M, U, n_steps, total_rs, RT, blocks;
+    size_t MU;
+    const float* z; long zrs, zts;
+    const float *Wh, *c0; const int* lens; const float *cs, *dhout, *dh_final, *dc_final;
+    float *dz, *dh0, *dc0;
+    float *Wb, *dzfrag[2], *dC;
+};
+
+static int bwd_prepare(BwdSeq& q, float* ws, hipStream_t st) {
+    q.MU = (size_t)q.M * q.U;
+    q.total_rs = (q.M + 15) / 16;
+    const size_t Mp = (size_t)q.total_rs * 16;
+    const int U = q.U;
+    q.Wb = ws;
+    q.dzfrag[0] = q.Wb + (size_t)4 * U * U;
+    q.dzfrag[1] = q.dzfrag[0] + Mp * 4 * U;
+    q.dC = q.dzfrag[1] + Mp * 4 * U;
+    hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(pack_blocks((long)U * U / 4)), dim3(256), 0, st, U, q.Wh,
+                       (float4*)q.Wb);
+    D2P_LAUNCH_CHECK("pack_w_bwd");
+    if (q.dc_final) D2P_HIP(hipMemcpyAsync(q.dC, q.dc_final, q.MU * sizeof(float), hipMemcpyDeviceToDevice, st));
+    else D2P_HIP(hipMemsetAsync(q.dC, 0, q.MU * sizeof(float), st));
+    const int nnt = U / 16;
+    q.RT = pick_rt(q.total_rs, nnt, BWD_RSMAX, g_bwd_wgs);
+    q.blocks = nnt * q.RT;
+    return D2P_OK;
+}
+
+static StepBwdArgs bwd_args(const BwdSeq& q, int t) {
+    StepBwdArgs a;
+    a.M = q.M; a.U = q.U; a.total_rs = q.total_rs; a.RT = q.RT; a.t = t; a.n_steps = q.n_steps;
+    a.has_gemm = (t + 1 < q.n_steps) ? 1 : 0;
+    if (g_step_debug & 1) a.has_gemm = 0;
+    a.skip_epi = (g_step_debug & 2) ? 1 : 0;
+    a.mode = t < 0 ? 1 : 0;
+    a.dzfrag_in = (const float4*)q.dzfrag[(t + 1) & 1];
+    a.Wb = (const float4*)q.Wb;
+    a.z = t >= 0 ? q.z + (long)t * q.zts : nullptr; a.zrs = q.zrs;
+    a.c_prev = t > 0 ? q.cs + (size_t)(t - 1) * q.MU : q.c0;
+    a.c = t >= 0 ? q.cs + (size_t)t * q.MU : nullptr;
+    a.dhout = (q.dhout && t >= 0) ? q.dhout + (size_t)t * q.MU : nullptr;
+    a.dh_final = q.dh_final;
+    a.lens = q.lens;
+    a.dC = q.dC;
+    a.dz = t >= 0 ? q.dz + (long)t * q.zts : nullptr; a.dzrs = q.zrs;
+    a.dzfrag_out = q.dzfrag[t & 1];
+    a.dh0 = q.dh0;
+    return a;
+}
+
+// Launch j serves step t_i = n_i - 1 - j of every sequence (down to the final dh0 pass t = -1).
+int d2p_lstm_fused_bwd_multi(int nseq, BwdSeq* seqs, float** ws, hipStream_t st) {
+    int max_launches = 0;
+    for (int i = 0; i < nseq; ++i) {
+        int rc = bwd_prepare(seqs[i], ws[i], st);
+        if (rc) return rc;
+        const int n = seqs[i].n_steps + (seqs[i].dh0 ? 1 : 0);
+        if (n > max_launches) max_launches = n;
     }
-    const int nct = U / 8;
-    const int RT = pick_rt(total_rs, nct, FWD_RSMAX, g_fwd_wgs);
-    const int blocks = nct * RT;
-    const float* h_prev = h0;
-    const float* c_prev = c0;
-    for (int t = 0; t < n_steps; ++t) {
-        StepFwdArgs a;
-        a.M = M; a.U = U; a.total_rs = total_rs; a.RT = RT; a.t = t;
-        a.has_h = (t > 0 || h0) ? 1 : 0;
-        if (g_step_debug & 1) a.has_h = 0;
-        a.skip_epi = (g_step_debug & 2) ? 1 : 0;
-        a.hfrag_in = (const float4*)hfrag[t & 1];
-        a.Wf = (const float4*)Wf;
-        a.z = z + (long)t * zts; a.zrs = zrs;
-        a.c_prev = c_prev;
-        a.hs_prev = lens ? h_prev : nullptr;
-        a.lens = lens;
-        a.c_out = cs + t * MU;
-        a.hout = hout + t * MU;
-        a.hs_out = lens ? hs[t & 1] : nullptr;
-        a.hfrag_out = hfrag[(t + 1) & 1];
-        {
-            D2pProfScope prof(st, D2P_PROF_LSTM_STEP_FWD, 2.0 * M * 4.0 * U * U);
-            switch (U) {
-                case 64: launch_fwd<1>(a, blocks, st); break;
-                case 128: launch_fwd<2>(a, blocks, st); break;
-                case 256: launch_fwd<4>(a, blocks, st); break;
-                default: launch_fwd<8>(a, blocks, st); break;
-            }
+    const int U = seqs[0].U;
+    for (int j = 0; j < max_launches; ++j) {
+        StepBwdMulti m;
+        int blocks = 0, slot = 0;
+        double work = 0.0;
+        for (int i = 0; i < D2P_MAX_SEQ; ++i) m.nb[i] = 0;
+        for (int i = 0; i < nseq; ++i) {
+            const int t = seqs[i].n_steps - 1 - j;
+            if (t < -1 || (t < 0 && !seqs[i].dh0)) continue;
+            m.s[slot] = bwd_args(seqs[i], t);
+            m.nb[slot] = seqs[i].blocks;
+            blocks += seqs[i].blocks;
+            if (m.s[slot].has_gemm) work += 2.0 * seqs[i].M * 4.0 * U * U;
+            ++slot;
         }
-        D2P_LAUNCH_CHECK("lstm_step_fwd");
-        h_prev = lens ? hs[t & 1] : hout + t * MU;
-        c_prev = cs + t * MU;
+        if (slot == 0) break;
+        for (int i = slot; i < D2P_MAX_SEQ; ++i) m.s[i] = m.s[0];
+        {
+            D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, work);
+            hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), dim3(blocks), dim3(256), 0, st, m);
+        }
+        D2P_LAUNCH_CHECK("lstm_step_bwd");
     }
-    if (h_final) {
-        if (h_prev) D2P_HIP(hipMemcpyAsync(h_final, h_prev, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
-        else D2P_HIP(hipMemsetAsync(h_final, 0, MU * sizeof(float), st));
-    }
-    if (c_final) {
-        if (c_prev) D2P_HIP(hipMemcpyAsync(c_final, c_prev, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
-        else D2P_HIP(hipMemsetAsync(c_final, 0, MU * sizeof(float), st));
-    }
+    for (int i = 0; i < nseq; ++i)
+        if (seqs[i].dc0)
+            D2P_HIP(hipMemcpyAsync(seqs[i].dc0, seqs[i].dC, seqs[i].MU * sizeof(float), hipMemcpyDeviceToDevice, st));
     return D2P_OK;
 }
 
@@ -632,47 +803,84 @@ int d2p_lstm_fused_bwd(int M, int U, int n_steps, const float* z, long zrs, long
                        const float* c0, const int* lens, const float* cs, const float* dhout,
                        const float* dh_final, const float* dc_final, float* dz, float* dh0,
                        float* dc0, float* ws, hipStream_t st) {
-    const size_t MU = (size_t)M * U;
-    const int total_rs = (M + 15) / 16;
-    const size_t Mp = (size_t)total_rs * 16;
-    float* Wb = ws;
-    float* dzfrag[2] = {Wb + (size_t)4 * U * U, Wb + (size_t)4 * U * U + Mp * 4 * U};
-    float* dC = dzfrag[1] + Mp * 4 * U;
-    hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(pack_blocks((long)U * U / 4)), dim3(256), 0, st, U, Wh,
-                       (float4*)Wb);
-    D2P_LAUNCH_CHECK("pack_w_bwd");
-    if (dc_final) D2P_HIP(hipMemcpyAsync(dC, dc_final, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
-    else D2P_HIP(hipMemsetAsync(dC, 0, MU * sizeof(float), st));
-    const int nnt = U / 16;
-    const int RT = pick_rt(total_rs, nnt, BWD_RSMAX, g_bwd_wgs);
-    const int blocks = nnt * RT;
-    // steps n-1 .. 0 (mode 0), then the final dh0 GEMM (mode 1, t = -1)
-    for (int t = n_steps - 1; t >= -1; --t) {
-        if (t < 0 && !dh0) break;
-        StepBwdArgs a;
-        a.M = M; a.U = U; a.total_rs = total_rs; a.RT = RT; a.t = t; a.n_steps = n_steps;
-        a.has_gemm = (t + 1 < n_steps) ? 1 : 0;
-        if (g_step_debug & 1) a.has_gemm = 0;
-        a.skip_epi = (g_step_debug & 2) ? 1 : 0;
-        a.mode = t < 0 ? 1 : 0;
-        a.dzfrag_in = (const float4*)dzfrag[(t + 1) & 1];
-        a.Wb = (const float4*)Wb;
-        a.z = t >= 0 ? z + (long)t * zts : nullptr; a.zrs = zrs;
-        a.c_prev = t > 0 ? cs + (size_t)(t - 1) * MU : c0;
-        a.c = t >= 0 ? cs + (size_t)t * MU : nullptr;
-        a.dhout = (dhout && t >= 0) ? dhout + (size_t)t * MU : nullptr;
-        a.dh_final = dh_final;
-        a.lens = lens;
-        a.dC = dC;
-        a.dz = t >= 0 ? dz + (long)t * zts : nullptr; a.dzrs = zrs;
-        a.dzfrag_out = dzfrag[t & 1];
-        a.dh0 = dh0;
-        {
-            D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, a.has_gemm ? 2.0 * M * 4.0 * U * U : 0.0);
-            hipLaunchKernelGGL((lstm_step_bwd_kernel<0>), dim3(blocks), dim3(256), 0, st, a);
-        }
-        D2P_LAUNCH_CHECK("lstm_step_bwd");
+    BwdSeq q;
+    q.M = M; q.U = U; q.n_steps = n_steps; q.z = z; q.zrs = zrs; q.zts = zts; q.Wh = Wh; q.c0 = c0;
+    q.lens = lens; q.cs = cs; q.dhout = dhout; q.dh_final = dh_final; q.dc_final = dc_final;
+    q.dz = dz; q.dh0 = dh0; q.dc0 = dc0;
+    return d2p_lstm_fused_bwd_multi(1, &q, &ws, st);
+}
+
+// ---- C ABI: several independent sequences per launch (include/d2p.h) ----------------------
+static bool multi_fused_ok(int nseq, const int* Ms, const int* Us, const size_t* wsb, const void* const* wsp) {
+    extern int d2p_lstm_is_fused_enabled();
+    if (!d2p_lstm_is_fused_enabled() || nseq < 1 || nseq > D2P_MAX_SEQ) return false;
+    for (int i = 0; i < nseq; ++i)
+        if (!d2p_lstm_fused_eligible(Ms[i], Us[i]) || Us[i] != Us[0] || !wsp[i] ||
+            wsb[i] < d2p_lstm_fused_ws_bytes(Ms[i], Us[i]))
+            return false;
+    return true;
+}
+
+extern "C" int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* d, d2p_stream_t stream) {
+    D2P_REQUIRE(nseq >= 1 && d, D2P_EINVAL, "lstm fwd multi: bad arguments");
+    int Ms[D2P_MAX_SEQ], Us[D2P_MAX_SEQ];
+    size_t wsb[D2P_MAX_SEQ];
+    const void* wsp[D2P_MAX_SEQ];
+    bool ok = nseq <= D2P_MAX_SEQ;
+    for (int i = 0; ok && i < nseq; ++i) {
+        Ms[i] = d[i].M; Us[i] = d[i].U; wsb[i] = d[i].ws_bytes; wsp[i] = d[i].ws;
+        ok = d[i].n_steps > 0 && d[i].z_row_stride % 4 == 0 && (((uintptr_t)d[i].z & 15) == 0);
     }
-    if (dc0) D2P_HIP(hipMemcpyAsync(dc0, dC, MU * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (ok && multi_fused_ok(nseq, Ms, Us, wsb, wsp)) {
+        FwdSeq q[D2P_MAX_SEQ];
+        float* ws[D2P_MAX_SEQ];
+        for (int i = 0; i < nseq; ++i) {
+            q[i].M = d[i].M; q[i].U = d[i].U; q[i].n_steps = d[i].n_steps; q[i].z = d[i].z;
+            q[i].zrs = d[i].z_row_stride; q[i].zts = d[i].z_t_stride; q[i].Wh = d[i].Wh;
+            q[i].h0 = d[i].h0; q[i].c0 = d[i].c0; q[i].lens = d[i].lens; q[i].hout = d[i].hout;
+            q[i].cs = d[i].cs; q[i].h_final = d[i].h_final; q[i].c_final = d[i].c_final;
+            ws[i] = (float*)d[i].ws;
+        }
+        return d2p_lstm_fused_fwd_multi(nseq, q, ws, as_stream(stream));
+    }
+    for (int i = 0; i < nseq; ++i) {     // generic path: one sequence after the other
+        int rc = d2p_lstm_seq_fwd(d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride,
+                                  d[i].Wh, d[i].h0, d[i].c0, d[i].lens, d[i].hout, d[i].cs, d[i].h_final,
+                                  d[i].c_final, d[i].ws, d[i].ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return D2P_OK;
+}
+
+extern "C" int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* d, d2p_stream_t stream) {
+    D2P_REQUIRE(nseq >= 1 && d, D2P_EINVAL, "lstm bwd multi: bad arguments");
+    int Ms[D2P_MAX_SEQ], Us[D2P_MAX_SEQ];
+    size_t wsb[D2P_MAX_SEQ];
+    const void* wsp[D2P_MAX_SEQ];
+    bool ok = nseq <= D2P_MAX_SEQ;
+    for (int i = 0; ok && i < nseq; ++i) {
+        Ms[i] = d[i].M; Us[i] = d[i].U; wsb[i] = d[i].ws_bytes; wsp[i] = d[i].ws;
+        ok = d[i].n_steps > 0 && d[i].z_row_stride % 4 == 0 && (((uintptr_t)d[i].z & 15) == 0) &&
+             (((uintptr_t)d[i].dz & 15) == 0);
+    }
+    if (ok && multi_fused_ok(nseq, Ms, Us, wsb, wsp)) {
+        BwdSeq q[D2P_MAX_SEQ];
+        float* ws[D2P_MAX_SEQ];
+        for (int i = 0; i < nseq; ++i) {
+            q[i].M = d[i].M; q[i].U = d[i].U; q[i].n_steps = d[i].n_steps; q[i].z = d[i].z;
+            q[i].zrs = d[i].z_row_stride; q[i].zts = d[i].z_t_stride; q[i].Wh = d[i].Wh; q[i].c0 = d[i].c0;
+            q[i].lens = d[i].lens; q[i].cs = d[i].cs; q[i].dhout = d[i].dhout;
+            q[i].dh_final = d[i].dh_final; q[i].dc_final = d[i].dc_final; q[i].dz = d[i].dz;
+            q[i].dh0 = d[i].dh0; q[i].dc0 = d[i].dc0;
+            ws[i] = (float*)d[i].ws;
+        }
+        return d2p_lstm_fused_bwd_multi(nseq, q, ws, as_stream(stream));
+    }
+    for (int i = 0; i < nseq; ++i) {
+        int rc = d2p_lstm_seq_bwd(d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride,
+                                  d[i].Wh, d[i].c0, d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final,
+                                  d[i].dc_final, d[i].dz, d[i].dh0, d[i].dc0, d[i].ws, d[i].ws_bytes, stream);
+        if (rc) return rc;
+    }
     return D2P_OK;
 }

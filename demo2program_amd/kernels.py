@@ -220,6 +220,59 @@ def lstm_seq_bwd(z, z_row_stride, z_t_stride, M, U, n_steps, Wh, c0, lens, cs, d
                           ptr(dh0), ptr(dc0), ws, wsb, current_stream())
 
 
+class _MultiWs(object):
+    """One workspace per concurrently advancing sequence (they must not share scratch)."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, slot, nbytes):
+        b = self.bufs.get(slot)
+        if b is None or b.numel() < nbytes:
+            b = self.bufs[slot] = torch.empty(int(nbytes), dtype=torch.uint8, device='cuda')
+        return b
+
+
+_MULTI_WS = _MultiWs()
+
+
+def lstm_seq_fwd_multi(seqs):
+    """seqs: list (<= 3) of dicts with the d2p_lstm_seq_fwd arguments (time-major z)."""
+    import ctypes
+    from .lib import LstmFwdDesc
+    arr = (LstmFwdDesc * len(seqs))()
+    for i, q in enumerate(seqs):
+        M, U = q['M'], q['U']
+        nb = call.d2p_lstm_ws_bytes(M, U)
+        ws = _MULTI_WS.get(('f', i), nb)
+        d = arr[i]
+        d.M, d.U, d.n_steps = M, U, q['n_steps']
+        d.z, d.z_row_stride, d.z_t_stride = ptr(q['z']), 4 * U, M * 4 * U
+        d.Wh, d.h0, d.c0, d.lens = ptr(q['Wh']), ptr(q.get('h0')), ptr(q.get('c0')), ptr(q.get('lens'))
+        d.hout, d.cs = ptr(q['hout']), ptr(q['cs'])
+        d.h_final, d.c_final = ptr(q.get('h_final')), ptr(q.get('c_final'))
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    call.d2p_lstm_seq_fwd_multi(len(seqs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
+
+
+def lstm_seq_bwd_multi(seqs):
+    import ctypes
+    from .lib import LstmBwdDesc
+    arr = (LstmBwdDesc * len(seqs))()
+    for i, q in enumerate(seqs):
+        M, U = q['M'], q['U']
+        nb = call.d2p_lstm_ws_bytes(M, U)
+        ws = _MULTI_WS.get(('b', i), nb)
+        d = arr[i]
+        d.M, d.U, d.n_steps = M, U, q['n_steps']
+        d.z, d.z_row_stride, d.z_t_stride = ptr(q['z']), 4 * U, M * 4 * U
+        d.Wh, d.c0, d.lens, d.cs = ptr(q['Wh']), ptr(q.get('c0')), ptr(q.get('lens')), ptr(q['cs'])
+        d.dhout, d.dh_final, d.dc_final = ptr(q.get('dhout')), ptr(q.get('dh_final')), ptr(q.get('dc_final'))
+        d.dz, d.dh0, d.dc0 = ptr(q['dz']), ptr(q.get('dh0')), ptr(q.get('dc0'))
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    call.d2p_lstm_seq_bwd_multi(len(seqs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
+
+
 def lstm_gate_fwd(z, c_prev, h_prev, lens, t, c_out, hs_out, h_out):
     M = c_out.shape[0]
     U = c_out.shape[1]

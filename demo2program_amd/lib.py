@@ -44,6 +44,8 @@ SIGNATURES = {
     'd2p_lstm_set_tiling': (c_int, [c_int, c_int, c_int]),
     'd2p_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, c_long, c_long, P, P, P, P, P, P, P, P, P, c_size_t, S]),
     'd2p_lstm_seq_bwd': (c_int, [c_int, c_int, c_int, P, c_long, c_long, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
+    'd2p_lstm_seq_fwd_multi': (c_int, [c_int, P, S]),
+    'd2p_lstm_seq_bwd_multi': (c_int, [c_int, P, S]),
     'd2p_shift_tokens_tm': (c_int, [c_int, c_int, P, c_int, P, S]),
     'd2p_embedding_gather_oob0': (c_int, [c_int, c_int, c_int, P, P, P, S]),
     'd2p_embedding_scatter_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
@@ -71,6 +73,27 @@ SIGNATURES = {
     'd2p_prof_read': (c_int, [c_int, P, P, P]),
     'd2p_adam_clip_flat': (c_int, [c_size_t, P, P, P, P, P, c_float, c_float, c_float, P, c_float, c_float, c_float, S]),
 }
+
+
+
+class LstmFwdDesc(ctypes.Structure):
+    """d2p_lstm_fwd_desc (include/d2p.h)."""
+    _fields_ = [('M', c_int), ('U', c_int), ('n_steps', c_int),
+                ('z', c_void_p), ('z_row_stride', c_long), ('z_t_stride', c_long),
+                ('Wh', c_void_p), ('h0', c_void_p), ('c0', c_void_p), ('lens', c_void_p),
+                ('hout', c_void_p), ('cs', c_void_p), ('h_final', c_void_p), ('c_final', c_void_p),
+                ('ws', c_void_p), ('ws_bytes', c_size_t)]
+
+
+class LstmBwdDesc(ctypes.Structure):
+    """d2p_lstm_bwd_desc (include/d2p.h)."""
+    _fields_ = [('M', c_int), ('U', c_int), ('n_steps', c_int),
+                ('z', c_void_p), ('z_row_stride', c_long), ('z_t_stride', c_long),
+                ('Wh', c_void_p), ('c0', c_void_p), ('lens', c_void_p), ('cs', c_void_p),
+                ('dhout', c_void_p), ('dh_final', c_void_p), ('dc_final', c_void_p),
+                ('dz', c_void_p), ('dh0', c_void_p), ('dc0', c_void_p),
+                ('ws', c_void_p), ('ws_bytes', c_size_t)]
+
 
 _lib = None
 

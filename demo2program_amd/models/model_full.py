@@ -82,6 +82,7 @@ class Model(object):
         for s in ('rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2', 'per/fc'):
             self._init_moving(s, U)
         self.track_moving = True
+        self.fuse_decoders = False
         self._reserve_scratch()
 
     # ------------------------------------------------------------------ plumbing
@@ -160,6 +161,27 @@ class Model(object):
         lens_d, lens_p = feed['demo_len'], feed['program_len']
         n_p, n_d = feed['n_prog'], feed['n_demo']
 
+        # ---- side stream: everything that depends only on the batch -- decoder input ids,
+        #      embeddings, the perception encoder and the three hoisted decoder projections
+        #      (~30 GFLOP of MFMA-bound GEMM) -- runs concurrently with the encoder recurrences,
+        #      whose step kernels leave most of the matrix pipe idle.
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ids_p = K.shift_tokens_tm(feed['program_tokens'], V + 1, out=self._buf('ids_p', (L, B), torch.int32))
+            emb_p = K.embedding_gather(ids_p, p['prog/embedding'], out=self._buf('emb_p', (L * B, U)), n=n_p * B)
+            ids_a = K.shift_tokens_tm(feed['a_h_tokens'], A + 1, out=self._buf('ids_a', (T, M), torch.int32))
+            emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)), n=n_d * M)
+            # Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
+            per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
+            pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
+                               bias=p['per/fc/b'], act=0)
+            pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
+            z_a = self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d)
+            z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)
+            z_p = self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p)
+
         # ---- State_Encoder: conv -> +bias -> lrelu -> BN(train), per demo-index statistics
         x = feed['s_h']
         ctx['conv'] = []
@@ -197,20 +219,20 @@ class Model(object):
         rn_h = self._rn_fwd('rn_h', demo_h, B, k, U)
         rn_c = self._rn_fwd('rn_c', demo_c, B, k, U)
 
-        # ---- Program decoder (teacher forcing; <s> = out-of-range id -> zero vector)
-        ids_p = K.shift_tokens_tm(feed['program_tokens'], V + 1, out=self._buf('ids_p', (L, B), torch.int32))
-        emb_p = K.embedding_gather(ids_p, p['prog/embedding'], out=self._buf('emb_p', (L * B, U)), n=n_p * B)
-        dp = self._decoder_fwd('prog', emb_p, U, B, L, n_p, rn_h['out'], rn_c['out'], V)
-        # ---- Action decoders (all k in one batch)
-        ids_a = K.shift_tokens_tm(feed['a_h_tokens'], A + 1, out=self._buf('ids_a', (T, M), torch.int32))
-        emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)), n=n_d * M)
-        da = self._decoder_fwd('act', emb_a, U, M, T, n_d, demo_h, demo_c, A)
-        # ---- Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
-        per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
-        pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
-                           bias=p['per/fc/b'], act=0)
-        pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
-        dq = self._decoder_fwd('per', pe, U, M, T, n_d, demo_h, demo_c, P)
+        main.wait_stream(side)
+        # ---- Program decoder (teacher forcing; <s> = out-of-range id -> zero vector),
+        #      action decoders (all k in one batch), perception decoders
+        #      The three decoders are independent LSTMs.  fuse_decoders=True advances them
+        #      together (one launch per time step for all three, d2p_lstm_seq_fwd_multi); measured
+        #      neutral-to-slower on MI355X (the step kernels are L2-bandwidth bound, DESIGN.md
+        #      3.2), so the default keeps one call per decoder.
+        specs = [('prog', emb_p, U, B, L, n_p, rn_h['out'], rn_c['out'], V, z_p),
+                 ('act', emb_a, U, M, T, n_d, demo_h, demo_c, A, z_a),
+                 ('per', pe, U, M, T, n_d, demo_h, demo_c, P, z_q)]
+        if self.fuse_decoders:
+            dp, da, dq = self._decoders_fwd(specs)
+        else:
+            dp, da, dq = [self._decoders_fwd([sp])[0] for sp in specs]
 
         # ---- losses: program + mean_k action + mean_k perception, each mask-count normalised
         nums = self._buf('loss_nums', (1 + 2 * k,))
@@ -234,6 +256,11 @@ class Model(object):
         self._loss, self._terms = loss, terms
         return loss
 
+    def _side_stream(self):
+        if getattr(self, '_side', None) is None:
+            self._side = torch.cuda.Stream()
+        return self._side
+
     def _bn_fwd(self, name, x2d, gamma, beta, G, inner):
         R, C = x2d.shape
         y = self._buf(name + '/bn_y', (R, C))
@@ -246,15 +273,25 @@ class Model(object):
             K.bn_update_moving(mean, var, mm, mv)       # G sequential updates
         return y, mean, rstd
 
-    def _lstm_fwd(self, name, x2d, I, M, T, n_steps, h0, c0, lens, want_final):
-        """x2d: [T*M, I] time-major inputs.  Returns saved tensors for backward."""
+    def _lstm_xproj(self, name, x2d, I, M, T, n_steps):
+        """Hoisted input projection z = x·Wx + b for all steps (one GEMM)."""
         p = self.params.p
         U = self.num_lstm_cell_units
         kernel, bias = p[name + '/kernel'], p[name + '/bias']
-        Wx, Wh = kernel[:I], kernel[I:]
         z = self._buf(name + '/z', (T * M, 4 * U))
         if n_steps > 0:
-            K.gemm_raw('nn', n_steps * M, 4 * U, I, x2d, x2d.stride(0), Wx, 4 * U, z, 4 * U, bias=bias)
+            K.gemm_raw('nn', n_steps * M, 4 * U, I, x2d, x2d.stride(0), kernel[:I], 4 * U, z, 4 * U,
+                       bias=bias)
+        return z
+
+    def _lstm_fwd(self, name, x2d, I, M, T, n_steps, h0, c0, lens, want_final, z=None):
+        """x2d: [T*M, I] time-major inputs.  Returns saved tensors for backward."""
+        p = self.params.p
+        U = self.num_lstm_cell_units
+        kernel = p[name + '/kernel']
+        Wx, Wh = kernel[:I], kernel[I:]
+        if z is None:
+            z = self._lstm_xproj(name, x2d, I, M, T, n_steps)
         hout = self._buf(name + '/hout', (T, M, U))
         cs = self._buf(name + '/cs', (T, M, U))
         hf = self._buf(name + '/h_final', (M, U)) if want_final else None
@@ -263,11 +300,41 @@ class Model(object):
         return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
                     hout=hout, cs=cs, h_final=hf, c_final=cf, Wx=Wx, Wh=Wh)
 
-    def _decoder_fwd(self, scope, x2d, I, R, T, n_steps, h0, c0, token_dim):
+    def _decoders_fwd(self, specs):
+        """BasicDecoder + TrainingHelper + Dense(no bias) (models/model_full.py:440-490) for
+        several independent decoders at once."""
+        p = self.params.p
+        U = self.num_lstm_cell_units
+        es, seqs = [], []
+        for (scope, x2d, I, R, T, n_steps, h0, c0, token_dim, z) in specs:
+            name = scope + '/lstm'
+            kernel = p[name + '/kernel']
+            hout = self._buf(name + '/hout', (T, R, U))
+            cs = self._buf(name + '/cs', (T, R, U))
+            e = dict(name=name, x=x2d, I=I, M=R, T=T, n=n_steps, h0=h0, c0=c0, lens=None, z=z,
+                     hout=hout, cs=cs, h_final=None, c_final=None, Wx=kernel[:I], Wh=kernel[I:],
+                     token_dim=token_dim, scope=scope)
+            es.append(e)
+            if n_steps > 0:
+                seqs.append(dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs))
+        if seqs:
+            K.lstm_seq_fwd_multi(seqs)
+        for e in es:
+            scope, R, T, n_steps, token_dim = e['scope'], e['M'], e['T'], e['n'], e['token_dim']
+            logits = self._buf(scope + '/logits', (T, R, token_dim), zero=True)
+            if n_steps > 0:
+                K.gemm_raw('nn', n_steps * R, token_dim, U, e['hout'], U, p[scope + '/proj'], token_dim,
+                           logits, token_dim)
+            if n_steps < T:
+                logits[n_steps:].zero_()    # dynamic zero padding (:476-484); memset, no arithmetic
+            e['logits'] = logits
+        return es
+
+    def _decoder_fwd(self, scope, x2d, I, R, T, n_steps, h0, c0, token_dim, z=None):
         """BasicDecoder + TrainingHelper + Dense(no bias): models/model_full.py:440-490."""
         p = self.params.p
         U = self.num_lstm_cell_units
-        e = self._lstm_fwd(scope + '/lstm', x2d, I, R, T, n_steps, h0, c0, None, want_final=False)
+        e = self._lstm_fwd(scope + '/lstm', x2d, I, R, T, n_steps, h0, c0, None, want_final=False, z=z)
         logits = self._buf(scope + '/logits', (T, R, token_dim), zero=True)
         if n_steps > 0:
             K.gemm_raw('nn', n_steps * R, token_dim, U, e['hout'], U, p[scope + '/proj'], token_dim,
@@ -324,22 +391,35 @@ class Model(object):
         tmp_h, tmp_c = self._buf('tmp_dh', (M, U)), self._buf('tmp_dc', (M, U))
         d_rn_h, d_rn_c = self._buf('d_rn_h', (B, U)), self._buf('d_rn_c', (B, U))
 
-        # ---- program decoder: grads of embedding / lstm / proj, and of the rn summaries
-        dx_p = self._decoder_bwd(ctx['dp'], dl_p, d_rn_h, d_rn_c, want_dx=True)
-        K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
-        # ---- action decoder: initial-state grads start d_demo_{h,c}
-        dx_a = self._decoder_bwd(ctx['da'], dl_a, d_demo_h, d_demo_c, want_dx=True)
-        K.embedding_scatter_add(ctx['ids_a'], dx_a, g['act/embedding'], n=n_d * M)
-        # ---- perception decoder
-        dx_q = self._decoder_bwd(ctx['dq'], dl_q, tmp_h, tmp_c, want_dx=True)
+        # ---- decoder recurrences (main stream): projection grads, dz for every step, and the
+        #      initial-state gradients that feed the summarizer / encoder backward
+        bspecs = [(ctx['dp'], dl_p, d_rn_h, d_rn_c), (ctx['da'], dl_a, d_demo_h, d_demo_c),
+                  (ctx['dq'], dl_q, tmp_h, tmp_c)]
+        if self.fuse_decoders:
+            dz_p, dz_a, dz_q = self._decoders_bwd_rec(bspecs)
+        else:
+            dz_p, dz_a, dz_q = [self._decoders_bwd_rec([sp])[0] for sp in bspecs]
         K.axpy(1.0, tmp_h, d_demo_h)
         K.axpy(1.0, tmp_c, d_demo_c)
-        if n_d < T:
-            dx_q[n_d * M:].zero_()
-        d_pe_a = K.bn_bwd(ctx['pe_a'], dx_q, p['per/fc/gamma'], ctx['pe_mean'], ctx['pe_rstd'], k, 1,
-                          False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)))
-        K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
-        K.colsum(d_pe_a, out=g['per/fc/b'])
+
+        # ---- side stream: the decoders' weight / input gradients (9 large GEMMs, ~100 GFLOP,
+        #      MFMA-bound) are not needed by the rest of backward; they overlap the encoder's
+        #      backward recurrences, which are latency-bound.
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            dx_p = self._lstm_bwd_params(ctx['dp'], dz_p, True)
+            K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
+            dx_a = self._lstm_bwd_params(ctx['da'], dz_a, True)
+            K.embedding_scatter_add(ctx['ids_a'], dx_a, g['act/embedding'], n=n_d * M)
+            dx_q = self._lstm_bwd_params(ctx['dq'], dz_q, True)
+            if n_d < T:
+                dx_q[n_d * M:].zero_()
+            d_pe_a = K.bn_bwd(ctx['pe_a'], dx_q, p['per/fc/gamma'], ctx['pe_mean'], ctx['pe_rstd'], k, 1,
+                              False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)))
+            K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
+            K.colsum(d_pe_a, out=g['per/fc/b'])
 
         # ---- SummarizeFeature('rn') backward (adds into d_demo_{h,c})
         self._rn_bwd(ctx['rn_h'], d_rn_h, d_demo_h, B, k, U)
@@ -376,17 +456,25 @@ class Model(object):
             if l > 1:
                 dy = K.conv_dgrad(da_.view(NF, ho, wo, cout), p['conv%d/W' % l], (NF, h, w, cin),
                                   dx=self._buf('conv%d/dx' % l, (NF, h, w, cin)))
+        main.wait_stream(side)
         return self.params.grad
 
-    def _lstm_bwd(self, e, dhout, dh_final, dc_final, dh0, dc0, want_dx):
-        """Backward of _lstm_fwd.  Writes the kernel / bias gradients; returns dX [n*M, I]."""
+    def _lstm_bwd_rec(self, e, dhout, dh_final, dc_final, dh0, dc0):
+        """Backward through the recurrence only: dz for every step, dh0, dc0."""
+        name, M, T, n = e['name'], e['M'], e['T'], e['n']
+        U = self.num_lstm_cell_units
+        dz = self._buf(name + '/dz', (T * M, 4 * U))
+        K.lstm_seq_bwd(e['z'], 4 * U, M * 4 * U, M, U, n, e['Wh'], e['c0'], e['lens'], e['cs'],
+                       dhout, dh_final, dc_final, dz, dh0, dc0)
+        return dz
+
+    def _lstm_bwd_params(self, e, dz, want_dx):
+        """Kernel / bias gradients and dX [n*M, I] from dz (independent of the recurrence order:
+        three large GEMMs that may run on a side stream)."""
         g = self.params.g
         name, M, T, n, I = e['name'], e['M'], e['T'], e['n'], e['I']
         U = self.num_lstm_cell_units
         gk, gb = g[name + '/kernel'], g[name + '/bias']
-        dz = self._buf(name + '/dz', (T * M, 4 * U))
-        K.lstm_seq_bwd(e['z'], 4 * U, M * 4 * U, M, U, n, e['Wh'], e['c0'], e['lens'], e['cs'],
-                       dhout, dh_final, dc_final, dz, dh0, dc0)
         rows = n * M
         dz_n = dz[:rows] if rows > 0 else dz[:0]
         # dWx = X^T dZ ; db = colsum(dZ)
@@ -410,7 +498,38 @@ class Model(object):
             K.gemm_raw('nt', rows, I, 4 * U, dz_n, 4 * U, e['Wx'], 4 * U, dx, I)
         return dx
 
-    def _decoder_bwd(self, e, dlogits, dh0, dc0, want_dx):
+    def _lstm_bwd(self, e, dhout, dh_final, dc_final, dh0, dc0, want_dx):
+        """Backward of _lstm_fwd.  Writes the kernel / bias gradients; returns dX [n*M, I]."""
+        dz = self._lstm_bwd_rec(e, dhout, dh_final, dc_final, dh0, dc0)
+        return self._lstm_bwd_params(e, dz, want_dx)
+
+    def _decoders_bwd_rec(self, specs):
+        """Projection gradients, then the backward recurrences of several independent decoders
+        advancing together (one launch per step for all of them).  Returns their dz buffers."""
+        p, g = self.params.p, self.params.g
+        U = self.num_lstm_cell_units
+        seqs, dzs = [], []
+        for (e, dlogits, dh0, dc0) in specs:
+            scope, R, T, n, V = e['scope'], e['M'], e['T'], e['n'], e['token_dim']
+            rows = n * R
+            dhout = self._buf(scope + '/dhout', (T * R, U))
+            dz = self._buf(e['name'] + '/dz', (T * R, 4 * U))
+            dzs.append(dz)
+            if rows > 0:
+                K.gemm_raw('tn', U, V, rows, e['hout'].view(T * R, U), U, dlogits, V, g[scope + '/proj'], V)
+                K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
+                seqs.append(dict(M=R, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], cs=e['cs'],
+                                 dhout=dhout, dz=dz, dh0=dh0, dc0=dc0))
+            else:
+                g[scope + '/proj'].zero_()
+                dh0.zero_()
+                dc0.zero_()
+        if seqs:
+            K.lstm_seq_bwd_multi(seqs)
+        return dzs
+
+    def _decoder_bwd_rec(self, e, dlogits, dh0, dc0):
+        """Projection gradients + backward recurrence of one decoder; returns dz."""
         p, g = self.params.p, self.params.g
         scope, R, T, n, V = e['scope'], e['M'], e['T'], e['n'], e['token_dim']
         U = self.num_lstm_cell_units
@@ -422,7 +541,7 @@ class Model(object):
             K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
         else:
             g[scope + '/proj'].zero_()
-        return self._lstm_bwd(e, dhout, None, None, dh0, dc0, want_dx)
+        return self._lstm_bwd_rec(e, dhout, None, None, dh0, dc0)
 
     def _rn_bwd(self, r, d_out, d_feat, B, k, U):
         """d_out: [B,U] gradient of mean_k(feat) + rn_pool(feat); accumulates into d_feat [M,U]."""

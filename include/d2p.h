@@ -168,6 +168,30 @@ int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long z_row_strid
                      const float* dc_final, float* dz, float* dh0, float* dc0,
                      void* ws, size_t ws_bytes, d2p_stream_t stream);
 
+/* Several INDEPENDENT sequences (up to 3, same U) advanced together: launch j serves step j
+ * of every forward sequence (step n_i-1-j of every backward sequence) that still has one, so
+ * the action / perception / program decoders of the reference (models/model_full.py:497-599),
+ * which do not depend on each other, share launches and CUs.  Results are identical to
+ * calling d2p_lstm_seq_fwd / _bwd once per descriptor (that is also the fallback path).
+ * Every descriptor carries its own workspace (>= d2p_lstm_ws_bytes(M, U)). */
+typedef struct {
+    int M, U, n_steps;
+    float* z; long z_row_stride, z_t_stride;
+    const float* Wh; const float* h0; const float* c0; const int* lens;
+    float* hout; float* cs; float* h_final; float* c_final;
+    void* ws; size_t ws_bytes;
+} d2p_lstm_fwd_desc;
+typedef struct {
+    int M, U, n_steps;
+    const float* z; long z_row_stride, z_t_stride;
+    const float* Wh; const float* c0; const int* lens; const float* cs;
+    const float* dhout; const float* dh_final; const float* dc_final;
+    float* dz; float* dh0; float* dc0;
+    void* ws; size_t ws_bytes;
+} d2p_lstm_bwd_desc;
+int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* descs, d2p_stream_t stream);
+int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* descs, d2p_stream_t stream);
+
 /* ---- K6: embedding gather with out-of-range -> 0, and its scatter-add gradient ------
  * Replaces tf.nn.embedding_lookup (models/model_full.py:294); the reference's <s> id is
  * token_dim+1, out of range for the [token_dim+1, E] table, which TF-GPU gathers as zeros

@@ -309,6 +309,50 @@ def test_lstm_fused_equals_unfused_at_full_size(K, M, masked):
         assert err <= 2e-5 * max(1.0, b.abs().max().item()), (n, err)
 
 
+def test_lstm_multi_sequence_launch_equals_separate_calls(K):
+    """Horizontally fused decoders: three independent LSTMs (different M, n_steps, weights)
+    advanced by shared launches must give exactly what three separate calls give."""
+    U = 512
+    g = torch.Generator().manual_seed(9)
+    specs = [(32, 11), (320, 6), (320, 6)]
+    def mk(M, n, i):
+        T = n + 1
+        return dict(M=M, U=U, n_steps=n,
+                    z0=(torch.rand(T * M, 4 * U, generator=g) * 2 - 1).cuda(),
+                    Wh=((torch.rand(U, 4 * U, generator=g) * 2 - 1) * 0.05).cuda(),
+                    h0=(torch.rand(M, U, generator=g) * 2 - 1).cuda(),
+                    c0=(torch.rand(M, U, generator=g) * 2 - 1).cuda(),
+                    dhout=(torch.rand(T, M, U, generator=g) * 2 - 1).cuda(), T=T)
+    base = [mk(M, n, i) for i, (M, n) in enumerate(specs)]
+    results = []
+    for multi in (True, False):
+        fw, bw, outs = [], [], []
+        for b in base:
+            M, T = b['M'], b['T']
+            o = dict(z=b['z0'].clone(), hout=torch.zeros(T, M, U, device='cuda'),
+                     cs=torch.zeros(T, M, U, device='cuda'), dz=torch.zeros(T * M, 4 * U, device='cuda'),
+                     dh0=torch.zeros(M, U, device='cuda'), dc0=torch.zeros(M, U, device='cuda'))
+            outs.append(o)
+            fw.append(dict(M=M, U=U, n_steps=b['n_steps'], z=o['z'], Wh=b['Wh'], h0=b['h0'], c0=b['c0'],
+                           hout=o['hout'], cs=o['cs']))
+            bw.append(dict(M=M, U=U, n_steps=b['n_steps'], z=o['z'], Wh=b['Wh'], c0=b['c0'], cs=o['cs'],
+                           dhout=b['dhout'], dz=o['dz'], dh0=o['dh0'], dc0=o['dc0']))
+        if multi:
+            K.lstm_seq_fwd_multi(fw)
+            K.lstm_seq_bwd_multi(bw)
+        else:
+            for f, b_, base_b in zip(fw, bw, base):
+                M = f['M']
+                K.lstm_seq_fwd(f['z'], 4 * U, M * 4 * U, M, U, f['n_steps'], f['Wh'], f['h0'], f['c0'], None,
+                               f['hout'], f['cs'], None, None)
+                K.lstm_seq_bwd(b_['z'], 4 * U, M * 4 * U, M, U, b_['n_steps'], b_['Wh'], b_['c0'], None,
+                               b_['cs'], b_['dhout'], None, None, b_['dz'], b_['dh0'], b_['dc0'])
+        results.append(outs)
+    for a, b in zip(*results):
+        for n in ('z', 'hout', 'cs', 'dz', 'dh0', 'dc0'):
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_lstm_known_answer_scalar_cell(K):
     # SURVEY D5: U=1-like check of gate order i,j,f,o and forget bias 1.0 (U padded to 4)
     U = 4

@@ -117,6 +117,21 @@ def test_uint8_frames_give_the_same_result_as_float_frames():
         assert (g1 - m2.params.grad).abs().max().item() <= 1e-5 * g1.abs().max().item()
 
 
+def test_fused_decoders_option_gives_identical_results():
+    from demo2program_amd.models.model_full import Model
+    cfg, params, batch = small_case('karel', seed=17)
+    res = []
+    for fuse in (False, True):
+        m = Model(cfg, params=params)
+        m.fuse_decoders = fuse
+        loss = float(m.forward(m.get_feed_dict(batch)).item())
+        m.backward()
+        torch.cuda.synchronize()
+        res.append((loss, m.params.grad.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_output_list_and_dynamic_padding():
     cfg, params, batch = small_case('karel', seed=5)
     # shorten every program / demo so that dynamic_decode stops early
