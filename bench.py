@@ -34,6 +34,11 @@ import torch  # noqa: E402
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_HBM_GBS = 8000.0          # HBM3E spec (6290 GB/s measured copy)
 
+# kernel family -> key in profiles/*_pmc_traffic.json (tools/pmc_summary.py)
+PMC_KEYS = {1: 'gemm_mfma_kernel', 2: 'gemm_mfma_kernel<conv>', 7: 'lstm_step_fwd_kernel',
+            8: 'lstm_step_bwd_kernel', 3: 'lstm_gate_fwd_kernel', 4: 'lstm_gate_bwd_kernel'}
+PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+
 PROF_FAMILIES = {
     1: ('gemm_mfma_kernel (dense fp32 MFMA GEMM)', 'mfma'),
     2: ('gemm_mfma_kernel<Im2col> (conv implicit GEMM)', 'mfma'),
@@ -44,6 +49,17 @@ PROF_FAMILIES = {
 }
 
 
+def pmc_traffic(family):
+    """HBM bytes per launch of this kernel family from the committed PMC passes of this same
+    command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the
+    gfx950 correction; tools/profile_pmc.sh + tools/pmc_summary.py).  None if not collected."""
+    try:
+        d = json.load(open(PMC_FILE))
+        return round(d[PMC_KEYS[family]]['hbm_bytes_per_launch'], 1)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def roofline_leg(trainer, feeds, steps=2):
     """Re-runs `steps` training steps with per-launch HIP events enabled inside the library
     and reports the family/tag with the largest summed device time."""
@@ -52,6 +68,10 @@ def roofline_leg(trainer, feeds, steps=2):
     torch.cuda.synchronize()
     lib.d2p_prof_enable(1)
     lib._d2p_prof_on = True          # Trainer.train_step takes the eager (un-graphed) path
+    # one stream, so that a launch's event bracket measures that kernel alone (in the timed
+    # region independent GEMMs overlap the recurrent step kernels on a side stream)
+    side = trainer.model.use_side_stream
+    trainer.model.use_side_stream = False
     for i in range(steps):
         trainer.train_step(feeds[i % len(feeds)])
     torch.cuda.synchronize()
@@ -65,6 +85,7 @@ def roofline_leg(trainer, feeds, steps=2):
                                  total_ms=ms.value, work=work.value))
     lib.d2p_prof_enable(0)
     lib._d2p_prof_on = False
+    trainer.model.use_side_stream = side
     if not rows:
         return None, []
     rows.sort(key=lambda r: -r['total_ms'])
@@ -77,7 +98,7 @@ def roofline_leg(trainer, feeds, steps=2):
     roof = {
         'kernel': top['name'] + (' [inside the recurrence]' if top['tag'] == 1 else ''),
         'bound': top['bound'], 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
-        'frac': round(achieved / peak, 4), 'traffic': None,
+        'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(top['family']),
         'launches_per_step': top['launches'] / steps,
         'avg_launch_us': round(top['total_ms'] * 1e3 / top['launches'], 3),
         'work_per_launch': top['work'] / top['launches'],

@@ -83,6 +83,10 @@ class Model(object):
             self._init_moving(s, U)
         self.track_moving = True
         self.fuse_decoders = False
+        # independent GEMM-heavy work on a second stream (see forward/backward); set False (or
+        # D2P_NO_SIDE_STREAM=1) to serialise everything on one stream, e.g. for per-kernel timing
+        import os
+        self.use_side_stream = os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1'
         self._reserve_scratch()
 
     # ------------------------------------------------------------------ plumbing
@@ -257,6 +261,8 @@ class Model(object):
         return loss
 
     def _side_stream(self):
+        if not self.use_side_stream:
+            return torch.cuda.current_stream()
         if getattr(self, '_side', None) is None:
             self._side = torch.cuda.Stream()
         return self._side
