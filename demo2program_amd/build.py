@@ -4,7 +4,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-SOURCES = ['api.hip', 'gemm.hip', 'conv.hip', 'bn.hip', 'lstm.hip', 'lstm_step.hip', 'xent.hip', 'misc.hip',
+SOURCES = ['api.hip', 'gemm.hip', 'conv.hip', 'bn.hip', 'lstm.hip', 'lstm_step.hip', 'greedy.hip', 'xent.hip', 'misc.hip',
            'adam.hip']
 HEADERS = ['common.h', 'gemm_core.h', 'prof.h', 'lstm_math.h', os.path.join('..', '..', 'include', 'd2p.h')]
 OUT = os.path.join(CSRC, 'libd2p_hip.so')

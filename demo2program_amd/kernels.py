@@ -317,6 +317,24 @@ def embedding_scatter_add(ids, dout, dtable, n=None):
     return dtable
 
 
+def greedy_decode(table_proj, Wh, proj, h0, c0, start_id, end_id, L, logits, ids, lengths):
+    """table_proj [V+1,4U]; logits [L,M,V], ids [L,M] int32, lengths [M] int32 (outputs)."""
+    M, U = h0.shape
+    V = proj.shape[1]
+    ws, wsb = SCRATCH.get(call.d2p_greedy_ws_bytes(M, U, V))
+    call.d2p_greedy_decode(M, U, V, L, ptr(table_proj), ptr(Wh), ptr(proj), ptr(h0), ptr(c0),
+                           start_id, end_id, ptr(logits), ptr(ids), ptr(lengths), ws, wsb,
+                           current_stream())
+
+
+def argmax_rows(x2d, out=None):
+    rows, V = x2d.shape
+    if out is None:
+        out = torch.empty(rows, dtype=torch.int32, device=x2d.device)
+    call.d2p_argmax_rows(rows, V, ptr(x2d), x2d.stride(0), ptr(out), current_stream())
+    return out
+
+
 # ---------------------------------------------------------------- losses
 def _lab_strides(kind, V, T):
     # program labels [B,V,L]; action/per labels [B,k,T,V] flattened to rows r=(b,i)

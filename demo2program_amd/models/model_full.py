@@ -573,6 +573,103 @@ class Model(object):
         K.matmul_nt(dP, W1[:U], out=d_feat, accumulate=True)
         K.matmul_nt(dQ, W1[U:], out=d_feat, accumulate=True)
 
+    # ------------------------------------------------------------------ greedy decoding (N1)
+    PROGRAM_END_TOKEN = 3      # vocab.token2int['m)'] in the Karel and every ViZDoom vocabulary
+
+    def greedy_decode(self):
+        """Greedy twins of the program and action decoders (models/model_full.py:513-523,
+        546-558): argmax feedback from the <s> row (id token_dim) until the end token, weights
+        shared with the teacher-forced decoders.  Needs forward() on the current feed (uses
+        its summarizer outputs as initial states).  Reached from run_test / evaluation only."""
+        ctx, c, p = self._ctx, self.config, self.params.p
+        B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len
+        U, V, A = c.num_lstm_cell_units, c.dim_program_token, c.action_space
+        M = B * k
+        out = {}
+        for scope, R, steps, tok, h0, c0, end in (
+                ('prog', B, L, V, ctx['rn_h']['out'], ctx['rn_c']['out'], self.PROGRAM_END_TOKEN),
+                ('act', M, T, A, ctx['demo_h'], ctx['demo_c'], A - 1)):
+            kernel, bias = p[scope + '/lstm/kernel'], p[scope + '/lstm/bias']
+            # input projection of every possible token, once: [tok+1, 4U]
+            table_proj = K.matmul_nn(p[scope + '/embedding'], kernel[:U], bias=bias,
+                                     out=self._buf(scope + '/greedy_table', (tok + 1, 4 * U)))
+            logits = self._buf(scope + '/greedy_logits', (steps, R, tok))
+            ids = self._buf(scope + '/greedy_ids', (steps, R), torch.int32)
+            lens = self._buf(scope + '/greedy_len', (R,), torch.int32)
+            K.greedy_decode(table_proj, kernel[U:], p[scope + '/proj'], h0, c0, tok, end, steps,
+                            logits, ids, lens)
+            out[scope] = (logits, ids, lens)
+        lp, ip, np_ = out['prog']
+        la, ia, na = out['act']
+        self._greedy = dict(
+            greedy_pred_program=lp.permute(1, 2, 0),                  # [B, V, L]
+            greedy_program_tokens=ip.permute(1, 0),                   # [B, L]
+            greedy_pred_program_len=np_.view(B, 1),
+            greedy_pred_action=la.view(T, B, k, A).permute(1, 2, 0, 3),   # [B, k, T, A]
+            greedy_action_tokens=ia.view(T, B, k).permute(1, 2, 0),       # [B, k, T]
+            greedy_pred_action_len=na.view(B, k))
+        return self._greedy
+
+    @staticmethod
+    def sequence_stats(pred, gt, pred_len, gt_len):
+        """Accuracy statistics of Sequence_Loss (models/model_full.py:626-683) on the host
+        (these are logging metrics in the reference too).  pred, gt: [B, token_dim, max_len]
+        arrays; lengths [B].  Returns token_acc, seq_acc, is_same_seq, pred_tokens."""
+        pred, gt = np.asarray(pred, np.float32), np.asarray(gt, np.float32)
+        pred_len, gt_len = np.asarray(pred_len).reshape(-1), np.asarray(gt_len).reshape(-1)
+        max_len = pred.shape[2]
+        pos = np.arange(max_len)[None, :]
+        gt_mask = (pos < gt_len[:, None]).astype(np.float32)
+        max_mask = (pos < np.maximum(pred_len, gt_len)[:, None]).astype(np.float32)
+        min_mask = (pos < np.minimum(pred_len, gt_len)[:, None]).astype(np.float32)
+        label_argmax = gt.argmax(axis=1)
+        logit_argmax = pred.argmax(axis=1)
+        eq = (label_argmax == logit_argmax).astype(np.float32)
+        token_acc = float((eq * min_mask).sum() / max_mask.sum())
+        seq_equal = (label_argmax * gt_mask) == (logit_argmax * gt_mask)
+        is_same_seq = seq_equal.all(axis=1) & (gt_len == pred_len)
+        return dict(token_acc=token_acc, seq_acc=float(is_same_seq.mean()),
+                    is_same_seq=is_same_seq, pred_tokens=logit_argmax)
+
+    def report(self, with_greedy=True):
+        """report_loss / report_accuracy entries of the reference that do not need the DSL
+        interpreter (models/model_full.py:1102-1132): losses, token / sequence accuracies of the
+        teacher-forced and greedy program and action decoders."""
+        c, f = self.config, self._feed
+        B, k, T = c.batch_size, c.k, c.max_demo_len
+        gt_prog = f['program'].cpu().numpy()
+        plen = f['program_len'].cpu().numpy()
+        dlen = f['demo_len'].cpu().numpy().reshape(B, k)
+        gt_act = f['a_h'].view(B, k, T, self.action_space).permute(0, 1, 3, 2).cpu().numpy()
+        t = self._terms.cpu().numpy()
+        loss = {'program_loss': float(t[0]), 'avg_action_loss': float(t[1]), 'avg_per_loss': float(t[2])}
+        acc = {}
+        st = self.sequence_stats(self.pred_program.cpu().numpy(), gt_prog, plen, plen)
+        acc['program_token_acc'], acc['program_seq_acc'] = st['token_acc'], st['seq_acc']
+        pa = self.pred_action.permute(0, 1, 3, 2).cpu().numpy()
+        sts = [self.sequence_stats(pa[:, i], gt_act[:, i], dlen[:, i], dlen[:, i]) for i in range(k)]
+        acc['avg_action_token_acc'] = float(np.mean([s['token_acc'] for s in sts]))
+        acc['avg_action_seq_acc'] = float(np.mean([s['seq_acc'] for s in sts]))
+        if with_greedy:
+            g = self.greedy_decode()
+            st = self.sequence_stats(g['greedy_pred_program'].cpu().numpy(), gt_prog,
+                                     g['greedy_pred_program_len'].cpu().numpy(), plen)
+            acc['greedy_program_token_acc'], acc['greedy_program_seq_acc'] = st['token_acc'], st['seq_acc']
+            ga = g['greedy_pred_action'].permute(0, 1, 3, 2).cpu().numpy()
+            gl = g['greedy_pred_action_len'].cpu().numpy()
+            sts = [self.sequence_stats(ga[:, i], gt_act[:, i], gl[:, i], dlen[:, i]) for i in range(k)]
+            acc['greedy_avg_action_token_acc'] = float(np.mean([s['token_acc'] for s in sts]))
+            acc['greedy_avg_action_seq_acc'] = float(np.mean([s['seq_acc'] for s in sts]))
+        return loss, acc
+
+    @property
+    def greedy_pred_program(self):
+        return self._greedy['greedy_pred_program']
+
+    @property
+    def greedy_pred_program_len(self):
+        return self._greedy['greedy_pred_program_len']
+
     # ------------------------------------------------------------------ reference attributes
     @property
     def loss(self):

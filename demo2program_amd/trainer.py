@@ -189,8 +189,12 @@ class Trainer(object):
         loss = self.model.forward(feed)
         self.model.track_moving = track
         loss_value = float(loss.item())
+        # the 'test' summaries of the reference: greedy decoders + accuracies
+        # (models/model_full.py:1154-1177); the syntax / execution metrics need the DSL
+        # interpreter and are not built
+        self.last_test_report = self.model.report(with_greedy=True)
         _end_time = time.time()
-        return self.global_step, None, loss_value, None, (_end_time - _start_time)
+        return self.global_step, self.last_test_report, loss_value, None, (_end_time - _start_time)
 
     def train(self, max_steps=1000000):
         ckpt_save_step = 1000

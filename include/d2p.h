@@ -208,6 +208,22 @@ size_t d2p_embedding_scatter_ws_bytes(int n, int rows, int E);
 int d2p_embedding_scatter_add_oob0(int n, int rows, int E, const int* ids, const float* dout,
                                    float* dtable, void* ws, size_t ws_bytes, d2p_stream_t stream);
 
+/* ---- greedy decoding (evaluation path) -----------------------------------
+ * Replaces BasicDecoder + GreedyEmbeddingHelper + dynamic_decode(maximum_iterations=L)
+ * (models/model_full.py:424-435,465-490).  table_proj: [V+1, 4U] = embedding·Wx + b (the
+ * caller computes it once with d2p_gemm_f32_nn; steps then only gather rows).  start_id is
+ * token_dim (last table row), end_id the end token ('m)' = 3 for programs, A-1 for actions).
+ * Outputs (time-major): logits [L, M, V] zero past the steps TF would have run, ids [L, M]
+ * (argmax, first index on ties, 0 past the run), lengths [M] (1-based first end_id, L if none).
+ * No host synchronisation inside.  ws >= d2p_greedy_ws_bytes(M, U, V). */
+size_t d2p_greedy_ws_bytes(int M, int U, int V);
+int d2p_greedy_decode(int M, int U, int V, int L, const float* table_proj, const float* Wh,
+                      const float* proj, const float* h0, const float* c0, int start_id, int end_id,
+                      float* logits, int* ids, int* lengths, void* ws, size_t ws_bytes,
+                      d2p_stream_t stream);
+/* out[r] = argmax_v x[r*ld + v] (first index on ties, as tf.argmax) */
+int d2p_argmax_rows(int rows, int V, const float* x, long ld, int* out, d2p_stream_t stream);
+
 /* ---- K7: masked, count-normalised sequence cross-entropies --------------------------
  * Replaces Sequence_Loss (models/model_full.py:620-657): softmax_/sigmoid_cross_entropy_
  * with_logits, tf.sequence_mask and the sum(ce*mask)/sum(mask) normalisation.

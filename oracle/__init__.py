@@ -32,4 +32,7 @@ from .model_full import (  # noqa: F401
     polynomial_decay,
     PARAM_ORDER,
     param_shapes,
+    greedy_decoder,
+    sequence_stats,
+    greedy_program_and_actions,
 )

@@ -421,3 +421,82 @@ def adam_clip_step(params, grads, m, v, step, lr, clip=20.0, b1=0.9, b2=0.999, e
         v[n] = b2 * v[n] + (1 - b2) * g * g
         params[n] = params[n] - lr_t * m[n] / (v[n].sqrt() + eps)
     return norm
+
+
+# --------------------------------------------------------------------------- greedy decoding (N1)
+
+def greedy_decoder(table, c0, h0, kernel, bias, proj, start_id, end_id, max_len):
+    """[TF-1.3] BasicDecoder(cell, GreedyEmbeddingHelper(embedding, start_tokens, end_token),
+    (c0, h0), Dense(no bias)) under dynamic_decode(impute_finished=False,
+    maximum_iterations=max_len)  (models/model_full.py:424-435,465-490).
+
+    start_tokens = token_dim (the last, in-range embedding row, :426-427).  Each step:
+    logits = Dense(cell(inputs)); sample = argmax(logits) (first index on ties);
+    finished |= (sample == end_token); the next input is embedding(sample) for EVERY row
+    (finished rows keep running on their own samples until all rows are finished or max_len is
+    reached); sequence_length[r] = step+1 at which r first finished (max_len if never).
+    Returns (logits [B, token_dim, max_len] zero-padded past the steps that ran,
+             sample ids [B, max_len] (zeros past the steps that ran), lengths [B])."""
+    B = c0.shape[0]
+    token_dim = proj.shape[1]
+    c, h = c0, h0
+    inputs = table[torch.full((B,), start_id, dtype=torch.int64)]
+    finished = torch.zeros(B, dtype=torch.bool)
+    lengths = torch.zeros(B, dtype=torch.int64)
+    logits_l, ids_l = [], []
+    for t in range(max_len):
+        if bool(finished.all()):
+            break
+        c, h = basic_lstm_cell(inputs, c, h, kernel, bias)
+        logits = h @ proj
+        sample = torch.argmax(logits, dim=-1)
+        logits_l.append(logits)
+        ids_l.append(sample)
+        step_finished = sample == end_id
+        next_finished = finished | step_finished | (t + 1 >= max_len)
+        lengths = torch.where(~finished & next_finished, torch.full_like(lengths, t + 1), lengths)
+        finished = next_finished
+        inputs = table[sample]
+    n = len(logits_l)
+    out = torch.zeros(B, max_len, token_dim, dtype=c0.dtype)
+    ids = torch.zeros(B, max_len, dtype=torch.int64)
+    if n:
+        out[:, :n] = torch.stack(logits_l, dim=1)
+        ids[:, :n] = torch.stack(ids_l, dim=1)
+    return out.permute(0, 2, 1), ids, lengths
+
+
+def sequence_stats(pred, gt, pred_len, gt_len, max_len, token_dim):
+    """The accuracy statistics of Sequence_Loss (models/model_full.py:626-683):
+    token_acc = sum(eq * min_mask) / sum(max_mask); is_same_seq = all positions equal under the
+    gt mask AND equal lengths; seq_acc = mean(is_same_seq).  pred, gt: [B, token_dim, max_len]."""
+    B = pred.shape[0]
+    pos = torch.arange(max_len).unsqueeze(0)
+    gt_mask = (pos < gt_len.unsqueeze(1)).to(pred.dtype)
+    max_mask = (pos < torch.maximum(pred_len, gt_len).unsqueeze(1)).to(pred.dtype)
+    min_mask = (pos < torch.minimum(pred_len, gt_len).unsqueeze(1)).to(pred.dtype)
+    label_argmax = gt.permute(0, 2, 1).argmax(dim=-1)
+    logit_argmax = pred.permute(0, 2, 1).argmax(dim=-1)
+    eq = (label_argmax == logit_argmax).to(pred.dtype)
+    token_acc = (eq * min_mask).sum() / max_mask.sum()
+    seq_equal = (label_argmax.to(pred.dtype) * gt_mask) == (logit_argmax.to(pred.dtype) * gt_mask)
+    is_same_seq = seq_equal.all(dim=-1) & (gt_len == pred_len)
+    return dict(token_acc=token_acc, seq_acc=is_same_seq.to(pred.dtype).mean(),
+                is_same_seq=is_same_seq, pred_tokens=logit_argmax)
+
+
+def greedy_program_and_actions(p, batch, cfg, fwd):
+    """Greedy twins of the program and action decoders (models/model_full.py:513-523,546-558)
+    given a finished `forward` result (for the decoder initial states)."""
+    B, k, T, L = cfg.batch_size, cfg.k, cfg.max_demo_len, cfg.max_program_len
+    V, A = cfg.dim_program_token, cfg.action_space
+    gp, gp_ids, gp_len = greedy_decoder(p['prog/embedding'], fwd['demo_c_summary'], fwd['demo_h_summary'],
+                                        p['prog/lstm/kernel'], p['prog/lstm/bias'], p['prog/proj'],
+                                        start_id=V, end_id=3, max_len=L)     # 'm)' == 3
+    acts = [greedy_decoder(p['act/embedding'], fwd['demo_c'][:, i], fwd['demo_h'][:, i],
+                           p['act/lstm/kernel'], p['act/lstm/bias'], p['act/proj'],
+                           start_id=A, end_id=A - 1, max_len=T) for i in range(k)]
+    return dict(greedy_pred_program=gp, greedy_program_ids=gp_ids, greedy_pred_program_len=gp_len,
+                greedy_pred_action=torch.stack([a[0] for a in acts], dim=1),      # [B,k,A,T]
+                greedy_action_ids=torch.stack([a[1] for a in acts], dim=1),       # [B,k,T]
+                greedy_pred_action_len=torch.stack([a[2] for a in acts], dim=1))  # [B,k]
