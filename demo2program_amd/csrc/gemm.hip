@@ -15,6 +15,16 @@ static int check_gemm_args(int M, int N, int K, const float* A, const float* B, 
     return D2P_OK;
 }
 
+extern "C" int d2p_gemm_set_option(int bk32) {
+    g_gemm_bk32 = bk32 ? 1 : 0;
+    return D2P_OK;
+}
+extern "C" int d2p_gemm_force_plan(int tile, int splits) {
+    g_gemm_force_tile = tile;
+    g_gemm_force_split = splits;
+    return D2P_OK;
+}
+
 extern "C" size_t d2p_gemm_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     return d2p_plan_ws_bytes(M, N, K);

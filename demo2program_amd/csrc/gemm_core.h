@@ -122,11 +122,11 @@ struct EpiDense {
 //   128x32 (4x1, 1x1)  skinny N (conv Cout / Cin = 16..32): no wasted MFMA columns
 //   256x32 (4x1, 2x1)  very tall skinny N
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, bool FAST, class AL, class BL, class EP>
+template <int BM, int BN, int WM, int WN, int BK, bool FAST, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
-    constexpr int BK = D2P_GEMM_BK;
+    static_assert(BK % 8 == 0, "K slab is consumed in chunks of 8");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
     constexpr int A_LD = AL::KCONTIG ? (BK + 4) : BM;
@@ -169,14 +169,14 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
             const int q = tid + i * 256;                                                           \
             if (CA % 256 == 0 || q < CA) {                                                         \
-                if (AL::KCONTIG) OA[i] = al.template load4<FAST>(m0 + (q >> 2), k0 + (q & 3) * 4, kend, RA[i]); \
+                if (AL::KCONTIG) OA[i] = al.template load4<FAST>(m0 + q / (BK / 4), k0 + (q % (BK / 4)) * 4, kend, RA[i]); \
                 else OA[i] = al.template load4<FAST>(m0 + (q % (BM / 4)) * 4, k0 + q / (BM / 4), kend, RA[i]); \
             }                                                                                      \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < IB; ++i) {                                           \
             const int q = tid + i * 256;                                                           \
             if (CB % 256 == 0 || q < CB) {                                                         \
-                if (BL::KCONTIG) OB[i] = bl.template load4<FAST>(n0 + (q >> 2), k0 + (q & 3) * 4, kend, RB[i]); \
+                if (BL::KCONTIG) OB[i] = bl.template load4<FAST>(n0 + q / (BK / 4), k0 + (q % (BK / 4)) * 4, kend, RB[i]); \
                 else OB[i] = bl.template load4<FAST>(n0 + (q % (BN / 4)) * 4, k0 + q / (BN / 4), kend, RB[i]); \
             }                                                                                      \
         }                                                                                          \
@@ -190,7 +190,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             if (CA % 256 == 0 || q < CA) {                                                         \
                 float4 t = make_float4(OA[i] ? RA[i][0] : 0.f, OA[i] ? RA[i][1] : 0.f,             \
                                        OA[i] ? RA[i][2] : 0.f, OA[i] ? RA[i][3] : 0.f);            \
-                if (AL::KCONTIG) *reinterpret_cast<float4*>(&As[(q >> 2) * A_LD + (q & 3) * 4]) = t; \
+                if (AL::KCONTIG) *reinterpret_cast<float4*>(&As[(q / (BK / 4)) * A_LD + (q % (BK / 4)) * 4]) = t; \
                 else *reinterpret_cast<float4*>(&As[(q / (BM / 4)) * A_LD + (q % (BM / 4)) * 4]) = t; \
             }                                                                                      \
         }                                                                                          \
@@ -199,7 +199,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             if (CB % 256 == 0 || q < CB) {                                                         \
                 float4 t = make_float4(OB[i] ? RB[i][0] : 0.f, OB[i] ? RB[i][1] : 0.f,             \
                                        OB[i] ? RB[i][2] : 0.f, OB[i] ? RB[i][3] : 0.f);            \
-                if (BL::KCONTIG) *reinterpret_cast<float4*>(&Bs[(q >> 2) * B_LD + (q & 3) * 4]) = t; \
+                if (BL::KCONTIG) *reinterpret_cast<float4*>(&Bs[(q / (BK / 4)) * B_LD + (q % (BK / 4)) * 4]) = t; \
                 else *reinterpret_cast<float4*>(&Bs[(q / (BN / 4)) * B_LD + (q % (BN / 4)) * 4]) = t; \
             }                                                                                      \
         }                                                                                          \
@@ -317,6 +317,10 @@ gemm_splitk_reduce_flat_kernel(EP ep, const float* partial, int M, int N, int nz
 // ------------------------------------------------------------------------------------
 // Host-side launch policy shared by gemm.hip and conv.hip.
 // ------------------------------------------------------------------------------------
+static int g_gemm_bk32 = 0;   // per translation unit; toggled through d2p_gemm_set_option
+static int g_gemm_force_tile = -1;   // -1: automatic; else a GemmTile value (tuning experiments)
+static int g_gemm_force_split = 0;   // 0: automatic
+
 enum GemmTile { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x32 = 2, TILE_256x32 = 3, TILE_128x64 = 4 };
 
 struct GemmPlan {
@@ -329,20 +333,37 @@ struct GemmPlan {
 static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
     GemmPlan p;
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
+    // Measured on MI355X (tools/bench_gemm.py): every tile shape tops out near 100 TFLOP/s, so
+    // the choice is about wave quantisation over 256 CUs -- 6400x2048 runs 134 us on 64x64
+    // (3200 workgroups) vs 164 us on 128x128 (800 workgroups = 3.1 per CU -> 4 rounds).
     if (N <= 32) {                       // skinny outputs: keep every MFMA column useful
         const long t256 = (long)ceil_div(M, 256);
         if (t256 >= 1024) { p.tile = TILE_256x32; p.bm = 256; p.bn = 32; }
         else { p.tile = TILE_128x32; p.bm = 128; p.bn = 32; }
     } else if (N <= 64 && (long)ceil_div(M, 128) >= 512) {   // e.g. conv Cout = 48
         p.tile = TILE_128x64; p.bm = 128; p.bn = 64;
-    } else if (t128 >= 512) {            // >= 2 full rounds of 256 CUs at the large tile
+    } else if (t128 >= 2048) {           // >= 8 full rounds at the large tile: L2 traffic wins
         p.tile = TILE_128x128; p.bm = 128; p.bn = 128;
+    } else if (N <= 512 && M >= 4096) {  // tall, medium-width outputs (dX = dZ Wx^T)
+        p.tile = TILE_128x64; p.bm = 128; p.bn = 64;
     } else {
         p.tile = TILE_64x64; p.bm = 64; p.bn = 64;
+    }
+    if (g_gemm_force_tile >= 0) {
+        p.tile = g_gemm_force_tile;
+        const int bms[5] = {64, 128, 128, 256, 128}, bns[5] = {64, 128, 32, 32, 64};
+        p.bm = bms[p.tile]; p.bn = bns[p.tile];
     }
     p.splits = 1;
     p.k_per_split = K;
     const long tiles = (long)ceil_div(M, p.bm) * ceil_div(N, p.bn);
+    if (allow_split && g_gemm_force_split > 1) {
+        int kps = (K + g_gemm_force_split - 1) / g_gemm_force_split;
+        kps = (kps + 31) / 32 * 32;
+        p.k_per_split = kps;
+        p.splits = (K + kps - 1) / kps;
+        return p;
+    }
     if (allow_split && tiles <= 512 && K >= 1024) {
         long want = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
         long maxs = K / 512;                             // keep >= 512 of K per split
@@ -350,7 +371,7 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
         if (s > 256) s = 256;                            // bound the combine pass
         if (s > 1) {
             int kps = (int)((K + s - 1) / s);
-            kps = (kps + D2P_GEMM_BK - 1) / D2P_GEMM_BK * D2P_GEMM_BK;
+            kps = (kps + 31) / 32 * 32;
             p.k_per_split = kps;
             p.splits = (K + kps - 1) / kps;
         }
@@ -363,15 +384,15 @@ static inline size_t d2p_plan_ws_bytes(int M, int N, int K) {
     return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int WM, int WN, class AL, class BL, class EP>
+template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EP>
 static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
                             const GemmPlan& p, bool fast, float* partial, hipStream_t st) {
     dim3 grid(ceil_div(M, BM) * ceil_div(N, BN), 1, p.splits);
     if (fast)
-        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, true, AL, BL, EP>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, AL, BL, EP>), grid, dim3(256), 0, st,
                            al, bl, ep, M, N, K, p.k_per_split, partial);
     else
-        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, false, AL, BL, EP>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, false, AL, BL, EP>), grid, dim3(256), 0, st,
                            al, bl, ep, M, N, K, p.k_per_split, partial);
 }
 
@@ -394,11 +415,17 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
     }
     const bool fast = al.fast_ok(K) && bl.fast_ok(K);
     switch (p.tile) {
-        case TILE_128x128: d2p_launch_tile<128, 128, 2, 2>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_128x32: d2p_launch_tile<128, 32, 4, 1>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_256x32: d2p_launch_tile<256, 32, 4, 1>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_128x64: d2p_launch_tile<128, 64, 2, 2>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        default: d2p_launch_tile<64, 64, 2, 2>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_128x128: d2p_launch_tile<128, 128, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_128x32: d2p_launch_tile<128, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_256x32: d2p_launch_tile<256, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_128x64: d2p_launch_tile<128, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        default:
+            // long-K problems on the small tile: 32-deep slabs (half the barriers, 128-byte runs)
+            if (g_gemm_bk32 && K >= 256 && fast)
+                d2p_launch_tile<64, 64, 2, 2, 32>(al, bl, ep, M, N, K, p, fast, partial, st);
+            else
+                d2p_launch_tile<64, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st);
+            break;
     }
     D2P_LAUNCH_CHECK(name);
     if (p.splits > 1) {

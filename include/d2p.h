@@ -55,6 +55,12 @@ int d2p_device_info(int device, char* name, int name_len, int* cus, int* wave, s
  * C = act(A·B + C_old + bias)).
  * ws: scratch for split-K, at least d2p_gemm_ws_bytes(M,N,K) bytes (may be NULL if 0). */
 size_t d2p_gemm_ws_bytes(int M, int N, int K);
+/* Tuning knob for the dense entry points: 1 (default) lets long-K problems on the 64x64 tile use
+ * 32-deep K slabs, 0 keeps 16. */
+int d2p_gemm_set_option(int bk32);
+/* Tuning experiments only: force the tile (0 64x64, 1 128x128, 2 128x32, 3 256x32, 4 128x64; -1 auto)
+ * and the split-K factor (0 auto) of the dense entry points. */
+int d2p_gemm_force_plan(int tile, int splits);
 int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                     float* C, long ldc, const float* bias, int act, int accumulate,
                     void* ws, size_t ws_bytes, d2p_stream_t stream);

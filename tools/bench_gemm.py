@@ -1,0 +1,71 @@
+#!/usr/bin/env python
+"""Within-process A/B of the dense GEMM entry points on the shapes of one training step
+(run on the GPU box).  Prints us and TFLOP/s per shape for each knob setting, interleaved."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from demo2program_amd import build, kernels as K  # noqa: E402
+from demo2program_amd.lib import load  # noqa: E402
+
+SHAPES = [  # (kind, M, N, K, label)
+    ('tn', 512, 2048, 6400, 'dW  = X^T dZ   (512x2048, K=6400)'),
+    ('nn', 6400, 2048, 512, 'z   = X Wx     (6400x2048, K=512)'),
+    ('nt', 6400, 512, 2048, 'dX  = dZ Wx^T  (6400x512, K=2048)'),
+    ('nn', 3200, 512, 512, 'rn fc2 fwd     (3200x512, K=512)'),
+    ('tn', 512, 512, 3200, 'rn fc2 dW      (512x512, K=3200)'),
+    ('nn', 1600, 2048, 512, 'prog x-proj    (1600x2048, K=512)'),
+    ('nn', 6400, 2048, 48, 'demo x-proj    (6400x2048, K=48)'),
+]
+
+
+def timed(fn, reps=30):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def main():
+    build.build_library()
+    lib = load()
+    g = torch.Generator().manual_seed(0)
+    for kind, M, N, Kd, label in SHAPES:
+        if kind == 'nn':
+            A, B = torch.rand(M, Kd, generator=g).cuda() - 0.5, torch.rand(Kd, N, generator=g).cuda() - 0.5
+            fn = lambda: K.matmul_nn(A, B, out=C)
+        elif kind == 'nt':
+            A, B = torch.rand(M, Kd, generator=g).cuda() - 0.5, torch.rand(N, Kd, generator=g).cuda() - 0.5
+            fn = lambda: K.matmul_nt(A, B, out=C)
+        else:
+            A, B = torch.rand(Kd, M, generator=g).cuda() - 0.5, torch.rand(Kd, N, generator=g).cuda() - 0.5
+            fn = lambda: K.matmul_tn(A, B, out=C)
+        C = torch.empty(M, N, device='cuda')
+        fl = 2.0 * M * N * Kd
+        variants = [('auto', -1, 0), ('64x64', 0, 0), ('64x64 s2', 0, 2), ('64x64 s4', 0, 4), ('128x64', 4, 0),
+                    ('128x64 s2', 4, 2), ('128x128', 1, 0), ('128x128 s2', 1, 2), ('128x128 s4', 1, 4),
+                    ('128x128 s8', 1, 8)]
+        res = {}
+        ws_need = 16 * M * N * 4
+        K.SCRATCH.reserve(ws_need)
+        for rnd in range(2):
+            for name, tile, sp in variants:
+                if sp and Kd // sp < 64:
+                    continue
+                lib.d2p_gemm_force_plan(tile, sp)
+                res.setdefault(name, []).append(timed(fn, 20))
+        lib.d2p_gemm_force_plan(-1, 0)
+        print(label)
+        print('    ' + '  '.join('%s %.0fus %.0fTF' % (n, min(t) * 1e6, fl / min(t) / 1e12) for n, t in res.items()))
+
+
+if __name__ == '__main__':
+    main()
