@@ -183,13 +183,17 @@ struct EpiDgrad {   // scatter the class rows back to their stride-2 pixel posit
     float* dx;
     int H, W, Cin;
     DgradClass c;
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+    __device__ __forceinline__ float col_value(int) const { return 0.f; }
+    __device__ __forceinline__ bool has_c() const { return false; }
+    __device__ __forceinline__ float c_value(int, int) const { return 0.f; }
+    __device__ __forceinline__ void store(int row, int col, float v) const {
         const int hw = c.Hc * c.Wc;
         const int n = row / hw;
         const int rem = row - n * hw;
         const int j = rem / c.Wc, i = rem - j * c.Wc;
         dx[(((long)n * H + c.iy0 + 2 * j) * W + c.ix0 + 2 * i) * Cin + col] = v;
     }
+    __device__ __forceinline__ void operator()(int row, int col, float v) const { store(row, col, v); }
 };
 
 static int check_conv(int N, int H, int W, int Cin, int Cout) {

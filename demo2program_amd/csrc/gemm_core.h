@@ -99,18 +99,28 @@ struct DenseXC {  // elem(x,k) = p[k*ld + x]
 // ------------------------------------------------------------------------------------
 // Epilogues.  operator()(row, col, value): called once per in-range output element.
 // ------------------------------------------------------------------------------------
+// Interface used by the kernel epilogue (so that per-column values are loaded once per lane and
+// the C reads of an accumulating GEMM are issued together instead of one-load-one-wait):
+//   col_value(col)      value added to every element of the column (bias), 0 if none
+//   has_c()             whether C_old must be added
+//   c_value(row, col)   C_old
+//   store(row, col, v)  v already holds acc + C_old + col_value; applies act and writes
 struct EpiDense {
     float* C;
     long ldc;
     const float* bias;  // [N] or null
     int act;            // 0 none, 1 lrelu(0.2)
     int accumulate;     // C = act(v + C_old + bias)
-    __device__ __forceinline__ void operator()(int row, int col, float v) const {
-        float* c = C + (long)row * ldc + col;
-        if (accumulate) v += *c;
-        if (bias) v += bias[col];
+    __device__ __forceinline__ float col_value(int col) const { return bias ? bias[col] : 0.f; }
+    __device__ __forceinline__ bool has_c() const { return accumulate != 0; }
+    __device__ __forceinline__ float c_value(int row, int col) const { return C[(long)row * ldc + col]; }
+    __device__ __forceinline__ void store(int row, int col, float v) const {
         if (act == 1) v = d2p_lrelu(v);
-        *c = v;
+        C[(long)row * ldc + col] = v;
+    }
+    __device__ __forceinline__ void operator()(int row, int col, float v) const {
+        if (accumulate) v += c_value(row, col);
+        store(row, col, v + col_value(col));
     }
 };
 
@@ -267,19 +277,32 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
 #undef D2P_SSTORE
 
     const bool split = gridDim.z > 1;
+    const bool with_c = !split && ep.has_c();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * (BN / WN) + j * 32 + l32;
+            const int rbase = m0 + wm * (BM / WM) + i * 32 + 4 * hi;
+            if (col >= N) continue;
+            const float cv = split ? 0.f : ep.col_value(col);       // once per lane and column
+            float cold[16];
+            if (with_c) {                                           // all C reads in flight together
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int col = n0 + wn * (BN / WN) + j * 32 + l32;
-                if (row < M && col < N) {
-                    if (split) partial[((long)blockIdx.z * M + row) * N + col] = acc[i][j][r];
-                    else ep(row, col, acc[i][j][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    cold[r] = row < M ? ep.c_value(row, col) : 0.f;
                 }
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < M) {
+                    if (split) partial[((long)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+                    else ep.store(row, col, acc[i][j][r] + (with_c ? cold[r] : 0.f) + cv);
+                }
+            }
+        }
 }
 
 // Deterministic split-K combine: 16 lanes per output element each sum slabs z = l, l+16, ...
