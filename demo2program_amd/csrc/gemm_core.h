@@ -391,7 +391,7 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
         long want = (1024 + tiles - 1) / tiles;          // aim at ~4 workgroups per CU
         long maxs = K / 512;                             // keep >= 512 of K per split
         long s = want < maxs ? want : maxs;
-        if (s > 256) s = 256;                            // bound the combine pass
+        if (s > 1024) s = 1024;                          // bound the combine pass
         if (s > 1) {
             int kps = (int)((K + s - 1) / s);
             kps = (kps + 31) / 32 * 32;
