@@ -259,6 +259,8 @@ extern "C" int d2p_conv2d_nhwc_s2_same_dgrad(int N, int H, int W, int Cin, int C
     D2P_REQUIRE(dy && w && dx, D2P_EINVAL, "conv dgrad: null pointer");
     D2P_REQUIRE(Cout % 4 == 0 && (((uintptr_t)dy & 15) == 0) && (((uintptr_t)w & 15) == 0), D2P_EALIGN,
                 "conv dgrad: needs Cout %% 4 == 0 and 16-byte aligned dy/w (Cout=%d)", Cout);
+    // (Running the four classes chunk-by-chunk over frames, to keep dY in the Infinity Cache, was
+    // measured slower: the class GEMMs are MFMA-bound on the half-empty N=16 tile, not HBM-bound.)
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
     for (int qy = 0; qy < 2; ++qy)
         for (int qx = 0; qx < 2; ++qx) {

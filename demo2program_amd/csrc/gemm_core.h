@@ -132,10 +132,16 @@ struct EpiDense {
 //   128x32 (4x1, 1x1)  skinny N (conv Cout / Cin = 16..32): no wasted MFMA columns
 //   256x32 (4x1, 2x1)  very tall skinny N
 // ------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, int BK, bool FAST, class AL, class BL, class EP>
+// KS ("K split across waves") mode, for tiny outputs with a huge K (conv weight gradients:
+// 36x16 .. 432x48 outputs over up to 10M rows): all four waves own the SAME BM x BN tile and
+// each consumes one 8-deep chunk of every 32-deep K slab; every wave writes its own split-K
+// slab (slab index blockIdx.z*4 + wave), so the ordinary deterministic combine kernel finishes
+// the job.  Without it 3 of 4 waves idle on a one-tile output.
+template <int BM, int BN, int WM, int WN, int BK, bool FAST, bool KS, class AL, class BL, class EP>
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial) {
-    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(KS || WM * WN == 4, "4 waves per workgroup");
+    static_assert(!KS || (WM == 1 && WN == 1 && BK == 32), "KS: one tile for all waves, 4 chunks per slab");
     static_assert(BK % 8 == 0, "K slab is consumed in chunks of 8");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
@@ -150,7 +156,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, hi = lane >> 5;
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = KS ? 0 : wave / WN, wn = KS ? 0 : wave % WN;
 
     const int nbn = (N + BN - 1) / BN;
     const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
@@ -219,6 +225,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         const float* Bs = As + A_SZ;
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
+            if (KS && kk != wave) continue;
             float fa[TM][4], fb[TN][4];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -276,7 +283,8 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
 #undef D2P_GLOAD
 #undef D2P_SSTORE
 
-    const bool split = gridDim.z > 1;
+    const bool split = KS || gridDim.z > 1;
+    const int slab = KS ? blockIdx.z * 4 + wave : blockIdx.z;
     const bool with_c = !split && ep.has_c();
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -298,7 +306,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < M) {
-                    if (split) partial[((long)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+                    if (split) partial[((long)slab * M + row) * N + col] = acc[i][j][r];
                     else ep.store(row, col, acc[i][j][r] + (with_c ? cold[r] : 0.f) + cv);
                 }
             }
@@ -344,13 +352,15 @@ static int g_gemm_bk32 = 0;   // per translation unit; toggled through d2p_gemm_
 static int g_gemm_force_tile = -1;   // -1: automatic; else a GemmTile value (tuning experiments)
 static int g_gemm_force_split = 0;   // 0: automatic
 
-enum GemmTile { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x32 = 2, TILE_256x32 = 3, TILE_128x64 = 4 };
+enum GemmTile { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x32 = 2, TILE_256x32 = 3, TILE_128x64 = 4,
+                TILE_64x32_KS = 5, TILE_64x64_KS = 6 };
 
 struct GemmPlan {
     int tile;     // GemmTile
     int bm, bn;
     int splits;   // grid.z
     int k_per_split;
+    int slabs;    // partial slabs written (splits, or 4*splits in KS mode); 1 = no combine pass
 };
 
 static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
@@ -372,19 +382,40 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
     } else {
         p.tile = TILE_64x64; p.bm = 64; p.bn = 64;
     }
+    // tiny output, huge K: K split across the waves of a workgroup as well as across workgroups
+    if (allow_split && K >= 8192 && N <= 64 &&
+        (long)ceil_div(M, 64) * ceil_div(N, N <= 32 ? 32 : 64) <= 8) {
+        if (N <= 32) { p.tile = TILE_64x32_KS; p.bm = 64; p.bn = 32; }
+        else { p.tile = TILE_64x64_KS; p.bm = 64; p.bn = 64; }
+    }
     if (g_gemm_force_tile >= 0) {
         p.tile = g_gemm_force_tile;
-        const int bms[5] = {64, 128, 128, 256, 128}, bns[5] = {64, 128, 32, 32, 64};
+        const int bms[7] = {64, 128, 128, 256, 128, 64, 64}, bns[7] = {64, 128, 32, 32, 64, 32, 64};
         p.bm = bms[p.tile]; p.bn = bns[p.tile];
     }
+    const bool ks = (p.tile == TILE_64x32_KS || p.tile == TILE_64x64_KS);
     p.splits = 1;
     p.k_per_split = K;
+    p.slabs = ks ? 4 : 1;
     const long tiles = (long)ceil_div(M, p.bm) * ceil_div(N, p.bn);
+    if (ks) {
+        long s = 1024 / tiles;                           // ~4 workgroups per CU
+        const long maxs = K / 1024;                      // >= 32 slabs of 32 per workgroup
+        if (s > maxs) s = maxs;
+        if (s < 1) s = 1;
+        int kps = (int)((K + s - 1) / s);
+        kps = (kps + 31) / 32 * 32;
+        p.k_per_split = kps;
+        p.splits = (K + kps - 1) / kps;
+        p.slabs = 4 * p.splits;
+        return p;
+    }
     if (allow_split && g_gemm_force_split > 1) {
         int kps = (K + g_gemm_force_split - 1) / g_gemm_force_split;
         kps = (kps + 31) / 32 * 32;
         p.k_per_split = kps;
         p.splits = (K + kps - 1) / kps;
+        p.slabs = p.splits;
         return p;
     }
     if (allow_split && tiles <= 512 && K >= 1024) {
@@ -397,6 +428,7 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
             kps = (kps + 31) / 32 * 32;
             p.k_per_split = kps;
             p.splits = (K + kps - 1) / kps;
+            p.slabs = p.splits;
         }
     }
     return p;
@@ -404,18 +436,18 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
 
 static inline size_t d2p_plan_ws_bytes(int M, int N, int K) {
     GemmPlan p = d2p_plan_gemm(M, N, K, true);
-    return p.splits > 1 ? (size_t)p.splits * M * N * sizeof(float) : 0;
+    return p.slabs > 1 ? (size_t)p.slabs * M * N * sizeof(float) : 0;
 }
 
-template <int BM, int BN, int WM, int WN, int BK, class AL, class BL, class EP>
+template <int BM, int BN, int WM, int WN, int BK, bool KS = false, class AL, class BL, class EP>
 static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
                             const GemmPlan& p, bool fast, float* partial, hipStream_t st) {
     dim3 grid(ceil_div(M, BM) * ceil_div(N, BN), 1, p.splits);
     if (fast)
-        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, AL, BL, EP>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP>), grid, dim3(256), 0, st,
                            al, bl, ep, M, N, K, p.k_per_split, partial);
     else
-        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, false, AL, BL, EP>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, false, KS, AL, BL, EP>), grid, dim3(256), 0, st,
                            al, bl, ep, M, N, K, p.k_per_split, partial);
 }
 
@@ -427,11 +459,10 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
     D2pProfScope prof(st, prof_family, 2.0 * M * N * K);
     GemmPlan p = d2p_plan_gemm(M, N, K, ws != nullptr);
     float* partial = nullptr;
-    if (p.splits > 1) {
-        const size_t need = (size_t)p.splits * M * N * sizeof(float);
+    if (p.slabs > 1) {
+        const size_t need = (size_t)p.slabs * M * N * sizeof(float);
         if (ws_bytes < need) {   // not enough scratch: fall back to a single pass
-            p.splits = 1;
-            p.k_per_split = K;
+            p = d2p_plan_gemm(M, N, K, false);
         } else {
             partial = (float*)ws;
         }
@@ -442,6 +473,8 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         case TILE_128x32: d2p_launch_tile<128, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         case TILE_256x32: d2p_launch_tile<256, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         case TILE_128x64: d2p_launch_tile<128, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_64x32_KS: d2p_launch_tile<64, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_64x64_KS: d2p_launch_tile<64, 64, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         default:
             // long-K problems on the small tile: 32-deep slabs (half the barriers, 128-byte runs)
             if (g_gemm_bk32 && K >= 256 && fast)
@@ -451,18 +484,18 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
             break;
     }
     D2P_LAUNCH_CHECK(name);
-    if (p.splits > 1) {
+    if (p.slabs > 1) {
         const long total = (long)M * N;
-        if (p.splits <= 16) {
+        if (p.slabs <= 16) {
             int blocks = (int)((total + 255) / 256);
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL((gemm_splitk_reduce_flat_kernel<EP>), dim3(blocks), dim3(256), 0, st, ep,
-                               partial, M, N, p.splits);
+                               partial, M, N, p.slabs);
         } else {
             int blocks = (int)((total * 16 + 255) / 256);
             if (blocks > 4096) blocks = 4096;
             hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EP>), dim3(blocks), dim3(256), 0, st, ep,
-                               partial, M, N, p.splits);
+                               partial, M, N, p.slabs);
         }
         D2P_LAUNCH_CHECK("gemm_splitk_reduce");
     }

@@ -39,7 +39,8 @@ def rnd(*shape, seed=0, scale=1.0):
 
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize('M,N,K_', [(64, 64, 16), (70, 50, 37), (320, 2048, 512), (6400, 6, 512),
-                                    (33, 512, 5), (1, 1, 1), (130, 260, 1030), (144, 16, 20480),
+                                    (33, 512, 5), (1, 1, 1), (130, 260, 1030), (144, 16, 20480), (36, 16, 40961),
+                                    (288, 48, 12000), (432, 48, 8200),
                                     (1024, 1024, 64)])
 def test_gemm_nn_nt_tn(K, M, N, K_):
     A = rnd(M, K_, seed=1)
