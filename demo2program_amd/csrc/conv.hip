@@ -7,28 +7,11 @@
 //   dgrad : dX[p, c]   = sum_(tap,co) colT(dY)[p, (tap,co)] * W[tap, c, co]
 // The im2col matrix is never materialised: the A-operand loader gathers NHWC pixels
 // (4 consecutive channels per 16-byte load when Cin % 4 == 0) straight into the LDS tile.
-// TF SAME padding for k=3,s=2: out = ceil(n/2), pad_total = max((out-1)*2+3-n, 0),
-// pad_before = pad_total/2  => even n: (0,1); odd n: (1,1).   
+// Geometry and SAME padding: conv_geom.h.  Small-channel layers (Cout <= 32, and the Karel
+// 2x2 -> 1x1 layer) are served by the direct kernels in conv_direct.hip; everything else, and
+// every call when those are disabled, runs here.
 #include "gemm_core.h"
-
-struct ConvGeom {
-    int N, H, W, Cin, Cout, Ho, Wo, pt, pl;
-};
-
-static inline void same_pad(int n, int* out, int* before) {
-    *out = (n + 1) / 2;
-    int total = (*out - 1) * 2 + 3 - n;
-    if (total < 0) total = 0;
-    *before = total / 2;
-}
-
-static inline ConvGeom make_geom(int N, int H, int W, int Cin, int Cout) {
-    ConvGeom g;
-    g.N = N; g.H = H; g.W = W; g.Cin = Cin; g.Cout = Cout;
-    same_pad(H, &g.Ho, &g.pt);
-    same_pad(W, &g.Wo, &g.pl);
-    return g;
-}
+#include "conv_geom.h"
 
 __device__ __forceinline__ float ld1(const float* p) { return *p; }
 __device__ __forceinline__ float ld1(const uint8_t* p) { return (float)*p; }
@@ -207,8 +190,11 @@ static int check_conv(int N, int H, int W, int Cin, int Cout) {
 extern "C" size_t d2p_conv_ws_bytes(int N, int H, int W, int Cin, int Cout) {
     if (N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
-    return d2p_plan_ws_bytes(9 * Cin, Cout, N * g.Ho * g.Wo);
+    const size_t a = d2p_plan_ws_bytes(9 * Cin, Cout, N * g.Ho * g.Wo), b = d2p_conv_direct_wgrad_ws(g);
+    return a > b ? a : b;
 }
+
+extern "C" void d2p_conv_set_direct(int fwd, int dgrad, int wgrad) { d2p_conv_direct_enable(fwd, dgrad, wgrad); }
 
 extern "C" int d2p_conv2d_nhwc_s2_same_fwd(int N, int H, int W, int Cin, int Cout, const void* x,
                                            int x_is_u8, const float* w, const float* bias, int act,
@@ -219,6 +205,8 @@ extern "C" int d2p_conv2d_nhwc_s2_same_fwd(int N, int H, int W, int Cin, int Cou
     D2P_REQUIRE(x && w && y, D2P_EINVAL, "conv fwd: null pointer");
     D2P_REQUIRE(act == 0 || act == 1, D2P_EINVAL, "conv fwd: unknown act %d", act);
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    rc = d2p_conv_direct_fwd(g, x, x_is_u8, w, bias, act, y, as_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : D2P_OK;
     const int M = N * g.Ho * g.Wo, K = 9 * Cin;
     const int vecx = (Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
     DenseXC bl{w, Cout, Cout, (Cout % 4 == 0) && (((uintptr_t)w & 15) == 0)};
@@ -238,6 +226,8 @@ extern "C" int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int C
     if (rc) return rc;
     D2P_REQUIRE(dw && (N == 0 || (x && dy)), D2P_EINVAL, "conv wgrad: null pointer");
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    rc = d2p_conv_direct_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, as_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : D2P_OK;
     const int Mred = N * g.Ho * g.Wo, KK = 9 * Cin;
     const int vecx = (Cin % 4 == 0) && (((uintptr_t)x & 15) == 0);
     DenseXC bl{dy, Cout, Cout, (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0)};
@@ -262,6 +252,8 @@ extern "C" int d2p_conv2d_nhwc_s2_same_dgrad(int N, int H, int W, int Cin, int C
     // (Running the four classes chunk-by-chunk over frames, to keep dY in the Infinity Cache, was
     // measured slower: the class GEMMs are MFMA-bound on the half-empty N=16 tile, not HBM-bound.)
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    rc = d2p_conv_direct_dgrad(g, dy, w, dx, as_stream(stream));
+    if (rc != 0) return rc < 0 ? rc : D2P_OK;
     for (int qy = 0; qy < 2; ++qy)
         for (int qx = 0; qx < 2; ++qx) {
             DgradClass c;

@@ -92,7 +92,10 @@ def _conv_ref(x, w, b):
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout', [(40, 8, 8, 16, 16), (40, 4, 4, 16, 32), (40, 2, 2, 32, 48),
                                             (6, 80, 80, 3, 16), (7, 5, 5, 48, 48), (9, 3, 3, 48, 48),
-                                            (3, 10, 10, 48, 48), (5, 7, 9, 4, 8)])
+                                            (3, 10, 10, 48, 48), (5, 7, 9, 4, 8),
+                                            (41, 4, 4, 16, 32), (37, 2, 2, 32, 48), (33, 8, 8, 16, 16),
+                                            (3, 20, 20, 16, 32), (2, 21, 19, 16, 16), (5, 11, 14, 4, 16),
+                                            (1, 1, 1, 16, 16), (700, 8, 8, 16, 16)])
 def test_conv_fwd_dgrad_wgrad(K, N, H, W, Cin, Cout):
     x = rnd(N, H, W, Cin, seed=1).requires_grad_(True)
     w = rnd(3, 3, Cin, Cout, seed=2, scale=0.3).requires_grad_(True)
