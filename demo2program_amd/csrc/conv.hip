@@ -194,7 +194,10 @@ extern "C" size_t d2p_conv_ws_bytes(int N, int H, int W, int Cin, int Cout) {
     return a > b ? a : b;
 }
 
-extern "C" void d2p_conv_set_direct(int fwd, int dgrad, int wgrad) { d2p_conv_direct_enable(fwd, dgrad, wgrad); }
+extern "C" int d2p_conv_set_direct(int fwd, int dgrad, int wgrad) {
+    d2p_conv_direct_enable(fwd, dgrad, wgrad);
+    return D2P_OK;
+}
 
 extern "C" int d2p_conv2d_nhwc_s2_same_fwd(int N, int H, int W, int Cin, int Cout, const void* x,
                                            int x_is_u8, const float* w, const float* bias, int act,

@@ -540,12 +540,13 @@ static int direct_waves(int units, int per_wave) {
 }
 
 static int g_direct_fwd_tpw = 2, g_direct_dgrad_tpw = 2, g_direct_wgrad_wgs = 256;
-extern "C" void d2p_conv_direct_tune(int fwd_tpw, int dgrad_tpw, int wgrad_wgs) {
+extern "C" int d2p_conv_direct_tune(int fwd_tpw, int dgrad_tpw, int wgrad_wgs) {
     if (fwd_tpw > 0) g_direct_fwd_tpw = fwd_tpw;
     if (dgrad_tpw > 0) g_direct_dgrad_tpw = dgrad_tpw;
     if (wgrad_wgs > 0) g_direct_wgrad_wgs = wgrad_wgs;
     if (wgrad_wgs != 0) d2p_conv_frames_wgrad_cap(wgrad_wgs > 0 ? wgrad_wgs : 0);
     if (fwd_tpw > 0) d2p_conv_frames_tune(fwd_tpw);
+    return D2P_OK;
 }
 
 template <int CIN, int COUT, int MASK, typename T>

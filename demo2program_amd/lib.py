@@ -31,8 +31,8 @@ SIGNATURES = {
     'd2p_colsum_ws_bytes': (c_size_t, [c_int, c_int]),
     'd2p_colsum_f32': (c_int, [c_int, c_int, P, c_long, P, P, c_size_t, S]),
     'd2p_conv_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    'd2p_conv_set_direct': (None, [c_int, c_int, c_int]),
-    'd2p_conv_direct_tune': (None, [c_int, c_int, c_int]),
+    'd2p_conv_set_direct': (c_int, [c_int, c_int, c_int]),
+    'd2p_conv_direct_tune': (c_int, [c_int, c_int, c_int]),
     'd2p_conv2d_nhwc_s2_same_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, P, S]),
     'd2p_conv2d_nhwc_s2_same_dgrad': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, S]),
     'd2p_conv2d_nhwc_s2_same_wgrad': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_size_t, S]),

@@ -99,8 +99,8 @@ int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int Cout,
  * run on register-resident-filter direct kernels by default (selector 2: whole-frame LDS-staged
  * kernels for the Karel geometries, gather kernels otherwise; 1: gather kernels only); 0 routes
  * that direction through the implicit-im2col GEMM instead.  Results agree to fp32 rounding. */
-void d2p_conv_set_direct(int fwd, int dgrad, int wgrad);
-void d2p_conv_direct_tune(int fwd_tiles_per_wave, int dgrad_tiles_per_wave, int wgrad_workgroups);
+int d2p_conv_set_direct(int fwd, int dgrad, int wgrad);
+int d2p_conv_direct_tune(int fwd_tiles_per_wave, int dgrad_tiles_per_wave, int wgrad_workgroups);
 
 /* ---- K2: training-mode batch norm over row groups (+ fused lrelu backward) ---------
  * Replaces tf.contrib.layers.batch_norm(is_training=True, decay=0.9,
