@@ -35,11 +35,26 @@ static inline BnPlan bn_plan(int R, int C, int G) {
     return p;
 }
 
+static inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
+
+// grid of the backward apply pass when it also produces column sums: thread count a multiple
+// of the channel-vector count so that every thread keeps one column
+static inline int bn_sum_blocks(long R, int C, int vec) {
+    const int CV = C / vec;
+    const int unit = CV / gcd_i(CV, 256);              // blocks must be a multiple of this
+    long want = (R * CV + 255) / 256;
+    if (want > 1024) want = 1024;
+    long b = (want + unit - 1) / unit * unit;
+    return (int)(b < unit ? unit : b);
+}
+
 extern "C" size_t d2p_bn_ws_bytes(int R, int C, int G) {
     if (R <= 0 || C <= 0 || G <= 0) return 0;
     BnPlan p = bn_plan(R, C, G);
-    return (size_t)G * p.S * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(double) +
-           (size_t)G * C * 2 * sizeof(float);
+    const int vec = (C % 4 == 0) ? 4 : 1;
+    const size_t stats = (size_t)G * p.S * C * 2 * sizeof(double) + (size_t)G * C * 2 * sizeof(double) +
+                         align_up((size_t)G * C * 2 * sizeof(float), 16);
+    return stats + (size_t)bn_sum_blocks(R, C, vec) * C * sizeof(float);
 }
 
 // partial[((g*S + s)*C + c)*2 + {0,1}] = sum over this block's rows of (a, b) where
@@ -216,23 +231,85 @@ bn_apply_fwd_vec4_kernel(long R, int C, int G, int inner, const float* x, const 
     }
 }
 
+// dx = gamma * rstd * (dy - m1 - xhat * m2) [* lrelu'(x)].  VEC consecutive channels per thread;
+// no division in the loop (row / channel-vector advance incrementally).  With SUM the grid is
+// sized so that a thread keeps ONE channel vector for the whole grid-stride loop and leaves the
+// column sum of its dx values in colpart[thread][VEC] -- that is the bias gradient of the layer
+// under the BN (conv / fc bias sits before lrelu + BN), which otherwise costs one more full
+// read of dx by a separate column-sum pass.
+template <int VEC, bool SUM>
 __global__ void __launch_bounds__(256)
-bn_apply_bwd_kernel(long R, int C, int G, int inner, const float* x, const float* dy,
-                    const float* gamma, const float* mean, const float* rstd, const float* m12,
-                    int act_bwd, float* dx) {
-    const long total = R * C;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-        const long r = idx / C;
-        const int c = (int)(idx - r * C);
-        const int g = (int)((r / inner) % G);
-        const float xv = x[idx];
-        const float rs = rstd[g * C + c];
-        const float xhat = (xv - mean[g * C + c]) * rs;
-        const float m1 = m12[((long)g * C + c) * 2], m2 = m12[((long)g * C + c) * 2 + 1];
-        float d = gamma[c] * rs * (dy[idx] - m1 - xhat * m2);
-        if (act_bwd) d *= d2p_lrelu_grad_from_out(xv);
-        dx[idx] = d;
+bn_apply_bwd_kernel(int R, int C, int G, int inner, const float* __restrict__ x,
+                    const float* __restrict__ dy, const float* __restrict__ gamma,
+                    const float* __restrict__ mean, const float* __restrict__ rstd,
+                    const float* __restrict__ m12, int act_bwd, float* __restrict__ dx,
+                    float* __restrict__ colpart) {
+    const int CV = C / VEC;
+    const long tid = blockIdx.x * 256L + threadIdx.x;
+    const long stride = gridDim.x * 256L;
+    const int dr = (int)(stride / CV), dc = (int)(stride % CV);   // dc == 0 when SUM
+    int r = (int)(tid / CV), cv = (int)(tid % CV);
+    float s[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) s[j] = 0.f;
+    float gm[VEC];
+    if (SUM) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) gm[j] = gamma[cv * VEC + j];
     }
+    while (r < R) {
+        const int g = (r / inner) % G;
+        const long e = (long)r * C + cv * VEC;
+        float xv[VEC], dv[VEC], o[VEC];
+        if (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(x + e), d = *reinterpret_cast<const float4*>(dy + e);
+            xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+            dv[0] = d.x; dv[1] = d.y; dv[2] = d.z; dv[3] = d.w;
+        } else {
+            xv[0] = x[e]; dv[0] = dy[e];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = cv * VEC + j;
+            const float rs = rstd[g * C + c];
+            const float xhat = (xv[j] - mean[g * C + c]) * rs;
+            const float m1 = m12[((long)g * C + c) * 2], m2 = m12[((long)g * C + c) * 2 + 1];
+            float d = (SUM ? gm[j] : gamma[c]) * rs * (dv[j] - m1 - xhat * m2);
+            if (act_bwd) d *= d2p_lrelu_grad_from_out(xv[j]);
+            o[j] = d;
+            s[j] += d;
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(dx + e) = make_float4(o[0], o[1], o[2], o[3]);
+        else dx[e] = o[0];
+        r += dr; cv += dc;
+        if (cv >= CV) { cv -= CV; ++r; }
+    }
+    if (SUM) {
+        // block-level column sums in thread order, then one row of C floats per block
+        __shared__ float red[256][VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) red[threadIdx.x][j] = s[j];
+        __syncthreads();
+        const int base = (int)((blockIdx.x * 256L) % CV);
+        for (int c = threadIdx.x; c < C; c += 256) {
+            const int cvv = c / VEC, j = c % VEC;
+            float t = 0.f;
+            for (int tt = (cvv - base + CV) % CV; tt < 256; tt += CV) t += red[tt][j];
+            colpart[(long)blockIdx.x * C + c] = t;
+        }
+    }
+}
+
+// out[c] = sum over blocks of colpart[block][c] (fixed order: deterministic)
+__global__ void __launch_bounds__(256)
+bn_colsum_finalize_kernel(int C, int nblocks, const float* __restrict__ colpart, float* __restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int b = lane; b < nblocks; b += 64) acc += (double)colpart[(long)b * C + c];
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) out[c] = (float)acc;
 }
 
 static int bn_check(int R, int C, int G, int inner) {
@@ -291,8 +368,8 @@ extern "C" int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, 
 
 extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float* dy,
                                 const float* gamma, const float* mean, const float* rstd,
-                                int act_bwd, float* dx, float* dgamma, float* dbeta, void* ws,
-                                size_t ws_bytes, d2p_stream_t stream) {
+                                int act_bwd, float* dx, float* dgamma, float* dbeta, float* dx_colsum,
+                                void* ws, size_t ws_bytes, d2p_stream_t stream) {
     int rc = bn_check(R, C, G, inner);
     if (rc) return rc;
     if (R == 0) return D2P_OK;
@@ -319,9 +396,30 @@ extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, 
     hipLaunchKernelGGL(bn_dparam_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, G, gsum, dgamma,
                        dbeta);
     D2P_LAUNCH_CHECK("bn_dparam");
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_blocks((long)R * C)), dim3(256), 0, st, (long)R,
-                       C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx);
-    D2P_LAUNCH_CHECK("bn_apply_bwd");
+    const bool v4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
+    float* colpart = (float*)((char*)m12 + align_up((size_t)G * C * 2 * sizeof(float), 16));
+    if (dx_colsum) {
+        const int vec = v4 ? 4 : 1;
+        const int blocks = bn_sum_blocks(R, C, vec);
+        if (v4)
+            hipLaunchKernelGGL((bn_apply_bwd_kernel<4, true>), dim3(blocks), dim3(256), 0, st, R, C, G, inner, x, dy,
+                               gamma, mean, rstd, m12, act_bwd, dx, colpart);
+        else
+            hipLaunchKernelGGL((bn_apply_bwd_kernel<1, true>), dim3(blocks), dim3(256), 0, st, R, C, G, inner, x, dy,
+                               gamma, mean, rstd, m12, act_bwd, dx, colpart);
+        D2P_LAUNCH_CHECK("bn_apply_bwd");
+        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, C, blocks, colpart,
+                           dx_colsum);
+        D2P_LAUNCH_CHECK("bn_colsum_finalize");
+    } else {
+        if (v4)
+            hipLaunchKernelGGL((bn_apply_bwd_kernel<4, false>), dim3(ew_blocks((long)R * C / 4)), dim3(256), 0, st, R,
+                               C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr);
+        else
+            hipLaunchKernelGGL((bn_apply_bwd_kernel<1, false>), dim3(ew_blocks((long)R * C)), dim3(256), 0, st, R, C,
+                               G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr);
+        D2P_LAUNCH_CHECK("bn_apply_bwd");
+    }
     return D2P_OK;
 }
 

@@ -180,14 +180,16 @@ def bn_fwd(x2d, gamma, beta, G, inner, y=None, mean=None, rstd=None, var=None):
     return y, mean, rstd, var
 
 
-def bn_bwd(x2d, dy, gamma, mean, rstd, G, inner, act_bwd, dgamma, dbeta, dx=None):
+def bn_bwd(x2d, dy, gamma, mean, rstd, G, inner, act_bwd, dgamma, dbeta, dx=None, dbias=None):
+    """Training-mode BN backward (+ lrelu' of the layer underneath when act_bwd).  dbias, if
+    given, receives colsum(dx): the gradient of the bias added before the activation."""
     _require_gpu(x2d, dy)
     R, C = x2d.shape
     if dx is None:
         dx = torch.empty_like(x2d)
     ws, wsb = SCRATCH.get(call.d2p_bn_ws_bytes(R, C, G))
     call.d2p_bn_group_bwd(R, C, G, inner, ptr(x2d), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd),
-                          1 if act_bwd else 0, ptr(dx), ptr(dgamma), ptr(dbeta), ws, wsb,
+                          1 if act_bwd else 0, ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dbias), ws, wsb,
                           current_stream())
     return dx
 

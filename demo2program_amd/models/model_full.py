@@ -423,9 +423,9 @@ class Model(object):
             if n_d < T:
                 dx_q[n_d * M:].zero_()
             d_pe_a = K.bn_bwd(ctx['pe_a'], dx_q, p['per/fc/gamma'], ctx['pe_mean'], ctx['pe_rstd'], k, 1,
-                              False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)))
+                              False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)),
+                              dbias=g['per/fc/b'])
             K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
-            K.colsum(d_pe_a, out=g['per/fc/b'])
 
         # ---- SummarizeFeature('rn') backward (adds into d_demo_{h,c})
         self._rn_bwd(ctx['rn_h'], d_rn_h, d_demo_h, B, k, U)
@@ -450,8 +450,7 @@ class Model(object):
             x_in, a, mean, rstd = ctx['conv'][l - 1]
             da_ = K.bn_bwd(a.view(NF * ho * wo, cout), dy.view(NF * ho * wo, cout), p['conv%d/gamma' % l],
                            mean, rstd, k, T * ho * wo, True, g['conv%d/gamma' % l], g['conv%d/beta' % l],
-                           dx=self._buf('conv%d/da' % l, (NF * ho * wo, cout)))
-            K.colsum(da_, out=g['conv%d/b' % l])
+                           dx=self._buf('conv%d/da' % l, (NF * ho * wo, cout)), dbias=g['conv%d/b' % l])
             if x_in.shape[3] != cin:            # channel-padded conv1 input: unpad the gradient
                 cp = x_in.shape[3]
                 gpad = K.conv_wgrad(x_in, da_.view(NF, ho, wo, cout),
@@ -558,13 +557,13 @@ class Model(object):
         dy2 = self._buf(s + '/dy2', (B * k * k, U))
         K.pair_mean_bwd(d_out, dy2, B, k * k, U)
         dy2a = K.bn_bwd(r['y2a'], dy2, p[s + '/fc2/gamma'], r['m2'], r['r2'], 1, 1, True,
-                        g[s + '/fc2/gamma'], g[s + '/fc2/beta'], dx=self._buf(s + '/dy2a', (B * k * k, U)))
+                        g[s + '/fc2/gamma'], g[s + '/fc2/beta'], dx=self._buf(s + '/dy2a', (B * k * k, U)),
+                        dbias=g[s + '/fc2/b'])
         K.matmul_tn(r['y1'], dy2a, out=g[s + '/fc2/W'])
-        K.colsum(dy2a, out=g[s + '/fc2/b'])
         dy1 = K.matmul_nt(dy2a, W2, out=self._buf(s + '/dy1', (B * k * k, U)))
         dy1a = K.bn_bwd(r['y1a'], dy1, p[s + '/fc1/gamma'], r['m1'], r['r1'], 1, 1, True,
-                        g[s + '/fc1/gamma'], g[s + '/fc1/beta'], dx=self._buf(s + '/dy1a', (B * k * k, U)))
-        K.colsum(dy1a, out=g[s + '/fc1/b'])
+                        g[s + '/fc1/gamma'], g[s + '/fc1/beta'], dx=self._buf(s + '/dy1a', (B * k * k, U)),
+                        dbias=g[s + '/fc1/b'])
         dP, dQ = self._buf(s + '/dP', (B * k, U)), self._buf(s + '/dQ', (B * k, U))
         K.rn_pair_bwd(dy1a, dP, dQ, B, k, U)
         gW1 = g[s + '/fc1/W']

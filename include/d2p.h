@@ -115,14 +115,17 @@ int d2p_conv_direct_tune(int fwd_tiles_per_wave, int dgrad_tiles_per_wave, int w
  *   dgamma[c] = sum_all dy*xhat,  dbeta[c] = sum_all dy.
  * act_bwd = 1: x is the lrelu OUTPUT feeding BN (conv/fc -> lrelu -> BN order,
  * models/ops.py:14-24), and dx is additionally multiplied by lrelu'(pre-activation),
- * whose sign equals sign(x): 1 (x>0), 0.2 (x<0), 0.6 (x==0, TF's abs'(0)=0). */
+ * whose sign equals sign(x): 1 (x>0), 0.2 (x<0), 0.6 (x==0, TF's abs'(0)=0).
+ * dx_colsum (nullable, [C]): column sums of dx = the gradient of the bias that the layer under
+ * the BN adds before the activation (slim.conv2d / slim.fully_connected biases), produced by
+ * the same pass that writes dx. */
 size_t d2p_bn_ws_bytes(int R, int C, int G);
 int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, const float* gamma,
                      const float* beta, float* y, float* mean, float* rstd, float* var_out,
                      void* ws, size_t ws_bytes, d2p_stream_t stream);
 int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float* dy,
                      const float* gamma, const float* mean, const float* rstd, int act_bwd,
-                     float* dx, float* dgamma, float* dbeta,
+                     float* dx, float* dgamma, float* dbeta, float* dx_colsum,
                      void* ws, size_t ws_bytes, d2p_stream_t stream);
 /* moving <- decay*moving + (1-decay)*batch, applied G times in group order (the
  * reference updates once per Demo_Encoder call).  moving_mean/var: [C]. */

@@ -141,7 +141,8 @@ def test_conv_uint8_input(K):
 
 # ------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize('B,k,inner,C,act', [(3, 4, 20, 16, True), (2, 10, 8, 48, True),
-                                             (5, 1, 7, 512, True), (4, 3, 1, 512, False)])
+                                             (5, 1, 7, 512, True), (4, 3, 1, 512, False),
+                                             (3, 2, 5, 6, True), (64, 10, 32, 16, True)])
 def test_bn_group_fwd_bwd(K, B, k, inner, C, act):
     R = B * k * inner
     x = rnd(R, C, seed=1, scale=3.0)
@@ -168,6 +169,11 @@ def test_bn_group_fwd_bwd(K, B, k, inner, C, act):
     dbeta = torch.empty(C, device='cuda')
     dx = K.bn_bwd(a_dev, dev(dy), dev(gamma), mean, rstd, k, inner, act, dgamma, dbeta)
     close(dx, pre.grad, atol=1e-4)
+    # the same pass can also emit colsum(dx) = the gradient of a bias added before the activation
+    dbias = torch.empty(C, device='cuda')
+    dx2 = K.bn_bwd(a_dev, dev(dy), dev(gamma), mean, rstd, k, inner, act, dgamma, dbeta, dbias=dbias)
+    close(dx2, dx, atol=1e-6)
+    close(dbias, pre.grad.sum(0), atol=1e-3, rtol=1e-4)
     close(dgamma, gamma.grad, atol=1e-3, rtol=1e-4)
     close(dbeta, beta.grad, atol=1e-3, rtol=1e-4)
 
