@@ -41,7 +41,7 @@ PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
 
 PROF_FAMILIES = {
     1: ('gemm_mfma_kernel (dense fp32 MFMA GEMM)', 'mfma'),
-    2: ('gemm_mfma_kernel<Im2col> (conv implicit GEMM)', 'mfma'),
+    2: ('conv kernels (whole-frame / direct 16x16x4 MFMA, implicit-GEMM fallback)', 'mfma'),
     3: ('lstm_gate_fwd_kernel', 'hbm'),
     4: ('lstm_gate_bwd_kernel', 'hbm'),
     7: ('lstm_step_fwd_kernel (fused recurrent GEMM + gates)', 'mfma'),
@@ -109,6 +109,54 @@ def roofline_leg(trainer, feeds, steps=2):
                   rate=round(r['work'] / (r['total_ms'] / 1e3) / (1e12 if r['bound'] == 'mfma' else 1e9), 2),
                   unit='TFLOP/s' if r['bound'] == 'mfma' else 'GB/s') for r in rows]
     return roof, table
+
+
+def north_star_targets(config, table):
+    """The two kernel-level targets BASELINE.json's north_star names, measured live:
+    (1) the conv encoder's fraction of the fp32 MFMA peak (conv family of the instrumented pass:
+        forward + dgrad + wgrad of every layer, 2*M*K*N flops each);
+    (2) the LSTM gate kernel's fraction of the HBM roofline (14 336 B/row forward,
+        26 624 B/row backward at U=512), on the rows of one training step applied in one launch
+        (B*k*T rows) and, for reference, at the per-time-step granularity (B*k rows), where a
+        4.6 MB launch is latency-bound.  In the shipped path the gate math is the epilogue of
+        the fused recurrent step kernels; these standalone kernels are the d2p_lstm_gate_* ABI
+        entry points (and the unfused d2p_lstm_set_fused(0) path)."""
+    from demo2program_amd import kernels as K
+    out = {}
+    conv = [r for r in table if r['kernel'].startswith('conv kernels')]
+    if conv:
+        out['conv_encoder'] = {'achieved': conv[0]['rate'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(conv[0]['rate'] / PEAK_F32_MFMA_TFLOPS, 4),
+                               'ms_per_step': conv[0]['ms_per_step'],
+                               'launches_per_step': conv[0]['launches_per_step']}
+    U = config.num_lstm_cell_units
+    M = config.batch_size * config.k
+    gate = {}
+    for label, rows in (('rows_per_step_batched', M * config.max_demo_len), ('rows_per_time_step', M)):
+        z = torch.randn(rows, 4 * U, device='cuda')
+        c_prev = torch.randn(rows, U, device='cuda')
+        c_out, h_out = torch.empty(rows, U, device='cuda'), torch.empty(rows, U, device='cuda')
+        dh, dc = torch.randn(rows, U, device='cuda'), torch.randn(rows, U, device='cuda')
+        dz = torch.empty(rows, 4 * U, device='cuda')
+        res = {'rows': rows}
+        for name, fn, nbytes in (
+                ('fwd', lambda: K.lstm_gate_fwd(z, c_prev, None, None, 0, c_out, None, h_out), rows * 7 * U * 4.0),
+                ('bwd', lambda: K.lstm_gate_bwd(z, c_prev, c_out, dh, None, None, 0, dc, dz, None), rows * 13 * U * 4.0)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(50):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e-3 / 50
+            res[name] = {'us': round(t * 1e6, 2), 'achieved': round(nbytes / t / 1e9, 1), 'peak': PEAK_HBM_GBS,
+                         'unit': 'GB/s', 'frac': round(nbytes / t / 1e9 / PEAK_HBM_GBS, 4)}
+        gate[label] = res
+    out['lstm_gate_kernel'] = gate
+    return out
 
 
 def cpu_baseline_leg(config, batch, params, steps=2):
@@ -248,6 +296,8 @@ def main():
         roof, table = roofline_leg(trainer, feeds)
         out['roofline'] = roof
         out['kernel_table'] = table
+        if dp.rank == 0:
+            out['north_star_targets'] = north_star_targets(config, table)
     if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:
         from demo2program_amd.params import init_params
         log('cpu baseline leg (%d host cores)' % (os.cpu_count() or 1))
