@@ -51,6 +51,12 @@ class Model(object):
         self.h, self.w, self.depth = config.h, config.w, config.depth
         self.action_space = config.action_space
         self.per_dim = config.per_dim
+        # models/model_full.py:70-77: the DSL vocabulary behind intseq2str / the 'm)' end token
+        if self.dataset_type == 'karel':
+            from ..karel_env import get_KarelDSL
+            self.vocab = get_KarelDSL(dsl_type=getattr(config, 'dsl_type', 'prob'), seed=123)
+        else:
+            self.vocab = None           # ViZDoom vocabulary / engine: not built
 
         if self.scheduled_sampling:
             if global_step is None:
@@ -630,36 +636,134 @@ class Model(object):
         return dict(token_acc=token_acc, seq_acc=float(is_same_seq.mean()),
                     is_same_seq=is_same_seq, pred_tokens=logit_argmax)
 
-    def report(self, with_greedy=True):
-        """report_loss / report_accuracy entries of the reference that do not need the DSL
-        interpreter (models/model_full.py:1102-1132): losses, token / sequence accuracies of the
-        teacher-forced and greedy program and action decoders."""
+    def report(self, with_greedy=True, with_programs=None):
+        """report_loss / report_accuracy / report_hist of the reference
+        (models/model_full.py:1102-1132): losses, token / sequence accuracies of the
+        teacher-forced and greedy program and action decoders, and -- `with_programs`, default on
+        for Karel -- the DSL metrics: syntax accuracy, exact-program accuracy and the execution
+        histograms on the seen and the held-out demonstrations (host-side, as in the reference's
+        py_funcs).  Returns (loss, accuracy) dicts; the histograms and per-row results are kept
+        on the model (`report_hist`, `program_is_correct_syntax`, ...)."""
+        from . import program_metrics as PM
         c, f = self.config, self._feed
         B, k, T = c.batch_size, c.k, c.max_demo_len
+        if with_programs is None:
+            with_programs = self.dataset_type == 'karel'
+        if with_programs:
+            PM.require_env(self.dataset_type)
         gt_prog = f['program'].cpu().numpy()
         plen = f['program_len'].cpu().numpy()
         dlen = f['demo_len'].cpu().numpy().reshape(B, k)
         gt_act = f['a_h'].view(B, k, T, self.action_space).permute(0, 1, 3, 2).cpu().numpy()
         t = self._terms.cpu().numpy()
         loss = {'program_loss': float(t[0]), 'avg_action_loss': float(t[1]), 'avg_per_loss': float(t[2])}
-        acc = {}
+        acc, hist, rows = {}, {}, {}
+        gt_tokens = gt_prog.argmax(axis=1)
+
+        if with_programs:
+            vocab = self.vocab
+            make_error = getattr(c, 'env_type', None) != 'no_error'
+            s_h = f['s_h'].view(B, k, T, c.h, c.w, c.depth).float().cpu().numpy()
+            host = f.get('host', {})
+            test = None
+            if 'test_s_h' in host and 'test_demo_len' in host:
+                ts = host['test_s_h']
+                ts = ts.cpu().numpy() if torch.is_tensor(ts) else np.asarray(ts)
+                tl = host['test_demo_len']
+                tl = tl.cpu().numpy() if torch.is_tensor(tl) else np.asarray(tl)
+                test = (ts.astype(np.float32), tl.astype(np.int32).reshape(B, -1))
+
+        def program_block(prefix, st, p_len):
+            """syntax / exact / execution metrics of one decoded program set"""
+            syn = PM.check_correct_syntax(vocab, st['pred_tokens'], p_len, st['is_same_seq'])
+            exact = PM.exact_program_compare(vocab, st['pred_tokens'], p_len, syn, gt_tokens, plen)
+            rows[prefix + 'is_correct_syntax'] = syn
+            rows[prefix + 'exact_program_correct'] = exact
+            exe, exe_len = PM.generate_program_output(vocab, s_h[:, :, 0], T, st['pred_tokens'], p_len, syn,
+                                                      st['is_same_seq'], make_error)
+            num, ok, h_ = PM.compare_demo_and_execution(s_h, dlen, exe, exe_len, st['is_same_seq'])
+            rows[prefix + 'num_execution_correct'], rows[prefix + 'is_correct_execution'] = num, ok
+            out = {'syntax_acc': float(syn.mean()), 'exact_acc': float(exact.mean()), 'hist': h_}
+            if test is not None:
+                exe, exe_len = PM.generate_program_output(vocab, test[0][:, :, 0], T, st['pred_tokens'], p_len,
+                                                          syn, st['is_same_seq'], make_error)
+                num, ok, h_ = PM.compare_demo_and_execution(test[0], test[1], exe, exe_len, st['is_same_seq'])
+                rows['test_' + prefix + 'num_execution_correct'] = num
+                rows['test_' + prefix + 'is_correct_execution'] = ok
+                out['test_hist'] = h_
+            return out
+
         st = self.sequence_stats(self.pred_program.cpu().numpy(), gt_prog, plen, plen)
         acc['program_token_acc'], acc['program_seq_acc'] = st['token_acc'], st['seq_acc']
+        if with_programs:
+            r = program_block('program_', st, plen)
+            acc['program_syntax_acc'] = r['syntax_acc']
+            acc['pred_exact_program_accuracy'] = r['exact_acc']
+            hist['program_execution_acc_hist'] = r['hist']
+            if 'test_hist' in r:
+                hist['test_program_execution_acc_hist'] = r['test_hist']
         pa = self.pred_action.permute(0, 1, 3, 2).cpu().numpy()
         sts = [self.sequence_stats(pa[:, i], gt_act[:, i], dlen[:, i], dlen[:, i]) for i in range(k)]
-        acc['avg_action_token_acc'] = float(np.mean([s['token_acc'] for s in sts]))
-        acc['avg_action_seq_acc'] = float(np.mean([s['seq_acc'] for s in sts]))
+        acc['avg_action_token_acc'] = float(np.mean([s_['token_acc'] for s_ in sts]))
+        acc['avg_action_seq_acc'] = float(np.mean([s_['seq_acc'] for s_ in sts]))
         if with_greedy:
             g = self.greedy_decode()
-            st = self.sequence_stats(g['greedy_pred_program'].cpu().numpy(), gt_prog,
-                                     g['greedy_pred_program_len'].cpu().numpy(), plen)
+            glen = g['greedy_pred_program_len'].cpu().numpy().reshape(-1)
+            st = self.sequence_stats(g['greedy_pred_program'].cpu().numpy(), gt_prog, glen, plen)
             acc['greedy_program_token_acc'], acc['greedy_program_seq_acc'] = st['token_acc'], st['seq_acc']
+            if with_programs:
+                r = program_block('greedy_', st, glen)
+                acc['greedy_program_syntax_acc'] = r['syntax_acc']
+                acc['greedy_exact_program_accuracy'] = r['exact_acc']
+                hist['greedy_program_execution_acc_hist'] = r['hist']
+                if 'test_hist' in r:
+                    hist['test_greedy_program_execution_acc_hist'] = r['test_hist']
             ga = g['greedy_pred_action'].permute(0, 1, 3, 2).cpu().numpy()
             gl = g['greedy_pred_action_len'].cpu().numpy()
             sts = [self.sequence_stats(ga[:, i], gt_act[:, i], gl[:, i], dlen[:, i]) for i in range(k)]
-            acc['greedy_avg_action_token_acc'] = float(np.mean([s['token_acc'] for s in sts]))
-            acc['greedy_avg_action_seq_acc'] = float(np.mean([s['seq_acc'] for s in sts]))
+            acc['greedy_avg_action_token_acc'] = float(np.mean([s_['token_acc'] for s_ in sts]))
+            acc['greedy_avg_action_seq_acc'] = float(np.mean([s_['seq_acc'] for s_ in sts]))
+        self.report_accuracy, self.report_hist, self._program_rows = acc, hist, rows
         return loss, acc
+
+    # per-row results of the last report(), under the attribute names evaler.py:264-278 reads
+    def _row(self, name):
+        rows = getattr(self, '_program_rows', None)
+        if not rows or name not in rows:
+            raise AttributeError('%s: call Model.report(with_programs=True) first' % name)
+        return rows[name]
+
+    @property
+    def program_is_correct_syntax(self):
+        return self._row('program_is_correct_syntax')
+
+    @property
+    def greedy_program_is_correct_syntax(self):
+        return self._row('greedy_is_correct_syntax')
+
+    @property
+    def program_num_execution_correct(self):
+        return self._row('program_num_execution_correct')
+
+    @property
+    def program_is_correct_execution(self):
+        return self._row('program_is_correct_execution')
+
+    @property
+    def greedy_num_execution_correct(self):
+        return self._row('greedy_num_execution_correct')
+
+    @property
+    def greedy_is_correct_execution(self):
+        return self._row('greedy_is_correct_execution')
+
+    @property
+    def test_greedy_num_execution_correct(self):
+        return self._row('test_greedy_num_execution_correct')
+
+    @property
+    def test_greedy_is_correct_execution(self):
+        return self._row('test_greedy_is_correct_execution')
 
     @property
     def greedy_pred_program(self):

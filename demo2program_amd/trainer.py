@@ -189,9 +189,8 @@ class Trainer(object):
         loss = self.model.forward(feed)
         self.model.track_moving = track
         loss_value = float(loss.item())
-        # the 'test' summaries of the reference: greedy decoders + accuracies
-        # (models/model_full.py:1154-1177); the syntax / execution metrics need the DSL
-        # interpreter and are not built
+        # the 'test' summaries of the reference: greedy decoders + accuracies, and for Karel the
+        # syntax / exact-program / execution metrics (models/model_full.py:1102-1177)
         self.last_test_report = self.model.report(with_greedy=True)
         _end_time = time.time()
         return self.global_step, self.last_test_report, loss_value, None, (_end_time - _start_time)

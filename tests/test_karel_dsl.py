@@ -104,3 +104,45 @@ def test_world_error_modes():
     assert w.s[0, 0, 5 + 9] and w.marker_present()
     with pytest.raises(RuntimeError):
         w.state_transition(4)                           # a tenth marker
+
+
+def test_state_generator_reproduces_reference_worlds():
+    """KarelStateGenerator(seed=11): same RNG call order as karel_env/state_generator.py, so the
+    first eight states equal the ones the reference generated for the fixture."""
+    from demo2program_amd.karel_env.generator import KarelStateGenerator
+    g = KarelStateGenerator(seed=11)
+    mine = [g.generate_single_state(8, 8, 0.1)[0] for _ in range(6)]
+    mine += [g.generate_single_state(8, 8, 0.35)[0] for _ in range(2)]
+    for a, b in zip(mine, WORLDS):
+        assert np.array_equal(a, b)
+
+
+def test_sample_batch_layout():
+    """dataset_karel.py:38-115 layout: one-hot program, zero padding past the lengths, <e> closing
+    every action sequence, frames = the program's own execution."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.karel_env.generator import random_program, sample_batch
+    rng = np.random.RandomState(3)
+    for _ in range(100):
+        p = parse(random_program(rng))
+        assert p.ok and p.symbol == 'prog'
+    cfg = make_config('karel_tiny')
+    b = sample_batch(cfg, seed=9)
+    B, k, T, A = cfg.batch_size, cfg.k, cfg.max_demo_len, cfg.action_space
+    v = KarelVocab()
+    for i in range(B):
+        n = int(b['program_len'][i, 0])
+        assert v.intseq2str(b['program_tokens'][i, :n]) == str(b['codes'][i])
+        assert b['program'][i].sum() == n and not b['program'][i, :, n:].any()
+        assert (b['program'][i].argmax(0)[:n] == b['program_tokens'][i, :n]).all()
+        for pre, nd in (('', k), ('test_', cfg.test_k)):
+            for d in range(nd):
+                m = int(b[pre + 'demo_len'][i, d])
+                assert 2 <= m <= T
+                assert b[pre + 'a_h_tokens'][i, d, m - 1] == A - 1 and not b[pre + 'a_h_tokens'][i, d, m:].any()
+                assert b[pre + 'a_h'][i, d].sum() == m and not b[pre + 's_h'][i, d, m:].any()
+                w = Karel_world(b[pre + 's_h'][i, d, 0], make_error=True)
+                _, _, ok = parse(str(b['codes'][i])).run(w)
+                assert ok and len(w.s_h) == m
+                assert np.array_equal(np.stack(w.s_h), b[pre + 's_h'][i, d, :m].astype(bool))
+                assert np.array_equal(np.stack(w.p_v_h), b[pre + 'per'][i, d, :m].astype(bool))

@@ -153,6 +153,43 @@ def test_greedy_decode_matches_oracle():
         assert abs(acc['program_token_acc'] - float(st['token_acc'])) < 1e-6
 
 
+def test_report_program_metrics_on_real_programs():
+    """Model.report on a batch of real Karel programs with executed demonstrations: the DSL
+    metrics of models/model_full.py:1102-1132 are present, consistent with the host functions
+    applied to the model's own argmax tokens, and a model that predicts the ground truth gets
+    full syntax / exact / execution accuracy."""
+    from demo2program_amd.karel_env.generator import sample_batch
+    from demo2program_amd.models import program_metrics as PM
+    from demo2program_amd.models.model_full import Model
+    cfg, params, _ = small_case('karel', seed=5)
+    batch = sample_batch(cfg, seed=21)
+    m = Model(cfg, params=params)
+    m.forward(m.get_feed_dict(batch))
+    loss, acc = m.report(with_greedy=True)
+    for key in ('program_syntax_acc', 'pred_exact_program_accuracy', 'greedy_program_syntax_acc',
+                'greedy_exact_program_accuracy', 'program_token_acc', 'greedy_avg_action_seq_acc'):
+        assert 0.0 <= acc[key] <= 1.0, key
+    for key in ('program_execution_acc_hist', 'greedy_program_execution_acc_hist',
+                'test_program_execution_acc_hist', 'test_greedy_program_execution_acc_hist'):
+        h = m.report_hist[key]
+        assert h.shape == ((cfg.test_k if key.startswith('test_') else cfg.k) + 1,) and abs(h.sum() - 1) < 1e-6
+    B = cfg.batch_size
+    plen = batch['program_len'].reshape(-1).astype(np.int64)
+    st = Model.sequence_stats(m.pred_program.cpu().numpy(), batch['program'], plen, plen)
+    syn = PM.check_correct_syntax(m.vocab, st['pred_tokens'], plen, st['is_same_seq'])
+    assert np.array_equal(syn, m.program_is_correct_syntax) and abs(acc['program_syntax_acc'] - syn.mean()) < 1e-7
+    assert m.program_is_correct_execution.shape == (B, cfg.k)
+    assert m.test_greedy_is_correct_execution.shape == (B, cfg.test_k)
+    # a "perfect" decoder: the teacher-forced logits replaced by the one-hot ground truth
+    onehot = torch.from_numpy(batch['program']).cuda().permute(2, 0, 1).contiguous() * 10.0
+    m._ctx['dp']['logits'].copy_(onehot)
+    _, acc2 = m.report(with_greedy=False)
+    assert acc2['program_seq_acc'] == 1.0 and acc2['program_syntax_acc'] == 1.0
+    assert acc2['pred_exact_program_accuracy'] == 1.0
+    assert m.report_hist['program_execution_acc_hist'][cfg.k] == 1.0
+    assert m.report_hist['test_program_execution_acc_hist'][cfg.test_k] == 1.0
+
+
 def test_greedy_decode_length_and_padding_invariants():
     """Size-independent properties of dynamic_decode + GreedyEmbeddingHelper on the GPU outputs
     alone: length = 1 + first position of the end token (L if absent); logits / ids past the
