@@ -18,16 +18,25 @@ def _require_gpu(*tensors):
 
 class Scratch(object):
     """One growing device scratch buffer.  Every kernel is launched on the same stream, so
-    successive ops may reuse it (stream order serialises their accesses)."""
+    successive ops may reuse it (stream order serialises their accesses).
+
+    A buffer that has been outgrown is RETIRED, not freed: a captured hipGraph keeps replaying
+    with the workspace pointers it recorded, so that memory must stay allocated (and must not be
+    handed to another tensor) for as long as the process lives.  Growth is geometric, so the
+    retired buffers add up to less than the live one."""
 
     def __init__(self):
         self.buf = None
+        self.retired = []
 
     def get(self, nbytes):
         nbytes = int(nbytes)
         if nbytes == 0:
             return None, 0
         if self.buf is None or self.buf.numel() < nbytes:
+            if self.buf is not None:
+                self.retired.append(self.buf)
+                nbytes = max(nbytes, 2 * self.buf.numel())
             self.buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device='cuda')
         return self.buf.data_ptr(), self.buf.numel()
 

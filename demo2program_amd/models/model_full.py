@@ -115,7 +115,10 @@ class Model(object):
         need = [call.d2p_lstm_ws_bytes(M, U), call.d2p_xent_ws_bytes(k),
                 call.d2p_l2norm_ws_bytes(self.params.size),
                 call.d2p_bn_ws_bytes(B * k * k, U, 1), call.d2p_bn_ws_bytes(T * M, U, k),
-                call.d2p_colsum_ws_bytes(T * M, 4 * U)]
+                call.d2p_colsum_ws_bytes(T * M, 4 * U),
+                call.d2p_greedy_ws_bytes(M, U, max(c.dim_program_token, c.action_space)),
+                call.d2p_gemm_ws_bytes(U, 4 * U, T * M), call.d2p_gemm_ws_bytes(2 * U, 4 * U, T * M),
+                call.d2p_embedding_scatter_ws_bytes(T * M, c.dim_program_token + 1, U)]
         for (h, w, cin, cout, ho, wo) in self._conv:
             need.append(call.d2p_conv_ws_bytes(M * T, h, w, cin, cout))
             need.append(call.d2p_bn_ws_bytes(M * T * ho * wo, cout, k))

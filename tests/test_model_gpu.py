@@ -301,6 +301,42 @@ def test_trainer_steps_match_oracle_adam():
     assert tr.global_step == 3
 
 
+def test_graph_replay_survives_scratch_growth_and_new_shapes():
+    """Regression: a captured hipGraph keeps the workspace pointers it recorded.  Growing the
+    scratch buffer (a later batch with longer sequences, or greedy decoding between steps) used
+    to free that memory under the graph -> memory access fault on replay.  Outgrown buffers are
+    now retired, not freed; replayed steps must equal eager steps on interleaved batch shapes."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.karel_env.generator import sample_batch
+    from demo2program_amd.trainer import Trainer
+    s = K.Scratch()
+    p1, n1 = s.get(1 << 20)
+    p2, n2 = s.get((1 << 20) + 1)
+    assert s.retired and s.retired[0].data_ptr() == p1 and n2 >= 2 * n1 and p2 != p1
+    cfg, params, _ = small_case('karel', seed=3)
+    batches = [sample_batch(cfg, seed=40 + i) for i in range(3)]
+
+    def run(use_graph):
+        tr = Trainer(cfg, make_train_dir=False, use_graph=use_graph)
+        tr.model.params.load(params)
+        feeds = [tr.model.get_feed_dict(b) for b in batches]
+        assert len({(f['n_prog'], f['n_demo']) for f in feeds}) > 1     # several graph keys
+        losses = []
+        for i in (0, 1, 2, 0, 1, 2, 0):
+            losses.append(float(tr.train_step(feeds[i]).item()))
+            if use_graph and i == 1:
+                tr.model.report(with_greedy=True)                       # eager work between replays
+                K.SCRATCH.reserve(4 * K.SCRATCH._cur().buf.numel())     # force a growth
+                junk = torch.full((K.SCRATCH._cur().retired[-1].numel() // 4,), 7.0, device='cuda')
+                del junk
+        return losses
+
+    eager, graphed = run(False), run(True)
+    for a, b in zip(eager, graphed):
+        assert abs(a - b) <= 1e-4 * abs(a), (eager, graphed)
+    assert graphed[-1] < graphed[0]
+
+
 def test_bn_moving_statistics_follow_reference_updates():
     cfg, params, batch = small_case('karel', seed=9)
     from demo2program_amd.models.model_full import Model
