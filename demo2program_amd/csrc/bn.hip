@@ -446,3 +446,48 @@ extern "C" int d2p_bn_update_moving(int C, int G, float decay, const float* mean
     D2P_LAUNCH_CHECK("bn_update_moving");
     return D2P_OK;
 }
+
+// ---- inference mode (is_training=False: evaler.py:61 builds Model(config, is_train=False)) ----
+// y = (x - moving_mean) * rsqrt(moving_var + eps) * gamma + beta, per channel.
+template <int VEC>
+__global__ void __launch_bounds__(256)
+bn_inference_kernel(long total_v, int C, const float* __restrict__ x, const float* __restrict__ gamma,
+                    const float* __restrict__ beta, const float* __restrict__ mm, const float* __restrict__ mv,
+                    float eps, float* __restrict__ y) {
+    const int CV = C / VEC;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total_v; i += (long)gridDim.x * 256L) {
+        const int c0 = (int)(i % CV) * VEC;
+        float xv[VEC], o[VEC];
+        if (VEC == 4) {
+            const float4 a = *reinterpret_cast<const float4*>(x + i * 4);
+            xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+        } else {
+            xv[0] = x[i];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = c0 + j;
+            o[j] = (xv[j] - mm[c]) * rsqrtf(mv[c] + eps) * gamma[c] + beta[c];
+        }
+        if (VEC == 4) *reinterpret_cast<float4*>(y + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        else y[i] = o[0];
+    }
+}
+
+extern "C" int d2p_bn_inference_fwd(int R, int C, const float* x, const float* gamma, const float* beta,
+                                    const float* moving_mean, const float* moving_var, float* y,
+                                    d2p_stream_t stream) {
+    D2P_REQUIRE(R >= 0 && C > 0, D2P_EINVAL, "bn inference: bad sizes R=%d C=%d", R, C);
+    if (R == 0) return D2P_OK;
+    D2P_REQUIRE(x && gamma && beta && moving_mean && moving_var && y, D2P_EINVAL, "bn inference: null pointer");
+    hipStream_t st = as_stream(stream);
+    const bool v4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y) & 15) == 0);
+    if (v4)
+        hipLaunchKernelGGL((bn_inference_kernel<4>), dim3(ew_blocks((long)R * C / 4)), dim3(256), 0, st,
+                           (long)R * C / 4, C, x, gamma, beta, moving_mean, moving_var, 1e-3f, y);
+    else
+        hipLaunchKernelGGL((bn_inference_kernel<1>), dim3(ew_blocks((long)R * C)), dim3(256), 0, st, (long)R * C, C,
+                           x, gamma, beta, moving_mean, moving_var, 1e-3f, y);
+    D2P_LAUNCH_CHECK("bn_inference");
+    return D2P_OK;
+}

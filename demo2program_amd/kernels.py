@@ -203,6 +203,17 @@ def bn_bwd(x2d, dy, gamma, mean, rstd, G, inner, act_bwd, dgamma, dbeta, dx=None
     return dx
 
 
+def bn_inference(x2d, gamma, beta, moving_mean, moving_var, y=None):
+    """is_training=False batch norm: normalise [R, C] rows with the moving statistics."""
+    _require_gpu(x2d)
+    R, C = x2d.shape
+    if y is None:
+        y = torch.empty_like(x2d)
+    call.d2p_bn_inference_fwd(R, C, ptr(x2d), ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var),
+                              ptr(y), current_stream())
+    return y
+
+
 def bn_update_moving(mean, var, moving_mean, moving_var, decay=0.9):
     G, C = mean.shape
     call.d2p_bn_update_moving(C, G, decay, ptr(mean), ptr(var), ptr(moving_mean), ptr(moving_var),

@@ -68,8 +68,8 @@ class Model(object):
             # the reference reads cell_state.h/.c (models/model_full.py:258), which only an
             # LSTMStateTuple has: 'rnn' / 'gru' cannot work there either
             raise ValueError('Unknown encoder rnn type')
-        if not is_train:
-            raise NotImplementedError('is_train=False (moving-average BN, evaler.py:61) is not built yet')
+        # is_train=False (evaler.py:61): every batch norm normalises with its moving statistics;
+        # forward / greedy decoding / report only -- backward() refuses.
         if not torch.cuda.is_available():
             raise RuntimeError('demo2program_amd.Model needs an MI355X (torch.cuda unavailable); '
                                'there is no CPU fallback')
@@ -279,6 +279,10 @@ class Model(object):
     def _bn_fwd(self, name, x2d, gamma, beta, G, inner):
         R, C = x2d.shape
         y = self._buf(name + '/bn_y', (R, C))
+        if not self.is_train:
+            mm, mv = self.moving[name]
+            K.bn_inference(x2d, gamma, beta, mm, mv, y=y)
+            return y, None, None
         mean = self._buf(name + '/bn_mean', (G, C))
         rstd = self._buf(name + '/bn_rstd', (G, C))
         var = self._buf(name + '/bn_var', (G, C)) if self.track_moving else None
@@ -382,6 +386,8 @@ class Model(object):
     # ------------------------------------------------------------------ backward
     def backward(self, loss_scale=1.0):
         """Hand-written reverse schedule; writes every entry of params.grad exactly once."""
+        if not self.is_train:
+            raise RuntimeError('Model(is_train=False) is the evaluation graph: no backward pass')
         ctx, c, p, g = self._ctx, self.config, self.params.p, self.params.g
         feed = ctx['feed']
         B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len

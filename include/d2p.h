@@ -127,6 +127,11 @@ int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float
                      const float* gamma, const float* mean, const float* rstd, int act_bwd,
                      float* dx, float* dgamma, float* dbeta, float* dx_colsum,
                      void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* Inference mode (is_training=False, evaler.py:61): y = (x - moving_mean) * rsqrt(moving_var +
+ * 1e-3) * gamma + beta per channel.  x, y: [R, C]. */
+int d2p_bn_inference_fwd(int R, int C, const float* x, const float* gamma, const float* beta,
+                         const float* moving_mean, const float* moving_var, float* y,
+                         d2p_stream_t stream);
 /* moving <- decay*moving + (1-decay)*batch, applied G times in group order (the
  * reference updates once per Demo_Encoder call).  moving_mean/var: [C]. */
 int d2p_bn_update_moving(int C, int G, float decay, const float* mean, const float* var,

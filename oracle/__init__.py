@@ -22,6 +22,7 @@ from .model_full import (  # noqa: F401
     same_pad_s2k3,
     conv2d_lrelu_bn,
     batch_norm_train,
+    batch_norm_infer,
     basic_lstm_cell,
     dynamic_rnn,
     training_decoder,

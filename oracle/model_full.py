@@ -138,7 +138,21 @@ def batch_norm_train(x, beta, gamma):
     return y, mean, var
 
 
-def conv2d_lrelu_bn(x, W, b, beta, gamma):
+def batch_norm_infer(x, beta, gamma, moving_mean, moving_var):
+    """[TF-1.3] contrib.layers.batch_norm(is_training=False) (models/ops.py:20-23 with
+    is_train=False, as evaler.py:61 builds the model): normalise with the moving statistics."""
+    return (x - moving_mean) * torch.rsqrt(moving_var + BN_EPS) * gamma + beta
+
+
+def _bn(x, beta, gamma, moving=None):
+    """Training-mode BN, or inference BN when `moving` = (moving_mean, moving_var) is given."""
+    if moving is None:
+        return batch_norm_train(x, beta, gamma)
+    mm, mv = moving
+    return batch_norm_infer(x, beta, gamma, mm.to(x.dtype), mv.to(x.dtype)), mm, mv
+
+
+def conv2d_lrelu_bn(x, W, b, beta, gamma, moving=None):
     """models/ops.py:27-33 as called from State_Encoder (model_full.py:219-229):
     slim.conv2d 3x3 stride 2 SAME + bias -> lrelu(0.2) -> BN(train).
 
@@ -152,17 +166,17 @@ def conv2d_lrelu_bn(x, W, b, beta, gamma):
     y = F.conv2d(xn, wt, bias=b, stride=2)
     y = y.permute(0, 2, 3, 1)                        # back to NHWC
     a = lrelu(y)
-    out, mean, var = batch_norm_train(a, beta, gamma)
+    out, mean, var = _bn(a, beta, gamma, moving)
     return out, mean, var
 
 
-def fc_lrelu_bn(x, W, b, beta, gamma, act=True):
+def fc_lrelu_bn(x, W, b, beta, gamma, act=True, moving=None):
     """models/ops.py:149-155: slim.fully_connected (+bias) -> [lrelu] -> BN.
     Contracts the last axis; BN over all other axes."""
     y = x @ W + b
     if act:
         y = lrelu(y)
-    return batch_norm_train(y, beta, gamma)
+    return _bn(y, beta, gamma, moving)
 
 
 def basic_lstm_cell(x, c, h, kernel, bias, forget_bias=1.0):
@@ -255,24 +269,28 @@ def sequence_loss(pred, gt, gt_len, max_len, token_dim, sequence_type):
     return (ce * gt_mask.reshape(-1)).sum() / gt_mask.sum()
 
 
-def rn_pool(feat, p, scope):
+def rn_pool(feat, p, scope, moving=None):
     """model_full.py:333-349: relation network over ordered demo pairs.
     feat: [B, k, U]."""
     B, k, U = feat.shape
     tile1 = feat.unsqueeze(1).expand(B, k, k, U)     # tile1[b,a,c] = feat[b,c]
     tile2 = feat.unsqueeze(2).expand(B, k, k, U)     # tile2[b,a,c] = feat[b,a]
     x = torch.cat([tile1, tile2], dim=3).reshape(B * k * k, 2 * U)
+    mv = (lambda n: None) if moving is None else (lambda n: moving[scope + n])
     x, _, _ = fc_lrelu_bn(x, p[scope + '/fc1/W'], p[scope + '/fc1/b'],
-                          p[scope + '/fc1/beta'], p[scope + '/fc1/gamma'])
+                          p[scope + '/fc1/beta'], p[scope + '/fc1/gamma'], moving=mv('/fc1'))
     x, _, _ = fc_lrelu_bn(x, p[scope + '/fc2/W'], p[scope + '/fc2/b'],
-                          p[scope + '/fc2/beta'], p[scope + '/fc2/gamma'])
+                          p[scope + '/fc2/beta'], p[scope + '/fc2/gamma'], moving=mv('/fc2'))
     return x.reshape(B, k, k, U).mean(dim=1).mean(dim=1)
 
 
 # --------------------------------------------------------------------------- the graph
 
-def forward(p, batch, cfg):
+def forward(p, batch, cfg, moving=None):
     """models/model_full.py:208-600 (graph) + :918-932,1014-1038,1061-1079 (loss).
+    moving: None = training-mode BN (batch statistics per call); a dict name -> (moving_mean,
+    moving_var) for 'conv<l>', 'rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2', 'per/fc' = the
+    is_train=False graph of evaler.py:61.
 
     p: name -> tensor (see param_shapes).  batch: dict with the reference's
     batch_chunk keys (model_full.py:185-206) as torch tensors:
@@ -292,7 +310,8 @@ def forward(p, batch, cfg):
         x = s
         for l in range(1, cfg.n_conv + 1):
             x, m, v = conv2d_lrelu_bn(x, p['conv%d/W' % l], p['conv%d/b' % l],
-                                      p['conv%d/beta' % l], p['conv%d/gamma' % l])
+                                      p['conv%d/beta' % l], p['conv%d/gamma' % l],
+                                      moving=None if moving is None else moving['conv%d' % l])
             bn_stats.setdefault('conv%d' % l, []).append((m, v))
         return x.reshape(x.shape[0], -1)
 
@@ -319,8 +338,8 @@ def forward(p, batch, cfg):
         demo_c.append(c)
     stack_h = torch.stack(demo_h, dim=1)
     stack_c = torch.stack(demo_c, dim=1)
-    demo_h_summary = stack_h.mean(dim=1) + rn_pool(stack_h, p, 'rn_h')   # :399-404
-    demo_c_summary = stack_c.mean(dim=1) + rn_pool(stack_c, p, 'rn_c')
+    demo_h_summary = stack_h.mean(dim=1) + rn_pool(stack_h, p, 'rn_h', moving)   # :399-404
+    demo_c_summary = stack_c.mean(dim=1) + rn_pool(stack_c, p, 'rn_c', moving)
 
     def shift_tokens(tokens, token_dim):                     # model_full.py:447-450
         s_tok = torch.full((tokens.shape[0], 1), token_dim + 1, dtype=tokens.dtype)
@@ -351,7 +370,8 @@ def forward(p, batch, cfg):
     per = batch['per'].to(dt)
     for i in range(k):
         pin, m, v = fc_lrelu_bn(per[:, i], p['per/fc/W'], p['per/fc/b'],
-                                p['per/fc/beta'], p['per/fc/gamma'], act=False)
+                                p['per/fc/beta'], p['per/fc/gamma'], act=False,
+                                moving=None if moving is None else moving['per/fc'])
         bn_stats.setdefault('per/fc', []).append((m, v))
         pred_per.append(training_decoder(
             pin, demo_len[:, i], demo_c[i], demo_h[i],

@@ -178,6 +178,15 @@ def test_bn_group_fwd_bwd(K, B, k, inner, C, act):
     close(dbeta, beta.grad, atol=1e-3, rtol=1e-4)
 
 
+def test_bn_inference_mode(K):
+    """is_training=False: normalise with the moving statistics (evaler.py:61)."""
+    for R, C in ((37, 48), (20, 6), (640, 512)):
+        x, gamma, beta = rnd(R, C, seed=1, scale=2.0), rnd(C, seed=2) + 1.5, rnd(C, seed=3)
+        mm, mv = rnd(C, seed=4), rnd(C, seed=5).abs() + 0.1
+        ref = oracle.batch_norm_infer(x, beta, gamma, mm, mv)
+        close(K.bn_inference(dev(x), dev(gamma), dev(beta), dev(mm), dev(mv)), ref, atol=1e-5, rtol=1e-5)
+
+
 def test_bn_moving_average_k_updates(K):
     mean, var = rnd(5, 8, seed=1), rnd(5, 8, seed=2).abs()
     mm, mv = torch.zeros(8, dtype=torch.float64), torch.ones(8, dtype=torch.float64)
