@@ -545,7 +545,7 @@ extern "C" int d2p_conv_direct_tune(int fwd_tpw, int dgrad_tpw, int wgrad_wgs) {
     if (dgrad_tpw > 0) g_direct_dgrad_tpw = dgrad_tpw;
     if (wgrad_wgs > 0) g_direct_wgrad_wgs = wgrad_wgs;
     if (wgrad_wgs != 0) d2p_conv_frames_wgrad_cap(wgrad_wgs > 0 ? wgrad_wgs : 0);
-    if (fwd_tpw > 0) d2p_conv_frames_tune(fwd_tpw);
+    if (fwd_tpw != 0) d2p_conv_frames_tune(fwd_tpw > 0 ? fwd_tpw : 0);
     return D2P_OK;
 }
 

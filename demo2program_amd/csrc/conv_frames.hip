@@ -386,7 +386,7 @@ struct WgradLaunch {
 
 }   // namespace
 
-void d2p_conv_frames_tune(int tpw) { if (tpw > 0) g_frames_tpw = tpw; }
+void d2p_conv_frames_tune(int tpw) { g_frames_tpw = tpw > 0 ? tpw : 0; }
 void d2p_conv_frames_wgrad_cap(int cap) { g_frames_wgrad_cap = cap; }
 
 int d2p_conv_frames_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias,

@@ -144,8 +144,15 @@ class Model(object):
 
         s_h = batch_chunk['s_h']
         s_dtype = torch.uint8 if getattr(s_h, 'dtype', None) in (np.uint8, torch.uint8) else torch.float32
+        frames = dev(s_h, s_dtype).view(B * k * T, c.h, c.w, c.depth)
+        if c.depth % 4 != 0:
+            # device layout of the frames is NHWC with the channel count rounded up to 4 (zeros):
+            # part of staging the batch, like the H2D copy, not of the training step
+            cp = (c.depth + 3) // 4 * 4
+            frames = K.pad_axis(frames, B * k * T * c.h * c.w, c.depth, cp, 1,
+                                torch.empty(B * k * T, c.h, c.w, cp, dtype=s_dtype, device='cuda'))
         feed = {
-            's_h': dev(s_h, s_dtype).view(B * k * T, c.h, c.w, c.depth),
+            's_h': frames,
             'program': dev(batch_chunk['program'], torch.float32),
             'program_tokens': dev(batch_chunk['program_tokens'], torch.int32),
             'a_h': dev(batch_chunk['a_h'], torch.float32),
@@ -201,11 +208,13 @@ class Model(object):
         for l, (h, w, cin, cout, ho, wo) in enumerate(self._conv, start=1):
             Wl = p['conv%d/W' % l]
             if l == 1 and cin % 4 != 0:
-                # 3-channel (ViZDoom) frames: zero-pad frames and weights to 4 channels so every
-                # tap is one 16-byte (uint8x4: 4-byte) gather; the extra channel contributes 0
+                # 3-channel (ViZDoom) frames: frames (once per batch, in get_feed_dict) and
+                # weights are zero-padded to 4 channels so every tap is one 16-byte (uint8x4:
+                # 4-byte) access; the extra channel contributes 0
                 cp = (cin + 3) // 4 * 4
-                x = K.pad_axis(x, NF * h * w, cin, cp, 1,
-                               self._buf('conv1/xpad', (NF, h, w, cp), x.dtype))
+                if x.shape[3] != cp:
+                    x = K.pad_axis(x, NF * h * w, cin, cp, 1,
+                                   self._buf('conv1/xpad', (NF, h, w, cp), x.dtype))
                 Wl = K.pad_axis(Wl, 9, cin, cp, cout, self._buf('conv1/Wpad', (3, 3, cp, cout)))
             a = K.conv_fwd(x, Wl, p['conv%d/b' % l], act=1,
                            out=self._buf('conv%d/a' % l, (NF, ho, wo, cout)))

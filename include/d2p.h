@@ -100,6 +100,7 @@ int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int Cout,
  * kernels for the Karel geometries, gather kernels otherwise; 1: gather kernels only); 0 routes
  * that direction through the implicit-im2col GEMM instead.  Results agree to fp32 rounding. */
 int d2p_conv_set_direct(int fwd, int dgrad, int wgrad);
+/* > 0 sets a knob, 0 leaves it, < 0 (fwd, wgrad) returns it to the automatic per-layer choice */
 int d2p_conv_direct_tune(int fwd_tiles_per_wave, int dgrad_tiles_per_wave, int wgrad_workgroups);
 
 /* ---- K2: training-mode batch norm over row groups (+ fused lrelu backward) ---------

@@ -67,7 +67,7 @@ def main():
                 lib.d2p_conv_direct_tune(*kn)
                 t = min(timed(fn), timed(fn))
                 out.append('direct%s %.1fus %.1fTF %.0fGB/s' % (str(max(kn)), t * 1e6, fl / t / 1e12, by[name] / t / 1e9))
-            lib.d2p_conv_direct_tune(2, 2, 256)
+            lib.d2p_conv_direct_tune(-1, 2, -1)          # back to the automatic settings
             print('  %-5s ' % name + ' | '.join(out))
 
 
