@@ -150,3 +150,71 @@ extern "C" int d2p_greedy_decode(int M, int U, int V, int L, const float* table_
     D2P_LAUNCH_CHECK("greedy_zero_tail");
     return D2P_OK;
 }
+
+// ---- scheduled sampling (models/model_full.py:59-67,414-423; seq2seq.ScheduledEmbeddingTrainingHelper)
+// For each decoder row after step t:  with probability p_sample the next input is a draw from
+// Categorical(softmax(logits_t)), otherwise the ground-truth token of step t+1.  The draw is
+// Gumbel-max over counter-based Philox4x32-10 noise keyed by (seed, step counter, row, token):
+// no RNG state to carry, replays of a captured graph get fresh noise because the step counter
+// lives in device memory.  p_sample is read from device memory too (it follows
+// polynomial_decay(global_step) and must change between graph replays).
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+__device__ __forceinline__ float u01(uint32_t x) {      // (0, 1): never 0 or 1
+    return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);
+}
+
+// one wave per row; rng[0] = seed, rng[1] = step counter (both uint64 in device memory)
+__global__ void __launch_bounds__(256)
+sched_sample_kernel(int M, int V, const float* __restrict__ logits, const int* __restrict__ gt_next,
+                    const float* __restrict__ p_sample, const unsigned long long* __restrict__ rng, int t,
+                    int* __restrict__ next_ids, int* __restrict__ sampled_flag) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const unsigned long long seed = rng[0], ctr = rng[1];
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+    // Bernoulli draw: stream (ctr, t, row, 0xFFFFFFFF)
+    uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32) ^ ((uint32_t)t << 16), (uint32_t)r, 0xFFFFFFFFu};
+    philox4x32_10(c, k0, k1);
+    const bool take = u01(c[0]) < p_sample[0];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int v = lane; v < V; v += 64) {
+        uint32_t d[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32) ^ ((uint32_t)t << 16), (uint32_t)r, (uint32_t)v};
+        philox4x32_10(d, k0, k1);
+        const float g = -logf(-logf(u01(d[0])));
+        const float f = logits[(long)r * V + v] + g;
+        if (f > best || (f == best && v < bi)) { best = f; bi = v; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+        next_ids[r] = take ? bi : gt_next[r];
+        if (sampled_flag) sampled_flag[r] = take ? 1 : 0;
+    }
+}
+
+extern "C" int d2p_sched_sample(int M, int V, const float* logits, const int* gt_next, const float* p_sample_dev,
+                                const void* rng_dev, int t, int* next_ids, int* sampled_flag,
+                                d2p_stream_t stream) {
+    D2P_REQUIRE(M >= 0 && V > 0 && t >= 0 && t < 65536, D2P_EINVAL, "sched_sample: bad sizes");
+    if (M == 0) return D2P_OK;
+    D2P_REQUIRE(logits && gt_next && p_sample_dev && rng_dev && next_ids, D2P_EINVAL, "sched_sample: null pointer");
+    hipLaunchKernelGGL(sched_sample_kernel, dim3(ceil_div(M, 4)), dim3(256), 0, as_stream(stream), M, V, logits,
+                       gt_next, p_sample_dev, (const unsigned long long*)rng_dev, t, next_ids, sampled_flag);
+    D2P_LAUNCH_CHECK("sched_sample");
+    return D2P_OK;
+}

@@ -437,6 +437,15 @@ def pad_axis(x, outer, C, Cp, inner, out, unpad=False):
     return out
 
 
+def sched_sample(logits2d, gt_next, p_sample_dev, rng_dev, t, next_ids, sampled_flag=None):
+    """One scheduled-sampling decision per row: next_ids = Categorical(logits) with probability
+    p_sample_dev[0] else gt_next (seq2seq.ScheduledEmbeddingTrainingHelper)."""
+    M, V = logits2d.shape
+    call.d2p_sched_sample(M, V, ptr(logits2d), ptr(gt_next), ptr(p_sample_dev), ptr(rng_dev), int(t),
+                          ptr(next_ids), ptr(sampled_flag), current_stream())
+    return next_ids
+
+
 # ---------------------------------------------------------------- optimizer
 def l2norm_flat(g, prescale, sumsq):
     ws, wsb = SCRATCH.get(call.d2p_l2norm_ws_bytes(g.numel()))

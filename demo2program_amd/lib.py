@@ -57,6 +57,7 @@ SIGNATURES = {
     'd2p_embedding_scatter_add_oob0': (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, S]),
     'd2p_greedy_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'd2p_greedy_decode': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_int, P, P, P, P, c_size_t, S]),
+    'd2p_sched_sample': (c_int, [c_int, c_int, P, P, P, P, c_int, P, P, S]),
     'd2p_argmax_rows': (c_int, [c_int, c_int, P, c_long, P, S]),
     'd2p_xent_ws_bytes': (c_size_t, [c_int]),
     'd2p_softmax_xent_masked_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, P, P, c_size_t, S]),

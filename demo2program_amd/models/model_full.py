@@ -58,12 +58,8 @@ class Model(object):
         else:
             self.vocab = None           # ViZDoom vocabulary / engine: not built
 
-        if self.scheduled_sampling:
-            if global_step is None:
-                raise ValueError('scheduled sampling requires global_step')   # model_full.py:59-61
-            raise NotImplementedError(
-                'scheduled sampling (models/model_full.py:414-423) is not on the parity path '
-                '(categorical sampling; SURVEY F13) and is not built yet')
+        if self.scheduled_sampling and global_step is None:
+            raise ValueError('scheduled sampling requires global_step')       # model_full.py:59-61
         if self.encoder_rnn_type != 'lstm':
             # the reference reads cell_state.h/.c (models/model_full.py:258), which only an
             # LSTMStateTuple has: 'rnn' / 'gru' cannot work there either
@@ -88,6 +84,14 @@ class Model(object):
         for s in ('rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2', 'per/fc'):
             self._init_moving(s, U)
         self.track_moving = True
+        # scheduled sampling state (device memory: read by kernels inside a captured graph)
+        #   _ss_prob : probability of feeding the decoder its own sample instead of the ground truth
+        #              = 1 - polynomial_decay(1.0 -> 0.1 over decay_steps) (model_full.py:62-67,420-422)
+        #   _ss_rng  : {seed, step counter}; set_sampling_step() advances it once per training step
+        self._ss_prob = torch.zeros(1, device='cuda')
+        self._ss_rng = torch.tensor([seed * 2654435761 + 12345, 0], dtype=torch.int64, device='cuda')
+        if self.scheduled_sampling:
+            self.set_sampling_step(int(global_step) if not callable(global_step) else 0)
         self.fuse_decoders = False
         # independent GEMM-heavy work on a second stream (see forward/backward); set False (or
         # D2P_NO_SIDE_STREAM=1) to serialise everything on one stream, e.g. for per-kernel timing
@@ -251,7 +255,14 @@ class Model(object):
         specs = [('prog', emb_p, U, B, L, n_p, rn_h['out'], rn_c['out'], V, z_p),
                  ('act', emb_a, U, M, T, n_d, demo_h, demo_c, A, z_a),
                  ('per', pe, U, M, T, n_d, demo_h, demo_c, P, z_q)]
-        if self.fuse_decoders:
+        if self.scheduled_sampling and self.is_train:
+            # program and action decoders feed back their own samples (per uses TrainingHelper,
+            # model_full.py:409); the hoisted z_p / z_a of the side stream are simply not used
+            dp = self._decoder_fwd_sampled('prog', ids_p, B, L, n_p, rn_h['out'], rn_c['out'], V, 0)
+            da = self._decoder_fwd_sampled('act', ids_a, M, T, n_d, demo_h, demo_c, A, 4096)
+            dq = self._decoders_fwd([specs[2]])[0]
+            ids_p, ids_a = dp['fed_ids'], da['fed_ids']        # embedding gradient goes to what was fed
+        elif self.fuse_decoders:
             dp, da, dq = self._decoders_fwd(specs)
         else:
             dp, da, dq = [self._decoders_fwd([sp])[0] for sp in specs]
@@ -357,6 +368,62 @@ class Model(object):
                 logits[n_steps:].zero_()    # dynamic zero padding (:476-484); memset, no arithmetic
             e['logits'] = logits
         return es
+
+    def sample_prob_at(self, step):
+        """models/model_full.py:62-67: teacher-forcing probability, polynomial_decay(1.0 -> 0.1)
+        over scheduled_sampling_decay_steps, power 1, no cycling."""
+        d = float(self.scheduled_sampling_decay_steps)
+        s_ = min(float(step), d)
+        return (1.0 - 0.1) * (1.0 - s_ / d) + 0.1
+
+    def set_sampling_step(self, step):
+        """Host-side update of the sampling probability and the noise counter for this step
+        (two tiny device writes outside any captured graph)."""
+        self._ss_prob.fill_(1.0 - self.sample_prob_at(step))
+        self._ss_rng[1] = int(step)
+
+    def _decoder_fwd_sampled(self, scope, gt_ids_tm, R, T, n_steps, h0, c0, token_dim, salt):
+        """BasicDecoder + ScheduledEmbeddingTrainingHelper + Dense (models/model_full.py:414-423,
+        463-471).  The next input depends on this step's logits, so nothing can be hoisted: per
+        step  z_t = table[fed_t] + h_{t-1} Wh  (table = embedding·Wx + b for every token, one row
+        of b for the out-of-range <s>), gates, logits_t = h_t·proj, then one sampling decision
+        per row.  Saves exactly what the teacher-forced path saves (pre-activations z, hout, cs)
+        plus the ids actually fed, which the backward pass uses for the embedding gradient."""
+        p = self.params.p
+        U = self.num_lstm_cell_units
+        name = scope + '/lstm'
+        kernel, bias = p[name + '/kernel'], p[name + '/bias']
+        emb = p[scope + '/embedding']                                     # [token_dim + 1, U]
+        rows = emb.shape[0]
+        table = self._buf(scope + '/ss_table', (rows + 1, 4 * U))
+        K.matmul_nn(emb, kernel[:U], bias=bias, out=table[:rows])
+        table[rows].copy_(bias)                                           # <s>: zero embedding (F9)
+        z = self._buf(name + '/z', (T * R, 4 * U))
+        hout = self._buf(name + '/hout', (T, R, U))
+        cs = self._buf(name + '/cs', (T, R, U))
+        logits = self._buf(scope + '/logits', (T, R, token_dim), zero=True)
+        fed = self._buf(scope + '/fed_ids', (T, R), torch.int32)
+        flags = self._buf(scope + '/ss_flags', (T, R), torch.int32)
+        fed.copy_(gt_ids_tm)
+        flags.zero_()
+        Wh = kernel[U:]
+        h_prev, c_prev = h0, c0
+        for t in range(n_steps):
+            z_t = z[t * R:(t + 1) * R]
+            K.embedding_gather(fed[t], table, out=z_t, n=R)
+            K.gemm_raw('nn', R, 4 * U, U, h_prev, U, Wh, 4 * U, z_t, 4 * U, accumulate=True)
+            K.lstm_gate_fwd(z_t, c_prev, None, None, t, cs[t], None, hout[t])
+            K.gemm_raw('nn', R, token_dim, U, hout[t], U, p[scope + '/proj'], token_dim, logits[t], token_dim)
+            if t + 1 < n_steps:
+                K.sched_sample(logits[t], gt_ids_tm[t + 1], self._ss_prob, self._ss_rng, t + salt, fed[t + 1],
+                               flags[t + 1])
+            h_prev, c_prev = hout[t], cs[t]
+        if n_steps < T:
+            logits[n_steps:].zero_()
+        x2d = K.embedding_gather(fed, emb, out=self._buf(scope + '/ss_x', (T * R, U)), n=n_steps * R)
+        return dict(name=name, x=x2d, I=U, M=R, T=T, n=n_steps, h0=h0, c0=c0, lens=None, z=z, hout=hout, cs=cs,
+                    h_final=None, c_final=None, Wx=kernel[:U], Wh=Wh, token_dim=token_dim, scope=scope,
+                    logits=logits, fed_ids=fed, sampled=flags)
 
     def _decoder_fwd(self, scope, x2d, I, R, T, n_steps, h0, c0, token_dim, z=None):
         """BasicDecoder + TrainingHelper + Dense(no bias): models/model_full.py:440-490."""

@@ -110,6 +110,8 @@ class Trainer(object):
         graph launch.  The all-reduce, norm and Adam stay outside the graph (RCCL call; the
         Adam rate changes per step and is read from device memory)."""
         m = self.model
+        if m.scheduled_sampling:
+            m.set_sampling_step(self.global_step)     # sampling probability + noise counter of this step
         if self.use_graph and not self._profiling():
             loss = self._graphed_forward_backward(feed)
         else:

@@ -244,6 +244,15 @@ int d2p_greedy_decode(int M, int U, int V, int L, const float* table_proj, const
                       const float* proj, const float* h0, const float* c0, int start_id, int end_id,
                       float* logits, int* ids, int* lengths, void* ws, size_t ws_bytes,
                       d2p_stream_t stream);
+/* ---- scheduled sampling step (models/model_full.py:59-67,414-423) -----------------------
+ * seq2seq.ScheduledEmbeddingTrainingHelper.sample + next_inputs for one decoder step t:
+ * next_ids[r] = Categorical(softmax(logits[r,:])) draw with probability *p_sample_dev, else
+ * gt_next[r].  Noise: Gumbel-max over Philox4x32-10 keyed by rng_dev = {uint64 seed, uint64
+ * step counter} (device memory, so a captured graph draws fresh noise per replay), t, row and
+ * token.  sampled_flag (nullable): 1 where the draw was taken.  Parity with TF is statistical
+ * only (different generator). */
+int d2p_sched_sample(int M, int V, const float* logits, const int* gt_next, const float* p_sample_dev,
+                     const void* rng_dev, int t, int* next_ids, int* sampled_flag, d2p_stream_t stream);
 /* out[r] = argmax_v x[r*ld + v] (first index on ties, as tf.argmax) */
 int d2p_argmax_rows(int rows, int V, const float* x, long ld, int* out, d2p_stream_t stream);
 

@@ -286,11 +286,17 @@ def rn_pool(feat, p, scope, moving=None):
 
 # --------------------------------------------------------------------------- the graph
 
-def forward(p, batch, cfg, moving=None):
+def forward(p, batch, cfg, moving=None, fed_ids=None):
     """models/model_full.py:208-600 (graph) + :918-932,1014-1038,1061-1079 (loss).
     moving: None = training-mode BN (batch statistics per call); a dict name -> (moving_mean,
     moving_var) for 'conv<l>', 'rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2', 'per/fc' = the
     is_train=False graph of evaler.py:61.
+    fed_ids: None = teacher forcing (TrainingHelper).  {'prog': [B,L] ids, 'act': [B,k,T] ids} = the
+    decoder INPUT ids actually fed at each step under scheduled sampling
+    (ScheduledEmbeddingTrainingHelper, model_full.py:414-423): a mixture of ground-truth tokens
+    and draws from the decoder's own predictions.  The draws are random (and not differentiated
+    through), so for a parity check they are taken from the implementation under test and the
+    oracle reproduces everything that follows from them.
 
     p: name -> tensor (see param_shapes).  batch: dict with the reference's
     batch_chunk keys (model_full.py:185-206) as torch tensors:
@@ -348,6 +354,8 @@ def forward(p, batch, cfg, moving=None):
     # ---- Program decoder (model_full.py:497-511)
     V = cfg.dim_program_token
     ptoks = shift_tokens(batch['program_tokens'].to(torch.int64), V)
+    if fed_ids is not None:
+        ptoks = fed_ids['prog'].to(torch.int64)
     pemb = embedding_lookup_oob0(p['prog/embedding'], ptoks)
     pred_program = training_decoder(pemb, program_len, demo_c_summary, demo_h_summary,
                                     p['prog/lstm/kernel'], p['prog/lstm/bias'],
@@ -358,6 +366,8 @@ def forward(p, batch, cfg, moving=None):
     pred_action = []
     for i in range(k):
         atoks = shift_tokens(batch['a_h_tokens'][:, i].to(torch.int64), A)
+        if fed_ids is not None:
+            atoks = fed_ids['act'][:, i].to(torch.int64)
         aemb = embedding_lookup_oob0(p['act/embedding'], atoks)
         pred_action.append(training_decoder(
             aemb, demo_len[:, i], demo_c[i], demo_h[i],
@@ -399,11 +409,11 @@ def forward(p, batch, cfg, moving=None):
                 bn_stats=bn_stats)
 
 
-def loss_and_grads(params, batch, cfg, dtype=torch.float32):
+def loss_and_grads(params, batch, cfg, dtype=torch.float32, fed_ids=None):
     """Forward + torch autograd.  Returns (outputs dict (detached), grads dict)."""
     p = {n: torch.as_tensor(v).detach().clone().to(dtype).requires_grad_(True)
          for n, v in params.items()}
-    out = forward(p, batch, cfg)
+    out = forward(p, batch, cfg, fed_ids=fed_ids)
     out['loss'].backward()
     grads = {n: (t.grad.detach() if t.grad is not None else torch.zeros_like(t))
              for n, t in p.items()}

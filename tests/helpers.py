@@ -49,7 +49,7 @@ def small_case(kind='karel', seed=7, **over):
     return cfg, params, batch
 
 
-def run_oracle(cfg, params, batch, dtype=torch.float64):
+def run_oracle(cfg, params, batch, dtype=torch.float64, fed_ids=None):
     tb = to_torch(batch)
     tp = {n: torch.from_numpy(v) for n, v in params.items()}
-    return oracle.loss_and_grads(tp, tb, oracle_config(cfg), dtype=dtype)
+    return oracle.loss_and_grads(tp, tb, oracle_config(cfg), dtype=dtype, fed_ids=fed_ids)

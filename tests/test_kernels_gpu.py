@@ -139,6 +139,41 @@ def test_conv_uint8_input(K):
     close(dw, dwf, atol=1e-2, rtol=1e-5)
 
 
+# ------------------------------------------------------------------ scheduled sampling
+def test_sched_sample_statistics(K):
+    """d2p_sched_sample: p = 0 keeps the ground truth, p = 1 always draws, the draw frequencies
+    follow softmax(logits) (chi-square), the take rate follows p, and a new step counter gives
+    new noise while the same counter reproduces it (graph replays read it from device memory)."""
+    M, V = 20000, 6
+    logits = torch.tensor([0.5, -1.0, 2.0, 0.0, 1.0, -3.0]).repeat(M, 1).cuda()
+    gt = torch.full((M,), 4, dtype=torch.int32, device='cuda')
+    rng = torch.tensor([1234, 7], dtype=torch.int64, device='cuda')
+    out = torch.empty(M, dtype=torch.int32, device='cuda')
+    flag = torch.empty(M, dtype=torch.int32, device='cuda')
+
+    def draw(p, t=3):
+        K.sched_sample(logits, gt, torch.tensor([p], device='cuda'), rng, t, out, flag)
+        return out.cpu().numpy().copy(), flag.cpu().numpy().copy()
+
+    ids, fl = draw(0.0)
+    assert (ids == 4).all() and not fl.any()
+    ids, fl = draw(1.0)
+    assert fl.all()
+    prob = torch.softmax(logits[0].double().cpu(), 0).numpy()
+    cnt = np.bincount(ids, minlength=V)
+    chi2 = ((cnt - M * prob) ** 2 / (M * prob)).sum()
+    assert chi2 < 25.0, (chi2, cnt, M * prob)             # 5 dof: P(chi2 > 25) ~ 1e-4
+    ids2, _ = draw(1.0)
+    assert (ids2 == ids).all()                              # same (seed, counter, t): same noise
+    rng[1] = 8
+    ids3, _ = draw(1.0)
+    assert (ids3 != ids).mean() > 0.3
+    ids4, _ = draw(1.0, t=4)
+    assert (ids4 != ids3).mean() > 0.3
+    _, fl = draw(0.3)
+    assert abs(fl.mean() - 0.3) < 0.015
+
+
 # ------------------------------------------------------------------ batch norm
 @pytest.mark.parametrize('B,k,inner,C,act', [(3, 4, 20, 16, True), (2, 10, 8, 48, True),
                                              (5, 1, 7, 512, True), (4, 3, 1, 512, False),

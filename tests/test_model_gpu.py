@@ -387,6 +387,92 @@ def test_eval_mode_matches_oracle_and_evaler_runs(tmp_path):
     assert '[Final Avg Report]' in open(ev.summary_file).read()
 
 
+def test_scheduled_sampling_decoders():
+    """models/model_full.py:59-67,414-423.  (1) sampling probability 0 (global_step 0: teacher
+    forcing probability 1.0) reproduces the teacher-forced path exactly; (2) with sampling on, the
+    ids fed are ground truth where no draw was taken and a valid token elsewhere, <s> first;
+    (3) GIVEN those fed ids, loss, logits and every gradient equal the oracle's
+    (ScheduledEmbeddingTrainingHelper does not differentiate through the draw); (4) the decay
+    schedule is polynomial_decay(1.0 -> 0.1)."""
+    from demo2program_amd.models.model_full import Model
+    cfg, params, batch = small_case('karel', seed=13)
+    base = Model(cfg, params=params)
+    l0 = float(base.forward(base.get_feed_dict(batch)).item())
+    base.backward()
+    g0 = base.params.grad.clone()
+
+    cfg_ss = small_case('karel', seed=13)[0]
+    cfg_ss.scheduled_sampling = True
+    cfg_ss.scheduled_sampling_decay_steps = 1000
+    with pytest.raises(ValueError):
+        Model(cfg_ss, params=params)                              # needs global_step
+    m = Model(cfg_ss, params=params, global_step=0)
+    for step in (0, 250, 1000, 5000):
+        assert abs(m.sample_prob_at(step) - oracle.polynomial_decay(1.0, step, 1000, 0.1)) < 1e-12
+    l1 = float(m.forward(m.get_feed_dict(batch)).item())          # step 0: p(sample) = 0
+    m.backward()
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert (m.params.grad - g0).abs().max().item() <= 1e-5 * g0.abs().max().item()
+    assert int(m._ctx['dp']['sampled'].sum()) == 0
+
+    m.set_sampling_step(600)                                      # p(sample) = 0.54
+    feed = m.get_feed_dict(batch)
+    loss = float(m.forward(feed).item())
+    m.backward()
+    B, k, T, L = cfg.batch_size, cfg.k, cfg.max_demo_len, cfg.max_program_len
+    V, A = cfg.dim_program_token, cfg.action_space
+    n_p, n_d = feed['n_prog'], feed['n_demo']
+    fed_p = m._ctx['dp']['fed_ids'].cpu().numpy()                 # [L, B]
+    fl_p = m._ctx['dp']['sampled'].cpu().numpy()
+    fed_a = m._ctx['da']['fed_ids'].cpu().numpy()                 # [T, B*k]
+    fl_a = m._ctx['da']['sampled'].cpu().numpy()
+    gt_p = np.concatenate([np.full((1, B), V + 1), batch['program_tokens'].T[:-1]], 0)
+    gt_a = np.concatenate([np.full((1, B * k), A + 1), batch['a_h_tokens'].reshape(B * k, T).T[:-1]], 0)
+    assert (fed_p[0] == V + 1).all() and (fed_a[0] == A + 1).all()
+    assert (fed_p[fl_p == 0] == gt_p[fl_p == 0]).all() and (fed_a[fl_a == 0] == gt_a[fl_a == 0]).all()
+    assert ((fed_p[fl_p == 1] >= 0) & (fed_p[fl_p == 1] < V)).all()
+    assert 0.15 < fl_p[1:n_p].mean() < 0.9 and 0.2 < fl_a[1:n_d].mean() < 0.85   # rates: test_sched_sample_statistics
+    fed = {'prog': torch.from_numpy(fed_p.T.copy()).long(),
+           'act': torch.from_numpy(fed_a.T.reshape(B, k, T).copy()).long()}
+    out, grads = run_oracle(cfg, params, batch, fed_ids=fed)
+    assert abs(loss - float(out['loss'])) <= 2e-5 * abs(float(out['loss']))
+    assert _maxerr(m.pred_program, out['pred_program']) <= 1e-4
+    got = m.params.to_numpy('g')
+    for n in grads:
+        ref = grads[n].numpy()
+        assert np.abs(got[n] - ref).max() <= 2e-4 * max(np.abs(ref).max(), 1e-3), n
+    # a different step draws different noise
+    m.set_sampling_step(601)
+    m.forward(feed)
+    assert (m._ctx['da']['fed_ids'].cpu().numpy() != fed_a).any()
+
+
+def test_scheduled_sampling_training_graph_equals_eager():
+    """Trainer with --scheduled_sampling: the sampling probability and the noise counter live in
+    device memory, so hipGraph replays follow the schedule and draw fresh noise; with the same
+    seed the graphed and the eager trainer take identical steps."""
+    from demo2program_amd.trainer import Trainer
+    cfg, params, batch = small_case('karel', seed=17)
+    cfg.scheduled_sampling, cfg.scheduled_sampling_decay_steps = True, 10
+
+    def run(use_graph):
+        tr = Trainer(cfg, make_train_dir=False, use_graph=use_graph)
+        tr.model.params.load(params)
+        feed = tr.model.get_feed_dict(batch)
+        losses, fed = [], []
+        for _ in range(6):
+            losses.append(float(tr.train_step(feed).item()))
+            fed.append(tr.model._ctx['da']['fed_ids'].cpu().numpy().copy())
+        return losses, fed
+
+    (le, fe), (lg, fg) = run(False), run(True)
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-4 * abs(a), (le, lg)
+    for a, b in zip(fe, fg):
+        assert (a == b).all()
+    assert any((fe[i] != fe[i + 1]).any() for i in range(1, 5))     # fresh draws per step
+
+
 def test_bn_moving_statistics_follow_reference_updates():
     cfg, params, batch = small_case('karel', seed=9)
     from demo2program_amd.models.model_full import Model

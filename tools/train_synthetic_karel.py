@@ -24,6 +24,8 @@ def main():
     k = int(sys.argv[4]) if len(sys.argv) > 4 else 10
     build.build_library()
     config = make_config('karel', batch_size=bs, k=k)
+    if os.environ.get('D2P_SCHEDULED_SAMPLING', '0') == '1':
+        config.scheduled_sampling, config.scheduled_sampling_decay_steps = True, max(steps, 1)
     t0 = time.time()
     train = [sample_batch(config, seed=1000 + i) for i in range(n_batches)]
     held = sample_batch(config, seed=7)
