@@ -82,8 +82,8 @@ class Trainer(object):
 
         self.batch_size = config.batch_size
         self.dp = dp if dp is not None else DataParallel()
-        self.batch_train = dataset if dataset is not None else SyntheticBatches(config, 123, rank=self.dp.rank)
-        self.batch_test = dataset_test if dataset_test is not None else SyntheticBatches(config, 321, 2, rank=self.dp.rank)
+        self.batch_train = self._batches(dataset, config, 123, True)
+        self.batch_test = self._batches(dataset_test, config, 321, False)
 
         self.global_step = 0
         Model = self.get_model_class(config.model)
@@ -100,6 +100,20 @@ class Trainer(object):
             self.load_checkpoint(config.checkpoint)
 
     # ------------------------------------------------------------------ one optimizer step
+    def _batches(self, dataset, config, seed, is_training):
+        """A reference-style Dataset (has get_data) gets the input pipeline of trainer.py:43-48
+        (create_input_ops; with data parallelism each rank reads ids[rank::world], SURVEY 8(e));
+        anything with .next() is used as is; None -> synthetic batches."""
+        if dataset is None:
+            return SyntheticBatches(config, seed, 8 if is_training else 2, rank=self.dp.rank)
+        if hasattr(dataset, 'get_data'):
+            from .karel_env.input_ops_karel import create_input_ops
+            ids = dataset.ids[self.dp.rank::self.dp.world_size] if self.dp.world_size > 1 else dataset.ids
+            _, batch = create_input_ops(dataset, self.batch_size, is_training=is_training, data_id=ids,
+                                        shuffle=is_training, seed=seed + self.dp.rank)
+            return batch
+        return dataset
+
     def train_step(self, feed):
         """forward + backward + (all-reduce) + clip + Adam on a device-resident feed.
         Asynchronous: returns the device loss tensor without synchronising.
@@ -291,7 +305,23 @@ def main(argv=None):
     flags['k'] = args.num_k
     config = make_config(preset, **flags)
     dp = DataParallel.from_env()
-    trainer = Trainer(config, dp=dp)
+    dataset_train = dataset_test = None
+    if os.path.exists(os.path.join(config.dataset_path, 'data_info.json')) or \
+            os.path.exists(os.path.join(config.dataset_path, 'data.hdf5')):
+        if config.dataset_type != 'karel':
+            raise NotImplementedError('only the Karel dataset reader is built (SURVEY 8(f) N2)')
+        from .karel_env import dataset_karel as dataset
+        dataset_train, dataset_test, _ = dataset.create_default_splits(config.dataset_path, num_k=config.num_k)
+        # data dimensions from the first example (trainer.py:306-335)
+        program, _, s_h, test_s_h, a_h, _, _, _, _, _, _, per, _ = dataset_train.get_data(dataset_train.ids[0])
+        config.dim_program_token, config.max_program_len = int(program.shape[0]), int(program.shape[1])
+        config.k, config.test_k, config.max_demo_len = int(s_h.shape[0]), int(test_s_h.shape[0]), int(s_h.shape[1])
+        config.h, config.w, config.depth = (int(v) for v in s_h.shape[2:5])
+        config.action_space, config.per_dim = int(a_h.shape[2]), int(per.shape[2])
+        config.dsl_type, config.env_type = dataset_train.dsl_type, dataset_train.env_type
+    else:
+        print('no dataset under %s: training on synthetic Karel-shaped batches' % config.dataset_path)
+    trainer = Trainer(config, dataset_train, dataset_test, dp=dp)
     trainer.train(max_steps=args.max_steps)
 
 

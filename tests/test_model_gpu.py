@@ -387,6 +387,31 @@ def test_eval_mode_matches_oracle_and_evaler_runs(tmp_path):
     assert '[Final Avg Report]' in open(ev.summary_file).read()
 
 
+def test_trainer_on_the_converted_reference_dataset():
+    """End to end on data written by the reference's own generator: Dataset -> create_input_ops ->
+    get_feed_dict -> train steps -> run_test with the program metrics (tests/golden/karel_dataset,
+    12 programs, 3 seen + 2 held-out demonstrations each)."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.karel_env import dataset_karel as DK
+    from demo2program_amd.trainer import Trainer
+    path = os.path.join(GOLDEN, 'karel_dataset')
+    DK.rs = np.random.RandomState(123)
+    tr_ds, te_ds, _ = DK.create_default_splits(path, num_k=3)
+    program, _, s_h, test_s_h, a_h, _, _, _, _, _, _, per, _ = tr_ds.get_data(tr_ds.ids[0])
+    cfg = make_config('karel', batch_size=4, k=int(s_h.shape[0]), num_k=3, test_k=int(test_s_h.shape[0]),
+                      max_demo_len=int(s_h.shape[1]), max_program_len=int(program.shape[1]),
+                      num_lstm_cell_units=64, dataset_path=path)
+    tr = Trainer(cfg, tr_ds, te_ds, make_train_dir=False)
+    losses = [tr.run_single_step(tr.batch_train)[2] for _ in range(12)]
+    assert all(np.isfinite(losses)) and min(losses[-4:]) < losses[0]
+    step, report, loss, _, _ = tr.run_test(tr.batch_test)
+    assert step == 12 and np.isfinite(loss)
+    _, acc = report
+    assert 'greedy_program_syntax_acc' in acc and 'test_greedy_program_execution_acc_hist' in tr.model.report_hist
+    tr.batch_train.close()
+    tr.batch_test.close()
+
+
 def test_scheduled_sampling_decoders():
     """models/model_full.py:59-67,414-423.  (1) sampling probability 0 (global_step 0: teacher
     forcing probability 1.0) reproduces the teacher-forced path exactly; (2) with sampling on, the
