@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
@@ -214,6 +215,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--h2d', action='store_true', help='also report the host-batch (PCIe-inclusive) rate')
+    ap.add_argument('--frames', default='uint8', choices=['uint8', 'float32'],
+                    help='precision the demonstration frames are staged in: uint8 = the dataset\'s own (Karel states are '
+                         'booleans, ViZDoom frames bytes), widened on load inside conv1; float32 = the reference\'s feed dtype')
     args = ap.parse_args()
 
     from demo2program_amd import build
@@ -238,6 +242,10 @@ def main():
     log('trainer ready; making batches')
     # distinct per-rank synthetic batches, made resident in HBM before the timed region
     host_batches = [make_batch(config, seed=123 + 7919 * dp.rank + i) for i in range(4)]
+    if args.frames == 'uint8':
+        for b in host_batches:
+            assert np.array_equal(b['s_h'].astype(np.uint8).astype(b['s_h'].dtype), b['s_h'])   # lossless
+            b['s_h'] = b['s_h'].astype(np.uint8)
     feeds = [trainer.model.get_feed_dict(b) for b in host_batches]
     torch.cuda.synchronize()
     log('feeds resident; warmup')
@@ -275,6 +283,7 @@ def main():
                         (args.preset, config.k, config.h, config.w, config.depth, config.max_demo_len,
                          config.max_program_len, config.batch_size),
             'global_batch': global_batch, 'parallelism': 'dp%d' % dp.world_size,
+            'frames': args.frames,
             'lstm_units': config.num_lstm_cell_units,
         },
         'demo_instances_per_sec': round(value * config.k, 1),

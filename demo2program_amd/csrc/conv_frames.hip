@@ -55,7 +55,8 @@ struct FrameShape {
     static constexpr int NPIX = F * H * W;        // staged input pixels per tile
     static constexpr int PSF = CIN + 4;           // floats per staged pixel (16-byte pad)
     static constexpr int BUF = NPIX * PSF + 4;    // + zero slot
-    static constexpr int CHUNK = NPIX * CIN;      // contiguous input floats per tile
+    static constexpr int CIN_ = CIN;
+    static constexpr int CHUNK = NPIX * CIN;      // contiguous input elements per tile
     static constexpr int MASK = tap_mask(H, W);
     static constexpr int CB = CIN / 16, NT = popcount9(MASK), NCH = NT * CB, NB = COUT / 16;
     static constexpr int Q4 = CIN / 4;            // 16-byte pieces per pixel
@@ -65,12 +66,81 @@ struct FrameShape {
     static constexpr size_t lds_bytes = (size_t)4 * 2 * BUF * sizeof(float);
 };
 
-template <int CIN, int COUT, int H, int W>
+// Register staging of one tile's contiguous input chunk and its scatter into the padded LDS
+// image.  float frames: NL 16-byte loads per lane, one ds_write_b128 each.  uint8 frames (the
+// dataset's own precision for the first layer: Karel states are booleans): one 16-byte load
+// carries 16 channels = 4 float4 stores after widening -- a quarter of the HBM bytes.
+template <typename T, class S>
+struct Stager;
+
+template <class S>
+struct Stager<float, S> {
+    static constexpr int N = S::NL;
+    f32x4 r[N];
+    int soff[N];
+    __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = i * 64 + lane;
+            soff[i] = (j / S::Q4) * S::PSF + (j % S::Q4) * 4;
+        }
+    }
+    __device__ __forceinline__ void load(const float* __restrict__ x, int tile, long total, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            long e = (long)tile * S::CHUNK + (i * 64 + lane) * 4;
+            e = e < total - 4 ? e : total - 4;           // last tile may run past the tensor
+            r[i] = *reinterpret_cast<const f32x4*>(x + e);
+        }
+    }
+    __device__ __forceinline__ void store(float* img) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) *reinterpret_cast<f32x4*>(img + soff[i]) = r[i];
+    }
+};
+
+template <class S>
+struct Stager<uint8_t, S> {
+    static_assert(S::CHUNK % 1024 == 0 && S::CIN_ % 16 == 0, "uint8 staging moves whole 16-channel groups");
+    static constexpr int N = S::CHUNK / 1024;            // 16-byte loads per lane
+    uint4 r[N];
+    int soff[N];
+    __device__ __forceinline__ void init(int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int b = (i * 64 + lane) * 16;          // first channel-element of this piece
+            soff[i] = (b / S::CIN_) * S::PSF + (b % S::CIN_);
+        }
+    }
+    __device__ __forceinline__ void load(const uint8_t* __restrict__ x, int tile, long total, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            long e = (long)tile * S::CHUNK + (i * 64 + lane) * 16;
+            e = e < total - 16 ? e : total - 16;
+            r[i] = *reinterpret_cast<const uint4*>(x + e);
+        }
+    }
+    __device__ __forceinline__ void store(float* img) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const uint32_t w4[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 v;
+                v.x = (float)(w4[k] & 255u); v.y = (float)((w4[k] >> 8) & 255u);
+                v.z = (float)((w4[k] >> 16) & 255u); v.w = (float)(w4[k] >> 24);
+                *reinterpret_cast<f32x4*>(img + soff[i] + 4 * k) = v;
+            }
+        }
+    }
+};
+
+template <int CIN, int COUT, int H, int W, typename T>
 __global__ void __launch_bounds__(256)
-conv_frames_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+conv_frames_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
                        int act, float* __restrict__ y, int nframes, int ntiles) {
     using S = FrameShape<CIN, COUT, H, W>;
-    constexpr int NCH = S::NCH, NB = S::NB, CB = S::CB, NL = S::NL, PSF = S::PSF, BUF = S::BUF;
+    constexpr int NCH = S::NCH, NB = S::NB, CB = S::CB, PSF = S::PSF, BUF = S::BUF;
     extern __shared__ float lds[];
     const int lane = threadIdx.x & 63, p = lane & 15, q = lane >> 4, wid = threadIdx.x >> 6;
     const int wave = blockIdx.x * 4 + wid, NW = gridDim.x * 4;
@@ -93,13 +163,9 @@ conv_frames_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
             toff[ch] = ok ? ((f * H + iy) * W + ix) * PSF + (ch % CB) * 16 + 4 * q : S::NPIX * PSF;
         }
     }
-    // staging: piece j = i*64 + lane of the tile's contiguous chunk -> padded image
-    int soff[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int j = i * 64 + lane;
-        soff[i] = (j / S::Q4) * PSF + (j % S::Q4) * 4;
-    }
+    // staging: the tile's contiguous chunk -> padded image
+    Stager<T, S> st;
+    st.init(lane);
 
     // filter -> registers (A operand): wr[ch][j][b] = W[tap, 16 cb + 4q + j][16 b + p]
     float wr[NCH][4][NB];
@@ -115,24 +181,11 @@ conv_frames_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
     for (int b = 0; b < NB; ++b) bv[b] = bias ? *reinterpret_cast<const f32x4*>(bias + b * 16 + 4 * q)
                                                : f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const long total = (long)nframes * H * W * CIN;   // floats in x (a multiple of 4)
+    const long total = (long)nframes * H * W * CIN;   // elements in x (a multiple of 16)
     const int P = nframes * S::HW;
-    auto stage_load = [&](int tile, f32x4 (&st)[NL]) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            long e = (long)tile * S::CHUNK + (i * 64 + lane) * 4;
-            e = e < total - 4 ? e : total - 4;           // last tile may run past the tensor
-            st[i] = *reinterpret_cast<const f32x4*>(x + e);
-        }
-    };
-    auto stage_store = [&](float* img, const f32x4 (&st)[NL]) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(img + soff[i]) = st[i];
-    };
     auto step = [&](int tile, const float* rimg, float* wimg) {
-        f32x4 st[NL];
         const int nt = tile + NW;
-        stage_load(nt < ntiles ? nt : ntiles - 1, st);
+        st.load(x, nt < ntiles ? nt : ntiles - 1, total, lane);
         f32x4 acc[2][NB];
 #pragma unroll
         for (int b = 0; b < NB; ++b) acc[0][b] = acc[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -153,14 +206,13 @@ conv_frames_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                 *reinterpret_cast<f32x4*>(y + (long)pix * COUT + b * 16 + 4 * q) = o;
             }
         }
-        stage_store(wimg, st);
+        st.store(wimg);
     };
 
     int tile = wave;
     if (tile < ntiles) {
-        f32x4 st[NL];
-        stage_load(tile, st);
-        stage_store(img0, st);
+        st.load(x, tile, total, lane);
+        st.store(img0);
     }
     while (tile < ntiles) {
         step(tile, img0, img1);
@@ -173,13 +225,13 @@ conv_frames_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
 
 int g_frames_tpw = 0;   // 0: automatic
 
-template <int CIN, int COUT, int H, int W>
-int launch_frames_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, int act, float* y,
+template <int CIN, int COUT, int H, int W, typename T>
+int launch_frames_fwd(const ConvGeom& g, const T* x, const float* w, const float* bias, int act, float* y,
                       hipStream_t st) {
     using S = FrameShape<CIN, COUT, H, W>;
     static bool attr_set = false;
     if (!attr_set) {
-        D2P_HIP(hipFuncSetAttribute((const void*)conv_frames_fwd_kernel<CIN, COUT, H, W>,
+        D2P_HIP(hipFuncSetAttribute((const void*)conv_frames_fwd_kernel<CIN, COUT, H, W, T>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)S::lds_bytes));
         attr_set = true;
     }
@@ -189,7 +241,7 @@ int launch_frames_fwd(const ConvGeom& g, const float* x, const float* w, const f
     if (waves > 2048) waves = 2048;
     const int blocks = ceil_div((int)waves, 4);
     D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * S::HW * 9 * CIN * COUT);
-    hipLaunchKernelGGL((conv_frames_fwd_kernel<CIN, COUT, H, W>), dim3(blocks), dim3(256), S::lds_bytes, st, x, w,
+    hipLaunchKernelGGL((conv_frames_fwd_kernel<CIN, COUT, H, W, T>), dim3(blocks), dim3(256), S::lds_bytes, st, x, w,
                        bias, act, y, g.N, ntiles);
     D2P_LAUNCH_CHECK("conv_frames_fwd");
     return 1;
@@ -203,12 +255,12 @@ int launch_frames_fwd(const ConvGeom& g, const float* x, const float* w, const f
 // ds_read_b32 at per-lane offsets fixed for the kernel; dY (64-byte rows) comes straight from
 // global memory.  WAVES waves per workgroup are summed through LDS in a fixed tree, so one
 // slab per workgroup reaches the deterministic combine pass.
-template <int CIN, int COUT, int H, int W, int WAVES>
+template <int CIN, int COUT, int H, int W, int WAVES, typename T>
 __global__ void __launch_bounds__(WAVES * 64)
-conv_frames_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
+conv_frames_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
                          int nframes, int ntiles) {
     using S = FrameShape<CIN, COUT, H, W>;
-    constexpr int CB = S::CB, NT = S::NT, AB = NT * CB, NBO = COUT / 16, NL = S::NL, PSF = S::PSF;
+    constexpr int CB = S::CB, NT = S::NT, AB = NT * CB, NBO = COUT / 16, PSF = S::PSF;
     constexpr int IMG = S::NPIX * PSF + 4;             // floats per wave image (+ zero slot)
     constexpr int ACC = AB * NBO * 4;                  // accumulator floats per lane
     constexpr int KK = 9 * CIN;
@@ -232,12 +284,8 @@ conv_frames_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ 
             toff[a][m] = ok ? ((f * H + iy) * W + ix) * PSF + (a % CB) * 16 + c : S::NPIX * PSF;
         }
     }
-    int soff[NL];
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        const int j = i * 64 + lane;
-        soff[i] = (j / S::Q4) * PSF + (j % S::Q4) * 4;
-    }
+    Stager<T, S> st;
+    st.init(lane);
 
     f32x4 acc[AB][NBO];
 #pragma unroll
@@ -247,13 +295,8 @@ conv_frames_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ 
 
     const long total = (long)nframes * H * W * CIN;
     const int P = nframes * S::HW;
-    auto load_tile = [&](int tile, f32x4 (&st)[NL], float (&bv)[4][NBO]) {
-#pragma unroll
-        for (int i = 0; i < NL; ++i) {
-            long e = (long)tile * S::CHUNK + (i * 64 + lane) * 4;
-            e = e < total - 4 ? e : total - 4;
-            st[i] = *reinterpret_cast<const f32x4*>(x + e);
-        }
+    auto load_tile = [&](int tile, float (&bv)[4][NBO]) {
+        st.load(x, tile, total, lane);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             const int pix = tile * 16 + 4 * m + kq;
@@ -263,14 +306,12 @@ conv_frames_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ 
         }
     };
 
-    f32x4 st[NL];
     float bv[4][NBO];
     int tile = wave;
-    if (tile < ntiles) load_tile(tile, st, bv);
+    if (tile < ntiles) load_tile(tile, bv);
     while (tile < ntiles) {
         // stage this tile, then immediately put the next one in flight
-#pragma unroll
-        for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4*>(img + soff[i]) = st[i];
+        st.store(img);
         float bc[4][NBO];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
@@ -279,7 +320,7 @@ conv_frames_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ 
             for (int b = 0; b < NBO; ++b) bc[m][b] = valid ? bv[m][b] : 0.f;
         }
         const int nt = tile + NW;
-        load_tile(nt < ntiles ? nt : ntiles - 1, st, bv);
+        load_tile(nt < ntiles ? nt : ntiles - 1, bv);
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -339,7 +380,7 @@ conv_frames_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ 
 
 int g_frames_wgrad_cap = 0;   // 0: per-layer default
 
-template <int CIN, int COUT, int H, int W, int WAVES, int CAP>
+template <int CIN, int COUT, int H, int W, int WAVES, int CAP, typename T>
 struct WgradLaunch {
     using S = FrameShape<CIN, COUT, H, W>;
     static constexpr int ACC = S::NT * S::CB * (COUT / 16) * 4;
@@ -353,11 +394,11 @@ struct WgradLaunch {
         if (b > cap) b = cap;
         return b < 1 ? 1 : b;
     }
-    static int run(const ConvGeom& g, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
+    static int run(const ConvGeom& g, const T* x, const float* dy, float* dw, void* ws, size_t ws_bytes,
                    hipStream_t st) {
         static bool attr_set = false;
         if (!attr_set) {
-            D2P_HIP(hipFuncSetAttribute((const void*)conv_frames_wgrad_kernel<CIN, COUT, H, W, WAVES>,
+            D2P_HIP(hipFuncSetAttribute((const void*)conv_frames_wgrad_kernel<CIN, COUT, H, W, WAVES, T>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             attr_set = true;
         }
@@ -367,7 +408,7 @@ struct WgradLaunch {
                     "conv wgrad: workspace too small (%zu bytes)", ws_bytes);
         float* slabs = (float*)ws;
         D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * S::HW * KK * COUT);
-        hipLaunchKernelGGL((conv_frames_wgrad_kernel<CIN, COUT, H, W, WAVES>), dim3(nb), dim3(WAVES * 64),
+        hipLaunchKernelGGL((conv_frames_wgrad_kernel<CIN, COUT, H, W, WAVES, T>), dim3(nb), dim3(WAVES * 64),
                            lds_bytes, st, x, dy, slabs, g.N, ceil_div(g.N, S::F));
         D2P_LAUNCH_CHECK("conv_frames_wgrad");
         EpiDense ep{dw, COUT, nullptr, 0, 0};
@@ -391,29 +432,39 @@ void d2p_conv_frames_wgrad_cap(int cap) { g_frames_wgrad_cap = cap; }
 
 int d2p_conv_frames_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias,
                         int act, float* y, hipStream_t st) {
-    if (x_is_u8 || g.N < 1) return 0;
+    if (g.N < 1) return 0;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
+    if (x_is_u8) {      // frames as stored (booleans / bytes): first layer only
+        if (g.Cin == 16 && g.Cout == 16 && g.H == 8 && g.W == 8)
+            return launch_frames_fwd<16, 16, 8, 8, uint8_t>(g, (const uint8_t*)x, w, bias, act, y, st);
+        return 0;
+    }
     const float* xf = (const float*)x;
-    if (g.Cin == 16 && g.Cout == 16 && g.H == 8 && g.W == 8) return launch_frames_fwd<16, 16, 8, 8>(g, xf, w, bias, act, y, st);
-    if (g.Cin == 16 && g.Cout == 32 && g.H == 4 && g.W == 4) return launch_frames_fwd<16, 32, 4, 4>(g, xf, w, bias, act, y, st);
-    if (g.Cin == 32 && g.Cout == 48 && g.H == 2 && g.W == 2) return launch_frames_fwd<32, 48, 2, 2>(g, xf, w, bias, act, y, st);
+    if (g.Cin == 16 && g.Cout == 16 && g.H == 8 && g.W == 8) return launch_frames_fwd<16, 16, 8, 8, float>(g, xf, w, bias, act, y, st);
+    if (g.Cin == 16 && g.Cout == 32 && g.H == 4 && g.W == 4) return launch_frames_fwd<16, 32, 4, 4, float>(g, xf, w, bias, act, y, st);
+    if (g.Cin == 32 && g.Cout == 48 && g.H == 2 && g.W == 2) return launch_frames_fwd<32, 48, 2, 2, float>(g, xf, w, bias, act, y, st);
     return 0;
 }
 
 size_t d2p_conv_frames_wgrad_ws(const ConvGeom& g) {
-    if (g.Cin == 16 && g.Cout == 16 && g.H == 8 && g.W == 8) return (size_t)WgradLaunch<16, 16, 8, 8, 4, 256>::blocks(g.N) * 9 * 16 * 16 * 4;
-    if (g.Cin == 16 && g.Cout == 32 && g.H == 4 && g.W == 4) return (size_t)WgradLaunch<16, 32, 4, 4, 4, 128>::blocks(g.N) * 9 * 16 * 32 * 4;
-    if (g.Cin == 32 && g.Cout == 48 && g.H == 2 && g.W == 2) return (size_t)WgradLaunch<32, 48, 2, 2, 4, 64>::blocks(g.N) * 9 * 32 * 48 * 4;
+    if (g.Cin == 16 && g.Cout == 16 && g.H == 8 && g.W == 8) return (size_t)WgradLaunch<16, 16, 8, 8, 4, 256, float>::blocks(g.N) * 9 * 16 * 16 * 4;
+    if (g.Cin == 16 && g.Cout == 32 && g.H == 4 && g.W == 4) return (size_t)WgradLaunch<16, 32, 4, 4, 4, 128, float>::blocks(g.N) * 9 * 16 * 32 * 4;
+    if (g.Cin == 32 && g.Cout == 48 && g.H == 2 && g.W == 2) return (size_t)WgradLaunch<32, 48, 2, 2, 4, 64, float>::blocks(g.N) * 9 * 32 * 48 * 4;
     return 0;
 }
 
 int d2p_conv_frames_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,
                           size_t ws_bytes, hipStream_t st) {
-    if (x_is_u8 || g.N < 1) return 0;
+    if (g.N < 1) return 0;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 3)) return 0;
+    if (x_is_u8) {
+        if (g.Cin == 16 && g.Cout == 16 && g.H == 8 && g.W == 8)
+            return WgradLaunch<16, 16, 8, 8, 4, 256, uint8_t>::run(g, (const uint8_t*)x, dy, dw, ws, ws_bytes, st);
+        return 0;
+    }
     const float* xf = (const float*)x;
-    if (g.Cin == 16 && g.Cout == 16 && g.H == 8 && g.W == 8) return WgradLaunch<16, 16, 8, 8, 4, 256>::run(g, xf, dy, dw, ws, ws_bytes, st);
-    if (g.Cin == 16 && g.Cout == 32 && g.H == 4 && g.W == 4) return WgradLaunch<16, 32, 4, 4, 4, 128>::run(g, xf, dy, dw, ws, ws_bytes, st);
-    if (g.Cin == 32 && g.Cout == 48 && g.H == 2 && g.W == 2) return WgradLaunch<32, 48, 2, 2, 4, 64>::run(g, xf, dy, dw, ws, ws_bytes, st);
+    if (g.Cin == 16 && g.Cout == 16 && g.H == 8 && g.W == 8) return WgradLaunch<16, 16, 8, 8, 4, 256, float>::run(g, xf, dy, dw, ws, ws_bytes, st);
+    if (g.Cin == 16 && g.Cout == 32 && g.H == 4 && g.W == 4) return WgradLaunch<16, 32, 4, 4, 4, 128, float>::run(g, xf, dy, dw, ws, ws_bytes, st);
+    if (g.Cin == 32 && g.Cout == 48 && g.H == 2 && g.W == 2) return WgradLaunch<32, 48, 2, 2, 4, 64, float>::run(g, xf, dy, dw, ws, ws_bytes, st);
     return 0;
 }

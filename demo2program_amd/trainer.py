@@ -109,8 +109,10 @@ class Trainer(object):
         if hasattr(dataset, 'get_data'):
             from .karel_env.input_ops_karel import create_input_ops
             ids = dataset.ids[self.dp.rank::self.dp.world_size] if self.dp.world_size > 1 else dataset.ids
+            # frames stay uint8 end to end (the HDF5 stores booleans): a quarter of the H2D bytes and of
+            # conv1's HBM reads; the kernels widen on load, results identical to the float32 feed
             _, batch = create_input_ops(dataset, self.batch_size, is_training=is_training, data_id=ids,
-                                        shuffle=is_training, seed=seed + self.dp.rank)
+                                        shuffle=is_training, seed=seed + self.dp.rank, frames_dtype=np.uint8)
             return batch
         return dataset
 

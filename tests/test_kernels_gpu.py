@@ -139,6 +139,26 @@ def test_conv_uint8_input(K):
     close(dw, dwf, atol=1e-2, rtol=1e-5)
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(41, 8, 8, 16, 16), (7, 12, 10, 4, 16), (3, 8, 8, 16, 32)])
+def test_conv_uint8_frames_equal_float_frames(K, N, H, W, Cin, Cout):
+    """uint8 frames (the dataset's own precision) are widened on load: same result as feeding the
+    float copy, on every conv back end that takes them (whole-frame, direct, implicit GEMM)."""
+    g = torch.Generator().manual_seed(3)
+    xu = torch.randint(0, 256 if Cin == 4 else 2, (N, H, W, Cin), generator=g, dtype=torch.uint8)
+    w = rnd(3, 3, Cin, Cout, seed=2, scale=0.05)
+    b = rnd(Cout, seed=3)
+    ref = _conv_ref(xu.double(), w, b)
+    out = K.conv_fwd(xu.cuda(), dev(w), dev(b), act=0)
+    close(out, ref, atol=2e-3, rtol=1e-5)
+    close(out, K.conv_fwd(dev(xu.double()), dev(w), dev(b), act=0), atol=1e-4)
+    dy = rnd(*ref.shape, seed=5)
+    dw = torch.empty(3, 3, Cin, Cout, device='cuda')
+    K.conv_wgrad(xu.cuda(), dev(dy), dw)
+    dwf = torch.empty(3, 3, Cin, Cout, device='cuda')
+    K.conv_wgrad(dev(xu.double()), dev(dy), dwf)
+    close(dw, dwf, atol=1e-3, rtol=1e-5)
+
+
 # ------------------------------------------------------------------ scheduled sampling
 def test_sched_sample_statistics(K):
     """d2p_sched_sample: p = 0 keeps the ground truth, p = 1 always draws, the draw frequencies
