@@ -4,7 +4,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-SOURCES = ['api.hip', 'gemm.hip', 'conv.hip', 'conv_direct.hip', 'conv_frames.hip', 'bn.hip', 'lstm.hip', 'lstm_step.hip', 'greedy.hip', 'xent.hip', 'misc.hip',
+SOURCES = ['api.hip', 'gemm.hip', 'conv.hip', 'conv_direct.hip', 'conv_frames.hip', 'conv_rows.hip', 'bn.hip', 'lstm.hip', 'lstm_step.hip', 'greedy.hip', 'xent.hip', 'misc.hip',
            'adam.hip']
 HEADERS = ['common.h', 'conv_geom.h', 'gemm_core.h', 'prof.h', 'lstm_math.h', os.path.join('..', '..', 'include', 'd2p.h')]
 OUT = os.path.join(CSRC, 'libd2p_hip.so')

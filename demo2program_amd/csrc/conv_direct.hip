@@ -545,6 +545,7 @@ extern "C" int d2p_conv_direct_tune(int fwd_tpw, int dgrad_tpw, int wgrad_wgs) {
     if (dgrad_tpw > 0) g_direct_dgrad_tpw = dgrad_tpw;
     if (wgrad_wgs > 0) g_direct_wgrad_wgs = wgrad_wgs;
     if (wgrad_wgs != 0) d2p_conv_frames_wgrad_cap(wgrad_wgs > 0 ? wgrad_wgs : 0);
+    if (wgrad_wgs != 0) d2p_conv_rows_tune(wgrad_wgs);
     if (fwd_tpw != 0) d2p_conv_frames_tune(fwd_tpw > 0 ? fwd_tpw : 0);
     return D2P_OK;
 }
@@ -636,7 +637,9 @@ static int wgrad_blocks(const ConvGeom& g) {
 }
 
 size_t d2p_conv_direct_wgrad_ws(const ConvGeom& g) {
-    const size_t fr = d2p_conv_frames_wgrad_ws(g);
+    size_t fr = d2p_conv_frames_wgrad_ws(g);
+    const size_t rw = d2p_conv_rows_wgrad_ws(g);
+    if (rw > fr) fr = rw;
     if (!wgrad_supported(g)) return fr;
     const size_t di = (size_t)wgrad_blocks(g) * 9 * g.Cin * g.Cout * sizeof(float);
     return fr > di ? fr : di;
@@ -669,7 +672,9 @@ int d2p_conv_direct_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const f
                           size_t ws_bytes, hipStream_t st) {
     if (!g_direct_wgrad) return 0;
     if (g_direct_wgrad >= 2) {
-        const int rc = d2p_conv_frames_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st);
+        int rc = d2p_conv_frames_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st);
+        if (rc != 0) return rc;
+        rc = d2p_conv_rows_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st);
         if (rc != 0) return rc;
     }
     if (!wgrad_supported(g)) return 0;

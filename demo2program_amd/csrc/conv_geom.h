@@ -43,4 +43,10 @@ int d2p_conv_frames_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const f
                           void* ws, size_t ws_bytes, hipStream_t st);
 size_t d2p_conv_frames_wgrad_ws(const ConvGeom& g);
 void d2p_conv_frames_tune(int tiles_per_wave);
+
+// Row-strip back end (conv_rows.hip): weight gradients of the narrow layers of large frames.
+int d2p_conv_rows_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,
+                        size_t ws_bytes, hipStream_t st);
+size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g);
+void d2p_conv_rows_tune(int wgrad_workgroups);
 void d2p_conv_frames_wgrad_cap(int cap);

@@ -1,0 +1,289 @@
+// K1 (row-strip back end): weight gradient of the two narrow ViZDoom layers
+// (80x80x{3->4} -> 40x40x16 and 40x40x16 -> 20x20x32; models/model_full.py:216-231), the largest
+// single kernels of that configuration.  Same idea as conv_frames.hip at a size where a frame no
+// longer fits a tile: a wave's unit of work is ONE OUTPUT ROW of one frame.  Its three input rows
+// are contiguous in NHWC, so they are fetched with lane-linear 16-byte loads (uint8 frames: 16
+// bytes = 4 pixels, widened on the way) into a wave-private LDS strip with a zero pixel of halo on
+// either side; the A operand (x, reduction index = pixel, 4 pixels per MFMA) is ds_read_b32 at
+// per-lane offsets that are fixed for the kernel plus a constant per k-step; dY rows (contiguous)
+// go straight to registers in the MFMA B layout.  No bounds arithmetic in the loop at all: column
+// overhang lands in the halo, out-of-image rows are staged as zeros.  The whole dW lives in
+// accumulators; waves are summed in a fixed tree; one slab per workgroup -> deterministic combine.
+#include "conv_geom.h"
+#include "gemm_core.h"
+#include "prof.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define D2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+namespace {
+
+constexpr int r_out(int n) { return (n + 1) / 2; }
+constexpr int r_before(int n) {
+    int total = (r_out(n) - 1) * 2 + 3 - n;
+    return total < 0 ? 0 : total / 2;
+}
+
+template <int CIN, int COUT, int W>
+struct RowShape {
+    static constexpr int Wo = r_out(W), PL = r_before(W);
+    static constexpr int KS = (Wo + 3) / 4;                  // MFMA k-steps (4 output pixels each) per row
+    static constexpr int PSF = CIN == 4 ? 4 : CIN + 8;       // floats per staged pixel (bank spreading)
+    static constexpr int ROWPIX = 8 * KS + 4;                // staged pixels per row incl. halo / overhang
+    static constexpr int ROWF = ROWPIX * PSF;
+    static constexpr int IMG = 3 * ROWF;                     // floats per wave
+    static constexpr int AB = CIN == 4 ? 3 : 9 * (CIN / 16); // 16-row blocks of dW
+    static constexpr int NBO = COUT / 16;
+    static constexpr int RP4 = W * CIN / 4;                  // 16-byte float pieces per input row
+    static constexpr int NLF = (3 * RP4 + 63) / 64;          // float pieces per lane per strip
+    static constexpr int RP16 = W * CIN / 16;                // 16-byte uint8 pieces per input row
+    static constexpr int NLU = (3 * RP16 + 63) / 64;
+    static_assert(W * CIN % 16 == 0, "rows must be whole 16-byte pieces");
+    static_assert(2 * (4 * KS - 1) + 2 + 1 < ROWPIX, "overhang must stay inside the staged row");
+};
+
+// -- staging of the strip's three input rows (float / uint8) ----------------------------------
+template <typename T, class S, int CIN, int W>
+struct RowStager;
+
+template <class S, int CIN, int W>
+struct RowStager<float, S, CIN, W> {
+    static constexpr int N = S::NLF;
+    f32x4 r[N];
+    __device__ __forceinline__ void load(const float* __restrict__ x, long frame_off, int iy0, int H, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = i * 64 + lane;
+            const int row = j / S::RP4, wi = j - row * S::RP4;
+            const int iy = iy0 + row;
+            const bool ok = (row < 3) & (iy >= 0) & (iy < H);
+            const int iyc = min(max(iy, 0), H - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + frame_off + ((long)iyc * W) * CIN + (row < 3 ? wi : 0) * 4);
+            r[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    __device__ __forceinline__ void store(float* img, int lane) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = i * 64 + lane;
+            const int row = j / S::RP4, wi = j - row * S::RP4;
+            if (row < 3)
+                *reinterpret_cast<f32x4*>(img + row * S::ROWF + (wi / (CIN / 4) + 1) * S::PSF + (wi % (CIN / 4)) * 4) = r[i];
+        }
+    }
+};
+
+template <class S, int CIN, int W>
+struct RowStager<uint8_t, S, CIN, W> {
+    static constexpr int N = S::NLU;
+    uint4 r[N];
+    __device__ __forceinline__ void load(const uint8_t* __restrict__ x, long frame_off, int iy0, int H, int lane) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = i * 64 + lane;
+            const int row = j / S::RP16, wi = j - row * S::RP16;
+            const int iy = iy0 + row;
+            const bool ok = (row < 3) & (iy >= 0) & (iy < H);
+            const int iyc = min(max(iy, 0), H - 1);
+            const uint4 v = *reinterpret_cast<const uint4*>(x + frame_off + ((long)iyc * W) * CIN + (row < 3 ? wi : 0) * 16);
+            r[i] = ok ? v : uint4{0u, 0u, 0u, 0u};
+        }
+    }
+    __device__ __forceinline__ void store(float* img, int lane) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = i * 64 + lane;
+            const int row = j / S::RP16, wi = j - row * S::RP16;
+            if (row >= 3) continue;
+            const uint32_t w4[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = wi * 16 + 4 * k;                    // first channel-element of this float4
+                f32x4 v;
+                v.x = (float)(w4[k] & 255u); v.y = (float)((w4[k] >> 8) & 255u);
+                v.z = (float)((w4[k] >> 16) & 255u); v.w = (float)(w4[k] >> 24);
+                *reinterpret_cast<f32x4*>(img + row * S::ROWF + (e / CIN + 1) * S::PSF + e % CIN) = v;
+            }
+        }
+    }
+};
+
+template <int CIN, int COUT, int W, typename T>
+__global__ void __launch_bounds__(256)
+conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs, int nframes,
+                       int H, int Ho, int pt) {
+    using S = RowShape<CIN, COUT, W>;
+    constexpr int AB = S::AB, NBO = S::NBO, KS = S::KS, PSF = S::PSF, Wo = S::Wo;
+    constexpr int ACC = AB * NBO * 4, KK = 9 * CIN;
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, c = lane & 15, kq = lane >> 4, wid = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wid, NW = gridDim.x * 4;
+    float* const img = lds + (size_t)wid * S::IMG;
+    for (int i = lane; i < S::IMG; i += 64) img[i] = 0.f;        // halo / overhang stay zero for good
+
+    // A-operand offset of k-step 0 for each 16-row block of dW; a k-step advances 8 input pixels
+    int aoff[AB];
+    float amask[AB];
+#pragma unroll
+    for (int a = 0; a < AB; ++a) {
+        int tap, ci;
+        if (CIN == 4) { tap = 4 * a + (c >> 2); ci = c & 3; }
+        else { tap = a / (CIN / 16); ci = (a % (CIN / 16)) * 16 + c; }
+        const bool ok = tap < 9;
+        const int ky = ok ? tap / 3 : 0, kx = ok ? tap % 3 : 0;
+        aoff[a] = ky * S::ROWF + (2 * kq - S::PL + kx + 1) * PSF + ci;
+        amask[a] = ok ? 1.f : 0.f;
+    }
+
+    f32x4 acc[AB][NBO];
+#pragma unroll
+    for (int a = 0; a < AB; ++a)
+#pragma unroll
+        for (int b = 0; b < NBO; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nstrips = nframes * Ho;
+    const long frame_elems = (long)H * W * CIN;
+    // No software pipeline: a strip is "load rows + dY -> LDS -> 30-90 MFMAs", and latency is hidden by
+    // occupancy instead (<= 128 VGPRs and 4-13 KB of LDS per wave: up to 8 waves per SIMD).  Both
+    // register-prefetch variants were slower -- a "cur = next" copy let the compiler rotate the
+    // loop so each strip waited for its own loads (9 us per strip); explicit ping-pong sets kept
+    // the distance but cost 128-400 VGPRs, i.e. the occupancy that was hiding the latency.
+    RowStager<T, S, CIN, W> st;
+    float colmask[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) colmask[s] = (4 * s + kq < Wo) ? 1.f : 0.f;
+    for (int strip = wave; strip < nstrips; strip += NW) {
+        const int n = strip / Ho, oy = strip - n * Ho;
+        st.load(x, (long)n * frame_elems, 2 * oy - pt, H, lane);
+        float bv[KS][NBO];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int ox = 4 * s + kq;
+            const int oxc = ox < Wo ? ox : Wo - 1;
+#pragma unroll
+            for (int b = 0; b < NBO; ++b) bv[s][b] = dy[((long)strip * Wo + oxc) * COUT + b * 16 + c];
+        }
+        st.store(img, lane);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            float bc[NBO];
+#pragma unroll
+            for (int b = 0; b < NBO; ++b) bc[b] = (4 * (KS - 1) + 3 < Wo) ? bv[s][b] : bv[s][b] * colmask[s];
+#pragma unroll
+            for (int a = 0; a < AB; ++a) {
+                float av = img[aoff[a] + s * 8 * PSF];
+                if (CIN == 4 && a == AB - 1) av *= amask[a];
+#pragma unroll
+                for (int b = 0; b < NBO; ++b) acc[a][b] = D2P_MFMA16(av, bc[b], acc[a][b]);
+            }
+        }
+    }
+
+    // fixed-order tree over the 4 waves (scratch reuses the strip area)
+    __syncthreads();
+    float* const red = lds;
+#pragma unroll
+    for (int step = 1; step < 4; step *= 2) {
+        if ((wid & (2 * step - 1)) == step) {
+            float* dst = red + (size_t)(wid / (2 * step)) * ACC * 64;
+#pragma unroll
+            for (int a = 0; a < AB; ++a)
+#pragma unroll
+                for (int b = 0; b < NBO; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((a * NBO + b) * 4 + r) * 64 + lane] = acc[a][b][r];
+        }
+        __syncthreads();
+        if ((wid & (2 * step - 1)) == 0) {
+            const float* src = red + (size_t)(wid / (2 * step)) * ACC * 64;
+#pragma unroll
+            for (int a = 0; a < AB; ++a)
+#pragma unroll
+                for (int b = 0; b < NBO; ++b)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][b][r] += src[((a * NBO + b) * 4 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wid == 0) {
+        float* slab = slabs + (long)blockIdx.x * KK * COUT;
+#pragma unroll
+        for (int a = 0; a < AB; ++a)
+#pragma unroll
+            for (int b = 0; b < NBO; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int row;                 // flattened (tap, ci) = D row 4*kq + r of block a
+                    if (CIN == 4) row = 16 * a + 4 * kq + r;
+                    else row = (a / (CIN / 16)) * CIN + (a % (CIN / 16)) * 16 + 4 * kq + r;
+                    if (row < KK) slab[row * COUT + b * 16 + c] = acc[a][b][r];
+                }
+    }
+}
+
+int g_rows_wgrad_wgs = 0;      // 0: per-layer default (template CAP)
+
+template <int CIN, int COUT, int W, typename T, int CAP>
+struct RowsWgrad {
+    using S = RowShape<CIN, COUT, W>;
+    static constexpr int ACC = S::AB * S::NBO * 4;
+    static constexpr size_t img_bytes = (size_t)4 * S::IMG * sizeof(float);
+    static constexpr size_t red_bytes = (size_t)2 * ACC * 64 * sizeof(float);
+    static constexpr size_t lds_bytes = img_bytes > red_bytes ? img_bytes : red_bytes;
+    static int blocks(const ConvGeom& g) {
+        int b = ceil_div(g.N * g.Ho, 4 * 8);             // >= 8 strips per wave
+        const int cap = g_rows_wgrad_wgs > 0 ? g_rows_wgrad_wgs : CAP;   // measured: kernel keeps scaling to 2048
+        if (b > cap) b = cap;                                              // workgroups, the combine pass does not
+        return b < 1 ? 1 : b;
+    }
+    static int run(const ConvGeom& g, const T* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_wgrad_kernel<CIN, COUT, W, T>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_set = true;
+        }
+        const int KK = 9 * CIN, nb = blocks(g);
+        D2P_REQUIRE(ws && ws_bytes >= (size_t)nb * KK * COUT * sizeof(float), D2P_EWS,
+                    "conv wgrad: workspace too small (%zu bytes)", ws_bytes);
+        float* slabs = (float*)ws;
+        D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * KK * COUT);
+        hipLaunchKernelGGL((conv_rows_wgrad_kernel<CIN, COUT, W, T>), dim3(nb), dim3(256), lds_bytes, st, x, dy, slabs,
+                           g.N, g.H, g.Ho, g.pt);
+        D2P_LAUNCH_CHECK("conv_rows_wgrad");
+        EpiDense ep{dw, COUT, nullptr, 0, 0};
+        const long total = (long)KK * COUT;
+        hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EpiDense>), dim3((int)((total * 16 + 255) / 256)), dim3(256), 0,
+                           st, ep, slabs, KK, COUT, nb);
+        D2P_LAUNCH_CHECK("conv_rows_wgrad_combine");
+        return 1;
+    }
+};
+
+}   // namespace
+
+void d2p_conv_rows_tune(int wgrad_wgs) { g_rows_wgrad_wgs = wgrad_wgs > 0 ? wgrad_wgs : 0; }
+
+static int rows_key(const ConvGeom& g) {
+    if (g.Cin == 4 && g.Cout == 16 && g.W == 80) return 1;
+    if (g.Cin == 16 && g.Cout == 32 && g.W == 40) return 2;
+    return 0;
+}
+
+size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g) {
+    if (!rows_key(g)) return 0;
+    return (size_t)(g_rows_wgrad_wgs > 2048 ? g_rows_wgrad_wgs : 2048) * 9 * g.Cin * g.Cout * sizeof(float);
+}
+
+int d2p_conv_rows_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,
+                        size_t ws_bytes, hipStream_t st) {
+    const int key = rows_key(g);
+    if (!key || g.N < 1) return 0;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 3)) return 0;
+    if (key == 1) {
+        if (x_is_u8) return RowsWgrad<4, 16, 80, uint8_t, 1024>::run(g, (const uint8_t*)x, dy, dw, ws, ws_bytes, st);
+        return RowsWgrad<4, 16, 80, float, 1024>::run(g, (const float*)x, dy, dw, ws, ws_bytes, st);
+    }
+    if (x_is_u8) return 0;
+    return RowsWgrad<16, 32, 40, float, 512>::run(g, (const float*)x, dy, dw, ws, ws_bytes, st);
+}

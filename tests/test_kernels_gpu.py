@@ -95,7 +95,9 @@ def _conv_ref(x, w, b):
                                             (3, 10, 10, 48, 48), (5, 7, 9, 4, 8),
                                             (41, 4, 4, 16, 32), (37, 2, 2, 32, 48), (33, 8, 8, 16, 16),
                                             (3, 20, 20, 16, 32), (2, 21, 19, 16, 16), (5, 11, 14, 4, 16),
-                                            (1, 1, 1, 16, 16), (700, 8, 8, 16, 16)])
+                                            (1, 1, 1, 16, 16), (700, 8, 8, 16, 16),
+                                            (3, 80, 80, 4, 16), (2, 37, 80, 4, 16), (3, 40, 40, 16, 32),
+                                            (2, 21, 40, 16, 32), (70, 6, 80, 4, 16)])
 def test_conv_fwd_dgrad_wgrad(K, N, H, W, Cin, Cout):
     x = rnd(N, H, W, Cin, seed=1).requires_grad_(True)
     w = rnd(3, 3, Cin, Cout, seed=2, scale=0.3).requires_grad_(True)
@@ -139,7 +141,8 @@ def test_conv_uint8_input(K):
     close(dw, dwf, atol=1e-2, rtol=1e-5)
 
 
-@pytest.mark.parametrize('N,H,W,Cin,Cout', [(41, 8, 8, 16, 16), (7, 12, 10, 4, 16), (3, 8, 8, 16, 32)])
+@pytest.mark.parametrize('N,H,W,Cin,Cout', [(41, 8, 8, 16, 16), (7, 12, 10, 4, 16), (3, 8, 8, 16, 32),
+                                            (3, 80, 80, 4, 16), (5, 9, 80, 4, 16)])
 def test_conv_uint8_frames_equal_float_frames(K, N, H, W, Cin, Cout):
     """uint8 frames (the dataset's own precision) are widened on load: same result as feeding the
     float copy, on every conv back end that takes them (whole-frame, direct, implicit GEMM)."""

@@ -59,10 +59,10 @@ def main():
             lib.d2p_conv_set_direct(0, 0, 0)
             t = min(timed(fn), timed(fn))
             out.append('gemm %.1fus %.1fTF %.0fGB/s' % (t * 1e6, fl / t / 1e12, by[name] / t / 1e9))
-            lib.d2p_conv_set_direct(1, 1, 1)
+            lib.d2p_conv_set_direct(2, 2, 2)
             knobs = {'fwd': [(1, 0, 0), (2, 0, 0), (3, 0, 0), (4, 0, 0), (8, 0, 0)],
                      'dgrad': [(0, 1, 0), (0, 2, 0), (0, 4, 0), (0, 8, 0)],
-                     'wgrad': [(0, 0, 64), (0, 0, 128), (0, 0, 256), (0, 0, 512), (0, 0, 1024)]}[name]
+                     'wgrad': [(0, 0, 128), (0, 0, 256), (0, 0, 512), (0, 0, 1024), (0, 0, 2048)]}[name]
             for kn in knobs:
                 lib.d2p_conv_direct_tune(*kn)
                 t = min(timed(fn), timed(fn))
