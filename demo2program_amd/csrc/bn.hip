@@ -133,67 +133,74 @@ bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, co
     }
 }
 
-// One wavefront per (group, channel): lanes stride over the S partials, wave-reduce in fp64.
+// One wavefront per CHANNEL, looping over the groups in group order: lanes stride over the S
+// partials of a (group, channel), wave-reduce in fp64.  Doing all groups of a channel in one wave
+// lets the same launch finish what needs them in order: the moving-average updates (one per
+// group = one per reference BN call, models/model_full.py:373-379) in the forward kernel, and
+// dgamma / dbeta (sums over the groups) in the backward kernel.
 __global__ void __launch_bounds__(256)
 bn_finalize_fwd_kernel(int n, int C, int G, int S, const double* partial, float* mean, float* rstd,
-                       float* var_out) {
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+                       float* var_out, float* moving_mean, float* moving_var, float decay) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (idx >= G * C) return;
-    const int g = idx / C, c = idx - g * C;
-    double a = 0.0, b = 0.0;
-    for (int s = lane; s < S; s += 64) {
-        const double* p = partial + (((long)g * S + s) * C + c) * 2;
-        a += p[0];
-        b += p[1];
-    }
-    a = wave_reduce_sum(a);
-    b = wave_reduce_sum(b);
-    if (lane == 0) {
+    if (c >= C) return;
+    float mm = moving_mean ? moving_mean[c] : 0.f, mv = moving_var ? moving_var[c] : 0.f;
+    for (int g = 0; g < G; ++g) {
+        double a = 0.0, b = 0.0;
+        for (int s = lane; s < S; s += 64) {
+            const double* p = partial + (((long)g * S + s) * C + c) * 2;
+            a += p[0];
+            b += p[1];
+        }
+        a = wave_reduce_sum(a);
+        b = wave_reduce_sum(b);
         const double mu = a / n;
         double var = b / n - mu * mu;   // biased variance
         if (var < 0.0) var = 0.0;
-        mean[idx] = (float)mu;
-        rstd[idx] = (float)(1.0 / sqrt(var + BN_EPS));
-        if (var_out) var_out[idx] = (float)var;
+        if (lane == 0) {
+            const int idx = g * C + c;
+            mean[idx] = (float)mu;
+            rstd[idx] = (float)(1.0 / sqrt(var + BN_EPS));
+            if (var_out) var_out[idx] = (float)var;
+        }
+        // one moving-average update per group, in group order (same arithmetic as bn_update_moving_kernel)
+        mm = decay * mm + (1.f - decay) * (float)mu;
+        mv = decay * mv + (1.f - decay) * (float)var;
+    }
+    if (lane == 0 && moving_mean) {
+        moving_mean[c] = mm;
+        moving_var[c] = mv;
     }
 }
 
-// m12[(g*C+c)*2 + {0,1}] = (mean_g(dy), mean_g(dy*xhat)); gsum[(g*C+c)*2 + {0,1}] = raw sums
+// m12[(g*C+c)*2 + {0,1}] = (mean_g(dy), mean_g(dy*xhat)); dgamma / dbeta = sums over the groups
 __global__ void __launch_bounds__(256)
-bn_finalize_bwd_kernel(int n, int C, int G, int S, const double* partial, float* m12, double* gsum) {
-    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+bn_finalize_bwd_kernel(int n, int C, int G, int S, const double* partial, float* m12, float* dgamma,
+                       float* dbeta) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (idx >= G * C) return;
-    const int g = idx / C, c = idx - g * C;
-    double a = 0.0, b = 0.0;
-    for (int s = lane; s < S; s += 64) {
-        const double* p = partial + (((long)g * S + s) * C + c) * 2;
-        a += p[0];
-        b += p[1];
-    }
-    a = wave_reduce_sum(a);
-    b = wave_reduce_sum(b);
-    if (lane == 0) {
-        m12[(long)idx * 2 + 0] = (float)(a / n);
-        m12[(long)idx * 2 + 1] = (float)(b / n);
-        gsum[(long)idx * 2 + 0] = a;
-        gsum[(long)idx * 2 + 1] = b;
-    }
-}
-
-// dgamma / dbeta: sum over the groups in group order (gamma, beta are shared by all groups)
-__global__ void __launch_bounds__(256)
-bn_dparam_kernel(int C, int G, const double* gsum, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
     double sb = 0.0, sg = 0.0;
     for (int g = 0; g < G; ++g) {
-        sb += gsum[((long)g * C + c) * 2 + 0];
-        sg += gsum[((long)g * C + c) * 2 + 1];
+        double a = 0.0, b = 0.0;
+        for (int s = lane; s < S; s += 64) {
+            const double* p = partial + (((long)g * S + s) * C + c) * 2;
+            a += p[0];
+            b += p[1];
+        }
+        a = wave_reduce_sum(a);
+        b = wave_reduce_sum(b);
+        if (lane == 0) {
+            m12[((long)g * C + c) * 2 + 0] = (float)(a / n);
+            m12[((long)g * C + c) * 2 + 1] = (float)(b / n);
+        }
+        sb += a;
+        sg += b;
     }
-    if (dgamma) dgamma[c] = (float)sg;
-    if (dbeta) dbeta[c] = (float)sb;
+    if (lane == 0) {
+        if (dgamma) dgamma[c] = (float)sg;
+        if (dbeta) dbeta[c] = (float)sb;
+    }
 }
 
 __global__ void __launch_bounds__(256)
@@ -329,11 +336,14 @@ static inline int ew_blocks(long total) {
 
 extern "C" int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, const float* gamma,
                                 const float* beta, float* y, float* mean, float* rstd,
-                                float* var_out, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+                                float* var_out, float* moving_mean, float* moving_var, float decay,
+                                void* ws, size_t ws_bytes, d2p_stream_t stream) {
     int rc = bn_check(R, C, G, inner);
     if (rc) return rc;
     if (R == 0) return D2P_OK;
     D2P_REQUIRE(x && gamma && beta && y && mean && rstd, D2P_EINVAL, "bn fwd: null pointer");
+    D2P_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), D2P_EINVAL,
+                "bn fwd: moving_mean and moving_var go together");
     D2P_REQUIRE(ws && ws_bytes >= d2p_bn_ws_bytes(R, C, G), D2P_EWS,
                 "bn fwd: workspace too small (%zu < %zu)", ws_bytes, d2p_bn_ws_bytes(R, C, G));
     hipStream_t st = as_stream(stream);
@@ -350,8 +360,8 @@ extern "C" int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, 
                            (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, (const float*)nullptr,
                            (const float*)nullptr, (const float*)nullptr, partial);
     D2P_LAUNCH_CHECK("bn_partial_fwd");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, st, n, C, G,
-                       p.S, partial, mean, rstd, var_out);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, n, C, G,
+                       p.S, partial, mean, rstd, var_out, moving_mean, moving_var, decay);
     D2P_LAUNCH_CHECK("bn_finalize_fwd");
     const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma |
                                         (uintptr_t)beta | (uintptr_t)mean | (uintptr_t)rstd) & 15) == 0);
@@ -390,12 +400,9 @@ extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, 
         hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
                            (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, dy, mean, rstd, partial);
     D2P_LAUNCH_CHECK("bn_partial_bwd");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, st, n, C, G,
-                       p.S, partial, m12, gsum);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, n, C, G,
+                       p.S, partial, m12, dgamma, dbeta);
     D2P_LAUNCH_CHECK("bn_finalize_bwd");
-    hipLaunchKernelGGL(bn_dparam_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, G, gsum, dgamma,
-                       dbeta);
-    D2P_LAUNCH_CHECK("bn_dparam");
     const bool v4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
     float* colpart = (float*)((char*)m12 + align_up((size_t)G * C * 2 * sizeof(float), 16));
     if (dx_colsum) {

@@ -65,7 +65,7 @@ extern "C" int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, co
 
 // ---- column sum (bias gradients): two-stage, deterministic --------------------------
 // stage 1: block (cb, s) sums rows r = s*4+rl, step S*4, of 64 columns -> part[s][c];
-// stage 2: block per 64 columns, 4 lanes per column over the S partials, fixed-order tree.
+// stage 2: block per 16 columns x 16 lanes over the S partials, fixed-order tree.
 // S adapts so that ~2048 workgroups stream the matrix (HBM-bound: rows*cols*4 bytes).
 static inline int colsum_S(int rows, int cols) {
     const int cb = ceil_div(cols, 64);
@@ -101,20 +101,36 @@ colsum_stage1(int rows, int cols, const float* X, long ld, float* part) {
             (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 // fold > 1: the matrix was viewed as [rows/fold, cols*fold]; out[c] = sum_g colsum[g*cols + c]
+// Block = 16 columns x 16 partial-row lanes (all S*fold loads of a column are independent and in
+// flight together; 128 workgroups for 2048 columns instead of 32), fixed-order tree in LDS.
 __global__ void __launch_bounds__(256)
 colsum_stage2(int cols, int fold, int S, const float* part, float* out) {
-    __shared__ float red[4][64];
+    __shared__ float red[16][17];
     const int wc = cols * fold;                       // width of the partial rows
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int sl = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s = 0.f;
-    if (c < cols)
-        for (int i = sl; i < S; i += 4)
-            for (int g = 0; g < fold; ++g) s += part[(long)i * wc + g * cols + c];
-    red[sl][threadIdx.x & 63] = s;
+    if (c < cols) {
+        const int n = S * fold;                       // partial entries of this column
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int e = pl;
+        for (; e + 48 < n; e += 64) {
+            s0 += part[(long)(e / fold) * wc + (e % fold) * cols + c];
+            s1 += part[(long)((e + 16) / fold) * wc + ((e + 16) % fold) * cols + c];
+            s2 += part[(long)((e + 32) / fold) * wc + ((e + 32) % fold) * cols + c];
+            s3 += part[(long)((e + 48) / fold) * wc + ((e + 48) % fold) * cols + c];
+        }
+        for (; e < n; e += 16) s0 += part[(long)(e / fold) * wc + (e % fold) * cols + c];
+        s = (s0 + s1) + (s2 + s3);
+    }
+    red[pl][cl] = s;
     __syncthreads();
-    if (sl == 0 && c < cols)
-        out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    if (pl == 0 && c < cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][cl];
+        out[c] = t;
+    }
 }
 
 extern "C" size_t d2p_colsum_ws_bytes(int rows, int cols) {
@@ -140,7 +156,7 @@ extern "C" int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float
     hipLaunchKernelGGL(colsum_stage1, dim3(ceil_div(vcols, 64), S), dim3(256), 0, st, vrows, vcols, X,
                        (long)(fold > 1 ? vcols : ld), part);
     D2P_LAUNCH_CHECK("colsum_stage1");
-    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 64)), dim3(256), 0, st, cols, fold, S, part,
+    hipLaunchKernelGGL(colsum_stage2, dim3(ceil_div(cols, 16)), dim3(256), 0, st, cols, fold, S, part,
                        out);
     D2P_LAUNCH_CHECK("colsum_stage2");
     return D2P_OK;

@@ -173,8 +173,9 @@ def conv_dgrad(dy, w, x_shape, dx=None):
 
 
 # ---------------------------------------------------------------- batch norm
-def bn_fwd(x2d, gamma, beta, G, inner, y=None, mean=None, rstd=None, var=None):
-    """x2d [R,C]; returns (y, mean[G,C], rstd[G,C], var) -- var only if a buffer is passed."""
+def bn_fwd(x2d, gamma, beta, G, inner, y=None, mean=None, rstd=None, var=None, moving=None, decay=0.9):
+    """x2d [R,C]; returns (y, mean[G,C], rstd[G,C], var) -- var only if a buffer is passed.
+    moving = (moving_mean, moving_var) [C]: also applies this call's G moving-average updates."""
     _require_gpu(x2d)
     R, C = x2d.shape
     if y is None:
@@ -184,8 +185,9 @@ def bn_fwd(x2d, gamma, beta, G, inner, y=None, mean=None, rstd=None, var=None):
     if rstd is None:
         rstd = torch.empty(G, C, dtype=torch.float32, device=x2d.device)
     ws, wsb = SCRATCH.get(call.d2p_bn_ws_bytes(R, C, G))
+    mm, mv = moving if moving is not None else (None, None)
     call.d2p_bn_group_fwd(R, C, G, inner, ptr(x2d), ptr(gamma), ptr(beta), ptr(y), ptr(mean),
-                          ptr(rstd), ptr(var), ws, wsb, current_stream())
+                          ptr(rstd), ptr(var), ptr(mm), ptr(mv), decay, ws, wsb, current_stream())
     return y, mean, rstd, var
 
 

@@ -305,11 +305,9 @@ class Model(object):
             return y, None, None
         mean = self._buf(name + '/bn_mean', (G, C))
         rstd = self._buf(name + '/bn_rstd', (G, C))
-        var = self._buf(name + '/bn_var', (G, C)) if self.track_moving else None
-        K.bn_fwd(x2d, gamma, beta, G, inner, y=y, mean=mean, rstd=rstd, var=var)
-        if self.track_moving:
-            mm, mv = self.moving[name]
-            K.bn_update_moving(mean, var, mm, mv)       # G sequential updates
+        # the statistics kernel also applies the G moving-average updates
+        K.bn_fwd(x2d, gamma, beta, G, inner, y=y, mean=mean, rstd=rstd,
+                 moving=self.moving[name] if self.track_moving else None)
         return y, mean, rstd
 
     def _lstm_xproj(self, name, x2d, I, M, T, n_steps):

@@ -123,11 +123,15 @@ int d2p_conv_direct_tune(int fwd_tiles_per_wave, int dgrad_tiles_per_wave, int w
 size_t d2p_bn_ws_bytes(int R, int C, int G);
 int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, const float* gamma,
                      const float* beta, float* y, float* mean, float* rstd, float* var_out,
+                     float* moving_mean, float* moving_var, float decay,
                      void* ws, size_t ws_bytes, d2p_stream_t stream);
 int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float* dy,
                      const float* gamma, const float* mean, const float* rstd, int act_bwd,
                      float* dx, float* dgamma, float* dbeta, float* dx_colsum,
                      void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* d2p_bn_group_fwd's moving_mean / moving_var ([C], nullable together): the G moving-average
+ * updates of this call (one per group = one per reference BN call, in group order) are applied
+ * by the statistics kernel itself; d2p_bn_update_moving below is the same update stand-alone. */
 /* Inference mode (is_training=False, evaler.py:61): y = (x - moving_mean) * rsqrt(moving_var +
  * 1e-3) * gamma + beta per channel.  x, y: [R, C]. */
 int d2p_bn_inference_fwd(int R, int C, const float* x, const float* gamma, const float* beta,

@@ -48,5 +48,5 @@ def test_argument_errors_do_not_touch_the_gpu(d2p_lib):
     rc = d2p_lib.d2p_gemm_f32_nn(-1, 4, 4, None, 4, None, 4, None, 4, None, 0, 0, None, 0, None)
     assert rc == -1
     assert b'negative' in d2p_lib.d2p_last_error()
-    rc = d2p_lib.d2p_bn_group_fwd(10, 4, 3, 1, None, None, None, None, None, None, None, None, 0, None)
+    rc = d2p_lib.d2p_bn_group_fwd(10, 4, 3, 1, None, None, None, None, None, None, None, None, None, 0.9, None, 0, None)
     assert rc == -1

@@ -219,8 +219,15 @@ def test_bn_group_fwd_bwd(K, B, k, inner, C, act):
     yref.backward(dy)
     a_dev = dev(a)
     var = torch.empty(k, C, device='cuda')
-    y, mean, rstd, var = K.bn_fwd(a_dev, dev(gamma), dev(beta), k, inner, var=var)
+    mm_d, mv_d = torch.zeros(C, device='cuda'), torch.ones(C, device='cuda')
+    y, mean, rstd, var = K.bn_fwd(a_dev, dev(gamma), dev(beta), k, inner, var=var, moving=(mm_d, mv_d))
     close(y, yref, atol=1e-4)
+    mm_ref, mv_ref = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    for i in range(k):                               # one moving-average update per call
+        mm_ref = 0.9 * mm_ref + 0.1 * means[i]
+        mv_ref = 0.9 * mv_ref + 0.1 * vars_[i]
+    close(mm_d, mm_ref, atol=1e-5)
+    close(mv_d, mv_ref, atol=1e-5)
     close(mean, torch.stack(means), atol=1e-5)
     close(var, torch.stack(vars_), atol=1e-5)
     dgamma = torch.empty(C, device='cuda')
