@@ -512,6 +512,34 @@ def test_bn_moving_statistics_follow_reference_updates():
     assert _maxerr(model.moving['conv1'][1], mv) < 1e-5
 
 
+def test_headline_config_matches_oracle_at_full_size():
+    """BASELINE config 2 at its FULL size (Karel, B=32, k=10, T=20, L=50, U=512), on a batch of
+    real generated programs: loss, the three kinds of logits and every gradient tensor against
+    the fp64 CPU oracle (one oracle forward+backward, ~10-20 s of host time)."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.karel_env.generator import sample_batch
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.params import init_params
+    cfg = make_config('karel')
+    params = init_params(cfg, 123)
+    batch = sample_batch(cfg, seed=11)
+    model = Model(cfg, params=params)
+    loss = float(model.forward(model.get_feed_dict(batch)).item())
+    model.backward()
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    out, grads = run_oracle(cfg, params, batch, dtype=torch.float64)
+    assert abs(loss - float(out['loss'])) <= 1e-5 * abs(float(out['loss']))
+    assert _maxerr(model.pred_program, out['pred_program']) <= 1e-4
+    assert _maxerr(model.pred_action, out['pred_action'].permute(0, 1, 3, 2)) <= 1e-4
+    assert _maxerr(model.pred_per, out['pred_per'].permute(0, 1, 3, 2)) <= 1e-4
+    got = model.params.to_numpy('g')
+    # fp32 sums over 3 200 - 6 400 rows vs fp64: 1e-3 of the tensor's scale plus an absolute floor for the
+    # tensors whose true gradient is ~0 by cancellation (biases under a batch norm: exactly 0 for per/fc/b)
+    for n in grads:
+        ref = grads[n].numpy()
+        assert np.abs(got[n] - ref).max() <= 1e-3 * np.abs(ref).max() + 2e-6, (n, float(np.abs(ref).max()))
+
+
 def test_headline_config_properties():
     """BASELINE config 2 (Karel, B=32, k=10): too slow for a per-element oracle comparison in a
     unit test budget, so check size-independent properties: finite loss near the
