@@ -18,6 +18,8 @@ What is batched differently from the reference (results are identical, see DESIG
     [B*k*k, 2U] pair matrix (:335-341) is never materialised.
 Row order everywhere: sequences m = b*k + i; recurrent tensors are time-major [T, M, *].
 """
+import os
+
 import numpy as np
 import torch
 
@@ -92,10 +94,9 @@ class Model(object):
         self._ss_rng = torch.tensor([seed * 2654435761 + 12345, 0], dtype=torch.int64, device='cuda')
         if self.scheduled_sampling:
             self.set_sampling_step(int(global_step) if not callable(global_step) else 0)
-        self.fuse_decoders = False
+        self.fuse_decoders = os.environ.get('D2P_FUSE_DECODERS', '0') == '1'
         # independent GEMM-heavy work on a second stream (see forward/backward); set False (or
         # D2P_NO_SIDE_STREAM=1) to serialise everything on one stream, e.g. for per-kernel timing
-        import os
         self.use_side_stream = os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1'
         self._reserve_scratch()
 
