@@ -299,6 +299,29 @@ def main():
             trainer.train_step(trainer.model.get_feed_dict(host_batches[i % len(host_batches)]))
         torch.cuda.synchronize()
         out['value_incl_h2d'] = round(global_batch * n / dp.max_over_ranks(time.perf_counter() - t1), 3)
+        # the same with the trainer's prefetcher: next batch pinned + copied on a side stream meanwhile
+        from demo2program_amd.trainer import FeedPrefetcher
+
+        class _Cycle(object):
+            def __init__(self, bs):
+                self.bs, self.i = bs, 0
+
+            def next(self):
+                self.i += 1
+                return self.bs[self.i % len(self.bs)]
+
+        pf = FeedPrefetcher(trainer.model, _Cycle(host_batches))
+        for _ in range(8):          # every staging set of the ring allocated (pinned) before timing
+            trainer.train_step(pf.take())
+            pf.stage()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n):
+            trainer.train_step(pf.take())
+            pf.stage()
+        torch.cuda.synchronize()
+        out['value_incl_h2d_prefetched'] = round(global_batch * n / dp.max_over_ranks(time.perf_counter() - t1), 3)
+        pf.close()
 
     if not args.no_roofline:
         log('roofline leg')

@@ -46,6 +46,56 @@ class SyntheticBatches(object):
         return b
 
 
+class FeedPrefetcher(object):
+    """Stages the NEXT batch while the current step runs on the GPU: after a step has been
+    launched (asynchronously), `stage()` takes the next host batch_chunk from the input pipeline
+    and issues its host-to-device copies (and the NHWC4 padding of 3-channel frames) on a copy
+    stream; `take()` hands out that device-resident feed
+    after making the training stream wait for the copy event.  This is the reference's
+    queue-runner + feed_dict step (trainer.py:187-199) taken off the critical path; with uint8
+    frames one Karel batch is 6.5 MB of PCIe traffic.
+
+    Single-threaded on purpose: a loader thread doing this work fights the training thread for
+    the GIL (measured 3x slower than no prefetching at all); all that is needed is that the
+    staging happens between a step's launch and the next synchronisation point."""
+
+    def __init__(self, model, batches):
+        self.model, self.batches = model, batches
+        self.stream = torch.cuda.Stream()
+        self._staged = None
+        self.stage()
+
+    def stage(self):
+        """Host batch -> device feed on the copy stream.  The copies come from pageable memory, so the
+        host blocks in them -- but it does so AFTER the current step was launched, i.e. while the GPU
+        is busy, which is all the overlap that is needed.  (Copying into hipHostMalloc'ed staging
+        buffers first was measured 2x slower end to end: CPU writes into that memory are slow here.)"""
+        chunk = self.batches.next()
+        with torch.cuda.stream(self.stream):
+            feed = self.model.get_feed_dict(chunk)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self._staged = (feed, ev)
+
+    def take(self):
+        feed, ev = self._staged
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for v in feed.values():           # allocated on the copy stream, consumed on this one
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return feed
+
+    def next(self):
+        """take() + stage() for callers that do not separate launch and staging (no overlap)."""
+        feed = self.take()
+        self.stage()
+        return feed
+
+    def close(self):
+        pass
+
+
 class Trainer(object):
 
     @staticmethod
@@ -188,11 +238,18 @@ class Trainer(object):
         return m.loss
 
     def run_single_step(self, batch, step=None, is_train=True):
-        """trainer.py:186-205: step_time spans batch fetch + feed + run."""
+        """trainer.py:186-205: step_time spans batch fetch + feed + run.  A FeedPrefetcher hands
+        over feeds that are already on the device (the fetch + feed of the next batch overlaps
+        this step)."""
         _start_time = time.time()
-        batch_chunk = batch.next()
-        feed = self.model.get_feed_dict(batch_chunk, step=step, is_training=is_train)
-        loss = self.train_step(feed)
+        if isinstance(batch, FeedPrefetcher):
+            feed = batch.take()
+            loss = self.train_step(feed)
+            batch.stage()                 # next batch: host work + H2D while this step runs
+        else:
+            batch_chunk = batch.next()
+            feed = self.model.get_feed_dict(batch_chunk, step=step, is_training=is_train)
+            loss = self.train_step(feed)
         loss_value = float(loss.item())             # the reference fetches the loss every step
         _end_time = time.time()
         return self.global_step, None, loss_value, None, (_end_time - _start_time)
@@ -213,11 +270,12 @@ class Trainer(object):
         _end_time = time.time()
         return self.global_step, self.last_test_report, loss_value, None, (_end_time - _start_time)
 
-    def train(self, max_steps=1000000):
+    def train(self, max_steps=1000000, prefetch=True):
         ckpt_save_step = 1000
+        source = FeedPrefetcher(self.model, self.batch_train) if prefetch else self.batch_train
         for s in range(max_steps):
             step, train_summary, loss, output, step_time = \
-                self.run_single_step(self.batch_train, step=s, is_train=True)
+                self.run_single_step(source, step=s, is_train=True)
             if s % self.log_step == 0:
                 self.log_step_message(step, loss, step_time)
             if s % self.test_sample_step == 0:
