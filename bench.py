@@ -257,8 +257,11 @@ def main():
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
     for i in range(args.steps):
         loss = trainer.train_step(feeds[i % len(feeds)])
+        marks[i + 1].record()             # device-side step boundaries (no host sync inside the region)
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -266,6 +269,9 @@ def main():
     final_loss = float(loss.item())
     log('timed region done: %.3f s' % elapsed)
 
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_stats = {'median': round(per_step[len(per_step) // 2], 4), 'p10': round(per_step[len(per_step) // 10], 4),
+                  'p90': round(per_step[(len(per_step) * 9) // 10], 4)} if per_step else None
     global_batch = config.batch_size * dp.world_size
     value = global_batch * args.steps / elapsed
     out = {
@@ -287,6 +293,7 @@ def main():
             'lstm_units': config.num_lstm_cell_units,
         },
         'demo_instances_per_sec': round(value * config.k, 1),
+        'device_step_ms': step_stats,
         'final_loss': round(final_loss, 5),
     }
 
