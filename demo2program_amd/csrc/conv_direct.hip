@@ -547,6 +547,7 @@ extern "C" int d2p_conv_direct_tune(int fwd_tpw, int dgrad_tpw, int wgrad_wgs) {
     if (wgrad_wgs != 0) d2p_conv_frames_wgrad_cap(wgrad_wgs > 0 ? wgrad_wgs : 0);
     if (wgrad_wgs != 0) d2p_conv_rows_tune(wgrad_wgs);
     if (fwd_tpw != 0) d2p_conv_frames_tune(fwd_tpw > 0 ? fwd_tpw : 0);
+    if (fwd_tpw > 0) d2p_conv_rows_fwd_tune(fwd_tpw * 256);
     return D2P_OK;
 }
 
@@ -567,7 +568,9 @@ int d2p_conv_direct_fwd(const ConvGeom& g, const void* x, int x_is_u8, const flo
                         int act, float* y, hipStream_t st) {
     if (!g_direct_fwd) return 0;
     if (g_direct_fwd >= 2) {
-        const int rc = d2p_conv_frames_fwd(g, x, x_is_u8, w, bias, act, y, st);
+        int rc = d2p_conv_frames_fwd(g, x, x_is_u8, w, bias, act, y, st);
+        if (rc != 0) return rc;
+        rc = d2p_conv_rows_fwd(g, x, x_is_u8, w, bias, act, y, st);
         if (rc != 0) return rc;
     }
     if (((uintptr_t)x & (x_is_u8 ? 3 : 15)) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;

@@ -221,6 +221,118 @@ conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, fl
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// forward for the 3(4)-channel first layer: same staging, one output row per strip, 16-pixel MFMA
+// tiles along the row (the last tile of a 40-pixel row is half empty: 17 % padding, the price of
+// keeping every tile inside one row so that all offsets are per-lane constants).
+template <int CIN, int COUT, int W>
+struct FwdRowShape {
+    static constexpr int Wo = r_out(W), PL = r_before(W);
+    static constexpr int NTILE = (Wo + 15) / 16;
+    static constexpr int PSF = CIN == 4 ? 4 : CIN + 4;
+    static constexpr int ROWPIX = 32 * NTILE + 4;
+    static constexpr int ROWF = ROWPIX * PSF;
+    static constexpr int IMG = 3 * ROWF;
+    static constexpr int NCH = CIN == 4 ? 3 : 9 * (CIN / 16);
+    static constexpr int NB = COUT / 16;
+    static constexpr int RP4 = W * CIN / 4, NLF = (3 * RP4 + 63) / 64;
+    static constexpr int RP16 = W * CIN / 16, NLU = (3 * RP16 + 63) / 64;
+    static_assert(W + 2 <= ROWPIX, "staged row must hold the image row and its halo");
+};
+
+template <int CIN, int COUT, int W, typename T>
+__global__ void __launch_bounds__(256)
+conv_rows_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int act,
+                     float* __restrict__ y, int nframes, int H, int Ho, int pt) {
+    using S = FwdRowShape<CIN, COUT, W>;
+    constexpr int NCH = S::NCH, NB = S::NB, PSF = S::PSF, Wo = S::Wo, KK = 9 * CIN;
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, p = lane & 15, q = lane >> 4, wid = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wid, NW = gridDim.x * 4;
+    float* const img = lds + (size_t)wid * S::IMG;
+    for (int i = lane; i < S::IMG; i += 64) img[i] = 0.f;
+
+    // B-fragment offset of tile 0 per 16-deep chunk (a tile advances 32 input pixels); filter -> registers
+    int boff[NCH];
+    float bmask[NCH];
+    float wr[NCH][4][NB];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        int tap, c0;
+        if (CIN == 4) { tap = 4 * ch + q; c0 = 0; }
+        else { tap = ch / (CIN / 16); c0 = (ch % (CIN / 16)) * 16 + 4 * q; }
+        const bool ok = tap < 9;
+        const int ky = ok ? tap / 3 : 0, kx = ok ? tap % 3 : 0;
+        boff[ch] = ky * S::ROWF + (2 * p - S::PL + kx + 1) * PSF + c0;
+        bmask[ch] = ok ? 1.f : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kg = CIN == 4 ? tap * 4 + j : tap * CIN + c0 + j;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) wr[ch][j][b] = (ok && kg < KK) ? w[kg * COUT + b * 16 + p] : 0.f;
+        }
+    }
+    f32x4 bv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) bv[b] = bias ? *reinterpret_cast<const f32x4*>(bias + b * 16 + 4 * q)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nstrips = nframes * Ho;
+    const long frame_elems = (long)H * W * CIN;
+    RowStager<T, S, CIN, W> st;
+    for (int strip = wave; strip < nstrips; strip += NW) {
+        const int n = strip / Ho, oy = strip - n * Ho;
+        st.load(x, (long)n * frame_elems, 2 * oy - pt, H, lane);
+        st.store(img, lane);
+#pragma unroll
+        for (int t = 0; t < S::NTILE; ++t) {
+            f32x4 acc[2][NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[0][b] = acc[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                f32x4 bb = *reinterpret_cast<const f32x4*>(img + boff[ch] + t * 32 * PSF);
+                if (CIN == 4 && ch == NCH - 1) bb *= bmask[ch];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[j & 1][b] = D2P_MFMA16(wr[ch][j][b], bb[j], acc[j & 1][b]);
+            }
+            const int ox = 16 * t + p;
+            if (ox < Wo) {
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    f32x4 o = (acc[0][b] + acc[1][b]) + bv[b];
+                    if (act) { o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w); }
+                    *reinterpret_cast<f32x4*>(y + ((long)strip * Wo + ox) * COUT + b * 16 + 4 * q) = o;
+                }
+            }
+        }
+    }
+}
+
+int g_rows_fwd_wgs = 2048;
+
+template <int CIN, int COUT, int W, typename T>
+int launch_rows_fwd(const ConvGeom& g, const T* x, const float* w, const float* bias, int act, float* y, hipStream_t st) {
+    using S = FwdRowShape<CIN, COUT, W>;
+    constexpr size_t lds_bytes = (size_t)4 * S::IMG * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_fwd_kernel<CIN, COUT, W, T>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    int nb = ceil_div(g.N * g.Ho, 4 * 4);                 // >= 4 strips per wave
+    if (nb > g_rows_fwd_wgs) nb = g_rows_fwd_wgs;
+    if (nb < 1) nb = 1;
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * 9 * CIN * COUT);
+    hipLaunchKernelGGL((conv_rows_fwd_kernel<CIN, COUT, W, T>), dim3(nb), dim3(256), lds_bytes, st, x, w, bias, act, y,
+                       g.N, g.H, g.Ho, g.pt);
+    D2P_LAUNCH_CHECK("conv_rows_fwd");
+    return 1;
+}
+
 int g_rows_wgrad_wgs = 0;      // 0: per-layer default (template CAP)
 
 template <int CIN, int COUT, int W, typename T, int CAP>
@@ -263,11 +375,20 @@ struct RowsWgrad {
 }   // namespace
 
 void d2p_conv_rows_tune(int wgrad_wgs) { g_rows_wgrad_wgs = wgrad_wgs > 0 ? wgrad_wgs : 0; }
+void d2p_conv_rows_fwd_tune(int wgs) { if (wgs > 0) g_rows_fwd_wgs = wgs; }
 
 static int rows_key(const ConvGeom& g) {
     if (g.Cin == 4 && g.Cout == 16 && g.W == 80) return 1;
     if (g.Cin == 16 && g.Cout == 32 && g.W == 40) return 2;
     return 0;
+}
+
+int d2p_conv_rows_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act,
+                      float* y, hipStream_t st) {
+    if (!(g.Cin == 4 && g.Cout == 16 && g.W == 80) || g.N < 1) return 0;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
+    if (x_is_u8) return launch_rows_fwd<4, 16, 80, uint8_t>(g, (const uint8_t*)x, w, bias, act, y, st);
+    return launch_rows_fwd<4, 16, 80, float>(g, (const float*)x, w, bias, act, y, st);
 }
 
 size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g) {
