@@ -543,6 +543,7 @@ static int g_direct_fwd_tpw = 2, g_direct_dgrad_tpw = 2, g_direct_wgrad_wgs = 25
 extern "C" int d2p_conv_direct_tune(int fwd_tpw, int dgrad_tpw, int wgrad_wgs) {
     if (fwd_tpw > 0) g_direct_fwd_tpw = fwd_tpw;
     if (dgrad_tpw > 0) g_direct_dgrad_tpw = dgrad_tpw;
+    if (dgrad_tpw > 0) d2p_conv_rows_dgrad_tune(dgrad_tpw * 256);
     if (wgrad_wgs > 0) g_direct_wgrad_wgs = wgrad_wgs;
     if (wgrad_wgs != 0) d2p_conv_frames_wgrad_cap(wgrad_wgs > 0 ? wgrad_wgs : 0);
     if (wgrad_wgs != 0) d2p_conv_rows_tune(wgrad_wgs);
@@ -618,6 +619,10 @@ static int launch_dgrad(const ConvGeom& g, const float* dy, const float* w, floa
 
 int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
     if (!g_direct_dgrad) return 0;
+    if (g_direct_dgrad >= 2) {
+        const int rc = d2p_conv_rows_dgrad(g, dy, w, dx, st);
+        if (rc != 0) return rc;
+    }
     if (((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return 0;
     const int mask = tap_mask_for(g);
     const int key = g.Cin * 100 + g.Cout;

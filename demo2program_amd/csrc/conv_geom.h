@@ -51,5 +51,7 @@ size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g);
 int d2p_conv_rows_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act,
                       float* y, hipStream_t st);
 void d2p_conv_rows_fwd_tune(int workgroups);
+int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
+void d2p_conv_rows_dgrad_tune(int workgroups);
 void d2p_conv_rows_tune(int wgrad_workgroups);
 void d2p_conv_frames_wgrad_cap(int cap);

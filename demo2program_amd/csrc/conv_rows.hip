@@ -12,6 +12,7 @@
 #include "conv_geom.h"
 #include "gemm_core.h"
 #include "prof.h"
+#include <type_traits>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define D2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
@@ -333,6 +334,165 @@ int launch_rows_fwd(const ConvGeom& g, const T* x, const float* w, const float* 
     return 1;
 }
 
+// ------------------------------------------------------------------------------------------
+// dgrad for 40x40x16 <- 20x20x32: dX[iy, ix, ci] = sum over the taps whose parity matches
+// (ky = (iy + pt) mod 2 (+2), kx likewise) of dY[(iy + pt - ky)/2, (ix + pl - kx)/2, :] . W[ky, kx, ci, :].
+// A strip is TWO input rows of equal row parity (so 2 x 20 = 40 pixels per column-parity class =
+// 3 MFMA tiles, 17 % padding instead of 37 % for one row); the 2-3 dY rows they need are staged
+// with a zero halo pixel on both sides.  Per column-parity class only its 1, 2 or 4 taps are
+// multiplied (2.25 per pixel on average, as in the parity-class GEMMs of conv.hip).
+template <int CIN, int COUT, int W>
+struct DgradRowShape {
+    static constexpr int Wo = r_out(W), PL = r_before(W);
+    static constexpr int PSF = COUT + 4;                     // floats per staged dY pixel
+    static constexpr int ROWPIX = Wo + 2;
+    static constexpr int ROWF = ROWPIX * PSF;
+    static constexpr int NROW = 3;
+    static constexpr int IMG = NROW * ROWF + 4;
+    static constexpr int CC = COUT / 16;
+    static constexpr int RP4 = Wo * COUT / 4;                // float4 pieces per dY row
+    static constexpr int NL = (NROW * RP4 + 63) / 64;
+    // pixels of one column-parity class in a 2-row strip, and its 16-pixel tiles
+    static constexpr int X0 = (PL & 1) ? 1 : 0;              // first ix with (ix + pl) even
+    static constexpr int NC0 = (W - X0 + 1) / 2, NC1 = (W - (1 - X0) + 1) / 2;
+    static constexpr int NT0 = (2 * NC0 + 15) / 16, NT1 = (2 * NC1 + 15) / 16;
+    static_assert(CIN == 16, "one 16-channel block of dX per MFMA row tile");
+};
+
+template <int CIN, int COUT, int W>
+__global__ void __launch_bounds__(256)
+conv_rows_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int nframes,
+                       int H, int Ho, int pt) {
+    using S = DgradRowShape<CIN, COUT, W>;
+    constexpr int CC = S::CC, PSF = S::PSF, Wo = S::Wo, PL = S::PL, NL = S::NL;
+    extern __shared__ float lds[];
+    const int lane = threadIdx.x & 63, p = lane & 15, q = lane >> 4, wid = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + wid, NW = gridDim.x * 4;
+    float* const img = lds + (size_t)wid * S::IMG;
+    for (int i = lane; i < S::IMG; i += 64) img[i] = 0.f;
+
+    // W^T -> registers: wr[tap][cc][j] = W[tap][ci = p][co = 16 cc + 4q + j]
+    float wr[9][CC][4];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int cc = 0; cc < CC; ++cc)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wr[tap][cc][j] = w[(tap * CIN + p) * COUT + cc * 16 + 4 * q + j];
+
+    // per-lane pixel of tile t in column-parity class ex: idx = 16 t + p -> (row j, column i of the class)
+    constexpr int NTMAX = S::NT0 > S::NT1 ? S::NT0 : S::NT1;
+    int poff[2][NTMAX], xoff[2][NTMAX];
+#pragma unroll
+    for (int ex = 0; ex < 2; ++ex) {
+        const int nc = ex == 0 ? S::NC0 : S::NC1;
+        const int ix0 = ex == 0 ? S::X0 : 1 - S::X0;
+        const int oxb = (ix0 + PL - ex) / 2;                  // ox of column i = 0 for the tap with kx = ex
+#pragma unroll
+        for (int t = 0; t < NTMAX; ++t) {
+            const int idx = 16 * t + p;
+            const bool ok = idx < 2 * nc;
+            const int idc = ok ? idx : 2 * nc - 1;            // padding lanes re-read the last pixel, store nothing
+            const int j = idc / nc, i = idc - j * nc;
+            poff[ex][t] = (j * S::ROWPIX + i + oxb + 1) * PSF + 4 * q;
+            xoff[ex][t] = ok ? (2 * j * W + ix0 + 2 * i) * CIN + 4 * q : -1;
+        }
+    }
+
+    // strips: per frame, rows of parity class ey = (iy + pt) & 1, two at a time
+    const int e0 = pt & 1;                                   // first iy with (iy + pt) even
+    const int n0 = (H - e0 + 1) / 2, n1 = (H - (1 - e0) + 1) / 2;
+    const int s0 = (n0 + 1) / 2, s1 = (n1 + 1) / 2, per_frame = s0 + s1;
+    const long nstrips = (long)nframes * per_frame;
+    for (long strip = wave; strip < nstrips; strip += NW) {
+        const int n = (int)(strip / per_frame);
+        int sidx = (int)(strip - (long)n * per_frame);
+        const int ey = sidx >= s0 ? 1 : 0;
+        if (ey) sidx -= s0;
+        const int iy0 = (ey ? 1 - e0 : e0) + 4 * sidx;       // rows iy0 and iy0 + 2
+        // staged dY rows r = 0..2 <-> oy = oy_first + r ; ey = 0: taps ky = 0 (r = j + 1) and ky = 2 (r = j);
+        // ey = 1: tap ky = 1 (r = j)
+        const int oy_first = ey ? (iy0 + pt - 1) / 2 : (iy0 + pt) / 2 - 1;
+        f32x4 st[NL];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int jj = i * 64 + lane;
+            const int r = jj / S::RP4, wi = jj - r * S::RP4;
+            const int oy = oy_first + r;
+            const bool ok = (r < S::NROW) & (oy >= 0) & (oy < Ho);
+            const int oyc = min(max(oy, 0), Ho - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(dy + (((long)n * Ho + oyc) * Wo) * COUT + (r < S::NROW ? wi : 0) * 4);
+            st[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int jj = i * 64 + lane;
+            const int r = jj / S::RP4, wi = jj - r * S::RP4;
+            if (r < S::NROW)
+                *reinterpret_cast<f32x4*>(img + (r * S::ROWPIX + wi / (COUT / 4) + 1) * PSF + (wi % (COUT / 4)) * 4) = st[i];
+        }
+        float* const out = dx + ((long)n * H + iy0) * W * CIN;
+        const bool row1 = iy0 + 2 < H;
+        auto run = [&](auto EYc) {
+            constexpr int EY = decltype(EYc)::value;
+#pragma unroll
+            for (int ex = 0; ex < 2; ++ex) {
+                const int nt = ex == 0 ? S::NT0 : S::NT1;
+#pragma unroll
+                for (int t = 0; t < NTMAX; ++t) {
+                    if (t >= nt) continue;
+                    f32x4 acc[2];
+                    acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ty = 0; ty < (EY ? 1 : 2); ++ty)
+#pragma unroll
+                        for (int tx = 0; tx < (ex ? 1 : 2); ++tx) {
+                            const int ky = EY ? 1 : 2 * ty, kx = ex ? 1 : 2 * tx;
+                            // row: ky = 0 -> r = j + 1, ky = 2 -> r = j, ky = 1 -> r = j;  column: kx = 2 -> ox - 1
+                            const int toff = ((EY == 0 && ky == 0) ? S::ROWF : 0) - ((ex == 0 && kx == 2) ? PSF : 0);
+#pragma unroll
+                            for (int cc = 0; cc < CC; ++cc) {
+                                const f32x4 bb = *reinterpret_cast<const f32x4*>(img + poff[ex][t] + toff + cc * 16);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    acc[j & 1] = D2P_MFMA16(wr[ky * 3 + kx][cc][j], bb[j], acc[j & 1]);
+                            }
+                        }
+                    const int xo = xoff[ex][t];
+                    // second row of the strip may be past the image (odd row count)
+                    if (xo >= 0 && (row1 || xo < W * CIN))
+                        *reinterpret_cast<f32x4*>(out + xo) = acc[0] + acc[1];
+                }
+            }
+        };
+        if (ey) run(std::integral_constant<int, 1>{});
+        else run(std::integral_constant<int, 0>{});
+    }
+}
+
+int g_rows_dgrad_wgs = 512;     // measured best (occupancy-limited: 160 VGPRs, 38 KB LDS per workgroup)
+
+template <int CIN, int COUT, int W>
+int launch_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+    using S = DgradRowShape<CIN, COUT, W>;
+    constexpr size_t lds_bytes = (size_t)4 * S::IMG * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_dgrad_kernel<CIN, COUT, W>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        attr_set = true;
+    }
+    long strips = (long)g.N * ((g.H + 3) / 4 * 2 + 2);
+    int nb = (int)((strips + 15) / 16);
+    if (nb > g_rows_dgrad_wgs) nb = g_rows_dgrad_wgs;
+    if (nb < 1) nb = 1;
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * 9 * CIN * COUT);
+    hipLaunchKernelGGL((conv_rows_dgrad_kernel<CIN, COUT, W>), dim3(nb), dim3(256), lds_bytes, st, dy, w, dx, g.N, g.H,
+                       g.Ho, g.pt);
+    D2P_LAUNCH_CHECK("conv_rows_dgrad");
+    return 1;
+}
+
 int g_rows_wgrad_wgs = 0;      // 0: per-layer default (template CAP)
 
 template <int CIN, int COUT, int W, typename T, int CAP>
@@ -390,6 +550,13 @@ int d2p_conv_rows_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float
     if (x_is_u8) return launch_rows_fwd<4, 16, 80, uint8_t>(g, (const uint8_t*)x, w, bias, act, y, st);
     return launch_rows_fwd<4, 16, 80, float>(g, (const float*)x, w, bias, act, y, st);
 }
+
+int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+    if (!(g.Cin == 16 && g.Cout == 32 && g.W == 40) || g.N < 1) return 0;
+    if (((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return 0;
+    return launch_rows_dgrad<16, 32, 40>(g, dy, w, dx, st);
+}
+void d2p_conv_rows_dgrad_tune(int wgs) { if (wgs > 0) g_rows_dgrad_wgs = wgs; }
 
 size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g) {
     if (!rows_key(g)) return 0;
