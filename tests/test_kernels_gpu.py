@@ -41,7 +41,8 @@ def rnd(*shape, seed=0, scale=1.0):
 @pytest.mark.parametrize('M,N,K_', [(64, 64, 16), (70, 50, 37), (320, 2048, 512), (6400, 6, 512),
                                     (33, 512, 5), (1, 1, 1), (130, 260, 1030), (144, 16, 20480), (36, 16, 40961),
                                     (288, 48, 12000), (432, 48, 8200),
-                                    (1024, 1024, 64)])
+                                    (1024, 1024, 64), (6400, 5, 512), (1600, 50, 512), (37, 64, 260), (6400, 512, 6),
+                                    (333, 512, 16), (512, 6, 6400), (5, 512, 6400), (512, 50, 1600), (3, 700, 2048)])
 def test_gemm_nn_nt_tn(K, M, N, K_):
     A = rnd(M, K_, seed=1)
     B = rnd(K_, N, seed=2)
