@@ -200,6 +200,7 @@ class Trainer(object):
         from .lib import load
         return bool(getattr(load(), '_d2p_prof_on', False))
 
+    MAX_GRAPHS = 128      # distinct (n_prog, n_demo) pairs kept as instantiated graphs
     _STATIC_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'program_len',
                     'demo_len')
 
@@ -216,6 +217,11 @@ class Trainer(object):
         key = (feed['n_prog'], feed['n_demo'])
         static = dict(sf, n_prog=key[0], n_demo=key[1], id=feed.get('id'), host=feed.get('host'))
         g = self._graphs.get(key)
+        if g is None and len(self._graphs) >= self.MAX_GRAPHS:
+            # an unusually ragged dataset: stop instantiating graphs, run further new shapes eagerly
+            loss = m.forward(static)
+            m.backward()
+            return loss
         if g is None:
             # one eager pass sizes every buffer / scratch, then capture the same schedule; the
             # BN moving statistics are restored so the warm-up does not count as a step

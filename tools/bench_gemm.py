@@ -11,6 +11,9 @@ from demo2program_amd import build, kernels as K  # noqa: E402
 from demo2program_amd.lib import load  # noqa: E402
 
 SHAPES = [  # (kind, M, N, K, label)
+    ('nn', 320, 512, 512, 'rn fc1 P/Q      (320x512, K=512)'),
+    ('nt', 320, 512, 512, 'rn fc1 dfeat    (320x512, K=512)'),
+    ('tn', 512, 512, 320, 'rn fc1 dW       (512x512, K=320)'),
     ('tn', 512, 2048, 6400, 'dW  = X^T dZ   (512x2048, K=6400)'),
     ('nn', 6400, 2048, 512, 'z   = X Wx     (6400x2048, K=512)'),
     ('nt', 6400, 512, 2048, 'dX  = dZ Wx^T  (6400x512, K=2048)'),
@@ -35,6 +38,9 @@ def timed(fn, reps=30):
 
 
 def main():
+    only = len(sys.argv) > 1 and sys.argv[1] == 'small'
+    if only:
+        del SHAPES[3:]
     build.build_library()
     lib = load()
     g = torch.Generator().manual_seed(0)
@@ -59,6 +65,8 @@ def main():
         for rnd in range(2):
             for name, tile, sp in variants:
                 if sp and Kd // sp < 64:
+                    continue
+                if only and name.split()[0] not in ('auto', '64x64'):
                     continue
                 lib.d2p_gemm_force_plan(tile, sp)
                 res.setdefault(name, []).append(timed(fn, 20))
