@@ -412,6 +412,27 @@ def test_trainer_on_the_converted_reference_dataset():
     tr.batch_test.close()
 
 
+def test_trainer_and_evaler_command_lines(tmp_path, monkeypatch, capsys):
+    """The two entry points with the reference's flags: `trainer` trains on the converted reference
+    dataset, logs the reference's line, saves model-<step>.npz; `evaler --train_dir` picks the
+    newest checkpoint, evaluates generated programs and writes the summary file."""
+    import glob
+    from demo2program_amd import evaler, trainer
+    monkeypatch.chdir(tmp_path)
+    ds = os.path.join(GOLDEN, 'karel_dataset')
+    trainer.main(['--dataset_path', ds, '--batch_size', '4', '--num_k', '3', '--num_lstm_cell_units', '64',
+                  '--max_steps', '12', '--prefix', 'clitest'])
+    out = capsys.readouterr().out
+    assert ' [train step' in out and 'instances/sec' in out and ' [val   step' in out
+    dirs = glob.glob(str(tmp_path / 'train_dir' / 'karel-*clitest*'))
+    assert len(dirs) == 1 and os.path.exists(os.path.join(dirs[0], 'model-1.npz'))
+    evaler.main(['--train_dir', dirs[0], '--batch_size', '4', '--num_k', '3', '--num_lstm_cell_units', '64',
+                 '--max_steps', '2', '--output_dir', str(tmp_path / 'eval')])
+    out = capsys.readouterr().out
+    assert 'Loaded from checkpoint!' in out and '[Final Avg Report]' in out and 'greedy_exact_program_accuracy' in out
+    assert glob.glob(os.path.join(dirs[0], 'model-*_report_testdata8_num_k3.txt'))
+
+
 def test_feed_prefetcher_equals_direct_feeding():
     """FeedPrefetcher (loader thread, pinned buffers, copy stream) hands out the same feeds in the
     same order as feeding host batches directly: identical losses step by step."""
