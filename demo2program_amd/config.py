@@ -13,11 +13,12 @@ PRESETS = {
                   h=8, w=8, depth=16, dim_program_token=50, action_space=6, per_dim=5),
     # 4: ViZDoom full model, 1 GPU
     'vizdoom': dict(dataset_type='vizdoom', batch_size=32, k=10, max_demo_len=20, max_program_len=32,
-                    h=80, w=80, depth=3, dim_program_token=42, action_space=12, per_dim=6),
+                    h=80, w=80, depth=3, dim_program_token=42, action_space=12, per_dim=6,
+                    perception_type='simple', level='not_simple'),
     # 5 (per rank): ViZDoom k=25, 16 programs per rank
     'vizdoom_k25': dict(dataset_type='vizdoom', batch_size=16, k=25, max_demo_len=20,
                         max_program_len=32, h=80, w=80, depth=3, dim_program_token=42,
-                        action_space=12, per_dim=6),
+                        action_space=12, per_dim=6, perception_type='simple', level='not_simple'),
 }
 
 
@@ -62,3 +63,50 @@ def conv_shapes(config):
 def feature_dim(config):
     _, _, _, cout, ho, wo = conv_shapes(config)[-1]
     return ho * wo * cout
+
+
+def dataset_module(dataset_type):
+    """The reader module the reference imports per dataset type (trainer.py:294-300)."""
+    if dataset_type == 'karel':
+        from .karel_env import dataset_karel as dataset
+    elif dataset_type == 'vizdoom':
+        from .vizdoom_env import dataset_vizdoom as dataset
+    else:
+        raise ValueError(dataset_type)
+    return dataset
+
+
+def input_ops_module(dataset_type):
+    if dataset_type == 'karel':
+        from .karel_env import input_ops_karel as ops
+    elif dataset_type == 'vizdoom':
+        from .vizdoom_env import input_ops_vizdoom as ops
+    else:
+        raise NotImplementedError('The dataset related code is not implemented.')
+    return ops
+
+
+def has_dataset(path):
+    import os
+    return os.path.exists(os.path.join(path, 'data_info.json')) or os.path.exists(os.path.join(path, 'data.hdf5'))
+
+
+def config_from_dataset(config, dataset):
+    """Data dimensions from the first example and the dataset's DSL / environment fields
+    (trainer.py:306-335, evaler.py:457-488)."""
+    data = dataset.get_data(dataset.ids[0])
+    program, _, s_h, test_s_h, a_h, _, _, _, _, _, _, per, _ = data[:13]
+    config.dim_program_token, config.max_program_len = int(program.shape[0]), int(program.shape[1])
+    config.k, config.test_k, config.max_demo_len = int(s_h.shape[0]), int(test_s_h.shape[0]), int(s_h.shape[1])
+    config.h, config.w, config.depth = (int(v) for v in s_h.shape[2:5])
+    config.action_space, config.per_dim = int(a_h.shape[2]), int(per.shape[2])
+    if config.dataset_type == 'karel':
+        config.dsl_type, config.env_type = dataset.dsl_type, dataset.env_type
+        config.vizdoom_pos_keys, config.vizdoom_max_init_pos_len = [], -1
+        config.perception_type, config.level = '', None
+    else:
+        config.dsl_type = config.env_type = 'vizdoom_default'
+        config.vizdoom_pos_keys = dataset.vizdoom_pos_keys
+        config.vizdoom_max_init_pos_len = dataset.vizdoom_max_init_pos_len
+        config.perception_type, config.level = dataset.perception_type, dataset.level
+    return config

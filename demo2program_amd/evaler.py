@@ -18,7 +18,7 @@ import time
 import numpy as np
 import torch
 
-from .config import make_config
+from .config import config_from_dataset, dataset_module, has_dataset, input_ops_module, make_config
 
 
 class Evaler(object):
@@ -39,7 +39,12 @@ class Evaler(object):
         self.output_dir = getattr(config, 'output_dir', None) or self.train_dir or '.'
         self.batch_size = config.batch_size
         self.dataset = dataset
-        self.batch = dataset
+        if hasattr(dataset, 'get_data'):
+            # a reference-style Dataset gets the input ops of evaler.py:45-56 (in order, no shuffling)
+            _, self.batch = input_ops_module(config.dataset_type).create_input_ops(
+                dataset, self.batch_size, is_training=False, shuffle=False, frames_dtype=np.uint8)
+        else:
+            self.batch = dataset            # anything with .next()
         Model = self.get_model_class(config.model)
         self.model = Model(config, is_train=False)
         self.global_step = 0
@@ -79,6 +84,7 @@ class Evaler(object):
         loss, acc = m.report(with_greedy=True)
         hist = dict(m.report_hist)
         have_rows = bool(getattr(m, '_program_rows', None))
+        have_exec = have_rows and 'program_num_execution_correct' in m._program_rows   # needs an environment
         B = self.batch_size
         none = [None] * B
         out = (
@@ -90,10 +96,10 @@ class Evaler(object):
             m.ground_truth_program.cpu().numpy(), m.program_len.cpu().numpy(),
             None,                                           # model.output: not materialised here
             batch_chunk.get('id', np.arange(B)) if hasattr(batch_chunk, 'get') else np.arange(B),
-            m.program_num_execution_correct if have_rows else none,
-            m.program_is_correct_execution if have_rows else none,
-            m.greedy_num_execution_correct if have_rows else none,
-            m.greedy_is_correct_execution if have_rows else none,
+            m.program_num_execution_correct if have_exec else none,
+            m.program_is_correct_execution if have_exec else none,
+            m.greedy_num_execution_correct if have_exec else none,
+            m.greedy_is_correct_execution if have_exec else none,
             time.time() - _start_time,
         )
         return out
@@ -133,11 +139,13 @@ class Evaler(object):
                     if pid not in records:
                         records[pid] = {
                             'program_prediction': p_str, 'program_syntax': correctness[int(pred_syntax[i])],
-                            'program_num_execution_correct': int(num_exec[i]),
-                            'program_is_correct_execution': [bool(v) for v in is_exec[i]],
-                            'greedy_prediction': g_str, 'greedy_syntax': correctness[int(greedy_syntax[i])],
-                            'greedy_num_execution_correct': int(g_num_exec[i]),
-                            'greedy_is_correct_execution': [bool(v) for v in g_is_exec[i]]}
+                            'greedy_prediction': g_str, 'greedy_syntax': correctness[int(greedy_syntax[i])]}
+                        if num_exec[i] is not None:              # execution results need an environment
+                            records[pid].update({
+                                'program_num_execution_correct': int(num_exec[i]),
+                                'program_is_correct_execution': [bool(v) for v in is_exec[i]],
+                                'greedy_num_execution_correct': int(g_num_exec[i]),
+                                'greedy_is_correct_execution': [bool(v) for v in g_is_exec[i]]})
                     text_file.write('[id: {}]\ngt: {}\npred{}: {}\ngreedy{}: {}\n'.format(
                         pid, dsl.intseq2str(np.argmax(gt[i, :, :int(gt_len[i, 0])], axis=0)),
                         '(error)' if pred_syntax[i] == 0 else '', p_str,
@@ -258,17 +266,35 @@ def main(argv=None):
     args = build_arg_parser().parse_args(argv)
     if args.result_data:
         raise NotImplementedError('--result_data writes HDF5 (h5py is not available in this image)')
-    if args.dataset_type != 'karel':
-        raise NotImplementedError('evaluation needs the ViZDoom engine for dataset_type=vizdoom')
-    config = make_config('karel', batch_size=args.batch_size, k=args.num_k, num_k=args.num_k, model=args.model,
+    preset = 'karel' if args.dataset_type == 'karel' else 'vizdoom'
+    config = make_config(preset, batch_size=args.batch_size, k=args.num_k, num_k=args.num_k, model=args.model,
                          dataset_path=args.dataset_path, encoder_rnn_type=args.encoder_rnn_type,
                          num_lstm_cell_units=args.num_lstm_cell_units, demo_aggregation=args.demo_aggregation)
     for n in ('dataset_split', 'checkpoint', 'train_dir', 'output_dir', 'max_steps', 'no_loss', 'pred_program', 'quiet'):
         setattr(config, n, getattr(args, n))
     config.write_summary = not args.no_write_summary
-    if config.max_steps == 0:
-        config.max_steps = 1            # a generated dataset has no natural end
-    Evaler(config, GeneratedKarelBatches(config)).eval_run()
+    if has_dataset(config.dataset_path):
+        # evaler.py:431-488: the split to evaluate, steps = one pass, dimensions from the data
+        splits = dataset_module(config.dataset_type).create_default_splits(
+            config.dataset_path, is_train=False, num_k=config.num_k)
+        if config.dataset_split not in ('train', 'test', 'val'):
+            raise ValueError('Unknown dataset split')
+        target = splits[('train', 'test', 'val').index(config.dataset_split)]
+        if args.id_list:
+            with open(args.id_list) as f:
+                target._ids = [s.strip() for s in f.readlines() if s.strip()]
+        if not config.max_steps > 0:
+            config.max_steps = int(len(target.ids) / config.batch_size)
+        config_from_dataset(config, target)
+    elif args.dataset_type == 'karel':
+        print('no dataset under %s: evaluating on generated Karel programs' % config.dataset_path)
+        target = GeneratedKarelBatches(config)
+        if config.max_steps == 0:
+            config.max_steps = 1        # a generated dataset has no natural end
+    else:
+        raise IOError('no ViZDoom dataset under %s (and none can be generated without the engine)'
+                      % config.dataset_path)
+    Evaler(config, target).eval_run()
 
 
 if __name__ == '__main__':

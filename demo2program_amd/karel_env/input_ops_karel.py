@@ -30,10 +30,10 @@ def check_data_id(dataset, data_id):
         raise RuntimeError('There are %d invalid ids, including %s' % (len(wrong), wrong[:5]))
 
 
-def load_example(dataset, id_, frames_dtype=np.float32):
+def load_example(dataset, id_, frames_dtype=np.float32, keys=KEYS, dtypes=_DTYPES):
     out = {'id': id_}
-    for n, v in zip(KEYS, dataset.get_data(id_)):
-        dt = frames_dtype if n in ('s_h', 'test_s_h') else _DTYPES[n]
+    for n, v in zip(keys, dataset.get_data(id_)):
+        dt = frames_dtype if n in ('s_h', 'test_s_h') else dtypes[n]
         out[n] = np.asarray(v).astype(dt)
     return out
 
@@ -42,8 +42,9 @@ class BatchIterator(object):
     """Endless stream of batches over `data_id` (cycled, like string_input_producer)."""
 
     def __init__(self, dataset, batch_size, data_id, shuffle, num_threads=4, seed=123, prefetch=4,
-                 frames_dtype=np.float32):
+                 frames_dtype=np.float32, load=load_example, keys=KEYS):
         self.dataset, self.batch_size, self.ids = dataset, batch_size, list(data_id)
+        self._load, self.keys = load, keys
         self.shuffle = shuffle
         self.rng = np.random.RandomState(seed)
         self.frames_dtype = frames_dtype
@@ -76,8 +77,8 @@ class BatchIterator(object):
         return picked
 
     def _assemble(self, ids):
-        ex = [load_example(self.dataset, i, self.frames_dtype) for i in ids]
-        batch = {n: np.stack([e[n] for e in ex]) for n in KEYS}
+        ex = [self._load(self.dataset, i, self.frames_dtype) for i in ids]
+        batch = {n: np.stack([e[n] for e in ex]) for n in self.keys}
         batch['id'] = np.array(ids)
         return batch
 

@@ -58,7 +58,15 @@ class Model(object):
             from ..karel_env import get_KarelDSL
             self.vocab = get_KarelDSL(dsl_type=getattr(config, 'dsl_type', 'prob'), seed=123)
         else:
-            self.vocab = None           # ViZDoom vocabulary / engine: not built
+            from ..vizdoom_env import VizDoomDSLVocab
+            try:
+                self.vocab = VizDoomDSLVocab(perception_type=getattr(config, 'perception_type', ''),
+                                             level=getattr(config, 'level', None))
+            except NotImplementedError:
+                self.vocab = None       # py2-ordered vocabularies: training works, DSL metrics refuse
+        # ViZDoom execution metrics run on the caller's engine: world_factory() -> world
+        # (program_metrics.generate_program_output_vizdoom); None = syntax / exact-program only
+        self.world_factory = getattr(config, 'world_factory', None)
 
         if self.scheduled_sampling and global_step is None:
             raise ValueError('scheduled sampling requires global_step')       # model_full.py:59-61
@@ -172,7 +180,8 @@ class Model(object):
         feed['n_prog'] = int(min(int(plen.max()) if B else 0, L))
         feed['n_demo'] = int(min(int(dlen.max()) if B * k else 0, T))
         feed['id'] = batch_chunk.get('id') if hasattr(batch_chunk, 'get') else None
-        feed['host'] = {n: batch_chunk[n] for n in ('test_s_h', 'test_demo_len', 'test_per')
+        feed['host'] = {n: batch_chunk[n] for n in ('test_s_h', 'test_demo_len', 'test_per', 'init_pos',
+                                                    'init_pos_len', 'test_init_pos', 'test_init_pos_len')
                         if n in batch_chunk}
         return feed
 
@@ -732,9 +741,13 @@ class Model(object):
         c, f = self.config, self._feed
         B, k, T = c.batch_size, c.k, c.max_demo_len
         if with_programs is None:
-            with_programs = self.dataset_type == 'karel'
-        if with_programs:
-            PM.require_env(self.dataset_type)
+            with_programs = self.vocab is not None
+        if with_programs and self.vocab is None:
+            raise NotImplementedError('no DSL vocabulary for perception_type=%r (vizdoom_env/dsl.py)'
+                                      % (getattr(c, 'perception_type', None),))
+        karel = self.dataset_type == 'karel'
+        with_execution = with_programs and (karel or self.world_factory is not None)
+        parse = PM.parser_for(self.dataset_type)
         gt_prog = f['program'].cpu().numpy()
         plen = f['program_len'].cpu().numpy()
         dlen = f['demo_len'].cpu().numpy().reshape(B, k)
@@ -747,9 +760,17 @@ class Model(object):
         if with_programs:
             vocab = self.vocab
             make_error = getattr(c, 'env_type', None) != 'no_error'
-            s_h = f['s_h'].view(B, k, T, c.h, c.w, c.depth).float().cpu().numpy()
+            # the feed keeps depth%4 frames padded to NHWC4 (get_feed_dict); metrics see the real depth
+            s_h = f['s_h'].view(B, k, T, c.h, c.w, -1)[..., :c.depth].float().cpu().numpy()
             host = f.get('host', {})
             test = None
+
+            def host_np(name):
+                v = host[name]
+                return v.cpu().numpy() if torch.is_tensor(v) else np.asarray(v)
+
+            if not karel and with_execution and 'init_pos' not in host:
+                raise KeyError('ViZDoom execution metrics need init_pos / init_pos_len in the batch')
             if 'test_s_h' in host and 'test_demo_len' in host:
                 ts = host['test_s_h']
                 ts = ts.cpu().numpy() if torch.is_tensor(ts) else np.asarray(ts)
@@ -759,18 +780,29 @@ class Model(object):
 
         def program_block(prefix, st, p_len):
             """syntax / exact / execution metrics of one decoded program set"""
-            syn = PM.check_correct_syntax(vocab, st['pred_tokens'], p_len, st['is_same_seq'])
-            exact = PM.exact_program_compare(vocab, st['pred_tokens'], p_len, syn, gt_tokens, plen)
+            syn = PM.check_correct_syntax(vocab, st['pred_tokens'], p_len, st['is_same_seq'], parse=parse)
+            exact = PM.exact_program_compare(vocab, st['pred_tokens'], p_len, syn, gt_tokens, plen, parse=parse)
             rows[prefix + 'is_correct_syntax'] = syn
             rows[prefix + 'exact_program_correct'] = exact
-            exe, exe_len = PM.generate_program_output(vocab, s_h[:, :, 0], T, st['pred_tokens'], p_len, syn,
+            out = {'syntax_acc': float(syn.mean()), 'exact_acc': float(exact.mean())}
+            if not with_execution:
+                return out
+
+            def execute(first_frames, which, demo_k):
+                if karel:
+                    return PM.generate_program_output(vocab, first_frames, T, st['pred_tokens'], p_len, syn,
                                                       st['is_same_seq'], make_error)
+                return PM.generate_program_output_vizdoom(
+                    vocab, self.world_factory, host_np(which + 'init_pos'), host_np(which + 'init_pos_len'),
+                    c.vizdoom_pos_keys, T, demo_k, c.h, c.w, c.depth, st['pred_tokens'], p_len, syn,
+                    st['is_same_seq'])
+
+            exe, exe_len = execute(s_h[:, :, 0], '', k)
             num, ok, h_ = PM.compare_demo_and_execution(s_h, dlen, exe, exe_len, st['is_same_seq'])
             rows[prefix + 'num_execution_correct'], rows[prefix + 'is_correct_execution'] = num, ok
-            out = {'syntax_acc': float(syn.mean()), 'exact_acc': float(exact.mean()), 'hist': h_}
-            if test is not None:
-                exe, exe_len = PM.generate_program_output(vocab, test[0][:, :, 0], T, st['pred_tokens'], p_len,
-                                                          syn, st['is_same_seq'], make_error)
+            out['hist'] = h_
+            if test is not None and (karel or 'test_init_pos' in host):
+                exe, exe_len = execute(test[0][:, :, 0], 'test_', test[0].shape[1])
                 num, ok, h_ = PM.compare_demo_and_execution(test[0], test[1], exe, exe_len, st['is_same_seq'])
                 rows['test_' + prefix + 'num_execution_correct'] = num
                 rows['test_' + prefix + 'is_correct_execution'] = ok
@@ -783,7 +815,8 @@ class Model(object):
             r = program_block('program_', st, plen)
             acc['program_syntax_acc'] = r['syntax_acc']
             acc['pred_exact_program_accuracy'] = r['exact_acc']
-            hist['program_execution_acc_hist'] = r['hist']
+            if 'hist' in r:
+                hist['program_execution_acc_hist'] = r['hist']
             if 'test_hist' in r:
                 hist['test_program_execution_acc_hist'] = r['test_hist']
         pa = self.pred_action.permute(0, 1, 3, 2).cpu().numpy()
@@ -799,7 +832,8 @@ class Model(object):
                 r = program_block('greedy_', st, glen)
                 acc['greedy_program_syntax_acc'] = r['syntax_acc']
                 acc['greedy_exact_program_accuracy'] = r['exact_acc']
-                hist['greedy_program_execution_acc_hist'] = r['hist']
+                if 'hist' in r:
+                    hist['greedy_program_execution_acc_hist'] = r['hist']
                 if 'test_hist' in r:
                     hist['test_greedy_program_execution_acc_hist'] = r['test_hist']
             ga = g['greedy_pred_action'].permute(0, 1, 3, 2).cpu().numpy()

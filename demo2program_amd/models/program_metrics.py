@@ -5,22 +5,36 @@ execution accuracy.  In the reference these are tf.py_func callbacks inside the 
 evaluation metrics, never part of the loss, so they stay on the host here too and work on the
 arrays the GPU path hands back (argmax tokens, lengths, is_same_seq).
 
-Karel only: the ViZDoom variants need the game engine (`vizdoom`, `cv2`), which this build
-does not ship -- `require_env` raises for them.
+Syntax and exact-program metrics exist for both DSLs (`parser_for`).  Execution is built in for
+Karel; the ViZDoom variant (model_full.py:789-848) drives whatever world object the caller's
+`world_factory` returns -- the game engine (`vizdoom`, `cv2`) is not part of this build, and
+without a factory `require_env` raises for it.
 """
 import numpy as np
 
 from ..karel_env import Karel_world, parse
 
 
-def require_env(dataset_type):
-    if dataset_type != 'karel':
+def parser_for(dataset_type):
+    """The stack parser the reference imports per dataset type (model_full.py:603-606)."""
+    if dataset_type == 'karel':
+        return parse
+    if dataset_type == 'vizdoom':
+        from ..vizdoom_env.dsl import parse as parse_vizdoom
+        return parse_vizdoom
+    raise ValueError('unknown dataset_type %r' % (dataset_type,))
+
+
+def require_env(dataset_type, world_factory=None):
+    """Execution metrics need an environment: Karel's is built in, ViZDoom's is the caller's."""
+    if dataset_type != 'karel' and world_factory is None:
         raise NotImplementedError(
-            'syntax / execution metrics for dataset_type=%r need the ViZDoom engine '
-            '(vizdoom_env/vizdoom_env.py); only the Karel interpreter is built' % (dataset_type,))
+            'execution metrics for dataset_type=%r need the ViZDoom engine (vizdoom_env/vizdoom_env.py), '
+            'which this build does not ship: pass a world_factory, or ask for syntax / exact-program '
+            'metrics only' % (dataset_type,))
 
 
-def check_correct_syntax(vocab, p_token, p_len, is_same_seq):
+def check_correct_syntax(vocab, p_token, p_len, is_same_seq, parse=parse):
     """[B] float32: 1 where the predicted token string is accepted by the stack parser; rows that
     already equal the ground truth are 1 without parsing (model_full.py:608-610)."""
     p_len = np.asarray(p_len).reshape(-1)
@@ -33,7 +47,7 @@ def check_correct_syntax(vocab, p_token, p_len, is_same_seq):
     return out
 
 
-def exact_program_compare(vocab, p_token, p_len, is_correct_syntax, gt_token, gt_len):
+def exact_program_compare(vocab, p_token, p_len, is_correct_syntax, gt_token, gt_len, parse=parse):
     """[B] float32: canonical form of the prediction == canonical form of the ground truth, for
     rows with correct syntax (model_full.py:713-729)."""
     p_len, gt_len = np.asarray(p_len).reshape(-1), np.asarray(gt_len).reshape(-1)
@@ -71,6 +85,54 @@ def generate_program_output(vocab, initial_states, max_demo_len, p_token, p_len,
                 execution_len[i, d] = hist.shape[0]
                 n = min(hist.shape[0], max_demo_len)
                 execution[i, d, :n] = hist[:n]
+    return execution, execution_len
+
+
+def generate_program_output_vizdoom(vocab, world_factory, init_pos, init_pos_len, pos_keys, max_demo_len, demo_k,
+                                    h, w, depth, p_token, p_len, is_correct_syntax, is_same_seq):
+    """ViZDoom counterpart (model_full.py:789-848): for every row that is neither identical to
+    the ground truth nor a syntax error, start an episode per demonstration from its initial
+    positions and run the predicted program.
+
+    `world_factory()` -> a world with the reference Vizdoom_env surface the metric uses:
+    `new_episode(init_dict)` (init_dict[key] = squeezed init_pos[i, d, p, :len]), the four DSL
+    methods, `s_h` (list of [h, w, depth] frames) and optionally `init_game()` / `end_game()`.
+    Frames must already have the dataset's size (the reference shrinks with cv2 INTER_AREA,
+    which this build does not ship).  -> (execution [B, demo_k, max_demo_len, h, w, depth]
+    float32, execution_len [B, demo_k] int32)."""
+    from ..vizdoom_env.dsl import parse as parse_vizdoom
+    B = p_token.shape[0]
+    p_len = np.asarray(p_len).reshape(-1)
+    execution = np.zeros((B, demo_k, max_demo_len, h, w, depth), np.float32)
+    execution_len = np.zeros((B, demo_k), np.int32)
+    world = world_factory()
+    if hasattr(world, 'init_game'):
+        world.init_game()
+    try:
+        for i in range(B):
+            if is_same_seq[i] != 0 or is_correct_syntax[i] != 1:
+                continue
+            prog = parse_vizdoom(vocab.intseq2str(p_token[i, :int(p_len[i])]))
+            if not prog.ok:
+                raise RuntimeError('Compile failure should not happen here')
+            for d in range(demo_k):
+                init_dict = {key: np.squeeze(init_pos[i, d, p][:int(init_pos_len[i, d, p])])
+                             for p, key in enumerate(pos_keys)}
+                world.new_episode(init_dict)
+                _, _, ok = prog.run(world)
+                if not ok:
+                    continue
+                frames = [np.asarray(s) for s in world.s_h]
+                if frames and frames[0].shape != (h, w, depth):
+                    raise ValueError('world frames are %s, the dataset has %s: resize them in the world'
+                                     % (frames[0].shape, (h, w, depth)))
+                execution_len[i, d] = len(frames)
+                n = min(len(frames), max_demo_len)
+                if n:
+                    execution[i, d, :n] = np.stack(frames[:n], axis=0)
+    finally:
+        if hasattr(world, 'end_game'):
+            world.end_game()
     return execution, execution_len
 
 

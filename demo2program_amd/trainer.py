@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import kernels as K
-from .config import make_config
+from .config import config_from_dataset, dataset_module, has_dataset, input_ops_module, make_config
 from .dist import DataParallel
 from .synthetic import make_batch
 
@@ -157,9 +157,9 @@ class Trainer(object):
         if dataset is None:
             return SyntheticBatches(config, seed, 8 if is_training else 2, rank=self.dp.rank)
         if hasattr(dataset, 'get_data'):
-            from .karel_env.input_ops_karel import create_input_ops
+            create_input_ops = input_ops_module(config.dataset_type).create_input_ops
             ids = dataset.ids[self.dp.rank::self.dp.world_size] if self.dp.world_size > 1 else dataset.ids
-            # frames stay uint8 end to end (the HDF5 stores booleans): a quarter of the H2D bytes and of
+            # frames stay uint8 end to end (the HDF5 stores booleans / 0..255 pixels): a quarter of the H2D bytes and of
             # conv1's HBM reads; the kernels widen on load, results identical to the float32 feed
             _, batch = create_input_ops(dataset, self.batch_size, is_training=is_training, data_id=ids,
                                         shuffle=is_training, seed=seed + self.dp.rank, frames_dtype=np.uint8)
@@ -372,21 +372,12 @@ def main(argv=None):
     config = make_config(preset, **flags)
     dp = DataParallel.from_env()
     dataset_train = dataset_test = None
-    if os.path.exists(os.path.join(config.dataset_path, 'data_info.json')) or \
-            os.path.exists(os.path.join(config.dataset_path, 'data.hdf5')):
-        if config.dataset_type != 'karel':
-            raise NotImplementedError('only the Karel dataset reader is built (SURVEY 8(f) N2)')
-        from .karel_env import dataset_karel as dataset
-        dataset_train, dataset_test, _ = dataset.create_default_splits(config.dataset_path, num_k=config.num_k)
-        # data dimensions from the first example (trainer.py:306-335)
-        program, _, s_h, test_s_h, a_h, _, _, _, _, _, _, per, _ = dataset_train.get_data(dataset_train.ids[0])
-        config.dim_program_token, config.max_program_len = int(program.shape[0]), int(program.shape[1])
-        config.k, config.test_k, config.max_demo_len = int(s_h.shape[0]), int(test_s_h.shape[0]), int(s_h.shape[1])
-        config.h, config.w, config.depth = (int(v) for v in s_h.shape[2:5])
-        config.action_space, config.per_dim = int(a_h.shape[2]), int(per.shape[2])
-        config.dsl_type, config.env_type = dataset_train.dsl_type, dataset_train.env_type
+    if has_dataset(config.dataset_path):
+        dataset_train, dataset_test, _ = dataset_module(config.dataset_type).create_default_splits(
+            config.dataset_path, num_k=config.num_k)
+        config_from_dataset(config, dataset_train)          # trainer.py:306-335
     else:
-        print('no dataset under %s: training on synthetic Karel-shaped batches' % config.dataset_path)
+        print('no dataset under %s: training on synthetic %s-shaped batches' % (config.dataset_path, preset))
     trainer = Trainer(config, dataset_train, dataset_test, dp=dp)
     trainer.train(max_steps=args.max_steps)
 

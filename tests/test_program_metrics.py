@@ -94,7 +94,79 @@ def test_failed_and_overlong_executions():
     assert ln2[0, 0] == 25 and exe.shape[2] == T and exe[0, 0, T - 1].any()
 
 
-def test_vizdoom_metrics_are_refused():
+def test_vizdoom_execution_needs_a_world_factory():
     with pytest.raises(NotImplementedError):
         PM.require_env('vizdoom')
+    PM.require_env('vizdoom', world_factory=lambda: None)
     PM.require_env('karel')
+
+
+class _FrameWorld(object):
+    """Tiny stand-in for the game: the frame is a counter image, ATTACK fails when no Demon is there."""
+
+    def __init__(self):
+        self.episodes = []
+
+    def new_episode(self, init_dict):
+        self.episodes.append(init_dict)
+        self.demon = bool(init_dict['demon_pos'].size and int(np.atleast_2d(init_dict['demon_pos'])[0, 0]) > 0)
+        self.s_h = [np.zeros((2, 2, 3))]
+
+    def state_transition(self, action):
+        if action == 'ATTACK' and not self.demon:
+            raise RuntimeError('nothing to attack')
+        self.s_h.append(self.s_h[-1] + 1)
+
+    def is_there(self, actor):
+        return self.demon and actor == 'Demon'
+
+    def in_target(self, actor):
+        return False
+
+    def exist_actor_in_distance_horizontal(self, actor, dist, horz):
+        return False
+
+
+def test_vizdoom_program_metrics():
+    from demo2program_amd.vizdoom_env import VizDoomDSLVocab
+    vocab = VizDoomDSLVocab('simple', 'not_simple')
+    parse = PM.parser_for('vizdoom')
+    codes = ['DEF run m( IF c( ISTHERE Demon c) i( ATTACK i) MOVE_LEFT m)',     # runs everywhere
+             'DEF run m( ATTACK m)',                                              # fails without a demon
+             'DEF run m( ATTACK ATTACK',                                          # syntax error
+             'DEF run m( MOVE_LEFT m)']                                           # identical to the ground truth
+    gts = ['DEF run m( IFELSE c( ISTHERE Demon c) i( ATTACK MOVE_LEFT i) ELSE e( MOVE_LEFT e) m)',
+           'DEF run m( REPEAT R=2 r( ATTACK r) m)', 'DEF run m( ATTACK m)', 'DEF run m( MOVE_LEFT m)']
+    L = 24
+    tok, ln = np.zeros((4, L), np.int64), np.zeros((4, 1), np.int64)
+    gtok, gln = np.zeros((4, L), np.int64), np.zeros((4, 1), np.int64)
+    for i, (c, g) in enumerate(zip(codes, gts)):
+        ids, gids = vocab.str2intseq(c), vocab.str2intseq(g)
+        tok[i, :len(ids)], ln[i] = ids, len(ids)
+        gtok[i, :len(gids)], gln[i] = gids, len(gids)
+    same = np.array([0, 0, 0, 1])
+    syn = PM.check_correct_syntax(vocab, tok, ln, same, parse=parse)
+    assert syn.tolist() == [1, 1, 0, 1]
+    exact = PM.exact_program_compare(vocab, tok, ln, syn, gtok, gln, parse=parse)
+    assert exact.tolist() == [0, 0, 0, 1]
+    # 'IF c ATTACK; MOVE_LEFT' != 'IFELSE c (ATTACK MOVE_LEFT) else (MOVE_LEFT)' in canonical form, but
+    # REPEAT unrolls: ATTACK ATTACK == REPEAT R=2 ATTACK
+    two = vocab.str2intseq('DEF run m( ATTACK ATTACK m)')
+    t2 = np.zeros((1, L), np.int64)
+    t2[0, :len(two)] = two
+    assert PM.exact_program_compare(vocab, t2, np.array([[len(two)]]), np.ones(1), gtok[1:2], gln[1:2],
+                                    parse=parse).tolist() == [1]
+    # execution: 2 demos, demon present in the first only
+    init_pos = np.zeros((4, 2, 2, 3, 2), np.int32)
+    init_pos[:, 0, 1, 0] = (5, 5)
+    init_pos_len = np.ones((4, 2, 2), np.int32)
+    world = _FrameWorld()
+    exe, exe_len = PM.generate_program_output_vizdoom(vocab, lambda: world, init_pos, init_pos_len,
+                                                      ['player_pos', 'demon_pos'], 5, 2, 2, 2, 3, tok, ln, syn, same)
+    assert exe.shape == (4, 2, 5, 2, 2, 3)
+    assert exe_len.tolist() == [[3, 2], [2, 0], [0, 0], [0, 0]]
+    assert exe[0, 0, 2].max() == 2 and exe[0, 0, 3].max() == 0
+    assert len(world.episodes) == 4 and world.episodes[0]['demon_pos'].tolist() == [5, 5]
+    demo = exe.copy()
+    num, ok, hist = PM.compare_demo_and_execution(demo, exe_len, exe, exe_len, same)
+    assert num.tolist() == [2, 2, 2, 2]
