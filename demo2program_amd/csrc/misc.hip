@@ -113,6 +113,58 @@ extern "C" int d2p_group_mean_bwd(int B, int k, int U, const float* dout, const 
     return D2P_OK;
 }
 
+// ---- maxpool aggregation of the synthesis baseline (models/baselines/model_synthesis.py:345-358:
+// max_pooling1d over the k demonstrations).  The winner's index is kept for the backward pass;
+// ties go to the lowest demonstration index.
+__global__ void __launch_bounds__(256)
+group_max_kernel(int B, int k, int U, const float* x, float* out, int* arg) {
+    const long total = (long)B * U;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int b = (int)(idx / U), u = (int)(idx - (long)b * U);
+        float best = x[(long)b * k * U + u];
+        int at = 0;
+        for (int i = 1; i < k; ++i) {
+            const float v = x[((long)b * k + i) * U + u];
+            if (v > best) { best = v; at = i; }
+        }
+        out[idx] = best;
+        arg[idx] = at;
+    }
+}
+
+extern "C" int d2p_group_max(int B, int k, int U, const float* x, float* out, int* arg, d2p_stream_t stream) {
+    D2P_REQUIRE(B >= 0 && k > 0 && U > 0, D2P_EINVAL, "group_max: bad sizes");
+    if (B == 0) return D2P_OK;
+    D2P_REQUIRE(x && out && arg, D2P_EINVAL, "group_max: null pointer");
+    hipLaunchKernelGGL(group_max_kernel, dim3(ew_blocks((long)B * U)), dim3(256), 0, as_stream(stream),
+                       B, k, U, x, out, arg);
+    D2P_LAUNCH_CHECK("group_max");
+    return D2P_OK;
+}
+
+__global__ void __launch_bounds__(256)
+group_max_bwd_kernel(int B, int k, int U, const float* dout, const int* arg, float* dx, int accumulate) {
+    const long total = (long)B * k * U;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int u = (int)(idx % U);
+        const long row = idx / U;
+        const int i = (int)(row % k), b = (int)(row / k);
+        const float v = arg[(long)b * U + u] == i ? dout[(long)b * U + u] : 0.f;
+        dx[idx] = accumulate ? dx[idx] + v : v;
+    }
+}
+
+extern "C" int d2p_group_max_bwd(int B, int k, int U, const float* dout, const int* arg, float* dx,
+                                 int accumulate, d2p_stream_t stream) {
+    D2P_REQUIRE(B >= 0 && k > 0 && U > 0, D2P_EINVAL, "group_max_bwd: bad sizes");
+    if (B == 0) return D2P_OK;
+    D2P_REQUIRE(dout && arg && dx, D2P_EINVAL, "group_max_bwd: null pointer");
+    hipLaunchKernelGGL(group_max_bwd_kernel, dim3(ew_blocks((long)B * k * U)), dim3(256), 0, as_stream(stream),
+                       B, k, U, dout, arg, dx, accumulate);
+    D2P_LAUNCH_CHECK("group_max_bwd");
+    return D2P_OK;
+}
+
 // ---- rn_pool first layer, pairs never materialised ---------------------------------------
 // models/model_full.py:333-343: row (b, a, c) of the pair matrix is [feat[b,c] || feat[b,a]],
 // so fc1(row) = feat[b,c]·W1[:U] + feat[b,a]·W1[U:] + bias = P[b,c] + Q[b,a] + bias.

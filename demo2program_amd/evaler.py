@@ -25,11 +25,11 @@ class Evaler(object):
 
     @staticmethod
     def get_model_class(model_name):
-        if model_name == 'full':
+        if model_name in ('full', 'summarizer', 'synthesis_baseline'):     # variants of one graph
             from .models.model_full import Model
             return Model
-        if model_name in ('synthesis_baseline', 'induction_baseline', 'summarizer'):
-            raise NotImplementedError('%s: baseline models are not built (SURVEY 8(f) N4)' % model_name)
+        if model_name == 'induction_baseline':
+            raise NotImplementedError('induction_baseline: not built (SURVEY 8(f) N4)')
         raise ValueError(model_name)
 
     def __init__(self, config, dataset):

@@ -403,6 +403,14 @@ def group_mean_bwd(dout, dbcast, dx, B, k, U, accumulate):
                             current_stream())
 
 
+def group_max(x, B, k, U, out, arg):
+    call.d2p_group_max(B, k, U, ptr(x), ptr(out), ptr(arg), current_stream())
+
+
+def group_max_bwd(dout, arg, dx, B, k, U, accumulate):
+    call.d2p_group_max_bwd(B, k, U, ptr(dout), ptr(arg), ptr(dx), 1 if accumulate else 0, current_stream())
+
+
 def rn_pair_fwd(P, Q, bias, y, B, k, U):
     call.d2p_rn_pair_fwd(B, k, U, ptr(P), ptr(Q), ptr(bias), ptr(y), current_stream())
 

@@ -43,7 +43,19 @@ class Model(object):
         self.batch_size = config.batch_size
         self.encoder_rnn_type = config.encoder_rnn_type
         self.num_lstm_cell_units = config.num_lstm_cell_units
-        self.demo_aggregation = config.demo_aggregation    # parsed, ignored (as the reference)
+        self.demo_aggregation = config.demo_aggregation    # only the synthesis baseline reads it
+        # 'full', or one of the program-synthesis ablations that reuse this graph: 'summarizer'
+        # (models/baselines/model_summarizer.py: both encoder passes, relation network alone as
+        # the summary, program loss only) and 'synthesis_baseline' (model_synthesis.py: one encoder
+        # pass, avg / max pooling over the demonstrations, program loss only)
+        self.variant = getattr(config, 'model', 'full') or 'full'
+        if self.variant not in ('full', 'summarizer', 'synthesis_baseline'):
+            raise NotImplementedError('%s: not built (the induction baseline is an attention decoder '
+                                      'over the test demonstrations, a different graph)' % self.variant)
+        if self.variant == 'synthesis_baseline' and self.demo_aggregation not in ('avgpool', 'maxpool'):
+            # 'concat' hands a [B, k*U] state to a U-unit cell (model_synthesis.py:339-341,463-467)
+            raise ValueError('Unknown demo aggregation type')
+        self.multitask = self.variant == 'full'
         self.dim_program_token = config.dim_program_token
         self.max_program_len = config.max_program_len
         self.max_demo_len = config.max_demo_len
@@ -91,7 +103,10 @@ class Model(object):
         for l, (_, _, _, cout, _, _) in enumerate(self._conv, start=1):
             self._init_moving('conv%d' % l, cout)
         U = self.num_lstm_cell_units
-        for s in ('rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2', 'per/fc'):
+        bn_scopes = {'full': ('rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2', 'per/fc'),
+                     'summarizer': ('rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2'),
+                     'synthesis_baseline': ()}[self.variant]
+        for s in bn_scopes:
             self._init_moving(s, U)
         self.track_moving = True
         # scheduled sampling state (device memory: read by kernels inside a captured graph)
@@ -205,15 +220,17 @@ class Model(object):
         with torch.cuda.stream(side):
             ids_p = K.shift_tokens_tm(feed['program_tokens'], V + 1, out=self._buf('ids_p', (L, B), torch.int32))
             emb_p = K.embedding_gather(ids_p, p['prog/embedding'], out=self._buf('emb_p', (L * B, U)), n=n_p * B)
-            ids_a = K.shift_tokens_tm(feed['a_h_tokens'], A + 1, out=self._buf('ids_a', (T, M), torch.int32))
-            emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)), n=n_d * M)
-            # Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
-            per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
-            pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
-                               bias=p['per/fc/b'], act=0)
-            pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
-            z_a = self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d)
-            z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)
+            if self.multitask:
+                ids_a = K.shift_tokens_tm(feed['a_h_tokens'], A + 1, out=self._buf('ids_a', (T, M), torch.int32))
+                emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)),
+                                           n=n_d * M)
+                # Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
+                per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
+                pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
+                                   bias=p['per/fc/b'], act=0)
+                pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
+                z_a = self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d)
+                z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)
             z_p = self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p)
 
         # ---- State_Encoder: conv -> +bias -> lrelu -> BN(train), per demo-index statistics
@@ -242,18 +259,33 @@ class Model(object):
         # ---- Demo_Encoder LSTM (zero initial state, length-masked)
         e1 = self._lstm_fwd('demo_lstm', feats_tm.view(T * M, F), F, M, T, T, None, None, lens_d,
                             want_final=True)
-        # ---- summary = mean over k; broadcast as SecondPath initial state
-        sum_h, h0_2 = self._buf('sum_h', (B, U)), self._buf('h0_2', (M, U))
-        sum_c, c0_2 = self._buf('sum_c', (B, U)), self._buf('c0_2', (M, U))
-        K.group_mean(e1['h_final'], B, k, U, sum_h, h0_2)
-        K.group_mean(e1['c_final'], B, k, U, sum_c, c0_2)
-        # ---- SecondPathEncoder over the step-1 outputs (zeros past len)
-        e2 = self._lstm_fwd('second_lstm', e1['hout'].view(T * M, U), U, M, T, T, h0_2, c0_2, lens_d,
-                            want_final=True)
-        demo_h, demo_c = e2['h_final'], e2['c_final']
-        # ---- SummarizeFeature('rn') = mean_k + rn_pool
-        rn_h = self._rn_fwd('rn_h', demo_h, B, k, U)
-        rn_c = self._rn_fwd('rn_c', demo_c, B, k, U)
+        if self.variant == 'synthesis_baseline':
+            # model_synthesis.py:324-358: no second pass; the program decoder starts from the
+            # demonstrations' final states pooled over k
+            init_h, init_c = self._buf('pool_h', (B, U)), self._buf('pool_c', (B, U))
+            if self.demo_aggregation == 'avgpool':
+                K.group_mean(e1['h_final'], B, k, U, init_h, None)
+                K.group_mean(e1['c_final'], B, k, U, init_c, None)
+            else:
+                ctx['arg_h'] = self._buf('pool_arg_h', (B, U), torch.int32)
+                ctx['arg_c'] = self._buf('pool_arg_c', (B, U), torch.int32)
+                K.group_max(e1['h_final'], B, k, U, init_h, ctx['arg_h'])
+                K.group_max(e1['c_final'], B, k, U, init_c, ctx['arg_c'])
+            e2 = rn_h = rn_c = h0_2 = c0_2 = demo_h = demo_c = None
+        else:
+            # ---- summary = mean over k; broadcast as SecondPath initial state
+            sum_h, h0_2 = self._buf('sum_h', (B, U)), self._buf('h0_2', (M, U))
+            sum_c, c0_2 = self._buf('sum_c', (B, U)), self._buf('c0_2', (M, U))
+            K.group_mean(e1['h_final'], B, k, U, sum_h, h0_2)
+            K.group_mean(e1['c_final'], B, k, U, sum_c, c0_2)
+            # ---- SecondPathEncoder over the step-1 outputs (zeros past len)
+            e2 = self._lstm_fwd('second_lstm', e1['hout'].view(T * M, U), U, M, T, T, h0_2, c0_2, lens_d,
+                                want_final=True)
+            demo_h, demo_c = e2['h_final'], e2['c_final']
+            # ---- SummarizeFeature('rn') = mean_k + rn_pool (the summarizer baseline: rn_pool alone)
+            rn_h = self._rn_fwd('rn_h', demo_h, B, k, U, add_mean=self.multitask)
+            rn_c = self._rn_fwd('rn_c', demo_c, B, k, U, add_mean=self.multitask)
+            init_h, init_c = rn_h['out'], rn_c['out']
 
         main.wait_stream(side)
         # ---- Program decoder (teacher forcing; <s> = out-of-range id -> zero vector),
@@ -262,38 +294,49 @@ class Model(object):
         #      together (one launch per time step for all three, d2p_lstm_seq_fwd_multi); measured
         #      neutral-to-slower on MI355X (the step kernels are L2-bandwidth bound, DESIGN.md
         #      3.2), so the default keeps one call per decoder.
-        specs = [('prog', emb_p, U, B, L, n_p, rn_h['out'], rn_c['out'], V, z_p),
-                 ('act', emb_a, U, M, T, n_d, demo_h, demo_c, A, z_a),
-                 ('per', pe, U, M, T, n_d, demo_h, demo_c, P, z_q)]
+        specs = [('prog', emb_p, U, B, L, n_p, init_h, init_c, V, z_p)]
+        if self.multitask:
+            specs += [('act', emb_a, U, M, T, n_d, demo_h, demo_c, A, z_a),
+                      ('per', pe, U, M, T, n_d, demo_h, demo_c, P, z_q)]
+        da = dq = None
         if self.scheduled_sampling and self.is_train:
             # program and action decoders feed back their own samples (per uses TrainingHelper,
             # model_full.py:409); the hoisted z_p / z_a of the side stream are simply not used
-            dp = self._decoder_fwd_sampled('prog', ids_p, B, L, n_p, rn_h['out'], rn_c['out'], V, 0)
-            da = self._decoder_fwd_sampled('act', ids_a, M, T, n_d, demo_h, demo_c, A, 4096)
-            dq = self._decoders_fwd([specs[2]])[0]
-            ids_p, ids_a = dp['fed_ids'], da['fed_ids']        # embedding gradient goes to what was fed
-        elif self.fuse_decoders:
+            dp = self._decoder_fwd_sampled('prog', ids_p, B, L, n_p, init_h, init_c, V, 0)
+            ids_p = dp['fed_ids']                               # embedding gradient goes to what was fed
+            if self.multitask:
+                da = self._decoder_fwd_sampled('act', ids_a, M, T, n_d, demo_h, demo_c, A, 4096)
+                dq = self._decoders_fwd([specs[2]])[0]
+                ids_a = da['fed_ids']
+        elif self.fuse_decoders and self.multitask:
             dp, da, dq = self._decoders_fwd(specs)
         else:
-            dp, da, dq = [self._decoders_fwd([sp])[0] for sp in specs]
+            outs = [self._decoders_fwd([sp])[0] for sp in specs]
+            dp = outs[0]
+            if self.multitask:
+                da, dq = outs[1], outs[2]
 
         # ---- losses: program + mean_k action + mean_k perception, each mask-count normalised
+        #      (the baselines: the program term alone)
         nums = self._buf('loss_nums', (1 + 2 * k,))
         dens = self._buf('loss_dens', (1 + 2 * k,))
+        loss = self._buf('loss', (1,))
+        terms = self._buf('loss_terms', (3,), zero=True)
         K.xent_fwd('softmax', dp['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
                    nums[0:1], dens[0:1])
-        K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
-                   nums[1:1 + k], dens[1:1 + k])
-        K.xent_fwd('sigmoid', dq['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
-                   nums[1 + k:], dens[1 + k:])
-        loss = self._buf('loss', (1,))
-        terms = self._buf('loss_terms', (3,))
-        K.loss_assemble([1, k, k], nums, dens, loss, terms)
+        if self.multitask:
+            K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                       nums[1:1 + k], dens[1:1 + k])
+            K.xent_fwd('sigmoid', dq['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                       nums[1 + k:], dens[1 + k:])
+            K.loss_assemble([1, k, k], nums, dens, loss, terms)
+            ctx.update(da=da, dq=dq, ids_a=ids_a, emb_a=emb_a, per_tm=per_tm, pe_a=pe_a, pe=pe,
+                       pe_mean=pe_mean, pe_rstd=pe_rstd)
+        else:
+            K.loss_assemble([1], nums, dens, loss, terms)
 
-        ctx.update(e1=e1, e2=e2, rn_h=rn_h, rn_c=rn_c, dp=dp, da=da, dq=dq, feats_tm=feats_tm,
-                   ids_p=ids_p, ids_a=ids_a, emb_p=emb_p, emb_a=emb_a, per_tm=per_tm, pe_a=pe_a,
-                   pe=pe, pe_mean=pe_mean, pe_rstd=pe_rstd, dens=dens, h0_2=h0_2, c0_2=c0_2,
-                   demo_h=demo_h, demo_c=demo_c)
+        ctx.update(e1=e1, e2=e2, rn_h=rn_h, rn_c=rn_c, dp=dp, feats_tm=feats_tm, ids_p=ids_p, emb_p=emb_p,
+                   dens=dens, h0_2=h0_2, c0_2=c0_2, demo_h=demo_h, demo_c=demo_c, init_h=init_h, init_c=init_c)
         self._ctx = ctx
         self._feed = feed
         self._loss, self._terms = loss, terms
@@ -449,8 +492,9 @@ class Model(object):
         e['scope'] = scope
         return e
 
-    def _rn_fwd(self, scope, feat, B, k, U):
-        """SummarizeFeature('rn'): mean over k + rn_pool (models/model_full.py:333-362)."""
+    def _rn_fwd(self, scope, feat, B, k, U, add_mean=True):
+        """SummarizeFeature('rn'): mean over k + rn_pool (models/model_full.py:333-362); without
+        the mean term it is the summarizer baseline's (model_summarizer.py:345-352)."""
         p = self.params.p
         W1, W2 = p[scope + '/fc1/W'], p[scope + '/fc2/W']
         Pm = K.matmul_nn(feat, W1[:U], out=self._buf(scope + '/P', (B * k, U)))
@@ -461,11 +505,14 @@ class Model(object):
         y2a = K.matmul_nn(y1, W2, out=self._buf(scope + '/y2a', (B * k * k, U)),
                           bias=p[scope + '/fc2/b'], act=1)
         y2, m2, r2 = self._bn_fwd(scope + '/fc2', y2a, p[scope + '/fc2/gamma'], p[scope + '/fc2/beta'], 1, 1)
-        base = self._buf(scope + '/base', (B, U))
-        K.group_mean(feat, B, k, U, base, None)
+        base = None
+        if add_mean:
+            base = self._buf(scope + '/base', (B, U))
+            K.group_mean(feat, B, k, U, base, None)
         out = self._buf(scope + '/out', (B, U))
         K.pair_mean_fwd(y2, base, out, B, k * k, U)
-        return dict(scope=scope, feat=feat, y1a=y1a, y1=y1, m1=m1, r1=r1, y2a=y2a, m2=m2, r2=r2, out=out)
+        return dict(scope=scope, feat=feat, y1a=y1a, y1=y1, m1=m1, r1=r1, y2a=y2a, m2=m2, r2=r2, out=out,
+                    add_mean=add_mean)
 
     # ------------------------------------------------------------------ backward
     def backward(self, loss_scale=1.0):
@@ -483,61 +530,83 @@ class Model(object):
 
         # ---- losses -> dlogits (time-major, first n_steps*R rows)
         dl_p = self._buf('prog/dlogits', (L * B, V))
-        dl_a = self._buf('act/dlogits', (T * M, A))
-        dl_q = self._buf('per/dlogits', (T * M, P))
         K.xent_bwd('softmax', ctx['dp']['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
                    dens[0:1], loss_scale, dl_p)
-        K.xent_bwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
-                   dens[1:1 + k], loss_scale, dl_a)
-        K.xent_bwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
-                   dens[1 + k:], loss_scale, dl_q)
-
-        d_demo_h, d_demo_c = self._buf('d_demo_h', (M, U)), self._buf('d_demo_c', (M, U))
-        tmp_h, tmp_c = self._buf('tmp_dh', (M, U)), self._buf('tmp_dc', (M, U))
-        d_rn_h, d_rn_c = self._buf('d_rn_h', (B, U)), self._buf('d_rn_c', (B, U))
-
-        # ---- decoder recurrences (main stream): projection grads, dz for every step, and the
-        #      initial-state gradients that feed the summarizer / encoder backward
-        bspecs = [(ctx['dp'], dl_p, d_rn_h, d_rn_c), (ctx['da'], dl_a, d_demo_h, d_demo_c),
-                  (ctx['dq'], dl_q, tmp_h, tmp_c)]
-        if self.fuse_decoders:
-            dz_p, dz_a, dz_q = self._decoders_bwd_rec(bspecs)
-        else:
-            dz_p, dz_a, dz_q = [self._decoders_bwd_rec([sp])[0] for sp in bspecs]
-        K.axpy(1.0, tmp_h, d_demo_h)
-        K.axpy(1.0, tmp_c, d_demo_c)
-
-        # ---- side stream: the decoders' weight / input gradients (9 large GEMMs, ~100 GFLOP,
-        #      MFMA-bound) are not needed by the rest of backward; they overlap the encoder's
-        #      backward recurrences, which are latency-bound.
+        d_init_h, d_init_c = self._buf('d_rn_h', (B, U)), self._buf('d_rn_c', (B, U))
         main = torch.cuda.current_stream()
         side = self._side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            dx_p = self._lstm_bwd_params(ctx['dp'], dz_p, True)
-            K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
-            dx_a = self._lstm_bwd_params(ctx['da'], dz_a, True)
-            K.embedding_scatter_add(ctx['ids_a'], dx_a, g['act/embedding'], n=n_d * M)
-            dx_q = self._lstm_bwd_params(ctx['dq'], dz_q, True)
-            if n_d < T:
-                dx_q[n_d * M:].zero_()
-            d_pe_a = K.bn_bwd(ctx['pe_a'], dx_q, p['per/fc/gamma'], ctx['pe_mean'], ctx['pe_rstd'], k, 1,
-                              False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)),
-                              dbias=g['per/fc/b'])
-            K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
+        if self.multitask:
+            dl_a = self._buf('act/dlogits', (T * M, A))
+            dl_q = self._buf('per/dlogits', (T * M, P))
+            K.xent_bwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                       dens[1:1 + k], loss_scale, dl_a)
+            K.xent_bwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                       dens[1 + k:], loss_scale, dl_q)
 
-        # ---- SummarizeFeature('rn') backward (adds into d_demo_{h,c})
-        self._rn_bwd(ctx['rn_h'], d_rn_h, d_demo_h, B, k, U)
-        self._rn_bwd(ctx['rn_c'], d_rn_c, d_demo_c, B, k, U)
+            d_demo_h, d_demo_c = self._buf('d_demo_h', (M, U)), self._buf('d_demo_c', (M, U))
+            tmp_h, tmp_c = self._buf('tmp_dh', (M, U)), self._buf('tmp_dc', (M, U))
 
-        # ---- SecondPathEncoder backward: only the final states carry gradient
-        e2 = ctx['e2']
-        dh0_2, dc0_2 = self._buf('dh0_2', (M, U)), self._buf('dc0_2', (M, U))
-        d_hout1 = self._lstm_bwd(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2, want_dx=True)
-        # summary = mean_k(step-1 final states), broadcast to every demo of the program
+            # ---- decoder recurrences (main stream): projection grads, dz for every step, and the
+            #      initial-state gradients that feed the summarizer / encoder backward
+            bspecs = [(ctx['dp'], dl_p, d_init_h, d_init_c), (ctx['da'], dl_a, d_demo_h, d_demo_c),
+                      (ctx['dq'], dl_q, tmp_h, tmp_c)]
+            if self.fuse_decoders:
+                dz_p, dz_a, dz_q = self._decoders_bwd_rec(bspecs)
+            else:
+                dz_p, dz_a, dz_q = [self._decoders_bwd_rec([sp])[0] for sp in bspecs]
+            K.axpy(1.0, tmp_h, d_demo_h)
+            K.axpy(1.0, tmp_c, d_demo_c)
+
+            # ---- side stream: the decoders' weight / input gradients (9 large GEMMs, ~100 GFLOP,
+            #      MFMA-bound) are not needed by the rest of backward; they overlap the encoder's
+            #      backward recurrences, which are latency-bound.
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dx_p = self._lstm_bwd_params(ctx['dp'], dz_p, True)
+                K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
+                dx_a = self._lstm_bwd_params(ctx['da'], dz_a, True)
+                K.embedding_scatter_add(ctx['ids_a'], dx_a, g['act/embedding'], n=n_d * M)
+                dx_q = self._lstm_bwd_params(ctx['dq'], dz_q, True)
+                if n_d < T:
+                    dx_q[n_d * M:].zero_()
+                d_pe_a = K.bn_bwd(ctx['pe_a'], dx_q, p['per/fc/gamma'], ctx['pe_mean'], ctx['pe_rstd'], k, 1,
+                                  False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)),
+                                  dbias=g['per/fc/b'])
+                K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
+        else:
+            # baselines: the program decoder is the only one
+            dz_p = self._decoders_bwd_rec([(ctx['dp'], dl_p, d_init_h, d_init_c)])[0]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dx_p = self._lstm_bwd_params(ctx['dp'], dz_p, True)
+                K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
+
         d_h1f, d_c1f = self._buf('d_h1f', (M, U)), self._buf('d_c1f', (M, U))
-        K.group_mean_bwd(None, dh0_2, d_h1f, B, k, U, False)
-        K.group_mean_bwd(None, dc0_2, d_c1f, B, k, U, False)
+        if self.variant == 'synthesis_baseline':
+            # pooled final states of the only encoder pass; no gradient through its outputs
+            if self.demo_aggregation == 'avgpool':
+                K.group_mean_bwd(d_init_h, None, d_h1f, B, k, U, False)
+                K.group_mean_bwd(d_init_c, None, d_c1f, B, k, U, False)
+            else:
+                K.group_max_bwd(d_init_h, ctx['arg_h'], d_h1f, B, k, U, False)
+                K.group_max_bwd(d_init_c, ctx['arg_c'], d_c1f, B, k, U, False)
+            d_hout1 = None
+        else:
+            if not self.multitask:
+                d_demo_h, d_demo_c = self._buf('d_demo_h', (M, U)), self._buf('d_demo_c', (M, U))
+                d_demo_h.zero_()
+                d_demo_c.zero_()
+            # ---- SummarizeFeature('rn') backward (adds into d_demo_{h,c})
+            self._rn_bwd(ctx['rn_h'], d_init_h, d_demo_h, B, k, U)
+            self._rn_bwd(ctx['rn_c'], d_init_c, d_demo_c, B, k, U)
+
+            # ---- SecondPathEncoder backward: only the final states carry gradient
+            e2 = ctx['e2']
+            dh0_2, dc0_2 = self._buf('dh0_2', (M, U)), self._buf('dc0_2', (M, U))
+            d_hout1 = self._lstm_bwd(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2, want_dx=True)
+            # summary = mean_k(step-1 final states), broadcast to every demo of the program
+            K.group_mean_bwd(None, dh0_2, d_h1f, B, k, U, False)
+            K.group_mean_bwd(None, dc0_2, d_c1f, B, k, U, False)
         # ---- Demo_Encoder LSTM backward
         d_feats_tm = self._lstm_bwd(ctx['e1'], d_hout1, d_h1f, d_c1f, None, None, want_dx=True)
         d_feats = K.transpose_rt(d_feats_tm.view(T, M, F), T, M, F, out=self._buf('d_feats', (M, T, F)))
@@ -652,7 +721,8 @@ class Model(object):
         p, g = self.params.p, self.params.g
         s = r['scope']
         W1, W2 = p[s + '/fc1/W'], p[s + '/fc2/W']
-        K.group_mean_bwd(d_out, None, d_feat, B, k, U, True)                 # the avg-pool branch
+        if r['add_mean']:
+            K.group_mean_bwd(d_out, None, d_feat, B, k, U, True)             # the avg-pool branch
         dy2 = self._buf(s + '/dy2', (B * k * k, U))
         K.pair_mean_bwd(d_out, dy2, B, k * k, U)
         dy2a = K.bn_bwd(r['y2a'], dy2, p[s + '/fc2/gamma'], r['m2'], r['r2'], 1, 1, True,
@@ -684,9 +754,10 @@ class Model(object):
         U, V, A = c.num_lstm_cell_units, c.dim_program_token, c.action_space
         M = B * k
         out = {}
-        for scope, R, steps, tok, h0, c0, end in (
-                ('prog', B, L, V, ctx['rn_h']['out'], ctx['rn_c']['out'], self.PROGRAM_END_TOKEN),
-                ('act', M, T, A, ctx['demo_h'], ctx['demo_c'], A - 1)):
+        todo = [('prog', B, L, V, ctx['init_h'], ctx['init_c'], self.PROGRAM_END_TOKEN)]
+        if self.multitask:
+            todo.append(('act', M, T, A, ctx['demo_h'], ctx['demo_c'], A - 1))
+        for scope, R, steps, tok, h0, c0, end in todo:
             kernel, bias = p[scope + '/lstm/kernel'], p[scope + '/lstm/bias']
             # input projection of every possible token, once: [tok+1, 4U]
             table_proj = K.matmul_nn(p[scope + '/embedding'], kernel[:U], bias=bias,
@@ -698,14 +769,16 @@ class Model(object):
                             logits, ids, lens)
             out[scope] = (logits, ids, lens)
         lp, ip, np_ = out['prog']
-        la, ia, na = out['act']
         self._greedy = dict(
             greedy_pred_program=lp.permute(1, 2, 0),                  # [B, V, L]
             greedy_program_tokens=ip.permute(1, 0),                   # [B, L]
-            greedy_pred_program_len=np_.view(B, 1),
-            greedy_pred_action=la.view(T, B, k, A).permute(1, 2, 0, 3),   # [B, k, T, A]
-            greedy_action_tokens=ia.view(T, B, k).permute(1, 2, 0),       # [B, k, T]
-            greedy_pred_action_len=na.view(B, k))
+            greedy_pred_program_len=np_.view(B, 1))
+        if self.multitask:
+            la, ia, na = out['act']
+            self._greedy.update(
+                greedy_pred_action=la.view(T, B, k, A).permute(1, 2, 0, 3),   # [B, k, T, A]
+                greedy_action_tokens=ia.view(T, B, k).permute(1, 2, 0),       # [B, k, T]
+                greedy_pred_action_len=na.view(B, k))
         return self._greedy
 
     @staticmethod
@@ -753,7 +826,9 @@ class Model(object):
         dlen = f['demo_len'].cpu().numpy().reshape(B, k)
         gt_act = f['a_h'].view(B, k, T, self.action_space).permute(0, 1, 3, 2).cpu().numpy()
         t = self._terms.cpu().numpy()
-        loss = {'program_loss': float(t[0]), 'avg_action_loss': float(t[1]), 'avg_per_loss': float(t[2])}
+        loss = {'program_loss': float(t[0])}
+        if self.multitask:
+            loss.update({'avg_action_loss': float(t[1]), 'avg_per_loss': float(t[2])})
         acc, hist, rows = {}, {}, {}
         gt_tokens = gt_prog.argmax(axis=1)
 
@@ -819,10 +894,11 @@ class Model(object):
                 hist['program_execution_acc_hist'] = r['hist']
             if 'test_hist' in r:
                 hist['test_program_execution_acc_hist'] = r['test_hist']
-        pa = self.pred_action.permute(0, 1, 3, 2).cpu().numpy()
-        sts = [self.sequence_stats(pa[:, i], gt_act[:, i], dlen[:, i], dlen[:, i]) for i in range(k)]
-        acc['avg_action_token_acc'] = float(np.mean([s_['token_acc'] for s_ in sts]))
-        acc['avg_action_seq_acc'] = float(np.mean([s_['seq_acc'] for s_ in sts]))
+        if self.multitask:
+            pa = self.pred_action.permute(0, 1, 3, 2).cpu().numpy()
+            sts = [self.sequence_stats(pa[:, i], gt_act[:, i], dlen[:, i], dlen[:, i]) for i in range(k)]
+            acc['avg_action_token_acc'] = float(np.mean([s_['token_acc'] for s_ in sts]))
+            acc['avg_action_seq_acc'] = float(np.mean([s_['seq_acc'] for s_ in sts]))
         if with_greedy:
             g = self.greedy_decode()
             glen = g['greedy_pred_program_len'].cpu().numpy().reshape(-1)
@@ -836,11 +912,12 @@ class Model(object):
                     hist['greedy_program_execution_acc_hist'] = r['hist']
                 if 'test_hist' in r:
                     hist['test_greedy_program_execution_acc_hist'] = r['test_hist']
-            ga = g['greedy_pred_action'].permute(0, 1, 3, 2).cpu().numpy()
-            gl = g['greedy_pred_action_len'].cpu().numpy()
-            sts = [self.sequence_stats(ga[:, i], gt_act[:, i], gl[:, i], dlen[:, i]) for i in range(k)]
-            acc['greedy_avg_action_token_acc'] = float(np.mean([s_['token_acc'] for s_ in sts]))
-            acc['greedy_avg_action_seq_acc'] = float(np.mean([s_['seq_acc'] for s_ in sts]))
+            if self.multitask:
+                ga = g['greedy_pred_action'].permute(0, 1, 3, 2).cpu().numpy()
+                gl = g['greedy_pred_action_len'].cpu().numpy()
+                sts = [self.sequence_stats(ga[:, i], gt_act[:, i], gl[:, i], dlen[:, i]) for i in range(k)]
+                acc['greedy_avg_action_token_acc'] = float(np.mean([s_['token_acc'] for s_ in sts]))
+                acc['greedy_avg_action_seq_acc'] = float(np.mean([s_['seq_acc'] for s_ in sts]))
         self.report_accuracy, self.report_hist, self._program_rows = acc, hist, rows
         return loss, acc
 

@@ -49,6 +49,15 @@ def param_shapes(config):
     s['per/lstm/kernel'] = (2 * U, 4 * U)
     s['per/lstm/bias'] = (4 * U,)
     s['per/proj'] = (U, config.per_dim)
+    model = getattr(config, 'model', 'full')
+    if model == 'summarizer':            # models/baselines/model_summarizer.py: no multi-task decoders
+        drop = ('act/', 'per/')
+    elif model == 'synthesis_baseline':  # model_synthesis.py: nor second pass / relation network
+        drop = ('act/', 'per/', 'second_lstm/', 'rn_h/', 'rn_c/')
+    else:
+        drop = None
+    if drop:
+        s = OrderedDict((n, sh) for n, sh in s.items() if not n.startswith(drop))
     return s
 
 

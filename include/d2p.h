@@ -302,6 +302,11 @@ int d2p_group_mean(int B, int k, int U, const float* x, float* out, float* bcast
 /* dx[b,i,:] (=|+=) (dout[b,:] + sum_i dbcast[b,i,:]) / k   (dbcast may be NULL) */
 int d2p_group_mean_bwd(int B, int k, int U, const float* dout, const float* dbcast, float* dx,
                        int accumulate, d2p_stream_t stream);
+/* max over k with the winning index (ties: lowest), and its backward -- the 'maxpool' demo
+ * aggregation of the synthesis baseline (models/baselines/model_synthesis.py:345-358) */
+int d2p_group_max(int B, int k, int U, const float* x, float* out, int* arg, d2p_stream_t stream);
+int d2p_group_max_bwd(int B, int k, int U, const float* dout, const int* arg, float* dx,
+                      int accumulate, d2p_stream_t stream);
 /* rn_pool first layer without materialising pairs:
  *   y[b,a,c,:] = lrelu(P[b,c,:] + Q[b,a,:] + bias)   with P = feat·W1[:U], Q = feat·W1[U:] */
 int d2p_rn_pair_fwd(int B, int k, int U, const float* P, const float* Q, const float* bias,

@@ -39,6 +39,11 @@ class OracleConfig:
     per_dim: int
     num_lstm_cell_units: int = 512
     dataset_type: str = 'karel'
+    # 'full' (models/model_full.py) or one of the program-synthesis ablations
+    # 'summarizer' (models/baselines/model_summarizer.py), 'synthesis_baseline'
+    # (models/baselines/model_synthesis.py); demo_aggregation only matters for the latter
+    model: str = 'full'
+    demo_aggregation: str = 'avgpool'
 
     @property
     def n_conv(self):
@@ -96,6 +101,12 @@ def param_shapes(cfg):
     shapes['per/lstm/kernel'] = (2 * U, 4 * U)
     shapes['per/lstm/bias'] = (4 * U,)
     shapes['per/proj'] = (U, cfg.per_dim)
+    model = getattr(cfg, 'model', 'full')
+    if model != 'full':
+        # the baselines have no multi-task decoders; the synthesis baseline also has neither the
+        # second encoder pass nor the relation network (model_synthesis.py:324-358)
+        drop = ('act/', 'per/') if model == 'summarizer' else ('act/', 'per/', 'second_lstm/', 'rn_h/', 'rn_c/')
+        shapes = {n: sh for n, sh in shapes.items() if not n.startswith(drop)}
     return shapes
 
 
@@ -331,6 +342,13 @@ def forward(p, batch, cfg, moving=None, fed_ids=None):
         step1_hist.append(outs)
         step1_h.append(h)
         step1_c.append(c)
+    model = getattr(cfg, 'model', 'full')
+    if model not in ('full', 'summarizer', 'synthesis_baseline'):
+        raise ValueError(model)
+    if model == 'synthesis_baseline':
+        # models/baselines/model_synthesis.py:324-358: one encoder pass, demonstrations pooled
+        return _baseline_tail(p, batch, cfg, torch.stack(step1_h, dim=1), torch.stack(step1_c, dim=1),
+                              None, None, bn_stats, fed_ids, moving)
     summary_h = torch.stack(step1_h, dim=1).mean(dim=1)      # :380-385 avgpool
     summary_c = torch.stack(step1_c, dim=1).mean(dim=1)
 
@@ -344,6 +362,9 @@ def forward(p, batch, cfg, moving=None, fed_ids=None):
         demo_c.append(c)
     stack_h = torch.stack(demo_h, dim=1)
     stack_c = torch.stack(demo_c, dim=1)
+    if model == 'summarizer':
+        # models/baselines/model_summarizer.py:345-352,389-394: relation network ONLY (no avg term)
+        return _baseline_tail(p, batch, cfg, stack_h, stack_c, summary_h, summary_c, bn_stats, fed_ids, moving)
     demo_h_summary = stack_h.mean(dim=1) + rn_pool(stack_h, p, 'rn_h', moving)   # :399-404
     demo_c_summary = stack_c.mean(dim=1) + rn_pool(stack_c, p, 'rn_c', moving)
 
@@ -407,6 +428,37 @@ def forward(p, batch, cfg, moving=None, fed_ids=None):
                 demo_h=stack_h, demo_c=stack_c,
                 demo_h_summary=demo_h_summary, demo_c_summary=demo_c_summary,
                 bn_stats=bn_stats)
+
+
+def _baseline_tail(p, batch, cfg, stack_h, stack_c, summary_h, summary_c, bn_stats, fed_ids, moving):
+    """Program decoder + program loss of the two program-synthesis baselines
+    (model_summarizer.py:500-518,834-847; model_synthesis.py:461-479,795-808): the only loss term."""
+    dt = stack_h.dtype
+    B, L, V = cfg.batch_size, cfg.max_program_len, cfg.dim_program_token
+    program_len = batch['program_len'].to(torch.int64).reshape(B)
+    if cfg.model == 'summarizer':
+        demo_h_summary = rn_pool(stack_h, p, 'rn_h', moving)
+        demo_c_summary = rn_pool(stack_c, p, 'rn_c', moving)
+    elif cfg.demo_aggregation == 'avgpool':
+        demo_h_summary, demo_c_summary = stack_h.mean(dim=1), stack_c.mean(dim=1)
+    elif cfg.demo_aggregation == 'maxpool':
+        demo_h_summary, demo_c_summary = stack_h.max(dim=1).values, stack_c.max(dim=1).values
+    else:
+        # 'concat' hands a [B, k*U] state to a U-unit cell (model_synthesis.py:339-341,463-467)
+        raise ValueError('Unknown demo aggregation type')
+    tokens = batch['program_tokens'].to(torch.int64)
+    ptoks = torch.cat([torch.full((B, 1), V + 1, dtype=tokens.dtype), tokens[:, :-1]], dim=1)
+    if fed_ids is not None:
+        ptoks = fed_ids['prog'].to(torch.int64)
+    pemb = embedding_lookup_oob0(p['prog/embedding'], ptoks)
+    pred_program = training_decoder(pemb, program_len, demo_c_summary, demo_h_summary,
+                                    p['prog/lstm/kernel'], p['prog/lstm/bias'], p['prog/proj'], L)
+    program_loss = sequence_loss(pred_program, batch['program'].to(dt), program_len, L, V, 'program')
+    zero = program_loss.detach() * 0
+    return dict(loss=program_loss, program_loss=program_loss, avg_action_loss=zero, avg_per_loss=zero,
+                pred_program=pred_program, summary_h=summary_h, summary_c=summary_c,
+                demo_h=stack_h, demo_c=stack_c, demo_h_summary=demo_h_summary,
+                demo_c_summary=demo_c_summary, bn_stats=bn_stats)
 
 
 def loss_and_grads(params, batch, cfg, dtype=torch.float32, fed_ids=None):
@@ -523,6 +575,8 @@ def greedy_program_and_actions(p, batch, cfg, fwd):
     gp, gp_ids, gp_len = greedy_decoder(p['prog/embedding'], fwd['demo_c_summary'], fwd['demo_h_summary'],
                                         p['prog/lstm/kernel'], p['prog/lstm/bias'], p['prog/proj'],
                                         start_id=V, end_id=3, max_len=L)     # 'm)' == 3
+    if getattr(cfg, 'model', 'full') != 'full':                               # baselines: program only
+        return dict(greedy_pred_program=gp, greedy_program_ids=gp_ids, greedy_pred_program_len=gp_len)
     acts = [greedy_decoder(p['act/embedding'], fwd['demo_c'][:, i], fwd['demo_h'][:, i],
                            p['act/lstm/kernel'], p['act/lstm/bias'], p['act/proj'],
                            start_id=A, end_id=A - 1, max_len=T) for i in range(k)]

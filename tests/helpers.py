@@ -15,7 +15,8 @@ def oracle_config(cfg):
         max_program_len=cfg.max_program_len, h=cfg.h, w=cfg.w, depth=cfg.depth,
         dim_program_token=cfg.dim_program_token, action_space=cfg.action_space,
         per_dim=cfg.per_dim, num_lstm_cell_units=cfg.num_lstm_cell_units,
-        dataset_type=cfg.dataset_type)
+        dataset_type=cfg.dataset_type, model=getattr(cfg, 'model', 'full'),
+        demo_aggregation=getattr(cfg, 'demo_aggregation', 'avgpool'))
 
 
 def perturbed_params(cfg, seed):

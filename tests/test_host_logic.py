@@ -74,8 +74,24 @@ def test_model_class_lookup_and_errors():
     with pytest.raises(ValueError):
         Trainer.get_model_class('bogus')
     with pytest.raises(NotImplementedError):
-        Trainer.get_model_class('summarizer')
-    assert Trainer.get_model_class('full').__name__ == 'Model'
+        Trainer.get_model_class('induction_baseline')
+    for name in ('full', 'summarizer', 'synthesis_baseline'):      # one graph, three variants
+        assert Trainer.get_model_class(name).__name__ == 'Model'
+
+
+def test_baseline_parameter_sets():
+    from demo2program_amd.params import param_shapes
+    import oracle
+    from helpers import oracle_config
+    full = set(param_shapes(make_config('karel')))
+    summ = set(param_shapes(make_config('karel', model='summarizer')))
+    synt = set(param_shapes(make_config('karel', model='synthesis_baseline')))
+    assert synt < summ < full
+    assert not any(n.startswith(('act/', 'per/')) for n in summ) and 'rn_h/fc1/W' in summ
+    assert not any(n.startswith(('second_lstm/', 'rn_')) for n in synt) and 'demo_lstm/kernel' in synt
+    for model in ('full', 'summarizer', 'synthesis_baseline'):
+        cfg = make_config('karel_tiny', model=model)
+        assert list(param_shapes(cfg).items()) == list(oracle.param_shapes(oracle_config(cfg)).items())
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')

@@ -65,6 +65,53 @@ def test_forward_backward_matches_oracle_small(kind):
     _check_against_oracle(cfg, params, batch, out, grads)
 
 
+@pytest.mark.parametrize('kind,model,agg', [
+    ('karel', 'summarizer', 'avgpool'), ('karel', 'synthesis_baseline', 'avgpool'),
+    ('karel', 'synthesis_baseline', 'maxpool'), ('vizdoom', 'summarizer', 'avgpool'),
+    ('vizdoom', 'synthesis_baseline', 'maxpool')])
+def test_baseline_variants_match_oracle(kind, model, agg):
+    """models/baselines/model_summarizer.py and model_synthesis.py as variants of the same graph:
+    loss, program logits and every gradient against the oracle's restatement of them; the greedy
+    program decoder too."""
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.synthetic import to_torch
+    cfg, params, batch = small_case(kind, seed=23, model=model, demo_aggregation=agg)
+    assert not any(n.startswith(('act/', 'per/')) for n in params)
+    out, grads = run_oracle(cfg, params, batch, dtype=torch.float64)
+    m = Model(cfg, params=params)
+    loss = m.forward(m.get_feed_dict(batch))
+    m.backward()
+    ref = float(out['loss'])
+    assert abs(float(loss.item()) - ref) <= 1e-5 * abs(ref) + 1e-6
+    assert _maxerr(m.pred_program, out['pred_program']) <= 1e-4
+    g = m.params.to_numpy('g')
+    assert set(g) == set(grads)
+    for n, r in grads.items():
+        r = r.double().numpy()
+        assert np.abs(g[n] - r).max() <= 2e-4 * np.abs(r).max() + 1e-6, n
+    rl, acc = m.report(with_greedy=True)
+    assert set(rl) == {'program_loss'} and 'avg_action_token_acc' not in acc
+    assert 'greedy_program_syntax_acc' in acc
+    p64 = {n: torch.from_numpy(v).double() for n, v in params.items()}
+    tb = to_torch(batch)
+    fwd = oracle.forward(p64, tb, oracle_config(cfg))
+    gref = oracle.greedy_program_and_actions(p64, tb, oracle_config(cfg), fwd)
+    assert torch.equal(m.greedy_pred_program_len.view(-1).cpu().long(), gref['greedy_pred_program_len'])
+    assert _maxerr(m.greedy_pred_program, gref['greedy_pred_program']) <= 1e-4
+
+
+def test_baseline_trains_through_the_trainer():
+    from demo2program_amd.trainer import Trainer
+    cfg, params, batch = small_case('karel', seed=31, model='summarizer')
+    tr = Trainer(cfg, make_train_dir=False)
+    tr.model.params.load(params)
+    feed = tr.model.get_feed_dict(batch)
+    losses = [float(tr.train_step(feed).item()) for _ in range(30)]
+    assert losses[-1] < 0.7 * losses[0], losses[::6]
+    with pytest.raises(ValueError):
+        Trainer(small_case('karel', model='synthesis_baseline', demo_aggregation='concat')[0], make_train_dir=False)
+
+
 def test_forward_backward_matches_oracle_u512_karel():
     # full-width cells (U=512, the shipped configuration) on a small batch
     cfg, params, batch = small_case('karel', seed=11, batch_size=2, k=2, max_demo_len=8,
@@ -439,6 +486,16 @@ def test_trainer_and_evaler_command_lines(tmp_path, monkeypatch, capsys):
     assert '[Final Avg Report]' in out and 'test_greedy_program_execution_acc_hist' in out
     listing = glob.glob(str(tmp_path / 'eval2' / 'out_*_train.txt'))
     assert len(listing) == 1 and '[id: ' in open(listing[0]).read()
+    # a baseline through the same two entry points (trainer.py:18-30 model switch)
+    base = ['--model', 'synthesis_baseline', '--demo_aggregation', 'maxpool', '--dataset_path', ds, '--batch_size', '4',
+            '--num_k', '3', '--num_lstm_cell_units', '64']
+    trainer.main(base + ['--max_steps', '4', '--prefix', 'clibase'])
+    dirs = glob.glob(str(tmp_path / 'train_dir' / 'karel-*synthesis_baseline*clibase*'))
+    assert len(dirs) == 1, os.listdir(str(tmp_path / 'train_dir'))
+    capsys.readouterr()
+    evaler.main(base + ['--train_dir', dirs[0], '--dataset_split', 'train', '--max_steps', '1'])
+    out = capsys.readouterr().out
+    assert 'greedy_exact_program_accuracy' in out and 'avg_action_loss' not in out
 
 
 def test_vizdoom_command_lines_and_metrics(tmp_path, monkeypatch, capsys):
