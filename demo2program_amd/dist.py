@@ -17,6 +17,7 @@ the one exchange step the sharded path needs:
 ``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used for the CPU tests.
 """
 import os
+import sys
 
 import torch
 
@@ -29,12 +30,17 @@ class DataParallel(object):
         self.initialized = initialized
 
     @classmethod
-    def from_env(cls, backend=None):
-        """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run)."""
+    def from_env(cls, backend=None, force_init=None):
+        """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (set by torch.distributed.run).
+        force_init (or D2P_FORCE_DIST=1): create the process group even for a single rank, so the
+        RCCL calls of the exchange step run (as identities) on a one-GPU box -- the self-test of
+        SURVEY 8(e)(iii)."""
         world = int(os.environ.get('WORLD_SIZE', '1'))
         rank = int(os.environ.get('RANK', '0'))
         local = int(os.environ.get('LOCAL_RANK', str(rank)))
-        if world <= 1:
+        if force_init is None:
+            force_init = os.environ.get('D2P_FORCE_DIST', '0') == '1'
+        if world <= 1 and not force_init:
             if torch.cuda.is_available():
                 torch.cuda.set_device(0)
             return cls(0, 1, False)
@@ -48,7 +54,25 @@ class DataParallel(object):
         if backend is None:
             backend = 'nccl' if use_cuda else 'gloo'
         if not dist.is_initialized():
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            # RCCL prints a version banner on STDOUT when its communicator comes up; stdout is the
+            # bench's one-JSON-line channel, so the process-level fd 1 points at stderr until the
+            # communicator exists (forced here by a first tiny all-reduce)
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                if backend == 'nccl':
+                    dev = torch.device('cuda', torch.cuda.current_device())
+                    dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=dev)
+                    warm = torch.zeros(1, device=dev)
+                    dist.all_reduce(warm)
+                    torch.cuda.synchronize()
+                else:
+                    dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
         return cls(rank, world, True)
 
     @property
@@ -56,14 +80,15 @@ class DataParallel(object):
         return 1.0 / self.world_size
 
     def all_reduce_grads(self, flat_grad):
-        """SUM the flat gradient buffer across ranks, in place (no-op for one rank)."""
-        if self.world_size > 1:
+        """SUM the flat gradient buffer across ranks, in place (no-op for one rank without a
+        process group)."""
+        if self.world_size > 1 or self.initialized:
             import torch.distributed as dist
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         return flat_grad
 
     def broadcast_params(self, flat_params, src=0):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.initialized:
             import torch.distributed as dist
             dist.broadcast(flat_params, src=src)
         return flat_params
@@ -74,13 +99,13 @@ class DataParallel(object):
         return list(ids)[self.rank::self.world_size]
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.world_size > 1 or self.initialized:
             import torch.distributed as dist
             dist.barrier()
 
     def max_over_ranks(self, value):
         """max of a python float across ranks (bench timing)."""
-        if self.world_size <= 1:
+        if self.world_size <= 1 and not self.initialized:
             return value
         import torch.distributed as dist
         dev = 'cuda' if torch.cuda.is_available() and dist.get_backend() == 'nccl' else 'cpu'

@@ -733,3 +733,39 @@ def test_headline_config_properties():
     assert torch.isfinite(g1).all() and float(g1.norm()) > 0
     n = feed['n_prog']
     assert model.pred_program[:, :, n:].abs().max().item() == 0 if n < cfg.max_program_len else True
+
+
+def test_rccl_single_rank_self_test(monkeypatch):
+    """the exchange step's RCCL calls (broadcast of the flat parameters,
+    all-reduce of the flat gradient, the bench's MAX reduce and barrier) on a one-rank process
+    group, through Trainer.train_step: same losses as without a process group."""
+    import socket
+    from demo2program_amd.dist import DataParallel
+    from demo2program_amd.trainer import Trainer
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    for n, v in (('RANK', '0'), ('LOCAL_RANK', '0'), ('WORLD_SIZE', '1'), ('MASTER_ADDR', '127.0.0.1'),
+                 ('MASTER_PORT', str(port))):
+        monkeypatch.setenv(n, v)
+    cfg, params, batch = small_case('karel', seed=37)
+
+    def run(dp):
+        tr = Trainer(cfg, make_train_dir=False, dp=dp)
+        tr.model.params.load(params)
+        if dp is not None:
+            dp.broadcast_params(tr.model.params.flat)
+        feed = tr.model.get_feed_dict(batch)
+        return [float(tr.train_step(feed).item()) for _ in range(4)]
+
+    plain = run(None)
+    dp = DataParallel.from_env(force_init=True)
+    try:
+        import torch.distributed as dist
+        assert dp.initialized and dist.get_backend() == 'nccl' and dp.world_size == 1
+        with_group = run(dp)
+        assert dp.max_over_ranks(1.25) == 1.25
+        dp.barrier()
+    finally:
+        dp.shutdown()
+    assert with_group == plain
