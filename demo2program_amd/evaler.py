@@ -7,7 +7,8 @@ GPU and the program metrics (syntax / exact program / execution accuracy, Karel)
 Checkpoints are this build's own .npz files (trainer.Trainer.save_checkpoint; TF checkpoints
 cannot be read offline).  `--pred_program` writes the reference's text listing
 (`[id: ..]\\ngt: ..\\npred: ..\\ngreedy: ..`) and, in place of its HDF5 file (h5py is not in this
-image), a .json with the same per-program fields.
+image), a .json with the same per-program fields; `--result_data` writes the reference's per-program
+groups (program, pred_program, pred_program_len, s_h, test_s_h) as '<id>/<field>' entries of an .npz.
 """
 import argparse
 import glob
@@ -120,6 +121,10 @@ class Evaler(object):
             text_file = open('{}.txt'.format(base_name), 'w')
             log_file = open('{}.log'.format(base_name), 'w')
             dsl = self.model.vocab
+        # --result_data (evaler.py:130-162): per program the ground truth, the greedy prediction and
+        # its demonstrations.  The reference writes HDF5 groups; this build writes the same fields
+        # as '<id>/<field>' entries of an .npz (h5py is not in the training image)
+        result = {} if getattr(cfg, 'result_data', False) else None
         loss_all, acc_all, hist_all, time_all = [], [], {}, []
         loss_keys = acc_keys = None
         final_msg = ''
@@ -129,6 +134,18 @@ class Evaler(object):
             step_msg = ''
             if not getattr(cfg, 'quiet', False):
                 step_msg = self.log_step_message(s, loss, acc, hist, step_time)
+            if result is not None:
+                for i in range(len(program_id)):
+                    pid = str(program_id[i])
+                    if pid + '/program' in result:
+                        print('Duplicates: {}'.format(pid))
+                        continue
+                    result[pid + '/program'] = gt[i]
+                    result[pid + '/pred_program'] = greedy[i]
+                    result[pid + '/pred_program_len'] = np.asarray(greedy_len[i][0])
+                    if hasattr(self.dataset, 'get_data'):
+                        data = self.dataset.get_data(pid)
+                        result[pid + '/s_h'], result[pid + '/test_s_h'] = data[2], data[3]
             if pred_program:
                 log_file.write('{}\n'.format(step_msg))
                 correctness = ['wrong', 'correct']
@@ -175,6 +192,11 @@ class Evaler(object):
             text_file.close()
             with open('{}.json'.format(base_name), 'w') as f:
                 json.dump(records, f)
+        if result is not None:
+            path = getattr(cfg, 'result_data_path', 'result.hdf5')
+            path = (path[:-5] if path.endswith('.hdf5') else path) + ('' if path.endswith('.npz') else '.npz')
+            np.savez_compressed(path, **result)
+            print('Wrote %d programs to %s' % (len({n.split('/')[0] for n in result}), path))
         print('Completed Evaluation.')
 
     # ------------------------------------------------------------------ messages (reference formats)
@@ -264,13 +286,12 @@ class GeneratedKarelBatches(object):
 
 def main(argv=None):
     args = build_arg_parser().parse_args(argv)
-    if args.result_data:
-        raise NotImplementedError('--result_data writes HDF5 (h5py is not available in this image)')
     preset = 'karel' if args.dataset_type == 'karel' else 'vizdoom'
     config = make_config(preset, batch_size=args.batch_size, k=args.num_k, num_k=args.num_k, model=args.model,
                          dataset_path=args.dataset_path, encoder_rnn_type=args.encoder_rnn_type,
                          num_lstm_cell_units=args.num_lstm_cell_units, demo_aggregation=args.demo_aggregation)
-    for n in ('dataset_split', 'checkpoint', 'train_dir', 'output_dir', 'max_steps', 'no_loss', 'pred_program', 'quiet'):
+    for n in ('dataset_split', 'checkpoint', 'train_dir', 'output_dir', 'max_steps', 'no_loss', 'pred_program', 'quiet',
+              'result_data', 'result_data_path'):
         setattr(config, n, getattr(args, n))
     config.write_summary = not args.no_write_summary
     if has_dataset(config.dataset_path):

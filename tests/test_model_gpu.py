@@ -481,9 +481,13 @@ def test_trainer_and_evaler_command_lines(tmp_path, monkeypatch, capsys):
     # the dataset's own split, one pass (evaler.py:431-450): max_steps = len(split) // batch_size
     evaler.main(['--train_dir', dirs[0], '--dataset_path', ds, '--dataset_split', 'train', '--batch_size', '2',
                  '--num_k', '3', '--num_lstm_cell_units', '64', '--output_dir', str(tmp_path / 'eval2'),
-                 '--pred_program'])
+                 '--pred_program', '--result_data', '--result_data_path', str(tmp_path / 'result.hdf5')])
     out = capsys.readouterr().out
     assert '[Final Avg Report]' in out and 'test_greedy_program_execution_acc_hist' in out
+    res = np.load(str(tmp_path / 'result.npz'))
+    ids = sorted({n.split('/')[0] for n in res.files})
+    assert len(ids) >= 2 and res[ids[0] + '/pred_program'].shape == res[ids[0] + '/program'].shape
+    assert res[ids[0] + '/s_h'].shape[0] == 3 and res[ids[0] + '/test_s_h'].ndim == 5
     listing = glob.glob(str(tmp_path / 'eval2' / 'out_*_train.txt'))
     assert len(listing) == 1 and '[id: ' in open(listing[0]).read()
     # a baseline through the same two entry points (trainer.py:18-30 model switch)
