@@ -145,6 +145,9 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     static_assert(BK % 8 == 0, "K slab is consumed in chunks of 8");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+    // KS on a single 32x32 tile: the four waves' partial tiles are summed through LDS, so a
+    // workgroup writes finished values (or ONE split-K slab) -- the small-problem path
+    constexpr bool KSR = KS && BM == 32 && BN == 32;
     constexpr int A_LD = AL::KCONTIG ? (BK + 4) : BM;
     constexpr int B_LD = BL::KCONTIG ? (BK + 4) : BN;
     constexpr int A_SZ = AL::KCONTIG ? BM * (BK + 4) : BK * BM;
@@ -283,6 +286,27 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
 #undef D2P_GLOAD
 #undef D2P_SSTORE
 
+    if constexpr (KSR) {
+        static_assert(!KSR || 2 * (A_SZ + B_SZ) >= 4 * 1024, "LDS holds the four 32x32 partial tiles");
+        __syncthreads();                                   // every wave is done with the last slab
+#pragma unroll
+        for (int r = 0; r < 16; ++r) smem[wave * 1024 + r * 64 + lane] = acc[0][0][r];
+        __syncthreads();
+        const bool to_partial = gridDim.z > 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int idx = tid + e * 256;
+            const float s = ((smem[idx] + smem[1024 + idx]) + smem[2048 + idx]) + smem[3072 + idx];
+            const int r = idx >> 6, ln = idx & 63;
+            const int col = n0 + (ln & 31);
+            const int row = m0 + 4 * (ln >> 5) + (r & 3) + 8 * (r >> 2);
+            if (row < M && col < N) {
+                if (to_partial) partial[((long)blockIdx.z * M + row) * N + col] = s;
+                else ep.store(row, col, s + (ep.has_c() ? ep.c_value(row, col) : 0.f) + ep.col_value(col));
+            }
+        }
+        return;
+    }
     const bool split = KS || gridDim.z > 1;
     const int slab = KS ? blockIdx.z * 4 + wave : blockIdx.z;
     const bool with_c = !split && ep.has_c();
@@ -353,7 +377,7 @@ static int g_gemm_force_tile = -1;   // -1: automatic; else a GemmTile value (tu
 static int g_gemm_force_split = 0;   // 0: automatic
 
 enum GemmTile { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x32 = 2, TILE_256x32 = 3, TILE_128x64 = 4,
-                TILE_64x32_KS = 5, TILE_64x64_KS = 6 };
+                TILE_64x32_KS = 5, TILE_64x64_KS = 6, TILE_32x32_KSR = 7 };
 
 struct GemmPlan {
     int tile;     // GemmTile
@@ -363,7 +387,7 @@ struct GemmPlan {
     int slabs;    // partial slabs written (splits, or 4*splits in KS mode); 1 = no combine pass
 };
 
-static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
+static inline GemmPlan d2p_plan_gemm_base(int M, int N, int K, bool allow_split) {
     GemmPlan p;
     const long t128 = (long)ceil_div(M, 128) * ceil_div(N, 128);
     // Measured on MI355X (tools/bench_gemm.py): every tile shape tops out near 100 TFLOP/s, so
@@ -390,8 +414,16 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
     }
     if (g_gemm_force_tile >= 0) {
         p.tile = g_gemm_force_tile;
-        const int bms[7] = {64, 128, 128, 256, 128, 64, 64}, bns[7] = {64, 128, 32, 32, 64, 32, 64};
+        const int bms[8] = {64, 128, 128, 256, 128, 64, 64, 32}, bns[8] = {64, 128, 32, 32, 64, 32, 64, 32};
         p.bm = bms[p.tile]; p.bn = bns[p.tile];
+    }
+    if (p.tile == TILE_32x32_KSR) {                      // forced (tuning): one slab per workgroup
+        int s = (allow_split && g_gemm_force_split > 1) ? g_gemm_force_split : 1;
+        int kps = ((K + s - 1) / s + 31) / 32 * 32;
+        p.k_per_split = kps;
+        p.splits = (K + kps - 1) / kps;
+        p.slabs = p.splits;
+        return p;
     }
     const bool ks = (p.tile == TILE_64x32_KS || p.tile == TILE_64x64_KS);
     p.splits = 1;
@@ -431,6 +463,32 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
             p.slabs = p.splits;
         }
     }
+    return p;
+}
+
+static int g_gemm_small_ksr = 1;   // 0: never pick the 32x32 wave-split tile automatically
+
+static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
+    GemmPlan p = d2p_plan_gemm_base(M, N, K, allow_split);
+    if (g_gemm_force_tile >= 0 || g_gemm_force_split > 1 || !g_gemm_small_ksr) return p;
+    // Small problems: the plan above would occupy fewer than half the CUs, each workgroup walking a
+    // long K loop alone (measured 19 us for 320x512x512 on 40 workgroups).  32x32 tiles give 4x
+    // the workgroups, the four waves of each split K between them and combine through LDS.
+    const long wgs = (long)ceil_div(M, p.bm) * ceil_div(N, p.bn) * p.splits;
+    if (wgs >= 128 || K < 128) return p;
+    const long t32 = (long)ceil_div(M, 32) * ceil_div(N, 32);
+    long s = 1;
+    if (allow_split && K >= 1024 && t32 < 256) {
+        s = (512 + t32 - 1) / t32;                       // ~2 workgroups per CU
+        const long maxs = K / 256;                       // >= 64 of K per wave
+        if (s > maxs) s = maxs;
+        if (s < 1) s = 1;
+    }
+    p.tile = TILE_32x32_KSR; p.bm = 32; p.bn = 32;
+    int kps = (int)(((K + s - 1) / s + 31) / 32 * 32);
+    p.k_per_split = kps;
+    p.splits = (K + kps - 1) / kps;
+    p.slabs = p.splits;
     return p;
 }
 
@@ -475,6 +533,7 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         case TILE_128x64: d2p_launch_tile<128, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         case TILE_64x32_KS: d2p_launch_tile<64, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         case TILE_64x64_KS: d2p_launch_tile<64, 64, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_32x32_KSR: d2p_launch_tile<32, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st); break;
         default:
             // long-K problems on the small tile: 32-deep slabs (half the barriers, 128-byte runs)
             if (g_gemm_bk32 && K >= 256 && fast)

@@ -55,8 +55,9 @@ int d2p_device_info(int device, char* name, int name_len, int* cus, int* wave, s
  * C = act(A·B + C_old + bias)).
  * ws: scratch for split-K, at least d2p_gemm_ws_bytes(M,N,K) bytes (may be NULL if 0). */
 size_t d2p_gemm_ws_bytes(int M, int N, int K);
-/* Tuning knob for the dense entry points: 1 (default) lets long-K problems on the 64x64 tile use
- * 32-deep K slabs, 0 keeps 16. */
+/* Tuning knobs for the dense entry points (bit mask): bit 0 lets long-K problems on the 64x64 tile
+ * use 32-deep K slabs; bit 1 switches OFF the small-problem path (32x32 tiles whose four waves split
+ * K and combine through LDS, picked when the ordinary plan would fill fewer than 128 workgroups). */
 int d2p_gemm_set_option(int bk32);
 /* Tuning experiments only: force the tile (0 64x64, 1 128x128, 2 128x32, 3 256x32, 4 128x64; -1 auto)
  * and the split-K factor (0 auto) of the dense entry points. */

@@ -42,7 +42,10 @@ def rnd(*shape, seed=0, scale=1.0):
                                     (33, 512, 5), (1, 1, 1), (130, 260, 1030), (144, 16, 20480), (36, 16, 40961),
                                     (288, 48, 12000), (432, 48, 8200),
                                     (1024, 1024, 64), (6400, 5, 512), (1600, 50, 512), (37, 64, 260), (6400, 512, 6),
-                                    (333, 512, 16), (512, 6, 6400), (5, 512, 6400), (512, 50, 1600), (3, 700, 2048)])
+                                    (333, 512, 16), (512, 6, 6400), (5, 512, 6400), (512, 50, 1600), (3, 700, 2048),
+                                    # the small-problem path (32x32 tiles, K split across the waves)
+                                    (320, 512, 512), (512, 512, 320), (70, 45, 300), (31, 33, 129), (100, 100, 1100),
+                                    (1568, 50, 512), (32, 32, 128), (95, 200, 4099)])
 def test_gemm_nn_nt_tn(K, M, N, K_):
     A = rnd(M, K_, seed=1)
     B = rnd(K_, N, seed=2)
@@ -67,6 +70,28 @@ def test_gemm_epilogue_bias_lrelu_accumulate_and_strides(K):
     K.gemm_raw('nn', M, N, K_, dev(A), K_, dev(B), N, view.data_ptr(), 3 * N)
     close(big[:, N:2 * N], A @ B, atol=1e-4)
     assert big[:, :N].abs().max().item() == 0 and big[:, 2 * N:].abs().max().item() == 0
+
+
+def test_gemm_small_problem_path_epilogues_and_switch(K):
+    """The 32x32 wave-split tile applies the same epilogue (bias, leaky relu, accumulate) and can be
+    switched off (d2p_gemm_set_option bit 1): same values either way, within summation order."""
+    from demo2program_amd.lib import call
+    M, N, K_ = 320, 512, 512
+    A, B, bias, C0 = rnd(M, K_, seed=13), rnd(K_, N, seed=14), rnd(N, seed=15), rnd(M, N, seed=16)
+    outs = []
+    for off in (0, 2):
+        call.d2p_gemm_set_option(off)
+        try:
+            o1 = K.matmul_nn(dev(A), dev(B), bias=dev(bias), act=1)
+            c = dev(C0)
+            K.matmul_nt(dev(A), dev(B.t().contiguous()), out=c, accumulate=True)
+            outs.append((o1.clone(), c.clone()))
+        finally:
+            call.d2p_gemm_set_option(0)
+    close(outs[0][0], oracle.lrelu(A @ B + bias), atol=2e-4)
+    close(outs[0][1], A @ B + C0, atol=2e-4)
+    assert (outs[0][0] - outs[1][0]).abs().max().item() < 1e-4
+    assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-4
 
 
 def test_gemm_is_transpose_detecting(K):

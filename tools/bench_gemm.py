@@ -41,6 +41,8 @@ def main():
     only = len(sys.argv) > 1 and sys.argv[1] == 'small'
     if only:
         del SHAPES[3:]
+        SHAPES.extend([('nn', 3200, 512, 512, 'rn fc2 fwd (3200x512, K=512)'), ('tn', 512, 512, 3200, 'rn fc2 dW'),
+                       ('tn', 512, 2048, 320, 'h0 dWh (512x2048, K=320)'), ('nn', 1568, 2048, 512, 'prog x-proj')])
     build.build_library()
     lib = load()
     g = torch.Generator().manual_seed(0)
@@ -62,15 +64,19 @@ def main():
         res = {}
         ws_need = 16 * M * N * 4
         K.SCRATCH.reserve(ws_need)
+        if only:
+            variants = variants + [('64x64 bk32', 0, 0), ('64x64 bk32 s2', 0, 2), ('64x64 bk32 s4', 0, 4)]
         for rnd in range(2):
             for name, tile, sp in variants:
                 if sp and Kd // sp < 64:
                     continue
                 if only and name.split()[0] not in ('auto', '64x64'):
                     continue
+                lib.d2p_gemm_set_option(1 if 'bk32' in name else 0)
                 lib.d2p_gemm_force_plan(tile, sp)
                 res.setdefault(name, []).append(timed(fn, 20))
         lib.d2p_gemm_force_plan(-1, 0)
+        lib.d2p_gemm_set_option(0)
         print(label)
         print('    ' + '  '.join('%s %.0fus %.0fTF' % (n, min(t) * 1e6, fl / min(t) / 1e12) for n, t in res.items()))
 

@@ -1,0 +1,64 @@
+#!/usr/bin/env python
+"""Per-shape census of the dense GEMM launches of one training step (run on the GPU box):
+every d2p_gemm_f32_* call of an eager forward+backward is bracketed with events (one stream,
+synchronised), grouped by (kind, M, N, K, accumulate, bias/act) and printed by summed time."""
+import collections
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ['D2P_NO_SIDE_STREAM'] = '1'
+from demo2program_amd import kernels as K  # noqa: E402
+from demo2program_amd.config import make_config  # noqa: E402
+from demo2program_amd.synthetic import make_batch  # noqa: E402
+from demo2program_amd.trainer import Trainer  # noqa: E402
+
+
+def main():
+    preset = sys.argv[1] if len(sys.argv) > 1 else 'karel'
+    cfg = make_config(preset)
+    tr = Trainer(cfg, make_train_dir=False, use_graph=False)
+    feed = tr.model.get_feed_dict(make_batch(cfg, seed=1))
+    for _ in range(3):
+        tr.train_step(feed)
+    torch.cuda.synchronize()
+    rec = collections.OrderedDict()
+    orig = K.gemm_raw
+
+    def timed(kind, M, N, Kd, A, lda, B, ldb, C, ldc, bias=None, act=0, accumulate=False, allow_split=True):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(kind, M, N, Kd, A, lda, B, ldb, C, ldc, bias, act, accumulate, allow_split)
+        e1.record()
+        key = (kind, M, N, Kd, bool(accumulate), bias is not None, act)
+        rec.setdefault(key, []).append((e0, e1))
+
+    K.gemm_raw = timed
+    reps = 5
+    for _ in range(reps):
+        tr.model.forward(feed)
+        tr.model.backward()
+    torch.cuda.synchronize()
+    K.gemm_raw = orig
+    rows = []
+    for key, evs in rec.items():
+        us = sum(a.elapsed_time(b) for a, b in evs) * 1e3 / reps
+        n = len(evs) / reps
+        kind, M, N, Kd = key[:4]
+        fl = 2.0 * M * N * Kd * n
+        rows.append((us, n, key, fl / (us * 1e-6) / 1e12 if us > 0 else 0.0))
+    rows.sort(reverse=True)
+    tot = sum(r[0] for r in rows)
+    print('%-4s %6s %6s %6s %5s %5s | %5s %9s %8s %6s' % ('kind', 'M', 'N', 'K', 'acc', 'epi', 'n', 'us/step', 'TFLOP/s', 'share'))
+    for us, n, key, tf in rows:
+        kind, M, N, Kd, acc, hasb, act = key
+        print('%-4s %6d %6d %6d %5s %5s | %5.1f %9.1f %8.1f %5.1f%%' % (kind, M, N, Kd, 'y' if acc else '-',
+              ('b' if hasb else '-') + str(act), n, us, tf, 100 * us / tot))
+    fl = sum(2.0 * k[1] * k[2] * k[3] * len(v) / reps for k, v in rec.items())
+    print('total %.1f us/step, %.1f GFLOP, %.1f TFLOP/s' % (tot, fl / 1e9, fl / tot / 1e6))
+
+
+if __name__ == '__main__':
+    main()
