@@ -42,7 +42,9 @@ def main():
     if only:
         del SHAPES[3:]
         SHAPES.extend([('nn', 3200, 512, 512, 'rn fc2 fwd (3200x512, K=512)'), ('tn', 512, 512, 3200, 'rn fc2 dW'),
-                       ('tn', 512, 2048, 320, 'h0 dWh (512x2048, K=320)'), ('nn', 1568, 2048, 512, 'prog x-proj')])
+                       ('tn', 512, 2048, 320, 'h0 dWh (512x2048, K=320)'), ('nn', 1568, 2048, 512, 'prog x-proj'),
+                       ('tn', 48, 2048, 6400, 'demo dWx (48x2048, K=6400)'), ('nt', 6400, 48, 2048, 'demo dX'),
+                       ('nn', 6400, 2048, 48, 'demo x-proj K=48'), ('nt', 3200, 512, 512, 'rn fc2 dy1')])
     build.build_library()
     lib = load()
     g = torch.Generator().manual_seed(0)
@@ -65,12 +67,14 @@ def main():
         ws_need = 16 * M * N * 4
         K.SCRATCH.reserve(ws_need)
         if only:
-            variants = variants + [('64x64 bk32', 0, 0), ('64x64 bk32 s2', 0, 2), ('64x64 bk32 s4', 0, 4)]
+            variants = variants + [('64x64 bk32', 0, 0), ('64x64 bk32 s2', 0, 2), ('64x64 bk32 s4', 0, 4),
+                                   ('32x32ksr', 7, 0), ('32x32ksr s2', 7, 2), ('32x32ksr s4', 7, 4),
+                                   ('128x64', 4, 0), ('128x64 s2', 4, 2), ('128x32', 2, 0), ('128x32 s4', 2, 4)]
         for rnd in range(2):
             for name, tile, sp in variants:
                 if sp and Kd // sp < 64:
                     continue
-                if only and name.split()[0] not in ('auto', '64x64'):
+                if only and name.split()[0] not in ('auto', '64x64', '32x32ksr', '128x64', '128x32'):
                     continue
                 lib.d2p_gemm_set_option(1 if 'bk32' in name else 0)
                 lib.d2p_gemm_force_plan(tile, sp)
