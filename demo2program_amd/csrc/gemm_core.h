@@ -96,6 +96,13 @@ struct DenseXC {  // elem(x,k) = p[k*ld + x]
     }
 };
 
+// Loaders whose out-of-range rows / columns may hold ANYTHING (they only feed output rows /
+// columns that are never stored) and whose only zeros are k >= klim: with K a multiple of the
+// slab depth such a loader needs no select at all between the global load and the LDS store.
+template <class L> struct d2p_nosel_ok { static constexpr bool value = false; };
+template <> struct d2p_nosel_ok<DenseKC> { static constexpr bool value = true; };
+template <> struct d2p_nosel_ok<DenseXC> { static constexpr bool value = true; };
+
 // ------------------------------------------------------------------------------------
 // Epilogues.  operator()(row, col, value): called once per in-range output element.
 // ------------------------------------------------------------------------------------
@@ -137,9 +144,10 @@ struct EpiDense {
 // each consumes one 8-deep chunk of every 32-deep K slab; every wave writes its own split-K
 // slab (slab index blockIdx.z*4 + wave), so the ordinary deterministic combine kernel finishes
 // the job.  Without it 3 of 4 waves idle on a one-tile output.
-template <int BM, int BN, int WM, int WN, int BK, bool FAST, bool KS, class AL, class BL, class EP>
+template <int BM, int BN, int WM, int WN, int BK, bool FAST, bool KS, class AL, class BL, class EP, bool NOSEL = false>
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial) {
+    static_assert(!NOSEL || FAST, "NOSEL is a refinement of the fast loaders");
     static_assert(KS || WM * WN == 4, "4 waves per workgroup");
     static_assert(!KS || (WM == 1 && WN == 1 && BK == 32), "KS: one tile for all waves, 4 chunks per slab");
     static_assert(BK % 8 == 0, "K slab is consumed in chunks of 8");
@@ -207,8 +215,9 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
             const int q = tid + i * 256;                                                           \
             if (CA % 256 == 0 || q < CA) {                                                         \
-                float4 t = make_float4(OA[i] ? RA[i][0] : 0.f, OA[i] ? RA[i][1] : 0.f,             \
-                                       OA[i] ? RA[i][2] : 0.f, OA[i] ? RA[i][3] : 0.f);            \
+                const bool k_ = NOSEL || OA[i];                                                    \
+                float4 t = make_float4(k_ ? RA[i][0] : 0.f, k_ ? RA[i][1] : 0.f,                   \
+                                       k_ ? RA[i][2] : 0.f, k_ ? RA[i][3] : 0.f);                  \
                 if (AL::KCONTIG) *reinterpret_cast<float4*>(&As[(q / (BK / 4)) * A_LD + (q % (BK / 4)) * 4]) = t; \
                 else *reinterpret_cast<float4*>(&As[(q / (BM / 4)) * A_LD + (q % (BM / 4)) * 4]) = t; \
             }                                                                                      \
@@ -216,8 +225,9 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         _Pragma("unroll") for (int i = 0; i < IB; ++i) {                                           \
             const int q = tid + i * 256;                                                           \
             if (CB % 256 == 0 || q < CB) {                                                         \
-                float4 t = make_float4(OB[i] ? RB[i][0] : 0.f, OB[i] ? RB[i][1] : 0.f,             \
-                                       OB[i] ? RB[i][2] : 0.f, OB[i] ? RB[i][3] : 0.f);            \
+                const bool k_ = NOSEL || OB[i];                                                    \
+                float4 t = make_float4(k_ ? RB[i][0] : 0.f, k_ ? RB[i][1] : 0.f,                   \
+                                       k_ ? RB[i][2] : 0.f, k_ ? RB[i][3] : 0.f);                  \
                 if (BL::KCONTIG) *reinterpret_cast<float4*>(&Bs[(q / (BK / 4)) * B_LD + (q % (BK / 4)) * 4]) = t; \
                 else *reinterpret_cast<float4*>(&Bs[(q / (BN / 4)) * B_LD + (q % (BN / 4)) * 4]) = t; \
             }                                                                                      \
@@ -263,23 +273,48 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         }
     };
 
-    // loads past the end of K return zeros (klim checks), so the steady-state loop prefetches
-    // unconditionally; slabs nk and nk+1 are never stored.
+    // NOSEL: the steady-state loop is straight-line -- slabs are consumed in pairs with unconditional
+    // prefetches (loads past the end of K come from a clamped address and are never used), an odd
+    // last slab is finished after the loop, and nothing sits between a global load and its LDS
+    // store, so the compiler cannot consume a prefetch early.  (Fencing the prefetch above and the
+    // stores below each slab's MFMAs with __builtin_amdgcn_sched_barrier gives the textbook
+    // two-slab distance in the ISA but measured equal on small grids and 5-15 % slower on large
+    // ones: left to the scheduler.)
+    // Loaders that need the select keep the guarded form: written straight-line, hipcc hoists the
+    // select (and a vmcnt(0)) right behind each load.
     if (nk > 0) {
         D2P_GLOAD(ra0, rb0, oa0, ob0, 0)
         D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
         D2P_GLOAD(ra1, rb1, oa1, ob1, 1)
         __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            D2P_GLOAD(ra0, rb0, oa0, ob0, kt + 2)  // in flight during compute(kt) and compute(kt+1)
-            compute(0);
-            if (kt + 1 < nk) D2P_SSTORE(ra1, rb1, oa1, ob1, 1)
-            __syncthreads();
-            if (kt + 1 < nk) {
+        if constexpr (NOSEL) {
+            const int npairs = nk >> 1;
+            for (int pr = 0; pr < npairs; ++pr) {
+                const int kt = 2 * pr;
+                D2P_GLOAD(ra0, rb0, oa0, ob0, kt + 2)  // in flight during compute(kt) and compute(kt+1)
+                compute(0);
+                D2P_SSTORE(ra1, rb1, oa1, ob1, 1)
+                __syncthreads();
                 D2P_GLOAD(ra1, rb1, oa1, ob1, kt + 3)
                 compute(1);
-                if (kt + 2 < nk) D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
+                D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
                 __syncthreads();
+            }
+            if (nk & 1) compute(0);
+        } else {
+            // loads past the end of K return zeros (klim checks): prefetch unconditionally;
+            // slabs nk and nk+1 are never stored
+            for (int kt = 0; kt < nk; kt += 2) {
+                D2P_GLOAD(ra0, rb0, oa0, ob0, kt + 2)
+                compute(0);
+                if (kt + 1 < nk) D2P_SSTORE(ra1, rb1, oa1, ob1, 1)
+                __syncthreads();
+                if (kt + 1 < nk) {
+                    D2P_GLOAD(ra1, rb1, oa1, ob1, kt + 3)
+                    compute(1);
+                    if (kt + 2 < nk) D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
+                    __syncthreads();
+                }
             }
         }
     }
@@ -373,6 +408,7 @@ gemm_splitk_reduce_flat_kernel(EP ep, const float* partial, int M, int N, int nz
 // Host-side launch policy shared by gemm.hip and conv.hip.
 // ------------------------------------------------------------------------------------
 static int g_gemm_bk32 = 0;   // per translation unit; toggled through d2p_gemm_set_option
+static int g_gemm_nosel = 1;  // 0: always keep the select between global load and LDS store
 static int g_gemm_force_tile = -1;   // -1: automatic; else a GemmTile value (tuning experiments)
 static int g_gemm_force_split = 0;   // 0: automatic
 
@@ -501,7 +537,12 @@ template <int BM, int BN, int WM, int WN, int BK, bool KS = false, class AL, cla
 static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
                             const GemmPlan& p, bool fast, float* partial, hipStream_t st) {
     dim3 grid(ceil_div(M, BM) * ceil_div(N, BN), 1, p.splits);
-    if (fast)
+    constexpr bool NOSEL_OK = d2p_nosel_ok<AL>::value && d2p_nosel_ok<BL>::value;
+    if (NOSEL_OK && fast && g_gemm_nosel && K % BK == 0 && (p.splits == 1 || p.k_per_split % BK == 0)) {
+        if constexpr (NOSEL_OK)
+            hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP, true>), grid, dim3(256), 0,
+                               st, al, bl, ep, M, N, K, p.k_per_split, partial);
+    } else if (fast)
         hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP>), grid, dim3(256), 0, st,
                            al, bl, ep, M, N, K, p.k_per_split, partial);
     else

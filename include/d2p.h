@@ -57,7 +57,9 @@ int d2p_device_info(int device, char* name, int name_len, int* cus, int* wave, s
 size_t d2p_gemm_ws_bytes(int M, int N, int K);
 /* Tuning knobs for the dense entry points (bit mask): bit 0 lets long-K problems on the 64x64 tile
  * use 32-deep K slabs; bit 1 switches OFF the small-problem path (32x32 tiles whose four waves split
- * K and combine through LDS, picked when the ordinary plan would fill fewer than 128 workgroups). */
+ * K and combine through LDS, picked when the ordinary plan would fill fewer than 128 workgroups);
+ * bit 2 keeps the select between global load and LDS store even when K is a multiple of the slab
+ * depth (the dense loaders then need none). */
 int d2p_gemm_set_option(int bk32);
 /* Tuning experiments only: force the tile (0 64x64, 1 128x128, 2 128x32, 3 256x32, 4 128x64; -1 auto)
  * and the split-K factor (0 auto) of the dense entry points. */

@@ -66,8 +66,10 @@ def main():
         res = {}
         ws_need = 16 * M * N * 4
         K.SCRATCH.reserve(ws_need)
+        if not only:
+            variants = [('auto', -1, 0), ('auto select', -1, 0)]
         if only:
-            variants = variants + [('64x64 bk32', 0, 0), ('64x64 bk32 s2', 0, 2), ('64x64 bk32 s4', 0, 4),
+            variants = variants + [('auto select', -1, 0),('64x64 bk32', 0, 0), ('64x64 bk32 s2', 0, 2), ('64x64 bk32 s4', 0, 4),
                                    ('32x32ksr', 7, 0), ('32x32ksr s2', 7, 2), ('32x32ksr s4', 7, 4),
                                    ('128x64', 4, 0), ('128x64 s2', 4, 2), ('128x32', 2, 0), ('128x32 s4', 2, 4)]
         for rnd in range(2):
@@ -76,7 +78,9 @@ def main():
                     continue
                 if only and name.split()[0] not in ('auto', '64x64', '32x32ksr', '128x64', '128x32'):
                     continue
-                lib.d2p_gemm_set_option(1 if 'bk32' in name else 0)
+                opt = 1 if 'bk32' in name else 0
+                opt |= 4 if 'select' in name else 0
+                lib.d2p_gemm_set_option(opt)
                 lib.d2p_gemm_force_plan(tile, sp)
                 res.setdefault(name, []).append(timed(fn, 20))
         lib.d2p_gemm_force_plan(-1, 0)
