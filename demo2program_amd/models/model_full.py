@@ -118,9 +118,12 @@ class Model(object):
         if self.scheduled_sampling:
             self.set_sampling_step(int(global_step) if not callable(global_step) else 0)
         self.fuse_decoders = os.environ.get('D2P_FUSE_DECODERS', '0') == '1'
-        # independent GEMM-heavy work on a second stream (see forward/backward); set False (or
-        # D2P_NO_SIDE_STREAM=1) to serialise everything on one stream, e.g. for per-kernel timing
-        self.use_side_stream = os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1'
+        # Second stream for the batch-only work (forward) and the decoders' weight gradients
+        # (backward).  OFF by default: it paid off (~4 %) while the step took 7 ms, but once the small
+        # GEMMs and the K loop were fixed the fork/join edges of the captured two-queue graph cost
+        # more than the remaining overlap buys (6.19 vs 6.29 ms/step Karel, 11.00 vs 11.09 ViZDoom).
+        self.use_side_stream = (os.environ.get('D2P_SIDE_STREAM', '0') == '1' and
+                                os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1')
         self._reserve_scratch()
 
     # ------------------------------------------------------------------ plumbing

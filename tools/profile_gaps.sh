@@ -1,0 +1,10 @@
+export TMPDIR=/tmp
+REPO=$PWD
+OUT=$REPO/gpurun_out/prof_graph
+mkdir -p $OUT
+cd /tmp
+rocprofv3 --kernel-trace -d $OUT -o bench -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline > $OUT/stdout.log 2> $OUT/stderr.log
+DB=$(find $OUT -name "*.db" | head -1)
+python $REPO/tools/rocpd_gaps.py $DB 5
+python $REPO/tools/rocpd_gaps.py $DB 5 head
+rm -f $DB
