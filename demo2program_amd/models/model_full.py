@@ -156,6 +156,33 @@ class Model(object):
         K.SCRATCH.reserve(max(need))
 
     # ------------------------------------------------------------------ feed
+    FEED_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'program_len', 'demo_len')
+
+    def alloc_feed(self, frames_dtype=torch.float32):
+        """Empty device feed: the tensors of FEED_KEYS as 256-byte aligned views into one byte buffer
+        (kept under '_flat')."""
+        c = self.config
+        B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len
+        cp = (c.depth + 3) // 4 * 4
+        spec = [('s_h', frames_dtype, (B * k * T, c.h, c.w, cp)),
+                ('program', torch.float32, (B, c.dim_program_token, L)),
+                ('program_tokens', torch.int32, (B, L)),
+                ('a_h', torch.float32, (B, k, T, c.action_space)),
+                ('a_h_tokens', torch.int32, (B * k, T)),
+                ('per', torch.float32, (B, k, T, c.per_dim)),
+                ('program_len', torch.int32, (B,)), ('demo_len', torch.int32, (B * k,))]
+        offs, total = [], 0
+        for _, dt, shape in spec:
+            offs.append(total)
+            n = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
+            total += (n + 255) // 256 * 256
+        flat = torch.empty(max(total, 256), dtype=torch.uint8, device='cuda')
+        feed = {'_flat': flat}
+        for (name, dt, shape), o in zip(spec, offs):
+            n = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
+            feed[name] = flat[o:o + n].view(dt).view(shape)
+        return feed
+
     def get_feed_dict(self, batch_chunk, step=None, is_training=True):
         """batch_chunk (numpy arrays or torch tensors, keys of models/model_full.py:185-206)
         -> device-resident feed.  Lengths arrive as float32 and are cast to int32 exactly as the
@@ -164,36 +191,38 @@ class Model(object):
         c = self.config
         B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len
 
-        def dev(x, dtype):
-            t = torch.as_tensor(x) if not torch.is_tensor(x) else x
-            if t.dtype != dtype:
-                t = t.to(dtype)
-            return t.to('cuda', non_blocking=True).contiguous()
-
         def host_np(x):
             return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
 
         s_h = batch_chunk['s_h']
         s_dtype = torch.uint8 if getattr(s_h, 'dtype', None) in (np.uint8, torch.uint8) else torch.float32
-        frames = dev(s_h, s_dtype).view(B * k * T, c.h, c.w, c.depth)
+        # all device tensors of a batch are views into ONE allocation (alloc_feed): a consumer that
+        # needs a private copy (the trainer's graph-static feed) moves the batch with a single copy
+        feed = self.alloc_feed(s_dtype)
+
+        def put(name, x):
+            t = torch.as_tensor(x) if not torch.is_tensor(x) else x
+            dst = feed[name]
+            if t.dtype != dst.dtype:
+                t = t.to(dst.dtype)
+            dst.copy_(t.reshape(dst.shape), non_blocking=True)
+
         if c.depth % 4 != 0:
             # device layout of the frames is NHWC with the channel count rounded up to 4 (zeros):
             # part of staging the batch, like the H2D copy, not of the training step
-            cp = (c.depth + 3) // 4 * 4
-            frames = K.pad_axis(frames, B * k * T * c.h * c.w, c.depth, cp, 1,
-                                torch.empty(B * k * T, c.h, c.w, cp, dtype=s_dtype, device='cuda'))
-        feed = {
-            's_h': frames,
-            'program': dev(batch_chunk['program'], torch.float32),
-            'program_tokens': dev(batch_chunk['program_tokens'], torch.int32),
-            'a_h': dev(batch_chunk['a_h'], torch.float32),
-            'a_h_tokens': dev(batch_chunk['a_h_tokens'], torch.int32).view(B * k, T),
-            'per': dev(batch_chunk['per'], torch.float32),
-        }
+            raw = torch.as_tensor(s_h) if not torch.is_tensor(s_h) else s_h
+            if raw.dtype != s_dtype:
+                raw = raw.to(s_dtype)
+            raw = raw.to('cuda', non_blocking=True).contiguous().view(B * k * T, c.h, c.w, c.depth)
+            K.pad_axis(raw, B * k * T * c.h * c.w, c.depth, feed['s_h'].shape[3], 1, feed['s_h'])
+        else:
+            put('s_h', s_h)
+        for name in ('program', 'program_tokens', 'a_h', 'a_h_tokens', 'per'):
+            put(name, batch_chunk[name])
         plen = host_np(batch_chunk['program_len']).astype(np.int32).reshape(B)
         dlen = host_np(batch_chunk['demo_len']).astype(np.int32).reshape(B * k)
-        feed['program_len'] = dev(plen, torch.int32)
-        feed['demo_len'] = dev(dlen, torch.int32)
+        put('program_len', plen)
+        put('demo_len', dlen)
         # dynamic_decode runs until the longest sequence of the batch
         feed['n_prog'] = int(min(int(plen.max()) if B else 0, L))
         feed['n_demo'] = int(min(int(dlen.max()) if B * k else 0, T))

@@ -207,16 +207,18 @@ class Trainer(object):
 
     def _graphed_forward_backward(self, feed):
         m = self.model
-        if self._static_feed is None:
-            self._static_feed = {k: torch.empty_like(feed[k]) for k in self._STATIC_KEYS}
         sf = self._static_feed
-        for k in self._STATIC_KEYS:
-            if sf[k].dtype != feed[k].dtype:         # e.g. uint8 frames after float32 frames
-                sf[k] = torch.empty_like(feed[k])
-                self._graphs.clear()
-            sf[k].copy_(feed[k], non_blocking=True)
+        if sf is None or sf['s_h'].dtype != feed['s_h'].dtype:    # e.g. uint8 frames after float32 frames
+            sf = self._static_feed = m.alloc_feed(feed['s_h'].dtype)
+            self._graphs.clear()
+        if '_flat' in feed and feed['_flat'].numel() == sf['_flat'].numel():
+            sf['_flat'].copy_(feed['_flat'], non_blocking=True)   # the whole batch: one device copy
+        else:                                                      # a hand-built feed
+            for k in self._STATIC_KEYS:
+                sf[k].copy_(feed[k].reshape(sf[k].shape), non_blocking=True)
         key = (feed['n_prog'], feed['n_demo'])
-        static = dict(sf, n_prog=key[0], n_demo=key[1], id=feed.get('id'), host=feed.get('host'))
+        static = dict({k: sf[k] for k in self._STATIC_KEYS}, n_prog=key[0], n_demo=key[1], id=feed.get('id'),
+                      host=feed.get('host'))
         g = self._graphs.get(key)
         if g is None and len(self._graphs) >= self.MAX_GRAPHS:
             # an unusually ragged dataset: stop instantiating graphs, run further new shapes eagerly
