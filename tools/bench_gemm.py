@@ -67,7 +67,7 @@ def main():
         ws_need = 16 * M * N * 4
         K.SCRATCH.reserve(ws_need)
         if not only:
-            variants = [('auto', -1, 0), ('auto select', -1, 0)]
+            variants = variants + [('auto select', -1, 0), ('64x64 s1', 0, 1), ('64x64 s3', 0, 3), ('64x64 s6', 0, 6), ('64x64 s8', 0, 8), ('128x64 s4', 4, 4)]
         if only:
             variants = variants + [('auto select', -1, 0),('64x64 bk32', 0, 0), ('64x64 bk32 s2', 0, 2), ('64x64 bk32 s4', 0, 4),
                                    ('32x32ksr', 7, 0), ('32x32ksr s2', 7, 2), ('32x32ksr s4', 7, 4),
