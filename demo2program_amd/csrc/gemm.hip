@@ -43,6 +43,36 @@ extern "C" int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, co
     return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_nn");
 }
 
+// Strided batch of nb1 x nb0 equally shaped problems in ONE launch (grid.y): problem (i, j) uses
+// A + i*sA1 + j*sA0 etc.  kind: 0 = nn, 1 = nt, 2 = tn.  No split-K (no workspace).
+extern "C" int d2p_gemm_f32_batched(int kind, int nb1, int nb0, int M, int N, int K, const float* A, long lda,
+                                    long sA1, long sA0, const float* B, long ldb, long sB1, long sB0, float* C,
+                                    long ldc, long sC1, long sC0, const float* bias, long sbias1, long sbias0,
+                                    int act, int accumulate, d2p_stream_t stream) {
+    int rc = check_gemm_args(M, N, K, A, B, C, act);
+    if (rc) return rc;
+    D2P_REQUIRE(kind >= 0 && kind <= 2 && nb1 > 0 && nb0 > 0 && (long)nb1 * nb0 <= 65535, D2P_EINVAL,
+                "gemm_batched: kind=%d batch=%dx%d", kind, nb1, nb0);
+    const int va = vec_ok(A, lda) && sA1 % 4 == 0 && sA0 % 4 == 0;
+    const int vb = vec_ok(B, ldb) && sB1 % 4 == 0 && sB0 % 4 == 0;
+    EpiDense ep{C, ldc, bias, act, accumulate, sC1, sC0, sbias1, sbias0, nb0};
+    const int batch = nb1 * nb0;
+    hipStream_t st = as_stream(stream);
+    if (kind == 0) {
+        DenseKC al{A, lda, M, va, sA1, sA0, nb0};
+        DenseXC bl{B, ldb, N, vb, sB1, sB0, nb0};
+        return d2p_launch_gemm(al, bl, ep, M, N, K, nullptr, 0, st, "gemm_batched_nn", D2P_PROF_GEMM, batch);
+    }
+    if (kind == 1) {
+        DenseKC al{A, lda, M, va, sA1, sA0, nb0};
+        DenseKC bl{B, ldb, N, vb, sB1, sB0, nb0};
+        return d2p_launch_gemm(al, bl, ep, M, N, K, nullptr, 0, st, "gemm_batched_nt", D2P_PROF_GEMM, batch);
+    }
+    DenseXC al{A, lda, M, va, sA1, sA0, nb0};
+    DenseXC bl{B, ldb, N, vb, sB1, sB0, nb0};
+    return d2p_launch_gemm(al, bl, ep, M, N, K, nullptr, 0, st, "gemm_batched_tn", D2P_PROF_GEMM, batch);
+}
+
 extern "C" int d2p_gemm_f32_nt(int M, int N, int K, const float* A, long lda, const float* B,
                                long ldb, float* C, long ldc, const float* bias, int act,
                                int accumulate, void* ws, size_t ws_bytes, d2p_stream_t stream) {

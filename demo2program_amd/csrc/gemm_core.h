@@ -36,6 +36,10 @@ struct DenseKC {  // elem(x,k) = p[x*ld + k]
     long ld;
     int X;
     int vec;  // ld % 4 == 0 and p 16-byte aligned
+    // strided batch (grid.y): problem b reads from p + (b / nb0) * bs1 + (b % nb0) * bs0
+    long bs1 = 0, bs0 = 0;
+    int nb0 = 1;
+    __device__ __forceinline__ void shift(int b) { p += (long)(b / nb0) * bs1 + (long)(b % nb0) * bs0; }
     // FAST: vec && K % 4 == 0: one unconditional 16-byte load from a clamped address, then a
     // select -- no control flow, so hipcc keeps counted vmcnt waits across the K loop.
     bool fast_ok(int K) const { return vec && K >= 4 && (K % 4) == 0 && X > 0; }
@@ -71,6 +75,9 @@ struct DenseXC {  // elem(x,k) = p[k*ld + x]
     long ld;
     int X;
     int vec;
+    long bs1 = 0, bs0 = 0;   // strided batch, as DenseKC
+    int nb0 = 1;
+    __device__ __forceinline__ void shift(int b) { p += (long)(b / nb0) * bs1 + (long)(b % nb0) * bs0; }
     bool fast_ok(int K) const { return vec && X >= 4 && (X % 4) == 0 && K > 0; }
     template <bool FAST>
     __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
@@ -102,6 +109,8 @@ struct DenseXC {  // elem(x,k) = p[k*ld + x]
 template <class L> struct d2p_nosel_ok { static constexpr bool value = false; };
 template <> struct d2p_nosel_ok<DenseKC> { static constexpr bool value = true; };
 template <> struct d2p_nosel_ok<DenseXC> { static constexpr bool value = true; };
+// strided-batched launches (grid.y > 1) exist for dense operands with the dense epilogue only
+template <class EP> struct d2p_batch_ok { static constexpr bool value = false; };
 
 // ------------------------------------------------------------------------------------
 // Epilogues.  operator()(row, col, value): called once per in-range output element.
@@ -118,6 +127,12 @@ struct EpiDense {
     const float* bias;  // [N] or null
     int act;            // 0 none, 1 lrelu(0.2)
     int accumulate;     // C = act(v + C_old + bias)
+    long cs1 = 0, cs0 = 0, bb1 = 0, bb0 = 0;   // strided batch: C and bias offsets of problem b
+    int nb0 = 1;
+    __device__ __forceinline__ void shift(int b) {
+        C += (long)(b / nb0) * cs1 + (long)(b % nb0) * cs0;
+        if (bias) bias += (long)(b / nb0) * bb1 + (long)(b % nb0) * bb0;
+    }
     __device__ __forceinline__ float col_value(int col) const { return bias ? bias[col] : 0.f; }
     __device__ __forceinline__ bool has_c() const { return accumulate != 0; }
     __device__ __forceinline__ float c_value(int row, int col) const { return C[(long)row * ldc + col]; }
@@ -164,6 +179,13 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     constexpr int IA = (CA + 255) / 256, IB = (CB + 255) / 256; // per-thread staging loads
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
 
+    if constexpr (d2p_nosel_ok<AL>::value && d2p_nosel_ok<BL>::value && d2p_batch_ok<EP>::value) {
+        if (gridDim.y > 1) {          // strided batch: this workgroup's problem
+            al.shift(blockIdx.y);
+            bl.shift(blockIdx.y);
+            ep.shift(blockIdx.y);
+        }
+    }
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l32 = lane & 31, hi = lane >> 5;
@@ -372,6 +394,8 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         }
 }
 
+template <> struct d2p_batch_ok<EpiDense> { static constexpr bool value = true; };
+
 // Deterministic split-K combine: 16 lanes per output element each sum slabs z = l, l+16, ...
 // then a fixed-order xor-shuffle tree combines them; EP is applied by lane 0 of the group.
 template <class EP>
@@ -535,8 +559,8 @@ static inline size_t d2p_plan_ws_bytes(int M, int N, int K) {
 
 template <int BM, int BN, int WM, int WN, int BK, bool KS = false, class AL, class BL, class EP>
 static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
-                            const GemmPlan& p, bool fast, float* partial, hipStream_t st) {
-    dim3 grid(ceil_div(M, BM) * ceil_div(N, BN), 1, p.splits);
+                            const GemmPlan& p, bool fast, float* partial, hipStream_t st, int batch = 1) {
+    dim3 grid(ceil_div(M, BM) * ceil_div(N, BN), batch, p.splits);
     constexpr bool NOSEL_OK = d2p_nosel_ok<AL>::value && d2p_nosel_ok<BL>::value;
     if (NOSEL_OK && fast && g_gemm_nosel && K % BK == 0 && (p.splits == 1 || p.k_per_split % BK == 0)) {
         if constexpr (NOSEL_OK)
@@ -553,10 +577,11 @@ static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int
 template <class AL, class BL, class EP>
 static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
                            void* ws, size_t ws_bytes, hipStream_t st, const char* name,
-                           int prof_family = D2P_PROF_GEMM) {
-    if (M <= 0 || N <= 0) return D2P_OK;
-    D2pProfScope prof(st, prof_family, 2.0 * M * N * K);
-    GemmPlan p = d2p_plan_gemm(M, N, K, ws != nullptr);
+                           int prof_family = D2P_PROF_GEMM, int batch = 1) {
+    if (M <= 0 || N <= 0 || batch <= 0) return D2P_OK;
+    D2pProfScope prof(st, prof_family, 2.0 * M * N * K * batch);
+    // a strided batch (grid.y) never splits K: the slabs of different problems would need their own scratch
+    GemmPlan p = d2p_plan_gemm(M, N, K, ws != nullptr && batch == 1);
     float* partial = nullptr;
     if (p.slabs > 1) {
         const size_t need = (size_t)p.slabs * M * N * sizeof(float);
@@ -568,19 +593,19 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
     }
     const bool fast = al.fast_ok(K) && bl.fast_ok(K);
     switch (p.tile) {
-        case TILE_128x128: d2p_launch_tile<128, 128, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_128x32: d2p_launch_tile<128, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_256x32: d2p_launch_tile<256, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_128x64: d2p_launch_tile<128, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_64x32_KS: d2p_launch_tile<64, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_64x64_KS: d2p_launch_tile<64, 64, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st); break;
-        case TILE_32x32_KSR: d2p_launch_tile<32, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st); break;
+        case TILE_128x128: d2p_launch_tile<128, 128, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
+        case TILE_128x32: d2p_launch_tile<128, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
+        case TILE_256x32: d2p_launch_tile<256, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
+        case TILE_128x64: d2p_launch_tile<128, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
+        case TILE_64x32_KS: d2p_launch_tile<64, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
+        case TILE_64x64_KS: d2p_launch_tile<64, 64, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
+        case TILE_32x32_KSR: d2p_launch_tile<32, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
         default:
             // long-K problems on the small tile: 32-deep slabs (half the barriers, 128-byte runs)
             if (g_gemm_bk32 && K >= 256 && fast)
-                d2p_launch_tile<64, 64, 2, 2, 32>(al, bl, ep, M, N, K, p, fast, partial, st);
+                d2p_launch_tile<64, 64, 2, 2, 32>(al, bl, ep, M, N, K, p, fast, partial, st, batch);
             else
-                d2p_launch_tile<64, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st);
+                d2p_launch_tile<64, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch);
             break;
     }
     D2P_LAUNCH_CHECK(name);

@@ -80,6 +80,15 @@ def gemm_raw(kind, M, N, K, A, lda, B, ldb, C, ldc, bias=None, act=0, accumulate
        ws, wsb, current_stream())
 
 
+def gemm_batched(kind, nb1, nb0, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, bias=None, sbias=(0, 0), act=0,
+                 accumulate=False):
+    """nb1 x nb0 problems of one shape in one launch; sA / sB / sC / sbias = (stride over the first batch
+    index, stride over the second), in floats.  A / B / C: tensors or data pointers of problem (0, 0)."""
+    call.d2p_gemm_f32_batched({'nn': 0, 'nt': 1, 'tn': 2}[kind], nb1, nb0, M, N, K, _p(A), lda, sA[0], sA[1],
+                              _p(B), ldb, sB[0], sB[1], _p(C), ldc, sC[0], sC[1], _p(bias), sbias[0], sbias[1],
+                              act, 1 if accumulate else 0, current_stream())
+
+
 def _p(x):
     if x is None or isinstance(x, int):
         return x

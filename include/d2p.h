@@ -55,6 +55,14 @@ int d2p_device_info(int device, char* name, int name_len, int* cus, int* wave, s
  * C = act(A·B + C_old + bias)).
  * ws: scratch for split-K, at least d2p_gemm_ws_bytes(M,N,K) bytes (may be NULL if 0). */
 size_t d2p_gemm_ws_bytes(int M, int N, int K);
+/* nb1 x nb0 equally shaped problems in one launch (the relation network's h / c summaries and their
+ * two fc1 halves, models/model_full.py:333-349): problem (i, j) uses A + i*sA1 + j*sA0, B, C and bias
+ * likewise (strides in floats; a zero stride shares the operand).  kind: 0 = nn, 1 = nt, 2 = tn with
+ * the operand layouts of the entry points above.  K is never split: no workspace. */
+int d2p_gemm_f32_batched(int kind, int nb1, int nb0, int M, int N, int K, const float* A, long lda,
+                         long sA1, long sA0, const float* B, long ldb, long sB1, long sB0, float* C,
+                         long ldc, long sC1, long sC0, const float* bias, long sbias1, long sbias0,
+                         int act, int accumulate, d2p_stream_t stream);
 /* Tuning knobs for the dense entry points (bit mask): bit 0 lets long-K problems on the 64x64 tile
  * use 32-deep K slabs; bit 1 switches OFF the small-problem path (32x32 tiles whose four waves split
  * K and combine through LDS, picked when the ordinary plan would fill fewer than 128 workgroups);

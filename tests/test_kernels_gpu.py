@@ -94,6 +94,38 @@ def test_gemm_small_problem_path_epilogues_and_switch(K):
     assert (outs[0][1] - outs[1][1]).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize('M,N,K_', [(320, 512, 512), (3200, 512, 512), (512, 512, 320), (70, 45, 300), (33, 64, 16)])
+def test_gemm_strided_batch(K, M, N, K_):
+    """d2p_gemm_f32_batched: 2 x 2 problems in one launch (shared A over the second index, as the
+    relation network's P / Q projections), every kind, with bias + leaky relu and with accumulate."""
+    nb1, nb0 = 2, 2
+    A = rnd(nb1, M, K_, seed=21)
+    B = rnd(nb1, nb0, K_, N, seed=22)
+    bias = rnd(nb1, N, seed=23)
+    C0 = rnd(nb1, nb0, M, N, seed=24)
+    ref = torch.einsum('imk,ijkn->ijmn', A, B)
+    tol = dict(atol=2e-6 * K_ + 1e-5, rtol=1e-5)
+    dA, dB = dev(A), dev(B)
+    out = torch.zeros(nb1, nb0, M, N, device='cuda')
+    K.gemm_batched('nn', nb1, nb0, M, N, K_, dA, K_, (M * K_, 0), dB, N, (nb0 * K_ * N, K_ * N), out, N,
+                   (nb0 * M * N, M * N), bias=dev(bias), sbias=(N, 0), act=1)
+    close(out, oracle.lrelu(ref + bias[:, None, None, :]), **tol)
+    Bt = dev(B.transpose(2, 3).contiguous())                       # [nb1, nb0, N, K]
+    acc = dev(C0)
+    K.gemm_batched('nt', nb1, nb0, M, N, K_, dA, K_, (M * K_, 0), Bt, K_, (nb0 * N * K_, N * K_), acc, N,
+                   (nb0 * M * N, M * N), accumulate=True)
+    close(acc, ref + C0, **tol)
+    At = dev(A.transpose(1, 2).contiguous())                       # [nb1, K, M]
+    out.zero_()
+    K.gemm_batched('tn', nb1, nb0, M, N, K_, At, M, (K_ * M, 0), dB, N, (nb0 * K_ * N, K_ * N), out, N,
+                   (nb0 * M * N, M * N))
+    close(out, ref, **tol)
+    # batch of one == the plain entry point
+    one = torch.zeros(M, N, device='cuda')
+    K.gemm_batched('nn', 1, 1, M, N, K_, dA, K_, (0, 0), dB, N, (0, 0), one, N, (0, 0))
+    close(one, ref[0, 0], **tol)
+
+
 def test_gemm_is_transpose_detecting(K):
     # A = I with an asymmetric B catches a swapped C layout (cdna guide §3)
     n = 96
