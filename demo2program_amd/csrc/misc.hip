@@ -170,7 +170,7 @@ extern "C" int d2p_group_max_bwd(int B, int k, int U, const float* dout, const i
 // so fc1(row) = feat[b,c]·W1[:U] + feat[b,a]·W1[U:] + bias = P[b,c] + Q[b,a] + bias.
 __global__ void __launch_bounds__(256)
 rn_pair_fwd_kernel(int B, int k, int U4, const float4* P, const float4* Q, const float4* bias,
-                   float4* y) {
+                   int Bs, long bias_stride4, float4* y) {
     const long total = (long)B * k * k * U4;
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
         const int u = (int)(idx % U4);
@@ -178,7 +178,9 @@ rn_pair_fwd_kernel(int B, int k, int U4, const float4* P, const float4* Q, const
         const int c = (int)(row % k); row /= k;
         const int a = (int)(row % k);
         const int b = (int)(row / k);
-        const float4 p = P[((long)b * k + c) * U4 + u], q = Q[((long)b * k + a) * U4 + u], bb = bias[u];
+        // programs b / Bs = 0, 1, .. belong to different summaries stacked along B, each with its own bias
+        const float4 p = P[((long)b * k + c) * U4 + u], q = Q[((long)b * k + a) * U4 + u],
+                     bb = bias[(long)(b / Bs) * bias_stride4 + u];
         float4 o;
         o.x = d2p_lrelu(p.x + q.x + bb.x);
         o.y = d2p_lrelu(p.y + q.y + bb.y);
@@ -189,13 +191,15 @@ rn_pair_fwd_kernel(int B, int k, int U4, const float4* P, const float4* Q, const
 }
 
 extern "C" int d2p_rn_pair_fwd(int B, int k, int U, const float* P, const float* Q,
-                               const float* bias, float* y, d2p_stream_t stream) {
+                               const float* bias, int scopes, long bias_stride, float* y, d2p_stream_t stream) {
     D2P_REQUIRE(B >= 0 && k > 0 && U > 0 && U % 4 == 0, D2P_EINVAL, "rn_pair_fwd: bad sizes");
+    D2P_REQUIRE(scopes >= 1 && B % scopes == 0 && bias_stride % 4 == 0, D2P_EINVAL,
+                "rn_pair_fwd: %d programs in %d scopes, bias stride %ld", B, scopes, bias_stride);
     if (B == 0) return D2P_OK;
     D2P_REQUIRE(P && Q && bias && y, D2P_EINVAL, "rn_pair_fwd: null pointer");
     hipLaunchKernelGGL(rn_pair_fwd_kernel, dim3(ew_blocks((long)B * k * k * U / 4)), dim3(256), 0,
                        as_stream(stream), B, k, U / 4, (const float4*)P, (const float4*)Q,
-                       (const float4*)bias, (float4*)y);
+                       (const float4*)bias, B / scopes, bias_stride / 4, (float4*)y);
     D2P_LAUNCH_CHECK("rn_pair_fwd");
     return D2P_OK;
 }

@@ -420,8 +420,8 @@ def group_max_bwd(dout, arg, dx, B, k, U, accumulate):
     call.d2p_group_max_bwd(B, k, U, ptr(dout), ptr(arg), ptr(dx), 1 if accumulate else 0, current_stream())
 
 
-def rn_pair_fwd(P, Q, bias, y, B, k, U):
-    call.d2p_rn_pair_fwd(B, k, U, ptr(P), ptr(Q), ptr(bias), ptr(y), current_stream())
+def rn_pair_fwd(P, Q, bias, y, B, k, U, scopes=1, bias_stride=0):
+    call.d2p_rn_pair_fwd(B, k, U, ptr(P), ptr(Q), ptr(bias), scopes, bias_stride, ptr(y), current_stream())
 
 
 def rn_pair_bwd(dy, dP, dQ, B, k, U):

@@ -71,7 +71,7 @@ SIGNATURES = {
     'd2p_group_mean_bwd': (c_int, [c_int, c_int, c_int, P, P, P, c_int, S]),
     'd2p_group_max': (c_int, [c_int, c_int, c_int, P, P, P, S]),
     'd2p_group_max_bwd': (c_int, [c_int, c_int, c_int, P, P, P, c_int, S]),
-    'd2p_rn_pair_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, S]),
+    'd2p_rn_pair_fwd': (c_int, [c_int, c_int, c_int, P, P, P, c_int, c_long, P, S]),
     'd2p_rn_pair_bwd': (c_int, [c_int, c_int, c_int, P, P, P, S]),
     'd2p_pair_mean_fwd': (c_int, [c_int, c_int, c_int, P, P, P, S]),
     'd2p_pair_mean_bwd': (c_int, [c_int, c_int, c_int, P, P, S]),

@@ -311,13 +311,15 @@ class Model(object):
             K.group_mean(e1['h_final'], B, k, U, sum_h, h0_2)
             K.group_mean(e1['c_final'], B, k, U, sum_c, c0_2)
             # ---- SecondPathEncoder over the step-1 outputs (zeros past len)
+            # the final states of all demonstrations, h then c, in one buffer: the two relation networks
+            # (separate weights, same shapes) then run as strided-batched launches
+            demo_hc = self._buf('demo_hc', (2, M, U))
             e2 = self._lstm_fwd('second_lstm', e1['hout'].view(T * M, U), U, M, T, T, h0_2, c0_2, lens_d,
-                                want_final=True)
-            demo_h, demo_c = e2['h_final'], e2['c_final']
+                                want_final=True, final_out=(demo_hc[0], demo_hc[1]))
+            demo_h, demo_c = demo_hc[0], demo_hc[1]
             # ---- SummarizeFeature('rn') = mean_k + rn_pool (the summarizer baseline: rn_pool alone)
-            rn_h = self._rn_fwd('rn_h', demo_h, B, k, U, add_mean=self.multitask)
-            rn_c = self._rn_fwd('rn_c', demo_c, B, k, U, add_mean=self.multitask)
-            init_h, init_c = rn_h['out'], rn_c['out']
+            rn_h = rn_c = self._rn_fwd(demo_hc, B, k, U, add_mean=self.multitask)
+            init_h, init_c = rn_h['out'][0], rn_h['out'][1]
 
         main.wait_stream(side)
         # ---- Program decoder (teacher forcing; <s> = out-of-range id -> zero vector),
@@ -381,9 +383,10 @@ class Model(object):
             self._side = torch.cuda.Stream()
         return self._side
 
-    def _bn_fwd(self, name, x2d, gamma, beta, G, inner):
+    def _bn_fwd(self, name, x2d, gamma, beta, G, inner, y=None):
         R, C = x2d.shape
-        y = self._buf(name + '/bn_y', (R, C))
+        if y is None:
+            y = self._buf(name + '/bn_y', (R, C))
         if not self.is_train:
             mm, mv = self.moving[name]
             K.bn_inference(x2d, gamma, beta, mm, mv, y=y)
@@ -406,7 +409,7 @@ class Model(object):
                        bias=bias)
         return z
 
-    def _lstm_fwd(self, name, x2d, I, M, T, n_steps, h0, c0, lens, want_final, z=None):
+    def _lstm_fwd(self, name, x2d, I, M, T, n_steps, h0, c0, lens, want_final, z=None, final_out=None):
         """x2d: [T*M, I] time-major inputs.  Returns saved tensors for backward."""
         p = self.params.p
         U = self.num_lstm_cell_units
@@ -416,8 +419,11 @@ class Model(object):
             z = self._lstm_xproj(name, x2d, I, M, T, n_steps)
         hout = self._buf(name + '/hout', (T, M, U))
         cs = self._buf(name + '/cs', (T, M, U))
-        hf = self._buf(name + '/h_final', (M, U)) if want_final else None
-        cf = self._buf(name + '/c_final', (M, U)) if want_final else None
+        if final_out is not None:
+            hf, cf = final_out
+        else:
+            hf = self._buf(name + '/h_final', (M, U)) if want_final else None
+            cf = self._buf(name + '/c_final', (M, U)) if want_final else None
         K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, n_steps, Wh, h0, c0, lens, hout, cs, hf, cf)
         return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
                     hout=hout, cs=cs, h_final=hf, c_final=cf, Wx=Wx, Wh=Wh)
@@ -524,27 +530,48 @@ class Model(object):
         e['scope'] = scope
         return e
 
-    def _rn_fwd(self, scope, feat, B, k, U, add_mean=True):
-        """SummarizeFeature('rn'): mean over k + rn_pool (models/model_full.py:333-362); without
-        the mean term it is the summarizer baseline's (model_summarizer.py:345-352)."""
+    RN_SCOPES = ('rn_h', 'rn_c')
+
+    def _rn_stride(self):
+        """floats between a tensor of rn_h and the same tensor of rn_c in the flat parameter / gradient
+        buffers (the two scopes have identical layouts, so one stride serves every tensor)."""
+        p, g = self.params.p, self.params.g
+        st = (p['rn_c/fc1/W'].data_ptr() - p['rn_h/fc1/W'].data_ptr()) // 4
+        for leaf in ('fc1/W', 'fc1/b', 'fc2/W', 'fc2/b'):
+            assert (p['rn_c/' + leaf].data_ptr() - p['rn_h/' + leaf].data_ptr()) // 4 == st
+            assert (g['rn_c/' + leaf].data_ptr() - g['rn_h/' + leaf].data_ptr()) // 4 == st
+        return st
+
+    def _rn_fwd(self, feat, B, k, U, add_mean=True):
+        """SummarizeFeature('rn') for BOTH summaries at once: feat [2, B*k, U] (h states, then c
+        states) -> out [2, B, U] = mean over k + rn_pool (models/model_full.py:333-362); without the
+        mean term it is the summarizer baseline's (model_summarizer.py:345-352).  rn_h and rn_c have
+        separate weights but identical shapes: their GEMMs run as strided batches (one launch for
+        the four fc1 half-projections, one for the two fc2 layers) and the row-wise kernels see 2B
+        programs; batch norm stays one call per summary (own statistics, own parameters)."""
         p = self.params.p
-        W1, W2 = p[scope + '/fc1/W'], p[scope + '/fc2/W']
-        Pm = K.matmul_nn(feat, W1[:U], out=self._buf(scope + '/P', (B * k, U)))
-        Qm = K.matmul_nn(feat, W1[U:], out=self._buf(scope + '/Q', (B * k, U)))
-        y1a = self._buf(scope + '/y1a', (B * k * k, U))
-        K.rn_pair_fwd(Pm, Qm, p[scope + '/fc1/b'], y1a, B, k, U)
-        y1, m1, r1 = self._bn_fwd(scope + '/fc1', y1a, p[scope + '/fc1/gamma'], p[scope + '/fc1/beta'], 1, 1)
-        y2a = K.matmul_nn(y1, W2, out=self._buf(scope + '/y2a', (B * k * k, U)),
-                          bias=p[scope + '/fc2/b'], act=1)
-        y2, m2, r2 = self._bn_fwd(scope + '/fc2', y2a, p[scope + '/fc2/gamma'], p[scope + '/fc2/beta'], 1, 1)
+        M, R = B * k, B * k * k
+        ps = self._rn_stride()
+        W1, W2 = p['rn_h/fc1/W'], p['rn_h/fc2/W']
+        # PQ[half][scope]: P = feat . W1[:U], Q = feat . W1[U:]
+        PQ = self._buf('rn/PQ', (2, 2, M, U))
+        K.gemm_batched('nn', 2, 2, M, U, U, feat, U, (M * U, 0), W1, U, (ps, U * U), PQ, U, (M * U, 2 * M * U))
+        y1a = self._buf('rn/y1a', (2, R, U))
+        K.rn_pair_fwd(PQ[0], PQ[1], p['rn_h/fc1/b'], y1a, 2 * B, k, U, scopes=2, bias_stride=ps)
+        y1, y2a, y2 = self._buf('rn/y1', (2, R, U)), self._buf('rn/y2a', (2, R, U)), self._buf('rn/y2', (2, R, U))
+        st1 = [self._bn_fwd(sc + '/fc1', y1a[i], p[sc + '/fc1/gamma'], p[sc + '/fc1/beta'], 1, 1, y=y1[i])
+               for i, sc in enumerate(self.RN_SCOPES)]
+        K.gemm_batched('nn', 2, 1, R, U, U, y1, U, (R * U, 0), W2, U, (ps, 0), y2a, U, (R * U, 0),
+                       bias=p['rn_h/fc2/b'], sbias=(ps, 0), act=1)
+        st2 = [self._bn_fwd(sc + '/fc2', y2a[i], p[sc + '/fc2/gamma'], p[sc + '/fc2/beta'], 1, 1, y=y2[i])
+               for i, sc in enumerate(self.RN_SCOPES)]
         base = None
         if add_mean:
-            base = self._buf(scope + '/base', (B, U))
-            K.group_mean(feat, B, k, U, base, None)
-        out = self._buf(scope + '/out', (B, U))
-        K.pair_mean_fwd(y2, base, out, B, k * k, U)
-        return dict(scope=scope, feat=feat, y1a=y1a, y1=y1, m1=m1, r1=r1, y2a=y2a, m2=m2, r2=r2, out=out,
-                    add_mean=add_mean)
+            base = self._buf('rn/base', (2, B, U))
+            K.group_mean(feat, 2 * B, k, U, base, None)
+        out = self._buf('rn/out', (2, B, U))
+        K.pair_mean_fwd(y2, base, out, 2 * B, k * k, U)
+        return dict(feat=feat, y1a=y1a, y1=y1, y2a=y2a, st1=st1, st2=st2, out=out, add_mean=add_mean, ps=ps)
 
     # ------------------------------------------------------------------ backward
     def backward(self, loss_scale=1.0):
@@ -564,7 +591,8 @@ class Model(object):
         dl_p = self._buf('prog/dlogits', (L * B, V))
         K.xent_bwd('softmax', ctx['dp']['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
                    dens[0:1], loss_scale, dl_p)
-        d_init_h, d_init_c = self._buf('d_rn_h', (B, U)), self._buf('d_rn_c', (B, U))
+        d_init = self._buf('d_rn', (2, B, U))
+        d_init_h, d_init_c = d_init[0], d_init[1]
         main = torch.cuda.current_stream()
         side = self._side_stream()
         if self.multitask:
@@ -575,7 +603,8 @@ class Model(object):
             K.xent_bwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
                        dens[1 + k:], loss_scale, dl_q)
 
-            d_demo_h, d_demo_c = self._buf('d_demo_h', (M, U)), self._buf('d_demo_c', (M, U))
+            d_demo = self._buf('d_demo', (2, M, U))
+            d_demo_h, d_demo_c = d_demo[0], d_demo[1]
             tmp_h, tmp_c = self._buf('tmp_dh', (M, U)), self._buf('tmp_dc', (M, U))
 
             # ---- decoder recurrences (main stream): projection grads, dz for every step, and the
@@ -625,12 +654,11 @@ class Model(object):
             d_hout1 = None
         else:
             if not self.multitask:
-                d_demo_h, d_demo_c = self._buf('d_demo_h', (M, U)), self._buf('d_demo_c', (M, U))
-                d_demo_h.zero_()
-                d_demo_c.zero_()
-            # ---- SummarizeFeature('rn') backward (adds into d_demo_{h,c})
-            self._rn_bwd(ctx['rn_h'], d_init_h, d_demo_h, B, k, U)
-            self._rn_bwd(ctx['rn_c'], d_init_c, d_demo_c, B, k, U)
+                d_demo = self._buf('d_demo', (2, M, U))
+                d_demo_h, d_demo_c = d_demo[0], d_demo[1]
+                d_demo.zero_()
+            # ---- SummarizeFeature('rn') backward, both summaries (adds into d_demo)
+            self._rn_bwd(ctx['rn_h'], d_init, d_demo, B, k, U)
 
             # ---- SecondPathEncoder backward: only the final states carry gradient
             e2 = ctx['e2']
@@ -749,29 +777,37 @@ class Model(object):
         return self._lstm_bwd_rec(e, dhout, None, None, dh0, dc0)
 
     def _rn_bwd(self, r, d_out, d_feat, B, k, U):
-        """d_out: [B,U] gradient of mean_k(feat) + rn_pool(feat); accumulates into d_feat [M,U]."""
+        """d_out [2, B, U]: gradient of mean_k(feat) + rn_pool(feat) for the h and the c summary;
+        accumulates into d_feat [2, B*k, U]."""
         p, g = self.params.p, self.params.g
-        s = r['scope']
-        W1, W2 = p[s + '/fc1/W'], p[s + '/fc2/W']
+        M, R, ps = B * k, B * k * k, r['ps']
+        W1, W2 = p['rn_h/fc1/W'], p['rn_h/fc2/W']
+        feat = r['feat']
         if r['add_mean']:
-            K.group_mean_bwd(d_out, None, d_feat, B, k, U, True)             # the avg-pool branch
-        dy2 = self._buf(s + '/dy2', (B * k * k, U))
-        K.pair_mean_bwd(d_out, dy2, B, k * k, U)
-        dy2a = K.bn_bwd(r['y2a'], dy2, p[s + '/fc2/gamma'], r['m2'], r['r2'], 1, 1, True,
-                        g[s + '/fc2/gamma'], g[s + '/fc2/beta'], dx=self._buf(s + '/dy2a', (B * k * k, U)),
-                        dbias=g[s + '/fc2/b'])
-        K.matmul_tn(r['y1'], dy2a, out=g[s + '/fc2/W'])
-        dy1 = K.matmul_nt(dy2a, W2, out=self._buf(s + '/dy1', (B * k * k, U)))
-        dy1a = K.bn_bwd(r['y1a'], dy1, p[s + '/fc1/gamma'], r['m1'], r['r1'], 1, 1, True,
-                        g[s + '/fc1/gamma'], g[s + '/fc1/beta'], dx=self._buf(s + '/dy1a', (B * k * k, U)),
-                        dbias=g[s + '/fc1/b'])
-        dP, dQ = self._buf(s + '/dP', (B * k, U)), self._buf(s + '/dQ', (B * k, U))
-        K.rn_pair_bwd(dy1a, dP, dQ, B, k, U)
-        gW1 = g[s + '/fc1/W']
-        K.matmul_tn(r['feat'], dP, out=gW1[:U])
-        K.matmul_tn(r['feat'], dQ, out=gW1[U:])
-        K.matmul_nt(dP, W1[:U], out=d_feat, accumulate=True)
-        K.matmul_nt(dQ, W1[U:], out=d_feat, accumulate=True)
+            K.group_mean_bwd(d_out, None, d_feat, 2 * B, k, U, True)         # the avg-pool branch
+        dy2 = self._buf('rn/dy2', (2, R, U))
+        K.pair_mean_bwd(d_out, dy2, 2 * B, k * k, U)
+        dy2a, dy1, dy1a = self._buf('rn/dy2a', (2, R, U)), self._buf('rn/dy1', (2, R, U)), self._buf('rn/dy1a', (2, R, U))
+        for i, sc in enumerate(self.RN_SCOPES):
+            _, m2, r2 = r['st2'][i]
+            K.bn_bwd(r['y2a'][i], dy2[i], p[sc + '/fc2/gamma'], m2, r2, 1, 1, True,
+                     g[sc + '/fc2/gamma'], g[sc + '/fc2/beta'], dx=dy2a[i], dbias=g[sc + '/fc2/b'])
+            K.matmul_tn(r['y1'][i], dy2a[i], out=g[sc + '/fc2/W'])       # K = B*k*k: split-K, one call each
+        K.gemm_batched('nt', 2, 1, R, U, U, dy2a, U, (R * U, 0), W2, U, (ps, 0), dy1, U, (R * U, 0))
+        for i, sc in enumerate(self.RN_SCOPES):
+            _, m1, r1 = r['st1'][i]
+            K.bn_bwd(r['y1a'][i], dy1[i], p[sc + '/fc1/gamma'], m1, r1, 1, 1, True,
+                     g[sc + '/fc1/gamma'], g[sc + '/fc1/beta'], dx=dy1a[i], dbias=g[sc + '/fc1/b'])
+        dPQ = self._buf('rn/dPQ', (2, 2, M, U))                          # [half][scope], as PQ
+        K.rn_pair_bwd(dy1a, dPQ[0], dPQ[1], 2 * B, k, U)
+        # gW1[:U] = feat^T dP, gW1[U:] = feat^T dQ for both scopes: four problems, one launch
+        K.gemm_batched('tn', 2, 2, U, U, M, feat, U, (M * U, 0), dPQ, U, (M * U, 2 * M * U),
+                       g['rn_h/fc1/W'], U, (ps, U * U))
+        # d_feat += dP . W1[:U]^T, then += dQ . W1[U:]^T (two launches: both write d_feat)
+        K.gemm_batched('nt', 2, 1, M, U, U, dPQ[0], U, (M * U, 0), W1, U, (ps, 0), d_feat, U, (M * U, 0),
+                       accumulate=True)
+        K.gemm_batched('nt', 2, 1, M, U, U, dPQ[1], U, (M * U, 0), W1[U:], U, (ps, 0), d_feat, U, (M * U, 0),
+                       accumulate=True)
 
     # ------------------------------------------------------------------ greedy decoding (N1)
     PROGRAM_END_TOKEN = 3      # vocab.token2int['m)'] in the Karel and every ViZDoom vocabulary

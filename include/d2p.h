@@ -319,9 +319,11 @@ int d2p_group_max(int B, int k, int U, const float* x, float* out, int* arg, d2p
 int d2p_group_max_bwd(int B, int k, int U, const float* dout, const int* arg, float* dx,
                       int accumulate, d2p_stream_t stream);
 /* rn_pool first layer without materialising pairs:
- *   y[b,a,c,:] = lrelu(P[b,c,:] + Q[b,a,:] + bias)   with P = feat·W1[:U], Q = feat·W1[U:] */
+ *   y[b,a,c,:] = lrelu(P[b,c,:] + Q[b,a,:] + bias)   with P = feat·W1[:U], Q = feat·W1[U:]
+ * `scopes` summaries (h and c) may be stacked along B: programs [s*B/scopes, (s+1)*B/scopes) use
+ * bias + s*bias_stride. */
 int d2p_rn_pair_fwd(int B, int k, int U, const float* P, const float* Q, const float* bias,
-                    float* y, d2p_stream_t stream);
+                    int scopes, long bias_stride, float* y, d2p_stream_t stream);
 /* dP[b,c,:] = sum_a dy[b,a,c,:], dQ[b,a,:] = sum_c dy[b,a,c,:]   (dy already wrt pre-activation) */
 int d2p_rn_pair_bwd(int B, int k, int U, const float* dy, float* dP, float* dQ, d2p_stream_t stream);
 /* out[b,:] = mean_{a,c} y[b,a,c,:] + base[b,:]  and its backward dy[b,a,c,:] = dout[b,:]/k^2 */
