@@ -25,15 +25,26 @@ def build_library(force=False, verbose=False):
     without a GPU present."""
     if not force and not _stale():
         return OUT
-    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    if not os.path.exists(hipcc):
-        hipcc = 'hipcc'
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-           '-Wno-unused-result'] + SOURCES + ['-o', OUT + '.tmp']
-    if verbose:
-        print(' '.join(cmd))
-    subprocess.run(cmd, cwd=CSRC, check=True)
-    os.replace(OUT + '.tmp', OUT)
+    # one builder at a time (several ranks of a multi-GPU launch may get here together): the others
+    # wait on the lock and then find the library fresh
+    import fcntl
+    with open(os.path.join(CSRC, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return OUT
+            hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+            if not os.path.exists(hipcc):
+                hipcc = 'hipcc'
+            tmp = '%s.tmp.%d' % (OUT, os.getpid())
+            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
+                   '-Wno-unused-result'] + SOURCES + ['-o', tmp]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.run(cmd, cwd=CSRC, check=True)
+            os.replace(tmp, OUT)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return OUT
 
 
