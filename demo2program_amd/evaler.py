@@ -64,7 +64,12 @@ class Evaler(object):
             '_report_testdata{}_num_k{}.txt'.format(max_steps * self.batch_size, getattr(config, 'num_k', config.k))
 
     def load_checkpoint(self, path):
-        """Weights and BN moving statistics of a Trainer.save_checkpoint file."""
+        """Weights and BN moving statistics of a Trainer.save_checkpoint file, or of a TensorFlow V2
+        checkpoint prefix written by the reference (tf_checkpoint.py; unverified offline)."""
+        from . import tf_checkpoint
+        if tf_checkpoint.is_tf_checkpoint(path):
+            self.global_step = tf_checkpoint.import_checkpoint(path, self.model)
+            return
         z = np.load(path)
         P = self.model.params
         P.load({n: z['p/' + n] for n in P.shapes})

@@ -321,6 +321,13 @@ class Trainer(object):
         np.savez(path, **blob)
 
     def load_checkpoint(self, path):
+        """This build's .npz, or a TensorFlow V2 checkpoint prefix of the reference (`model-<step>`
+        next to `model-<step>.index`): parameters and moving statistics only, as the reference's
+        pretrain_saver restores trainable variables (trainer.py:115,142-147)."""
+        from . import tf_checkpoint
+        if tf_checkpoint.is_tf_checkpoint(path):
+            self.global_step = tf_checkpoint.import_checkpoint(path, self.model)
+            return
         z = np.load(path)
         P = self.model.params
         P.load({n: z['p/' + n] for n in P.shapes})

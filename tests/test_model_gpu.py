@@ -773,3 +773,35 @@ def test_rccl_single_rank_self_test(monkeypatch):
     finally:
         dp.shutdown()
     assert with_group == plain
+
+
+def test_tf_checkpoint_export_import_round_trip(tmp_path):
+    """tf_checkpoint.export_checkpoint writes parameters + moving statistics under the reference's
+    variable names as a TF V2 bundle; Trainer.load_checkpoint / Evaler recognise such a prefix and
+    restore an identical model (format unverified against TensorFlow itself, see the module)."""
+    from demo2program_amd import tf_checkpoint
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.trainer import Trainer
+    cfg, params, batch = small_case('karel', seed=41)
+    m = Model(cfg, params=params)
+    for _ in range(2):                                   # move the moving statistics off their initial values
+        m.forward(m.get_feed_dict(batch))
+    prefix = str(tmp_path / 'model-77')
+    written = tf_checkpoint.export_checkpoint(m, prefix, global_step=77)
+    assert 'Demo_Encoder/State_Encoder/conv1/Conv/weights' in written and 'global_step' in written
+    tr = Trainer(cfg, make_train_dir=False)
+    tr.load_checkpoint(prefix)
+    assert tr.global_step == 77
+    a, b = m.params.to_numpy('p'), tr.model.params.to_numpy('p')
+    for n in a:
+        assert np.array_equal(a[n], b[n]), n
+    for n in m.moving:
+        assert torch.equal(m.moving[n][0], tr.model.moving[n][0]) and torch.equal(m.moving[n][1], tr.model.moving[n][1]), n
+    # a file whose names do not match is reported, not half-loaded
+    tensors = tf_checkpoint.read_bundle(prefix)
+    tensors['Demo_Encoder/State_Encoder/conv1/Conv/kernel'] = tensors.pop('Demo_Encoder/State_Encoder/conv1/Conv/weights')
+    tf_checkpoint.write_bundle(str(tmp_path / 'odd'), tensors)
+    with pytest.raises(KeyError, match='conv1/Conv/kernel'):
+        tf_checkpoint.import_checkpoint(str(tmp_path / 'odd'), tr.model)
+    tf_checkpoint.import_checkpoint(str(tmp_path / 'odd'), tr.model,
+                                    name_map={'conv1/W': 'Demo_Encoder/State_Encoder/conv1/Conv/kernel'})
