@@ -1,0 +1,30 @@
+import sys, itertools, torch, numpy as np
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+from helpers import small_case, run_oracle
+from demo2program_amd.models.model_full import Model
+cases = [dict(batch_size=5, k=1), dict(batch_size=1, k=7), dict(batch_size=2, k=2, num_lstm_cell_units=128),
+         dict(batch_size=3, k=4, num_lstm_cell_units=256), dict(batch_size=2, k=3, max_demo_len=2, max_program_len=3),
+         dict(batch_size=7, k=5, max_demo_len=9), dict(batch_size=16, k=10, num_lstm_cell_units=128, max_demo_len=6, max_program_len=10)]
+bad = 0
+for kind in ('karel', 'vizdoom'):
+    for model in ('full', 'summarizer', 'synthesis_baseline'):
+        for over in cases:
+            if kind == 'vizdoom' and over.get('batch_size', 0) >= 7:
+                continue
+            cfg, params, batch = small_case(kind, seed=3, model=model, **over)
+            out, grads = run_oracle(cfg, params, batch, dtype=torch.float64)
+            m = Model(cfg, params=params)
+            loss = m.forward(m.get_feed_dict(batch)); m.backward()
+            ref = float(out['loss'])
+            ok = abs(float(loss.item()) - ref) <= 1e-5 * abs(ref) + 1e-6
+            g = m.params.to_numpy('g')
+            worst = 0.0
+            for n, r in grads.items():
+                r = r.double().numpy()
+                e = np.abs(g[n] - r).max() / (np.abs(r).max() + 1e-12)
+                if np.abs(g[n] - r).max() > 2e-4 * np.abs(r).max() + 1e-6:
+                    ok = False
+                worst = max(worst, e)
+            print(kind, model, over, 'OK' if ok else 'MISMATCH', '%.2e' % worst, flush=True)
+            bad += (not ok)
+print('bad', bad)
