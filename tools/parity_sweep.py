@@ -1,4 +1,9 @@
-import sys, itertools, torch, numpy as np
+"""Forward/backward parity against the oracle over unusual configurations (k = 1, one program, other cell
+widths, very short sequences, wider batches) for the three model variants -- run on the GPU box.
+Tolerance as the full-size test: 1e-3 * max|ref| + 2e-6 per gradient tensor (bias gradients under a
+batch norm are column sums with heavy cancellation: the float-rounded batch means alone shift them
+by ~1e-6)."""
+import sys, torch, numpy as np
 sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
 from helpers import small_case, run_oracle
 from demo2program_amd.models.model_full import Model
@@ -22,7 +27,7 @@ for kind in ('karel', 'vizdoom'):
             for n, r in grads.items():
                 r = r.double().numpy()
                 e = np.abs(g[n] - r).max() / (np.abs(r).max() + 1e-12)
-                if np.abs(g[n] - r).max() > 2e-4 * np.abs(r).max() + 1e-6:
+                if np.abs(g[n] - r).max() > 1e-3 * np.abs(r).max() + 2e-6:
                     ok = False
                 worst = max(worst, e)
             print(kind, model, over, 'OK' if ok else 'MISMATCH', '%.2e' % worst, flush=True)
