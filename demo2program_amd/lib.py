@@ -120,6 +120,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: it ships its own HIP runtime (libamdhip64 of the ROCm it was built with); loading this
+    # library before it would pull in the system runtime instead and leave the process with two --
+    # kernels then fail with "no ROCm-capable device is detected"
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise D2PError(
             'libd2p_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; '
