@@ -212,8 +212,48 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     float ra0[IA][4], rb0[IB][4], ra1[IA][4], rb1[IB][4];
     bool oa0[IA], ob0[IB], oa1[IA], ob1[IB];
 
+    // NOSEL: this thread's operand pointers for slab 0, rows / columns clamped into range ONCE (an
+    // out-of-range row or column only feeds outputs that are never stored); a slab then costs one
+    // 64-bit add per load -- the slab offset is wave-uniform -- instead of the multiply / compare /
+    // select chain of the generic loaders (4.7 VALU instructions per MFMA before, SQ_INSTS_VALU).
+    const float* pa[IA];
+    const float* pb[IB];
+    long astep = 0, bstep = 0;                                   // floats per K slab
+    if constexpr (NOSEL) {
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int q = tid + i * 256;
+            pa[i] = al.p;
+            if (CA % 256 == 0 || q < CA) {
+                if (AL::KCONTIG) pa[i] = al.p + (long)min(m0 + q / (BK / 4), al.X - 1) * al.ld + kbeg + (q % (BK / 4)) * 4;
+                else pa[i] = al.p + (long)(kbeg + q / (BM / 4)) * al.ld + min(m0 + (q % (BM / 4)) * 4, al.X - 4);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int q = tid + i * 256;
+            pb[i] = bl.p;
+            if (CB % 256 == 0 || q < CB) {
+                if (BL::KCONTIG) pb[i] = bl.p + (long)min(n0 + q / (BK / 4), bl.X - 1) * bl.ld + kbeg + (q % (BK / 4)) * 4;
+                else pb[i] = bl.p + (long)(kbeg + q / (BN / 4)) * bl.ld + min(n0 + (q % (BN / 4)) * 4, bl.X - 4);
+            }
+        }
+        astep = AL::KCONTIG ? (long)BK : (long)BK * al.ld;
+        bstep = BL::KCONTIG ? (long)BK : (long)BK * bl.ld;
+    }
+
 #define D2P_GLOAD(RA, RB, OA, OB, kt)                                                              \
-    {                                                                                              \
+    if constexpr (NOSEL) {                                                                         \
+        const long so_ = (long)min((int)(kt), nk - 1);          /* prefetches past the end re-read the last slab */ \
+        _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
+            const float4 t_ = *reinterpret_cast<const float4*>(pa[i] + so_ * astep);               \
+            RA[i][0] = t_.x; RA[i][1] = t_.y; RA[i][2] = t_.z; RA[i][3] = t_.w; OA[i] = true;      \
+        }                                                                                          \
+        _Pragma("unroll") for (int i = 0; i < IB; ++i) {                                           \
+            const float4 t_ = *reinterpret_cast<const float4*>(pb[i] + so_ * bstep);               \
+            RB[i][0] = t_.x; RB[i][1] = t_.y; RB[i][2] = t_.z; RB[i][3] = t_.w; OB[i] = true;      \
+        }                                                                                          \
+    } else {                                                                                       \
         const int k0 = kbeg + (kt) * BK;                                                           \
         _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
             const int q = tid + i * 256;                                                           \
