@@ -641,8 +641,9 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         case TILE_64x64_KS: d2p_launch_tile<64, 64, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
         case TILE_32x32_KSR: d2p_launch_tile<32, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
         default:
-            // long-K problems on the small tile: 32-deep slabs (half the barriers, 128-byte runs)
-            if (g_gemm_bk32 && K >= 256 && fast)
+            // 32-deep slabs (half the barriers, 128-byte runs): +3-5 % on the large grids, a loss when
+            // the workgroups are few (each then walks its K loop with less overlap)
+            if ((g_gemm_bk32 || (long)ceil_div(M, 64) * ceil_div(N, 64) * p.splits >= 1024) && K >= 256 && fast)
                 d2p_launch_tile<64, 64, 2, 2, 32>(al, bl, ep, M, N, K, p, fast, partial, st, batch);
             else
                 d2p_launch_tile<64, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch);
