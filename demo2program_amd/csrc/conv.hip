@@ -31,17 +31,22 @@ struct Im2colElem {
     const T* x;
     ConvGeom g;
     int vec;   // Cin % 4 == 0 and base aligned
+    D2pDiv d_howo, d_wo, d_cin;
+    static Im2colElem make(const T* x, const ConvGeom& g, int vec) {
+        return Im2colElem{x, g, vec, d2p_make_div(g.Ho * g.Wo), d2p_make_div(g.Wo), d2p_make_div(g.Cin)};
+    }
     // branch-free variant (vec path only): clamped address + select
     __device__ __forceinline__ bool gather4_fast(int m, int kk, bool ok, float (&v)[4]) const {
         const int howo = g.Ho * g.Wo;
-        const int n = m / howo;
+        const int n = d2p_div(m, d_howo);
         const int rem = m - n * howo;
-        const int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-        const int tap = kk / g.Cin, c = kk - tap * g.Cin;
+        const int oy = d2p_div(rem, d_wo), ox = rem - oy * g.Wo;
+        const int tap = d2p_div(kk, d_cin), c = kk - tap * g.Cin;
         const int ky = tap / 3, kx = tap - ky * 3;
         const int iy = oy * 2 - g.pt + ky, ix = ox * 2 - g.pl + kx;
         ok = ok & (iy >= 0) & (iy < g.H) & (ix >= 0) & (ix < g.W);
-        ld4(x + (ok ? (((long)n * g.H + iy) * g.W + ix) * g.Cin + c : 0L), v);
+        // 32-bit offsets: check_conv bounds every tensor below 2^31 elements
+        ld4(x + (ok ? ((n * g.H + iy) * g.W + ix) * g.Cin + c : 0), v);
         return ok;
     }
     __device__ __forceinline__ void gather4(int m, int kk, int kklim, float (&v)[4]) const {
@@ -124,20 +129,21 @@ struct DgradAKC {   // A operand: colT(dY) restricted to one parity class
     DgradClass c;
     int Mrows;
     int vec;
+    D2pDiv d_hw, d_wc, d_cout, d_ntx;
     bool fast_ok(int K) const { return vec && Mrows > 0 && K >= 4; }
     template <bool FAST>
     __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
         bool ok = (x < Mrows) & (k < klim);
         const int hw = c.Hc * c.Wc;
-        const int n = x / hw;
+        const int n = d2p_div(x, d_hw);
         const int rem = x - n * hw;
-        const int j = rem / c.Wc, i = rem - j * c.Wc;
-        const int t = k / g.Cout, co = k - t * g.Cout;
-        const int ty = t / c.ntx, tx = t - ty * c.ntx;
+        const int j = d2p_div(rem, d_wc), i = rem - j * c.Wc;
+        const int t = d2p_div(k, d_cout), co = k - t * g.Cout;
+        const int ty = d2p_div(t, d_ntx), tx = t - ty * c.ntx;
         const int oy = j + ((c.iy0 + g.pt - (c.qy + 2 * ty)) >> 1);
         const int ox = i + ((c.ix0 + g.pl - (c.qx + 2 * tx)) >> 1);
         ok = ok & (oy >= 0) & (oy < g.Ho) & (ox >= 0) & (ox < g.Wo);
-        ld4(dy + (ok ? (((long)n * g.Ho + oy) * g.Wo + ox) * g.Cout + co : 0L), v);
+        ld4(dy + (ok ? ((n * g.Ho + oy) * g.Wo + ox) * g.Cout + co : 0), v);
         if (!FAST && !ok) v[0] = v[1] = v[2] = v[3] = 0.f;
         return FAST ? ok : true;
     }
@@ -149,14 +155,15 @@ struct DgradBKC {   // B operand: columns x = c (input channel), k = (t, co): W[
     int Cin, Cout;
     DgradClass c;
     int vec;
+    D2pDiv d_cout, d_ntx;
     bool fast_ok(int K) const { return vec && Cin > 0 && K >= 4; }
     template <bool FAST>
     __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
         const bool ok = (x < Cin) & (k < klim);
-        const int t = k / Cout, co = k - t * Cout;
-        const int ty = t / c.ntx, tx = t - ty * c.ntx;
+        const int t = d2p_div(k, d_cout), co = k - t * Cout;
+        const int ty = d2p_div(t, d_ntx), tx = t - ty * c.ntx;
         const int tap = (c.qy + 2 * ty) * 3 + (c.qx + 2 * tx);
-        ld4(w + (ok ? ((long)tap * Cin + x) * Cout + co : 0L), v);
+        ld4(w + (ok ? (tap * Cin + x) * Cout + co : 0), v);
         if (!FAST && !ok) v[0] = v[1] = v[2] = v[3] = 0.f;
         return FAST ? ok : true;
     }
@@ -166,15 +173,16 @@ struct EpiDgrad {   // scatter the class rows back to their stride-2 pixel posit
     float* dx;
     int H, W, Cin;
     DgradClass c;
+    D2pDiv d_hw, d_wc;
     __device__ __forceinline__ float col_value(int) const { return 0.f; }
     __device__ __forceinline__ bool has_c() const { return false; }
     __device__ __forceinline__ float c_value(int, int) const { return 0.f; }
     __device__ __forceinline__ void store(int row, int col, float v) const {
         const int hw = c.Hc * c.Wc;
-        const int n = row / hw;
+        const int n = d2p_div(row, d_hw);
         const int rem = row - n * hw;
-        const int j = rem / c.Wc, i = rem - j * c.Wc;
-        dx[(((long)n * H + c.iy0 + 2 * j) * W + c.ix0 + 2 * i) * Cin + col] = v;
+        const int j = d2p_div(rem, d_wc), i = rem - j * c.Wc;
+        dx[((n * H + c.iy0 + 2 * j) * W + c.ix0 + 2 * i) * Cin + col] = v;
     }
     __device__ __forceinline__ void operator()(int row, int col, float v) const { store(row, col, v); }
 };
@@ -215,10 +223,10 @@ extern "C" int d2p_conv2d_nhwc_s2_same_fwd(int N, int H, int W, int Cin, int Cou
     DenseXC bl{w, Cout, Cout, (Cout % 4 == 0) && (((uintptr_t)w & 15) == 0)};
     EpiDense ep{y, Cout, bias, act, 0};
     if (x_is_u8) {
-        Im2colKC<uint8_t> al{{(const uint8_t*)x, g, (Cin % 4 == 0) && (((uintptr_t)x & 3) == 0)}, M};
+        Im2colKC<uint8_t> al{Im2colElem<uint8_t>::make((const uint8_t*)x, g, (Cin % 4 == 0) && (((uintptr_t)x & 3) == 0)), M};
         return d2p_launch_gemm(al, bl, ep, M, Cout, K, nullptr, 0, as_stream(stream), "conv_fwd_u8", D2P_PROF_CONV);
     }
-    Im2colKC<float> al{{(const float*)x, g, vecx}, M};
+    Im2colKC<float> al{Im2colElem<float>::make((const float*)x, g, vecx), M};
     return d2p_launch_gemm(al, bl, ep, M, Cout, K, nullptr, 0, as_stream(stream), "conv_fwd", D2P_PROF_CONV);
 }
 
@@ -236,10 +244,10 @@ extern "C" int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int C
     DenseXC bl{dy, Cout, Cout, (Cout % 4 == 0) && (((uintptr_t)dy & 15) == 0)};
     EpiDense ep{dw, Cout, nullptr, 0, 0};
     if (x_is_u8) {
-        Im2colXC<uint8_t> al{{(const uint8_t*)x, g, (Cin % 4 == 0) && (((uintptr_t)x & 3) == 0)}, KK};
+        Im2colXC<uint8_t> al{Im2colElem<uint8_t>::make((const uint8_t*)x, g, (Cin % 4 == 0) && (((uintptr_t)x & 3) == 0)), KK};
         return d2p_launch_gemm(al, bl, ep, KK, Cout, Mred, ws, ws_bytes, as_stream(stream), "conv_wgrad_u8", D2P_PROF_CONV);
     }
-    Im2colXC<float> al{{(const float*)x, g, vecx}, KK};
+    Im2colXC<float> al{Im2colElem<float>::make((const float*)x, g, vecx), KK};
     return d2p_launch_gemm(al, bl, ep, KK, Cout, Mred, ws, ws_bytes, as_stream(stream), "conv_wgrad", D2P_PROF_CONV);
 }
 
@@ -269,9 +277,11 @@ extern "C" int d2p_conv2d_nhwc_s2_same_dgrad(int N, int H, int W, int Cin, int C
             c.Wc = (W - c.ix0 + 1) / 2;
             if (c.Hc <= 0 || c.Wc <= 0) continue;
             const int Mc = N * c.Hc * c.Wc, K = c.nty * c.ntx * Cout;
-            DgradAKC al{dy, g, c, Mc, 1};
-            DgradBKC bl{w, Cin, Cout, c, 1};
-            EpiDgrad ep{dx, H, W, Cin, c};
+            const D2pDiv d_hw = d2p_make_div(c.Hc * c.Wc), d_wc = d2p_make_div(c.Wc),
+                         d_cout = d2p_make_div(Cout), d_ntx = d2p_make_div(c.ntx);
+            DgradAKC al{dy, g, c, Mc, 1, d_hw, d_wc, d_cout, d_ntx};
+            DgradBKC bl{w, Cin, Cout, c, 1, d_cout, d_ntx};
+            EpiDgrad ep{dx, H, W, Cin, c, d_hw, d_wc};
             rc = d2p_launch_gemm(al, bl, ep, Mc, Cin, K, nullptr, 0, as_stream(stream), "conv_dgrad",
                                  D2P_PROF_CONV);
             if (rc) return rc;

@@ -55,3 +55,24 @@ int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, floa
 void d2p_conv_rows_dgrad_tune(int workgroups);
 void d2p_conv_rows_tune(int wgrad_workgroups);
 void d2p_conv_frames_wgrad_cap(int cap);
+
+// floor(n / d) for 0 <= n < 2^31 and d >= 1 by multiply-high + shift (exact: m = ceil(2^(31+s) / d),
+// s = ceil(log2 d)).  An integer division costs ~25 VALU instructions on gfx950; the implicit-GEMM
+// loaders decompose a row / column index several times per 16-byte load (VALU : MFMA was 10-38 : 1).
+struct D2pDiv {
+    unsigned int m;
+    int s;
+};
+static inline D2pDiv d2p_make_div(int d) {
+    D2pDiv f;
+    f.s = 0;
+    while ((1L << f.s) < d) ++f.s;
+    const unsigned long long num = 1ULL << (31 + f.s);
+    f.m = (unsigned int)((num + (unsigned long long)d - 1) / (unsigned long long)d);
+    return f;
+}
+#if defined(__HIPCC__)
+__device__ __forceinline__ int d2p_div(int n, D2pDiv f) {
+    return (int)((unsigned int)(((unsigned long long)(unsigned int)n * f.m) >> 31) >> f.s);
+}
+#endif
