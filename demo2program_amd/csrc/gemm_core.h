@@ -335,21 +335,24 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         }
     };
 
-    // NOSEL: the steady-state loop is straight-line -- slabs are consumed in pairs with unconditional
-    // prefetches (loads past the end of K come from a clamped address and are never used), an odd
-    // last slab is finished after the loop, and nothing sits between a global load and its LDS
-    // store, so the compiler cannot consume a prefetch early.  (Fencing the prefetch above and the
-    // stores below each slab's MFMAs with __builtin_amdgcn_sched_barrier gives the textbook
-    // two-slab distance in the ISA but measured equal on small grids and 5-15 % slower on large
-    // ones: left to the scheduler.)
-    // Loaders that need the select keep the guarded form: written straight-line, hipcc hoists the
-    // select (and a vmcnt(0)) right behind each load.
+    // FAST loaders (no control flow around a load): the steady-state loop is straight-line -- slabs
+    // are consumed in pairs with unconditional prefetches (loads past the end of K come from a
+    // clamped address and are zeroed or never used), an odd last slab is finished after the loop.
+    // With branches in the loop hipcc (a) waits vmcnt(0) at the loop head and (b) for tiles with
+    // several accumulators shuffles them between AGPRs and VGPRs every slab (64 v_accvgpr moves
+    // per 32 MFMAs in the 128x64 im2col kernel).  For NOSEL nothing sits between a global load
+    // and its LDS store; with a select the compiler may pull it (and a wait) up behind the load,
+    // which costs the dense kernels 1-3 % -- they take the NOSEL variant whenever K allows.
+    // (Fencing the prefetch above and the stores below each slab's MFMAs with
+    // __builtin_amdgcn_sched_barrier gives the textbook two-slab distance in the ISA but measured
+    // equal on small grids and 5-15 % slower on large ones: left to the scheduler.)
+    // The general loaders (scalar tails, branches inside) keep the guarded form.
     if (nk > 0) {
         D2P_GLOAD(ra0, rb0, oa0, ob0, 0)
         D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
         D2P_GLOAD(ra1, rb1, oa1, ob1, 1)
         __syncthreads();
-        if constexpr (NOSEL) {
+        if constexpr (FAST) {
             const int npairs = nk >> 1;
             for (int pr = 0; pr < npairs; ++pr) {
                 const int kt = 2 * pr;
