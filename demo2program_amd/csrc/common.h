@@ -56,8 +56,18 @@ __device__ __forceinline__ float d2p_lrelu_grad_from_out(float a) {
 }
 // Accurate (ocml) exp/tanh: the gate kernels are HBM/latency-bound, so the few extra
 // VALU ops are free, and they keep logits within the 1e-4 parity budget over 50 steps.
-__device__ __forceinline__ float d2p_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float d2p_tanh(float x) { return tanhf(x); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32, v_rcp_f32: ~1 ulp each)
+// instead of the libm-grade expf / tanhf / IEEE division (~160 VALU instructions per LSTM cell
+// against ~35): the recurrent step's epilogue sits after its MFMA chain, so these run exposed.
+// sigmoid: absolute error <= 2e-7.  tanh through e^(-2|x|) (no overflow, sign restored): absolute
+// error <= 2e-7 -- the same order as TF's own Eigen approximations of these functions.
+__device__ __forceinline__ float d2p_sigmoid(float x) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float d2p_tanh(float x) {
+    const float t = __builtin_amdgcn_exp2f(-2.8853900817779268f * fabsf(x));     // e^(-2|x|) in (0, 1]
+    return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+}
 
 template <typename T>
 __device__ __forceinline__ T wave_reduce_sum(T v) {

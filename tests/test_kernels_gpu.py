@@ -495,6 +495,27 @@ def test_lstm_multi_sequence_launch_equals_separate_calls(K):
             assert torch.equal(a[n], b[n]), n
 
 
+def test_gate_nonlinearities_are_fp32_accurate(K):
+    """The gate math runs on the hardware exp2 / rcp units (common.h d2p_sigmoid / d2p_tanh): over the
+    whole useful range, including saturation and tiny arguments, c' and h' of one cell step stay
+    within 1e-6 absolute of an fp64 evaluation (fp32 rounding of the inputs alone is ~1e-7)."""
+    M, U = 64, 512
+    g = torch.Generator().manual_seed(5)
+    z = (torch.rand(M, 4 * U, generator=g, dtype=torch.float64) * 2 - 1) * 12.0
+    z[:8] *= 1e-3                                   # tiny pre-activations (tanh cancellation range)
+    z[8:16] *= 8.0                                  # deep saturation, |z| up to ~100
+    c_prev = (torch.rand(M, U, generator=g, dtype=torch.float64) * 2 - 1) * 2.0
+    zf32, cf32 = z.float(), c_prev.float()
+    zi, zj, zf, zo = [zf32.double()[:, i * U:(i + 1) * U] for i in range(4)]
+    c_ref = cf32.double() * torch.sigmoid(zf + 1.0) + torch.sigmoid(zi) * torch.tanh(zj)
+    h_ref = torch.tanh(c_ref) * torch.sigmoid(zo)
+    c_out, h_out = torch.empty(M, U, device='cuda'), torch.empty(M, U, device='cuda')
+    K.lstm_gate_fwd(zf32.cuda(), cf32.cuda(), None, None, 0, c_out, None, h_out)
+    assert (c_out.double().cpu() - c_ref).abs().max().item() <= 1e-6 * max(1.0, c_ref.abs().max().item())
+    assert (h_out.double().cpu() - h_ref).abs().max().item() <= 1e-6
+    assert torch.isfinite(c_out).all() and torch.isfinite(h_out).all()
+
+
 def test_lstm_known_answer_scalar_cell(K):
     # SURVEY D5: U=1-like check of gate order i,j,f,o and forget bias 1.0 (U padded to 4)
     U = 4
