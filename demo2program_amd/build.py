@@ -1,23 +1,44 @@
-"""In-tree build of libd2p_hip.so with hipcc for gfx950 (no JIT cache, no cmake)."""
+"""In-tree build of libd2p_hip.so with hipcc for gfx950 (no JIT cache, no cmake).
+
+Every source is compiled to its own object (csrc/build/*.o, in parallel, rebuilt only when the
+source or a header is newer) and the objects are linked into csrc/libd2p_hip.so."""
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-SOURCES = ['api.hip', 'gemm.hip', 'conv.hip', 'conv_direct.hip', 'conv_frames.hip', 'conv_rows.hip', 'bn.hip', 'lstm.hip', 'lstm_step.hip', 'greedy.hip', 'xent.hip', 'misc.hip',
-           'adam.hip']
-HEADERS = ['common.h', 'conv_geom.h', 'gemm_core.h', 'prof.h', 'lstm_math.h', os.path.join('..', '..', 'include', 'd2p.h')]
+SOURCES = ['api.hip', 'gemm.hip', 'conv.hip', 'conv_direct.hip', 'conv_frames.hip', 'conv_rows.hip', 'bn.hip',
+           'lstm.hip', 'lstm_step.hip', 'lstm_persist.hip', 'greedy.hip', 'xent.hip', 'misc.hip', 'adam.hip']
+HEADERS = ['common.h', 'conv_geom.h', 'gemm_core.h', 'prof.h', 'lstm_math.h', 'lstm_internal.h',
+           os.path.join('..', '..', 'include', 'd2p.h')]
 OUT = os.path.join(CSRC, 'libd2p_hip.so')
+OBJDIR = os.path.join(CSRC, 'build')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-result']
+
+
+def _mtime(p):
+    return os.path.getmtime(p) if os.path.exists(p) else 0.0
+
+
+def _newest_header():
+    return max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+
+def _obj(src):
+    return os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+
+
+def _stale_objects():
+    hdr = _newest_header()
+    return [s for s in SOURCES if _mtime(_obj(s)) < max(_mtime(os.path.join(CSRC, s)), hdr)]
 
 
 def _stale():
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    for f in SOURCES + HEADERS:
-        if os.path.getmtime(os.path.join(CSRC, f)) > t:
-            return True
-    return False
+    return any(_mtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
 def build_library(force=False, verbose=False):
@@ -36,11 +57,22 @@ def build_library(force=False, verbose=False):
             hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
             if not os.path.exists(hipcc):
                 hipcc = 'hipcc'
+            os.makedirs(OBJDIR, exist_ok=True)
+            todo = list(SOURCES) if force else _stale_objects()
+
+            def compile_one(src):
+                cmd = [hipcc] + FLAGS + ['-c', src, '-o', _obj(src)]
+                if verbose:
+                    print(' '.join(cmd), flush=True)
+                subprocess.run(cmd, cwd=CSRC, check=True)
+
+            jobs = int(os.environ.get('D2P_BUILD_JOBS', str(min(8, os.cpu_count() or 1))))
+            with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:
+                list(pool.map(compile_one, todo))
             tmp = '%s.tmp.%d' % (OUT, os.getpid())
-            cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-shared', '-fPIC',
-                   '-Wno-unused-result'] + SOURCES + ['-o', tmp]
+            cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + [_obj(s) for s in SOURCES] + ['-o', tmp]
             if verbose:
-                print(' '.join(cmd))
+                print(' '.join(cmd), flush=True)
             subprocess.run(cmd, cwd=CSRC, check=True)
             os.replace(tmp, OUT)
         finally:
@@ -49,4 +81,5 @@ def build_library(force=False, verbose=False):
 
 
 if __name__ == '__main__':
-    print(build_library(force=True, verbose=True))
+    import sys
+    print(build_library(force='--force' in sys.argv, verbose=True))

@@ -14,6 +14,7 @@
 #include "prof.h"
 
 #include "lstm_math.h"
+#include "lstm_internal.h"
 
 __global__ void __launch_bounds__(256)
 lstm_gate_fwd_kernel(int M, int U, const float* __restrict__ z, long zrs,
@@ -167,7 +168,9 @@ extern "C" size_t d2p_lstm_ws_bytes(int M, int U) {
     if (M <= 0 || U <= 0) return 0;
     size_t a = unfused_ws_bytes(M, U);
     if (d2p_lstm_fused_eligible(M, U)) {
-        const size_t b = d2p_lstm_fused_ws_bytes(M, U);
+        size_t b = d2p_lstm_fused_ws_bytes(M, U);
+        if (b > a) a = b;
+        b = d2p_lstm_persist_ws_bytes(M, U);
         if (b > a) a = b;
     }
     return a;
@@ -199,6 +202,10 @@ extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_
     D2P_REQUIRE(n_steps == 0 || (z && Wh && hout && cs), D2P_EINVAL, "lstm seq fwd: null pointer");
     D2P_REQUIRE(ws && ws_bytes >= unfused_ws_bytes(M, U), D2P_EWS,
                 "lstm seq fwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
+    if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && d2p_lstm_persist_fwd_ok(M, U, n_steps) &&
+        ws_bytes >= d2p_lstm_persist_ws_bytes(M, U))
+        return d2p_lstm_persist_fwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, h0, c0, lens, hout, cs,
+                                    h_final, c_final, (float*)ws, st);
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes))
         return d2p_lstm_fused_fwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, h0, c0, lens, hout,
                                   cs, h_final, c_final, (float*)ws, st);
@@ -238,6 +245,10 @@ extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long 
     D2P_REQUIRE(n_steps == 0 || (z && Wh && cs && dz), D2P_EINVAL, "lstm seq bwd: null pointer");
     D2P_REQUIRE(ws && ws_bytes >= unfused_ws_bytes(M, U), D2P_EWS,
                 "lstm seq bwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
+    if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && (((uintptr_t)dz & 15) == 0) &&
+        d2p_lstm_persist_bwd_ok(M, U, n_steps) && ws_bytes >= d2p_lstm_persist_ws_bytes(M, U))
+        return d2p_lstm_persist_bwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
+                                    dh_final, dc_final, dz, dh0, dc0, (float*)ws, st);
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && (((uintptr_t)dz & 15) == 0))
         return d2p_lstm_fused_bwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
                                   dh_final, dc_final, dz, dh0, dc0, (float*)ws, st);

@@ -23,6 +23,7 @@
 //     with 16-byte global accesses.
 #include "common.h"
 #include "lstm_math.h"
+#include "lstm_internal.h"
 #include "prof.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -90,10 +91,24 @@ static inline int pack_blocks(long total) {
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
 }
 
-// fragment-major offset (in floats) of (row, k..k+3), k % 4 == 0, for a matrix with KCx chunks
-__device__ __forceinline__ long frag_off(int row, int k, int KCx) {
-    return ((((long)(row >> 4) * KCx + (k >> 4)) * 64) + (((k & 15) >> 2) << 4) + (row & 15)) * 4;
+int d2p_lstm_pack_w_fwd(int U, const float* Wh, float* Wf, hipStream_t st) {
+    hipLaunchKernelGGL(pack_w_fwd_kernel, dim3(pack_blocks((long)U * U / 4)), dim3(256), 0, st, U, Wh, (float4*)Wf);
+    D2P_LAUNCH_CHECK("pack_w_fwd");
+    return D2P_OK;
 }
+int d2p_lstm_pack_w_bwd(int U, const float* Wh, float* Wb, hipStream_t st) {
+    hipLaunchKernelGGL(pack_w_bwd_kernel, dim3(pack_blocks((long)U * U / 4)), dim3(256), 0, st, U, Wh, (float4*)Wb);
+    D2P_LAUNCH_CHECK("pack_w_bwd");
+    return D2P_OK;
+}
+int d2p_lstm_pack_rows(int M, int K, int total_rs, const float* X, float* Af, hipStream_t st) {
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(pack_blocks((long)total_rs * 16 * K / 4)), dim3(256), 0, st, M, K,
+                       total_rs, X, (float4*)Af);
+    D2P_LAUNCH_CHECK("pack_rows");
+    return D2P_OK;
+}
+
+#define frag_off d2p_frag_off
 
 // row sub-tile range of row tile rt when total_rs sub-tiles are spread over RT tiles
 __device__ __forceinline__ void rt_range(int rt, int total_rs, int RT, int& rs0, int& nrs) {

@@ -6,7 +6,7 @@ CUDA (ROCm) fp32 / int32 and contiguous unless a stride is passed explicitly.
 """
 import torch
 
-from .lib import call, current_stream, ptr
+from .lib import call, current_stream, load as _load_lib, ptr
 
 
 def _require_gpu(*tensors):
@@ -235,6 +235,16 @@ def bn_update_moving(mean, var, moving_mean, moving_var, decay=0.9):
 def set_lstm_fused(on):
     """Process-global knob: fused recurrent-step kernels (default) vs GEMM + gate per step."""
     call.d2p_lstm_set_fused(1 if on else 0)
+
+
+def set_lstm_persistent(on):
+    """Process-global knob: one persistent launch per sequence (default) vs one fused launch per step."""
+    call.d2p_lstm_set_persistent(1 if on else 0)
+
+
+def lstm_persist_error(reset=True):
+    """Synchronising: non-zero when a persistent LSTM launch gave up on a hand-off (results invalid)."""
+    return _load_lib().d2p_lstm_persist_error(1 if reset else 0)
 
 
 def lstm_seq_fwd(z, z_row_stride, z_t_stride, M, U, n_steps, Wh, h0, c0, lens, hout, cs,

@@ -47,6 +47,8 @@ SIGNATURES = {
     'd2p_lstm_gate_bwd': (c_int, [c_int, c_int, P, c_long, P, P, P, P, P, c_int, P, P, c_long, P, S]),
     'd2p_lstm_ws_bytes': (c_size_t, [c_int, c_int]),
     'd2p_lstm_set_fused': (c_int, [c_int]),
+    'd2p_lstm_set_persistent': (c_int, [c_int]),
+    'd2p_lstm_persist_error': (c_int, [c_int]),
     'd2p_lstm_debug_flags': (c_int, [c_int]),
     'd2p_lstm_set_tiling': (c_int, [c_int, c_int, c_int]),
     'd2p_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, c_long, c_long, P, P, P, P, P, P, P, P, P, c_size_t, S]),

@@ -187,6 +187,17 @@ size_t d2p_lstm_ws_bytes(int M, int U);
  * step: h·Wh MFMA + gates) when U in {64,128,256,512} and ws >= d2p_lstm_ws_bytes;
  * 0 = generic GEMM + gate kernel per step.  Both produce the same results (tests compare). */
 int d2p_lstm_set_fused(int on);
+/* Tuning knob (process-global): 1 (default) = persistent sequence kernels (lstm_persist.hip: ONE
+ * launch runs all n_steps; the workgroup's slice of Wh stays in registers, the new h / dz rows
+ * travel between workgroups of a row domain through write-through stores + flags) whenever the
+ * fused path is eligible, U/8 (forward) resp. U/16 (backward) column tiles fit the device's CUs
+ * and M <= 128 rows per row domain; 0 = one fused launch per step.  Same results (tests compare). */
+int d2p_lstm_set_persistent(int on);
+/* Synchronising status query (NOT stream-async, do not call during graph capture): 0 = every
+ * persistent launch so far completed its hand-offs; non-zero = a bounded spin timed out (a
+ * workgroup was not resident, e.g. the device was shared) and the results of that launch are
+ * invalid: (code << 24) | 0x800000 | block.  reset != 0 clears the word. */
+int d2p_lstm_persist_error(int reset);
 /* Ablation knobs for tools/bench_lstm_step.py only (results are wrong when non-zero):
  * bit 0 skips the MFMA part of the fused step kernels, bit 1 skips their epilogue. */
 int d2p_lstm_debug_flags(int flags);
