@@ -16,36 +16,47 @@ __device__ __forceinline__ void stf4(float* p, const f4& a) {
 }
 __device__ __forceinline__ f4 zero4() { f4 r; r.v[0] = r.v[1] = r.v[2] = r.v[3] = 0.f; return r; }
 
-// c' = c*sigmoid(f+1) + sigmoid(i)*tanh(j);  h' = tanh(c')*sigmoid(o)
+// One cell.  c' = c*sigmoid(f+1) + sigmoid(i)*tanh(j);  h' = tanh(c')*sigmoid(o).
+// Contraction is pinned (one explicit fma) so that every kernel that calls this -- vectorised or
+// not -- rounds identically: the persistent and the per-step recurrences are compared bit for bit.
+__device__ __forceinline__ void lstm_cell_fwd(float zi, float zj, float zf, float zo, float cp, float& cn,
+                                              float& hn) {
+#pragma clang fp contract(off)
+    const float ij = d2p_sigmoid(zi) * d2p_tanh(zj);
+    const float c1 = fmaf(cp, d2p_sigmoid(zf + D2P_FORGET_BIAS), ij);
+    cn = c1;
+    hn = d2p_tanh(c1) * d2p_sigmoid(zo);
+}
 __device__ __forceinline__ void lstm_gate_fwd4(const f4& zi, const f4& zj, const f4& zf, const f4& zo,
                                                const f4& cp, f4& cn, f4& hn) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float c1 = cp.v[q] * d2p_sigmoid(zf.v[q] + D2P_FORGET_BIAS) +
-                         d2p_sigmoid(zi.v[q]) * d2p_tanh(zj.v[q]);
-        cn.v[q] = c1;
-        hn.v[q] = d2p_tanh(c1) * d2p_sigmoid(zo.v[q]);
-    }
+    for (int q = 0; q < 4; ++q) lstm_cell_fwd(zi.v[q], zj.v[q], zf.v[q], zo.v[q], cp.v[q], cn.v[q], hn.v[q]);
 }
 
 // Given pre-activations z, c_prev, c (= c after the step), the total gradient dh wrt the
 // emitted/next-state h and dc wrt the state c: pre-activation gradients and dc wrt c_prev.
+__device__ __forceinline__ void lstm_cell_bwd(float zi, float zj, float zf, float zo, float cp, float cc,
+                                              float dh, float dcv, float& gi, float& gj, float& gf, float& go,
+                                              float& dcn) {
+#pragma clang fp contract(off)
+    const float i = d2p_sigmoid(zi);
+    const float j = d2p_tanh(zj);
+    const float f = d2p_sigmoid(zf + D2P_FORGET_BIAS);
+    const float og = d2p_sigmoid(zo);
+    const float tc = d2p_tanh(cc);
+    const float d_o = dh * tc;
+    const float dct = fmaf(dh * og, 1.f - tc * tc, dcv);
+    gi = dct * j * i * (1.f - i);
+    gj = dct * i * (1.f - j * j);
+    gf = dct * cp * f * (1.f - f);
+    go = d_o * og * (1.f - og);
+    dcn = dct * f;
+}
 __device__ __forceinline__ void lstm_gate_bwd4(const f4& zi, const f4& zj, const f4& zf, const f4& zo,
                                                const f4& cp, const f4& cc, const f4& dh, const f4& dcv,
                                                f4& gi, f4& gj, f4& gf, f4& go, f4& dcn) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float i = d2p_sigmoid(zi.v[q]);
-        const float j = d2p_tanh(zj.v[q]);
-        const float f = d2p_sigmoid(zf.v[q] + D2P_FORGET_BIAS);
-        const float og = d2p_sigmoid(zo.v[q]);
-        const float tc = d2p_tanh(cc.v[q]);
-        const float d_o = dh.v[q] * tc;
-        const float dct = dcv.v[q] + dh.v[q] * og * (1.f - tc * tc);
-        gi.v[q] = dct * j * i * (1.f - i);
-        gj.v[q] = dct * i * (1.f - j * j);
-        gf.v[q] = dct * cp.v[q] * f * (1.f - f);
-        go.v[q] = d_o * og * (1.f - og);
-        dcn.v[q] = dct * f;
-    }
+    for (int q = 0; q < 4; ++q)
+        lstm_cell_bwd(zi.v[q], zj.v[q], zf.v[q], zo.v[q], cp.v[q], cc.v[q], dh.v[q], dcv.v[q], gi.v[q], gj.v[q],
+                      gf.v[q], go.v[q], dcn.v[q]);
 }

@@ -14,13 +14,23 @@
 //     computes phase p of step t, the other phases' results of step t / t-1 travel between the
 //     workgroups of the domain, so the hand-off latency (write-through store -> flag -> poll ->
 //     operand load, ~2.5 us) hides behind the MFMA work of the other phases (5 phases at M = 320).
-//   * wave roles: waves 0-3 = MFMA waves (K split four ways, partial tiles combined through LDS);
-//     wave 4 = epilogue wave (gate math, state, all global stores, publishes the new h / dz rows).
-//     The MFMA waves never wait for a store or for the epilogue; they prefetch the next phase's
-//     operands into a second register set behind a flag poll whose load was issued half a phase
-//     earlier.
+//   * wave roles: waves 0-3 = MFMA waves: K split four ways, partial tiles combined through LDS, and
+//     after the combine barrier each wave does the gate math of 4 of the phase's 16 rows ITSELF.
+//     (fp32 MFMA executes on the SIMD's vector ALUs: a separate epilogue wave, at any priority, got
+//     one VALU issue slot per 32-clock MFMA of its SIMD-mate -- measured 3400-4000 clocks for ~100
+//     instructions, 1.7x the phase's whole MFMA time.  In the MFMA wave's own stream the same
+//     instructions cost their issue time.)  Their global stores are unconditional (masked rows go to
+//     a dump line), so the compiler's counted vmcnt waits never turn into a drain.
+//     wave 4 = publish + prefetch wave: after the epilogue barrier it writes the new h / dz rows the
+//     MFMA waves staged in LDS with write-through stores, drains them (the only wave that ever waits
+//     for a store) and raises the flag; it also streams everything the epilogue reads that does NOT
+//     depend on the recurrence (hoisted input projections; saved z / c / dhout in backward)
+//     PS_PF_D phases ahead into an LDS ring with LDS-DMA loads (HBM latency, ~1-2 us under load,
+//     would otherwise sit on the critical hand-off path).  The MFMA waves fetch the next phase's
+//     operands into a second register set one phase ahead, behind a flag whose read was issued one
+//     more phase earlier (an sc1 read of a freshly written line takes ~0.8 us).
 //   * hand-off protocol (cdna_hip_programming.md Guideline 16, form R1): payload = 16-byte
-//     write-through (sc1) stores by ONE wave -> s_waitcnt vmcnt(0) -> one relaxed agent-scope flag
+//     write-through (sc1) stores by ONE wave -> s_waitcnt vmcnt(K), K = the DMA loads issued behind them -> one relaxed agent-scope flag
 //     store per (domain, phase, producer); consumers poll the flags of exactly the producers their
 //     K slice needs with relaxed agent-scope loads and read the payload with sc1 loads (L1 bypass).
 //     Correct under any workgroup -> CU/XCD placement; the block -> tile map only tries to keep a
@@ -37,7 +47,9 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define PS_NRS_MAX 8        // 16-row phases per domain (M <= RT * 128)
 #define PS_PLD 36           // LDS partial-tile row stride (floats)
-#define PS_THREADS 320      // 4 MFMA waves + 1 epilogue wave
+#define PS_THREADS 320      // 4 MFMA waves + the publish / prefetch wave
+#define PS_PF_D 3           // ticks the operand prefetch runs ahead of the epilogue
+#define PS_PF_R (PS_PF_D + 1)   // LDS ring slots
 #define PS_SPIN_LIMIT 60000 // ~50 ms of polling before giving up
 #define PS_AUX_SC1 16       // buffer-instruction cache policy: sc1 (agent scope, bypasses the CU's L1)
 
@@ -64,6 +76,35 @@ extern "C" int d2p_lstm_set_persistent(int on) {
     return D2P_OK;
 }
 int d2p_lstm_is_persistent_enabled() { return g_persist; }
+
+// ---- optional timeline trace (tools/trace_lstm_persist.py) -----------------------------------
+// One workgroup records shader-clock stamps of every tick: role 0 = MFMA wave 0, role 1 = epilogue.
+#define PS_TR_MAXT 512
+#define PS_TR_K 8
+static unsigned long long* g_ps_trace = nullptr;
+static int g_ps_trace_block = 0;
+extern "C" int d2p_lstm_persist_set_trace(void* buf, size_t bytes, int block) {
+    D2P_REQUIRE(!buf || bytes >= (size_t)2 * PS_TR_MAXT * PS_TR_K * sizeof(unsigned long long), D2P_EWS,
+                "lstm persist trace: buffer too small");
+    g_ps_trace = (unsigned long long*)buf;
+    g_ps_trace_block = block;
+    return D2P_OK;
+}
+struct PsTrace {
+    unsigned long long* buf;   // null: off
+    unsigned long long st[PS_TR_K];
+    __device__ __forceinline__ void stamp(int k) {
+        if (buf) st[k] = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void flush(int role, int n, int lane) {
+        if (buf && n < PS_TR_MAXT && lane < PS_TR_K) {
+            unsigned long long v = st[0];
+#pragma unroll
+            for (int k = 1; k < PS_TR_K; ++k) v = (lane == k) ? st[k] : v;
+            buf[((long)role * PS_TR_MAXT + n) * PS_TR_K + lane] = v;
+        }
+    }
+};
 
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ unsigned ps_ld_flag(const unsigned* p) {
@@ -129,6 +170,29 @@ __device__ __forceinline__ void ps_rt_range(int rt, int total_rs, int RT, int& r
 }
 
 // =============================================================================================
+// Shared pieces
+// =============================================================================================
+typedef __attribute__((address_space(3))) void ps_lds_void;
+typedef __attribute__((address_space(1))) const void ps_glb_void;
+
+// 64 lanes x 16 bytes from per-lane global addresses straight into LDS at dst + lane*16
+__device__ __forceinline__ void ps_dma16(const float* src, float* lds_dst) {
+    __builtin_amdgcn_global_load_lds((ps_glb_void*)src, (ps_lds_void*)lds_dst, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void ps_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+struct PsTick {     // (phase, step/pass) of a tick index, advanced incrementally
+    int p, t;
+    __device__ __forceinline__ void next(int nrs) {
+        if (++p == nrs) { p = 0; ++t; }
+    }
+};
+
+// =============================================================================================
 // Forward
 // =============================================================================================
 struct PsFwdArgs {
@@ -140,14 +204,16 @@ struct PsFwdArgs {
     const float* h0; const float* c0; const int* lens;
     float* hout; float* cs; float* h_final; float* c_final;
     unsigned* flags;        // [RT][PS_NRS_MAX][U/8], zeroed before the launch
+    float* dump;            // 64 floats nobody reads: target of masked lanes' stores
     unsigned* err;
+    unsigned long long* trace; int trace_block;
 };
 
 template <int CPW>
-__device__ __forceinline__ void ps_fwd_chain(const f32x4 (&av)[CPW], const f32x4 (&bv)[CPW][2], int c0, int c1,
-                                             f32x4& acc0, f32x4& acc1) {
+__device__ __forceinline__ void ps_fwd_chain(const f32x4 (&av)[CPW], const f32x4 (&bv)[CPW][2], f32x4& acc0,
+                                             f32x4& acc1) {
 #pragma unroll
-    for (int c = c0; c < c1; ++c)
+    for (int c = 0; c < CPW; ++c)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][jj], bv[c][0][jj], acc0, 0, 0, 0);
@@ -155,42 +221,156 @@ __device__ __forceinline__ void ps_fwd_chain(const f32x4 (&av)[CPW], const f32x4
         }
 }
 
-// One phase of one MFMA wave: K-slice product of the 16 rows in `cur` with the resident weight,
-// prefetch of the next phase's rows into `nxt` behind the flag poll.
-template <int CPW>
-__device__ __forceinline__ void ps_fwd_tick(const f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][2],
-                                            bool do_gemm, const unsigned* fl, unsigned need,
-                                            __amdgpu_buffer_rsrc_t hres, int next_off, float* Pw, int lane,
-                                            unsigned* err) {
-    constexpr int H = CPW / 2;
-    // the flag read is unconditional (need == 0 when nothing has to be waited for): a conditional
-    // load would be waited for at the join, i.e. before the MFMA chain instead of behind it
-    const unsigned fv = ps_ld_flag(fl);
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    if (do_gemm) ps_fwd_chain<CPW>(cur, bv, 0, H, acc0, acc1);
-    ps_wait_flags(fl, need, fv, err, 1);
+#define PS_FWD_SLOT 512     // floats per prefetch ring slot: 16 rows x 4 gates x 8 units
+
+struct PsFwdEpi {           // per-lane constants of an MFMA wave's share of the epilogue
+    int rr, un, u;          // row within the phase, unit within the tile, global unit
+    bool lane_on;
+    float *P, *stc, *sth, *stage, *ring;
+    int* stl;
+};
+
+// Gate math of this wave's 4 rows x 8 units of phase (p, t): lanes 0-31 one cell each.
+__device__ __forceinline__ void ps_fwd_epilogue(const PsFwdArgs& a, const PsFwdEpi& e, int rs0, int p, int t, int slot) {
+    const int U = a.U;
+    const int row = (rs0 + p) * 16 + e.rr;
+    const bool valid = e.lane_on && row < a.M;
+    const int sidx = (p * 16 + e.rr) * 8 + e.un;
+    const bool active = t < e.stl[sidx];
+    const bool has_gemm = (t > 0) || a.has_h0;
+    float zin[4], zz[4];
+    {
+        const float* zs = e.ring + slot * PS_FWD_SLOT + e.rr * 32 + e.un;
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_sc1(hres, next_off + c * 1024);
+        for (int g = 0; g < 4; ++g) zz[g] = zin[g] = zs[g * 8];
+    }
+    if (has_gemm) {
+        const float* Pb = e.P + e.rr * PS_PLD + e.un;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) zz[g] += Pb[w * 16 * PS_PLD + g * 8];
+    }
+    const float cp = e.stc[sidx], hp = e.sth[sidx];
+    float cn, hn;
+    lstm_cell_fwd(zz[0], zz[1], zz[2], zz[3], cp, cn, hn);
+    const float c_out = active ? cn : cp;
+    const float h_out = active ? hn : 0.f;        // emitted output: 0 past the row's length
+    const float h_state = active ? hn : hp;       // (c, h) copy through
+    if (e.lane_on) {
+        e.stc[sidx] = c_out;
+        e.sth[sidx] = h_state;
+        // staged in fragment-major order: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
+        e.stage[(((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = h_state;
+    }
+    // unconditional stores (masked lanes -> dump line; rows that keep their input projection write
+    // it back unchanged): the counted waits for the operand prefetch then never wait for a store
+    const long o = (long)row * U + e.u;
+    float* zr = valid ? a.z + (long)t * a.zts + (long)row * a.zrs + e.u : a.dump;
+    const long zg = valid ? (long)U : 0L;
+    const bool keep = !(active && has_gemm);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) zr[g * zg] = keep ? zin[g] : zz[g];
+    float* cq = valid ? a.cs + (size_t)t * a.M * U + o : a.dump;
+    float* hq = valid ? a.hout + (size_t)t * a.M * U + o : a.dump;
+    *cq = c_out;
+    *hq = h_out;
+}
+
+// One phase of one MFMA wave.  With look-ahead (la: the domain has >= 2 phases) the rows of the NEXT
+// phase are requested at the start of this one, behind a flag whose read `fv` was issued one phase
+// earlier, and the flag of the phase after that is read for the next call.  A single-phase domain's
+// next tick depends on THIS tick's epilogue: nothing can be fetched ahead, `cur` is loaded behind a
+// blocking poll instead.
+template <int CPW, bool la>
+__device__ __forceinline__ void ps_fwd_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][2],
+                                            const PsFwdArgs& a, const PsFwdEpi& e, PsTick k0,
+                                            const unsigned* fl_cur, int cur_off, const unsigned* fl1, unsigned need1,
+                                            int off1, const unsigned* fl2, unsigned& fv,
+                                            __amdgpu_buffer_rsrc_t hres, float* Pw, int rs0, int slot, int lane,
+                                            PsTrace& tr) {
+    tr.stamp(0);
+    if (la) {
+        ps_wait_flags(fl1, need1, fv, a.err, 1);
+    } else {
+        ps_wait_flags(fl_cur, (unsigned)k0.t, ps_ld_flag(fl_cur), a.err, 3);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) cur[c] = ps_ld_sc1(hres, cur_off + c * 1024);
+    }
+    tr.stamp(1);
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_sc1(hres, off1 + c * 1024);
+    fv = ps_ld_flag(fl2);
     __builtin_amdgcn_sched_barrier(0);
-    if (do_gemm) ps_fwd_chain<CPW>(cur, bv, H, CPW, acc0, acc1);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if ((k0.t > 0) || a.has_h0) ps_fwd_chain<CPW>(cur, bv, acc0, acc1);
+    tr.stamp(2);
     // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         Pw[((lane >> 4) * 4 + r) * PS_PLD + (lane & 15)] = acc0[r];
         Pw[((lane >> 4) * 4 + r) * PS_PLD + 16 + (lane & 15)] = acc1[r];
     }
-    ps_barrier();
+    ps_barrier();           // A: all four partial tiles of this phase are in LDS
+    tr.stamp(3);
+    ps_fwd_epilogue(a, e, rs0, k0.p, k0.t, slot);
+    ps_barrier();           // B: new rows staged, P and the ring slot free again
+    tr.stamp(4);
+}
+
+// All ticks of one MFMA wave (LA: look-ahead, i.e. the domain has >= 2 phases).  Two ticks per
+// iteration with the two operand register sets swapping roles, so they are never copied.
+template <int CPW, bool LA>
+__device__ __forceinline__ void ps_fwd_mfma_wave(const PsFwdArgs& a, const PsFwdEpi& e, const f32x4 (&bv)[CPW][2],
+                                                 __amdgpu_buffer_rsrc_t hres, const unsigned* fl, int nct, int rs0,
+                                                 int nrs, int nticks, int lane_off, float* Pw, int wave, int lane) {
+    constexpr int KC = 4 * CPW;
+        PsTrace tr;
+    tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
+    f32x4 a0[CPW], a1[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) a0[c] = ps_ld_sc1(hres, rs0 * KC * 1024 + lane_off + c * 1024);
+    PsTick k0 = {0, 0}, k1 = {0, 0}, k2 = {0, 0};      // ticks n, n+1, n+2
+    k1.next(nrs);
+    k2.next(nrs); k2.next(nrs);
+    unsigned fv = ps_ld_flag(fl + k1.p * nct);
+    int slot = 0;
+    // two ticks per iteration with the register sets swapping roles (never copied); odd tail after
+#define PS_FWD_ONE_TICK(CUR, NXT, m)                                                                              \
+    {                                                                                                         \
+        /* ticks past the end are clamped to the last one: their loads are issued unconditionally */         \
+        const bool e1 = (m) + 1 >= nticks, e2 = (m) + 2 >= nticks;                                            \
+        const PsTick q1 = e1 ? k0 : k1, q2 = e2 ? (e1 ? k0 : k1) : k2;                                        \
+        const unsigned need1 = e1 ? 0u : (unsigned)q1.t;     /* version t = published after step t-1 */       \
+        const int cur_off = (int)((k0.t & 1) * a.hfrag_bytes) + (rs0 + k0.p) * KC * 1024 + lane_off;          \
+        const int off1 = (int)((q1.t & 1) * a.hfrag_bytes) + (rs0 + q1.p) * KC * 1024 + lane_off;             \
+        ps_fwd_tick<CPW, LA>(CUR, NXT, bv, a, e, k0, fl + k0.p * nct, cur_off, fl + q1.p * nct, need1, off1, \
+                         fl + q2.p * nct, fv, hres, Pw, rs0, slot, lane, tr);                                 \
+        if (wave == 0) tr.flush(0, (m), lane);                                                                \
+        k0 = k1; k1 = k2; k2.next(nrs);                                                                       \
+        if (++slot == PS_PF_R) slot = 0;                                                                      \
+    }
+    int n = 0;
+#pragma unroll 1
+    for (; n + 1 < nticks; n += 2) {
+        PS_FWD_ONE_TICK(a0, a1, n)
+        PS_FWD_ONE_TICK(a1, a0, n + 1)
+    }
+    if (n < nticks) PS_FWD_ONE_TICK(a0, a1, n)
+#undef PS_FWD_ONE_TICK
 }
 
 template <int CPW>   // U = 64 * CPW
 __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs a) {
     constexpr int KC = 4 * CPW;
     // ONE shared array (a second __shared__ object de-pipelines loads, cdna_hip_programming.md)
-    __shared__ __attribute__((aligned(16))) float lds[2 * 4 * 16 * PS_PLD + PS_NRS_MAX * 64 * 5];
-    float* P = lds;                                            // [2][4][16][PS_PLD]
-    float* stc = lds + 2 * 4 * 16 * PS_PLD;                    // [NRS][64][2] cell state
-    float* sth = stc + PS_NRS_MAX * 64 * 2;                    // [NRS][64][2] hidden state
-    int* stl = reinterpret_cast<int*>(sth + PS_NRS_MAX * 64 * 2);   // [NRS][64] row length
+    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * PS_PLD + PS_NRS_MAX * 384 + 128 + PS_PF_R * PS_FWD_SLOT];
+    float* P = lds;                                            // [4][16][PS_PLD]
+    float* stc = lds + 4 * 16 * PS_PLD;                        // [NRS][16 rows][8 units] cell state
+    float* sth = stc + PS_NRS_MAX * 128;                       // [NRS][16][8] hidden state
+    int* stl = reinterpret_cast<int*>(sth + PS_NRS_MAX * 128); // [NRS][16][8] row length
+    float* stage = stc + PS_NRS_MAX * 384;                     // [2 quads][16 rows][4]: new h rows of the phase
+    float* ring = stage + 128;                                 // [PS_PF_R][16 rows][4 gates][8 units]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int U = a.U, nct = U >> 3;
@@ -210,135 +390,94 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
 #pragma unroll
             for (int s = 0; s < 2; ++s) bv[c][s] = Bf[(((long)ct * KC + wave * CPW + c) * 2 + s) * 64 + lane];
         const __amdgpu_buffer_rsrc_t hres = ps_rsrc(a.hfrag, 2u * a.hfrag_bytes);
-        // byte offset of this lane's float4 in block (rs, kc = wave*CPW) of buffer `b`
+        // byte offset of this lane's float4 in block (rs = 0, kc = wave*CPW)
         const int lane_off = (wave * CPW * 64 + lane) * 16;
+        // the 2*CPW producers (column tiles) whose units this wave's K slice covers
         const unsigned* fl = fbase + 2 * CPW * wave + (lane & (2 * CPW - 1));
-        f32x4 a0[CPW], a1[CPW];
-#pragma unroll
-        for (int c = 0; c < CPW; ++c) a0[c] = ps_ld_sc1(hres, rs0 * KC * 1024 + lane_off + c * 1024);
-        int p = 0, t = 0;
-        for (int n = 0; n < nticks; n += 2) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                if (half == 1 && n + 1 >= nticks) break;
-                // next tick (clamped to this one at the very end: the load is unconditional)
-                int p1 = p + 1, t1 = t;
-                if (p1 == nrs) { p1 = 0; t1 = t + 1; }
-                const bool last = (n + half + 1 >= nticks);
-                if (last) { p1 = p; t1 = t; }
-                const bool do_gemm = (t > 0) || a.has_h0;
-                const unsigned need = last ? 0u : (unsigned)t1;      // version t1 = published after step t1-1
-                const int next_off = (int)((t1 & 1) * a.hfrag_bytes) + (rs0 + p1) * KC * 1024 + lane_off;
-                float* Pw = P + (((n + half) & 1) * 4 + wave) * 16 * PS_PLD;
-                if (half == 0)
-                    ps_fwd_tick<CPW>(a0, a1, bv, do_gemm, fl + p1 * nct, need, hres, next_off, Pw, lane, a.err);
-                else
-                    ps_fwd_tick<CPW>(a1, a0, bv, do_gemm, fl + p1 * nct, need, hres, next_off, Pw, lane, a.err);
-                p = p1; t = t1;
-            }
-        }
-    } else {
-        // ---------------- epilogue wave ----------------
-        const int r = lane >> 2, pr = lane & 3;
-        const int u = ct * 8 + pr * 2;
-        const __amdgpu_buffer_rsrc_t hres = ps_rsrc(a.hfrag, 2u * a.hfrag_bytes);
-        for (int p = 0; p < nrs; ++p) {
-            const int row = (rs0 + p) * 16 + r;
-            const bool valid = row < a.M;
-            float2 c = make_float2(0.f, 0.f), h = make_float2(0.f, 0.f);
+        PsFwdEpi e;
+        e.rr = wave * 4 + ((lane >> 3) & 3);
+        e.un = lane & 7;
+        e.u = ct * 8 + e.un;
+        e.lane_on = lane < 32;
+        e.P = P; e.stc = stc; e.sth = sth; e.stl = stl; e.stage = stage; e.ring = ring;
+        for (int p = 0; p < nrs; ++p) {          // this wave's cells: initial state, row lengths
+            const int row = (rs0 + p) * 16 + e.rr;
+            float c = 0.f, h = 0.f;
             int len = 0x7fffffff;
-            if (valid) {
-                if (a.c0) c = *reinterpret_cast<const float2*>(a.c0 + (long)row * U + u);
-                if (a.h0) h = *reinterpret_cast<const float2*>(a.h0 + (long)row * U + u);
+            if (row < a.M) {
+                if (a.c0) c = a.c0[(long)row * U + e.u];
+                if (a.h0) h = a.h0[(long)row * U + e.u];
                 if (a.lens) len = a.lens[row];
             }
-            *reinterpret_cast<float2*>(stc + (p * 64 + lane) * 2) = c;
-            *reinterpret_cast<float2*>(sth + (p * 64 + lane) * 2) = h;
-            stl[p * 64 + lane] = len;
-        }
-        int p = 0, t = 0;
-        float2 zin[4];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) zin[g] = make_float2(0.f, 0.f);
-        {   // pre-activation inputs of the first phase
-            const int row = rs0 * 16 + r;
-            if (row < a.M && 0 < stl[lane]) {
-                const float* zr = a.z + (long)row * a.zrs + u;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) zin[g] = *reinterpret_cast<const float2*>(zr + (long)g * U);
+            if (e.lane_on) {
+                stc[(p * 16 + e.rr) * 8 + e.un] = c;
+                sth[(p * 16 + e.rr) * 8 + e.un] = h;
+                stl[(p * 16 + e.rr) * 8 + e.un] = len;
             }
         }
+        if (nrs >= 2)
+            ps_fwd_mfma_wave<CPW, true>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, P + wave * 16 * PS_PLD, wave, lane);
+        else
+            ps_fwd_mfma_wave<CPW, false>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, P + wave * 16 * PS_PLD, wave, lane);
+        if (e.lane_on)
+            for (int q = 0; q < nrs; ++q) {
+                const int row = (rs0 + q) * 16 + e.rr;
+                if (row < a.M) {
+                    if (a.h_final) a.h_final[(long)row * U + e.u] = sth[(q * 16 + e.rr) * 8 + e.un];
+                    if (a.c_final) a.c_final[(long)row * U + e.u] = stc[(q * 16 + e.rr) * 8 + e.un];
+                }
+            }
+    } else {
+        // ---------------- publish + prefetch wave ----------------
+        // prefetch: 2 DMA instructions per tick; quad = i*64 + lane = (row, gate, half): 16 bytes = 4 units
+        const float* src[2];
+        int rowoff[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int quad = i * 64 + lane;
+            rowoff[i] = quad >> 3;
+            src[i] = a.z + (long)((quad >> 1) & 3) * U + ct * 8 + (quad & 1) * 4;
+        }
+        PsTick kp = {0, 0};        // next tick to prefetch
+        int pslot = 0;
+        auto issue = [&]() {
+            const PsTick q = kp;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = min((rs0 + q.p) * 16 + rowoff[i], a.M - 1);
+                ps_dma16(src[i] + (long)q.t * a.zts + (long)row * a.zrs, ring + pslot * PS_FWD_SLOT + i * 256);
+            }
+            // past the last tick the same rows are fetched again: the counted waits below stay exact
+            if (q.p + 1 < nrs || q.t + 1 < a.T) kp.next(nrs);
+            if (++pslot == PS_PF_R) pslot = 0;
+        };
+        for (int d = 0; d < PS_PF_D; ++d) issue();
+        ps_wait_vmcnt<(PS_PF_D - 1) * 2>();         // tick 0's inputs have landed
+        const __amdgpu_buffer_rsrc_t hres = ps_rsrc(a.hfrag, 2u * a.hfrag_bytes);
+        PsTrace tr;
+        tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
+        PsTick k = {0, 0};
         for (int n = 0; n < nticks; ++n) {
-            ps_barrier();          // partial tiles of tick n are in P[n & 1]
-            const int row = (rs0 + p) * 16 + r;
-            const bool valid = row < a.M;
-            const int len = stl[p * 64 + lane];
-            const bool active = t < len;
-            const bool has_gemm = (t > 0) || a.has_h0;
-            const long o = (long)row * U + u;
-            float2 zz[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) zz[g] = zin[g];
-            if (has_gemm) {
-                const float* Pb = P + (n & 1) * 4 * 16 * PS_PLD + r * PS_PLD + pr * 2;
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const float2 q = *reinterpret_cast<const float2*>(Pb + w * 16 * PS_PLD + g * 8);
-                        zz[g].x += q.x;
-                        zz[g].y += q.y;
-                    }
-            }
-            const float2 cp = *reinterpret_cast<const float2*>(stc + (p * 64 + lane) * 2);
-            const float2 hp = *reinterpret_cast<const float2*>(sth + (p * 64 + lane) * 2);
-            float2 cn = cp, hs = hp, ho = make_float2(0.f, 0.f);
-            if (active) {
-                // c' = c*sigmoid(f+1) + sigmoid(i)*tanh(j);  h' = tanh(c')*sigmoid(o)   (lstm_math.h)
-                cn.x = cp.x * d2p_sigmoid(zz[2].x + D2P_FORGET_BIAS) + d2p_sigmoid(zz[0].x) * d2p_tanh(zz[1].x);
-                cn.y = cp.y * d2p_sigmoid(zz[2].y + D2P_FORGET_BIAS) + d2p_sigmoid(zz[0].y) * d2p_tanh(zz[1].y);
-                ho.x = d2p_tanh(cn.x) * d2p_sigmoid(zz[3].x);
-                ho.y = d2p_tanh(cn.y) * d2p_sigmoid(zz[3].y);
-                hs = ho;
-            }
-            // publish first: the new state rows in fragment-major layout, 16 bytes per even lane
-            const float px = __shfl_xor(hs.x, 1, 64), py = __shfl_xor(hs.y, 1, 64);
-            if (valid && !(pr & 1)) {
-                const int off = (int)(((t + 1) & 1) * a.hfrag_bytes) +
-                                (int)(d2p_frag_off(row, ct * 8 + (pr >> 1) * 4, U >> 4) * 4);
-                ps_st_sc1(hres, off, hs.x, hs.y, px, py);
-            }
-            if (valid) {
-                if (active && has_gemm) {
-                    float* zr = a.z + (long)t * a.zts + (long)row * a.zrs + u;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) *reinterpret_cast<float2*>(zr + (long)g * U) = zz[g];
-                }
-                *reinterpret_cast<float2*>(a.cs + (size_t)t * a.M * U + o) = cn;
-                *reinterpret_cast<float2*>(a.hout + (size_t)t * a.M * U + o) = ho;
-            }
-            *reinterpret_cast<float2*>(stc + (p * 64 + lane) * 2) = cn;
-            *reinterpret_cast<float2*>(sth + (p * 64 + lane) * 2) = hs;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) ps_st_flag(fbase + p * nct + ct, (unsigned)(t + 1));
-            // next phase + its pre-activation inputs (land while this wave waits at the barrier)
-            if (++p == nrs) { p = 0; ++t; }
-            if (n + 1 < nticks) {
-                const int row1 = (rs0 + p) * 16 + r;
-                if (row1 < a.M && t < stl[p * 64 + lane]) {
-                    const float* zr = a.z + (long)t * a.zts + (long)row1 * a.zrs + u;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) zin[g] = *reinterpret_cast<const float2*>(zr + (long)g * U);
-                }
-            }
+            tr.stamp(0);
+            ps_barrier();          // A
+            ps_barrier();          // B: the phase's new h rows are staged
+            tr.stamp(1);
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(stage + (lane & 31) * 4);
+            const int row = (rs0 + k.p) * 16 + (lane & 15);
+            const int off = (int)(((k.t + 1) & 1) * a.hfrag_bytes) +
+                            (int)(d2p_frag_off(row, ct * 8 + ((lane >> 4) & 1) * 4, U >> 4) * 4);
+            asm volatile("" ::: "memory");
+            if (lane < 32) ps_st_sc1(hres, off, hv[0], hv[1], hv[2], hv[3]);
+            asm volatile("" ::: "memory");
+            issue();                                 // tick n + D into the slot tick n - 1 used
+            tr.stamp(2);
+            ps_wait_vmcnt<2>();                      // everything but the two loads just issued: the store is out
+            tr.stamp(3);
+            if (lane == 0) ps_st_flag(fbase + k.p * nct + ct, (unsigned)(k.t + 1));
+            tr.flush(1, n, lane);
+            k.next(nrs);
         }
-        for (int q = 0; q < nrs; ++q) {
-            const int row = (rs0 + q) * 16 + r;
-            if (row < a.M) {
-                if (a.h_final) *reinterpret_cast<float2*>(a.h_final + (long)row * U + u) = *reinterpret_cast<const float2*>(sth + (q * 64 + lane) * 2);
-                if (a.c_final) *reinterpret_cast<float2*>(a.c_final + (long)row * U + u) = *reinterpret_cast<const float2*>(stc + (q * 64 + lane) * 2);
-            }
-        }
+        ps_wait_vmcnt<0>();
     }
 }
 
@@ -355,7 +494,9 @@ struct PsBwdArgs {
     const float* dhout; const float* dh_final; const float* dc_final;
     float* dz; float* dh0; float* dc0;
     unsigned* flags;        // [RT][PS_NRS_MAX][U/16]
+    float* dump;
     unsigned* err;
+    unsigned long long* trace; int trace_block;
 };
 
 template <int CB, int CPWB>
@@ -370,16 +511,67 @@ __device__ __forceinline__ void ps_bwd_stage(const f32x4 (&sv)[CB], const f32x4 
         }
 }
 
+#define PS_BWD_NOP 8                     // prefetched operands per tick: z (4 gates), c_prev, c, dhout, dh_final
+#define PS_BWD_SLOT (PS_BWD_NOP * 256)   // floats per ring slot: 16 rows x 16 units each
+
+struct PsBwdEpi {
+    int rr, un, u;
+    float *P, *stdc, *stage, *ring;
+    int* stl;
+};
+
+// Gate backward of this wave's 4 rows x 16 units of phase p, pass j (t = T-1-j; t = -1: dh0 pass)
+__device__ __forceinline__ void ps_bwd_epilogue(const PsBwdArgs& a, const PsBwdEpi& e, int rs0, int p, int j, int slot) {
+    const int U = a.U;
+    const int t = a.T - 1 - j;
+    const int row = (rs0 + p) * 16 + e.rr;
+    const bool valid = row < a.M;
+    const long o = (long)row * U + e.u;
+    const int len = e.stl[p * 16 + e.rr];
+    const bool next_active = (t + 1 < a.T) && (t + 1 < len);
+    const bool cur_active = (t >= 0) && (t < len);
+    const float* rs = e.ring + slot * PS_BWD_SLOT + e.rr * 16 + e.un;
+    // dH_t = dz[t+1]·Wh^T (+ dh_final for rows that are not active at t+1) (+ dhout[t])
+    float dH = (!next_active && a.dh_final) ? rs[7 * 256] : 0.f;
+    if (cur_active && a.dhout) dH += rs[6 * 256];
+    if (j > 0) {
+        const float* Pb = e.P + e.rr * PS_PLD + e.un;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) dH += Pb[w * 16 * PS_PLD];
+    }
+    const int sidx = (p * 16 + e.rr) * 16 + e.un;
+    float g[4], dcn;
+    const float cp = (t > 0 || a.c0) ? rs[4 * 256] : 0.f;
+    lstm_cell_bwd(rs[0], rs[256], rs[512], rs[768], cp, rs[5 * 256], dH, e.stdc[sidx], g[0], g[1], g[2], g[3], dcn);
+    if (cur_active) e.stdc[sidx] = dcn;
+#pragma unroll
+    for (int gg = 0; gg < 4; ++gg) {
+        g[gg] = cur_active ? g[gg] : 0.f;
+        // staged fragment-major per gate: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
+        e.stage[gg * 256 + (((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = g[gg];
+    }
+    // unconditional stores: dz[t] row-major (the dh0 pass writes dh0 with the first and dumps the rest)
+    const bool fin = t < 0;
+    float* dzr = (valid && !fin) ? a.dz + (long)t * a.zts + (long)row * a.zrs + e.u : a.dump;
+    const long zg = (valid && !fin) ? (long)U : 0L;
+    float* q0 = (valid && fin) ? a.dh0 + o : dzr;
+    *q0 = fin ? dH : g[0];
+#pragma unroll
+    for (int gg = 1; gg < 4; ++gg) dzr[gg * zg] = g[gg];
+}
+
 template <int CPW>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16
 __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs a) {
     constexpr int CPWB = 4 * CPW;                // chunks per wave
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
     constexpr int KC4 = 4 * CPWB;                // chunks over K = 4U
-    __shared__ __attribute__((aligned(16))) float lds[2 * 4 * 16 * PS_PLD + PS_NRS_MAX * 64 * 5];
-    float* P = lds;                                            // [2][4][16][PS_PLD] (16 columns used)
-    float* stdc = lds + 2 * 4 * 16 * PS_PLD;                   // [NRS][64][4] dC state
-    int* stl = reinterpret_cast<int*>(stdc + PS_NRS_MAX * 64 * 4);   // [NRS][64]
+    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * PS_PLD + PS_NRS_MAX * 256 + PS_NRS_MAX * 16 + 1024 + PS_PF_R * PS_BWD_SLOT];
+    float* P = lds;                                            // [4][16][PS_PLD] (16 columns used)
+    float* stdc = lds + 4 * 16 * PS_PLD;                       // [NRS][16 rows][16 units] dC state
+    int* stl = reinterpret_cast<int*>(stdc + PS_NRS_MAX * 256);     // [NRS][16] row length
+    float* stage = stdc + PS_NRS_MAX * 256 + PS_NRS_MAX * 16;  // [4 gates][4 quads][16 rows][4]: dz of the phase
+    float* ring = stage + 1024;                                // [PS_PF_R][8][16 rows][16 units]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int U = a.U, nnt = U >> 4;
@@ -399,32 +591,62 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         for (int c = 0; c < CPWB; ++c) bw[c] = Bf[(long)c * 64 + lane];
         const __amdgpu_buffer_rsrc_t dres = ps_rsrc(a.dzfrag, 2u * a.dzfrag_bytes);
         const int lane_off = (wave * CPWB * 64 + lane) * 16;
-        const unsigned* fl = fbase + (lane & (nnt - 1));
+        const unsigned* fl = fbase + (lane & (nnt - 1));      // every producer of the domain writes this gate
+        const bool la = nrs >= 2;      // see ps_fwd_tick
+        PsBwdEpi e;
+        e.rr = wave * 4 + (lane >> 4);
+        e.un = lane & 15;
+        e.u = nt * 16 + e.un;
+        e.P = P; e.stdc = stdc; e.stl = stl; e.stage = stage; e.ring = ring;
+        for (int p = 0; p < nrs; ++p) {
+            const int row = (rs0 + p) * 16 + e.rr;
+            float d = 0.f;
+            int len = a.T;
+            if (row < a.M) {
+                if (a.dc_final) d = a.dc_final[(long)row * U + e.u];
+                if (a.lens) len = a.lens[row];
+            }
+            stdc[(p * 16 + e.rr) * 16 + e.un] = d;
+            if (e.un == 0) stl[p * 16 + e.rr] = len;
+        }
+        PsTrace tr;
+        tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
         f32x4 s0[CB], s1[CB];
-        // pass j = 0 has no product (there is no dz[T]); its loads are harmless reads of the buffer
-        int p = 0, j = 0;
+        PsTick k0 = {0, 0}, k1 = {0, 0}, k2 = {0, 0};      // ticks n, n+1, n+2 (t = pass index j)
+        k1.next(nrs);
+        k2.next(nrs); k2.next(nrs);
+        // pass j consumes dz[t+1] with t = T-1-j, i.e. the buffer written in pass j-1: (T-j) & 1.
+        // pass 0 has no product (there is no dz[T]); its loads are harmless reads of the buffer
         {
-            const int off0 = (int)(((a.T - j) & 1) * a.dzfrag_bytes) + (rs0 + p) * KC4 * 1024 + lane_off;
+            const int off0 = (int)((a.T & 1) * a.dzfrag_bytes) + rs0 * KC4 * 1024 + lane_off;
 #pragma unroll
             for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, off0 + c * 1024);
         }
+        unsigned fv = ps_ld_flag(fl + k1.p * nnt);
+        int slot = 0;
+        float* Pw = P + wave * 16 * PS_PLD;
         for (int n = 0; n < nticks; ++n) {
-            int p1 = p + 1, j1 = j;
-            if (p1 == nrs) { p1 = 0; j1 = j + 1; }
-            const bool last = (n + 1 >= nticks);
-            if (last) { p1 = p; j1 = j; }
-            const bool do_gemm = j > 0;
-            const unsigned need = last ? 0u : (unsigned)j1;
-            // pass j consumes dz[t+1] with t = T-1-j, i.e. the buffer written in pass j-1: (T-j) & 1
-            const int off = (int)(((a.T - j) & 1) * a.dzfrag_bytes) + (rs0 + p) * KC4 * 1024 + lane_off;
-            const int off1 = (int)(((a.T - j1) & 1) * a.dzfrag_bytes) + (rs0 + p1) * KC4 * 1024 + lane_off;
-            const unsigned* fl1 = fl + p1 * nnt;
-            unsigned fv = 0u;
+            const bool e1 = n + 1 >= nticks, e2 = n + 2 >= nticks;
+            const PsTick q1 = e1 ? k0 : k1, q2 = e2 ? (e1 ? k0 : k1) : k2;
+            const bool do_gemm = k0.t > 0;
+            const unsigned need1 = e1 ? 0u : (unsigned)q1.t;
+            const int off = (int)(((a.T - k0.t) & 1) * a.dzfrag_bytes) + (rs0 + k0.p) * KC4 * 1024 + lane_off;
+            const int off1 = (int)(((a.T - q1.t) & 1) * a.dzfrag_bytes) + (rs0 + q1.p) * KC4 * 1024 + lane_off;
             f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+            tr.stamp(0);
+            if (!la) {
+                ps_wait_flags(fl + k0.p * nnt, (unsigned)k0.t, ps_ld_flag(fl + k0.p * nnt), a.err, 4);
+#pragma unroll
+                for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, off + c * 1024);
+            }
 #pragma unroll
             for (int st = 0; st < NB; ++st) {
-                if (st == NB - 2) fv = ps_ld_flag(fl1);        // unconditional, see ps_fwd_tick
-                if (st == NB - 1) ps_wait_flags(fl1, need, fv, a.err, 2);
+                if (st == NB - 1) {
+                    // the next tick's first stage: behind its flags, read one tick ago
+                    tr.stamp(1);
+                    if (la) ps_wait_flags(fl + q1.p * nnt, need1, fv, a.err, 2);
+                    tr.stamp(2);
+                }
                 const int noff = (st < NB - 1) ? off + (st + 1) * CB * 1024 : off1;
                 if ((st & 1) == 0) {
 #pragma unroll
@@ -434,104 +656,89 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
                 } else {
 #pragma unroll
                     for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, noff + c * 1024);
+                    if (st == NB - 1) fv = ps_ld_flag(fl + q2.p * nnt);
                     __builtin_amdgcn_sched_barrier(0);
                     if (do_gemm) ps_bwd_stage<CB, CPWB>(s1, bw, st * CB, acc0, acc1);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            float* Pw = P + ((n & 1) * 4 + wave) * 16 * PS_PLD;
 #pragma unroll
             for (int r = 0; r < 4; ++r) Pw[((lane >> 4) * 4 + r) * PS_PLD + (lane & 15)] = acc0[r] + acc1[r];
-            ps_barrier();
-            p = p1; j = j1;
-        }
-    } else {
-        // ---------------- epilogue wave: one (row, 4 units) item per lane ----------------
-        const int r = lane >> 2, q = lane & 3;
-        const int u = nt * 16 + q * 4;
-        const int KCx = U >> 2;
-        const __amdgpu_buffer_rsrc_t dres = ps_rsrc(a.dzfrag, 2u * a.dzfrag_bytes);
-        for (int p = 0; p < nrs; ++p) {
-            const int row = (rs0 + p) * 16 + r;
-            f4 d = zero4();
-            int len = a.T;
-            if (row < a.M) {
-                if (a.dc_final) d = ldf4(a.dc_final + (long)row * U + u);
-                if (a.lens) len = a.lens[row];
-            }
-            stf4(stdc + (p * 64 + lane) * 4, d);
-            stl[p * 64 + lane] = len;
-        }
-        int p = 0, j = 0;
-        for (int n = 0; n < nticks; ++n) {
-            // operands of this item that do not depend on the product: requested before the barrier
-            const int t = a.T - 1 - j;
-            const int row = (rs0 + p) * 16 + r;
-            const bool valid = row < a.M;
-            const long o = (long)row * U + u;
-            const int len = stl[p * 64 + lane];
-            const bool next_active = (t + 1 < a.T) && (t + 1 < len);
-            const bool cur_active = (t >= 0) && (t < len);
-            const bool has_gemm = j > 0;
-            f4 zi = zero4(), zj = zero4(), zf = zero4(), zo = zero4(), cp = zero4(), cc = zero4(), dhx = zero4();
-            if (valid) {
-                if (!next_active && a.dh_final) dhx = ldf4(a.dh_final + o);
-                if (cur_active) {
-                    const float* zr = a.z + (long)t * a.zts + (long)row * a.zrs + u;
-                    zi = ldf4(zr); zj = ldf4(zr + U); zf = ldf4(zr + 2L * U); zo = ldf4(zr + 3L * U);
-                    if (t > 0) cp = ldf4(a.cs + (size_t)(t - 1) * a.M * U + o);
-                    else if (a.c0) cp = ldf4(a.c0 + o);
-                    cc = ldf4(a.cs + (size_t)t * a.M * U + o);
-                    if (a.dhout) {
-                        const f4 e4 = ldf4(a.dhout + (size_t)t * a.M * U + o);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) dhx.v[e] += e4.v[e];
-                    }
-                }
-            }
-            ps_barrier();          // partial tiles of tick n are in P[n & 1]
-            f4 dH = dhx;
-            if (has_gemm) {
-                const float* Pb = P + (n & 1) * 4 * 16 * PS_PLD + r * PS_PLD + q * 4;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const f4 pp = ldf4(Pb + w * 16 * PS_PLD);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dH.v[e] += pp.v[e];
-                }
-            }
-            if (t < 0) {
-                if (valid) stf4(a.dh0 + o, dH);
-            } else {
-                f4 g[4];
-#pragma unroll
-                for (int gg = 0; gg < 4; ++gg) g[gg] = zero4();
-                if (cur_active) {
-                    const f4 dcv = ldf4(stdc + (p * 64 + lane) * 4);
-                    f4 dcn;
-                    lstm_gate_bwd4(zi, zj, zf, zo, cp, cc, dH, dcv, g[0], g[1], g[2], g[3], dcn);
-                    stf4(stdc + (p * 64 + lane) * 4, dcn);
-                }
-                if (valid) {
-                    const int fo = (int)((t & 1) * a.dzfrag_bytes);
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg)
-                        ps_st_sc1(dres, fo + (int)(d2p_frag_off(row, gg * U + u, KCx) * 4), g[gg].v[0], g[gg].v[1],
-                                  g[gg].v[2], g[gg].v[3]);
-                    float* dzr = a.dz + (long)t * a.zts + (long)row * a.zrs + u;
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) stf4(dzr + (long)gg * U, g[gg]);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) ps_st_flag(fbase + p * nnt + nt, (unsigned)(j + 1));
-            if (++p == nrs) { p = 0; ++j; }
+            ps_barrier();          // A: the four partial tiles are in LDS
+            tr.stamp(3);
+            ps_bwd_epilogue(a, e, rs0, k0.p, k0.t, slot);
+            ps_barrier();          // B: dz of the phase staged, P and the ring slot free again
+            tr.stamp(4);
+            if (wave == 0) tr.flush(0, n, lane);
+            k0 = k1; k1 = k2; k2.next(nrs);
+            if (++slot == PS_PF_R) slot = 0;
         }
         if (a.dc0)
             for (int qq = 0; qq < nrs; ++qq) {
-                const int row = (rs0 + qq) * 16 + r;
-                if (row < a.M) stf4(a.dc0 + (long)row * U + u, ldf4(stdc + (qq * 64 + lane) * 4));
+                const int row = (rs0 + qq) * 16 + e.rr;
+                if (row < a.M) a.dc0[(long)row * U + e.u] = stdc[(qq * 16 + e.rr) * 16 + e.un];
             }
+    } else {
+        // ---------------- publish + prefetch wave ----------------
+        // prefetch: 8 DMA instructions per tick, lane = (row r, quad q): z gates i, j, f, o, c before the
+        // step, c after it, dhout, dh_final.  Absent operands fetch a valid dummy (never read).
+        const int r = lane >> 2, q = lane & 3;
+        const int u = nt * 16 + q * 4;
+        PsTick kp = {0, 0};
+        int pslot = 0;
+        auto issue = [&]() {
+            const PsTick kk = kp;
+            const int t = max(a.T - 1 - kk.t, 0);                       // the dh0 pass fetches step 0 again (unused)
+            const int row = min((rs0 + kk.p) * 16 + r, a.M - 1);
+            const long o = (long)row * U + u;
+            float* dst = ring + pslot * PS_BWD_SLOT;
+            const float* zr = a.z + (long)t * a.zts + (long)row * a.zrs + u;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ps_dma16(zr + (long)g * U, dst + g * 256);
+            const float* cc = a.cs + (size_t)t * a.M * U + o;
+            const float* cp = t > 0 ? a.cs + (size_t)(t - 1) * a.M * U + o : (a.c0 ? a.c0 + o : cc);
+            ps_dma16(cp, dst + 4 * 256);
+            ps_dma16(cc, dst + 5 * 256);
+            ps_dma16(a.dhout ? a.dhout + (size_t)t * a.M * U + o : cc, dst + 6 * 256);
+            ps_dma16(a.dh_final ? a.dh_final + o : cc, dst + 7 * 256);
+            if (kk.p + 1 < nrs || kk.t + 1 < J) kp.next(nrs);
+            if (++pslot == PS_PF_R) pslot = 0;
+        };
+        for (int d = 0; d < PS_PF_D; ++d) issue();
+        ps_wait_vmcnt<(PS_PF_D - 1) * PS_BWD_NOP>();
+        const __amdgpu_buffer_rsrc_t dres = ps_rsrc(a.dzfrag, 2u * a.dzfrag_bytes);
+        const int KCx = U >> 2;
+        PsTrace tr;
+        tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
+        PsTick k = {0, 0};
+        for (int n = 0; n < nticks; ++n) {
+            tr.stamp(0);
+            ps_barrier();          // A
+            ps_barrier();          // B: dz of the phase is staged
+            tr.stamp(1);
+            const int t = a.T - 1 - k.t;
+            const int row = (rs0 + k.p) * 16 + (lane & 15);
+            const int fo = (int)((t & 1) * a.dzfrag_bytes);
+            f32x4 gv[4];
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) gv[gg] = *reinterpret_cast<const f32x4*>(stage + gg * 256 + lane * 4);
+            asm volatile("" ::: "memory");
+            if (t >= 0) {
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg)
+                    ps_st_sc1(dres, fo + (int)(d2p_frag_off(row, gg * U + nt * 16 + (lane >> 4) * 4, KCx) * 4), gv[gg][0],
+                              gv[gg][1], gv[gg][2], gv[gg][3]);
+            }
+            asm volatile("" ::: "memory");
+            issue();
+            tr.stamp(2);
+            ps_wait_vmcnt<PS_BWD_NOP>();
+            tr.stamp(3);
+            if (lane == 0) ps_st_flag(fbase + k.p * nnt + nt, (unsigned)(k.t + 1));
+            tr.flush(1, n, lane);
+            k.next(nrs);
+        }
+        ps_wait_vmcnt<0>();
     }
 }
 
@@ -551,15 +758,21 @@ static int ps_num_cus() {
 }
 
 // row domains for `ncol` column tiles: as many as fit the chip, at most one per 16-row sub-tile
-static int ps_pick_rt(int total_rs, int ncol) {
-    int rt = ps_num_cus() / ncol;
+static int g_ps_wgs_per_cu[2] = {1, 1};      // forward, backward (experiment knob)
+extern "C" int d2p_lstm_persist_set_wgs_per_cu(int fwd, int bwd) {
+    if (fwd > 0) g_ps_wgs_per_cu[0] = fwd;
+    if (bwd > 0) g_ps_wgs_per_cu[1] = bwd;
+    return D2P_OK;
+}
+static int ps_pick_rt(int total_rs, int ncol, int dir = 0) {
+    int rt = ps_num_cus() * g_ps_wgs_per_cu[dir] / ncol;
     if (rt > total_rs) rt = total_rs;
     return rt;
 }
-static bool ps_shape_ok(int M, int U, int n_steps, int ncol) {
+static bool ps_shape_ok(int M, int U, int n_steps, int ncol, int dir = 0) {
     if (M <= 0 || n_steps <= 0 || !(U == 64 || U == 128 || U == 256 || U == 512)) return false;
     const int total_rs = (M + 15) / 16;
-    const int rt = ps_pick_rt(total_rs, ncol);
+    const int rt = ps_pick_rt(total_rs, ncol, dir);
     if (rt < 1) return false;
     const long Mp = (long)total_rs * 16;
     if (2L * Mp * 4 * U * 4 > 0x7fffffffL) return false;        // 32-bit buffer offsets
@@ -569,15 +782,16 @@ bool d2p_lstm_persist_fwd_ok(int M, int U, int n_steps) {
     return g_persist && ps_shape_ok(M, U, n_steps, U / 8);
 }
 bool d2p_lstm_persist_bwd_ok(int M, int U, int n_steps) {
-    return g_persist && ps_shape_ok(M, U, n_steps, U / 16);
+    return g_persist && ps_shape_ok(M, U, n_steps, U / 16, 1);
 }
 
 #define PS_FLAG_WORDS 4096   // >= RT * PS_NRS_MAX * ncol for any grid <= 512 workgroups
+#define PS_DUMP_FLOATS 64
 
 size_t d2p_lstm_persist_ws_bytes(int M, int U) {
     const size_t Mp = (size_t)((M + 15) / 16) * 16;
     // packed weight + 2 fragment buffers over K = 4U (backward; forward needs U) + flags
-    return ((size_t)4 * U * U + 2 * Mp * 4 * U) * sizeof(float) + PS_FLAG_WORDS * sizeof(unsigned);
+    return ((size_t)4 * U * U + 2 * Mp * 4 * U) * sizeof(float) + PS_FLAG_WORDS * sizeof(unsigned) + PS_DUMP_FLOATS * sizeof(float);
 }
 
 int d2p_lstm_persist_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, const float* Wh,
@@ -595,7 +809,9 @@ int d2p_lstm_persist_fwd(int M, int U, int n_steps, float* z, long zrs, long zts
     a.hfrag = Wf + (size_t)4 * U * U;
     a.hfrag_bytes = (unsigned)(Mp * U * sizeof(float));
     a.flags = (unsigned*)(a.hfrag + 2 * Mp * U);
+    a.dump = (float*)(a.flags + PS_FLAG_WORDS);
     a.err = ps_err_ptr();
+    a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = z; a.zrs = zrs; a.zts = zts; a.h0 = h0; a.c0 = c0; a.lens = lens;
     a.hout = hout; a.cs = cs; a.h_final = h_final; a.c_final = c_final;
     int rc = d2p_lstm_pack_w_fwd(U, Wh, Wf, st);
@@ -627,7 +843,7 @@ int d2p_lstm_persist_bwd(int M, int U, int n_steps, const float* z, long zrs, lo
     a.M = M; a.U = U; a.T = n_steps;
     a.total_rs = (M + 15) / 16;
     const int nnt = U / 16;
-    a.RT = ps_pick_rt(a.total_rs, nnt);
+    a.RT = ps_pick_rt(a.total_rs, nnt, 1);
     a.want_dh0 = dh0 ? 1 : 0;
     const size_t Mp = (size_t)a.total_rs * 16;
     float* Wb = ws;
@@ -635,7 +851,9 @@ int d2p_lstm_persist_bwd(int M, int U, int n_steps, const float* z, long zrs, lo
     a.dzfrag = Wb + (size_t)4 * U * U;
     a.dzfrag_bytes = (unsigned)(Mp * 4 * U * sizeof(float));
     a.flags = (unsigned*)(a.dzfrag + 2 * Mp * 4 * U);
+    a.dump = (float*)(a.flags + PS_FLAG_WORDS);
     a.err = ps_err_ptr();
+    a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = z; a.zrs = zrs; a.zts = zts; a.c0 = c0; a.cs = cs; a.lens = lens;
     a.dhout = dhout; a.dh_final = dh_final; a.dc_final = dc_final;
     a.dz = dz; a.dh0 = dh0; a.dc0 = dc0;

@@ -198,6 +198,15 @@ int d2p_lstm_set_persistent(int on);
  * workgroup was not resident, e.g. the device was shared) and the results of that launch are
  * invalid: (code << 24) | 0x800000 | block.  reset != 0 clears the word. */
 int d2p_lstm_persist_error(int reset);
+/* Debugging (tools/trace_lstm_persist.py): workgroup `block` of every following persistent launch
+ * writes shader-clock stamps of each phase into buf (device memory, >= 2*512*8 uint64; NULL = off):
+ * [role][tick][8] with role 0 = MFMA wave 0 {start, first half issued, flags seen, partials written,
+ * barrier passed}, role 1 = epilogue wave {start, barrier passed, stores issued, stores drained}. */
+int d2p_lstm_persist_set_trace(void* buf, size_t bytes, int block);
+/* Tuning knob (process-global): workgroups per CU the persistent forward / backward kernels are
+ * sized for (0 keeps the current value; default 1).  2 cuts the rows into twice as many domains so
+ * that two workgroups share a CU and overlap each other's MFMA and epilogue phases. */
+int d2p_lstm_persist_set_wgs_per_cu(int fwd, int bwd);
 /* Ablation knobs for tools/bench_lstm_step.py only (results are wrong when non-zero):
  * bit 0 skips the MFMA part of the fused step kernels, bit 1 skips their epilogue. */
 int d2p_lstm_debug_flags(int flags);

@@ -146,6 +146,7 @@ if __name__ == '__main__':
     if not quick:
         bad += check(320, 512, 200, 1, 1, reps=10)     # long sequence: many hand-offs
     print('=== timing (graph replay)')
+    from demo2program_amd.lib import call
     bench(320, 512, 20, False)
     bench(320, 512, 20, True)
     bench(32, 512, 48, False)
