@@ -49,7 +49,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define PS_PLD 36           // LDS partial-tile row stride (floats)
 #define PS_THREADS 320      // 4 MFMA waves + the publish / prefetch wave
 #define PS_PF_D 3           // ticks the operand prefetch runs ahead of the epilogue
-#define PS_PF_R (PS_PF_D + 1)   // LDS ring slots
+#define PS_PF_R (PS_PF_D + 2)   // LDS ring slots (one more than the distance: a deferred epilogue reads its slot a tick late)
 #define PS_SPIN_LIMIT 60000 // ~50 ms of polling before giving up
 #define PS_AUX_SC1 16       // buffer-instruction cache policy: sc1 (agent scope, bypasses the CU's L1)
 
@@ -211,9 +211,9 @@ struct PsFwdArgs {
 
 template <int CPW>
 __device__ __forceinline__ void ps_fwd_chain(const f32x4 (&av)[CPW], const f32x4 (&bv)[CPW][2], f32x4& acc0,
-                                             f32x4& acc1) {
+                                             f32x4& acc1, int c0 = 0, int c1 = CPW) {
 #pragma unroll
-    for (int c = 0; c < CPW; ++c)
+    for (int c = c0; c < c1; ++c)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][jj], bv[c][0][jj], acc0, 0, 0, 0);
@@ -226,68 +226,102 @@ __device__ __forceinline__ void ps_fwd_chain(const f32x4 (&av)[CPW], const f32x4
 struct PsFwdEpi {           // per-lane constants of an MFMA wave's share of the epilogue
     int rr, un, u;          // row within the phase, unit within the tile, global unit
     bool lane_on;
-    float *P, *stc, *sth, *stage, *ring;
+    float *P, *stc, *sth, *stage, *ring, *spare;   // P, stage: two buffers each (tick parity)
     int* stl;
 };
+#define PS_P_FLOATS (4 * 16 * PS_PLD)
 
-// Gate math of this wave's 4 rows x 8 units of phase (p, t): lanes 0-31 one cell each.
-__device__ __forceinline__ void ps_fwd_epilogue(const PsFwdArgs& a, const PsFwdEpi& e, int rs0, int p, int t, int slot) {
+// Gate math of this wave's 4 rows x 8 units of phase (p, t): lanes 0-31 one cell each, in two parts so
+// that the deferred form below can issue the LDS reads early in the next phase's MFMA chain and do the
+// arithmetic late in it (a read next to its use makes the in-order wave -- MFMAs included -- wait out the
+// LDS latency every time).  No branch in here.
+struct PsFwdEpiIn {
+    float zin[4], part[4][4], cp, hp;
+    int len;
+};
+__device__ __forceinline__ void ps_fwd_epilogue_load(const PsFwdEpi& e, int p, int slot, int par, PsFwdEpiIn& in) {
+    const int sidx = (p * 16 + e.rr) * 8 + e.un;
+    const float* zs = e.ring + slot * PS_FWD_SLOT + e.rr * 32 + e.un;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) in.zin[g] = zs[g * 8];
+    // the partial tiles are zero when the step has no product (t = 0 without an initial state)
+    const float* Pb = e.P + par * PS_P_FLOATS + e.rr * PS_PLD + e.un;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) in.part[g][w] = Pb[w * 16 * PS_PLD + g * 8];
+    in.cp = e.stc[sidx];
+    in.hp = e.sth[sidx];
+    in.len = e.stl[sidx];
+}
+__device__ __forceinline__ void ps_fwd_epilogue_finish(const PsFwdArgs& a, const PsFwdEpi& e, int rs0, int p, int t,
+                                                       int par, const PsFwdEpiIn& in) {
     const int U = a.U;
     const int row = (rs0 + p) * 16 + e.rr;
     const bool valid = e.lane_on && row < a.M;
     const int sidx = (p * 16 + e.rr) * 8 + e.un;
-    const bool active = t < e.stl[sidx];
-    const bool has_gemm = (t > 0) || a.has_h0;
-    float zin[4], zz[4];
-    {
-        const float* zs = e.ring + slot * PS_FWD_SLOT + e.rr * 32 + e.un;
+    const bool active = t < in.len;
+    float zz[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) zz[g] = zin[g] = zs[g * 8];
+    for (int g = 0; g < 4; ++g) {
+        zz[g] = in.zin[g];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) zz[g] += in.part[g][w];
     }
-    if (has_gemm) {
-        const float* Pb = e.P + e.rr * PS_PLD + e.un;
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-#pragma unroll
-            for (int w = 0; w < 4; ++w) zz[g] += Pb[w * 16 * PS_PLD + g * 8];
-    }
-    const float cp = e.stc[sidx], hp = e.sth[sidx];
     float cn, hn;
-    lstm_cell_fwd(zz[0], zz[1], zz[2], zz[3], cp, cn, hn);
-    const float c_out = active ? cn : cp;
+    lstm_cell_fwd(zz[0], zz[1], zz[2], zz[3], in.cp, cn, hn);
+    const float c_out = active ? cn : in.cp;
     const float h_out = active ? hn : 0.f;        // emitted output: 0 past the row's length
-    const float h_state = active ? hn : hp;       // (c, h) copy through
-    if (e.lane_on) {
-        e.stc[sidx] = c_out;
-        e.sth[sidx] = h_state;
-        // staged in fragment-major order: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
-        e.stage[(((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = h_state;
-    }
+    const float h_state = active ? hn : in.hp;    // (c, h) copy through
+    // lanes 32-63 duplicate lanes 0-31 and write a spare word instead
+    *(e.lane_on ? e.stc + sidx : e.spare) = c_out;
+    *(e.lane_on ? e.sth + sidx : e.spare) = h_state;
+    // staged in fragment-major order: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
+    *(e.lane_on ? e.stage + par * 128 + (((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3) : e.spare) = h_state;
     // unconditional stores (masked lanes -> dump line; rows that keep their input projection write
-    // it back unchanged): the counted waits for the operand prefetch then never wait for a store
-    const long o = (long)row * U + e.u;
-    float* zr = valid ? a.z + (long)t * a.zts + (long)row * a.zrs + e.u : a.dump;
+    // it back unchanged): the counted waits for the operand prefetch then never wait for a store.
+    // Addresses are formed for a clamped row and only the final offset is selected: with the whole
+    // address expression under the select the compiler branches around it (and splits the block).
+    const int rowc = min(row, a.M - 1);
+    const long o = (long)rowc * U + e.u;
+    const long zo = (long)t * a.zts + (long)rowc * a.zrs + e.u;
+    const long so = (long)t * a.M * U + o;
+    const long dz = a.dump - a.z, dc = a.dump - a.cs, dh = a.dump - a.hout;    // wave-uniform
+    float* zr = a.z + (valid ? zo : dz);
     const long zg = valid ? (long)U : 0L;
-    const bool keep = !(active && has_gemm);
+    const bool keep = !(active && ((t > 0) || a.has_h0));
 #pragma unroll
-    for (int g = 0; g < 4; ++g) zr[g * zg] = keep ? zin[g] : zz[g];
-    float* cq = valid ? a.cs + (size_t)t * a.M * U + o : a.dump;
-    float* hq = valid ? a.hout + (size_t)t * a.M * U + o : a.dump;
-    *cq = c_out;
-    *hq = h_out;
+    for (int g = 0; g < 4; ++g) zr[g * zg] = keep ? in.zin[g] : zz[g];
+    a.cs[valid ? so : dc] = c_out;
+    a.hout[valid ? so : dh] = h_out;
+}
+__device__ __forceinline__ void ps_fwd_epilogue(const PsFwdArgs& a, const PsFwdEpi& e, int rs0, int p, int t, int slot,
+                                                int par) {
+    PsFwdEpiIn in;
+    ps_fwd_epilogue_load(e, p, slot, par, in);
+    ps_fwd_epilogue_finish(a, e, rs0, p, t, par, in);
 }
 
-// One phase of one MFMA wave.  With look-ahead (la: the domain has >= 2 phases) the rows of the NEXT
-// phase are requested at the start of this one, behind a flag whose read `fv` was issued one phase
-// earlier, and the flag of the phase after that is read for the next call.  A single-phase domain's
-// next tick depends on THIS tick's epilogue: nothing can be fetched ahead, `cur` is loaded behind a
-// blocking poll instead.
+__device__ __forceinline__ void ps_fwd_write_partials(float* Pw, int lane, const f32x4& acc0, const f32x4& acc1) {
+    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        Pw[((lane >> 4) * 4 + r) * PS_PLD + (lane & 15)] = acc0[r];
+        Pw[((lane >> 4) * 4 + r) * PS_PLD + 16 + (lane & 15)] = acc1[r];
+    }
+}
+
+// One phase of one MFMA wave, epilogue right behind its own product (domains with < 4 phases).  With
+// look-ahead (la: >= 2 phases) the rows of the NEXT phase are requested at the start of this one,
+// behind a flag whose read `fv` was issued one phase earlier, and the flag of the phase after that is
+// read for the next call.  A single-phase domain's next tick depends on THIS tick's epilogue: nothing
+// can be fetched ahead, `cur` is loaded behind a blocking poll instead.
 template <int CPW, bool la>
 __device__ __forceinline__ void ps_fwd_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][2],
                                             const PsFwdArgs& a, const PsFwdEpi& e, PsTick k0,
                                             const unsigned* fl_cur, int cur_off, const unsigned* fl1, unsigned need1,
                                             int off1, const unsigned* fl2, unsigned& fv,
-                                            __amdgpu_buffer_rsrc_t hres, float* Pw, int rs0, int slot, int lane,
+                                            __amdgpu_buffer_rsrc_t hres, int wave, int rs0, int slot, int lane,
                                             PsTrace& tr) {
     tr.stamp(0);
     if (la) {
@@ -305,38 +339,85 @@ __device__ __forceinline__ void ps_fwd_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW]
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if ((k0.t > 0) || a.has_h0) ps_fwd_chain<CPW>(cur, bv, acc0, acc1);
     tr.stamp(2);
-    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + r
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        Pw[((lane >> 4) * 4 + r) * PS_PLD + (lane & 15)] = acc0[r];
-        Pw[((lane >> 4) * 4 + r) * PS_PLD + 16 + (lane & 15)] = acc1[r];
-    }
+    ps_fwd_write_partials(e.P + wave * 16 * PS_PLD, lane, acc0, acc1);
     ps_barrier();           // A: all four partial tiles of this phase are in LDS
     tr.stamp(3);
-    ps_fwd_epilogue(a, e, rs0, k0.p, k0.t, slot);
+    ps_fwd_epilogue(a, e, rs0, k0.p, k0.t, slot, 0);
     ps_barrier();           // B: new rows staged, P and the ring slot free again
     tr.stamp(4);
 }
 
-// All ticks of one MFMA wave (LA: look-ahead, i.e. the domain has >= 2 phases).  Two ticks per
-// iteration with the two operand register sets swapping roles, so they are never copied.
-template <int CPW, bool LA>
+// Deferred form (domains with >= 4 phases): the gate math of the PREVIOUS phase runs inside this
+// phase's MFMA chain -- one basic block, and the scheduler is told to put two VALU and one LDS read
+// behind every MFMA (three VALU / SALU / LDS instructions per MFMA): the matrix pipe and the vector ALU are separate, so in the MFMA wave's own
+// instruction stream the epilogue costs (almost) nothing, where behind the chain it cost 1300 of a
+// phase's 4750 clocks.  One barrier per phase; the new rows are published one phase later, which a
+// domain with >= 4 phases in flight can afford.
+template <int CPW>
+__device__ __forceinline__ void ps_fwd_tick_defer(const f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][2],
+                                                  const PsFwdArgs& a, const PsFwdEpi& e, PsTick kprev, int slot_prev,
+                                                  const unsigned* fl1, unsigned need1, int off1, const unsigned* fl2,
+                                                  unsigned& fv, __amdgpu_buffer_rsrc_t hres, int wave, int rs0,
+                                                  int par, int lane, PsTrace& tr) {
+    tr.stamp(0);
+    ps_wait_flags(fl1, need1, fv, a.err, 1);
+    tr.stamp(1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int C1 = CPW >= 4 ? CPW / 4 : 0, C2 = CPW >= 4 ? CPW / 2 : 0;
+    // first quarter of the chain with the next phase's operand loads (~60 clocks of issue each) and
+    // the previous phase's LDS reads issued into it ...
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_sc1(hres, off1 + c * 1024);
+    fv = ps_ld_flag(fl2);
+    PsFwdEpiIn in;
+    ps_fwd_epilogue_load(e, kprev.p, slot_prev, par ^ 1, in);
+    ps_fwd_chain<CPW>(cur, bv, acc0, acc1, 0, C1);
+#pragma unroll
+    for (int i = 0; i < 8 * C1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one operand load
+        __builtin_amdgcn_sched_group_barrier(0x186, 3, 0);      // three of VALU / SALU / LDS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ... a quarter for them to land ...
+    ps_fwd_chain<CPW>(cur, bv, acc0, acc1, C1, C2);
+    __builtin_amdgcn_sched_barrier(0);
+    // ... and the arithmetic and stores spread over the second half
+    ps_fwd_chain<CPW>(cur, bv, acc0, acc1, C2, CPW);
+    ps_fwd_epilogue_finish(a, e, rs0, kprev.p, kprev.t, par ^ 1, in);
+#pragma unroll
+    for (int i = 0; i < 8 * (CPW - C2); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      // one MFMA
+        __builtin_amdgcn_sched_group_barrier(0x3d6, 4, 0);      // four of VALU / SALU / LDS / VMEM write
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tr.stamp(2);
+    ps_fwd_write_partials(e.P + par * PS_P_FLOATS + wave * 16 * PS_PLD, lane, acc0, acc1);
+    ps_barrier();           // partial tiles of this phase and the staged rows of the previous one are in LDS
+    tr.stamp(3);
+    tr.stamp(4);
+}
+
+// All ticks of one MFMA wave.  Two ticks per iteration with the two operand register sets swapping
+// roles, so they are never copied.  MODE 0: no look-ahead (1 phase), 1: look-ahead, 2: look-ahead +
+// deferred epilogue (>= 4 phases).
+template <int CPW, int MODE>
 __device__ __forceinline__ void ps_fwd_mfma_wave(const PsFwdArgs& a, const PsFwdEpi& e, const f32x4 (&bv)[CPW][2],
                                                  __amdgpu_buffer_rsrc_t hres, const unsigned* fl, int nct, int rs0,
-                                                 int nrs, int nticks, int lane_off, float* Pw, int wave, int lane) {
+                                                 int nrs, int nticks, int lane_off, int wave, int lane) {
     constexpr int KC = 4 * CPW;
-        PsTrace tr;
+    PsTrace tr;
     tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
     f32x4 a0[CPW], a1[CPW];
 #pragma unroll
     for (int c = 0; c < CPW; ++c) a0[c] = ps_ld_sc1(hres, rs0 * KC * 1024 + lane_off + c * 1024);
-    PsTick k0 = {0, 0}, k1 = {0, 0}, k2 = {0, 0};      // ticks n, n+1, n+2
+    PsTick kp = {0, 0}, k0 = {0, 0}, k1 = {0, 0}, k2 = {0, 0};      // ticks n-1, n, n+1, n+2
     k1.next(nrs);
     k2.next(nrs); k2.next(nrs);
     unsigned fv = ps_ld_flag(fl + k1.p * nct);
-    int slot = 0;
-    // two ticks per iteration with the register sets swapping roles (never copied); odd tail after
-#define PS_FWD_ONE_TICK(CUR, NXT, m)                                                                              \
+    int slot = 0, slot_prev = 0;
+#define PS_FWD_ONE_TICK(CUR, NXT, m)                                                                          \
     {                                                                                                         \
         /* ticks past the end are clamped to the last one: their loads are issued unconditionally */         \
         const bool e1 = (m) + 1 >= nticks, e2 = (m) + 2 >= nticks;                                            \
@@ -344,19 +425,51 @@ __device__ __forceinline__ void ps_fwd_mfma_wave(const PsFwdArgs& a, const PsFwd
         const unsigned need1 = e1 ? 0u : (unsigned)q1.t;     /* version t = published after step t-1 */       \
         const int cur_off = (int)((k0.t & 1) * a.hfrag_bytes) + (rs0 + k0.p) * KC * 1024 + lane_off;          \
         const int off1 = (int)((q1.t & 1) * a.hfrag_bytes) + (rs0 + q1.p) * KC * 1024 + lane_off;             \
-        ps_fwd_tick<CPW, LA>(CUR, NXT, bv, a, e, k0, fl + k0.p * nct, cur_off, fl + q1.p * nct, need1, off1, \
-                         fl + q2.p * nct, fv, hres, Pw, rs0, slot, lane, tr);                                 \
+        if (MODE == 2)                                                                                        \
+            ps_fwd_tick_defer<CPW>(CUR, NXT, bv, a, e, kp, slot_prev, fl + q1.p * nct, need1, off1, fl + q2.p * nct, \
+                                   fv, hres, wave, rs0, (m) & 1, lane, tr);                                   \
+        else                                                                                                  \
+            ps_fwd_tick<CPW, MODE != 0>(CUR, NXT, bv, a, e, k0, fl + k0.p * nct, cur_off, fl + q1.p * nct, need1, \
+                                        off1, fl + q2.p * nct, fv, hres, wave, rs0, slot, lane, tr);          \
         if (wave == 0) tr.flush(0, (m), lane);                                                                \
-        k0 = k1; k1 = k2; k2.next(nrs);                                                                       \
+        kp = k0; k0 = k1; k1 = k2; k2.next(nrs);                                                              \
+        slot_prev = slot;                                                                                     \
         if (++slot == PS_PF_R) slot = 0;                                                                      \
     }
     int n = 0;
+    if (MODE == 2) {
+        // first tick: nothing to finish yet (plain product, one barrier)
+        const unsigned need1 = (unsigned)k1.t;
+        const int off1 = (int)((k1.t & 1) * a.hfrag_bytes) + (rs0 + k1.p) * KC * 1024 + lane_off;
+        ps_wait_flags(fl + k1.p * nct, need1, fv, a.err, 1);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) a1[c] = ps_ld_sc1(hres, off1 + c * 1024);
+        fv = ps_ld_flag(fl + k2.p * nct);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        ps_fwd_chain<CPW>(a0, bv, acc0, acc1);
+        ps_fwd_write_partials(e.P + wave * 16 * PS_PLD, lane, acc0, acc1);
+        ps_barrier();
+        kp = k0; k0 = k1; k1 = k2; k2.next(nrs);
+        slot_prev = slot;
+        ++slot;
+        n = 1;
 #pragma unroll 1
-    for (; n + 1 < nticks; n += 2) {
-        PS_FWD_ONE_TICK(a0, a1, n)
-        PS_FWD_ONE_TICK(a1, a0, n + 1)
+        for (; n + 1 < nticks; n += 2) {
+            PS_FWD_ONE_TICK(a1, a0, n)
+            PS_FWD_ONE_TICK(a0, a1, n + 1)
+        }
+        if (n < nticks) PS_FWD_ONE_TICK(a1, a0, n)
+        // the last phase's gate math (kp is the last tick now)
+        ps_fwd_epilogue(a, e, rs0, kp.p, kp.t, slot_prev, (nticks - 1) & 1);
+    } else {
+#pragma unroll 1
+        for (; n + 1 < nticks; n += 2) {
+            PS_FWD_ONE_TICK(a0, a1, n)
+            PS_FWD_ONE_TICK(a1, a0, n + 1)
+        }
+        if (n < nticks) PS_FWD_ONE_TICK(a0, a1, n)
     }
-    if (n < nticks) PS_FWD_ONE_TICK(a0, a1, n)
 #undef PS_FWD_ONE_TICK
 }
 
@@ -364,13 +477,14 @@ template <int CPW>   // U = 64 * CPW
 __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs a) {
     constexpr int KC = 4 * CPW;
     // ONE shared array (a second __shared__ object de-pipelines loads, cdna_hip_programming.md)
-    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * PS_PLD + PS_NRS_MAX * 384 + 128 + PS_PF_R * PS_FWD_SLOT];
-    float* P = lds;                                            // [4][16][PS_PLD]
-    float* stc = lds + 4 * 16 * PS_PLD;                        // [NRS][16 rows][8 units] cell state
+    __shared__ __attribute__((aligned(16))) float lds[2 * PS_P_FLOATS + PS_NRS_MAX * 384 + 64 + 2 * 128 + PS_PF_R * PS_FWD_SLOT];
+    float* P = lds;                                            // [2][4][16][PS_PLD]
+    float* stc = lds + 2 * PS_P_FLOATS;                        // [NRS][16 rows][8 units] cell state
     float* sth = stc + PS_NRS_MAX * 128;                       // [NRS][16][8] hidden state
     int* stl = reinterpret_cast<int*>(sth + PS_NRS_MAX * 128); // [NRS][16][8] row length
-    float* stage = stc + PS_NRS_MAX * 384;                     // [2 quads][16 rows][4]: new h rows of the phase
-    float* ring = stage + 128;                                 // [PS_PF_R][16 rows][4 gates][8 units]
+    float* spare = stc + PS_NRS_MAX * 384;                     // [64] write target of the duplicate lanes
+    float* stage = spare + 64;                                 // [2][2 quads][16 rows][4]: new h rows of a phase
+    float* ring = stage + 2 * 128;                             // [PS_PF_R][16 rows][4 gates][8 units]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int U = a.U, nct = U >> 3;
@@ -380,6 +494,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
     ps_rt_range(rt, a.total_rs, a.RT, rs0, nrs);
     const int nticks = nrs * a.T;
     unsigned* fbase = a.flags + (long)rt * PS_NRS_MAX * nct;
+    // deferred epilogue: the domain must have phases to spare for the later publication, and every
+    // step must have a product (the host zero-fills the state buffer when there is no h0)
+    const bool defer = nrs >= 4;
 
     if (wave < 4) {
         // ---------------- MFMA waves ----------------
@@ -399,7 +516,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
         e.un = lane & 7;
         e.u = ct * 8 + e.un;
         e.lane_on = lane < 32;
-        e.P = P; e.stc = stc; e.sth = sth; e.stl = stl; e.stage = stage; e.ring = ring;
+        e.P = P; e.stc = stc; e.sth = sth; e.stl = stl; e.stage = stage; e.ring = ring; e.spare = spare + lane;
         for (int p = 0; p < nrs; ++p) {          // this wave's cells: initial state, row lengths
             const int row = (rs0 + p) * 16 + e.rr;
             float c = 0.f, h = 0.f;
@@ -415,10 +532,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
                 stl[(p * 16 + e.rr) * 8 + e.un] = len;
             }
         }
-        if (nrs >= 2)
-            ps_fwd_mfma_wave<CPW, true>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, P + wave * 16 * PS_PLD, wave, lane);
-        else
-            ps_fwd_mfma_wave<CPW, false>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, P + wave * 16 * PS_PLD, wave, lane);
+        if (defer) ps_fwd_mfma_wave<CPW, 2>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
+        else if (nrs >= 2) ps_fwd_mfma_wave<CPW, 1>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
+        else ps_fwd_mfma_wave<CPW, 0>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
         if (e.lane_on)
             for (int q = 0; q < nrs; ++q) {
                 const int row = (rs0 + q) * 16 + e.rr;
@@ -459,23 +575,26 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
         PsTick k = {0, 0};
         for (int n = 0; n < nticks; ++n) {
             tr.stamp(0);
-            ps_barrier();          // A
-            ps_barrier();          // B: the phase's new h rows are staged
+            ps_barrier();          // A (deferred form: the only barrier of the tick)
+            if (!defer) ps_barrier();          // B: the phase's new h rows are staged
             tr.stamp(1);
-            const f32x4 hv = *reinterpret_cast<const f32x4*>(stage + (lane & 31) * 4);
+            // deferred form: tick n-1's rows were staged during tick n and are published now
+            const bool pub = !defer || n > 0;
+            const int par = defer ? ((n - 1) & 1) : 0;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(stage + par * 128 + (lane & 31) * 4);
             const int row = (rs0 + k.p) * 16 + (lane & 15);
             const int off = (int)(((k.t + 1) & 1) * a.hfrag_bytes) +
                             (int)(d2p_frag_off(row, ct * 8 + ((lane >> 4) & 1) * 4, U >> 4) * 4);
             asm volatile("" ::: "memory");
-            if (lane < 32) ps_st_sc1(hres, off, hv[0], hv[1], hv[2], hv[3]);
+            if (lane < 32 && pub) ps_st_sc1(hres, off, hv[0], hv[1], hv[2], hv[3]);
             asm volatile("" ::: "memory");
             issue();                                 // tick n + D into the slot tick n - 1 used
             tr.stamp(2);
             ps_wait_vmcnt<2>();                      // everything but the two loads just issued: the store is out
             tr.stamp(3);
-            if (lane == 0) ps_st_flag(fbase + k.p * nct + ct, (unsigned)(k.t + 1));
+            if (lane == 0 && pub) ps_st_flag(fbase + k.p * nct + ct, (unsigned)(k.t + 1));
             tr.flush(1, n, lane);
-            k.next(nrs);
+            if (pub) k.next(nrs);
         }
         ps_wait_vmcnt<0>();
     }
@@ -819,6 +938,9 @@ int d2p_lstm_persist_fwd(int M, int U, int n_steps, float* z, long zrs, long zts
     if (h0) {
         rc = d2p_lstm_pack_rows(M, U, a.total_rs, h0, a.hfrag, st);
         if (rc) return rc;
+    } else {
+        // the deferred-epilogue form multiplies in every step: make the step-0 product an exact zero
+        D2P_HIP(hipMemsetAsync(a.hfrag, 0, a.hfrag_bytes, st));
     }
     D2P_HIP(hipMemsetAsync(a.flags, 0, (size_t)a.RT * PS_NRS_MAX * nct * sizeof(unsigned), st));
     const int blocks = nct * a.RT;
