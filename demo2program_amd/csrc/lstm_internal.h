@@ -16,6 +16,7 @@ __host__ __device__ __forceinline__ long d2p_frag_off(int row, int k, int KCx) {
 }
 
 // persistent-sequence back end (lstm_persist.hip)
+int d2p_lstm_is_persistent_enabled();
 bool d2p_lstm_persist_fwd_ok(int M, int U, int n_steps);
 bool d2p_lstm_persist_bwd_ok(int M, int U, int n_steps);
 size_t d2p_lstm_persist_ws_bytes(int M, int U);

@@ -71,8 +71,10 @@ extern "C" int d2p_lstm_persist_error(int reset) {
 }
 
 static int g_persist = 1;
+static int ps_num_cus();
 extern "C" int d2p_lstm_set_persistent(int on) {
     g_persist = on ? 1 : 0;
+    if (on) (void)ps_num_cus();
     return D2P_OK;
 }
 int d2p_lstm_is_persistent_enabled() { return g_persist; }
@@ -865,15 +867,18 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
 // Host side
 // =============================================================================================
 static int ps_num_cus() {
+    // hipDeviceGetAttribute is legal under stream capture (hipGetDeviceProperties is not: a first call from
+    // inside a captured training step would silently disable the persistent path); retried until it works
     static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            n = prop.multiProcessorCount;
-        if (n <= 0) n = 1;
+    if (n <= 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            n = v;
+        else
+            (void)hipGetLastError();
     }
-    return n;
+    return n > 0 ? n : 1;
 }
 
 // row domains for `ncol` column tiles: as many as fit the chip, at most one per 16-row sub-tile

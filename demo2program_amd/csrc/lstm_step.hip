@@ -846,7 +846,9 @@ extern "C" int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* d, d2p_
         Ms[i] = d[i].M; Us[i] = d[i].U; wsb[i] = d[i].ws_bytes; wsp[i] = d[i].ws;
         ok = d[i].n_steps > 0 && d[i].z_row_stride % 4 == 0 && (((uintptr_t)d[i].z & 15) == 0);
     }
-    if (ok && multi_fused_ok(nseq, Ms, Us, wsb, wsp)) {
+    // with the persistent back end on, every sequence gets its own persistent launch (the sequence
+    // entry point falls back to per-step launches for shapes it does not take)
+    if (ok && !d2p_lstm_is_persistent_enabled() && multi_fused_ok(nseq, Ms, Us, wsb, wsp)) {
         FwdSeq q[D2P_MAX_SEQ];
         float* ws[D2P_MAX_SEQ];
         for (int i = 0; i < nseq; ++i) {
@@ -878,7 +880,7 @@ extern "C" int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* d, d2p_
         ok = d[i].n_steps > 0 && d[i].z_row_stride % 4 == 0 && (((uintptr_t)d[i].z & 15) == 0) &&
              (((uintptr_t)d[i].dz & 15) == 0);
     }
-    if (ok && multi_fused_ok(nseq, Ms, Us, wsb, wsp)) {
+    if (ok && !d2p_lstm_is_persistent_enabled() && multi_fused_ok(nseq, Ms, Us, wsb, wsp)) {
         BwdSeq q[D2P_MAX_SEQ];
         float* ws[D2P_MAX_SEQ];
         for (int i = 0; i < nseq; ++i) {

@@ -400,15 +400,83 @@ def _lstm_case(K, M, T, I, U, masked, with_init, strided):
         close(dc0, c0.grad, **tol)
 
 
-@pytest.mark.parametrize('fused', [True, False])
+@pytest.mark.parametrize('backend', ['persistent', 'step', 'unfused'])
 @pytest.mark.parametrize('masked,with_init,strided', [(True, False, True), (True, True, False),
                                                       (False, True, False), (False, False, False)])
-def test_lstm_seq_fwd_bwd(K, masked, with_init, strided, fused):
-    K.set_lstm_fused(fused)
+def test_lstm_seq_fwd_bwd(K, masked, with_init, strided, backend):
+    """The three back ends of d2p_lstm_seq_fwd/_bwd (one persistent launch per sequence, one fused
+    launch per step, generic GEMM + gate kernel per step) against the oracle."""
+    K.set_lstm_fused(backend != 'unfused')
+    K.set_lstm_persistent(backend == 'persistent')
     try:
         _lstm_case(K, M=12, T=6, I=20, U=64, masked=masked, with_init=with_init, strided=strided)
+        assert K.lstm_persist_error() == 0
     finally:
         K.set_lstm_fused(True)
+        K.set_lstm_persistent(True)
+
+
+def _persist_vs_step(K, M, U, T, masked, with_init, seed, reps=2):
+    """Persistent kernels against the per-step kernels on the same inputs: the forward outputs must be
+    bit-identical (same K split, same summation order, shared cell math), the backward within fp32
+    round-off (the persistent kernel sums each wave's product in two accumulators).  A stale in-launch
+    hand-off would show up as a forward mismatch."""
+    g = torch.Generator().manual_seed(seed)
+    z0 = ((torch.rand(T * M, 4 * U, generator=g) - 0.5) * 2).cuda()
+    Wh = ((torch.rand(U, 4 * U, generator=g) - 0.5) * 0.2).cuda()
+    h0 = (torch.rand(M, U, generator=g) - 0.5).cuda() if with_init else None
+    c0 = (torch.rand(M, U, generator=g) - 0.5).cuda() if with_init else None
+    lens = None
+    if masked:
+        lens = torch.randint(0, T + 1, (M,), generator=g)
+        lens[0] = T
+        lens = lens.to(torch.int32).cuda()
+    dhout = (torch.rand(T, M, U, generator=g) - 0.5).cuda()
+    dhf, dcf = (torch.rand(M, U, generator=g) - 0.5).cuda(), (torch.rand(M, U, generator=g) - 0.5).cuda()
+
+    def run():
+        z = z0.clone()
+        o = dict(z=z, hout=torch.full((T, M, U), float('nan'), device='cuda'),
+                 cs=torch.full((T, M, U), float('nan'), device='cuda'),
+                 hf=torch.empty(M, U, device='cuda'), cf=torch.empty(M, U, device='cuda'),
+                 dz=torch.full((T * M, 4 * U), float('nan'), device='cuda'),
+                 dh0=torch.empty(M, U, device='cuda'), dc0=torch.empty(M, U, device='cuda'))
+        K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, T, Wh, h0, c0, lens, o['hout'], o['cs'], o['hf'], o['cf'])
+        K.lstm_seq_bwd(z, 4 * U, M * 4 * U, M, U, T, Wh, c0, lens, o['cs'], dhout, dhf, dcf, o['dz'], o['dh0'],
+                       o['dc0'])
+        torch.cuda.synchronize()
+        return o
+    K.set_lstm_persistent(False)
+    try:
+        ref = run()
+    finally:
+        K.set_lstm_persistent(True)
+    for _ in range(reps):
+        got = run()
+        assert K.lstm_persist_error() == 0
+        for n in ('z', 'hout', 'cs', 'hf', 'cf'):
+            assert torch.equal(got[n], ref[n]), n
+        for n in ('dz', 'dh0', 'dc0'):
+            err = (got[n] - ref[n]).abs().max().item()
+            assert err <= 2e-5 * ref[n].abs().max().item() + 1e-7, (n, err)
+
+
+@pytest.mark.parametrize('M,U,T,masked,with_init', [
+    (320, 512, 20, True, True),      # BASELINE config 2 / 4: 4 row domains x 5 phases, deferred epilogue
+    (320, 512, 20, False, False),
+    (32, 512, 40, False, True),      # program decoder: single-phase domains (no look-ahead)
+    (400, 512, 12, True, True),      # k = 25, B = 16: 6-7 phases per domain
+    (48, 512, 5, True, False),       # 3 single-phase domains, last rows padded
+    (96, 512, 6, False, True),       # 2 phases per domain... look-ahead without deferral
+    (176, 512, 5, True, True),       # 3 phases per domain
+    (320, 64, 30, True, True), (35, 128, 4, True, True), (80, 256, 5, False, True), (512, 512, 4, False, True)])
+def test_lstm_persistent_equals_per_step(K, M, U, T, masked, with_init):
+    _persist_vs_step(K, M, U, T, masked, with_init, seed=M + U + T)
+
+
+def test_lstm_persistent_long_sequence(K):
+    """4000 hand-offs per workgroup: rare stale reads would surface here."""
+    _persist_vs_step(K, 320, 512, 160, True, True, seed=3, reps=3)
 
 
 @pytest.mark.parametrize('M,U', [(35, 128), (80, 256), (48, 512)])
@@ -479,6 +547,7 @@ def test_lstm_multi_sequence_launch_equals_separate_calls(K):
                            hout=o['hout'], cs=o['cs']))
             bw.append(dict(M=M, U=U, n_steps=b['n_steps'], z=o['z'], Wh=b['Wh'], c0=b['c0'], cs=o['cs'],
                            dhout=b['dhout'], dz=o['dz'], dh0=o['dh0'], dc0=o['dc0']))
+        K.set_lstm_persistent(False)     # the shared launches are per-step kernels: compare like with like
         if multi:
             K.lstm_seq_fwd_multi(fw)
             K.lstm_seq_bwd_multi(bw)
@@ -489,6 +558,7 @@ def test_lstm_multi_sequence_launch_equals_separate_calls(K):
                                f['hout'], f['cs'], None, None)
                 K.lstm_seq_bwd(b_['z'], 4 * U, M * 4 * U, M, U, b_['n_steps'], b_['Wh'], b_['c0'], None,
                                b_['cs'], b_['dhout'], None, None, b_['dz'], b_['dh0'], b_['dc0'])
+        K.set_lstm_persistent(True)
         results.append(outs)
     for a, b in zip(*results):
         for n in ('z', 'hout', 'cs', 'dz', 'dh0', 'dc0'):
