@@ -4,8 +4,10 @@
 The model is built with is_train=False (evaler.py:61): every batch norm normalises with the
 moving statistics of the checkpoint; per batch the teacher-forced and greedy decoders run on the
 GPU and the program metrics (syntax / exact program / execution accuracy, Karel) on the host.
-Checkpoints are this build's own .npz files (trainer.Trainer.save_checkpoint; TF checkpoints
-cannot be read offline).  `--pred_program` writes the reference's text listing
+Checkpoints are this build's own .npz files (trainer.Trainer.save_checkpoint) or TensorFlow V2
+checkpoint prefixes of the reference (`model-<step>` next to `model-<step>.index`, read by
+tf_checkpoint.py without TensorFlow -- format and variable names follow TF-1.3 conventions but no
+TensorFlow-written file was available to check them against).  `--pred_program` writes the reference's text listing
 (`[id: ..]\\ngt: ..\\npred: ..\\ngreedy: ..`) and, in place of its HDF5 file (h5py is not in this
 image), a .json with the same per-program fields; `--result_data` writes the reference's per-program
 groups (program, pred_program, pred_program_len, s_h, test_s_h) as '<id>/<field>' entries of an .npz.
@@ -51,9 +53,21 @@ class Evaler(object):
         self.global_step = 0
         self.checkpoint = getattr(config, 'checkpoint', '') or ''
         if self.checkpoint == '' and self.train_dir:
-            found = sorted(glob.glob(os.path.join(self.train_dir, 'model-*.npz')),
-                           key=lambda p: int(os.path.basename(p)[6:-4]))
-            self.checkpoint = found[-1] if found else ''
+            # evaler.py:96-99 takes tf.train.latest_checkpoint(train_dir): here the highest step among
+            # this build's model-<step>.npz and the reference's model-<step>.index files
+            found = []
+            for path in glob.glob(os.path.join(self.train_dir, 'model-*')):
+                base = os.path.basename(path)
+                for suffix in ('.npz', '.index'):
+                    if base.endswith(suffix) and base[6:-len(suffix)].isdigit():
+                        found.append((int(base[6:-len(suffix)]), suffix == '.npz',
+                                      path if suffix == '.npz' else path[:-len('.index')]))
+            self.checkpoint = max(found)[2] if found else ''
+            if not found:
+                # asked to evaluate a training directory that holds nothing: do not silently
+                # report the accuracy of a random initialisation
+                raise IOError('no model-<step>.npz / model-<step>.index checkpoint under --train_dir %s'
+                              % self.train_dir)
         if self.checkpoint == '':
             print('No checkpoint is given. Just random initialization :-)')
             self.checkpoint_name = 'random_init'
@@ -248,8 +262,8 @@ class Evaler(object):
 
 
 def build_arg_parser():
-    """The reference's flags and defaults (evaler.py:362-427); --synthetic is this build's stand-in
-    for the HDF5 dataset (generated Karel programs, karel_env/generator.py)."""
+    """The reference's flags and defaults (evaler.py:362-427).  Without an HDF5-derived dataset under
+    --dataset_path this build evaluates generated Karel programs (karel_env/generator.py)."""
     parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     parser.add_argument('--model', type=str, default='full',
                         choices=['synthesis_baseline', 'induction_baseline', 'summarizer', 'full'])
@@ -270,10 +284,9 @@ def build_arg_parser():
     parser.add_argument('--result_data', action='store_true', default=False)
     parser.add_argument('--result_data_path', type=str, default='result.hdf5')
     parser.add_argument('--id_list', type=str)
-    parser.add_argument('--unseen_test', action='store_true', default=False)
+    parser.add_argument('--unseen_test', action='store_true', default=False)    # unused by the reference too (evaler.py:415)
     parser.add_argument('--quiet', action='store_true', default=False)
     parser.add_argument('--no_write_summary', action='store_true', default=False)
-    parser.add_argument('--synthetic', action='store_true', default=True)
     return parser
 
 

@@ -306,9 +306,13 @@ def variable_names(config):
         names[ours + '/lstm/kernel'] = scope + '/dynamic_decoder/basic_lstm_cell/kernel'
         names[ours + '/lstm/bias'] = scope + '/dynamic_decoder/basic_lstm_cell/bias'
         names[ours + '/proj'] = scope + '/dynamic_decoder/output_projection/kernel'
-    names['per/fc/W'] = 'Per_Decoder/Per_Encoder/fc2/fully_connected/weights'
-    names['per/fc/b'] = 'Per_Decoder/Per_Encoder/fc2/fully_connected/biases'
-    bn('per/fc', 'Per_Decoder/Per_Encoder/fc2')
+    # Per_Encoder returns a closure; its fc is only created when the closure is CALLED, and that happens
+    # in get_DecoderHelper after the `with tf.variable_scope('Per_Encoder')` block has exited
+    # (models/model_full.py:308-316,412-414,455-456), i.e. directly under LSTM_Decoder's 'Per_Decoder'
+    # scope -- unlike Token_Embedding, whose embedding_map is created inside its own scope (:288-296)
+    names['per/fc/W'] = 'Per_Decoder/fc2/fully_connected/weights'
+    names['per/fc/b'] = 'Per_Decoder/fc2/fully_connected/biases'
+    bn('per/fc', 'Per_Decoder/fc2')
     return names
 
 

@@ -137,6 +137,7 @@ class Trainer(object):
         self.batch_test = self._batches(dataset_test, config, 321, False)
 
         self.global_step = 0
+        self.adam_step = 0          # steps the Adam moments have accumulated (beta powers of TF's Adam)
         Model = self.get_model_class(config.model)
         self.model = Model(config, debug_information=config.debug, global_step=self.global_step)
         self.dp.broadcast_params(self.model.params.flat)
@@ -188,12 +189,16 @@ class Trainer(object):
         self.dp.all_reduce_grads(P.grad)            # SUM over ranks; mean folded into prescale
         pre = self.dp.prescale
         K.l2norm_flat(P.grad, pre, self._sumsq)
-        t = self.global_step + 1
+        # bias correction from the number of steps the MOMENTS have seen, not from global_step: the
+        # two differ when parameters are loaded without optimizer state (zero moments, restarted
+        # beta powers -- TF's Adam keeps beta1_power / beta2_power next to its slots)
+        t = self.adam_step + 1
         lr = learning_rate_at(self.config, self.global_step)
         lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
         K.adam_clip_flat(P.flat, P.grad, P.m, P.v, self._sumsq, pre, CLIP_GRADIENTS, lr_t,
                          ADAM_B1, ADAM_B2, ADAM_EPS)
-        self.global_step = t
+        self.adam_step = t
+        self.global_step += 1
         return loss
 
     @staticmethod
@@ -264,14 +269,14 @@ class Trainer(object):
         return self.global_step, None, loss_value, None, (_end_time - _start_time)
 
     def run_test(self, batch):
-        """trainer.py:207-225: the training-mode graph on a test batch, no update."""
+        """trainer.py:207-225: the training-mode graph on a test batch, no parameter update
+        (SURVEY F7).  The batch-norm moving statistics DO move: the reference builds its layers with
+        a Python is_train=True and updates_collections=None (models/ops.py:20-23), so the moving-
+        average update is part of every forward of that graph, test batches included."""
         _start_time = time.time()
         batch_chunk = batch.next()
         feed = self.model.get_feed_dict(batch_chunk, is_training=False)
-        track = self.model.track_moving
-        self.model.track_moving = False
         loss = self.model.forward(feed)
-        self.model.track_moving = track
         loss_value = float(loss.item())
         # the 'test' summaries of the reference: greedy decoders + accuracies, and for Karel the
         # syntax / exact-program / execution metrics (models/model_full.py:1102-1177)
@@ -317,6 +322,7 @@ class Trainer(object):
             blob['moving_mean/' + n] = mm.cpu().numpy()
             blob['moving_var/' + n] = mv.cpu().numpy()
         blob['global_step'] = np.asarray(self.global_step)
+        blob['adam_step'] = np.asarray(self.adam_step)
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
         np.savez(path, **blob)
 
@@ -326,12 +332,15 @@ class Trainer(object):
         pretrain_saver restores trainable variables (trainer.py:115,142-147)."""
         from . import tf_checkpoint
         if tf_checkpoint.is_tf_checkpoint(path):
-            self.global_step = tf_checkpoint.import_checkpoint(path, self.model)
+            # like the reference's pretrain_saver (trainer.py:100,115): trainable variables only --
+            # global_step, the learning-rate / sampling schedules and Adam all restart at 0
+            tf_checkpoint.import_checkpoint(path, self.model)
             return
         z = np.load(path)
         P = self.model.params
         P.load({n: z['p/' + n] for n in P.shapes})
-        if 'm/' + next(iter(P.shapes)) in z:
+        has_moments = 'm/' + next(iter(P.shapes)) in z
+        if has_moments:
             for which, buf in (('m', P.m), ('v', P.v)):
                 host = np.zeros(P.size, np.float32)
                 for n in P.shapes:
@@ -342,8 +351,10 @@ class Trainer(object):
             if 'moving_mean/' + n in z:
                 self.model.moving[n][0].copy_(torch.from_numpy(z['moving_mean/' + n]))
                 self.model.moving[n][1].copy_(torch.from_numpy(z['moving_var/' + n]))
-        if 'global_step' in z:
+        if has_moments and 'global_step' in z:
+            # a full resume of this build's own checkpoint; a parameters-only file restarts the schedules
             self.global_step = int(z['global_step'])
+            self.adam_step = int(z['adam_step']) if 'adam_step' in z else self.global_step
 
 
 def build_arg_parser():

@@ -14,7 +14,15 @@
  *  - plain pointers and sizes only; all pointers are DEVICE pointers unless noted;
  *    fp32 / int32, contiguous unless a stride argument says otherwise;
  *  - the caller owns every buffer, including scratch (`ws`); the library allocates
- *    nothing and keeps no global mutable state except a thread-local error string;
+ *    nothing.  Compute entry points keep no state between calls; the only mutable
+ *    globals are (a) the thread-local error string, (b) the process-global TUNING /
+ *    DEBUGGING switches marked as such below (d2p_gemm_set_option, d2p_conv_set_direct,
+ *    d2p_lstm_set_fused / _set_persistent / _set_tiling / _debug_flags /
+ *    _persist_set_trace / _persist_set_wgs_per_cu, d2p_prof_*): they select between
+ *    implementations that return the same results (or, for the debug ones, instrument
+ *    a launch), are not thread-safe against concurrent compute calls, and are meant to
+ *    be set once at start-up or by benchmarking tools; and (c) one device-side status
+ *    word of the persistent LSTM kernels (d2p_lstm_persist_error);
  *  - every call is asynchronous on `stream` (a hipStream_t passed as void*), performs
  *    no device synchronisation, and is hipGraph-capturable;
  *  - return 0 on success, a negative D2P_E* code for argument errors, or a positive

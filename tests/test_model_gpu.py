@@ -739,6 +739,66 @@ def test_headline_config_properties():
     assert model.pred_program[:, :, n:].abs().max().item() == 0 if n < cfg.max_program_len else True
 
 
+def test_vizdoom_80x80_frames_match_oracle():
+    """BASELINE config 4's frame geometry (80x80x3, five conv layers: the row-strip kernels of
+    conv_rows.hip for conv1 / conv2, the direct and implicit-GEMM back ends for the rest) through
+    Model.forward / backward against the oracle, at a batch the fp64 oracle finishes in seconds."""
+    cfg, params, batch = small_case('vizdoom', seed=51, h=80, w=80, batch_size=2, k=2, max_demo_len=3,
+                                    max_program_len=6)
+    out, grads = run_oracle(cfg, params, batch)
+    _check_against_oracle(cfg, params, batch, out, grads)
+
+
+def test_k25_demonstrations_match_oracle():
+    """BASELINE config 5's k = 25: 25 batch-norm groups per layer, 625 relation-network pairs per
+    program, 25 action / perception decoders -- against the oracle's per-demonstration loops."""
+    cfg, params, batch = small_case('vizdoom', seed=52, k=25, batch_size=2, max_demo_len=4, max_program_len=6)
+    out, grads = run_oracle(cfg, params, batch)
+    _check_against_oracle(cfg, params, batch, out, grads)
+
+
+@pytest.mark.parametrize('preset', ['vizdoom', 'vizdoom_k25'])
+def test_vizdoom_full_size_properties(preset):
+    """BASELINE configs 4 (80x80x3, B=32, k=10) and 5 per rank (k=25, B=16) at their full workload:
+    size-independent properties as for the headline config -- finite loss near the uniform-prediction
+    value, bitwise determinism of loss and gradient across two runs, loss terms summing to the total,
+    zero-padded logits past the batch's longest program, and one optimizer step that lowers the loss
+    on the same batch."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.synthetic import make_batch
+    from demo2program_amd.trainer import Trainer
+    cfg = make_config(preset)
+    batch = make_batch(cfg, seed=77)
+    tr = Trainer(cfg, make_train_dir=False)
+    model = tr.model
+    feed = model.get_feed_dict(batch)
+    l1 = float(model.forward(feed).item())
+    model.backward()
+    g1 = model.params.grad.clone()
+    l2 = float(model.forward(feed).item())
+    model.backward()
+    assert l1 == l2 and torch.equal(g1, model.params.grad)
+    uniform = math.log(cfg.dim_program_token) + math.log(cfg.action_space) + math.log(2)
+    assert abs(l1 - uniform) < 0.6, (l1, uniform)
+    t = model.report_loss
+    assert abs(sum(float(t[n].item()) for n in ('program_loss', 'avg_action_loss', 'avg_per_loss')) - l1) < 1e-5
+    assert torch.isfinite(g1).all() and float(g1.norm()) > 0
+    n = feed['n_prog']
+    if n < cfg.max_program_len:
+        assert model.pred_program[:, :, n:].abs().max().item() == 0
+    assert K_persist_ok()
+    for _ in range(3):
+        tr.train_step(feed)
+    l3 = float(model.forward(feed).item())
+    assert l3 < l1, (l3, l1)
+
+
+def K_persist_ok():
+    from demo2program_amd import kernels as K
+    return K.lstm_persist_error() == 0
+
+
 def test_rccl_single_rank_self_test(monkeypatch):
     """the exchange step's RCCL calls (broadcast of the flat parameters,
     all-reduce of the flat gradient, the bench's MAX reduce and barrier) on a one-rank process
@@ -791,7 +851,9 @@ def test_tf_checkpoint_export_import_round_trip(tmp_path):
     assert 'Demo_Encoder/State_Encoder/conv1/Conv/weights' in written and 'global_step' in written
     tr = Trainer(cfg, make_train_dir=False)
     tr.load_checkpoint(prefix)
-    assert tr.global_step == 77
+    # like the reference's pretrain_saver (trainer.py:100,115): trainable variables only -- global_step,
+    # the schedules and Adam's beta powers restart
+    assert tr.global_step == 0 and tr.adam_step == 0
     a, b = m.params.to_numpy('p'), tr.model.params.to_numpy('p')
     for n in a:
         assert np.array_equal(a[n], b[n]), n
@@ -805,3 +867,67 @@ def test_tf_checkpoint_export_import_round_trip(tmp_path):
         tf_checkpoint.import_checkpoint(str(tmp_path / 'odd'), tr.model)
     tf_checkpoint.import_checkpoint(str(tmp_path / 'odd'), tr.model,
                                     name_map={'conv1/W': 'Demo_Encoder/State_Encoder/conv1/Conv/kernel'})
+
+
+def test_parameters_only_checkpoint_restarts_adam_and_schedules(tmp_path):
+    """loading parameters without optimizer state (a TF checkpoint of the reference, or an
+    .npz without moments) must not apply a late-step bias correction to zero moments: the first update
+    after such a load equals the first update of a fresh optimizer on the same parameters, and a full
+    .npz resume continues the step counters."""
+    from demo2program_amd.trainer import Trainer
+    cfg, params, batch = small_case('karel', seed=43)
+    tr = Trainer(cfg, make_train_dir=False)
+    tr.model.params.load(params)
+    feed = tr.model.get_feed_dict(batch)
+    for _ in range(3):
+        tr.train_step(feed)
+    full = str(tmp_path / 'model-3.npz')
+    tr.save_checkpoint(full)
+    # parameters-only file
+    z = dict(np.load(full))
+    bare = str(tmp_path / 'bare.npz')
+    np.savez(bare, **{k: v for k, v in z.items() if k.startswith('p/') or k.startswith('moving_')})
+    a = Trainer(cfg, make_train_dir=False)
+    a.load_checkpoint(bare)
+    assert a.global_step == 0 and a.adam_step == 0
+    b = Trainer(cfg, make_train_dir=False)          # fresh optimizer on the same parameters / statistics
+    b.load_checkpoint(bare)
+    b.global_step, b.adam_step = 0, 0
+    a.train_step(a.model.get_feed_dict(batch))
+    b.train_step(b.model.get_feed_dict(batch))
+    pa, pb = a.model.params.to_numpy('p'), b.model.params.to_numpy('p')
+    for n in pa:
+        assert np.array_equal(pa[n], pb[n]), n
+    # the step size of that first update is the learning rate (Adam's first step), not several times it
+    before = {k[2:]: v for k, v in z.items() if k.startswith('p/')}
+    step = max(np.abs(pa[n] - before[n]).max() for n in pa)
+    assert step <= 1.001 * cfg.learning_rate, step
+    # full resume keeps both counters
+    c = Trainer(cfg, make_train_dir=False)
+    c.load_checkpoint(full)
+    assert c.global_step == 3 and c.adam_step == 3
+
+
+def test_run_test_moves_the_batch_norm_moving_statistics():
+    """models/ops.py:20-23 (updates_collections=None, Python is_train=True): the moving-average update
+    is part of every forward of the training graph, so the reference's run_test (trainer.py:207-225)
+    moves the statistics without touching the parameters."""
+    from demo2program_amd.trainer import Trainer
+
+    class One(object):
+        def __init__(self, b):
+            self.b = b
+
+        def next(self):
+            return self.b
+    cfg, params, batch = small_case('karel', seed=44)
+    tr = Trainer(cfg, make_train_dir=False)
+    tr.model.params.load(params)
+    p0 = tr.model.params.to_numpy('p')
+    mv0 = {n: (a.clone(), b.clone()) for n, (a, b) in tr.model.moving.items()}
+    tr.run_test(One(batch))
+    p1 = tr.model.params.to_numpy('p')
+    for n in p0:
+        assert np.array_equal(p0[n], p1[n]), n
+    moved = [n for n, (a, b) in tr.model.moving.items() if not torch.equal(a, mv0[n][0]) or not torch.equal(b, mv0[n][1])]
+    assert set(moved) == set(tr.model.moving), (moved, list(tr.model.moving))

@@ -90,5 +90,40 @@ def test_variable_name_table_covers_every_parameter(preset):
     assert names['conv1/W'] == 'Demo_Encoder/State_Encoder/conv1/Conv/weights'
     assert names['rn_c/fc2/gamma'] == 'demo_c_summary/rn_pool/fc2/bn_act/BatchNorm/gamma'
     assert names['prog/proj'] == 'Program_Decoder/dynamic_decoder/output_projection/kernel'
-    assert names['moving_var/per/fc'] == 'Per_Decoder/Per_Encoder/fc2/bn_act/BatchNorm/moving_variance'
+    assert names['moving_var/per/fc'] == 'Per_Decoder/fc2/bn_act/BatchNorm/moving_variance'
     assert ('conv5/W' in names) == (preset == 'vizdoom')
+
+
+# Variables of the reference's Karel full model, derived by hand by walking the variable scopes of
+# /root/reference/models/model_full.py (and models/ops.py for the layer helpers), NOT from the table under
+# test: State_Encoder (:216-231) inside Demo_Encoder (:235-258); tf.nn.dynamic_rnn's default scope 'rnn' +
+# BasicLSTMCell's 'basic_lstm_cell' (TF 1.3 names its variables kernel / bias); SecondPathEncoder called
+# with scope='SecondPathEncoder' (:395); rn_pool (:333-349) inside SummarizeFeature scopes demo_h_summary /
+# demo_c_summary (:399-404) -- the avgpool summaries (:380-385) own no variables; LSTM_Decoder (:444-471)
+# under 'Program_Decoder' / 'Action_Decoder' / 'Per_Decoder' (:508-592) with Token_Embedding's
+# embedding_map created INSIDE its scope (:283-296), the decoder cell and Dense(name='output_projection')
+# inside dynamic_decode(scope='dynamic_decoder'), and Per_Encoder's fc2 created when its closure is
+# called from get_DecoderHelper, after the 'Per_Encoder' scope has been left (:308-316,412-414).
+# slim.conv2d -> 'Conv/{weights,biases}', slim.fully_connected -> 'fully_connected/{weights,biases}',
+# contrib.layers.batch_norm under bn_act -> 'bn_act/BatchNorm/{beta,gamma,moving_mean,moving_variance}'.
+REFERENCE_KAREL_VARIABLES = sorted(
+    ['Demo_Encoder/State_Encoder/conv%d/Conv/%s' % (l, w) for l in (1, 2, 3) for w in ('weights', 'biases')] +
+    ['Demo_Encoder/State_Encoder/conv%d/bn_act/BatchNorm/%s' % (l, w) for l in (1, 2, 3)
+     for w in ('beta', 'gamma', 'moving_mean', 'moving_variance')] +
+    ['%s/rnn/basic_lstm_cell/%s' % (s, w) for s in ('Demo_Encoder', 'SecondPathEncoder') for w in ('kernel', 'bias')] +
+    ['%s/rn_pool/%s/fully_connected/%s' % (s, f, w) for s in ('demo_h_summary', 'demo_c_summary')
+     for f in ('fc1', 'fc2') for w in ('weights', 'biases')] +
+    ['%s/rn_pool/%s/bn_act/BatchNorm/%s' % (s, f, w) for s in ('demo_h_summary', 'demo_c_summary')
+     for f in ('fc1', 'fc2') for w in ('beta', 'gamma', 'moving_mean', 'moving_variance')] +
+    ['%s/Token_Embedding/embedding_map' % s for s in ('Program_Decoder', 'Action_Decoder')] +
+    ['%s/dynamic_decoder/%s' % (s, w) for s in ('Program_Decoder', 'Action_Decoder', 'Per_Decoder')
+     for w in ('basic_lstm_cell/kernel', 'basic_lstm_cell/bias', 'output_projection/kernel')] +
+    ['Per_Decoder/fc2/fully_connected/%s' % w for w in ('weights', 'biases')] +
+    ['Per_Decoder/fc2/bn_act/BatchNorm/%s' % w for w in ('beta', 'gamma', 'moving_mean', 'moving_variance')])
+
+
+def test_variable_name_table_equals_the_scope_walk_of_the_reference():
+    """an export/import round trip cannot catch a wrong name (both sides use the table)."""
+    names = T.variable_names(make_config('karel'))
+    assert sorted(names.values()) == REFERENCE_KAREL_VARIABLES
+    assert len(REFERENCE_KAREL_VARIABLES) == 6 + 12 + 4 + 8 + 16 + 2 + 9 + 2 + 4
