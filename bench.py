@@ -13,10 +13,18 @@ L=50, batch 32 programs per GPU.  value = programs (instances) per second over t
 job; an instance = one program with its k demonstrations (trainer.py:238).
 
 Besides the contract fields the JSON line carries
-  roofline     -- the dominant kernel family of the step, timed live with HIP events on the
-                  launch stream in an instrumented pass right after the timed region
+  roofline     -- the kernel family with the largest summed device time of the step (forward and
+                  backward recurrent kernels count as ONE family, like all GEMM instantiations do),
+                  timed live with HIP events on the launch stream in an instrumented pass right
+                  after the timed region; `furthest_below_roofline` names the family (>= 3 % of
+                  the step) with the lowest fraction of its roofline; `kernel_table` lists all
+  value_incl_h2d_prefetched -- the same step loop fed from HOST batches through the trainer's
+                  prefetcher (the reference's step time spans fetch + feed + run, trainer.py:187-205)
+  config4_vizdoom -- BASELINE config 4 (80x80x3 frames) timed in the same run: ms/step and the conv
+                  encoder's fraction of the fp32 MFMA peak (N = 1 only)
   cpu_baseline -- the CPU oracle (torch-CPU restatement, NOT TF1) timed on this box's host
-                  cores on the same batch (rank 0, N=1 only).
+                  cores on the same batch (rank 0, N=1 only): forward + backward WITHOUT the
+                  optimizer, on <= 16 threads.
 """
 import argparse
 import ctypes
@@ -33,20 +41,31 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-PEAK_HBM_GBS = 8000.0          # HBM3E spec (6290 GB/s measured copy)
+PEAK_HBM_GBS = 8000.0          # HBM3E spec
+MEASURED_HBM_GBS = 6290.0      # MI355X_MICROARCH.md: float4 copy, 79 % of spec
+EMPTY_LAUNCH_US = 2.7          # a dependent empty launch on one stream
 
 # kernel family -> key in profiles/*_pmc_traffic.json (tools/pmc_summary.py)
-PMC_KEYS = {1: 'gemm_mfma_kernel', 2: 'gemm_mfma_kernel<conv>', 7: 'lstm_step_fwd_kernel',
-            8: 'lstm_step_bwd_kernel', 3: 'lstm_gate_fwd_kernel', 4: 'lstm_gate_bwd_kernel'}
-PMC_FILE = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+PMC_KEYS = {1: 'gemm_mfma_kernel', 2: 'gemm_mfma_kernel<conv>', 7: 'lstm_persist_fwd_kernel',
+            8: 'lstm_persist_bwd_kernel', 3: 'lstm_gate_fwd_kernel', 4: 'lstm_gate_bwd_kernel'}
+PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')]
 
+# profiling key (include/d2p.h) -> (name, roofline that bounds it, reporting group)
 PROF_FAMILIES = {
-    1: ('gemm_mfma_kernel (dense fp32 MFMA GEMM)', 'mfma'),
-    2: ('conv kernels (whole-frame / direct 16x16x4 MFMA, implicit-GEMM fallback)', 'mfma'),
-    3: ('lstm_gate_fwd_kernel', 'hbm'),
-    4: ('lstm_gate_bwd_kernel', 'hbm'),
-    7: ('lstm_step_fwd_kernel (fused recurrent GEMM + gates)', 'mfma'),
-    8: ('lstm_step_bwd_kernel (fused recurrent GEMM + gate backward)', 'mfma'),
+    1: ('gemm_mfma_kernel (dense fp32 MFMA GEMM, all instantiations)', 'mfma', 'gemm'),
+    2: ('conv kernels (whole-frame / direct 16x16x4 MFMA / row-strip, implicit-GEMM fallback)', 'mfma', 'conv'),
+    3: ('lstm_gate_fwd_kernel', 'hbm', 'gate'),
+    4: ('lstm_gate_bwd_kernel', 'hbm', 'gate'),
+    7: ('recurrent forward (lstm_persist_fwd_kernel: one launch per sequence; lstm_step_fwd_kernel per step '
+        'for shapes it does not take)', 'mfma', 'recurrent'),
+    8: ('recurrent backward (lstm_persist_bwd_kernel / lstm_step_bwd_kernel)', 'mfma', 'recurrent'),
+}
+GROUP_NAMES = {
+    'gemm': 'gemm_mfma_kernel (dense fp32 MFMA GEMM, all instantiations)',
+    'conv': 'conv kernels (forward + dgrad + wgrad of every encoder layer)',
+    'recurrent': 'recurrent LSTM kernels, forward + backward (lstm_persist_fwd_kernel + lstm_persist_bwd_kernel: '
+                 'h.Wh / dz.Wh^T fp32 MFMA + gate math for all time steps of a sequence in one launch)',
+    'gate': 'standalone LSTM gate kernels',
 }
 
 
@@ -54,110 +73,227 @@ def pmc_traffic(family):
     """HBM bytes per launch of this kernel family from the committed PMC passes of this same
     command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs, FETCH_SIZE doubled per the
     gfx950 correction; tools/profile_pmc.sh + tools/pmc_summary.py).  None if not collected."""
-    try:
-        d = json.load(open(PMC_FILE))
-        return round(d[PMC_KEYS[family]]['hbm_bytes_per_launch'], 1)
-    except (OSError, KeyError, ValueError):
-        return None
+    for path in PMC_FILES:
+        try:
+            d = json.load(open(path))
+            return round(d[PMC_KEYS[family]]['hbm_bytes_per_launch'], 1)
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
+
+
+def _rate(work, ms, bound):
+    return work / (ms / 1e3) / (1e12 if bound == 'mfma' else 1e9)
 
 
 def roofline_leg(trainer, feeds, steps=2):
-    """Re-runs `steps` training steps with per-launch HIP events enabled inside the library
-    and reports the family/tag with the largest summed device time."""
+    """Re-runs `steps` training steps with per-launch HIP events enabled inside the library (events on
+    the launch stream, eager launches on ONE stream so a bracket times that kernel alone).  Families
+    are grouped before ranking: all GEMM instantiations are one family, and so are the forward and
+    backward recurrent kernels.  -> (roofline of the group with the largest summed time,
+    the group furthest below its roofline, per-family table)."""
     from demo2program_amd.lib import load
     lib = load()
     torch.cuda.synchronize()
     lib.d2p_prof_enable(1)
     lib._d2p_prof_on = True          # Trainer.train_step takes the eager (un-graphed) path
-    # one stream, so that a launch's event bracket measures that kernel alone (in the timed
-    # region independent GEMMs overlap the recurrent step kernels on a side stream)
     side = trainer.model.use_side_stream
     trainer.model.use_side_stream = False
     for i in range(steps):
         trainer.train_step(feeds[i % len(feeds)])
     torch.cuda.synchronize()
     rows = []
-    for fam, (name, bound) in PROF_FAMILIES.items():
+    for fam, (name, bound, group) in PROF_FAMILIES.items():
         for tag in (0, 1):
             cnt, ms, work = ctypes.c_int(0), ctypes.c_double(0), ctypes.c_double(0)
             lib.d2p_prof_read(fam * 8 + tag, ctypes.byref(cnt), ctypes.byref(ms), ctypes.byref(work))
             if cnt.value:
-                rows.append(dict(family=fam, tag=tag, name=name, bound=bound, launches=cnt.value,
+                rows.append(dict(family=fam, tag=tag, name=name, bound=bound, group=group, launches=cnt.value,
                                  total_ms=ms.value, work=work.value))
     lib.d2p_prof_enable(0)
     lib._d2p_prof_on = False
     trainer.model.use_side_stream = side
     if not rows:
-        return None, []
+        return None, None, []
+    total_ms = sum(r['total_ms'] for r in rows)
+    groups = {}
+    for r in rows:
+        g = groups.setdefault(r['group'], dict(group=r['group'], bound=r['bound'], launches=0, total_ms=0.0,
+                                               work=0.0, families=[]))
+        g['launches'] += r['launches']
+        g['total_ms'] += r['total_ms']
+        g['work'] += r['work']
+        g['families'].append(r)
+
+    def describe(g):
+        peak = PEAK_F32_MFMA_TFLOPS if g['bound'] == 'mfma' else PEAK_HBM_GBS
+        achieved = _rate(g['work'], g['total_ms'], g['bound'])
+        traffic = [pmc_traffic(r['family']) for r in g['families']]
+        d = {'kernel': GROUP_NAMES[g['group']], 'bound': g['bound'], 'achieved': round(achieved, 3), 'peak': peak,
+             'unit': 'TFLOP/s' if g['bound'] == 'mfma' else 'GB/s', 'frac': round(achieved / peak, 4),
+             'traffic': traffic[0] if len(traffic) == 1 else (None if any(t is None for t in traffic) else
+                                                              round(sum(t * r['launches'] for t, r in zip(traffic, g['families'])) / g['launches'], 1)),
+             'launches_per_step': g['launches'] / steps,
+             'avg_launch_us': round(g['total_ms'] * 1e3 / g['launches'], 3),
+             'work_per_launch': g['work'] / g['launches'],
+             'ms_per_step': round(g['total_ms'] / steps, 4),
+             'share_of_instrumented_ms': round(g['total_ms'] / total_ms, 3)}
+        if g['group'] == 'recurrent':
+            cfgm = trainer.config
+            flop_step = 2.0 * cfgm.batch_size * cfgm.k * 4 * cfgm.num_lstm_cell_units ** 2
+            d['parts'] = [{'kernel': r['name'], 'launches_per_step': r['launches'] / steps,
+                           'ms_per_step': round(r['total_ms'] / steps, 4),
+                           'achieved': round(_rate(r['work'], r['total_ms'], 'mfma'), 2),
+                           'frac': round(_rate(r['work'], r['total_ms'], 'mfma') / PEAK_F32_MFMA_TFLOPS, 4),
+                           # every sequence of the step priced per time step of a B*k-row recurrence
+                           'us_per_%d_row_time_step' % (cfgm.batch_size * cfgm.k):
+                               round(r['total_ms'] * 1e3 / (r['work'] / flop_step), 3)} for r in g['families']]
+        return d
+    ranked = sorted(groups.values(), key=lambda g: -g['total_ms'])
+    roof = describe(ranked[0])
+    sizeable = [g for g in ranked if g['total_ms'] >= 0.03 * total_ms]
+    worst = min(sizeable, key=lambda g: _rate(g['work'], g['total_ms'], g['bound']) /
+                (PEAK_F32_MFMA_TFLOPS if g['bound'] == 'mfma' else PEAK_HBM_GBS))
+    furthest = describe(worst)
     rows.sort(key=lambda r: -r['total_ms'])
-    top = rows[0]
-    sec = top['total_ms'] / 1e3
-    if top['bound'] == 'mfma':
-        achieved, peak, unit = top['work'] / sec / 1e12, PEAK_F32_MFMA_TFLOPS, 'TFLOP/s'
-    else:
-        achieved, peak, unit = top['work'] / sec / 1e9, PEAK_HBM_GBS, 'GB/s'
-    roof = {
-        'kernel': top['name'] + (' [inside the recurrence]' if top['tag'] == 1 else ''),
-        'bound': top['bound'], 'achieved': round(achieved, 3), 'peak': peak, 'unit': unit,
-        'frac': round(achieved / peak, 4), 'traffic': pmc_traffic(top['family']),
-        'launches_per_step': top['launches'] / steps,
-        'avg_launch_us': round(top['total_ms'] * 1e3 / top['launches'], 3),
-        'work_per_launch': top['work'] / top['launches'],
-        'share_of_instrumented_ms': round(top['total_ms'] / sum(r['total_ms'] for r in rows), 3),
-    }
-    table = [dict(kernel=r['name'], tag=r['tag'], launches_per_step=r['launches'] / steps,
+    table = [dict(kernel=r['name'], group=r['group'], tag=r['tag'], launches_per_step=r['launches'] / steps,
                   ms_per_step=round(r['total_ms'] / steps, 4),
-                  rate=round(r['work'] / (r['total_ms'] / 1e3) / (1e12 if r['bound'] == 'mfma' else 1e9), 2),
+                  rate=round(_rate(r['work'], r['total_ms'], r['bound']), 2),
                   unit='TFLOP/s' if r['bound'] == 'mfma' else 'GB/s') for r in rows]
-    return roof, table
+    return roof, furthest, table
+
+
+def conv_binding_roofline(config, measured_ms, launches):
+    """What bounds the conv encoder at this size (hard part 4): per layer and pass the
+    larger of its MFMA time at peak and its HBM time at the measured copy rate, and under all of it a
+    floor of one dependent launch per kernel.  -> the bound and measured / bound."""
+    from demo2program_amd.config import conv_shapes
+    n = config.batch_size * config.k * config.max_demo_len
+    t_mfma = t_hbm = flops = 0.0
+    for l, (h, w, cin, cout, ho, wo) in enumerate(conv_shapes(config)):
+        f = 2.0 * n * ho * wo * 9 * cin * cout
+        x_bytes = n * h * w * cin * (1.0 if l == 0 else 4.0)          # uint8 frames, fp32 activations
+        y_bytes = n * ho * wo * cout * 4.0
+        passes = [(f, x_bytes + y_bytes), (f, x_bytes + y_bytes)]     # forward, weight gradient
+        if l > 0:
+            passes.append((f, x_bytes + y_bytes))                     # input gradient
+        for pf, pb in passes:
+            flops += pf
+            t_mfma += pf / (PEAK_F32_MFMA_TFLOPS * 1e12)
+            t_hbm += pb / (MEASURED_HBM_GBS * 1e9)
+    t_floor = launches * EMPTY_LAUNCH_US * 1e-6
+    per_pass = max(t_mfma, t_hbm)
+    bound = max(per_pass, t_floor)
+    return {'flops_per_step': flops, 'mfma_ms_at_peak': round(t_mfma * 1e3, 4),
+            'hbm_ms_at_%d_GBs' % MEASURED_HBM_GBS: round(t_hbm * 1e3, 4),
+            'launch_floor_ms': round(t_floor * 1e3, 4), 'binding': 'launch floor' if bound == t_floor else
+            ('hbm' if t_hbm > t_mfma else 'mfma'), 'bound_ms': round(bound * 1e3, 4),
+            'measured_ms': round(measured_ms, 4), 'frac_of_binding_roofline': round(bound * 1e3 / measured_ms, 4)}
 
 
 def north_star_targets(config, table):
     """The two kernel-level targets BASELINE.json's north_star names, measured live:
     (1) the conv encoder's fraction of the fp32 MFMA peak (conv family of the instrumented pass:
-        forward + dgrad + wgrad of every layer, 2*M*K*N flops each);
+        forward + dgrad + wgrad of every layer, 2*M*K*N flops each), and next to it the roofline that
+        actually binds at this size (MFMA, HBM or the launch floor);
     (2) the LSTM gate kernel's fraction of the HBM roofline (14 336 B/row forward,
-        26 624 B/row backward at U=512), on the rows of one training step applied in one launch
-        (B*k*T rows) and, for reference, at the per-time-step granularity (B*k rows), where a
-        4.6 MB launch is latency-bound.  In the shipped path the gate math is the epilogue of
-        the fused recurrent step kernels; these standalone kernels are the d2p_lstm_gate_* ABI
-        entry points (and the unfused d2p_lstm_set_fused(0) path)."""
+        26 624 B/row backward at U=512).  A STANDALONE MICRO-BENCHMARK: in the product path the gate math is
+        the epilogue of the recurrent kernels and these d2p_lstm_gate_* kernels are never launched.
+        Measured over a ROTATING working set of > 600 MB (fresh buffers every launch: the 256 MiB
+        Infinity Cache cannot serve it), at 32 000 rows per launch and at the rows of one training
+        step (B*k*T), against both the 8.0 TB/s spec and the 6.29 TB/s this chip sustains on a copy;
+        and at the per-time-step granularity (B*k rows), where a 4.6 MB launch is launch-latency."""
     from demo2program_amd import kernels as K
     out = {}
-    conv = [r for r in table if r['kernel'].startswith('conv kernels')]
+    conv = [r for r in table if r['group'] == 'conv']
     if conv:
         out['conv_encoder'] = {'achieved': conv[0]['rate'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(conv[0]['rate'] / PEAK_F32_MFMA_TFLOPS, 4),
                                'ms_per_step': conv[0]['ms_per_step'],
-                               'launches_per_step': conv[0]['launches_per_step']}
+                               'launches_per_step': conv[0]['launches_per_step'],
+                               'binding_roofline': conv_binding_roofline(config, conv[0]['ms_per_step'],
+                                                                         conv[0]['launches_per_step'])}
     U = config.num_lstm_cell_units
     M = config.batch_size * config.k
-    gate = {}
-    for label, rows in (('rows_per_step_batched', M * config.max_demo_len), ('rows_per_time_step', M)):
-        z = torch.randn(rows, 4 * U, device='cuda')
-        c_prev = torch.randn(rows, U, device='cuda')
-        c_out, h_out = torch.empty(rows, U, device='cuda'), torch.empty(rows, U, device='cuda')
-        dh, dc = torch.randn(rows, U, device='cuda'), torch.randn(rows, U, device='cuda')
-        dz = torch.empty(rows, 4 * U, device='cuda')
-        res = {'rows': rows}
-        for name, fn, nbytes in (
-                ('fwd', lambda: K.lstm_gate_fwd(z, c_prev, None, None, 0, c_out, None, h_out), rows * 7 * U * 4.0),
-                ('bwd', lambda: K.lstm_gate_bwd(z, c_prev, c_out, dh, None, None, 0, dc, dz, None), rows * 13 * U * 4.0)):
-            for _ in range(3):
-                fn()
+    gate = {'note': 'standalone micro-benchmark of d2p_lstm_gate_fwd/_bwd; the training step never launches them '
+                    '(gate math = epilogue of the recurrent kernels)'}
+    for label, rows in (('rows_32000', 32000), ('rows_per_step_batched', M * config.max_demo_len),
+                        ('rows_per_time_step', M)):
+        per_set = rows * (4 * U + U + U + U + U + U + 4 * U) * 4.0       # bytes of one buffer set
+        nset = max(2, int(640e6 / per_set) + 1)
+        sets = []
+        for _ in range(nset):
+            sets.append(dict(z=torch.randn(rows, 4 * U, device='cuda'), c_prev=torch.randn(rows, U, device='cuda'),
+                             c_out=torch.empty(rows, U, device='cuda'), h_out=torch.empty(rows, U, device='cuda'),
+                             dh=torch.randn(rows, U, device='cuda'), dc=torch.randn(rows, U, device='cuda'),
+                             dz=torch.empty(rows, 4 * U, device='cuda')))
+        res = {'rows': rows, 'working_set_MB': round(nset * per_set / 1e6, 1)}
+
+        def fwd(b):
+            K.lstm_gate_fwd(b['z'], b['c_prev'], None, None, 0, b['c_out'], None, b['h_out'])
+
+        def bwd(b):
+            K.lstm_gate_bwd(b['z'], b['c_prev'], b['c_out'], b['dh'], None, None, 0, b['dc'], b['dz'], None)
+        for name, fn, nbytes in (('fwd', fwd, rows * 7 * U * 4.0), ('bwd', bwd, rows * 13 * U * 4.0)):
+            for b in sets[:3]:
+                fn(b)
+            reps = max(30, 2 * nset)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
-            for _ in range(50):
-                fn()
+            for i in range(reps):
+                fn(sets[i % nset])
             e1.record()
             torch.cuda.synchronize()
-            t = e0.elapsed_time(e1) * 1e-3 / 50
-            res[name] = {'us': round(t * 1e6, 2), 'achieved': round(nbytes / t / 1e9, 1), 'peak': PEAK_HBM_GBS,
-                         'unit': 'GB/s', 'frac': round(nbytes / t / 1e9 / PEAK_HBM_GBS, 4)}
+            t = e0.elapsed_time(e1) * 1e-3 / reps
+            gbs = nbytes / t / 1e9
+            res[name] = {'us': round(t * 1e6, 2), 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                         'frac': round(gbs / PEAK_HBM_GBS, 4),
+                         'frac_of_measured_copy_rate': round(gbs / MEASURED_HBM_GBS, 4)}
         gate[label] = res
+        del sets
+        torch.cuda.empty_cache()
     out['lstm_gate_kernel'] = gate
     return out
+
+
+def config4_leg(steps=10, warmup=3):
+    """BASELINE config 4 (ViZDoom full model, k=10, 80x80x3 frames, B=32) in the same run: ms/step of the
+    same optimizer step, inputs resident in HBM, and the conv encoder's fraction of the fp32 MFMA peak
+    from an instrumented pass."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.synthetic import make_batch
+    from demo2program_amd.trainer import Trainer
+    cfg = make_config('vizdoom')
+    tr = Trainer(cfg, make_train_dir=False)
+    batches = [make_batch(cfg, seed=321 + i) for i in range(2)]
+    for b in batches:
+        b['s_h'] = b['s_h'].astype(np.uint8)
+    feeds = [tr.model.get_feed_dict(b) for b in batches]
+    for i in range(warmup):
+        tr.train_step(feeds[i % 2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        tr.train_step(feeds[i % 2])
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    res = {'workload': 'vizdoom full model, k=%d, %dx%dx%d uint8 frames, T=%d, batch=%d, inputs resident in HBM'
+                       % (cfg.k, cfg.h, cfg.w, cfg.depth, cfg.max_demo_len, cfg.batch_size),
+           'steps': steps, 'ms_per_step': round(dt * 1e3, 4), 'value': round(cfg.batch_size / dt, 2),
+           'unit': 'instances/s'}
+    _, _, table = roofline_leg(tr, feeds)
+    conv = [r for r in table if r['group'] == 'conv']
+    if conv:
+        res['conv_encoder'] = {'achieved': conv[0]['rate'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(conv[0]['rate'] / PEAK_F32_MFMA_TFLOPS, 4),
+                               'ms_per_step': conv[0]['ms_per_step'], 'launches_per_step': conv[0]['launches_per_step'],
+                               'binding_roofline': conv_binding_roofline(cfg, conv[0]['ms_per_step'],
+                                                                         conv[0]['launches_per_step'])}
+    res['kernel_table'] = table
+    del tr
+    torch.cuda.empty_cache()
+    return res
 
 
 def cpu_baseline_leg(config, batch, params, steps=2):
@@ -189,7 +325,9 @@ def cpu_baseline_leg(config, batch, params, steps=2):
     except OSError:
         pass
     return {'value': round(config.batch_size / dt, 3), 'unit': 'instances/s',
-            'cores': torch.get_num_threads(), 'kind': 'port',
+            'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'kind': 'port',
+            'caveat': 'forward + backward only (no clip / Adam), %d of %d host threads, %d samples; a CPU restatement '
+                      'in torch, not TensorFlow 1.3' % (torch.get_num_threads(), os.cpu_count() or 0, steps),
             'sample': '%d full forward+backward steps (no optimizer) of the torch-CPU oracle on the '
                       'same batch of %d programs x %d demos, fp32, %.2f s/step; CPU restatement, '
                       'not TF1 (TensorFlow 1.3 is not installable here)' %
@@ -214,7 +352,10 @@ def main():
     ap.add_argument('--preset', default='karel', help='karel | vizdoom | vizdoom_k25 | karel_tiny')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--h2d', action='store_true', help='also report the host-batch (PCIe-inclusive) rate')
+    ap.add_argument('--h2d', action='store_true', help='also report the sequential host-batch rate (fetch + H2D + step, '
+                    'no prefetch); the prefetched PCIe-inclusive rate is always reported')
+    ap.add_argument('--no-h2d', action='store_true', help='skip the PCIe-inclusive leg')
+    ap.add_argument('--no-config4', action='store_true', help='skip the ViZDoom (BASELINE config 4) leg')
     ap.add_argument('--frames', default='uint8', choices=['uint8', 'float32'],
                     help='precision the demonstration frames are staged in: uint8 = the dataset\'s own (Karel states are '
                          'booleans, ViZDoom frames bytes), widened on load inside conv1; float32 = the reference\'s feed dtype')
@@ -297,16 +438,17 @@ def main():
         'final_loss': round(final_loss, 5),
     }
 
-    if args.h2d:
-        # PCIe-inclusive rate: host numpy batch -> H2D -> step (never `value`)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
+    if not args.no_h2d:
+        # PCIe-inclusive rates: host numpy batch -> H2D -> step (never `value`)
         n = max(5, args.steps // 5)
-        for i in range(n):
-            trainer.train_step(trainer.model.get_feed_dict(host_batches[i % len(host_batches)]))
-        torch.cuda.synchronize()
-        out['value_incl_h2d'] = round(global_batch * n / dp.max_over_ranks(time.perf_counter() - t1), 3)
-        # the same with the trainer's prefetcher: next batch pinned + copied on a side stream meanwhile
+        if args.h2d:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n):
+                trainer.train_step(trainer.model.get_feed_dict(host_batches[i % len(host_batches)]))
+            torch.cuda.synchronize()
+            out['value_incl_h2d'] = round(global_batch * n / dp.max_over_ranks(time.perf_counter() - t1), 3)
+        # the trainer's own loop: the next batch is pinned + copied on a copy stream while this step runs
         from demo2program_amd.trainer import FeedPrefetcher
 
         class _Cycle(object):
@@ -322,6 +464,7 @@ def main():
             trainer.train_step(pf.take())
             pf.stage()
         torch.cuda.synchronize()
+        dp.barrier()
         t1 = time.perf_counter()
         for _ in range(n):
             trainer.train_step(pf.take())
@@ -332,11 +475,15 @@ def main():
 
     if not args.no_roofline:
         log('roofline leg')
-        roof, table = roofline_leg(trainer, feeds)
+        roof, furthest, table = roofline_leg(trainer, feeds)
         out['roofline'] = roof
+        out['furthest_below_roofline'] = furthest
         out['kernel_table'] = table
         if dp.rank == 0:
             out['north_star_targets'] = north_star_targets(config, table)
+    if dp.rank == 0 and dp.world_size == 1 and args.preset == 'karel' and not args.no_config4:
+        log('config 4 (ViZDoom 80x80x3) leg')
+        out['config4_vizdoom'] = config4_leg()
     if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:
         from demo2program_amd.params import init_params
         log('cpu baseline leg (%d host cores)' % (os.cpu_count() or 1))

@@ -10,6 +10,8 @@ import sys
 
 
 def family(name):
+    if 'lstm_persist_fwd' in name: return 'lstm_persist_fwd_kernel'
+    if 'lstm_persist_bwd' in name: return 'lstm_persist_bwd_kernel'
     if 'lstm_step_fwd' in name: return 'lstm_step_fwd_kernel'
     if 'lstm_step_bwd' in name: return 'lstm_step_bwd_kernel'
     if 'gemm_mfma_kernel' in name:

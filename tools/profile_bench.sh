@@ -8,5 +8,5 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 REPO=$PWD
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $OUT -o bench -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline $BENCH_ARGS > $OUT/bench_stdout.log 2> $OUT/bench_stderr.log
+rocprofv3 --kernel-trace --stats -d $OUT -o bench -- python $REPO/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --no-h2d --no-config4 $BENCH_ARGS > $OUT/bench_stdout.log 2> $OUT/bench_stderr.log
 ls -R $OUT | head -30

@@ -11,6 +11,6 @@ export D2P_NO_GRAPH=1
 REPO=$PWD
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $C -d $OUT -o pmc_$C -- python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline $BENCH_ARGS > $OUT/${C}_stdout.log 2> $OUT/${C}_stderr.log
+  rocprofv3 --kernel-trace --pmc $C -d $OUT -o pmc_$C -- python $REPO/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-roofline --no-h2d --no-config4 $BENCH_ARGS > $OUT/${C}_stdout.log 2> $OUT/${C}_stderr.log
 done
 ls -la $OUT

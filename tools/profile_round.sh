@@ -1,10 +1,20 @@
+# Run on the GPU box (through gpurun): everything a round's profiles/ entry is made of.
+# usage: bash tools/profile_round.sh <tag>     (tag e.g. r02a; outputs under gpurun_out/)
+TAG=${1:-r02}
 set -x
-python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3
-python bench.py > gpurun_out/r01t_bench.json 2> gpurun_out/r01t_bench.err
-D2P_NO_GRAPH=1 D2P_NO_SIDE_STREAM=1 bash tools/profile_bench.sh r01t > /dev/null 2>&1
-DB=$(find gpurun_out/prof_r01t -name "*.db" | head -1)
-python tools/rocpd_summary.py $DB > gpurun_out/r01t_kernel_stats_serial.md
-bash tools/profile_pmc.sh r01t > /dev/null 2>&1
-python tools/pmc_summary.py gpurun_out/pmc_r01t gpurun_out/r01t_pmc_traffic.json > gpurun_out/r01t_pmc_traffic.md
-ls -la gpurun_out/ | tail
-rm -rf gpurun_out/prof_r01t/*/*.db gpurun_out/pmc_r01t/*/*.db 2>/dev/null; find gpurun_out -name "*.db" -size +20M -delete
+python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
+for P in vizdoom vizdoom_k25; do
+  python bench.py --preset $P --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_$P.json 2>> gpurun_out/${TAG}_bench.err
+done
+# kernel trace: eager one-stream launches (per-kernel durations), then the captured graph
+D2P_NO_GRAPH=1 bash tools/profile_bench.sh ${TAG}s > /dev/null 2>&1
+DB=$(find gpurun_out/prof_${TAG}s -name "*.db" | head -1)
+python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_serial.md
+bash tools/profile_bench.sh ${TAG}g > /dev/null 2>&1
+DB=$(find gpurun_out/prof_${TAG}g -name "*.db" | head -1)
+python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_graph.md
+# HBM traffic counters, one counter per pass
+bash tools/profile_pmc.sh $TAG > /dev/null 2>&1
+python tools/pmc_summary.py gpurun_out/pmc_$TAG gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_traffic.md
+find gpurun_out -name "*.db" -size +1M -delete
+ls -la gpurun_out/ | tail -12
