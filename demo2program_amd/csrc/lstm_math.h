@@ -60,3 +60,35 @@ __device__ __forceinline__ void lstm_gate_bwd4(const f4& zi, const f4& zj, const
         lstm_cell_bwd(zi.v[q], zj.v[q], zf.v[q], zo.v[q], cp.v[q], cc.v[q], dh.v[q], dcv.v[q], gi.v[q], gj.v[q],
                       gf.v[q], go.v[q], dcn.v[q]);
 }
+
+// The same cell backward in two parts for kernels that know z, c before they know dh (the persistent
+// backward kernel computes part 1 while the dz.Wh^T product is still running): part 1 = everything that
+// does not depend on dh / dc, part 2 = six multiplies.  Products are grouped differently from
+// lstm_cell_bwd (1-ulp differences).
+struct LstmCellBwdPre { float a_dct, b_i, b_j, b_f, b_o, f; };
+__device__ __forceinline__ LstmCellBwdPre lstm_cell_bwd_pre(float zi, float zj, float zf, float zo, float cp, float cc) {
+#pragma clang fp contract(off)
+    const float i = d2p_sigmoid(zi);
+    const float j = d2p_tanh(zj);
+    const float f = d2p_sigmoid(zf + D2P_FORGET_BIAS);
+    const float og = d2p_sigmoid(zo);
+    const float tc = d2p_tanh(cc);
+    LstmCellBwdPre q;
+    q.a_dct = og * (1.f - tc * tc);      // d c_t / d h
+    q.b_i = j * i * (1.f - i);
+    q.b_j = i * (1.f - j * j);
+    q.b_f = cp * f * (1.f - f);
+    q.b_o = tc * og * (1.f - og);
+    q.f = f;
+    return q;
+}
+__device__ __forceinline__ void lstm_cell_bwd_post(const LstmCellBwdPre& q, float dh, float dcv, float& gi, float& gj,
+                                                   float& gf, float& go, float& dcn) {
+#pragma clang fp contract(off)
+    const float dct = fmaf(dh, q.a_dct, dcv);
+    gi = dct * q.b_i;
+    gj = dct * q.b_j;
+    gf = dct * q.b_f;
+    go = dh * q.b_o;
+    dcn = dct * q.f;
+}

@@ -641,44 +641,149 @@ struct PsBwdEpi {
     int* stl;
 };
 
-// Gate backward of this wave's 4 rows x 16 units of phase p, pass j (t = T-1-j; t = -1: dh0 pass)
-__device__ __forceinline__ void ps_bwd_epilogue(const PsBwdArgs& a, const PsBwdEpi& e, int rs0, int p, int j, int slot) {
+// Gate backward of this wave's 4 rows x 16 units of phase p, pass j (t = T-1-j; t = -1: dh0 pass), in
+// two parts: everything that does not depend on the dz.Wh^T product (ring operands, the five
+// non-linearities, the gate derivative factors) is computed inside the product's last MFMA stage; behind
+// the combine barrier only the sum of the partial tiles, six multiplies and the stores remain.
+struct PsBwdEpiPre {
+    LstmCellBwdPre q;
+    float dhx, dcv;
+    bool cur_active;
+};
+__device__ __forceinline__ void ps_bwd_epilogue_pre(const PsBwdArgs& a, const PsBwdEpi& e, int p, int j, int slot,
+                                                    PsBwdEpiPre& pre) {
+    const int t = a.T - 1 - j;
+    const int len = e.stl[p * 16 + e.rr];
+    const bool next_active = (t + 1 < a.T) && (t + 1 < len);
+    pre.cur_active = (t >= 0) && (t < len);
+    const float* rs = e.ring + slot * PS_BWD_SLOT + e.rr * 16 + e.un;
+    // dH_t = dz[t+1]·Wh^T (+ dh_final for rows that are not active at t+1) (+ dhout[t])
+    float dhx = (!next_active && a.dh_final) ? rs[7 * 256] : 0.f;
+    dhx += (pre.cur_active && a.dhout) ? rs[6 * 256] : 0.f;
+    pre.dhx = dhx;
+    const float cp = (t > 0 || a.c0) ? rs[4 * 256] : 0.f;
+    pre.q = lstm_cell_bwd_pre(rs[0], rs[256], rs[512], rs[768], cp, rs[5 * 256]);
+    pre.dcv = e.stdc[(p * 16 + e.rr) * 16 + e.un];
+}
+__device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const PsBwdEpi& e, int rs0, int p, int j,
+                                                     const PsBwdEpiPre& pre) {
     const int U = a.U;
     const int t = a.T - 1 - j;
     const int row = (rs0 + p) * 16 + e.rr;
     const bool valid = row < a.M;
-    const long o = (long)row * U + e.u;
-    const int len = e.stl[p * 16 + e.rr];
-    const bool next_active = (t + 1 < a.T) && (t + 1 < len);
-    const bool cur_active = (t >= 0) && (t < len);
-    const float* rs = e.ring + slot * PS_BWD_SLOT + e.rr * 16 + e.un;
-    // dH_t = dz[t+1]·Wh^T (+ dh_final for rows that are not active at t+1) (+ dhout[t])
-    float dH = (!next_active && a.dh_final) ? rs[7 * 256] : 0.f;
-    if (cur_active && a.dhout) dH += rs[6 * 256];
-    if (j > 0) {
+    float dH = pre.dhx;
+    {   // the partial tiles are zero in pass 0 (the host zero-fills dz[T])
         const float* Pb = e.P + e.rr * PS_PLD + e.un;
 #pragma unroll
         for (int w = 0; w < 4; ++w) dH += Pb[w * 16 * PS_PLD];
     }
     const int sidx = (p * 16 + e.rr) * 16 + e.un;
     float g[4], dcn;
-    const float cp = (t > 0 || a.c0) ? rs[4 * 256] : 0.f;
-    lstm_cell_bwd(rs[0], rs[256], rs[512], rs[768], cp, rs[5 * 256], dH, e.stdc[sidx], g[0], g[1], g[2], g[3], dcn);
-    if (cur_active) e.stdc[sidx] = dcn;
+    lstm_cell_bwd_post(pre.q, dH, pre.dcv, g[0], g[1], g[2], g[3], dcn);
+    e.stdc[sidx] = pre.cur_active ? dcn : pre.dcv;
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
-        g[gg] = cur_active ? g[gg] : 0.f;
+        g[gg] = pre.cur_active ? g[gg] : 0.f;
         // staged fragment-major per gate: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
         e.stage[gg * 256 + (((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = g[gg];
     }
-    // unconditional stores: dz[t] row-major (the dh0 pass writes dh0 with the first and dumps the rest)
+    // unconditional stores: dz[t] row-major (the dh0 pass writes dh0 with the first and dumps the rest);
+    // addresses for a clamped row, only the final offset selected (see the forward epilogue)
     const bool fin = t < 0;
-    float* dzr = (valid && !fin) ? a.dz + (long)t * a.zts + (long)row * a.zrs + e.u : a.dump;
+    const int rowc = min(row, a.M - 1);
+    const long zo = (long)max(t, 0) * a.zts + (long)rowc * a.zrs + e.u;
+    const long dd = a.dump - a.dz;
+    float* dzr = a.dz + ((valid && !fin) ? zo : dd);
     const long zg = (valid && !fin) ? (long)U : 0L;
-    float* q0 = (valid && fin) ? a.dh0 + o : dzr;
+    float* q0 = (valid && fin) ? a.dh0 + (long)rowc * U + e.u : dzr;
     *q0 = fin ? dH : g[0];
 #pragma unroll
     for (int gg = 1; gg < 4; ++gg) dzr[gg * zg] = g[gg];
+}
+
+// All ticks of one backward MFMA wave (LA: look-ahead, i.e. the domain has >= 2 phases).  Pass 0 has
+// no product (there is no dz[T]): the host zero-fills that buffer and the chain runs unconditionally.
+template <int CPW, bool LA>
+__device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwdEpi& e, const f32x4 (&bw)[4 * CPW],
+                                                 __amdgpu_buffer_rsrc_t dres, const unsigned* fl, int nnt, int rs0,
+                                                 int nrs, int nticks, int lane_off, float* P, int wave, int lane) {
+    constexpr int CPWB = 4 * CPW;                // chunks per wave
+    constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
+    constexpr int CB = CPWB / NB;                // chunks per stage
+    constexpr int KC4 = 4 * CPWB;                // chunks over K = 4U
+    PsTrace tr;
+    tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
+    f32x4 s0[CB], s1[CB];
+    PsTick k0 = {0, 0}, k1 = {0, 0}, k2 = {0, 0};      // ticks n, n+1, n+2 (t = pass index j)
+    k1.next(nrs);
+    k2.next(nrs); k2.next(nrs);
+    // pass j consumes dz[t+1] with t = T-1-j, i.e. the buffer written in pass j-1: (T-j) & 1
+    {
+        const int off0 = (int)((a.T & 1) * a.dzfrag_bytes) + rs0 * KC4 * 1024 + lane_off;
+#pragma unroll
+        for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, off0 + c * 1024);
+    }
+    unsigned fv = ps_ld_flag(fl + k1.p * nnt);
+    int slot = 0;
+    float* Pw = P + wave * 16 * PS_PLD;
+#pragma unroll 1
+    for (int n = 0; n < nticks; ++n) {
+        const bool e1 = n + 1 >= nticks, e2 = n + 2 >= nticks;
+        const PsTick q1 = e1 ? k0 : k1, q2 = e2 ? (e1 ? k0 : k1) : k2;
+        const unsigned need1 = e1 ? 0u : (unsigned)q1.t;
+        const int off = (int)(((a.T - k0.t) & 1) * a.dzfrag_bytes) + (rs0 + k0.p) * KC4 * 1024 + lane_off;
+        const int off1 = (int)(((a.T - q1.t) & 1) * a.dzfrag_bytes) + (rs0 + q1.p) * KC4 * 1024 + lane_off;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        PsBwdEpiPre pre;
+        tr.stamp(0);
+        if (!LA) {
+            ps_wait_flags(fl + k0.p * nnt, (unsigned)k0.t, ps_ld_flag(fl + k0.p * nnt), a.err, 4);
+#pragma unroll
+            for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, off + c * 1024);
+        }
+#pragma unroll
+        for (int st = 0; st < NB; ++st) {
+            if (st == NB - 1) {
+                // the next tick's first stage: behind its flags, read one tick ago
+                tr.stamp(1);
+                if (LA) ps_wait_flags(fl + q1.p * nnt, need1, fv, a.err, 2);
+                tr.stamp(2);
+            }
+            const int noff = (st < NB - 1) ? off + (st + 1) * CB * 1024 : off1;
+            if ((st & 1) == 0) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) s1[c] = ps_ld_sc1(dres, noff + c * 1024);
+                ps_bwd_stage<CB, CPWB>(s0, bw, st * CB, acc0, acc1);
+            } else {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, noff + c * 1024);
+                if (st == NB - 1) {
+                    fv = ps_ld_flag(fl + q2.p * nnt);
+                    ps_bwd_epilogue_pre(a, e, k0.p, k0.t, slot, pre);      // interleaved with this stage's MFMAs
+                }
+                ps_bwd_stage<CB, CPWB>(s1, bw, st * CB, acc0, acc1);
+            }
+            // the next stage's operand loads (~60 clocks of issue each) and, in the last stage, the
+            // product-independent half of the gate math go between this stage's MFMAs
+#pragma unroll
+            for (int i = 0; i < 2 * CB; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // two MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one load
+                __builtin_amdgcn_sched_group_barrier(0x186, 4, 0);      // VALU / SALU / LDS reads
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pw[((lane >> 4) * 4 + r) * PS_PLD + (lane & 15)] = acc0[r] + acc1[r];
+        ps_barrier();          // A: the four partial tiles are in LDS
+        tr.stamp(3);
+        ps_bwd_epilogue_post(a, e, rs0, k0.p, k0.t, pre);
+        ps_barrier();          // B: dz of the phase staged, P and the ring slot free again
+        tr.stamp(4);
+        if (wave == 0) tr.flush(0, n, lane);
+        k0 = k1; k1 = k2; k2.next(nrs);
+        if (++slot == PS_PF_R) slot = 0;
+    }
 }
 
 template <int CPW>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16
@@ -713,7 +818,6 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         const __amdgpu_buffer_rsrc_t dres = ps_rsrc(a.dzfrag, 2u * a.dzfrag_bytes);
         const int lane_off = (wave * CPWB * 64 + lane) * 16;
         const unsigned* fl = fbase + (lane & (nnt - 1));      // every producer of the domain writes this gate
-        const bool la = nrs >= 2;      // see ps_fwd_tick
         PsBwdEpi e;
         e.rr = wave * 4 + (lane >> 4);
         e.un = lane & 15;
@@ -730,70 +834,8 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             stdc[(p * 16 + e.rr) * 16 + e.un] = d;
             if (e.un == 0) stl[p * 16 + e.rr] = len;
         }
-        PsTrace tr;
-        tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
-        f32x4 s0[CB], s1[CB];
-        PsTick k0 = {0, 0}, k1 = {0, 0}, k2 = {0, 0};      // ticks n, n+1, n+2 (t = pass index j)
-        k1.next(nrs);
-        k2.next(nrs); k2.next(nrs);
-        // pass j consumes dz[t+1] with t = T-1-j, i.e. the buffer written in pass j-1: (T-j) & 1.
-        // pass 0 has no product (there is no dz[T]); its loads are harmless reads of the buffer
-        {
-            const int off0 = (int)((a.T & 1) * a.dzfrag_bytes) + rs0 * KC4 * 1024 + lane_off;
-#pragma unroll
-            for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, off0 + c * 1024);
-        }
-        unsigned fv = ps_ld_flag(fl + k1.p * nnt);
-        int slot = 0;
-        float* Pw = P + wave * 16 * PS_PLD;
-        for (int n = 0; n < nticks; ++n) {
-            const bool e1 = n + 1 >= nticks, e2 = n + 2 >= nticks;
-            const PsTick q1 = e1 ? k0 : k1, q2 = e2 ? (e1 ? k0 : k1) : k2;
-            const bool do_gemm = k0.t > 0;
-            const unsigned need1 = e1 ? 0u : (unsigned)q1.t;
-            const int off = (int)(((a.T - k0.t) & 1) * a.dzfrag_bytes) + (rs0 + k0.p) * KC4 * 1024 + lane_off;
-            const int off1 = (int)(((a.T - q1.t) & 1) * a.dzfrag_bytes) + (rs0 + q1.p) * KC4 * 1024 + lane_off;
-            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-            tr.stamp(0);
-            if (!la) {
-                ps_wait_flags(fl + k0.p * nnt, (unsigned)k0.t, ps_ld_flag(fl + k0.p * nnt), a.err, 4);
-#pragma unroll
-                for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, off + c * 1024);
-            }
-#pragma unroll
-            for (int st = 0; st < NB; ++st) {
-                if (st == NB - 1) {
-                    // the next tick's first stage: behind its flags, read one tick ago
-                    tr.stamp(1);
-                    if (la) ps_wait_flags(fl + q1.p * nnt, need1, fv, a.err, 2);
-                    tr.stamp(2);
-                }
-                const int noff = (st < NB - 1) ? off + (st + 1) * CB * 1024 : off1;
-                if ((st & 1) == 0) {
-#pragma unroll
-                    for (int c = 0; c < CB; ++c) s1[c] = ps_ld_sc1(dres, noff + c * 1024);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (do_gemm) ps_bwd_stage<CB, CPWB>(s0, bw, st * CB, acc0, acc1);
-                } else {
-#pragma unroll
-                    for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, noff + c * 1024);
-                    if (st == NB - 1) fv = ps_ld_flag(fl + q2.p * nnt);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (do_gemm) ps_bwd_stage<CB, CPWB>(s1, bw, st * CB, acc0, acc1);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) Pw[((lane >> 4) * 4 + r) * PS_PLD + (lane & 15)] = acc0[r] + acc1[r];
-            ps_barrier();          // A: the four partial tiles are in LDS
-            tr.stamp(3);
-            ps_bwd_epilogue(a, e, rs0, k0.p, k0.t, slot);
-            ps_barrier();          // B: dz of the phase staged, P and the ring slot free again
-            tr.stamp(4);
-            if (wave == 0) tr.flush(0, n, lane);
-            k0 = k1; k1 = k2; k2.next(nrs);
-            if (++slot == PS_PF_R) slot = 0;
-        }
+        if (nrs >= 2) ps_bwd_mfma_wave<CPW, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane);
+        else ps_bwd_mfma_wave<CPW, false>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane);
         if (a.dc0)
             for (int qq = 0; qq < nrs; ++qq) {
                 const int row = (rs0 + qq) * 16 + e.rr;
@@ -986,6 +1028,8 @@ int d2p_lstm_persist_bwd(int M, int U, int n_steps, const float* z, long zrs, lo
     a.dz = dz; a.dh0 = dh0; a.dc0 = dc0;
     int rc = d2p_lstm_pack_w_bwd(U, Wh, Wb, st);
     if (rc) return rc;
+    // pass 0 has no product: the chain runs on an all-zero dz[T]
+    D2P_HIP(hipMemsetAsync((char*)a.dzfrag + (size_t)(n_steps & 1) * a.dzfrag_bytes, 0, a.dzfrag_bytes, st));
     D2P_HIP(hipMemsetAsync(a.flags, 0, (size_t)a.RT * PS_NRS_MAX * nnt * sizeof(unsigned), st));
     const int blocks = nnt * a.RT;
     {
