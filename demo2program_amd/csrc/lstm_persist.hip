@@ -589,12 +589,12 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
                             (int)(d2p_frag_off(row, ct * 8 + ((lane >> 4) & 1) * 4, U >> 4) * 4);
             asm volatile("" ::: "memory");
             if (lane < 32 && pub) ps_st_sc1(hres, off, hv[0], hv[1], hv[2], hv[3]);
-            asm volatile("" ::: "memory");
-            issue();                                 // tick n + D into the slot tick n - 1 used
             tr.stamp(2);
-            ps_wait_vmcnt<2>();                      // everything but the two loads just issued: the store is out
+            ps_wait_vmcnt<0>();                      // the store is out (and the loads of the last tick have landed)
             tr.stamp(3);
             if (lane == 0 && pub) ps_st_flag(fbase + k.p * nct + ct, (unsigned)(k.t + 1));
+            asm volatile("" ::: "memory");
+            issue();                                 // tick n + D into a free ring slot, off the hand-off path
             tr.flush(1, n, lane);
             if (pub) k.next(nrs);
         }
@@ -892,12 +892,12 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
                     ps_st_sc1(dres, fo + (int)(d2p_frag_off(row, gg * U + nt * 16 + (lane >> 4) * 4, KCx) * 4), gv[gg][0],
                               gv[gg][1], gv[gg][2], gv[gg][3]);
             }
-            asm volatile("" ::: "memory");
-            issue();
             tr.stamp(2);
-            ps_wait_vmcnt<PS_BWD_NOP>();
+            ps_wait_vmcnt<0>();                      // the stores are out (and the loads of the last tick have landed)
             tr.stamp(3);
             if (lane == 0) ps_st_flag(fbase + k.p * nnt + nt, (unsigned)(k.t + 1));
+            asm volatile("" ::: "memory");
+            issue();                                 // off the hand-off path
             tr.flush(1, n, lane);
             k.next(nrs);
         }

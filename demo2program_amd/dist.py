@@ -5,9 +5,13 @@ the one exchange step the sharded path needs:
 
   * each rank trains on B/N programs with ALL k demonstrations of each program (the
     summarizer mixes across k inside a program, never across programs);
-  * after backward, ONE all-reduce(SUM, fp32) over the flat gradient buffer (~45 MB);
-    xGMI is point-to-point, so a ring all-reduce is per-link bound and one large message
-    is the efficient shape (2*(N-1)/N*45 MB / 153 GB/s ~= 0.5 ms at N=8);
+  * the flat gradient buffer (~45 MB) is all-reduced (SUM, fp32) in TWO large pieces: the
+    decoders' slice (the tail of the buffer, 57 % of the bytes) is final two thirds of the way
+    through backward and is reduced on RCCL's stream WHILE the summarizer / encoder backward
+    runs (`all_reduce_start` at Model.backward's split point); the rest follows after backward
+    (`all_reduce_finish`).  xGMI is point-to-point, so a ring all-reduce is per-link bound and
+    few large messages are the efficient shape (2*(N-1)/N*45 MB / 153 GB/s ~= 0.5 ms at N=8);
+    `all_reduce_grads` is the one-message form (D2P_DP_OVERLAP=0, or a model on two streams);
   * the 1/N of the average is folded into the clip+Adam kernel's ``prescale`` -- the
     averaged gradient is never written back to HBM;
   * clip-by-global-norm runs AFTER the reduce, on every rank, as trainer.py:107 implies;
@@ -86,6 +90,34 @@ class DataParallel(object):
             import torch.distributed as dist
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         return flat_grad
+
+    @property
+    def active(self):
+        """True when the exchange step issues collectives (several ranks, or a forced one-rank group)."""
+        return self.world_size > 1 or self.initialized
+
+    def all_reduce_start(self, piece):
+        """Begins the SUM all-reduce of one contiguous piece of the flat gradient buffer on the
+        collective library's own stream: it starts when the work enqueued on the current stream SO
+        FAR is done and overlaps whatever is enqueued afterwards."""
+        if not self.active:
+            return
+        import torch.distributed as dist
+        if not hasattr(self, '_pending'):
+            self._pending = []
+        self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+
+    def all_reduce_finish(self, rest=None):
+        """All-reduces `rest` (the part of the buffer not started earlier) and makes the current stream
+        wait for every piece: after this the whole buffer holds the sum over ranks."""
+        if not self.active:
+            return
+        import torch.distributed as dist
+        if rest is not None and rest.numel():
+            dist.all_reduce(rest, op=dist.ReduceOp.SUM)
+        for w in getattr(self, '_pending', []):
+            w.wait()
+        self._pending = []
 
     def broadcast_params(self, flat_params, src=0):
         if self.world_size > 1 or self.initialized:

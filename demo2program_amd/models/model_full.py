@@ -574,8 +574,18 @@ class Model(object):
         return dict(feat=feat, y1a=y1a, y1=y1, y2a=y2a, st1=st1, st2=st2, out=out, add_mean=add_mean, ps=ps)
 
     # ------------------------------------------------------------------ backward
-    def backward(self, loss_scale=1.0):
-        """Hand-written reverse schedule; writes every entry of params.grad exactly once."""
+    def decoder_grad_offset(self):
+        """First element of the flat parameter / gradient buffer that belongs to the decoders
+        (params.py orders encoder, summarizer, then prog/ act/ per/): everything from here on is final
+        when `backward` reaches its split point."""
+        return self.params.offsets['prog/embedding']
+
+    def backward(self, loss_scale=1.0, split_cb=None):
+        """Hand-written reverse schedule; writes every entry of params.grad exactly once.
+        split_cb (data parallelism): called once, right after the last decoder gradient has been
+        launched (57 % of the gradient bytes, two thirds of the way through) and before the summarizer /
+        encoder backward -- the trainer starts the all-reduce of that slice there (or, under graph
+        capture, closes the first graph and opens the second)."""
         if not self.is_train:
             raise RuntimeError('Model(is_train=False) is the evaluation graph: no backward pass')
         ctx, c, p, g = self._ctx, self.config, self.params.p, self.params.g
@@ -634,6 +644,9 @@ class Model(object):
                                   False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)),
                                   dbias=g['per/fc/b'])
                 K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
+            if split_cb is not None:
+                main.wait_stream(side)
+                split_cb()
         else:
             # baselines: the program decoder is the only one
             dz_p = self._decoders_bwd_rec([(ctx['dp'], dl_p, d_init_h, d_init_c)])[0]
@@ -641,6 +654,9 @@ class Model(object):
             with torch.cuda.stream(side):
                 dx_p = self._lstm_bwd_params(ctx['dp'], dz_p, True)
                 K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
+            if split_cb is not None:
+                main.wait_stream(side)
+                split_cb()
 
         d_h1f, d_c1f = self._buf('d_h1f', (M, U)), self._buf('d_c1f', (M, U))
         if self.variant == 'synthesis_baseline':

@@ -117,6 +117,7 @@ class Trainer(object):
         if use_graph is None:
             use_graph = os.environ.get('D2P_NO_GRAPH', '0') != '1'
         self.use_graph = bool(use_graph)
+        self.dp_overlap = os.environ.get('D2P_DP_OVERLAP', '1') != '0'
         self._graphs = {}
         self._static_feed = None
         hyper_parameter_str = 'bs_{}_lr_{}_{}_cell_{}'.format(
@@ -180,13 +181,21 @@ class Trainer(object):
         m = self.model
         if m.scheduled_sampling:
             m.set_sampling_step(self.global_step)     # sampling probability + noise counter of this step
+        P = m.params
+        # data parallelism: the decoders' gradients (the tail of the flat buffer) are all-reduced while
+        # the rest of backward runs; one message for everything when that is switched off
+        overlap = self.dp.active and self.dp_overlap and not m.use_side_stream
+        dec = m.decoder_grad_offset() if overlap else 0
+        start = (lambda: self.dp.all_reduce_start(P.grad[dec:])) if overlap else None
         if self.use_graph and not self._profiling():
-            loss = self._graphed_forward_backward(feed)
+            loss = self._graphed_forward_backward(feed, start)
         else:
             loss = m.forward(feed)
-            m.backward()
-        P = m.params
-        self.dp.all_reduce_grads(P.grad)            # SUM over ranks; mean folded into prescale
+            m.backward(split_cb=start)
+        if overlap:
+            self.dp.all_reduce_finish(P.grad[:dec])
+        else:
+            self.dp.all_reduce_grads(P.grad)        # SUM over ranks; mean folded into prescale
         pre = self.dp.prescale
         K.l2norm_flat(P.grad, pre, self._sumsq)
         # bias correction from the number of steps the MOMENTS have seen, not from global_step: the
@@ -210,7 +219,9 @@ class Trainer(object):
     _STATIC_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'program_len',
                     'demo_len')
 
-    def _graphed_forward_backward(self, feed):
+    def _graphed_forward_backward(self, feed, split_cb=None):
+        """split_cb: with data parallelism the step is captured as TWO graphs cut at Model.backward's
+        split point; split_cb (the start of the decoders' all-reduce) is called between their launches."""
         m = self.model
         sf = self._static_feed
         if sf is None or sf['s_h'].dtype != feed['s_h'].dtype:    # e.g. uint8 frames after float32 frames
@@ -224,11 +235,12 @@ class Trainer(object):
         key = (feed['n_prog'], feed['n_demo'])
         static = dict({k: sf[k] for k in self._STATIC_KEYS}, n_prog=key[0], n_demo=key[1], id=feed.get('id'),
                       host=feed.get('host'))
+        key = key + (split_cb is not None,)
         g = self._graphs.get(key)
         if g is None and len(self._graphs) >= self.MAX_GRAPHS:
             # an unusually ragged dataset: stop instantiating graphs, run further new shapes eagerly
             loss = m.forward(static)
-            m.backward()
+            m.backward(split_cb=split_cb)
             return loss
         if g is None:
             # one eager pass sizes every buffer / scratch, then capture the same schedule; the
@@ -240,15 +252,37 @@ class Trainer(object):
                 m.moving[n][0].copy_(a)
                 m.moving[n][1].copy_(b)
             torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                m.forward(static)
-                m.backward()
+            if split_cb is None:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    m.forward(static)
+                    m.backward()
+            else:
+                # two graphs sharing one memory pool, cut inside backward
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                cap = torch.cuda.Stream()
+                cap.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(cap):
+                    g1.capture_begin()
+
+                    def cut():
+                        g1.capture_end()
+                        g2.capture_begin(pool=g1.pool())
+                    m.forward(static)
+                    m.backward(split_cb=cut)
+                    g2.capture_end()
+                torch.cuda.current_stream().wait_stream(cap)
+                g = (g1, g2)
             self._graphs[key] = g
         else:
             m._ctx['feed'] = static
             m._feed = static
-        g.replay()
+        if split_cb is None:
+            g.replay()
+        else:
+            g[0].replay()
+            split_cb()
+            g[1].replay()
         return m.loss
 
     def run_single_step(self, batch, step=None, is_train=True):

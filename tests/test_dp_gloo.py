@@ -50,7 +50,17 @@ def _worker(rank, world, port, outdir):
     loss, grads = _rank_grads(cfg, synced, rank)
     for n, gview in fp.g.items():
         gview.copy_(grads[n].float())
+    # the two-piece exchange of the trainer (decoders' tail started first, the rest finishing) must
+    # give the same buffer as the one-message form, bit for bit, on every rank
+    two = fp.grad.clone()
+    dec = fp.offsets['prog/embedding']
+    assert 0 < dec < two.numel()           # (57 % of the bytes at the headline configuration)
+    dp.all_reduce_start(two[dec:])
+    two[:dec].mul_(1.0)                    # "the rest of backward" between start and finish
+    dp.all_reduce_finish(two[:dec])
+    assert dp._pending == []
     dp.all_reduce_grads(fp.grad)
+    assert torch.equal(two, fp.grad)
     t = dp.max_over_ranks(float(rank + 1))
     ids = dp.shard(list(range(10)))
     np.savez(os.path.join(outdir, 'rank%d.npz' % rank), grad=fp.grad.numpy() * dp.prescale,
@@ -106,4 +116,8 @@ def test_single_rank_dataparallel_is_a_noop():
     dp = DataParallel()
     g = torch.arange(8, dtype=torch.float32)
     assert dp.prescale == 1.0 and dp.all_reduce_grads(g) is g and dp.shard([1, 2, 3]) == [1, 2, 3]
+    assert not dp.active
+    dp.all_reduce_start(g[4:])             # no process group: the two-piece form is a no-op as well
+    dp.all_reduce_finish(g[:4])
+    assert torch.equal(g, torch.arange(8, dtype=torch.float32))
     assert dp.max_over_ranks(1.5) == 1.5
