@@ -409,6 +409,7 @@ def main():
     elapsed = dp.max_over_ranks(time.perf_counter() - t0)
     final_loss = float(loss.item())
     log('timed region done: %.3f s' % elapsed)
+    trainer.check_device_status()          # a persistent LSTM launch that gave up a hand-off voids the run
 
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     step_stats = {'median': round(per_step[len(per_step) // 2], 4), 'p10': round(per_step[len(per_step) // 10], 4),

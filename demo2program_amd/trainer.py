@@ -117,7 +117,11 @@ class Trainer(object):
         if use_graph is None:
             use_graph = os.environ.get('D2P_NO_GRAPH', '0') != '1'
         self.use_graph = bool(use_graph)
-        self.dp_overlap = os.environ.get('D2P_DP_OVERLAP', '1') != '0'
+        # overlap of the decoders' all-reduce with the encoder backward: built and tested, OFF by default --
+        # the persistent LSTM kernels of that part of backward need every CU, so a collective kernel running
+        # beside them only delays their start (one rank, forced RCCL group: 5.20 vs 5.02 ms/step); no
+        # multi-GPU box was available to show a gain at N > 1
+        self.dp_overlap = os.environ.get('D2P_DP_OVERLAP', '0') == '1'
         self._graphs = {}
         self._static_feed = None
         hyper_parameter_str = 'bs_{}_lr_{}_{}_cell_{}'.format(
@@ -326,11 +330,22 @@ class Trainer(object):
                 self.run_single_step(source, step=s, is_train=True)
             if s % self.log_step == 0:
                 self.log_step_message(step, loss, step_time)
+                self.check_device_status()
             if s % self.test_sample_step == 0:
                 test_step, _, test_loss, _, test_step_time = self.run_test(self.batch_test)
                 self.log_step_message(step, test_loss, test_step_time, is_train=False)
             if s % ckpt_save_step == 0 and self.dp.rank == 0:
                 self.save_checkpoint(os.path.join(self.train_dir, 'model-%d.npz' % step))
+
+    @staticmethod
+    def check_device_status():
+        """The persistent LSTM kernels give up a hand-off after a bounded wait instead of hanging (a
+        workgroup that was not resident, e.g. a shared device) and record it; their results are then
+        invalid.  Synchronising: called at the logging cadence, not per step."""
+        err = K.lstm_persist_error(reset=True)
+        if err:
+            raise RuntimeError('persistent LSTM kernel gave up a hand-off (status 0x%08x): the device was shared or '
+                               'a workgroup was not resident; rerun, or set d2p_lstm_set_persistent(0)' % (err & 0xffffffff))
 
     def log_step_message(self, step, loss, step_time, is_train=True):
         """The reference's log line, verbatim (trainer.py:227-240)."""

@@ -827,13 +827,12 @@ def test_rccl_single_rank_self_test(monkeypatch):
     try:
         import torch.distributed as dist
         assert dp.initialized and dist.get_backend() == 'nccl' and dp.world_size == 1
-        # default: two graphs cut at the decoders' last gradient, their slice all-reduced on RCCL's
-        # stream between the two launches, the rest after the second
-        with_group = run(dp)
-        monkeypatch.setenv('D2P_DP_OVERLAP', '0')           # one message after backward
-        one_message = run(dp)
-        monkeypatch.setenv('D2P_NO_GRAPH', '1')             # eager launches, overlap on
+        one_message = run(dp)                               # default: one message after backward
+        # D2P_DP_OVERLAP=1: two graphs cut at the decoders' last gradient, their slice all-reduced on
+        # RCCL's stream between the two launches, the rest after the second
         monkeypatch.setenv('D2P_DP_OVERLAP', '1')
+        with_group = run(dp)
+        monkeypatch.setenv('D2P_NO_GRAPH', '1')             # eager launches, overlap on
         eager = run(dp)
         assert dp.max_over_ranks(1.25) == 1.25
         dp.barrier()
