@@ -122,7 +122,12 @@ class Model(object):
         # (backward).  OFF by default: it paid off (~4 %) while the step took 7 ms, but once the small
         # GEMMs and the K loop were fixed the fork/join edges of the captured two-queue graph cost
         # more than the remaining overlap buys (6.19 vs 6.29 ms/step Karel, 11.00 vs 11.09 ViZDoom).
-        self.use_side_stream = (os.environ.get('D2P_SIDE_STREAM', '0') == '1' and
+        # a second stream for the work that does not depend on the recurrences (decoder input projections in
+        # forward, the decoders' nine weight / input-gradient GEMMs in backward).  Round 1 measured it as a
+        # loss next to the per-step LSTM kernels; next to the persistent ones (round 2) the GEMMs fill the
+        # matrix pipe while a recurrence waits for its hand-offs: 4.82 vs 5.10 ms per step with eager
+        # launches.  D2P_NO_SIDE_STREAM=1 / D2P_SIDE_STREAM=0 switch it off.
+        self.use_side_stream = (os.environ.get('D2P_SIDE_STREAM', '1') == '1' and
                                 os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1')
         self._reserve_scratch()
 

@@ -115,7 +115,11 @@ class Trainer(object):
                  use_graph=None):
         self.config = config
         if use_graph is None:
-            use_graph = os.environ.get('D2P_NO_GRAPH', '0') != '1'
+            # eager launches by default since round 2: a step is ~215 launches (the recurrences are one
+            # launch per sequence), the host keeps ahead of the device, and the two-stream schedule runs
+            # faster eagerly (4.82 ms) than as a captured two-queue graph (4.94) or one stream (5.02).
+            # D2P_GRAPH=1 captures forward + backward per (n_prog, n_demo) as before (frees the host).
+            use_graph = os.environ.get('D2P_GRAPH', '0') == '1' and os.environ.get('D2P_NO_GRAPH', '0') != '1'
         self.use_graph = bool(use_graph)
         # overlap of the decoders' all-reduce with the encoder backward: built and tested, OFF by default --
         # the persistent LSTM kernels of that part of backward need every CU, so a collective kernel running
@@ -177,7 +181,7 @@ class Trainer(object):
         """forward + backward + (all-reduce) + clip + Adam on a device-resident feed.
         Asynchronous: returns the device loss tensor without synchronising.
 
-        With use_graph (default) forward+backward are captured once per (n_prog, n_demo) --
+        With use_graph (D2P_GRAPH=1) forward+backward are captured once per (n_prog, n_demo) --
         the two batch-dependent step counts of dynamic_decode -- into a hipGraph reading a
         static copy of the feed, and replayed: ~500 launches per step collapse into one
         graph launch.  The all-reduce, norm and Adam stay outside the graph (RCCL call; the

@@ -828,12 +828,14 @@ def test_rccl_single_rank_self_test(monkeypatch):
         import torch.distributed as dist
         assert dp.initialized and dist.get_backend() == 'nccl' and dp.world_size == 1
         one_message = run(dp)                               # default: one message after backward
-        # D2P_DP_OVERLAP=1: two graphs cut at the decoders' last gradient, their slice all-reduced on
-        # RCCL's stream between the two launches, the rest after the second
+        # D2P_DP_OVERLAP=1 (one compute stream): the decoders' slice all-reduced on RCCL's stream from
+        # Model.backward's split point, the rest after backward -- eager launches ...
         monkeypatch.setenv('D2P_DP_OVERLAP', '1')
-        with_group = run(dp)
-        monkeypatch.setenv('D2P_NO_GRAPH', '1')             # eager launches, overlap on
+        monkeypatch.setenv('D2P_SIDE_STREAM', '0')
         eager = run(dp)
+        # ... and as two graphs cut at the split point
+        monkeypatch.setenv('D2P_GRAPH', '1')
+        with_group = run(dp)
         assert dp.max_over_ranks(1.25) == 1.25
         dp.barrier()
     finally:

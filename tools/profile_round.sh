@@ -6,13 +6,13 @@ python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err
 for P in vizdoom vizdoom_k25; do
   python bench.py --preset $P --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_$P.json 2>> gpurun_out/${TAG}_bench.err
 done
-# kernel trace: eager one-stream launches (per-kernel durations), then the captured graph
-D2P_NO_GRAPH=1 bash tools/profile_bench.sh ${TAG}s > /dev/null 2>&1
+# kernel trace: eager one-stream launches (per-kernel durations), then the default two-stream schedule
+D2P_NO_SIDE_STREAM=1 bash tools/profile_bench.sh ${TAG}s > /dev/null 2>&1
 DB=$(find gpurun_out/prof_${TAG}s -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_serial.md
 bash tools/profile_bench.sh ${TAG}g > /dev/null 2>&1
 DB=$(find gpurun_out/prof_${TAG}g -name "*.db" | head -1)
-python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_graph.md
+python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_default.md
 # HBM traffic counters, one counter per pass
 bash tools/profile_pmc.sh $TAG > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_$TAG gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_traffic.md
