@@ -684,12 +684,21 @@ class Model(object):
             # ---- SecondPathEncoder backward: only the final states carry gradient
             e2 = ctx['e2']
             dh0_2, dc0_2 = self._buf('dh0_2', (M, U)), self._buf('dc0_2', (M, U))
-            d_hout1 = self._lstm_bwd(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2, want_dx=True)
+            # (its weight gradients go to the side stream: two large GEMMs beside the next recurrence)
+            dz2 = self._lstm_bwd_rec(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2)
+            d_hout1 = self._lstm_bwd_dx(e2, dz2)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._lstm_bwd_weights(e2, dz2)
             # summary = mean_k(step-1 final states), broadcast to every demo of the program
             K.group_mean_bwd(None, dh0_2, d_h1f, B, k, U, False)
             K.group_mean_bwd(None, dc0_2, d_c1f, B, k, U, False)
         # ---- Demo_Encoder LSTM backward
-        d_feats_tm = self._lstm_bwd(ctx['e1'], d_hout1, d_h1f, d_c1f, None, None, want_dx=True)
+        dz1 = self._lstm_bwd_rec(ctx['e1'], d_hout1, d_h1f, d_c1f, None, None)
+        d_feats_tm = self._lstm_bwd_dx(ctx['e1'], dz1)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self._lstm_bwd_weights(ctx['e1'], dz1)
         d_feats = K.transpose_rt(d_feats_tm.view(T, M, F), T, M, F, out=self._buf('d_feats', (M, T, F)))
 
         # ---- State_Encoder backward
@@ -725,6 +734,21 @@ class Model(object):
     def _lstm_bwd_params(self, e, dz, want_dx):
         """Kernel / bias gradients and dX [n*M, I] from dz (independent of the recurrence order:
         three large GEMMs that may run on a side stream)."""
+        self._lstm_bwd_weights(e, dz)
+        return self._lstm_bwd_dx(e, dz) if want_dx else None
+
+    def _lstm_bwd_dx(self, e, dz):
+        """dX [n*M, I] = dZ Wx^T: the only product of dz the rest of backward waits for."""
+        name, M, T, n, I = e['name'], e['M'], e['T'], e['n'], e['I']
+        U = self.num_lstm_cell_units
+        rows = n * M
+        dx = self._buf(name + '/dx', (T * M, I))
+        if rows > 0:
+            K.gemm_raw('nt', rows, I, 4 * U, dz[:rows], 4 * U, e['Wx'], 4 * U, dx, I)
+        return dx
+
+    def _lstm_bwd_weights(self, e, dz):
+        """Kernel / bias gradients from dz: nothing downstream reads them before the optimizer."""
         g = self.params.g
         name, M, T, n, I = e['name'], e['M'], e['T'], e['n'], e['I']
         U = self.num_lstm_cell_units
@@ -745,12 +769,6 @@ class Model(object):
             K.gemm_raw('tn', U, 4 * U, (n - 1) * M, hout2d, U, dz[M:], 4 * U, gk[I:], 4 * U)
         else:
             gk[I:].zero_()
-        if not want_dx:
-            return None
-        dx = self._buf(name + '/dx', (T * M, I))
-        if rows > 0:
-            K.gemm_raw('nt', rows, I, 4 * U, dz_n, 4 * U, e['Wx'], 4 * U, dx, I)
-        return dx
 
     def _lstm_bwd(self, e, dhout, dh_final, dc_final, dh0, dc0, want_dx):
         """Backward of _lstm_fwd.  Writes the kernel / bias gradients; returns dX [n*M, I]."""
