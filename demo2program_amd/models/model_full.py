@@ -626,29 +626,45 @@ class Model(object):
             #      initial-state gradients that feed the summarizer / encoder backward
             bspecs = [(ctx['dp'], dl_p, d_init_h, d_init_c), (ctx['da'], dl_a, d_demo_h, d_demo_c),
                       (ctx['dq'], dl_q, tmp_h, tmp_c)]
-            if self.fuse_decoders:
-                dz_p, dz_a, dz_q = self._decoders_bwd_rec(bspecs)
-            else:
-                dz_p, dz_a, dz_q = [self._decoders_bwd_rec([sp])[0] for sp in bspecs]
-            K.axpy(1.0, tmp_h, d_demo_h)
-            K.axpy(1.0, tmp_c, d_demo_c)
 
-            # ---- side stream: the decoders' weight / input gradients (9 large GEMMs, ~100 GFLOP,
-            #      MFMA-bound) are not needed by the rest of backward; they overlap the encoder's
-            #      backward recurrences, which are latency-bound.
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                dx_p = self._lstm_bwd_params(ctx['dp'], dz_p, True)
+            # ---- side stream: each decoder's weight / input gradients (three large GEMMs) are not needed
+            #      by the rest of backward.  The action and perception decoders' are forked right after
+            #      their own recurrence, so that they run beside the program decoder's recurrence -- 32
+            #      rows: its persistent kernel occupies half of the CUs -- and the summarizer / encoder
+            #      recurrences after it
+            def prog_grads(dz):
+                dx_p = self._lstm_bwd_params(ctx['dp'], dz, True)
                 K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
-                dx_a = self._lstm_bwd_params(ctx['da'], dz_a, True)
+
+            def act_grads(dz):
+                dx_a = self._lstm_bwd_params(ctx['da'], dz, True)
                 K.embedding_scatter_add(ctx['ids_a'], dx_a, g['act/embedding'], n=n_d * M)
-                dx_q = self._lstm_bwd_params(ctx['dq'], dz_q, True)
+
+            def per_grads(dz):
+                dx_q = self._lstm_bwd_params(ctx['dq'], dz, True)
                 if n_d < T:
                     dx_q[n_d * M:].zero_()
                 d_pe_a = K.bn_bwd(ctx['pe_a'], dx_q, p['per/fc/gamma'], ctx['pe_mean'], ctx['pe_rstd'], k, 1,
                                   False, g['per/fc/gamma'], g['per/fc/beta'], dx=self._buf('d_pe_a', (T * M, U)),
                                   dbias=g['per/fc/b'])
                 K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
+            grads = (prog_grads, act_grads, per_grads)
+            if self.fuse_decoders:
+                dzs = self._decoders_bwd_rec(bspecs)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    for fn, dz in zip(grads, dzs):
+                        fn(dz)
+            else:
+                # action, perception, then program: measured 4.49 ms per step against 4.70 for one fork
+                # after all three recurrences and 4.73 for program first (profiles/r02x_decoder_order.txt)
+                for i in (1, 2, 0):
+                    dz = self._decoders_bwd_rec([bspecs[i]])[0]
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        grads[i](dz)
+            K.axpy(1.0, tmp_h, d_demo_h)
+            K.axpy(1.0, tmp_c, d_demo_c)
             if split_cb is not None:
                 main.wait_stream(side)
                 split_cb()
