@@ -403,6 +403,7 @@ def main():
     for i in range(args.steps):
         loss = trainer.train_step(feeds[i % len(feeds)])
         marks[i + 1].record()             # device-side step boundaries (no host sync inside the region)
+    host_enqueue = time.perf_counter() - t0   # host time to ENQUEUE the K steps (device may still be running)
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -436,6 +437,7 @@ def main():
         },
         'demo_instances_per_sec': round(value * config.k, 1),
         'device_step_ms': step_stats,
+        'host_enqueue_ms_per_step': round(host_enqueue * 1e3 / args.steps, 4),
         'final_loss': round(final_loss, 5),
     }
 

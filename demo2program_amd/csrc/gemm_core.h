@@ -472,15 +472,291 @@ gemm_splitk_reduce_flat_kernel(EP ep, const float* partial, int M, int N, int nz
 }
 
 // ------------------------------------------------------------------------------------
+// LDS-DMA pipeline for the large dense GEMMs (K a multiple of 32, 16-byte aligned operands).
+//
+// The kernel above stages every operand slab global -> VGPR -> ds_write -> LDS, and hipcc sinks the
+// global loads next to their LDS stores: a wave waits a full L2 round trip per slab and the MFMA
+// pipe is kept busy only by the other resident waves (0.64 of the fp32 MFMA peak at best, every
+// tile shape).  Here the operand slabs go global -> LDS directly (global_load_lds_dwordx4: 64 lanes
+// x 16 bytes land at a wave-uniform LDS base + lane*16) into a ring of STAGES slabs, so a slab is
+// requested STAGES-1 slabs of MFMA time before it is consumed, costs no VGPRs and no ds_write
+// issue, and the only waits in the K loop are one counted vmcnt + one barrier per 32-deep slab.
+//
+// LDS layouts (unpadded -- the DMA destination is linear in the lane index):
+//   KCONTIG operand: [x][32 k] rows of 128 bytes; the 16-byte chunk c of row x sits at chunk
+//     position c ^ ((x >> 1) & 7).  A DMA instruction covers 8 rows; its 8 lanes per row read one
+//     whole 128-byte line (permuted) -> coalesced; ds_read_b128 of chunk c over 32 rows touches
+//     every 16-byte slot of the 256-byte bank row once per 16-lane service group
+//     (MI355X_MICROARCH.md, LDS: groups {0-3,12-15,20-27} ...) -> conflict-free.
+//   XCONTIG operand: [32 k][BX]; a DMA instruction covers 256 consecutive floats; ds_read_b32 with
+//     lanes 0-31 on consecutive floats -> conflict-free.
+// The k indices are consumed in the same order as in gemm_mfma_kernel, so the two kernels give
+// bit-identical results for the same split of K.
+// ------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void d2p_lds_void;
+typedef __attribute__((address_space(1))) const void d2p_glb_void;
+
+template <int N>
+__device__ __forceinline__ void d2p_wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// A fifth wave issues every DMA of the workgroup: hipcc's wait-count pass cannot tell which LDS bytes an
+// outstanding global_load_lds will write and puts s_waitcnt vmcnt(0) in front of every ds_read that
+// follows one IN THE SAME WAVE -- the prefetch distance collapses to zero.  The producer wave reads no
+// LDS; the four MFMA waves issue no DMA.
+//
+// Workgroups are PERSISTENT: workgroup w takes the work items (output tile x K split) w, w+G, w+2G, ...
+// and its producer streams their slabs back to back through the ring, so the first slabs of the next tile
+// land while the MFMA waves store the current one: the per-tile prologue (address setup + an L2/HBM
+// round trip with an idle matrix pipe) is paid once per workgroup, not once per tile.
+#define D2P_DMA_THREADS 320
+template <int BM, int BN, int WM, int WN, int STAGES, class AL, class BL, class EP>
+__global__ void __launch_bounds__(D2P_DMA_THREADS)
+gemm_dma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, int splits, float* partial) {
+    static_assert(WM * WN == 4, "4 MFMA waves per workgroup");
+    static_assert(STAGES >= 2 && STAGES <= 4, "ring depth");
+    constexpr int BK = 32;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_SZ = BM * BK, B_SZ = BN * BK, ST = A_SZ + B_SZ;   // floats per stage
+    constexpr int NA = BM / 8, NB = BN / 8;        // DMA instructions per slab (64 lanes x 16 bytes = 256 floats each)
+    constexpr int NI = NA + NB;
+    static_assert((STAGES - 1) * NI <= 96, "the producer keeps at most STAGES-1 slabs of requests in flight");
+    extern __shared__ __attribute__((aligned(16))) float dma_smem[];
+
+    if constexpr (d2p_batch_ok<EP>::value) {
+        if (gridDim.y > 1) {
+            al.shift(blockIdx.y);
+            bl.shift(blockIdx.y);
+            ep.shift(blockIdx.y);
+        }
+    }
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nbn = (N + BN - 1) / BN;
+    const int ntiles = ((M + BM - 1) / BM) * nbn;
+    const int nitems = ntiles * splits;            // item = split * ntiles + tile
+    const int G = gridDim.x;
+
+    if (wave == 4) {
+        // ---- producer
+        const float* pa[NA];
+        const float* pb[NB];
+        const long astep = AL::KCONTIG ? (long)BK : (long)BK * al.ld;     // floats per slab
+        const long bstep = BL::KCONTIG ? (long)BK : (long)BK * bl.ld;
+        int item = blockIdx.x, slab = 0, nk = 0;   // cursor of the NEXT slab to request
+        auto open_item = [&]() {                   // per-lane source pointers of the item's slab-0 requests
+            const int tile = item % ntiles, sp = item / ntiles;
+            const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+            const int kbeg = sp * k_per_split;
+            nk = (min(K, kbeg + k_per_split) - kbeg) / BK;
+            slab = 0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int u = i * 64 + lane;                              // 16-byte unit of the stage
+                if (AL::KCONTIG) {
+                    const int row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
+                    pa[i] = al.p + (long)min(m0 + row, al.X - 1) * al.ld + kbeg + 4 * c;
+                } else {
+                    const int k = u / (BM / 4), xq = u % (BM / 4);
+                    pa[i] = al.p + (long)(kbeg + k) * al.ld + min(m0 + 4 * xq, al.X - 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int u = i * 64 + lane;
+                if (BL::KCONTIG) {
+                    const int row = u >> 3, c = (u & 7) ^ ((row >> 1) & 7);
+                    pb[i] = bl.p + (long)min(n0 + row, bl.X - 1) * bl.ld + kbeg + 4 * c;
+                } else {
+                    const int k = u / (BN / 4), xq = u % (BN / 4);
+                    pb[i] = bl.p + (long)(kbeg + k) * bl.ld + min(n0 + 4 * xq, bl.X - 4);
+                }
+            }
+        };
+        int pbuf = 0;
+        // requests the cursor's slab into stage pbuf and advances; returns false past the last item
+        auto issue = [&]() -> bool {
+            if (item >= nitems) return false;
+            float* As = dma_smem + pbuf * ST;
+            float* Bs = As + A_SZ;
+#pragma unroll
+            for (int i = 0; i < NA; ++i)
+                __builtin_amdgcn_global_load_lds((d2p_glb_void*)(pa[i] + slab * astep), (d2p_lds_void*)(As + i * 256), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_global_load_lds((d2p_glb_void*)(pb[i] + slab * bstep), (d2p_lds_void*)(Bs + i * 256), 16, 0, 0);
+            pbuf = (pbuf + 1 == STAGES) ? 0 : pbuf + 1;
+            if (++slab == nk) {
+                item += G;
+                if (item < nitems) open_item();
+            }
+            return true;
+        };
+        // total slabs of this workgroup
+        int Q = 0;
+        for (int it = blockIdx.x; it < nitems; it += G) {
+            const int kbeg = (it / ntiles) * k_per_split;
+            Q += (min(K, kbeg + k_per_split) - kbeg) / BK;
+        }
+        open_item();
+        int ahead = 0;                             // slabs requested and not yet handed over
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s) ahead += issue() ? 1 : 0;
+        for (int q = 0; q < Q; ++q) {
+            // slab q must have landed: the requests behind it are those of the ahead-1 later slabs
+            if (ahead >= STAGES - 1) d2p_wait_vmcnt<(STAGES - 2) * NI>();
+            else if (STAGES >= 4 && ahead == 2) d2p_wait_vmcnt<NI>();
+            else d2p_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();          // hand it over; the MFMA waves are done with slab q-1
+            ahead += (issue() ? 1 : 0) - 1;        // into the stage slab q-1 occupied
+        }
+        return;
+    }
+
+    const int l32 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    // fragment addresses inside a stage (floats)
+    const int g8 = (l32 >> 1) & 7;
+    int aoff[TM], boff[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int x = wm * (BM / WM) + i * 32 + l32;
+        aoff[i] = AL::KCONTIG ? x * BK : x;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int x = wn * (BN / WN) + i * 32 + l32;
+        boff[i] = A_SZ + (BL::KCONTIG ? x * BK : x);
+    }
+    int cp[BK / 8];
+#pragma unroll
+    for (int kk = 0; kk < BK / 8; ++kk) cp[kk] = ((2 * kk + hi) ^ g8) * 4;
+
+    int buf = 0;
+    for (int item = blockIdx.x; item < nitems; item += G) {
+        const int tile = item % ntiles, sp = item / ntiles;
+        const int m0 = (tile / nbn) * BM, n0 = (tile % nbn) * BN;
+        const int kbeg = sp * k_per_split;
+        const int nk = (min(K, kbeg + k_per_split) - kbeg) / BK;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        for (int s = 0; s < nk; ++s) {
+            __builtin_amdgcn_s_barrier();          // slab s is in LDS (the producer waited for it)
+            const float* S = dma_smem + buf * ST;
+            float fa[2][TM][4], fb[2][TN][4];      // fragments of chunk kk in set kk & 1: read one chunk ahead
+            auto read_chunk = [&](int kk, int set) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if (AL::KCONTIG) {
+                        const float4 t = *reinterpret_cast<const float4*>(&S[aoff[i] + cp[kk]]);
+                        fa[set][i][0] = t.x; fa[set][i][1] = t.y; fa[set][i][2] = t.z; fa[set][i][3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fa[set][i][j] = S[aoff[i] + (kk * 8 + 4 * hi + j) * BM];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    if (BL::KCONTIG) {
+                        const float4 t = *reinterpret_cast<const float4*>(&S[boff[i] + cp[kk]]);
+                        fb[set][i][0] = t.x; fb[set][i][1] = t.y; fb[set][i][2] = t.z; fb[set][i][3] = t.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) fb[set][i][j] = S[boff[i] + (kk * 8 + 4 * hi + j) * BN];
+                    }
+                }
+            };
+            read_chunk(0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                if (kk + 1 < BK / 8) read_chunk(kk + 1, (kk + 1) & 1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < TN; ++jj)
+                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][i][j], fb[kk & 1][jj][j],
+                                                                              acc[i][jj], 0, 0, 0);
+                // the next chunk's LDS reads go out BEFORE this chunk's MFMAs (left alone, hipcc sinks them behind
+                // the MFMAs and the wave idles an LDS round trip per chunk)
+                if (kk + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+            }
+            buf = (buf + 1 == STAGES) ? 0 : buf + 1;
+        }
+
+        const bool split = splits > 1;
+        const bool with_c = !split && ep.has_c();
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / WN) + j * 32 + l32;
+                const int rbase = m0 + wm * (BM / WM) + i * 32 + 4 * hi;
+                if (col >= N) continue;
+                const float cv = split ? 0.f : ep.col_value(col);
+                float cold[16];
+                if (with_c) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        cold[r] = row < M ? ep.c_value(row, col) : 0.f;
+                    }
+                }
+                // every load of the epilogue is complete before its first store: the K loop of the next item
+                // then never waits on vmcnt (on gfx9 that counter also holds the stores -- a wait there would
+                // stall the next tile on this tile's write-back)
+                __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < M) {
+                        if (split) partial[((long)sp * M + row) * N + col] = acc[i][j][r];
+                        else ep.store(row, col, acc[i][j][r] + (with_c ? cold[r] : 0.f) + cv);
+                    }
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // Host-side launch policy shared by gemm.hip and conv.hip.
 // ------------------------------------------------------------------------------------
 static int g_gemm_bk32 = 0;   // per translation unit; toggled through d2p_gemm_set_option
 static int g_gemm_nosel = 1;  // 0: always keep the select between global load and LDS store
 static int g_gemm_force_tile = -1;   // -1: automatic; else a GemmTile value (tuning experiments)
 static int g_gemm_force_split = 0;   // 0: automatic
+static int g_gemm_dma_grid = 0;      // 0: CUs x resident workgroups per CU; else the persistent grid (tuning)
+static inline int d2p_gemm_num_cus() {
+    static int n = 0;
+    if (n <= 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else return 256;
+    }
+    return n;
+}
 
 enum GemmTile { TILE_64x64 = 0, TILE_128x128 = 1, TILE_128x32 = 2, TILE_256x32 = 3, TILE_128x64 = 4,
-                TILE_64x32_KS = 5, TILE_64x64_KS = 6, TILE_32x32_KSR = 7 };
+                TILE_64x32_KS = 5, TILE_64x64_KS = 6, TILE_32x32_KSR = 7,
+                // LDS-DMA pipeline (gemm_dma_kernel), dense operands with K % 32 == 0 only
+                TILE_DMA_64x64_S4 = 8, TILE_DMA_64x64_S3 = 9, TILE_DMA_128x64_S3 = 10, TILE_DMA_128x128_S2 = 11,
+                TILE_DMA_128x128_S3 = 12, TILE_COUNT = 13 };
+static inline bool d2p_tile_is_dma(int t) { return t >= TILE_DMA_64x64_S4 && t < TILE_COUNT; }
+static inline int d2p_tile_stages(int t) {
+    return t == TILE_DMA_64x64_S4 ? 4 : (t == TILE_DMA_128x128_S2 ? 2 : 3);
+}
 
 struct GemmPlan {
     int tile;     // GemmTile
@@ -517,7 +793,8 @@ static inline GemmPlan d2p_plan_gemm_base(int M, int N, int K, bool allow_split)
     }
     if (g_gemm_force_tile >= 0) {
         p.tile = g_gemm_force_tile;
-        const int bms[8] = {64, 128, 128, 256, 128, 64, 64, 32}, bns[8] = {64, 128, 32, 32, 64, 32, 64, 32};
+        const int bms[TILE_COUNT] = {64, 128, 128, 256, 128, 64, 64, 32, 64, 64, 128, 128, 128};
+        const int bns[TILE_COUNT] = {64, 128, 32, 32, 64, 32, 64, 32, 64, 64, 64, 128, 128};
         p.bm = bms[p.tile]; p.bn = bns[p.tile];
     }
     if (p.tile == TILE_32x32_KSR) {                      // forced (tuning): one slab per workgroup
@@ -617,6 +894,37 @@ static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int
                            al, bl, ep, M, N, K, p.k_per_split, partial);
 }
 
+template <int BM, int BN, int WM, int WN, int STAGES, class AL, class BL, class EP>
+static int d2p_launch_dma_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K, const GemmPlan& p,
+                               float* partial, hipStream_t st, int batch) {
+    constexpr int lds_bytes = STAGES * (BM + BN) * 32 * (int)sizeof(float);
+    auto kern = gemm_dma_kernel<BM, BN, WM, WN, STAGES, AL, BL, EP>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        D2P_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_set = true;
+    }
+    // persistent workgroups: as many as fit the chip at once (LDS-bound), never more than the work items
+    const int per_cu = (160 * 1024) / lds_bytes;
+    const long items = (long)ceil_div(M, BM) * ceil_div(N, BN) * p.splits;
+    long g = (long)d2p_gemm_num_cus() * per_cu;
+    if (g_gemm_dma_grid > 0) g = g_gemm_dma_grid;
+    if (g > items) g = items;
+    dim3 grid((unsigned)g, batch, 1);
+    hipLaunchKernelGGL(kern, grid, dim3(D2P_DMA_THREADS), lds_bytes, st, al, bl, ep, M, N, K, p.k_per_split, p.splits,
+                       partial);
+    return D2P_OK;
+}
+
+// dense operands the DMA pipeline can take: 16-byte aligned rows, whole 32-deep slabs in every split, and at
+// least STAGES-1 slabs in the shortest split
+template <class AL, class BL>
+static inline bool d2p_dma_shape_ok(const AL& al, const BL& bl, int K, const GemmPlan& p, int stages) {
+    if (!(al.fast_ok(K) && bl.fast_ok(K)) || K % 32 != 0 || p.k_per_split % 32 != 0) return false;
+    const int last = K - (p.splits - 1) * p.k_per_split;
+    return last >= (stages - 1) * 32 && p.k_per_split >= (stages - 1) * 32;
+}
+
 template <class AL, class BL, class EP>
 static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
                            void* ws, size_t ws_bytes, hipStream_t st, const char* name,
@@ -635,7 +943,27 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         }
     }
     const bool fast = al.fast_ok(K) && bl.fast_ok(K);
+    if (d2p_tile_is_dma(p.tile)) {
+        bool done = false;
+        if constexpr (d2p_nosel_ok<AL>::value && d2p_nosel_ok<BL>::value && d2p_batch_ok<EP>::value) {
+            if (d2p_dma_shape_ok(al, bl, K, p, d2p_tile_stages(p.tile))) {
+                int rc = D2P_OK;
+                switch (p.tile) {
+                    case TILE_DMA_64x64_S4: rc = d2p_launch_dma_tile<64, 64, 2, 2, 4>(al, bl, ep, M, N, K, p, partial, st, batch); break;
+                    case TILE_DMA_64x64_S3: rc = d2p_launch_dma_tile<64, 64, 2, 2, 3>(al, bl, ep, M, N, K, p, partial, st, batch); break;
+                    case TILE_DMA_128x64_S3: rc = d2p_launch_dma_tile<128, 64, 2, 2, 3>(al, bl, ep, M, N, K, p, partial, st, batch); break;
+                    case TILE_DMA_128x128_S2: rc = d2p_launch_dma_tile<128, 128, 2, 2, 2>(al, bl, ep, M, N, K, p, partial, st, batch); break;
+                    default: rc = d2p_launch_dma_tile<128, 128, 2, 2, 3>(al, bl, ep, M, N, K, p, partial, st, batch); break;
+                }
+                if (rc) return rc;
+                done = true;
+            }
+        }
+        if (!done) p.tile = (p.bm == 64) ? TILE_64x64 : (p.bn == 64 ? TILE_128x64 : TILE_128x128);   // staged form
+    }
     switch (p.tile) {
+        case TILE_DMA_64x64_S4: case TILE_DMA_64x64_S3: case TILE_DMA_128x64_S3: case TILE_DMA_128x128_S2:
+        case TILE_DMA_128x128_S3: break;            // launched above
         case TILE_128x128: d2p_launch_tile<128, 128, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
         case TILE_128x32: d2p_launch_tile<128, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
         case TILE_256x32: d2p_launch_tile<256, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;

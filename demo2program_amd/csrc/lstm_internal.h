@@ -15,6 +15,42 @@ __host__ __device__ __forceinline__ long d2p_frag_off(int row, int k, int KCx) {
     return ((((long)(row >> 4) * KCx + (k >> 4)) * 64) + (((k & 15) >> 2) << 4) + (row & 15)) * 4;
 }
 
+// One element (a float4) of the packed operands; idx is the float4 index in the packed image.
+// Forward B operand: Wf[((ct*KC + kc)*2 + cs)*64 + lane], ct = 8-unit column tile, local column
+// j = cs*16 + (lane&15) -> gate j>>3, unit ct*8 + (j&7); k = kc*16 + 4*(lane>>4) + jj
+__device__ __forceinline__ float4 d2p_pack_w_fwd_elem(int U, const float* __restrict__ Wh, long idx) {
+    const int KC = U >> 4;
+    const int lane = (int)(idx & 63);
+    const int cs = (int)((idx >> 6) & 1);
+    const long r = idx >> 7;
+    const int kc = (int)(r % KC), ct = (int)(r / KC);
+    const int j = cs * 16 + (lane & 15);
+    const long col = (long)(j >> 3) * U + ct * 8 + (j & 7);
+    const int k = kc * 16 + 4 * (lane >> 4);
+    const long ld = 4L * U;
+    return make_float4(Wh[(k + 0) * ld + col], Wh[(k + 1) * ld + col], Wh[(k + 2) * ld + col], Wh[(k + 3) * ld + col]);
+}
+// Backward B operand (Wh^T): Wb[(nt*KC4 + kc)*64 + lane], n = nt*16 + (lane&15) (unit),
+// k = kc*16 + 4*(lane>>4) (gate column): value Wh[n][k..k+3] -- a straight float4 copy.
+__device__ __forceinline__ float4 d2p_pack_w_bwd_elem(int U, const float* __restrict__ Wh, long idx) {
+    const int KC4 = U >> 2;
+    const int lane = (int)(idx & 63);
+    const long r = idx >> 6;
+    const int kc = (int)(r % KC4), nt = (int)(r / KC4);
+    const int n = nt * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4);
+    return *reinterpret_cast<const float4*>(Wh + (long)n * 4 * U + k);
+}
+// A operand from a row-major [M, K] matrix: Af[(rs*KCx + kc)*64 + lane], row = rs*16 + (lane&15);
+// rows >= M are zeros
+__device__ __forceinline__ float4 d2p_pack_rows_elem(int M, int K, const float* __restrict__ X, long idx) {
+    const int KCx = K >> 4;
+    const int lane = (int)(idx & 63);
+    const long r = idx >> 6;
+    const int kc = (int)(r % KCx), rs = (int)(r / KCx);
+    const int row = rs * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4);
+    return row < M ? *reinterpret_cast<const float4*>(X + (long)row * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // persistent-sequence back end (lstm_persist.hip)
 int d2p_lstm_is_persistent_enabled();
 bool d2p_lstm_persist_fwd_ok(int M, int U, int n_steps);

@@ -960,6 +960,40 @@ size_t d2p_lstm_persist_ws_bytes(int M, int U) {
     return ((size_t)4 * U * U + 2 * Mp * 4 * U) * sizeof(float) + PS_FLAG_WORDS * sizeof(unsigned) + PS_DUMP_FLOATS * sizeof(float);
 }
 
+// Everything a persistent launch needs prepared, in ONE launch instead of three (weight pack, initial-state
+// pack or zero fill, flag reset): the recurrences sit on the critical path of the step and every extra
+// dependent launch in front of them costs its few microseconds plus a kernel boundary.
+//   [0, nW)            packed weights (forward or backward image)
+//   [nW, nW + nA)      float4s of the initial operand buffer: rows of X in fragment order, or zeros if X is null
+//   [.., + nF)         flag words (one uint4 = 4 flags per index)
+__global__ void __launch_bounds__(256)
+ps_prep_kernel(int bwd, int U, const float* __restrict__ Wh, float4* __restrict__ Wp, long nW, int M,
+               const float* __restrict__ X, float4* __restrict__ Af, long nA, uint4* __restrict__ flags, long nF) {
+    const long total = nW + nA + nF;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        if (idx < nW) {
+            Wp[idx] = bwd ? d2p_pack_w_bwd_elem(U, Wh, idx) : d2p_pack_w_fwd_elem(U, Wh, idx);
+        } else if (idx < nW + nA) {
+            const long i = idx - nW;
+            Af[i] = X ? d2p_pack_rows_elem(M, U, X, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        } else {
+            flags[idx - nW - nA] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+static int ps_prep(int bwd, int U, const float* Wh, float* Wp, int M, const float* X, float* Af, size_t af_bytes,
+                   unsigned* flags, size_t nflags, hipStream_t st) {
+    const long nW = (long)U * U;                       // 4U^2 floats
+    const long nA = (long)(af_bytes / 16);
+    const long nF = (long)((nflags + 3) / 4);          // the flag area is PS_FLAG_WORDS (a multiple of 4) long
+    long blocks = (nW + nA + nF + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(ps_prep_kernel, dim3((unsigned)blocks), dim3(256), 0, st, bwd, U, Wh, (float4*)Wp, nW, M, X,
+                       (float4*)Af, nA, (uint4*)flags, nF);
+    D2P_LAUNCH_CHECK("lstm_persist_prep");
+    return D2P_OK;
+}
+
 int d2p_lstm_persist_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, const float* Wh,
                          const float* h0, const float* c0, const int* lens, float* hout, float* cs,
                          float* h_final, float* c_final, float* ws, hipStream_t st) {
@@ -980,16 +1014,10 @@ int d2p_lstm_persist_fwd(int M, int U, int n_steps, float* z, long zrs, long zts
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = z; a.zrs = zrs; a.zts = zts; a.h0 = h0; a.c0 = c0; a.lens = lens;
     a.hout = hout; a.cs = cs; a.h_final = h_final; a.c_final = c_final;
-    int rc = d2p_lstm_pack_w_fwd(U, Wh, Wf, st);
+    // packed weights; h0 in fragment order (without one the deferred-epilogue form still multiplies in step 0:
+    // an all-zero operand makes that product an exact zero); flags reset
+    int rc = ps_prep(0, U, Wh, Wf, M, h0, a.hfrag, a.hfrag_bytes, a.flags, (size_t)a.RT * PS_NRS_MAX * nct, st);
     if (rc) return rc;
-    if (h0) {
-        rc = d2p_lstm_pack_rows(M, U, a.total_rs, h0, a.hfrag, st);
-        if (rc) return rc;
-    } else {
-        // the deferred-epilogue form multiplies in every step: make the step-0 product an exact zero
-        D2P_HIP(hipMemsetAsync(a.hfrag, 0, a.hfrag_bytes, st));
-    }
-    D2P_HIP(hipMemsetAsync(a.flags, 0, (size_t)a.RT * PS_NRS_MAX * nct * sizeof(unsigned), st));
     const int blocks = nct * a.RT;
     {
         D2pProfScope prof(st, D2P_PROF_LSTM_STEP_FWD, 2.0 * M * 4.0 * U * U * (n_steps - (h0 ? 0 : 1)));
@@ -1026,11 +1054,10 @@ int d2p_lstm_persist_bwd(int M, int U, int n_steps, const float* z, long zrs, lo
     a.z = z; a.zrs = zrs; a.zts = zts; a.c0 = c0; a.cs = cs; a.lens = lens;
     a.dhout = dhout; a.dh_final = dh_final; a.dc_final = dc_final;
     a.dz = dz; a.dh0 = dh0; a.dc0 = dc0;
-    int rc = d2p_lstm_pack_w_bwd(U, Wh, Wb, st);
+    // packed Wh^T; pass 0 has no product -- the chain runs on an all-zero dz[T]; flags reset
+    int rc = ps_prep(1, U, Wh, Wb, M, nullptr, (float*)((char*)a.dzfrag + (size_t)(n_steps & 1) * a.dzfrag_bytes),
+                     a.dzfrag_bytes, a.flags, (size_t)a.RT * PS_NRS_MAX * nnt, st);
     if (rc) return rc;
-    // pass 0 has no product: the chain runs on an all-zero dz[T]
-    D2P_HIP(hipMemsetAsync((char*)a.dzfrag + (size_t)(n_steps & 1) * a.dzfrag_bytes, 0, a.dzfrag_bytes, st));
-    D2P_HIP(hipMemsetAsync(a.flags, 0, (size_t)a.RT * PS_NRS_MAX * nnt * sizeof(unsigned), st));
     const int blocks = nnt * a.RT;
     {
         D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, 2.0 * M * 4.0 * U * U * (n_steps - 1 + (dh0 ? 1 : 0)));

@@ -38,52 +38,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------
 // Packing kernels (HBM-bound copies, once per sequence call / per initial state)
 // ---------------------------------------------------------------------------------------
-// Forward B operand: Wf[((ct*KC + kc)*2 + cs)*64 + lane] (float4), ct = 8-unit column tile,
-// local column j = cs*16 + (lane&15) -> gate j>>3, unit ct*8 + (j&7); k = kc*16 + 4*(lane>>4)+jj
+// (element formulas: lstm_internal.h)
 __global__ void __launch_bounds__(256)
 pack_w_fwd_kernel(int U, const float* __restrict__ Wh, float4* __restrict__ Wf) {
-    const int KC = U >> 4;
-    const long total = (long)(U >> 3) * KC * 2 * 64;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-        const int lane = (int)(idx & 63);
-        const int cs = (int)((idx >> 6) & 1);
-        const long r = idx >> 7;
-        const int kc = (int)(r % KC), ct = (int)(r / KC);
-        const int j = cs * 16 + (lane & 15);
-        const long col = (long)(j >> 3) * U + ct * 8 + (j & 7);
-        const int k = kc * 16 + 4 * (lane >> 4);
-        const long ld = 4L * U;
-        Wf[idx] = make_float4(Wh[(k + 0) * ld + col], Wh[(k + 1) * ld + col], Wh[(k + 2) * ld + col],
-                              Wh[(k + 3) * ld + col]);
-    }
+    const long total = (long)(U >> 3) * (U >> 4) * 2 * 64;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L)
+        Wf[idx] = d2p_pack_w_fwd_elem(U, Wh, idx);
 }
-// Backward B operand (Wh^T): Wb[(nt*KC4 + kc)*64 + lane], n = nt*16 + (lane&15) (unit),
-// k = kc*16 + 4*(lane>>4) (gate column): value Wh[n][k..k+3] -- a straight float4 copy.
 __global__ void __launch_bounds__(256)
 pack_w_bwd_kernel(int U, const float* __restrict__ Wh, float4* __restrict__ Wb) {
-    const int KC4 = U >> 2;
-    const long total = (long)(U >> 4) * KC4 * 64;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-        const int lane = (int)(idx & 63);
-        const long r = idx >> 6;
-        const int kc = (int)(r % KC4), nt = (int)(r / KC4);
-        const int n = nt * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4);
-        Wb[idx] = *reinterpret_cast<const float4*>(Wh + (long)n * 4 * U + k);
-    }
+    const long total = (long)(U >> 4) * (U >> 2) * 64;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L)
+        Wb[idx] = d2p_pack_w_bwd_elem(U, Wh, idx);
 }
-// A operand from a row-major [M, K] matrix: Af[(rs*KCx + kc)*64 + lane], row = rs*16+(lane&15)
 __global__ void __launch_bounds__(256)
 pack_rows_kernel(int M, int K, int total_rs, const float* __restrict__ X, float4* __restrict__ Af) {
-    const int KCx = K >> 4;
-    const long total = (long)total_rs * KCx * 64;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
-        const int lane = (int)(idx & 63);
-        const long r = idx >> 6;
-        const int kc = (int)(r % KCx), rs = (int)(r / KCx);
-        const int row = rs * 16 + (lane & 15), k = kc * 16 + 4 * (lane >> 4);
-        Af[idx] = row < M ? *reinterpret_cast<const float4*>(X + (long)row * K + k)
-                          : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    const long total = (long)total_rs * (K >> 4) * 64;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L)
+        Af[idx] = d2p_pack_rows_elem(M, K, X, idx);
 }
 
 static inline int pack_blocks(long total) {

@@ -253,22 +253,6 @@ class Model(object):
         #      whose step kernels leave most of the matrix pipe idle.
         main = torch.cuda.current_stream()
         side = self._side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            ids_p = K.shift_tokens_tm(feed['program_tokens'], V + 1, out=self._buf('ids_p', (L, B), torch.int32))
-            emb_p = K.embedding_gather(ids_p, p['prog/embedding'], out=self._buf('emb_p', (L * B, U)), n=n_p * B)
-            if self.multitask:
-                ids_a = K.shift_tokens_tm(feed['a_h_tokens'], A + 1, out=self._buf('ids_a', (T, M), torch.int32))
-                emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)),
-                                           n=n_d * M)
-                # Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
-                per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
-                pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
-                                   bias=p['per/fc/b'], act=0)
-                pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
-                z_a = self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d)
-                z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)
-            z_p = self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p)
 
         # ---- State_Encoder: conv -> +bias -> lrelu -> BN(train), per demo-index statistics
         x = feed['s_h']
@@ -293,9 +277,30 @@ class Model(object):
         feats = x.view(M, T, F)
         feats_tm = K.transpose_rt(feats, M, T, F, out=self._buf('feats_tm', (T, M, F)))
 
+        z_e1 = self._lstm_xproj('demo_lstm', feats_tm.view(T * M, F), F, M, T, T)
+        # (forked here, not at the start of the step: beside the chain of small conv / batch-norm launches
+        #  these GEMMs only took the CUs the chain was waiting for -- 320 us instead of 100 for the chain;
+        #  beside the first recurrence they fill matrix-pipe time its hand-offs leave)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            ids_p = K.shift_tokens_tm(feed['program_tokens'], V + 1, out=self._buf('ids_p', (L, B), torch.int32))
+            emb_p = K.embedding_gather(ids_p, p['prog/embedding'], out=self._buf('emb_p', (L * B, U)), n=n_p * B)
+            if self.multitask:
+                ids_a = K.shift_tokens_tm(feed['a_h_tokens'], A + 1, out=self._buf('ids_a', (T, M), torch.int32))
+                emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)),
+                                           n=n_d * M)
+                # Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
+                per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
+                pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
+                                   bias=p['per/fc/b'], act=0)
+                pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
+                z_a = self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d)
+                z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)
+            z_p = self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p)
+
         # ---- Demo_Encoder LSTM (zero initial state, length-masked)
         e1 = self._lstm_fwd('demo_lstm', feats_tm.view(T * M, F), F, M, T, T, None, None, lens_d,
-                            want_final=True)
+                            want_final=True, z=z_e1)
         if self.variant == 'synthesis_baseline':
             # model_synthesis.py:324-358: no second pass; the program decoder starts from the
             # demonstrations' final states pooled over k

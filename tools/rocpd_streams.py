@@ -2,14 +2,17 @@
 """Two-stream view of a rocprofv3 kernel trace (rocpd sqlite) of the default training schedule: for the
 last N steps (delimited by adam_clip_kernel) the wall span per step, per queue the busy time and its
 largest kernels, and the time the main queue ran alone / both queues ran.
-usage: tools/rocpd_streams.py <results.db> [steps=5]"""
+usage: tools/rocpd_streams.py <results.db> [steps=5] [--seq]     (--seq: also the last step's launches in
+start order: queue, start offset us, duration us, gap to the previous launch of the same queue, name)"""
 import sqlite3
 import sys
 
 
 def main():
-    db = sys.argv[1]
-    nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    seq = '--seq' in sys.argv
+    argv = [a for a in sys.argv if a != '--seq']
+    db = argv[1]
+    nsteps = int(argv[2]) if len(argv) > 2 else 5
     con = sqlite3.connect(db)
     cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
     q = 'queue_id' if 'queue_id' in cols else 'stream_id'
@@ -58,6 +61,17 @@ def main():
     print('idle %.3f ms/step, two queues active %.3f, one queue alone: %s' % (
         idle / 1e6 / nsteps, both / 1e6 / nsteps,
         ', '.join('q%s %.3f' % (k, v / 1e6 / nsteps) for k, v in alone.items())))
+    if seq:
+        one = rows[adam[-2] + 1:adam[-1] + 1]
+        base = one[0][1]
+        qids = {}
+        last_end = {}
+        for name, st, en, qq in one:
+            qi = qids.setdefault(qq, len(qids))
+            gap = (st - last_end[qq]) / 1e3 if qq in last_end else 0.0
+            last_end[qq] = en
+            print('q%d %9.1f %8.1f %7.1f  %s' % (qi, (st - base) / 1e3, (en - st) / 1e3, gap,
+                                                name.split('(')[0].replace('void ', '')[:70]))
 
 
 if __name__ == '__main__':
