@@ -75,10 +75,13 @@ int d2p_gemm_f32_batched(int kind, int nb1, int nb0, int M, int N, int K, const 
  * use 32-deep K slabs; bit 1 switches OFF the small-problem path (32x32 tiles whose four waves split
  * K and combine through LDS, picked when the ordinary plan would fill fewer than 128 workgroups);
  * bit 2 keeps the select between global load and LDS store even when K is a multiple of the slab
- * depth (the dense loaders then need none). */
+ * depth (the dense loaders then need none); bits 8 and up: persistent grid size of the LDS-DMA kernel
+ * (0 = CUs x resident workgroups per CU). */
 int d2p_gemm_set_option(int bk32);
-/* Tuning experiments only: force the tile (0 64x64, 1 128x128, 2 128x32, 3 256x32, 4 128x64; -1 auto)
- * and the split-K factor (0 auto) of the dense entry points. */
+/* Tuning experiments only: force the tile (0 64x64, 1 128x128, 2 128x32, 3 256x32, 4 128x64, 5-7 the K-split
+ * forms; 8-12 the LDS-DMA pipeline: 64x64 with a 4- / 3-deep ring, 128x64 3-deep, 128x128 2- / 3-deep, which
+ * falls back to the staged kernel of the same tile when the operands are not 16-byte aligned or K is not a
+ * multiple of 32; -1 auto) and the split-K factor (0 auto) of the dense entry points. */
 int d2p_gemm_force_plan(int tile, int splits);
 int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                     float* C, long ldc, const float* bias, int act, int accumulate,

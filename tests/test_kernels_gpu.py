@@ -126,6 +126,38 @@ def test_gemm_strided_batch(K, M, N, K_):
     close(one, ref[0, 0], **tol)
 
 
+@pytest.mark.parametrize('tile', [8, 9, 10, 11, 12])
+@pytest.mark.parametrize('M,N,K_,splits', [(640, 256, 512, 1), (1000, 320, 256, 1), (512, 2048, 1600, 4),
+                                            (130, 196, 96, 1), (6400, 512, 2048, 2)])
+def test_gemm_lds_dma_pipeline_equals_staged_kernel(K, tile, M, N, K_, splits):
+    """gemm_dma_kernel (forced through d2p_gemm_force_plan, tiles 8..12: persistent workgroups, operands DMA'd
+    into an LDS ring by a producer wave) consumes K in the same order as the staged kernel: bit-identical
+    results for the same split of K, all three operand layouts, bias + leaky relu and accumulate epilogues,
+    ragged M / N edges."""
+    from demo2program_amd.lib import call
+    A, B, bias, C0 = rnd(M, K_, seed=31), rnd(K_, N, seed=32), rnd(N, seed=33), rnd(M, N, seed=34)
+    dA, dB, dAt, dBt = dev(A), dev(B), dev(A.t().contiguous()), dev(B.t().contiguous())
+    K.SCRATCH.reserve(8 * M * N * 4)
+
+    def run():
+        outs = [K.matmul_nn(dA, dB, bias=dev(bias), act=1).clone(), K.matmul_nt(dA, dBt).clone(),
+                K.matmul_tn(dAt, dB).clone()]
+        c = dev(C0)
+        K.matmul_nn(dA, dB, out=c, accumulate=True)
+        return outs + [c.clone()]
+    try:
+        call.d2p_gemm_force_plan(0 if tile in (8, 9) else (4 if tile == 10 else 1), splits)
+        staged = run()
+        call.d2p_gemm_force_plan(tile, splits)
+        dma = run()
+    finally:
+        call.d2p_gemm_force_plan(-1, 0)
+    for a, b in zip(staged, dma):
+        assert torch.equal(a, b)
+    close(dma[1], A @ B, atol=2e-6 * K_ + 1e-5, rtol=1e-5)
+    close(dma[0], oracle.lrelu(A @ B + bias), atol=2e-6 * K_ + 1e-5, rtol=1e-5)
+
+
 def test_gemm_is_transpose_detecting(K):
     # A = I with an asymmetric B catches a swapped C layout (cdna guide §3)
     n = 96

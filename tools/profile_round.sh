@@ -13,6 +13,7 @@ python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_serial.md
 bash tools/profile_bench.sh ${TAG}g > /dev/null 2>&1
 DB=$(find gpurun_out/prof_${TAG}g -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_default.md
+python tools/rocpd_streams.py $DB 5 --seq > gpurun_out/${TAG}_streams_timeline.txt
 # HBM traffic counters, one counter per pass
 bash tools/profile_pmc.sh $TAG > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_$TAG gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_traffic.md
