@@ -75,6 +75,13 @@ class DataParallel(object):
                     dist.init_process_group(backend=backend, rank=rank, world_size=world)
             finally:
                 sys.stdout.flush()
+                try:
+                    # the banner sits in the C library's stdout buffer (block-buffered on a pipe) until exit:
+                    # flush it while fd 1 still points at stderr
+                    import ctypes
+                    ctypes.CDLL(None).fflush(None)
+                except (OSError, AttributeError):
+                    pass
                 os.dup2(saved, 1)
                 os.close(saved)
         return cls(rank, world, True)

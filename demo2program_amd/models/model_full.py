@@ -19,6 +19,7 @@ What is batched differently from the reference (results are identical, see DESIG
 Row order everywhere: sequences m = b*k + i; recurrent tensors are time-major [T, M, *].
 """
 import os
+import sys
 
 import numpy as np
 import torch
@@ -26,6 +27,53 @@ import torch
 from .. import kernels as K
 from ..config import conv_shapes, feature_dim, n_conv
 from ..params import FlatParams
+
+
+def pick_concurrent_stream(against=None, max_tries=12, verbose=False):
+    """A stream whose work really runs beside the work of the streams in `against` (default: the current
+    stream).  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 by default) in creation
+    order, and two streams on one queue serialise: a fresh `torch.cuda.Stream()` is concurrent with the default
+    stream in a plain process, but NOT after `init_process_group` (RCCL's own streams shift the assignment) --
+    measured: the two-stream schedule then runs at the one-stream rate, 4.98 instead of 4.44 ms per step.  So
+    candidates are PROBED: a spin kernel on every stream of `against`, a tiny fill on the candidate; the
+    candidate is taken when its fill finishes long before the spins do."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream()
+    main = torch.cuda.current_stream()
+    against = [main] if against is None else list(against)
+    probe = torch.zeros(64, device='cuda')
+    for st in against:
+        with torch.cuda.stream(st):
+            torch.cuda._sleep(1000)        # load the spin kernel before anything is timed
+    cand = None
+    for i in range(max_tries):
+        cand = torch.cuda.Stream()
+        with torch.cuda.stream(cand):
+            probe.fill_(0.0)               # first use of a stream costs the host milliseconds: not part of the probe
+        torch.cuda.synchronize()
+        e0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ends = []
+        e0.record(main)
+        for st in against:
+            if st != main:
+                st.wait_event(e0)
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(2000000)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(st)
+                ends.append(e)
+        with torch.cuda.stream(cand):
+            probe.fill_(1.0)
+            c1.record(cand)
+        torch.cuda.synchronize()
+        spin, side = min(e0.elapsed_time(e) for e in ends), e0.elapsed_time(c1)
+        if verbose:
+            print('[stream probe %d] spin %.3f ms, candidate done after %.3f ms' % (i, spin, side), file=sys.stderr)
+        if side < 0.5 * spin:
+            return cand
+    print('[demo2program_amd] no stream concurrent with %d busy stream(s) in %d tries: that schedule will '
+          'serialise' % (len(against), max_tries), file=sys.stderr)
+    return cand
 
 
 class Model(object):
@@ -390,7 +438,7 @@ class Model(object):
         if not self.use_side_stream:
             return torch.cuda.current_stream()
         if getattr(self, '_side', None) is None:
-            self._side = torch.cuda.Stream()
+            self._side = pick_concurrent_stream()
         return self._side
 
     def _bn_fwd(self, name, x2d, gamma, beta, G, inner, y=None):
@@ -590,6 +638,21 @@ class Model(object):
         when `backward` reaches its split point."""
         return self.params.offsets['prog/embedding']
 
+    @staticmethod
+    def _call_split(split_cb, main, side):
+        """The split point of backward: every decoder gradient has been ENQUEUED -- the last ones on the side
+        stream.  Eager two-stream schedule: the callback runs with the side stream current, so a collective
+        started there waits for the side stream (which has waited for everything the main stream had enqueued
+        when the last decoder's gradients were forked) and the main stream goes on with the encoder backward
+        without waiting for anything.  One stream, or under graph capture (the callback ends the capture):
+        join first."""
+        if side == main or torch.cuda.is_current_stream_capturing():
+            main.wait_stream(side)
+            split_cb()
+        else:
+            with torch.cuda.stream(side):
+                split_cb()
+
     def backward(self, loss_scale=1.0, split_cb=None):
         """Hand-written reverse schedule; writes every entry of params.grad exactly once.
         split_cb (data parallelism): called once, right after the last decoder gradient has been
@@ -671,8 +734,7 @@ class Model(object):
             K.axpy(1.0, tmp_h, d_demo_h)
             K.axpy(1.0, tmp_c, d_demo_c)
             if split_cb is not None:
-                main.wait_stream(side)
-                split_cb()
+                self._call_split(split_cb, main, side)
         else:
             # baselines: the program decoder is the only one
             dz_p = self._decoders_bwd_rec([(ctx['dp'], dl_p, d_init_h, d_init_c)])[0]
@@ -681,8 +743,7 @@ class Model(object):
                 dx_p = self._lstm_bwd_params(ctx['dp'], dz_p, True)
                 K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
             if split_cb is not None:
-                main.wait_stream(side)
-                split_cb()
+                self._call_split(split_cb, main, side)
 
         d_h1f, d_c1f = self._buf('d_h1f', (M, U)), self._buf('d_c1f', (M, U))
         if self.variant == 'synthesis_baseline':

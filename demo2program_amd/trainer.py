@@ -61,7 +61,12 @@ class FeedPrefetcher(object):
 
     def __init__(self, model, batches):
         self.model, self.batches = model, batches
-        self.stream = torch.cuda.Stream()
+        # the copy stream must not share a hardware queue with the compute streams (it would queue behind them)
+        from .models.model_full import pick_concurrent_stream
+        busy = [torch.cuda.current_stream()]
+        if getattr(model, 'use_side_stream', False):
+            busy.append(model._side_stream())
+        self.stream = pick_concurrent_stream(against=busy)
         self._staged = None
         self.stage()
 
@@ -192,7 +197,7 @@ class Trainer(object):
         P = m.params
         # data parallelism: the decoders' gradients (the tail of the flat buffer) are all-reduced while
         # the rest of backward runs; one message for everything when that is switched off
-        overlap = self.dp.active and self.dp_overlap and not m.use_side_stream
+        overlap = self.dp.active and self.dp_overlap and not (m.use_side_stream and self.use_graph)
         dec = m.decoder_grad_offset() if overlap else 0
         start = (lambda: self.dp.all_reduce_start(P.grad[dec:])) if overlap else None
         if self.use_graph and not self._profiling():

@@ -831,6 +831,7 @@ def test_rccl_single_rank_self_test(monkeypatch):
         # D2P_DP_OVERLAP=1 (one compute stream): the decoders' slice all-reduced on RCCL's stream from
         # Model.backward's split point, the rest after backward -- eager launches ...
         monkeypatch.setenv('D2P_DP_OVERLAP', '1')
+        two_streams = run(dp)                               # default schedule: the collective hangs off the side stream
         monkeypatch.setenv('D2P_SIDE_STREAM', '0')
         eager = run(dp)
         # ... and as two graphs cut at the split point
@@ -840,7 +841,7 @@ def test_rccl_single_rank_self_test(monkeypatch):
         dp.barrier()
     finally:
         dp.shutdown()
-    assert with_group == plain and one_message == plain and eager == plain
+    assert with_group == plain and one_message == plain and eager == plain and two_streams == plain
 
 
 def test_tf_checkpoint_export_import_round_trip(tmp_path):
@@ -939,3 +940,29 @@ def test_run_test_moves_the_batch_norm_moving_statistics():
         assert np.array_equal(p0[n], p1[n]), n
     moved = [n for n, (a, b) in tr.model.moving.items() if not torch.equal(a, mv0[n][0]) or not torch.equal(b, mv0[n][1])]
     assert set(moved) == set(tr.model.moving), (moved, list(tr.model.moving))
+
+
+def test_side_stream_really_runs_beside_the_main_stream():
+    """HIP maps streams onto a few hardware queues; two streams on one queue serialise (a fresh stream does after
+    init_process_group: RCCL's streams shift the assignment).  The stream the model's two-stream schedule and
+    the feed prefetcher use is probed for concurrency: a spin on the current stream must not delay it."""
+    from demo2program_amd.models.model_full import pick_concurrent_stream
+    main = torch.cuda.current_stream()
+    side = pick_concurrent_stream()
+    assert side != main
+    x = torch.zeros(64, device='cuda')
+    with torch.cuda.stream(side):
+        x.fill_(0.0)
+    torch.cuda._sleep(1000)
+    torch.cuda.synchronize()
+    e0, e1, c1 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    e0.record(main)
+    torch.cuda._sleep(4000000)
+    e1.record(main)
+    with torch.cuda.stream(side):
+        x.fill_(1.0)
+        c1.record(side)
+    torch.cuda.synchronize()
+    assert e0.elapsed_time(c1) < 0.5 * e0.elapsed_time(e1)
+    third = pick_concurrent_stream(against=[main, side])
+    assert third != main and third != side
