@@ -287,7 +287,7 @@ def lstm_seq_fwd_multi(seqs):
     for i, q in enumerate(seqs):
         M, U = q['M'], q['U']
         nb = call.d2p_lstm_ws_bytes(M, U)
-        ws = _MULTI_WS.get(('f', i), nb)
+        ws = _MULTI_WS.get(('f', i, torch.cuda.current_stream().cuda_stream), nb)   # per stream: launches on two streams run concurrently
         d = arr[i]
         d.M, d.U, d.n_steps = M, U, q['n_steps']
         d.z, d.z_row_stride, d.z_t_stride = ptr(q['z']), 4 * U, M * 4 * U
@@ -305,7 +305,7 @@ def lstm_seq_bwd_multi(seqs):
     for i, q in enumerate(seqs):
         M, U = q['M'], q['U']
         nb = call.d2p_lstm_ws_bytes(M, U)
-        ws = _MULTI_WS.get(('b', i), nb)
+        ws = _MULTI_WS.get(('b', i, torch.cuda.current_stream().cuda_stream), nb)
         d = arr[i]
         d.M, d.U, d.n_steps = M, U, q['n_steps']
         d.z, d.z_row_stride, d.z_t_stride = ptr(q['z']), 4 * U, M * 4 * U
