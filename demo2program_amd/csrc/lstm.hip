@@ -191,6 +191,44 @@ static int copy_or_zero(float* dst, const float* src, size_t n, hipStream_t st) 
     return D2P_OK;
 }
 
+// Two sequences of a multi call as ONE persistent launch (lstm_persist.hip): taken when both would go to the
+// persistent back end on their own and sharing the chip is expected to pay.  Returns false when the caller
+// should issue them one after the other.
+bool d2p_lstm_try_pair_fwd(const d2p_lstm_fwd_desc* d, hipStream_t st, int* rc) {
+    for (int i = 0; i < 2; ++i) {
+        const d2p_lstm_fwd_desc& q = d[i];
+        if (q.M <= 0 || q.n_steps <= 0 || !(q.z && q.Wh && q.hout && q.cs && q.ws)) return false;
+        if (!use_fused(q.M, q.U, q.z_row_stride, q.z, q.ws_bytes) || q.ws_bytes < d2p_lstm_persist_ws_bytes(q.M, q.U))
+            return false;
+    }
+    if (d[0].U != d[1].U || d[0].ws == d[1].ws) return false;
+    if (!d2p_lstm_persist_fwd_pair_ok(d[0].M, d[0].n_steps, d[1].M, d[1].n_steps, d[0].U)) return false;
+    PsFwdCall c[2];
+    for (int i = 0; i < 2; ++i)
+        c[i] = PsFwdCall{d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh, d[i].h0,
+                         d[i].c0, d[i].lens, d[i].hout, d[i].cs, d[i].h_final, d[i].c_final, (float*)d[i].ws};
+    *rc = d2p_lstm_persist_fwd_pair(c[0], c[1], st);
+    return true;
+}
+bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc) {
+    for (int i = 0; i < 2; ++i) {
+        const d2p_lstm_bwd_desc& q = d[i];
+        if (q.M <= 0 || q.n_steps <= 0 || !(q.z && q.Wh && q.cs && q.dz && q.ws)) return false;
+        if (!use_fused(q.M, q.U, q.z_row_stride, q.z, q.ws_bytes) || (((uintptr_t)q.dz & 15) != 0) ||
+            q.ws_bytes < d2p_lstm_persist_ws_bytes(q.M, q.U))
+            return false;
+    }
+    if (d[0].U != d[1].U || d[0].ws == d[1].ws) return false;
+    if (!d2p_lstm_persist_bwd_pair_ok(d[0].M, d[0].n_steps, d[1].M, d[1].n_steps, d[0].U)) return false;
+    PsBwdCall c[2];
+    for (int i = 0; i < 2; ++i)
+        c[i] = PsBwdCall{d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh, d[i].c0,
+                         d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final, d[i].dc_final, d[i].dz, d[i].dh0, d[i].dc0,
+                         (float*)d[i].ws};
+    *rc = d2p_lstm_persist_bwd_pair(c[0], c[1], st);
+    return true;
+}
+
 extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_stride,
                                 long z_t_stride, const float* Wh, const float* h0, const float* c0,
                                 const int* lens, float* hout, float* cs, float* h_final,
@@ -204,8 +242,8 @@ extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_
                 "lstm seq fwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && d2p_lstm_persist_fwd_ok(M, U, n_steps) &&
         ws_bytes >= d2p_lstm_persist_ws_bytes(M, U))
-        return d2p_lstm_persist_fwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, h0, c0, lens, hout, cs,
-                                    h_final, c_final, (float*)ws, st);
+        return d2p_lstm_persist_fwd(PsFwdCall{M, U, n_steps, z, z_row_stride, z_t_stride, Wh, h0, c0, lens, hout, cs,
+                                              h_final, c_final, (float*)ws}, st);
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes))
         return d2p_lstm_fused_fwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, h0, c0, lens, hout,
                                   cs, h_final, c_final, (float*)ws, st);
@@ -247,8 +285,8 @@ extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long 
                 "lstm seq bwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && (((uintptr_t)dz & 15) == 0) &&
         d2p_lstm_persist_bwd_ok(M, U, n_steps) && ws_bytes >= d2p_lstm_persist_ws_bytes(M, U))
-        return d2p_lstm_persist_bwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
-                                    dh_final, dc_final, dz, dh0, dc0, (float*)ws, st);
+        return d2p_lstm_persist_bwd(PsBwdCall{M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
+                                              dh_final, dc_final, dz, dh0, dc0, (float*)ws}, st);
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && (((uintptr_t)dz & 15) == 0))
         return d2p_lstm_fused_bwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
                                   dh_final, dc_final, dz, dh0, dc0, (float*)ws, st);

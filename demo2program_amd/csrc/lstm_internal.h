@@ -56,10 +56,30 @@ int d2p_lstm_is_persistent_enabled();
 bool d2p_lstm_persist_fwd_ok(int M, int U, int n_steps);
 bool d2p_lstm_persist_bwd_ok(int M, int U, int n_steps);
 size_t d2p_lstm_persist_ws_bytes(int M, int U);
-int d2p_lstm_persist_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, const float* Wh,
-                         const float* h0, const float* c0, const int* lens, float* hout, float* cs,
-                         float* h_final, float* c_final, float* ws, hipStream_t st);
-int d2p_lstm_persist_bwd(int M, int U, int n_steps, const float* z, long zrs, long zts, const float* Wh,
-                         const float* c0, const int* lens, const float* cs, const float* dhout,
-                         const float* dh_final, const float* dc_final, float* dz, float* dh0,
-                         float* dc0, float* ws, hipStream_t st);
+// one sequence's arguments (those of d2p_lstm_seq_fwd / _bwd, include/d2p.h; ws holds d2p_lstm_persist_ws_bytes)
+struct PsFwdCall {
+    int M, U, n_steps;
+    float* z; long zrs, zts;
+    const float* Wh; const float* h0; const float* c0; const int* lens;
+    float* hout; float* cs; float* h_final; float* c_final;
+    float* ws;
+};
+struct PsBwdCall {
+    int M, U, n_steps;
+    const float* z; long zrs, zts;
+    const float* Wh; const float* c0; const int* lens; const float* cs;
+    const float* dhout; const float* dh_final; const float* dc_final;
+    float* dz; float* dh0; float* dc0;
+    float* ws;
+};
+int d2p_lstm_persist_fwd(const PsFwdCall& q, hipStream_t st);
+int d2p_lstm_persist_bwd(const PsBwdCall& q, hipStream_t st);
+// two independent sequences (same U) on disjoint workgroups of ONE launch; *_pair_ok: both shapes are taken and
+// sharing the chip is expected to beat the two launches back to back
+bool d2p_lstm_persist_fwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U);
+bool d2p_lstm_persist_bwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U);
+int d2p_lstm_persist_fwd_pair(const PsFwdCall& qa, const PsFwdCall& qb, hipStream_t st);
+int d2p_lstm_persist_bwd_pair(const PsBwdCall& qa, const PsBwdCall& qb, hipStream_t st);
+// multi entry points: two sequences as one persistent launch when that is possible and expected to pay (lstm.hip)
+bool d2p_lstm_try_pair_fwd(const d2p_lstm_fwd_desc* d, hipStream_t st, int* rc);
+bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc);

@@ -158,8 +158,9 @@ __device__ __forceinline__ void ps_wait_flags(const unsigned* f, unsigned need, 
 
 // block -> (row domain rt, column tile ct): consecutive tiles of a domain on the same XCD
 // (block b runs on XCD b % 8 -- a speed hint only, nothing depends on it)
-__device__ __forceinline__ void ps_block_tile(int ncol, int& rt, int& ct) {
-    const int g = gridDim.x, b = blockIdx.x;
+// b, g: the workgroup's index in and the size of ITS sequence's group of the launch (a launch carries one
+// sequence, or two independent ones on disjoint workgroups)
+__device__ __forceinline__ void ps_block_tile(int b, int g, int ncol, int& rt, int& ct) {
     int L = b;
     if ((g & 7) == 0) L = (b & 7) * (g >> 3) + (b >> 3);
     rt = L / ncol;
@@ -199,6 +200,7 @@ struct PsTick {     // (phase, step/pass) of a tick index, advanced incrementall
 // =============================================================================================
 struct PsFwdArgs {
     int M, U, T, total_rs, RT, has_h0;
+    int bid0, gsz;          // this sequence's workgroups are blocks [bid0, bid0 + gsz) of the launch
     const float4* Wf;       // packed Wh (lstm_step.hip forward layout)
     float* hfrag;           // 2 ping-pong buffers of Mp*U floats, fragment-major; [0] = state before step 0
     unsigned hfrag_bytes;   // bytes of ONE buffer
@@ -476,7 +478,10 @@ __device__ __forceinline__ void ps_fwd_mfma_wave(const PsFwdArgs& a, const PsFwd
 }
 
 template <int CPW>   // U = 64 * CPW
-__global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs a) {
+__global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs a0, PsFwdArgs a1) {
+    // two independent sequences may share a launch (a1.gsz > 0): the first a0.gsz workgroups run a0, the rest
+    // a1 -- nothing is exchanged between the two groups, they only have to be resident together
+    const PsFwdArgs a = ((int)blockIdx.x >= a0.gsz) ? a1 : a0;
     constexpr int KC = 4 * CPW;
     // ONE shared array (a second __shared__ object de-pipelines loads, cdna_hip_programming.md)
     __shared__ __attribute__((aligned(16))) float lds[2 * PS_P_FLOATS + PS_NRS_MAX * 384 + 64 + 2 * 128 + PS_PF_R * PS_FWD_SLOT];
@@ -491,7 +496,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int U = a.U, nct = U >> 3;
     int rt, ct;
-    ps_block_tile(nct, rt, ct);
+    ps_block_tile((int)blockIdx.x - a.bid0, a.gsz, nct, rt, ct);
     int rs0, nrs;
     ps_rt_range(rt, a.total_rs, a.RT, rs0, nrs);
     const int nticks = nrs * a.T;
@@ -607,6 +612,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
 // =============================================================================================
 struct PsBwdArgs {
     int M, U, T, total_rs, RT, want_dh0;
+    int bid0, gsz;          // this sequence's workgroups are blocks [bid0, bid0 + gsz) of the launch
     const float4* Wb;       // packed Wh^T (lstm_step.hip backward layout)
     float* dzfrag;          // 2 ping-pong buffers of Mp*4U floats, fragment-major over K = 4U
     unsigned dzfrag_bytes;  // bytes of ONE buffer
@@ -787,7 +793,8 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
 }
 
 template <int CPW>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16
-__global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs a) {
+__global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs a0, PsBwdArgs a1) {
+    const PsBwdArgs a = ((int)blockIdx.x >= a0.gsz) ? a1 : a0;      // two sequences per launch, as the forward kernel
     constexpr int CPWB = 4 * CPW;                // chunks per wave
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
@@ -802,7 +809,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int U = a.U, nnt = U >> 4;
     int rt, nt;
-    ps_block_tile(nnt, rt, nt);
+    ps_block_tile((int)blockIdx.x - a.bid0, a.gsz, nnt, rt, nt);
     int rs0, nrs;
     ps_rt_range(rt, a.total_rs, a.RT, rs0, nrs);
     const int J = a.T + (a.want_dh0 ? 1 : 0);    // passes: t = T-1 .. 0 (, -1)
@@ -994,17 +1001,17 @@ static int ps_prep(int bwd, int U, const float* Wh, float* Wp, int M, const floa
     return D2P_OK;
 }
 
-int d2p_lstm_persist_fwd(int M, int U, int n_steps, float* z, long zrs, long zts, const float* Wh,
-                         const float* h0, const float* c0, const int* lens, float* hout, float* cs,
-                         float* h_final, float* c_final, float* ws, hipStream_t st) {
-    PsFwdArgs a;
-    a.M = M; a.U = U; a.T = n_steps;
+// ---- one sequence's share of a launch -----------------------------------------------------------
+static int ps_fwd_setup(const PsFwdCall& q, int RT, int bid0, PsFwdArgs& a, hipStream_t st) {
+    const int M = q.M, U = q.U;
+    a.M = M; a.U = U; a.T = q.n_steps;
     a.total_rs = (M + 15) / 16;
     const int nct = U / 8;
-    a.RT = ps_pick_rt(a.total_rs, nct);
-    a.has_h0 = h0 ? 1 : 0;
+    a.RT = RT;
+    a.bid0 = bid0; a.gsz = nct * RT;
+    a.has_h0 = q.h0 ? 1 : 0;
     const size_t Mp = (size_t)a.total_rs * 16;
-    float* Wf = ws;
+    float* Wf = q.ws;
     a.Wf = (const float4*)Wf;
     a.hfrag = Wf + (size_t)4 * U * U;
     a.hfrag_bytes = (unsigned)(Mp * U * sizeof(float));
@@ -1012,38 +1019,97 @@ int d2p_lstm_persist_fwd(int M, int U, int n_steps, float* z, long zrs, long zts
     a.dump = (float*)(a.flags + PS_FLAG_WORDS);
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
-    a.z = z; a.zrs = zrs; a.zts = zts; a.h0 = h0; a.c0 = c0; a.lens = lens;
-    a.hout = hout; a.cs = cs; a.h_final = h_final; a.c_final = c_final;
+    a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.h0 = q.h0; a.c0 = q.c0; a.lens = q.lens;
+    a.hout = q.hout; a.cs = q.cs; a.h_final = q.h_final; a.c_final = q.c_final;
     // packed weights; h0 in fragment order (without one the deferred-epilogue form still multiplies in step 0:
     // an all-zero operand makes that product an exact zero); flags reset
-    int rc = ps_prep(0, U, Wh, Wf, M, h0, a.hfrag, a.hfrag_bytes, a.flags, (size_t)a.RT * PS_NRS_MAX * nct, st);
-    if (rc) return rc;
-    const int blocks = nct * a.RT;
-    {
-        D2pProfScope prof(st, D2P_PROF_LSTM_STEP_FWD, 2.0 * M * 4.0 * U * U * (n_steps - (h0 ? 0 : 1)));
-        switch (U) {
-            case 64: hipLaunchKernelGGL((lstm_persist_fwd_kernel<1>), dim3(blocks), dim3(PS_THREADS), 0, st, a); break;
-            case 128: hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), dim3(blocks), dim3(PS_THREADS), 0, st, a); break;
-            case 256: hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), dim3(blocks), dim3(PS_THREADS), 0, st, a); break;
-            default: hipLaunchKernelGGL((lstm_persist_fwd_kernel<8>), dim3(blocks), dim3(PS_THREADS), 0, st, a); break;
-        }
+    return ps_prep(0, U, q.Wh, Wf, M, q.h0, a.hfrag, a.hfrag_bytes, a.flags, (size_t)RT * PS_NRS_MAX * nct, st);
+}
+static int ps_fwd_launch(const PsFwdArgs& a0, const PsFwdArgs& a1, int U, double flops, hipStream_t st) {
+    const int blocks = a0.gsz + a1.gsz;
+    D2pProfScope prof(st, D2P_PROF_LSTM_STEP_FWD, flops);
+    switch (U) {
+        case 64: hipLaunchKernelGGL((lstm_persist_fwd_kernel<1>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
+        case 128: hipLaunchKernelGGL((lstm_persist_fwd_kernel<2>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
+        case 256: hipLaunchKernelGGL((lstm_persist_fwd_kernel<4>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
+        default: hipLaunchKernelGGL((lstm_persist_fwd_kernel<8>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
     }
     D2P_LAUNCH_CHECK("lstm_persist_fwd");
     return D2P_OK;
 }
+static inline double ps_fwd_flops(const PsFwdCall& q) {
+    return 2.0 * q.M * 4.0 * q.U * q.U * (q.n_steps - (q.h0 ? 0 : 1));
+}
 
-int d2p_lstm_persist_bwd(int M, int U, int n_steps, const float* z, long zrs, long zts, const float* Wh,
-                         const float* c0, const int* lens, const float* cs, const float* dhout,
-                         const float* dh_final, const float* dc_final, float* dz, float* dh0,
-                         float* dc0, float* ws, hipStream_t st) {
-    PsBwdArgs a;
+int d2p_lstm_persist_fwd(const PsFwdCall& q, hipStream_t st) {
+    PsFwdArgs a, none;
+    int rc = ps_fwd_setup(q, ps_pick_rt((q.M + 15) / 16, q.U / 8), 0, a, st);
+    if (rc) return rc;
+    none = a;
+    none.gsz = 0;
+    return ps_fwd_launch(a, none, q.U, ps_fwd_flops(q), st);
+}
+
+// ---- two sequences in one launch ---------------------------------------------------------------------
+// Row domains are dealt out between the two so that the slower one finishes as early as possible under a
+// simple per-step model (a step costs its phases, but never less than the hand-off latency of one phase);
+// the pair is taken only when that beats the two launches back to back.  Measured at U = 512 (us):
+// forward 1.6 per phase, floor 3.3; backward 3.3 per phase, floor 6.3.
+static bool ps_plan_pair(int trs_a, int T_a, int trs_b, int T_b, int ncol, int dir, int& RTa, int& RTb) {
+    const double ph = dir ? 3.3 : 1.6, fl = dir ? 6.3 : 3.3;
+    auto cost = [&](int trs, int T, int RT) {
+        const int nrs = (trs + RT - 1) / RT;
+        const double step = ph * nrs;
+        return T * (step > fl ? step : fl);
+    };
+    const int budget = ps_num_cus() / ncol;                 // row domains the chip holds at one workgroup per CU
+    const int fa = ps_pick_rt(trs_a, ncol, dir), fb = ps_pick_rt(trs_b, ncol, dir);
+    if (fa < 1 || fb < 1) return false;
+    const double serial = cost(trs_a, T_a, fa) + cost(trs_b, T_b, fb);
+    double best = serial * 0.9;                             // must win by a margin
+    bool found = false;
+    for (int rb = 1; rb < budget; ++rb) {
+        int ra = budget - rb;
+        if (ra > trs_a) ra = trs_a;
+        if (rb > trs_b || ra < 1) continue;
+        if ((trs_a + ra - 1) / ra > PS_NRS_MAX || (trs_b + rb - 1) / rb > PS_NRS_MAX) continue;
+        const double ca = cost(trs_a, T_a, ra), cb = cost(trs_b, T_b, rb);
+        const double c = ca > cb ? ca : cb;
+        if (c < best) { best = c; RTa = ra; RTb = rb; found = true; }
+    }
+    return found;
+}
+
+bool d2p_lstm_persist_fwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U) {
+    int ra, rb;
+    return g_persist && d2p_lstm_persist_fwd_ok(Ma, U, Ta) && d2p_lstm_persist_fwd_ok(Mb, U, Tb) &&
+           ps_plan_pair((Ma + 15) / 16, Ta, (Mb + 15) / 16, Tb, U / 8, 0, ra, rb);
+}
+static int g_ps_pair_launches = 0;
+extern "C" int d2p_lstm_persist_pair_launches(void) { return g_ps_pair_launches; }
+int d2p_lstm_persist_fwd_pair(const PsFwdCall& qa, const PsFwdCall& qb, hipStream_t st) {
+    int ra = 0, rb = 0;
+    if (!ps_plan_pair((qa.M + 15) / 16, qa.n_steps, (qb.M + 15) / 16, qb.n_steps, qa.U / 8, 0, ra, rb))
+        return D2P_EINVAL;
+    PsFwdArgs a, b;
+    int rc = ps_fwd_setup(qa, ra, 0, a, st);
+    if (rc) return rc;
+    rc = ps_fwd_setup(qb, rb, a.gsz, b, st);
+    if (rc) return rc;
+    ++g_ps_pair_launches;
+    return ps_fwd_launch(a, b, qa.U, ps_fwd_flops(qa) + ps_fwd_flops(qb), st);
+}
+
+static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipStream_t st) {
+    const int M = q.M, U = q.U, n_steps = q.n_steps;
     a.M = M; a.U = U; a.T = n_steps;
     a.total_rs = (M + 15) / 16;
     const int nnt = U / 16;
-    a.RT = ps_pick_rt(a.total_rs, nnt, 1);
-    a.want_dh0 = dh0 ? 1 : 0;
+    a.RT = RT;
+    a.bid0 = bid0; a.gsz = nnt * RT;
+    a.want_dh0 = q.dh0 ? 1 : 0;
     const size_t Mp = (size_t)a.total_rs * 16;
-    float* Wb = ws;
+    float* Wb = q.ws;
     a.Wb = (const float4*)Wb;
     a.dzfrag = Wb + (size_t)4 * U * U;
     a.dzfrag_bytes = (unsigned)(Mp * 4 * U * sizeof(float));
@@ -1051,23 +1117,51 @@ int d2p_lstm_persist_bwd(int M, int U, int n_steps, const float* z, long zrs, lo
     a.dump = (float*)(a.flags + PS_FLAG_WORDS);
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
-    a.z = z; a.zrs = zrs; a.zts = zts; a.c0 = c0; a.cs = cs; a.lens = lens;
-    a.dhout = dhout; a.dh_final = dh_final; a.dc_final = dc_final;
-    a.dz = dz; a.dh0 = dh0; a.dc0 = dc0;
+    a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.c0 = q.c0; a.cs = q.cs; a.lens = q.lens;
+    a.dhout = q.dhout; a.dh_final = q.dh_final; a.dc_final = q.dc_final;
+    a.dz = q.dz; a.dh0 = q.dh0; a.dc0 = q.dc0;
     // packed Wh^T; pass 0 has no product -- the chain runs on an all-zero dz[T]; flags reset
-    int rc = ps_prep(1, U, Wh, Wb, M, nullptr, (float*)((char*)a.dzfrag + (size_t)(n_steps & 1) * a.dzfrag_bytes),
-                     a.dzfrag_bytes, a.flags, (size_t)a.RT * PS_NRS_MAX * nnt, st);
-    if (rc) return rc;
-    const int blocks = nnt * a.RT;
-    {
-        D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, 2.0 * M * 4.0 * U * U * (n_steps - 1 + (dh0 ? 1 : 0)));
-        switch (U) {
-            case 64: hipLaunchKernelGGL((lstm_persist_bwd_kernel<1>), dim3(blocks), dim3(PS_THREADS), 0, st, a); break;
-            case 128: hipLaunchKernelGGL((lstm_persist_bwd_kernel<2>), dim3(blocks), dim3(PS_THREADS), 0, st, a); break;
-            case 256: hipLaunchKernelGGL((lstm_persist_bwd_kernel<4>), dim3(blocks), dim3(PS_THREADS), 0, st, a); break;
-            default: hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), dim3(blocks), dim3(PS_THREADS), 0, st, a); break;
-        }
+    return ps_prep(1, U, q.Wh, Wb, M, nullptr, (float*)((char*)a.dzfrag + (size_t)(n_steps & 1) * a.dzfrag_bytes),
+                   a.dzfrag_bytes, a.flags, (size_t)RT * PS_NRS_MAX * nnt, st);
+}
+static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, int U, double flops, hipStream_t st) {
+    const int blocks = a0.gsz + a1.gsz;
+    D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, flops);
+    switch (U) {
+        case 64: hipLaunchKernelGGL((lstm_persist_bwd_kernel<1>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
+        case 128: hipLaunchKernelGGL((lstm_persist_bwd_kernel<2>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
+        case 256: hipLaunchKernelGGL((lstm_persist_bwd_kernel<4>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
+        default: hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
     }
     D2P_LAUNCH_CHECK("lstm_persist_bwd");
     return D2P_OK;
+}
+static inline double ps_bwd_flops(const PsBwdCall& q) {
+    return 2.0 * q.M * 4.0 * q.U * q.U * (q.n_steps - 1 + (q.dh0 ? 1 : 0));
+}
+
+int d2p_lstm_persist_bwd(const PsBwdCall& q, hipStream_t st) {
+    PsBwdArgs a, none;
+    int rc = ps_bwd_setup(q, ps_pick_rt((q.M + 15) / 16, q.U / 16, 1), 0, a, st);
+    if (rc) return rc;
+    none = a;
+    none.gsz = 0;
+    return ps_bwd_launch(a, none, q.U, ps_bwd_flops(q), st);
+}
+bool d2p_lstm_persist_bwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U) {
+    int ra, rb;
+    return g_persist && d2p_lstm_persist_bwd_ok(Ma, U, Ta) && d2p_lstm_persist_bwd_ok(Mb, U, Tb) &&
+           ps_plan_pair((Ma + 15) / 16, Ta, (Mb + 15) / 16, Tb, U / 16, 1, ra, rb);
+}
+int d2p_lstm_persist_bwd_pair(const PsBwdCall& qa, const PsBwdCall& qb, hipStream_t st) {
+    int ra = 0, rb = 0;
+    if (!ps_plan_pair((qa.M + 15) / 16, qa.n_steps, (qb.M + 15) / 16, qb.n_steps, qa.U / 16, 1, ra, rb))
+        return D2P_EINVAL;
+    PsBwdArgs a, b;
+    int rc = ps_bwd_setup(qa, ra, 0, a, st);
+    if (rc) return rc;
+    rc = ps_bwd_setup(qb, rb, a.gsz, b, st);
+    if (rc) return rc;
+    ++g_ps_pair_launches;
+    return ps_bwd_launch(a, b, qa.U, ps_bwd_flops(qa) + ps_bwd_flops(qb), st);
 }

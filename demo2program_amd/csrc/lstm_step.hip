@@ -832,6 +832,10 @@ extern "C" int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* d, d2p_
         }
         return d2p_lstm_fused_fwd_multi(nseq, q, ws, as_stream(stream));
     }
+    if (nseq == 2 && d2p_lstm_is_persistent_enabled()) {     // two sequences sharing one persistent launch
+        int rc = D2P_OK;
+        if (d2p_lstm_try_pair_fwd(d, as_stream(stream), &rc)) return rc;
+    }
     for (int i = 0; i < nseq; ++i) {     // generic path: one sequence after the other
         int rc = d2p_lstm_seq_fwd(d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride,
                                   d[i].Wh, d[i].h0, d[i].c0, d[i].lens, d[i].hout, d[i].cs, d[i].h_final,
@@ -864,6 +868,10 @@ extern "C" int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* d, d2p_
             ws[i] = (float*)d[i].ws;
         }
         return d2p_lstm_fused_bwd_multi(nseq, q, ws, as_stream(stream));
+    }
+    if (nseq == 2 && d2p_lstm_is_persistent_enabled()) {
+        int rc = D2P_OK;
+        if (d2p_lstm_try_pair_bwd(d, as_stream(stream), &rc)) return rc;
     }
     for (int i = 0; i < nseq; ++i) {
         int rc = d2p_lstm_seq_bwd(d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride,

@@ -51,6 +51,7 @@ SIGNATURES = {
     'd2p_lstm_persist_error': (c_int, [c_int]),
     'd2p_lstm_persist_set_trace': (c_int, [P, c_size_t, c_int]),
     'd2p_lstm_persist_set_wgs_per_cu': (c_int, [c_int, c_int]),
+    'd2p_lstm_persist_pair_launches': (c_int, []),
     'd2p_lstm_debug_flags': (c_int, [c_int]),
     'd2p_lstm_set_tiling': (c_int, [c_int, c_int, c_int]),
     'd2p_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, c_long, c_long, P, P, P, P, P, P, P, P, P, c_size_t, S]),

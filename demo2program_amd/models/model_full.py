@@ -175,6 +175,8 @@ class Model(object):
         # loss next to the per-step LSTM kernels; next to the persistent ones (round 2) the GEMMs fill the
         # matrix pipe while a recurrence waits for its hand-offs: 4.82 vs 5.10 ms per step with eager
         # launches.  D2P_NO_SIDE_STREAM=1 / D2P_SIDE_STREAM=0 switch it off.
+        # two decoders per persistent launch (d2p_lstm_seq_*_multi with two sequences)
+        self.pair_decoders = os.environ.get('D2P_PAIR_DECODERS', '1') == '1'
         self.use_side_stream = (os.environ.get('D2P_SIDE_STREAM', '1') == '1' and
                                 os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1')
         self._reserve_scratch()
@@ -402,6 +404,11 @@ class Model(object):
                 ids_a = da['fed_ids']
         elif self.fuse_decoders and self.multitask:
             dp, da, dq = self._decoders_fwd(specs)
+        elif self.multitask and self.pair_decoders:
+            # the program decoder (32 rows: a latency-bound chain on a quarter of the CUs) shares ONE persistent
+            # launch with the action decoder, on disjoint workgroups; the perception decoder follows alone
+            dp, da = self._decoders_fwd(specs[:2])
+            dq = self._decoders_fwd([specs[2]])[0]
         else:
             outs = [self._decoders_fwd([sp])[0] for sp in specs]
             dp = outs[0]
@@ -723,6 +730,17 @@ class Model(object):
                 with torch.cuda.stream(side):
                     for fn, dz in zip(grads, dzs):
                         fn(dz)
+            elif self.pair_decoders:
+                # perception first, then action + program as one launch (as in forward); each group's gradient
+                # GEMMs are forked right behind its recurrence
+                order = os.environ.get('D2P_PAIR_ORDER', 'per_first')
+                groups = ((2,), (1, 0)) if order == 'per_first' else ((1, 0), (2,))
+                for grp in groups:
+                    dzs = self._decoders_bwd_rec([bspecs[i] for i in grp])
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        for i, dz in zip(grp, dzs):
+                            grads[i](dz)
             else:
                 # action, perception, then program: measured 4.49 ms per step against 4.70 for one fork
                 # after all three recurrences and 4.73 for program first (profiles/r02x_decoder_order.txt)

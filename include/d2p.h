@@ -218,6 +218,10 @@ int d2p_lstm_persist_set_trace(void* buf, size_t bytes, int block);
  * sized for (0 keeps the current value; default 1).  2 cuts the rows into twice as many domains so
  * that two workgroups share a CU and overlap each other's MFMA and epilogue phases. */
 int d2p_lstm_persist_set_wgs_per_cu(int fwd, int bwd);
+/* Number of persistent launches so far that carried TWO sequences (d2p_lstm_seq_{fwd,bwd}_multi with nseq == 2
+ * puts both on disjoint workgroups of one launch when both shapes are taken and sharing the chip is expected to
+ * beat two launches back to back).  For tests: the pair path must not be skipped silently. */
+int d2p_lstm_persist_pair_launches(void);
 /* Ablation knobs for tools/bench_lstm_step.py only (results are wrong when non-zero):
  * bit 0 skips the MFMA part of the fused step kernels, bit 1 skips their epilogue. */
 int d2p_lstm_debug_flags(int flags);

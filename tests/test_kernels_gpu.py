@@ -597,6 +597,59 @@ def test_lstm_multi_sequence_launch_equals_separate_calls(K):
             assert torch.equal(a[n], b[n]), n
 
 
+@pytest.mark.parametrize('specs,pairs', [([(320, 20), (32, 50)], 2), ([(32, 50), (320, 20)], 2),
+                                         # 400 rows = 25 sub-tiles: 3 of the forward's 4 row domains cannot hold them
+                                         # (9 > 8 phases) -> two forward launches, one backward pair
+                                         ([(400, 8), (16, 23)], 1)])
+def test_lstm_two_sequences_in_one_persistent_launch(K, specs, pairs):
+    """d2p_lstm_seq_{fwd,bwd}_multi with two sequences (the action and the program decoder: 320 rows x 20 steps
+    beside 32 rows x 50 steps) puts both on disjoint workgroups of ONE persistent launch -- the small,
+    latency-bound one hides beside the large one.  Only the row-domain split changes: results are bit-identical
+    to two persistent launches, and the pair path must really have been taken."""
+    from demo2program_amd.lib import load
+    lib = load()                              # raw handle: this entry point returns a count, not a status
+    U = 512
+    g = torch.Generator().manual_seed(19)
+
+    def mk(M, n):
+        T = n
+        return dict(M=M, n_steps=n, T=T,
+                    z0=(torch.rand(T * M, 4 * U, generator=g) * 2 - 1).cuda(),
+                    Wh=((torch.rand(U, 4 * U, generator=g) * 2 - 1) * 0.05).cuda(),
+                    h0=(torch.rand(M, U, generator=g) * 2 - 1).cuda(),
+                    c0=(torch.rand(M, U, generator=g) * 2 - 1).cuda(),
+                    dhout=(torch.rand(T, M, U, generator=g) * 2 - 1).cuda())
+    base = [mk(M, n) for (M, n) in specs]
+    results = []
+    before = lib.d2p_lstm_persist_pair_launches()
+    K.lstm_persist_error(True)
+    for multi in (True, False):
+        fw, bw, outs = [], [], []
+        for b in base:
+            M, T = b['M'], b['T']
+            o = dict(z=b['z0'].clone(), hout=torch.zeros(T, M, U, device='cuda'),
+                     cs=torch.zeros(T, M, U, device='cuda'), dz=torch.zeros(T * M, 4 * U, device='cuda'),
+                     dh0=torch.zeros(M, U, device='cuda'), dc0=torch.zeros(M, U, device='cuda'))
+            outs.append(o)
+            fw.append(dict(M=M, U=U, n_steps=b['n_steps'], z=o['z'], Wh=b['Wh'], h0=b['h0'], c0=b['c0'],
+                           hout=o['hout'], cs=o['cs']))
+            bw.append(dict(M=M, U=U, n_steps=b['n_steps'], z=o['z'], Wh=b['Wh'], c0=b['c0'], cs=o['cs'],
+                           dhout=b['dhout'], dz=o['dz'], dh0=o['dh0'], dc0=o['dc0']))
+        if multi:
+            K.lstm_seq_fwd_multi(fw)
+            K.lstm_seq_bwd_multi(bw)
+        else:
+            for f, b_ in zip(fw, bw):
+                K.lstm_seq_fwd_multi([f])
+                K.lstm_seq_bwd_multi([b_])
+        results.append(outs)
+    assert K.lstm_persist_error(True) == 0
+    assert lib.d2p_lstm_persist_pair_launches() == before + pairs       # forward and backward pair launches
+    for a, b in zip(*results):
+        for n in ('z', 'hout', 'cs', 'dz', 'dh0', 'dc0'):
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_gate_nonlinearities_are_fp32_accurate(K):
     """The gate math runs on the hardware exp2 / rcp units (common.h d2p_sigmoid / d2p_tanh): over the
     whole useful range, including saturation and tiny arguments, c' and h' of one cell step stay
