@@ -540,7 +540,10 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
             }
         }
         if (defer) ps_fwd_mfma_wave<CPW, 2>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
-        else if (nrs >= 2) ps_fwd_mfma_wave<CPW, 1>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
+        // look-ahead asks for the NEXT phase's rows at the start of a phase: with two phases those were
+        // published by the phase just finished, so the full hand-off latency sat in front of every phase
+        // (3.8 us per phase); a 2-phase domain polls for its own rows instead -- published a phase earlier
+        else if (nrs >= 3) ps_fwd_mfma_wave<CPW, 1>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
         else ps_fwd_mfma_wave<CPW, 0>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
         if (e.lane_on)
             for (int q = 0; q < nrs; ++q) {
