@@ -504,9 +504,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
     // deferred epilogue: the domain must have phases to spare for the later publication, and every
     // step must have a product (the host zero-fills the state buffer when there is no h0)
     // slack between a publication and the phase that asks for it, in phases: nrs - 1 without look-ahead,
-    // nrs - 2 with it, nrs - 3 with the deferred epilogue on top; a hand-off takes ~1.5 phases, so each form
-    // needs a slack of 2 (measured per step at 20 steps, U = 512: 4 phases deferred 16.8 us, 3 phases with
-    // look-ahead 11.8 us against 9.1 us for 5 phases deferred -- tools/lstm_persist_rows.py)
+    // nrs - 2 with it, nrs - 3 with the deferred epilogue on top; a hand-off takes ~1.5 phases, so the deferred
+    // form needs 5 phases (measured per step at 20 steps, U = 512: 4 phases deferred 16.8 us, with plain
+    // look-ahead 8.9 us; 5 phases deferred 9.1 us -- tools/lstm_persist_rows.py)
     const bool defer = nrs >= 5;
 
     if (wave < 4) {
@@ -546,8 +546,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
         if (defer) ps_fwd_mfma_wave<CPW, 2>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
         // look-ahead asks for the NEXT phase's rows at the start of a phase: with two phases those were
         // published by the phase just finished, so the full hand-off latency sat in front of every phase
-        // (3.8 us per phase); domains with up to 3 phases poll for their own rows instead
-        else if (nrs >= 4) ps_fwd_mfma_wave<CPW, 1>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
+        // (3.8 us per phase); 1- and 2-phase domains poll for their own rows instead (3 phases: look-ahead
+        // measured better, 8.9 against 13.1 us per step for a 3,2,2,2-phase split)
+        else if (nrs >= 3) ps_fwd_mfma_wave<CPW, 1>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
         else ps_fwd_mfma_wave<CPW, 0>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
         if (e.lane_on)
             for (int q = 0; q < nrs; ++q) {
