@@ -254,7 +254,61 @@ def north_star_targets(config, table):
         del sets
         torch.cuda.empty_cache()
     out['lstm_gate_kernel'] = gate
+    out['recurrent_step'] = recurrent_step_microbench(M, U, config.max_demo_len)
     return out
+
+
+def recurrent_step_microbench(M, U, T):
+    """The recurrent kernels on the encoder / action-decoder shape (M = B*k rows, T steps) outside the step:
+    one persistent launch per sequence timed at T and 2T steps, so that the per-call cost (preparation launch,
+    kernel prologue: weights into registers, launch latency) separates from the per-time-step rate.  flops per
+    time step = 2 * M * 4U * U (the h.Wh / dz.Wh^T product; the input projection is a separate GEMM)."""
+    from demo2program_amd import kernels as K
+    g = torch.Generator().manual_seed(7)
+
+    def seq(Tn):
+        f = dict(M=M, U=U, n_steps=Tn, z=(torch.rand(Tn * M, 4 * U, generator=g) - 0.5).cuda(),
+                 Wh=((torch.rand(U, 4 * U, generator=g) - 0.5) * 0.1).cuda(),
+                 h0=(torch.rand(M, U, generator=g) - 0.5).cuda(), c0=(torch.rand(M, U, generator=g) - 0.5).cuda(),
+                 hout=torch.zeros(Tn, M, U, device='cuda'), cs=torch.zeros(Tn, M, U, device='cuda'))
+        b = dict(M=M, U=U, n_steps=Tn, z=f['z'], Wh=f['Wh'], c0=f['c0'], cs=f['cs'],
+                 dhout=(torch.rand(Tn, M, U, generator=g) - 0.5).cuda(), dz=torch.zeros(Tn * M, 4 * U, device='cuda'),
+                 dh0=torch.zeros(M, U, device='cuda'), dc0=torch.zeros(M, U, device='cuda'))
+        return f, b
+
+    def timed(fn, reps=10):
+        fn()
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps           # us per call
+    res = {'rows': M, 'units': U, 'note': 'standalone: one persistent launch per sequence (+ its preparation launch) '
+                                           'at T and 2T steps; peak = fp32 MFMA'}
+    flop_step = 2.0 * M * 4 * U * U
+    for name, key in (('forward', 0), ('backward', 1)):
+        ts = []
+        for Tn in (T, 2 * T):
+            q = seq(Tn)
+            if key == 0:
+                ts.append(min(timed(lambda: K.lstm_seq_fwd_multi([q[0]])) for _ in range(2)))
+            else:
+                K.lstm_seq_fwd_multi([q[0]])
+                ts.append(min(timed(lambda: K.lstm_seq_bwd_multi([q[1]])) for _ in range(2)))
+        steady = (ts[1] - ts[0]) / T
+        res[name] = {'us_per_call_at_T': round(ts[0], 1), 'T': T,
+                     'us_per_time_step_at_T': round(ts[0] / T, 2),
+                     'frac_at_T': round(flop_step / (ts[0] / T * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     'us_per_time_step_steady': round(steady, 2),
+                     'frac_steady': round(flop_step / (steady * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                     'us_per_call_fixed': round(ts[0] - steady * T, 1)}
+    if K.lstm_persist_error(True):
+        res['error'] = 'a persistent launch gave up a hand-off during this micro-benchmark'
+    return res
 
 
 def config4_leg(steps=10, warmup=3):
