@@ -35,6 +35,15 @@ static inline BnPlan bn_plan(int R, int C, int G) {
     return p;
 }
 
+// Several independent, equally shaped BN problems in one launch (grid.z = problem): every pointer argument of
+// problem b is the first problem's plus b times a stride -- xs for the [R, C] inputs (x, dy), ys for the [R, C]
+// outputs (y, dx), ps for per-channel parameters and their gradients (gamma, beta, dgamma, dbeta, the bias
+// gradient), ms for the moving statistics, ss = G*C for mean / rstd / var, wsb BYTES for the workspace.
+// All zero for a single problem.
+struct BnBatch { long xs, ys, ps, ms, ss, wsb; };
+#define BN_SHIFT(ptr, stride) ptr = (ptr) ? (ptr) + (long)blockIdx.z * (stride) : (ptr)
+#define BN_SHIFT_WS(ptr, T) ptr = (T*)((char*)(ptr) + (long)blockIdx.z * bb.wsb)
+
 static inline int gcd_i(int a, int b) { while (b) { int t = a % b; a = b; b = t; } return a; }
 
 // grid of the backward apply pass when it also produces column sums: thread count a multiple
@@ -64,7 +73,8 @@ extern "C" size_t d2p_bn_ws_bytes(int R, int C, int G) {
 template <int MODE, int VEC>
 __global__ void __launch_bounds__(256)
 bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, const float* x,
-                  const float* dy, const float* mean, const float* rstd, double* partial) {
+                  const float* dy, const float* mean, const float* rstd, double* partial, BnBatch bb) {
+    BN_SHIFT(x, bb.xs); BN_SHIFT(dy, bb.xs); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss); BN_SHIFT_WS(partial, double);
     __shared__ double red[2][VEC][256];
     const int g = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     const int tid = threadIdx.x;
@@ -140,7 +150,9 @@ bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, co
 // dgamma / dbeta (sums over the groups) in the backward kernel.
 __global__ void __launch_bounds__(256)
 bn_finalize_fwd_kernel(int n, int C, int G, int S, const double* partial, float* mean, float* rstd,
-                       float* var_out, float* moving_mean, float* moving_var, float decay) {
+                       float* var_out, float* moving_mean, float* moving_var, float decay, BnBatch bb) {
+    BN_SHIFT_WS(partial, const double); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss); BN_SHIFT(var_out, bb.ss);
+    BN_SHIFT(moving_mean, bb.ms); BN_SHIFT(moving_var, bb.ms);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -176,7 +188,8 @@ bn_finalize_fwd_kernel(int n, int C, int G, int S, const double* partial, float*
 // m12[(g*C+c)*2 + {0,1}] = (mean_g(dy), mean_g(dy*xhat)); dgamma / dbeta = sums over the groups
 __global__ void __launch_bounds__(256)
 bn_finalize_bwd_kernel(int n, int C, int G, int S, const double* partial, float* m12, float* dgamma,
-                       float* dbeta) {
+                       float* dbeta, BnBatch bb) {
+    BN_SHIFT_WS(partial, const double); BN_SHIFT_WS(m12, float); BN_SHIFT(dgamma, bb.ps); BN_SHIFT(dbeta, bb.ps);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -205,7 +218,9 @@ bn_finalize_bwd_kernel(int n, int C, int G, int S, const double* partial, float*
 
 __global__ void __launch_bounds__(256)
 bn_apply_fwd_kernel(long R, int C, int G, int inner, const float* x, const float* gamma,
-                    const float* beta, const float* mean, const float* rstd, float* y) {
+                    const float* beta, const float* mean, const float* rstd, float* y, BnBatch bb) {
+    BN_SHIFT(x, bb.xs); BN_SHIFT(gamma, bb.ps); BN_SHIFT(beta, bb.ps); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss);
+    BN_SHIFT(y, bb.ys);
     const long total = R * C;
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
         const long r = idx / C;
@@ -217,7 +232,9 @@ bn_apply_fwd_kernel(long R, int C, int G, int inner, const float* x, const float
 
 __global__ void __launch_bounds__(256)
 bn_apply_fwd_vec4_kernel(long R, int C, int G, int inner, const float* x, const float* gamma,
-                         const float* beta, const float* mean, const float* rstd, float* y) {
+                         const float* beta, const float* mean, const float* rstd, float* y, BnBatch bb) {
+    BN_SHIFT(x, bb.xs); BN_SHIFT(gamma, bb.ps); BN_SHIFT(beta, bb.ps); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss);
+    BN_SHIFT(y, bb.ys);
     const int C4 = C >> 2;
     const long total = R * C4;
     for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
@@ -250,7 +267,10 @@ bn_apply_bwd_kernel(int R, int C, int G, int inner, const float* __restrict__ x,
                     const float* __restrict__ dy, const float* __restrict__ gamma,
                     const float* __restrict__ mean, const float* __restrict__ rstd,
                     const float* __restrict__ m12, int act_bwd, float* __restrict__ dx,
-                    float* __restrict__ colpart) {
+                    float* __restrict__ colpart, BnBatch bb) {
+    BN_SHIFT(x, bb.xs); BN_SHIFT(dy, bb.xs); BN_SHIFT(gamma, bb.ps); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss);
+    BN_SHIFT_WS(m12, const float); BN_SHIFT(dx, bb.ys);
+    if (colpart) BN_SHIFT_WS(colpart, float);
     const int CV = C / VEC;
     const long tid = blockIdx.x * 256L + threadIdx.x;
     const long stride = gridDim.x * 256L;
@@ -309,7 +329,8 @@ bn_apply_bwd_kernel(int R, int C, int G, int inner, const float* __restrict__ x,
 
 // out[c] = sum over blocks of colpart[block][c] (fixed order: deterministic)
 __global__ void __launch_bounds__(256)
-bn_colsum_finalize_kernel(int C, int nblocks, const float* __restrict__ colpart, float* __restrict__ out) {
+bn_colsum_finalize_kernel(int C, int nblocks, const float* __restrict__ colpart, float* __restrict__ out, BnBatch bb) {
+    BN_SHIFT_WS(colpart, const float); BN_SHIFT(out, bb.ps);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (c >= C) return;
@@ -334,45 +355,125 @@ static inline int ew_blocks(long total) {
     return (int)b;
 }
 
+static int bn_fwd_impl(int nb, long xs, long ys, long ps, long ms, int R, int C, int G, int inner, const float* x,
+                       const float* gamma, const float* beta, float* y, float* mean, float* rstd, float* var_out,
+                       float* moving_mean, float* moving_var, float decay, void* ws, size_t ws_bytes,
+                       d2p_stream_t stream) {
+    int rc = bn_check(R, C, G, inner);
+    if (rc) return rc;
+    if (R == 0) return D2P_OK;
+    D2P_REQUIRE(nb >= 1 && nb <= 65535, D2P_EINVAL, "bn fwd: batch of %d problems", nb);
+    D2P_REQUIRE(x && gamma && beta && y && mean && rstd, D2P_EINVAL, "bn fwd: null pointer");
+    D2P_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), D2P_EINVAL,
+                "bn fwd: moving_mean and moving_var go together");
+    const size_t ws1 = align_up(d2p_bn_ws_bytes(R, C, G), 256);
+    D2P_REQUIRE(ws && ws_bytes >= (nb > 1 ? ws1 * nb : d2p_bn_ws_bytes(R, C, G)), D2P_EWS,
+                "bn fwd: workspace too small (%zu < %zu)", ws_bytes, ws1 * nb);
+    hipStream_t st = as_stream(stream);
+    BnPlan p = bn_plan(R, C, G);
+    const int n = R / G;
+    const BnBatch bb{xs, ys, ps, ms, nb > 1 ? (long)G * C : 0L, nb > 1 ? (long)ws1 : 0L};
+    double* partial = (double*)ws;
+    const bool al = ((xs | ys | ps) % 4) == 0;
+    const bool vec4 = (C % 4 == 0) && (((uintptr_t)x & 15) == 0) && al;
+    if (vec4)
+        hipLaunchKernelGGL((bn_partial_kernel<0, 4>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
+                           p.lanes_c, p.row_lanes, x, (const float*)nullptr, (const float*)nullptr,
+                           (const float*)nullptr, partial, bb);
+    else
+        hipLaunchKernelGGL((bn_partial_kernel<0, 1>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
+                           (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, (const float*)nullptr,
+                           (const float*)nullptr, (const float*)nullptr, partial, bb);
+    D2P_LAUNCH_CHECK("bn_partial_fwd");
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, n, C, G,
+                       p.S, partial, mean, rstd, var_out, moving_mean, moving_var, decay, bb);
+    D2P_LAUNCH_CHECK("bn_finalize_fwd");
+    const bool vec = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma |
+                                              (uintptr_t)beta | (uintptr_t)mean | (uintptr_t)rstd) & 15) == 0);
+    if (vec) {
+        hipLaunchKernelGGL(bn_apply_fwd_vec4_kernel, dim3(ew_blocks((long)R * C / 4), 1, nb), dim3(256), 0,
+                           st, (long)R, C, G, inner, x, gamma, beta, mean, rstd, y, bb);
+    } else {
+        hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks((long)R * C), 1, nb), dim3(256), 0, st,
+                           (long)R, C, G, inner, x, gamma, beta, mean, rstd, y, bb);
+    }
+    D2P_LAUNCH_CHECK("bn_apply_fwd");
+    return D2P_OK;
+}
+
 extern "C" int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, const float* gamma,
                                 const float* beta, float* y, float* mean, float* rstd,
                                 float* var_out, float* moving_mean, float* moving_var, float decay,
                                 void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    return bn_fwd_impl(1, 0, 0, 0, 0, R, C, G, inner, x, gamma, beta, y, mean, rstd, var_out, moving_mean, moving_var,
+                       decay, ws, ws_bytes, stream);
+}
+extern "C" size_t d2p_bn_batched_ws_bytes(int nb, int R, int C, int G) {
+    return nb <= 0 ? 0 : align_up(d2p_bn_ws_bytes(R, C, G), 256) * (size_t)nb;
+}
+extern "C" int d2p_bn_group_fwd_batched(int nb, long xs, long ys, long ps, long ms, int R, int C, int G, int inner,
+                                        const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                                        float* rstd, float* var_out, float* moving_mean, float* moving_var,
+                                        float decay, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    return bn_fwd_impl(nb, xs, ys, ps, ms, R, C, G, inner, x, gamma, beta, y, mean, rstd, var_out, moving_mean,
+                       moving_var, decay, ws, ws_bytes, stream);
+}
+
+static int bn_bwd_impl(int nb, long xs, long ys, long ps, int R, int C, int G, int inner, const float* x,
+                       const float* dy, const float* gamma, const float* mean, const float* rstd, int act_bwd,
+                       float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* ws, size_t ws_bytes,
+                       d2p_stream_t stream) {
     int rc = bn_check(R, C, G, inner);
     if (rc) return rc;
     if (R == 0) return D2P_OK;
-    D2P_REQUIRE(x && gamma && beta && y && mean && rstd, D2P_EINVAL, "bn fwd: null pointer");
-    D2P_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), D2P_EINVAL,
-                "bn fwd: moving_mean and moving_var go together");
-    D2P_REQUIRE(ws && ws_bytes >= d2p_bn_ws_bytes(R, C, G), D2P_EWS,
-                "bn fwd: workspace too small (%zu < %zu)", ws_bytes, d2p_bn_ws_bytes(R, C, G));
+    D2P_REQUIRE(nb >= 1 && nb <= 65535, D2P_EINVAL, "bn bwd: batch of %d problems", nb);
+    D2P_REQUIRE(x && dy && gamma && mean && rstd && dx, D2P_EINVAL, "bn bwd: null pointer");
+    const size_t ws1 = align_up(d2p_bn_ws_bytes(R, C, G), 256);
+    D2P_REQUIRE(ws && ws_bytes >= (nb > 1 ? ws1 * nb : d2p_bn_ws_bytes(R, C, G)), D2P_EWS,
+                "bn bwd: workspace too small (%zu < %zu)", ws_bytes, ws1 * nb);
     hipStream_t st = as_stream(stream);
     BnPlan p = bn_plan(R, C, G);
     const int n = R / G;
+    const BnBatch bb{xs, ys, ps, 0L, nb > 1 ? (long)G * C : 0L, nb > 1 ? (long)ws1 : 0L};
     double* partial = (double*)ws;
-    const bool vec4 = (C % 4 == 0) && (((uintptr_t)x & 15) == 0);
+    double* gsum = partial + (size_t)G * p.S * C * 2;
+    float* m12 = (float*)(gsum + (size_t)G * C * 2);
+    const bool al = ((xs | ys | ps) % 4) == 0;
+    const bool vec4 = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
     if (vec4)
-        hipLaunchKernelGGL((bn_partial_kernel<0, 4>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
-                           p.lanes_c, p.row_lanes, x, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, partial);
+        hipLaunchKernelGGL((bn_partial_kernel<1, 4>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
+                           p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial, bb);
     else
-        hipLaunchKernelGGL((bn_partial_kernel<0, 1>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
-                           (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, partial);
-    D2P_LAUNCH_CHECK("bn_partial_fwd");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, n, C, G,
-                       p.S, partial, mean, rstd, var_out, moving_mean, moving_var, decay);
-    D2P_LAUNCH_CHECK("bn_finalize_fwd");
-    const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma |
-                                        (uintptr_t)beta | (uintptr_t)mean | (uintptr_t)rstd) & 15) == 0);
-    if (vec) {
-        hipLaunchKernelGGL(bn_apply_fwd_vec4_kernel, dim3(ew_blocks((long)R * C / 4)), dim3(256), 0,
-                           st, (long)R, C, G, inner, x, gamma, beta, mean, rstd, y);
+        hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
+                           (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, dy, mean, rstd, partial, bb);
+    D2P_LAUNCH_CHECK("bn_partial_bwd");
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, n, C, G,
+                       p.S, partial, m12, dgamma, dbeta, bb);
+    D2P_LAUNCH_CHECK("bn_finalize_bwd");
+    const bool v4 = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
+    float* colpart = (float*)((char*)m12 + align_up((size_t)G * C * 2 * sizeof(float), 16));
+    if (dx_colsum) {
+        const int vec = v4 ? 4 : 1;
+        const int blocks = bn_sum_blocks(R, C, vec);
+        if (v4)
+            hipLaunchKernelGGL((bn_apply_bwd_kernel<4, true>), dim3(blocks, 1, nb), dim3(256), 0, st, R, C, G, inner, x,
+                               dy, gamma, mean, rstd, m12, act_bwd, dx, colpart, bb);
+        else
+            hipLaunchKernelGGL((bn_apply_bwd_kernel<1, true>), dim3(blocks, 1, nb), dim3(256), 0, st, R, C, G, inner, x,
+                               dy, gamma, mean, rstd, m12, act_bwd, dx, colpart, bb);
+        D2P_LAUNCH_CHECK("bn_apply_bwd");
+        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, C, blocks, colpart,
+                           dx_colsum, bb);
+        D2P_LAUNCH_CHECK("bn_colsum_finalize");
     } else {
-        hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks((long)R * C)), dim3(256), 0, st,
-                           (long)R, C, G, inner, x, gamma, beta, mean, rstd, y);
+        if (v4)
+            hipLaunchKernelGGL((bn_apply_bwd_kernel<4, false>), dim3(ew_blocks((long)R * C / 4), 1, nb), dim3(256), 0, st,
+                               R, C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr, bb);
+        else
+            hipLaunchKernelGGL((bn_apply_bwd_kernel<1, false>), dim3(ew_blocks((long)R * C), 1, nb), dim3(256), 0, st, R,
+                               C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr, bb);
+        D2P_LAUNCH_CHECK("bn_apply_bwd");
     }
-    D2P_LAUNCH_CHECK("bn_apply_fwd");
     return D2P_OK;
 }
 
@@ -380,54 +481,15 @@ extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, 
                                 const float* gamma, const float* mean, const float* rstd,
                                 int act_bwd, float* dx, float* dgamma, float* dbeta, float* dx_colsum,
                                 void* ws, size_t ws_bytes, d2p_stream_t stream) {
-    int rc = bn_check(R, C, G, inner);
-    if (rc) return rc;
-    if (R == 0) return D2P_OK;
-    D2P_REQUIRE(x && dy && gamma && mean && rstd && dx, D2P_EINVAL, "bn bwd: null pointer");
-    D2P_REQUIRE(ws && ws_bytes >= d2p_bn_ws_bytes(R, C, G), D2P_EWS,
-                "bn bwd: workspace too small (%zu < %zu)", ws_bytes, d2p_bn_ws_bytes(R, C, G));
-    hipStream_t st = as_stream(stream);
-    BnPlan p = bn_plan(R, C, G);
-    const int n = R / G;
-    double* partial = (double*)ws;
-    double* gsum = partial + (size_t)G * p.S * C * 2;
-    float* m12 = (float*)(gsum + (size_t)G * C * 2);
-    const bool vec4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
-    if (vec4)
-        hipLaunchKernelGGL((bn_partial_kernel<1, 4>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
-                           p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial);
-    else
-        hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(G, p.S), dim3(256), 0, st, n, C, G, inner,
-                           (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, dy, mean, rstd, partial);
-    D2P_LAUNCH_CHECK("bn_partial_bwd");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, n, C, G,
-                       p.S, partial, m12, dgamma, dbeta);
-    D2P_LAUNCH_CHECK("bn_finalize_bwd");
-    const bool v4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
-    float* colpart = (float*)((char*)m12 + align_up((size_t)G * C * 2 * sizeof(float), 16));
-    if (dx_colsum) {
-        const int vec = v4 ? 4 : 1;
-        const int blocks = bn_sum_blocks(R, C, vec);
-        if (v4)
-            hipLaunchKernelGGL((bn_apply_bwd_kernel<4, true>), dim3(blocks), dim3(256), 0, st, R, C, G, inner, x, dy,
-                               gamma, mean, rstd, m12, act_bwd, dx, colpart);
-        else
-            hipLaunchKernelGGL((bn_apply_bwd_kernel<1, true>), dim3(blocks), dim3(256), 0, st, R, C, G, inner, x, dy,
-                               gamma, mean, rstd, m12, act_bwd, dx, colpart);
-        D2P_LAUNCH_CHECK("bn_apply_bwd");
-        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(ceil_div(C, 4)), dim3(256), 0, st, C, blocks, colpart,
-                           dx_colsum);
-        D2P_LAUNCH_CHECK("bn_colsum_finalize");
-    } else {
-        if (v4)
-            hipLaunchKernelGGL((bn_apply_bwd_kernel<4, false>), dim3(ew_blocks((long)R * C / 4)), dim3(256), 0, st, R,
-                               C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr);
-        else
-            hipLaunchKernelGGL((bn_apply_bwd_kernel<1, false>), dim3(ew_blocks((long)R * C)), dim3(256), 0, st, R, C,
-                               G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr);
-        D2P_LAUNCH_CHECK("bn_apply_bwd");
-    }
-    return D2P_OK;
+    return bn_bwd_impl(1, 0, 0, 0, R, C, G, inner, x, dy, gamma, mean, rstd, act_bwd, dx, dgamma, dbeta, dx_colsum, ws,
+                       ws_bytes, stream);
+}
+extern "C" int d2p_bn_group_bwd_batched(int nb, long xs, long ys, long ps, int R, int C, int G, int inner,
+                                        const float* x, const float* dy, const float* gamma, const float* mean,
+                                        const float* rstd, int act_bwd, float* dx, float* dgamma, float* dbeta,
+                                        float* dx_colsum, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    return bn_bwd_impl(nb, xs, ys, ps, R, C, G, inner, x, dy, gamma, mean, rstd, act_bwd, dx, dgamma, dbeta, dx_colsum,
+                       ws, ws_bytes, stream);
 }
 
 __global__ void __launch_bounds__(256)

@@ -214,6 +214,31 @@ def bn_bwd(x2d, dy, gamma, mean, rstd, G, inner, act_bwd, dgamma, dbeta, dx=None
     return dx
 
 
+def bn_fwd_batched(x3d, gamma, beta, pstride, G, inner, y, mean, rstd, moving=None, mstride=0, decay=0.9):
+    """nb = x3d.shape[0] independent BN problems [R, C] in one set of launches: problem b uses gamma + b*pstride
+    (beta likewise), moving statistics + b*mstride, mean / rstd [nb, G, C], y [nb, R, C]."""
+    _require_gpu(x3d)
+    nb, R, C = x3d.shape
+    ws, wsb = SCRATCH.get(call.d2p_bn_batched_ws_bytes(nb, R, C, G))
+    mm, mv = moving if moving is not None else (None, None)
+    call.d2p_bn_group_fwd_batched(nb, x3d.stride(0), y.stride(0), pstride, mstride, R, C, G, inner, ptr(x3d), ptr(gamma),
+                                  ptr(beta), ptr(y), ptr(mean), ptr(rstd), None, ptr(mm), ptr(mv), decay, ws, wsb,
+                                  current_stream())
+    return y, mean, rstd
+
+
+def bn_bwd_batched(x3d, dy3d, gamma, pstride, mean, rstd, G, inner, act_bwd, dgamma, dbeta, dx, dbias=None):
+    """Backward of bn_fwd_batched: dgamma / dbeta / dbias of problem b land at + b*pstride."""
+    _require_gpu(x3d, dy3d)
+    nb, R, C = x3d.shape
+    assert dy3d.stride(0) == x3d.stride(0)
+    ws, wsb = SCRATCH.get(call.d2p_bn_batched_ws_bytes(nb, R, C, G))
+    call.d2p_bn_group_bwd_batched(nb, x3d.stride(0), dx.stride(0), pstride, R, C, G, inner, ptr(x3d), ptr(dy3d), ptr(gamma),
+                                  ptr(mean), ptr(rstd), 1 if act_bwd else 0, ptr(dx), ptr(dgamma), ptr(dbeta),
+                                  ptr(dbias), ws, wsb, current_stream())
+    return dx
+
+
 def bn_inference(x2d, gamma, beta, moving_mean, moving_var, y=None):
     """is_training=False batch norm: normalise [R, C] rows with the moving statistics."""
     _require_gpu(x2d)

@@ -156,6 +156,13 @@ class Model(object):
                      'synthesis_baseline': ()}[self.variant]
         for s in bn_scopes:
             self._init_moving(s, U)
+        # the two relation networks' batch norms run as two-problem launches: their moving statistics sit at a
+        # constant stride (views of one allocation; checkpoint loading copies in place)
+        for leaf in ('fc1', 'fc2'):
+            if 'rn_h/' + leaf in self.moving:
+                mm, mv = torch.zeros(2, U, device='cuda'), torch.ones(2, U, device='cuda')
+                self.moving['rn_h/' + leaf] = (mm[0], mv[0])
+                self.moving['rn_c/' + leaf] = (mm[1], mv[1])
         self.track_moving = True
         # scheduled sampling state (device memory: read by kernels inside a captured graph)
         #   _ss_prob : probability of feeding the decoder its own sample instead of the ground truth
@@ -624,12 +631,10 @@ class Model(object):
         y1a = self._buf('rn/y1a', (2, R, U))
         K.rn_pair_fwd(PQ[0], PQ[1], p['rn_h/fc1/b'], y1a, 2 * B, k, U, scopes=2, bias_stride=ps)
         y1, y2a, y2 = self._buf('rn/y1', (2, R, U)), self._buf('rn/y2a', (2, R, U)), self._buf('rn/y2', (2, R, U))
-        st1 = [self._bn_fwd(sc + '/fc1', y1a[i], p[sc + '/fc1/gamma'], p[sc + '/fc1/beta'], 1, 1, y=y1[i])
-               for i, sc in enumerate(self.RN_SCOPES)]
+        st1 = self._rn_bn_fwd('fc1', y1a, y1, ps)
         K.gemm_batched('nn', 2, 1, R, U, U, y1, U, (R * U, 0), W2, U, (ps, 0), y2a, U, (R * U, 0),
                        bias=p['rn_h/fc2/b'], sbias=(ps, 0), act=1)
-        st2 = [self._bn_fwd(sc + '/fc2', y2a[i], p[sc + '/fc2/gamma'], p[sc + '/fc2/beta'], 1, 1, y=y2[i])
-               for i, sc in enumerate(self.RN_SCOPES)]
+        st2 = self._rn_bn_fwd('fc2', y2a, y2, ps)
         base = None
         if add_mean:
             base = self._buf('rn/base', (2, B, U))
@@ -637,6 +642,25 @@ class Model(object):
         out = self._buf('rn/out', (2, B, U))
         K.pair_mean_fwd(y2, base, out, 2 * B, k * k, U)
         return dict(feat=feat, y1a=y1a, y1=y1, y2a=y2a, st1=st1, st2=st2, out=out, add_mean=add_mean, ps=ps)
+
+    def _rn_bn_fwd(self, leaf, x, y, ps):
+        """Batch norm of layer `leaf` of BOTH relation networks: x, y [2, R, U].  Training: one two-problem
+        launch set (own statistics, own parameters at stride ps, own moving statistics); returns per scope
+        (y, mean, rstd) like _bn_fwd."""
+        p = self.params.p
+        if not self.is_train or os.environ.get('D2P_RN_BN_BATCHED', '1') != '1':
+            return [self._bn_fwd(sc + '/' + leaf, x[i], p[sc + '/' + leaf + '/gamma'], p[sc + '/' + leaf + '/beta'],
+                                 1, 1, y=y[i]) for i, sc in enumerate(self.RN_SCOPES)]
+        U = x.shape[2]
+        for q in ('gamma', 'beta'):
+            assert (p['rn_c/%s/%s' % (leaf, q)].data_ptr() - p['rn_h/%s/%s' % (leaf, q)].data_ptr()) // 4 == ps
+        mean = self._buf('rn/%s/bn_mean' % leaf, (2, 1, U))
+        rstd = self._buf('rn/%s/bn_rstd' % leaf, (2, 1, U))
+        mm, mv = self.moving['rn_h/' + leaf]
+        assert self.moving['rn_c/' + leaf][0].data_ptr() - mm.data_ptr() == 4 * U
+        K.bn_fwd_batched(x, p['rn_h/%s/gamma' % leaf], p['rn_h/%s/beta' % leaf], ps, 1, 1, y, mean, rstd,
+                         moving=(mm, mv) if self.track_moving else None, mstride=U)
+        return [(y[i], mean[i], rstd[i]) for i in range(2)]
 
     # ------------------------------------------------------------------ backward
     def decoder_grad_offset(self):
@@ -927,16 +951,26 @@ class Model(object):
         dy2 = self._buf('rn/dy2', (2, R, U))
         K.pair_mean_bwd(d_out, dy2, 2 * B, k * k, U)
         dy2a, dy1, dy1a = self._buf('rn/dy2a', (2, R, U)), self._buf('rn/dy1', (2, R, U)), self._buf('rn/dy1a', (2, R, U))
+        batched = os.environ.get('D2P_RN_BN_BATCHED', '1') == '1'
+        if batched:
+            # st[i] = (y, mean, rstd) with mean / rstd views of one [2, 1, U] buffer each
+            K.bn_bwd_batched(r['y2a'], dy2, p['rn_h/fc2/gamma'], ps, r['st2'][0][1], r['st2'][0][2], 1, 1, True,
+                             g['rn_h/fc2/gamma'], g['rn_h/fc2/beta'], dy2a, dbias=g['rn_h/fc2/b'])
         for i, sc in enumerate(self.RN_SCOPES):
-            _, m2, r2 = r['st2'][i]
-            K.bn_bwd(r['y2a'][i], dy2[i], p[sc + '/fc2/gamma'], m2, r2, 1, 1, True,
-                     g[sc + '/fc2/gamma'], g[sc + '/fc2/beta'], dx=dy2a[i], dbias=g[sc + '/fc2/b'])
+            if not batched:
+                _, m2, r2 = r['st2'][i]
+                K.bn_bwd(r['y2a'][i], dy2[i], p[sc + '/fc2/gamma'], m2, r2, 1, 1, True,
+                         g[sc + '/fc2/gamma'], g[sc + '/fc2/beta'], dx=dy2a[i], dbias=g[sc + '/fc2/b'])
             K.matmul_tn(r['y1'][i], dy2a[i], out=g[sc + '/fc2/W'])       # K = B*k*k: split-K, one call each
         K.gemm_batched('nt', 2, 1, R, U, U, dy2a, U, (R * U, 0), W2, U, (ps, 0), dy1, U, (R * U, 0))
-        for i, sc in enumerate(self.RN_SCOPES):
-            _, m1, r1 = r['st1'][i]
-            K.bn_bwd(r['y1a'][i], dy1[i], p[sc + '/fc1/gamma'], m1, r1, 1, 1, True,
-                     g[sc + '/fc1/gamma'], g[sc + '/fc1/beta'], dx=dy1a[i], dbias=g[sc + '/fc1/b'])
+        if batched:
+            K.bn_bwd_batched(r['y1a'], dy1, p['rn_h/fc1/gamma'], ps, r['st1'][0][1], r['st1'][0][2], 1, 1, True,
+                             g['rn_h/fc1/gamma'], g['rn_h/fc1/beta'], dy1a, dbias=g['rn_h/fc1/b'])
+        else:
+            for i, sc in enumerate(self.RN_SCOPES):
+                _, m1, r1 = r['st1'][i]
+                K.bn_bwd(r['y1a'][i], dy1[i], p[sc + '/fc1/gamma'], m1, r1, 1, 1, True,
+                         g[sc + '/fc1/gamma'], g[sc + '/fc1/beta'], dx=dy1a[i], dbias=g[sc + '/fc1/b'])
         dPQ = self._buf('rn/dPQ', (2, 2, M, U))                          # [half][scope], as PQ
         K.rn_pair_bwd(dy1a, dPQ[0], dPQ[1], 2 * B, k, U)
         # gW1[:U] = feat^T dP, gW1[U:] = feat^T dQ for both scopes: four problems, one launch

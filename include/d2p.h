@@ -151,6 +151,21 @@ int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float
                      const float* gamma, const float* mean, const float* rstd, int act_bwd,
                      float* dx, float* dgamma, float* dbeta, float* dx_colsum,
                      void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* nb independent, equally shaped batch-norm problems in ONE set of launches (grid.z = problem).  Problem b uses
+ * every pointer of problem 0 plus b times a stride, in floats: xs for the [R, C] inputs (x, dy), ys for the
+ * [R, C] outputs (y, dx), ps for per-channel parameters and their gradients (gamma, beta, dgamma, dbeta,
+ * dx_colsum), ms for the moving statistics; mean / rstd / var_out are [nb][G][C]; the workspace holds
+ * d2p_bn_batched_ws_bytes(nb, R, C, G).  Same arithmetic as nb separate calls (bit-identical).  Used for the two
+ * relation networks (rn_h / rn_c: same shapes, own parameters, models/model_full.py:333-362). */
+size_t d2p_bn_batched_ws_bytes(int nb, int R, int C, int G);
+int d2p_bn_group_fwd_batched(int nb, long xs, long ys, long ps, long ms, int R, int C, int G, int inner,
+                             const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                             float* rstd, float* var_out, float* moving_mean, float* moving_var, float decay,
+                             void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_bn_group_bwd_batched(int nb, long xs, long ys, long ps, int R, int C, int G, int inner, const float* x,
+                             const float* dy, const float* gamma, const float* mean, const float* rstd,
+                             int act_bwd, float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* ws,
+                             size_t ws_bytes, d2p_stream_t stream);
 /* d2p_bn_group_fwd's moving_mean / moving_var ([C], nullable together): the G moving-average
  * updates of this call (one per group = one per reference BN call, in group order) are applied
  * by the statistics kernel itself; d2p_bn_update_moving below is the same update stand-alone. */

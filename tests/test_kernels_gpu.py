@@ -37,6 +37,44 @@ def rnd(*shape, seed=0, scale=1.0):
     return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
 
 
+# ------------------------------------------------------------------ batched batch norm
+@pytest.mark.parametrize('R,C,G,inner', [(3200, 512, 1, 1), (640, 48, 10, 4), (70, 6, 2, 5)])
+def test_bn_two_problems_in_one_launch_equal_two_calls(K, R, C, G, inner):
+    """d2p_bn_group_{fwd,bwd}_batched: two independent BN problems (own inputs, parameters, moving statistics --
+    the two relation networks) in one set of launches give bit for bit what two separate calls give."""
+    nb, ps = 2, 3 * C + 8                     # parameters of problem b at + b*ps floats (as in a flat buffer)
+    x = dev(rnd(nb, R, C, seed=41, scale=3.0))
+    dy = dev(rnd(nb, R, C, seed=42))
+    par = dev(rnd(nb, ps, seed=43))           # per problem: gamma | beta | bias-grad slot | padding
+    gamma, beta = par[:, :C], par[:, C:2 * C]
+    # separate calls
+    ys, means, rstds, mms, mvs, dxs, dgs, dbs, dbias = [], [], [], [], [], [], [], [], []
+    for b in range(nb):
+        mm, mv = torch.zeros(C, device='cuda') + 0.25 * b, torch.ones(C, device='cuda')
+        y, mean, rstd, _ = K.bn_fwd(x[b], gamma[b].contiguous(), beta[b].contiguous(), G, inner, moving=(mm, mv))
+        dg, db, dbi = (torch.empty(C, device='cuda') for _ in range(3))
+        dx = K.bn_bwd(x[b], dy[b], gamma[b].contiguous(), mean, rstd, G, inner, True, dg, db, dbias=dbi)
+        for lst, v in zip((ys, means, rstds, mms, mvs, dxs, dgs, dbs, dbias), (y, mean, rstd, mm, mv, dx, dg, db, dbi)):
+            lst.append(v.clone())
+    # one batched call each way
+    y2 = torch.empty(nb, R, C, device='cuda')
+    mean2, rstd2 = torch.empty(nb, G, C, device='cuda'), torch.empty(nb, G, C, device='cuda')
+    mm2 = torch.stack([torch.zeros(C, device='cuda') + 0.25 * b for b in range(nb)])
+    mv2 = torch.ones(nb, C, device='cuda')
+    K.bn_fwd_batched(x, par[0, :C], par[0, C:2 * C], ps, G, inner, y2, mean2, rstd2, moving=(mm2, mv2), mstride=C)
+    grads = torch.zeros(nb, ps, device='cuda')
+    dx2 = torch.empty(nb, R, C, device='cuda')
+    K.bn_bwd_batched(x, dy, par[0, :C], ps, mean2, rstd2, G, inner, True, grads[0, :C], grads[0, C:2 * C], dx2,
+                     dbias=grads[0, 2 * C:3 * C])
+    for b in range(nb):
+        assert torch.equal(y2[b], ys[b]) and torch.equal(mean2[b], means[b]) and torch.equal(rstd2[b], rstds[b])
+        assert torch.equal(mm2[b], mms[b]) and torch.equal(mv2[b], mvs[b])
+        assert torch.equal(dx2[b], dxs[b])
+        assert torch.equal(grads[b, :C], dgs[b]) and torch.equal(grads[b, C:2 * C], dbs[b])
+        assert torch.equal(grads[b, 2 * C:3 * C], dbias[b])
+        assert grads[b, 3 * C:].abs().max().item() == 0
+
+
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize('M,N,K_', [(64, 64, 16), (70, 50, 37), (320, 2048, 512), (6400, 6, 512),
                                     (33, 512, 5), (1, 1, 1), (130, 260, 1030), (144, 16, 20480), (36, 16, 40961),
