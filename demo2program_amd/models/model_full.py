@@ -356,8 +356,10 @@ class Model(object):
             z_p = self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p)
 
         # ---- Demo_Encoder LSTM (zero initial state, length-masked)
+        e1_hc = self._buf('demo_lstm/hc_final', (2, M, U))
         e1 = self._lstm_fwd('demo_lstm', feats_tm.view(T * M, F), F, M, T, T, None, None, lens_d,
-                            want_final=True, z=z_e1)
+                            want_final=True, z=z_e1, final_out=(e1_hc[0], e1_hc[1]))
+        e1['hc_final'] = e1_hc
         if self.variant == 'synthesis_baseline':
             # model_synthesis.py:324-358: no second pass; the program decoder starts from the
             # demonstrations' final states pooled over k
@@ -373,10 +375,10 @@ class Model(object):
             e2 = rn_h = rn_c = h0_2 = c0_2 = demo_h = demo_c = None
         else:
             # ---- summary = mean over k; broadcast as SecondPath initial state
-            sum_h, h0_2 = self._buf('sum_h', (B, U)), self._buf('h0_2', (M, U))
-            sum_c, c0_2 = self._buf('sum_c', (B, U)), self._buf('c0_2', (M, U))
-            K.group_mean(e1['h_final'], B, k, U, sum_h, h0_2)
-            K.group_mean(e1['c_final'], B, k, U, sum_c, c0_2)
+            # (h and c final states share one [2, M, U] buffer: the row-wise kernels see 2B programs, one launch)
+            sum_hc, hc0_2 = self._buf('sum_hc', (2, B, U)), self._buf('hc0_2', (2, M, U))
+            K.group_mean(e1['hc_final'], 2 * B, k, U, sum_hc, hc0_2)
+            h0_2, c0_2 = hc0_2[0], hc0_2[1]
             # ---- SecondPathEncoder over the step-1 outputs (zeros past len)
             # the final states of all demonstrations, h then c, in one buffer: the two relation networks
             # (separate weights, same shapes) then run as strided-batched launches
@@ -719,7 +721,8 @@ class Model(object):
 
             d_demo = self._buf('d_demo', (2, M, U))
             d_demo_h, d_demo_c = d_demo[0], d_demo[1]
-            tmp_h, tmp_c = self._buf('tmp_dh', (M, U)), self._buf('tmp_dc', (M, U))
+            tmp_hc = self._buf('tmp_dhc', (2, M, U))
+            tmp_h, tmp_c = tmp_hc[0], tmp_hc[1]
 
             # ---- decoder recurrences (main stream): projection grads, dz for every step, and the
             #      initial-state gradients that feed the summarizer / encoder backward
@@ -775,8 +778,7 @@ class Model(object):
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         grads[i](dz)
-            K.axpy(1.0, tmp_h, d_demo_h)
-            K.axpy(1.0, tmp_c, d_demo_c)
+            K.axpy(1.0, tmp_hc, d_demo)
             if split_cb is not None:
                 self._call_split(split_cb, main, side)
         else:
@@ -789,7 +791,8 @@ class Model(object):
             if split_cb is not None:
                 self._call_split(split_cb, main, side)
 
-        d_h1f, d_c1f = self._buf('d_h1f', (M, U)), self._buf('d_c1f', (M, U))
+        d_hc1f = self._buf('d_hc1f', (2, M, U))
+        d_h1f, d_c1f = d_hc1f[0], d_hc1f[1]
         if self.variant == 'synthesis_baseline':
             # pooled final states of the only encoder pass; no gradient through its outputs
             if self.demo_aggregation == 'avgpool':
@@ -809,7 +812,8 @@ class Model(object):
 
             # ---- SecondPathEncoder backward: only the final states carry gradient
             e2 = ctx['e2']
-            dh0_2, dc0_2 = self._buf('dh0_2', (M, U)), self._buf('dc0_2', (M, U))
+            dhc0_2 = self._buf('dhc0_2', (2, M, U))
+            dh0_2, dc0_2 = dhc0_2[0], dhc0_2[1]
             # (its weight gradients go to the side stream: two large GEMMs beside the next recurrence)
             dz2 = self._lstm_bwd_rec(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2)
             d_hout1 = self._lstm_bwd_dx(e2, dz2)
@@ -817,8 +821,7 @@ class Model(object):
             with torch.cuda.stream(side):
                 self._lstm_bwd_weights(e2, dz2)
             # summary = mean_k(step-1 final states), broadcast to every demo of the program
-            K.group_mean_bwd(None, dh0_2, d_h1f, B, k, U, False)
-            K.group_mean_bwd(None, dc0_2, d_c1f, B, k, U, False)
+            K.group_mean_bwd(None, dhc0_2, d_hc1f, 2 * B, k, U, False)
         # ---- Demo_Encoder LSTM backward
         dz1 = self._lstm_bwd_rec(ctx['e1'], d_hout1, d_h1f, d_c1f, None, None)
         d_feats_tm = self._lstm_bwd_dx(ctx['e1'], dz1)
