@@ -1,5 +1,7 @@
+#!/usr/bin/env python
+"""Time of an RCCL all-reduce in a forced ONE-rank process group (a 10 us no-op: what D2P_FORCE_DIST=1 measurements include)."""
 import os, sys, torch, time
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ['D2P_FORCE_DIST'] = '1'
 from demo2program_amd.dist import DataParallel
 dp = DataParallel.from_env()

@@ -1,5 +1,7 @@
+#!/usr/bin/env python
+"""The write-bound floor of the 6400 x 2048 GEMM output: fill / copy / K = 32..128 GEMMs, and equal-flop shapes with smaller outputs."""
 import os, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from demo2program_amd import kernels as K
 from demo2program_amd.lib import load
 lib = load()

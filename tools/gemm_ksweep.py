@@ -1,5 +1,7 @@
+#!/usr/bin/env python
+"""GEMM time over K at a fixed 6400 x 2048 output, per forced tile: slope (main-loop rate) and intercept (per-launch cost)."""
 import os, sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from demo2program_amd import kernels as K
 from demo2program_amd.lib import load
 lib = load()

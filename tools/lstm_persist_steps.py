@@ -1,6 +1,8 @@
+#!/usr/bin/env python
+"""Persistent LSTM launches at 5..80 time steps: per-time-step rate and fixed cost per call (forward and backward, 320 and 32 rows)."""
 import os, sys, torch
-sys.path.insert(0, '/root/repo')
-sys.path.insert(0, '/root/repo/tools')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from demo2program_amd import kernels as K
 from lstm_persist_rows import mk, timed
 for M in (320, 32):
