@@ -184,6 +184,8 @@ class Model(object):
         # launches.  D2P_NO_SIDE_STREAM=1 / D2P_SIDE_STREAM=0 switch it off.
         # two decoders per persistent launch (d2p_lstm_seq_*_multi with two sequences)
         self.pair_decoders = os.environ.get('D2P_PAIR_DECODERS', '1') == '1'
+        # token-input decoders: project the embedding TABLE and gather, instead of projecting gathered rows
+        self.token_projection = os.environ.get('D2P_TOKEN_PROJECTION', '1') == '1'
         self.use_side_stream = (os.environ.get('D2P_SIDE_STREAM', '1') == '1' and
                                 os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1')
         self._reserve_scratch()
@@ -340,20 +342,30 @@ class Model(object):
         #  beside the first recurrence they fill matrix-pipe time its hand-offs leave)
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            # Token-input decoders: x = embedding[id], so x.Wx + b takes one of tok+2 values per row -- the
+            # projected TABLE (a [tok+1, U] x [U, 4U] GEMM: 7 or 51 rows) is gathered instead of projecting
+            # 6400 gathered rows (13.4 GFLOP per decoder and direction; backward: _lstm_bwd_weights).  The
+            # sampling decoders (scheduled sampling) choose their inputs step by step and keep the old form.
+            tokproj = self.token_projection and not (self.scheduled_sampling and self.is_train)
             ids_p = K.shift_tokens_tm(feed['program_tokens'], V + 1, out=self._buf('ids_p', (L, B), torch.int32))
-            emb_p = K.embedding_gather(ids_p, p['prog/embedding'], out=self._buf('emb_p', (L * B, U)), n=n_p * B)
+            emb_p = emb_a = None
+            if not tokproj:
+                emb_p = K.embedding_gather(ids_p, p['prog/embedding'], out=self._buf('emb_p', (L * B, U)), n=n_p * B)
             if self.multitask:
                 ids_a = K.shift_tokens_tm(feed['a_h_tokens'], A + 1, out=self._buf('ids_a', (T, M), torch.int32))
-                emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)),
-                                           n=n_d * M)
+                if not tokproj:
+                    emb_a = K.embedding_gather(ids_a, p['act/embedding'], out=self._buf('emb_a', (T * M, U)),
+                                               n=n_d * M)
                 # Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
                 per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
                 pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
                                    bias=p['per/fc/b'], act=0)
                 pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
-                z_a = self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d)
+                z_a = (self._token_xproj('act', ids_a, A, M, T, n_d) if tokproj
+                       else self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d))
                 z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)
-            z_p = self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p)
+            z_p = (self._token_xproj('prog', ids_p, V, B, L, n_p) if tokproj
+                   else self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p))
 
         # ---- Demo_Encoder LSTM (zero initial state, length-masked)
         e1_hc = self._buf('demo_lstm/hc_final', (2, M, U))
@@ -483,6 +495,22 @@ class Model(object):
                        bias=bias)
         return z
 
+    def _token_xproj(self, scope, ids, tok, R, T, n_steps):
+        """Input projection of a token-input decoder by table: P[v] = embedding[v] . Wx + b for v <= tok, P[tok+1] =
+        b (the <s> id is out of range for the [tok+1, U] table: TF-GPU gathers zeros there), then
+        z[row] = P[ids[row]].  Same values as projecting the gathered embeddings, up to the summation order of
+        a 7- or 51-row GEMM against a 6400-row one."""
+        p = self.params.p
+        U = self.num_lstm_cell_units
+        name = scope + '/lstm'
+        P = self._buf(scope + '/table_proj', (tok + 2, 4 * U))
+        K.matmul_nn(p[scope + '/embedding'], p[name + '/kernel'][:U], out=P[:tok + 1], bias=p[name + '/bias'])
+        P[tok + 1].copy_(p[name + '/bias'])
+        z = self._buf(name + '/z', (T * R, 4 * U))
+        if n_steps > 0:
+            K.embedding_gather(ids, P, out=z, n=n_steps * R)
+        return z
+
     def _lstm_fwd(self, name, x2d, I, M, T, n_steps, h0, c0, lens, want_final, z=None, final_out=None):
         """x2d: [T*M, I] time-major inputs.  Returns saved tensors for backward."""
         p = self.params.p
@@ -516,6 +544,8 @@ class Model(object):
             e = dict(name=name, x=x2d, I=I, M=R, T=T, n=n_steps, h0=h0, c0=c0, lens=None, z=z,
                      hout=hout, cs=cs, h_final=None, c_final=None, Wx=kernel[:I], Wh=kernel[I:],
                      token_dim=token_dim, scope=scope)
+            if x2d is None:                 # token-input decoder on the projected-table path
+                e['token_ids'] = self._bufs['ids_p' if scope == 'prog' else 'ids_a']
             es.append(e)
             if n_steps > 0:
                 seqs.append(dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs))
@@ -735,12 +765,10 @@ class Model(object):
             #      rows: its persistent kernel occupies half of the CUs -- and the summarizer / encoder
             #      recurrences after it
             def prog_grads(dz):
-                dx_p = self._lstm_bwd_params(ctx['dp'], dz, True)
-                K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
+                self._token_decoder_grads(ctx['dp'], dz, ctx['ids_p'], n_p * B)
 
             def act_grads(dz):
-                dx_a = self._lstm_bwd_params(ctx['da'], dz, True)
-                K.embedding_scatter_add(ctx['ids_a'], dx_a, g['act/embedding'], n=n_d * M)
+                self._token_decoder_grads(ctx['da'], dz, ctx['ids_a'], n_d * M)
 
             def per_grads(dz):
                 dx_q = self._lstm_bwd_params(ctx['dq'], dz, True)
@@ -786,8 +814,7 @@ class Model(object):
             dz_p = self._decoders_bwd_rec([(ctx['dp'], dl_p, d_init_h, d_init_c)])[0]
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                dx_p = self._lstm_bwd_params(ctx['dp'], dz_p, True)
-                K.embedding_scatter_add(ctx['ids_p'], dx_p, g['prog/embedding'], n=n_p * B)
+                self._token_decoder_grads(ctx['dp'], dz_p, ctx['ids_p'], n_p * B)
             if split_cb is not None:
                 self._call_split(split_cb, main, side)
 
@@ -874,6 +901,14 @@ class Model(object):
         self._lstm_bwd_weights(e, dz)
         return self._lstm_bwd_dx(e, dz) if want_dx else None
 
+    def _token_decoder_grads(self, e, dz, ids, rows):
+        """Kernel / bias / embedding gradients of a token-input decoder from its dz."""
+        if e.get('token_ids') is not None:
+            self._lstm_bwd_weights(e, dz)          # embedding gradient included (projected-table path)
+        else:
+            dx = self._lstm_bwd_params(e, dz, True)
+            K.embedding_scatter_add(ids, dx, self.params.g[e['scope'] + '/embedding'], n=rows)
+
     def _lstm_bwd_dx(self, e, dz):
         """dX [n*M, I] = dZ Wx^T: the only product of dz the rest of backward waits for."""
         name, M, T, n, I = e['name'], e['M'], e['T'], e['n'], e['I']
@@ -893,7 +928,22 @@ class Model(object):
         rows = n * M
         dz_n = dz[:rows] if rows > 0 else dz[:0]
         # dWx = X^T dZ ; db = colsum(dZ)
-        K.gemm_raw('tn', I, 4 * U, rows, e['x'], e['x'].stride(0), dz_n, 4 * U, gk[:I], 4 * U)
+        if e.get('token_ids') is not None:
+            # x = embedding[id]: S[v] = sum of the dz rows whose input token was v (one-hot GEMM, tok+2 rows),
+            # then dWx = embedding^T S and d embedding = S Wx^T -- three small products instead of two
+            # 13.4 GFLOP GEMMs (dWx, dX) and the scatter of dX
+            scope, tok = e['scope'], e['token_dim']
+            p = self.params.p
+            if rows > 0:
+                S = self._buf(name + '/dz_by_token', (tok + 2, 4 * U))
+                K.embedding_scatter_add(e['token_ids'], dz_n, S, n=rows)
+                K.matmul_tn(p[scope + '/embedding'], S[:tok + 1], out=gk[:I])
+                K.matmul_nt(S[:tok + 1], p[name + '/kernel'][:I], out=g[scope + '/embedding'])
+            else:
+                gk[:I].zero_()
+                g[scope + '/embedding'].zero_()
+        else:
+            K.gemm_raw('tn', I, 4 * U, rows, e['x'], e['x'].stride(0), dz_n, 4 * U, gk[:I], 4 * U)
         K.colsum(dz_n, out=gb, rows=rows) if rows > 0 else gb.zero_()
         # dWh = sum_t h_{t-1}^T dZ_t : h_{-1} = h0 (skipped when zero), then hout[t-1]
         hout2d = e['hout'].view(T * M, U)
