@@ -383,3 +383,95 @@ extern "C" int d2p_pad_axis(long outer, int C, int Cp, int inner, const void* in
     D2P_LAUNCH_CHECK("pad_axis");
     return D2P_OK;
 }
+
+// ---- Perception decoder input, factored (models/model_full.py:308-316, 573-599) -------------------
+// The perception decoder reads pe = BN_g(per . W + b) with per a P-wide row (P = 5): pe[r] = alpha_g * (per[r] . W) +
+// kappa_g with alpha_g = gamma * rstd_g, kappa_g = alpha_g * (b - mean_g) + beta (g = the row's demonstration
+// index).  So pe = A . H where A[r] holds per[r] and a 1 in the (P+1) columns of the row's group g and
+// H[g*(P+1) + j] = alpha_g * W[j] (j < P), H[g*(P+1) + P] = kappa_g: every product with pe (the decoder's input
+// projection pe . Wx, its weight gradient pe^T dZ) and every sum over rows in the batch-norm backward becomes
+// a product with the NC = G*(P+1) columns of A instead of a [rows, U] matrix.
+//
+// H [NCp, U] (rows >= G*(P+1) zero)
+__global__ void __launch_bounds__(256)
+per_affine_rows_kernel(int G, int P, int U, int NCp, const float* __restrict__ W, const float* __restrict__ b,
+                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                       const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ H) {
+    const long total = (long)NCp * U;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+        const int q = (int)(idx / U), c = (int)(idx - (long)q * U);
+        const int g = q / (P + 1), j = q - g * (P + 1);
+        float v = 0.f;
+        if (g < G) {
+            const float alpha = gamma[c] * rstd[g * U + c];
+            v = j < P ? alpha * W[j * U + c] : alpha * (b[c] - mean[g * U + c]) + beta[c];
+        }
+        H[idx] = v;
+    }
+}
+extern "C" int d2p_per_affine_rows(int G, int P, int U, int NCp, const float* W, const float* b, const float* gamma,
+                                   const float* beta, const float* mean, const float* rstd, float* H,
+                                   d2p_stream_t stream) {
+    D2P_REQUIRE(G > 0 && P > 0 && U > 0 && NCp >= G * (P + 1), D2P_EINVAL, "per_affine_rows: bad sizes");
+    D2P_REQUIRE(W && b && gamma && beta && mean && rstd && H, D2P_EINVAL, "per_affine_rows: null pointer");
+    hipLaunchKernelGGL(per_affine_rows_kernel, dim3(ew_blocks((long)NCp * U)), dim3(256), 0, as_stream(stream), G, P, U,
+                       NCp, W, b, gamma, beta, mean, rstd, H);
+    D2P_LAUNCH_CHECK("per_affine_rows");
+    return D2P_OK;
+}
+
+// Backward of fc + batch norm from the column sums alone.  Q [NCp, U] = (A^T dZ) . Wx^T: row g*(P+1)+j = sum over
+// the group's rows of per[r, j] * dpe[r, :], row g*(P+1)+P = sum of dpe[r, :] (dpe = dZ . Wx^T is never formed;
+// rows past the decoded steps contribute nothing to Q).  gram [NCp, NCp] = A^T A over ALL rows: per_g^T per_g and
+// colsum(per_g).  n = rows per group.  With u = per . W + b, xhat = (u - mean_g) * rstd_g:
+//   t_g = sum dpe, w_g = sum dpe * u = sum_j W[j] Q_g[j] + b t_g
+//   dgamma = sum_g rstd_g (w_g - mean_g t_g), dbeta = sum_g t_g
+//   m1_g = t_g / n, m2_g = rstd_g (w_g - mean_g t_g) / n              (batch-norm backward means)
+//   dW[j] = sum_g alpha_g ( Q_g[j] - p_g[j] m1_g - m2_g rstd_g ( sum_i C_g[j,i] W[i] + p_g[j] (b - mean_g) ) )
+//   db = 0 (a bias in front of a batch norm has no gradient: sum xhat = 0 and t_g = n m1_g)
+__global__ void __launch_bounds__(256)
+per_fc_bn_bwd_kernel(int G, int P, int U, int NCp, float n, const float* __restrict__ W, const float* __restrict__ b,
+                     const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                     const float* __restrict__ Q, const float* __restrict__ gram, float* __restrict__ dW,
+                     float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= U) return;
+    float w[8], dw[8];
+    for (int j = 0; j < P; ++j) { w[j] = W[j * U + c]; dw[j] = 0.f; }
+    const float bc = b[c], gm = gamma[c];
+    float dg = 0.f, dbt = 0.f;
+    for (int g = 0; g < G; ++g) {
+        const int q0 = g * (P + 1);
+        const float mu = mean[g * U + c], rs = rstd[g * U + c];
+        const float t = Q[(long)(q0 + P) * U + c];
+        float ww = bc * t;
+        for (int j = 0; j < P; ++j) ww += w[j] * Q[(long)(q0 + j) * U + c];
+        const float s = rs * (ww - mu * t);          // sum dpe * xhat
+        dg += s;
+        dbt += t;
+        const float m1 = t / n, m2 = s / n, alpha = gm * rs;
+        for (int j = 0; j < P; ++j) {
+            const float pj = gram[(long)(q0 + j) * NCp + q0 + P];
+            float cw = pj * (bc - mu);
+            for (int i = 0; i < P; ++i) cw += gram[(long)(q0 + j) * NCp + q0 + i] * w[i];
+            dw[j] += alpha * (Q[(long)(q0 + j) * U + c] - pj * m1 - m2 * rs * cw);
+        }
+    }
+    for (int j = 0; j < P; ++j) dW[j * U + c] = dw[j];
+    db[c] = 0.f;
+    dgamma[c] = dg;
+    dbeta[c] = dbt;
+}
+extern "C" int d2p_per_fc_bn_bwd(int G, int P, int U, int NCp, int rows_per_group, const float* W, const float* b,
+                                 const float* gamma, const float* mean, const float* rstd, const float* Q,
+                                 const float* gram, float* dW, float* db, float* dgamma, float* dbeta,
+                                 d2p_stream_t stream) {
+    D2P_REQUIRE(G > 0 && P > 0 && P <= 8 && U > 0 && NCp >= G * (P + 1) && rows_per_group > 0, D2P_EINVAL,
+                "per_fc_bn_bwd: bad sizes (P <= 8)");
+    D2P_REQUIRE(W && b && gamma && mean && rstd && Q && gram && dW && db && dgamma && dbeta, D2P_EINVAL,
+                "per_fc_bn_bwd: null pointer");
+    hipLaunchKernelGGL(per_fc_bn_bwd_kernel, dim3(ceil_div(U, 256)), dim3(256), 0, as_stream(stream), G, P, U, NCp,
+                       (float)rows_per_group, W, b, gamma, mean, rstd, Q, gram, dW, db, dgamma, dbeta);
+    D2P_LAUNCH_CHECK("per_fc_bn_bwd");
+    return D2P_OK;
+}

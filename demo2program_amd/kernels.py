@@ -239,6 +239,20 @@ def bn_bwd_batched(x3d, dy3d, gamma, pstride, mean, rstd, G, inner, act_bwd, dga
     return dx
 
 
+def per_affine_rows(G, P, W, b, gamma, beta, mean, rstd, H):
+    """H [NCp, U]: the rows pe = A . H is built from (d2p.h: d2p_per_affine_rows)."""
+    NCp, U = H.shape
+    call.d2p_per_affine_rows(G, P, U, NCp, ptr(W), ptr(b), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(H),
+                             current_stream())
+    return H
+
+
+def per_fc_bn_bwd(G, P, rows_per_group, W, b, gamma, mean, rstd, Q, gram, dW, db, dgamma, dbeta):
+    NCp, U = Q.shape
+    call.d2p_per_fc_bn_bwd(G, P, U, NCp, rows_per_group, ptr(W), ptr(b), ptr(gamma), ptr(mean), ptr(rstd), ptr(Q),
+                           ptr(gram), ptr(dW), ptr(db), ptr(dgamma), ptr(dbeta), current_stream())
+
+
 def bn_inference(x2d, gamma, beta, moving_mean, moving_var, y=None):
     """is_training=False batch norm: normalise [R, C] rows with the moving statistics."""
     _require_gpu(x2d)

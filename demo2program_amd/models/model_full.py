@@ -184,6 +184,9 @@ class Model(object):
         # launches.  D2P_NO_SIDE_STREAM=1 / D2P_SIDE_STREAM=0 switch it off.
         # two decoders per persistent launch (d2p_lstm_seq_*_multi with two sequences)
         self.pair_decoders = os.environ.get('D2P_PAIR_DECODERS', '1') == '1'
+        # perception decoder: its batch-normed fc features are never multiplied by Wx row by row (forward _per_xproj)
+        self.per_factored = os.environ.get('D2P_PER_FACTORED', '1') == '1' and config.per_dim <= 8
+        self.per_cols = (config.k * (config.per_dim + 1) + 3) // 4 * 4
         # token-input decoders: project the embedding TABLE and gather, instead of projecting gathered rows
         self.token_projection = os.environ.get('D2P_TOKEN_PROJECTION', '1') == '1'
         self.use_side_stream = (os.environ.get('D2P_SIDE_STREAM', '1') == '1' and
@@ -220,7 +223,8 @@ class Model(object):
         K.SCRATCH.reserve(max(need))
 
     # ------------------------------------------------------------------ feed
-    FEED_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'program_len', 'demo_len')
+    FEED_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'per_rows', 'per_gram', 'program_len',
+                 'demo_len')
 
     def alloc_feed(self, frames_dtype=torch.float32):
         """Empty device feed: the tensors of FEED_KEYS as 256-byte aligned views into one byte buffer
@@ -234,6 +238,10 @@ class Model(object):
                 ('a_h', torch.float32, (B, k, T, c.action_space)),
                 ('a_h_tokens', torch.int32, (B * k, T)),
                 ('per', torch.float32, (B, k, T, c.per_dim)),
+                # the perception rows spread by demonstration index (time-major) and their Gram matrix: what the
+                # factored perception decoder multiplies instead of [rows, U] features (d2p.h: d2p_per_affine_rows)
+                ('per_rows', torch.float32, (T * B * k, self.per_cols)),
+                ('per_gram', torch.float32, (self.per_cols, self.per_cols)),
                 ('program_len', torch.int32, (B,)), ('demo_len', torch.int32, (B * k,))]
         offs, total = [], 0
         for _, dt, shape in spec:
@@ -246,6 +254,21 @@ class Model(object):
             n = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
             feed[name] = flat[o:o + n].view(dt).view(shape)
         return feed
+
+    def derive_per_rows(self, feed):
+        """Fills feed['per_rows'] / feed['per_gram'] from feed['per'] (part of staging a batch, like the channel
+        padding of the frames): per_rows[t*M + b*k + i, i*(P+1) + j] = per[b, i, t, j], column i*(P+1) + P = 1,
+        zeros elsewhere; per_gram = per_rows^T per_rows."""
+        c = self.config
+        B, k, T, P_ = c.batch_size, c.k, c.max_demo_len, c.per_dim
+        NC = k * (P_ + 1)
+        rows = feed['per_rows']
+        rows.zero_()
+        blk = rows.view(T, B, k, self.per_cols)[..., :NC].view(T, B, k, k, P_ + 1)
+        ar = torch.arange(k, device=rows.device)
+        blk[:, :, ar, ar, :P_] = feed['per'].permute(2, 0, 1, 3)
+        blk[:, :, ar, ar, P_] = 1.0
+        K.matmul_tn(rows, rows, out=feed['per_gram'])
 
     def get_feed_dict(self, batch_chunk, step=None, is_training=True):
         """batch_chunk (numpy arrays or torch tensors, keys of models/model_full.py:185-206)
@@ -283,6 +306,7 @@ class Model(object):
             put('s_h', s_h)
         for name in ('program', 'program_tokens', 'a_h', 'a_h_tokens', 'per'):
             put(name, batch_chunk[name])
+        self.derive_per_rows(feed)
         plen = host_np(batch_chunk['program_len']).astype(np.int32).reshape(B)
         dlen = host_np(batch_chunk['demo_len']).astype(np.int32).reshape(B * k)
         put('program_len', plen)
@@ -363,7 +387,19 @@ class Model(object):
                 pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
                 z_a = (self._token_xproj('act', ids_a, A, M, T, n_d) if tokproj
                        else self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d))
-                z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)
+                if self.per_factored and self.is_train:
+                    # pe = rows . H (H from the fc weights, the batch-norm parameters and this batch's statistics):
+                    # z = rows . (H . Wx) + b -- a 60-row GEMM and a K = 60 GEMM instead of 6400 x 2048 x 512
+                    H = K.per_affine_rows(k, P, p['per/fc/W'], p['per/fc/b'], p['per/fc/gamma'], p['per/fc/beta'],
+                                          pe_mean, pe_rstd, self._buf('per/H', (self.per_cols, U)))
+                    HWx = K.matmul_nn(H, p['per/lstm/kernel'][:U], out=self._buf('per/HWx', (self.per_cols, 4 * U)))
+                    z_q = self._buf('per/lstm/z', (T * M, 4 * U))
+                    if n_d > 0:
+                        K.gemm_raw('nn', n_d * M, 4 * U, self.per_cols, feed['per_rows'], self.per_cols, HWx, 4 * U,
+                                   z_q, 4 * U, bias=p['per/lstm/bias'])
+                    pe = None
+                else:
+                    z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)
             z_p = (self._token_xproj('prog', ids_p, V, B, L, n_p) if tokproj
                    else self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p))
 
@@ -544,7 +580,7 @@ class Model(object):
             e = dict(name=name, x=x2d, I=I, M=R, T=T, n=n_steps, h0=h0, c0=c0, lens=None, z=z,
                      hout=hout, cs=cs, h_final=None, c_final=None, Wx=kernel[:I], Wh=kernel[I:],
                      token_dim=token_dim, scope=scope)
-            if x2d is None:                 # token-input decoder on the projected-table path
+            if x2d is None and scope in ('prog', 'act'):      # token-input decoder on the projected-table path
                 e['token_ids'] = self._bufs['ids_p' if scope == 'prog' else 'ids_a']
             es.append(e)
             if n_steps > 0:
@@ -771,6 +807,8 @@ class Model(object):
                 self._token_decoder_grads(ctx['da'], dz, ctx['ids_a'], n_d * M)
 
             def per_grads(dz):
+                if ctx['dq']['x'] is None:
+                    return self._per_factored_grads(ctx['dq'], dz, feed, ctx['pe_mean'], ctx['pe_rstd'], n_d * M)
                 dx_q = self._lstm_bwd_params(ctx['dq'], dz, True)
                 if n_d < T:
                     dx_q[n_d * M:].zero_()
@@ -901,6 +939,27 @@ class Model(object):
         self._lstm_bwd_weights(e, dz)
         return self._lstm_bwd_dx(e, dz) if want_dx else None
 
+    def _per_factored_grads(self, e, dz, feed, mean, rstd, rows):
+        """Perception decoder: kernel / bias gradients of its LSTM and the fc + batch-norm gradients of its input
+        encoder from dz, through the NC columns of feed['per_rows'] (d2p.h: d2p_per_fc_bn_bwd)."""
+        c, p, g = self.config, self.params.p, self.params.g
+        U, P, k = self.num_lstm_cell_units, c.per_dim, c.k
+        name = e['name']
+        gk = g[name + '/kernel']
+        NCp = self.per_cols
+        if rows > 0:
+            S = K.matmul_tn(feed['per_rows'][:rows], dz[:rows], out=self._buf('per/S', (NCp, 4 * U)))
+            K.matmul_tn(self._bufs['per/H'], S, out=gk[:U])                       # dWx = H^T (rows^T dZ)
+            Q = K.matmul_nt(S, p[name + '/kernel'][:U], out=self._buf('per/Q', (NCp, U)))
+            K.per_fc_bn_bwd(k, P, c.batch_size * c.max_demo_len, p['per/fc/W'], p['per/fc/b'], p['per/fc/gamma'],
+                            mean, rstd, Q, feed['per_gram'], g['per/fc/W'], g['per/fc/b'], g['per/fc/gamma'],
+                            g['per/fc/beta'])
+        else:
+            for n in ('per/fc/W', 'per/fc/b', 'per/fc/gamma', 'per/fc/beta'):
+                g[n].zero_()
+            gk[:U].zero_()
+        self._lstm_bwd_weights(e, dz)              # bias and recurrent-kernel gradients (e['factored_x'] skips dWx)
+
     def _token_decoder_grads(self, e, dz, ids, rows):
         """Kernel / bias / embedding gradients of a token-input decoder from its dz."""
         if e.get('token_ids') is not None:
@@ -942,8 +1001,9 @@ class Model(object):
             else:
                 gk[:I].zero_()
                 g[scope + '/embedding'].zero_()
-        else:
+        elif e['x'] is not None:
             K.gemm_raw('tn', I, 4 * U, rows, e['x'], e['x'].stride(0), dz_n, 4 * U, gk[:I], 4 * U)
+        # (x None without token ids: the factored perception decoder -- its dWx is written by _per_factored_grads)
         K.colsum(dz_n, out=gb, rows=rows) if rows > 0 else gb.zero_()
         # dWh = sum_t h_{t-1}^T dZ_t : h_{-1} = h0 (skipped when zero), then hout[t-1]
         hout2d = e['hout'].view(T * M, U)

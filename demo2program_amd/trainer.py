@@ -229,7 +229,7 @@ class Trainer(object):
         return bool(getattr(load(), '_d2p_prof_on', False))
 
     MAX_GRAPHS = 128      # distinct (n_prog, n_demo) pairs kept as instantiated graphs
-    _STATIC_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'program_len',
+    _STATIC_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'per_rows', 'per_gram', 'program_len',
                     'demo_len')
 
     def _graphed_forward_backward(self, feed, split_cb=None):
@@ -244,7 +244,10 @@ class Trainer(object):
             sf['_flat'].copy_(feed['_flat'], non_blocking=True)   # the whole batch: one device copy
         else:                                                      # a hand-built feed
             for k in self._STATIC_KEYS:
-                sf[k].copy_(feed[k].reshape(sf[k].shape), non_blocking=True)
+                if k in feed:
+                    sf[k].copy_(feed[k].reshape(sf[k].shape), non_blocking=True)
+            if 'per_rows' not in feed:
+                m.derive_per_rows(sf)
         key = (feed['n_prog'], feed['n_demo'])
         static = dict({k: sf[k] for k in self._STATIC_KEYS}, n_prog=key[0], n_demo=key[1], id=feed.get('id'),
                       host=feed.get('host'))

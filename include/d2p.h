@@ -391,6 +391,18 @@ int d2p_pad_axis(long outer, int C, int Cp, int inner, const void* in, void* out
 /* zero logits rows (t, r) with t >= nsteps_g[r % G]  (per-demo dynamic padding,
  * models/model_full.py:476-484); nsteps_g[g] = min(T, max_{r%G==g} lens[r]) computed on device. */
 int d2p_zero_past_group_steps(int T, int R, int V, int G, const int* lens, float* logits, d2p_stream_t stream);
+/* Perception decoder input in factored form (Per_Encoder = fc + batch norm per demonstration index in front of the
+ * decoder LSTM, models/model_full.py:308-316,573-599).  With A [rows, NCp] holding, for a row of demonstration
+ * index g, per[row] in columns g*(P+1) .. g*(P+1)+P-1 and a 1 in column g*(P+1)+P, the batch-normed features are
+ * pe = A . H: per_affine_rows writes H [NCp, U] from the fc weights, the batch-norm parameters and the batch
+ * statistics; the decoder's input projection is then A . (H . Wx), its weight gradient H^T . (A^T dZ), and
+ * per_fc_bn_bwd derives the fc / batch-norm gradients from Q = (A^T dZ) . Wx^T [NCp, U] and gram = A^T A
+ * [NCp, NCp] -- no [rows, U] matrix is multiplied by Wx in either direction.  P <= 8. */
+int d2p_per_affine_rows(int G, int P, int U, int NCp, const float* W, const float* b, const float* gamma,
+                        const float* beta, const float* mean, const float* rstd, float* H, d2p_stream_t stream);
+int d2p_per_fc_bn_bwd(int G, int P, int U, int NCp, int rows_per_group, const float* W, const float* b,
+                      const float* gamma, const float* mean, const float* rstd, const float* Q, const float* gram,
+                      float* dW, float* db, float* dgamma, float* dbeta, d2p_stream_t stream);
 
 /* ---- K8: global-norm clip + Adam over one flat buffer -------------------------------
  * Replaces tf.contrib.layers.optimize_loss(clip_gradients=20.0, AdamOptimizer)

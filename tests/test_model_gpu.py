@@ -992,3 +992,35 @@ def test_token_decoders_project_the_table_not_the_rows(kind, over, monkeypatch):
     for n in g0:
         scale = g0[n].abs().max().item() + 1e-12
         assert (g1[n] - g0[n]).abs().max().item() <= 5e-5 * scale, n
+
+
+@pytest.mark.parametrize('kind,over', [('karel', {}), ('vizdoom', {}),
+                                       ('karel', dict(batch_size=32, k=10, max_demo_len=20, max_program_len=50,
+                                                      num_lstm_cell_units=512))])
+def test_perception_decoder_factored_input_equals_row_wise_form(kind, over, monkeypatch):
+    """pe = BN(per . W + b) is rows . H with rows = the 5 perception bits spread by demonstration index: the
+    decoder's input projection, its weight gradient and the whole fc + batch-norm backward go through the 60
+    columns of `per_rows` (d2p_per_affine_rows / d2p_per_fc_bn_bwd) -- same loss, logits and gradients as the
+    row-wise form (D2P_PER_FACTORED=0), up to summation order; the fc bias in front of the batch norm gets an
+    exact zero gradient where the row-wise form leaves round-off."""
+    from demo2program_amd.models.model_full import Model
+    cfg, params, batch = small_case(kind, seed=59, **over)
+    runs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('D2P_PER_FACTORED', flag)
+        m = Model(cfg, params=params)
+        assert m.per_factored == (flag == '1')
+        loss = float(m.forward(m.get_feed_dict(batch)).item())
+        m.backward()
+        runs.append((loss, m._ctx['dq']['logits'].clone(), {n: t.clone() for n, t in m.params.g.items()}))
+    (l1, q1, g1), (l0, q0, g0) = runs
+    assert abs(l1 - l0) <= 1e-6 * abs(l0)
+    assert (q1 - q0).abs().max().item() <= 5e-5
+    assert g1['per/fc/b'].abs().max().item() == 0.0
+    ref = max(g0[n].abs().max().item() for n in ('per/fc/W', 'per/fc/gamma', 'per/fc/beta'))
+    assert g0['per/fc/b'].abs().max().item() <= 1e-4 * ref              # round-off of an exact zero
+    for n in g0:
+        if n == 'per/fc/b':
+            continue
+        scale = g0[n].abs().max().item() + 1e-12
+        assert (g1[n] - g0[n]).abs().max().item() <= 1e-4 * scale, n
