@@ -450,6 +450,7 @@ class Model(object):
             specs += [('act', emb_a, U, M, T, n_d, demo_h, demo_c, A, z_a),
                       ('per', pe, U, M, T, n_d, demo_h, demo_c, P, z_q)]
         da = dq = None
+        side_loss = False
         if self.scheduled_sampling and self.is_train:
             # program and action decoders feed back their own samples (per uses TrainingHelper,
             # model_full.py:409); the hoisted z_p / z_a of the side stream are simply not used
@@ -464,7 +465,20 @@ class Model(object):
         elif self.multitask and self.pair_decoders:
             # the program decoder (32 rows: a latency-bound chain on a quarter of the CUs) shares ONE persistent
             # launch with the action decoder, on disjoint workgroups; the perception decoder follows alone
-            dp, da = self._decoders_fwd(specs[:2])
+            side_loss = self.use_side_stream and os.environ.get('D2P_SIDE_LOSS', '1') == '1'
+            dp, da = self._decoders_fwd(specs[:2], logits=not side_loss)
+            if side_loss:
+                # their logits and cross-entropy sums go to the side stream, beside the perception decoder's
+                # recurrence (small launches: they finish well inside it)
+                nums, dens = self._buf('loss_nums', (1 + 2 * k,)), self._buf('loss_dens', (1 + 2 * k,))
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._decoder_logits(dp)
+                    self._decoder_logits(da)
+                    K.xent_fwd('softmax', dp['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
+                               nums[0:1], dens[0:1])
+                    K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                               nums[1:1 + k], dens[1:1 + k])
             dq = self._decoders_fwd([specs[2]])[0]
         else:
             outs = [self._decoders_fwd([sp])[0] for sp in specs]
@@ -478,13 +492,17 @@ class Model(object):
         dens = self._buf('loss_dens', (1 + 2 * k,))
         loss = self._buf('loss', (1,))
         terms = self._buf('loss_terms', (3,), zero=True)
-        K.xent_fwd('softmax', dp['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
-                   nums[0:1], dens[0:1])
+        if not side_loss:
+            K.xent_fwd('softmax', dp['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
+                       nums[0:1], dens[0:1])
         if self.multitask:
-            K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
-                       nums[1:1 + k], dens[1:1 + k])
+            if not side_loss:
+                K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                           nums[1:1 + k], dens[1:1 + k])
             K.xent_fwd('sigmoid', dq['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
                        nums[1 + k:], dens[1 + k:])
+            if side_loss:
+                main.wait_stream(side)
             K.loss_assemble([1, k, k], nums, dens, loss, terms)
             ctx.update(da=da, dq=dq, ids_a=ids_a, emb_a=emb_a, per_tm=per_tm, pe_a=pe_a, pe=pe,
                        pe_mean=pe_mean, pe_rstd=pe_rstd)
@@ -566,9 +584,10 @@ class Model(object):
         return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
                     hout=hout, cs=cs, h_final=hf, c_final=cf, Wx=Wx, Wh=Wh)
 
-    def _decoders_fwd(self, specs):
+    def _decoders_fwd(self, specs, logits=True):
         """BasicDecoder + TrainingHelper + Dense(no bias) (models/model_full.py:440-490) for
-        several independent decoders at once."""
+        several independent decoders at once.  logits=False: the recurrences only (the caller projects with
+        _decoder_logits, e.g. on the other stream)."""
         p = self.params.p
         U = self.num_lstm_cell_units
         es, seqs = [], []
@@ -587,16 +606,22 @@ class Model(object):
                 seqs.append(dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs))
         if seqs:
             K.lstm_seq_fwd_multi(seqs)
-        for e in es:
-            scope, R, T, n_steps, token_dim = e['scope'], e['M'], e['T'], e['n'], e['token_dim']
-            logits = self._buf(scope + '/logits', (T, R, token_dim), zero=True)
-            if n_steps > 0:
-                K.gemm_raw('nn', n_steps * R, token_dim, U, e['hout'], U, p[scope + '/proj'], token_dim,
-                           logits, token_dim)
-            if n_steps < T:
-                logits[n_steps:].zero_()    # dynamic zero padding (:476-484); memset, no arithmetic
-            e['logits'] = logits
+        if logits:
+            for e in es:
+                self._decoder_logits(e)
         return es
+
+    def _decoder_logits(self, e):
+        p = self.params.p
+        U = self.num_lstm_cell_units
+        scope, R, T, n_steps, token_dim = e['scope'], e['M'], e['T'], e['n'], e['token_dim']
+        logits = self._buf(scope + '/logits', (T, R, token_dim), zero=True)
+        if n_steps > 0:
+            K.gemm_raw('nn', n_steps * R, token_dim, U, e['hout'], U, p[scope + '/proj'], token_dim,
+                       logits, token_dim)
+        if n_steps < T:
+            logits[n_steps:].zero_()    # dynamic zero padding (:476-484); memset, no arithmetic
+        e['logits'] = logits
 
     def sample_prob_at(self, step):
         """models/model_full.py:62-67: teacher-forcing probability, polynomial_decay(1.0 -> 0.1)
