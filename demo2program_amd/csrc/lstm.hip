@@ -229,6 +229,27 @@ bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc) 
     return true;
 }
 
+bool d2p_lstm_try_triple_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc) {
+    int M[3], T[3];
+    for (int i = 0; i < 3; ++i) {
+        const d2p_lstm_bwd_desc& q = d[i];
+        if (q.M <= 0 || q.n_steps <= 0 || !(q.z && q.Wh && q.cs && q.dz && q.ws)) return false;
+        if (!use_fused(q.M, q.U, q.z_row_stride, q.z, q.ws_bytes) || (((uintptr_t)q.dz & 15) != 0) ||
+            q.ws_bytes < d2p_lstm_persist_ws_bytes(q.M, q.U) || q.U != d[0].U)
+            return false;
+        M[i] = q.M; T[i] = q.n_steps;
+    }
+    if (d[0].ws == d[1].ws || d[0].ws == d[2].ws || d[1].ws == d[2].ws) return false;
+    if (!d2p_lstm_persist_bwd_triple_ok(M, T, d[0].U)) return false;
+    PsBwdCall c[3];
+    for (int i = 0; i < 3; ++i)
+        c[i] = PsBwdCall{d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh, d[i].c0,
+                         d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final, d[i].dc_final, d[i].dz, d[i].dh0, d[i].dc0,
+                         (float*)d[i].ws};
+    *rc = d2p_lstm_persist_bwd_triple(c, st);
+    return true;
+}
+
 extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_stride,
                                 long z_t_stride, const float* Wh, const float* h0, const float* c0,
                                 const int* lens, float* hout, float* cs, float* h_final,

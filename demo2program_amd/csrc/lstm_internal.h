@@ -80,6 +80,10 @@ bool d2p_lstm_persist_fwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U);
 bool d2p_lstm_persist_bwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U);
 int d2p_lstm_persist_fwd_pair(const PsFwdCall& qa, const PsFwdCall& qb, hipStream_t st);
 int d2p_lstm_persist_bwd_pair(const PsBwdCall& qa, const PsBwdCall& qb, hipStream_t st);
+// the backward kernel also takes three (the three decoders)
+bool d2p_lstm_persist_bwd_triple_ok(const int M[3], const int T[3], int U);
+int d2p_lstm_persist_bwd_triple(const PsBwdCall q[3], hipStream_t st);
 // multi entry points: two sequences as one persistent launch when that is possible and expected to pay (lstm.hip)
 bool d2p_lstm_try_pair_fwd(const d2p_lstm_fwd_desc* d, hipStream_t st, int* rc);
 bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc);
+bool d2p_lstm_try_triple_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc);

@@ -801,8 +801,9 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
 }
 
 template <int CPW>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16
-__global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs a0, PsBwdArgs a1) {
-    const PsBwdArgs a = ((int)blockIdx.x >= a0.gsz) ? a1 : a0;      // two sequences per launch, as the forward kernel
+__global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs a0, PsBwdArgs a1, PsBwdArgs a2) {
+    // up to three independent sequences per launch (the three decoders), on disjoint workgroups as in the forward kernel
+    const PsBwdArgs a = ((int)blockIdx.x >= a0.gsz + a1.gsz) ? a2 : (((int)blockIdx.x >= a0.gsz) ? a1 : a0);
     constexpr int CPWB = 4 * CPW;                // chunks per wave
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
@@ -1132,14 +1133,15 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     return ps_prep(1, U, q.Wh, Wb, M, nullptr, (float*)((char*)a.dzfrag + (size_t)(n_steps & 1) * a.dzfrag_bytes),
                    a.dzfrag_bytes, a.flags, (size_t)RT * PS_NRS_MAX * nnt, st);
 }
-static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, int U, double flops, hipStream_t st) {
-    const int blocks = a0.gsz + a1.gsz;
+static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdArgs& a2, int U, double flops,
+                         hipStream_t st) {
+    const int blocks = a0.gsz + a1.gsz + a2.gsz;
     D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, flops);
     switch (U) {
-        case 64: hipLaunchKernelGGL((lstm_persist_bwd_kernel<1>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
-        case 128: hipLaunchKernelGGL((lstm_persist_bwd_kernel<2>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
-        case 256: hipLaunchKernelGGL((lstm_persist_bwd_kernel<4>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
-        default: hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1); break;
+        case 64: hipLaunchKernelGGL((lstm_persist_bwd_kernel<1>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1, a2); break;
+        case 128: hipLaunchKernelGGL((lstm_persist_bwd_kernel<2>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1, a2); break;
+        case 256: hipLaunchKernelGGL((lstm_persist_bwd_kernel<4>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1, a2); break;
+        default: hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1, a2); break;
     }
     D2P_LAUNCH_CHECK("lstm_persist_bwd");
     return D2P_OK;
@@ -1154,7 +1156,7 @@ int d2p_lstm_persist_bwd(const PsBwdCall& q, hipStream_t st) {
     if (rc) return rc;
     none = a;
     none.gsz = 0;
-    return ps_bwd_launch(a, none, q.U, ps_bwd_flops(q), st);
+    return ps_bwd_launch(a, none, none, q.U, ps_bwd_flops(q), st);
 }
 bool d2p_lstm_persist_bwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U) {
     int ra, rb;
@@ -1171,5 +1173,75 @@ int d2p_lstm_persist_bwd_pair(const PsBwdCall& qa, const PsBwdCall& qb, hipStrea
     rc = ps_bwd_setup(qb, rb, a.gsz, b, st);
     if (rc) return rc;
     ++g_ps_pair_launches;
-    return ps_bwd_launch(a, b, qa.U, ps_bwd_flops(qa) + ps_bwd_flops(qb), st);
+    PsBwdArgs none = b;
+    none.gsz = 0;
+    return ps_bwd_launch(a, b, none, qa.U, ps_bwd_flops(qa) + ps_bwd_flops(qb), st);
+}
+
+// three sequences (the three decoders' backward recurrences): row domains dealt out by the same cost model; taken
+// when it beats the best of {three launches, one launch + a pair}
+static double ps_bwd_cost(int trs, int T, int RT) {
+    const int nrs = (trs + RT - 1) / RT;
+    const double step = 3.3 * nrs;
+    return T * (step > 6.3 ? step : 6.3);
+}
+static bool ps_plan_triple_bwd(const int trs[3], const int T[3], int ncol, int R[3]) {
+    const int budget = ps_num_cus() / ncol;
+    double single[3];
+    for (int i = 0; i < 3; ++i) {
+        const int f = ps_pick_rt(trs[i], ncol, 1);
+        if (f < 1) return false;
+        single[i] = ps_bwd_cost(trs[i], T[i], f) + 25.0;                     // + the fixed cost of a launch
+    }
+    double alt = single[0] + single[1] + single[2];
+    for (int i = 0; i < 3; ++i) {                                             // one alone + the other two as a pair
+        const int j = (i + 1) % 3, l = (i + 2) % 3;
+        int ra, rb;
+        if (ps_plan_pair(trs[j], T[j], trs[l], T[l], ncol, 1, ra, rb)) {
+            const double cj = ps_bwd_cost(trs[j], T[j], ra), cl = ps_bwd_cost(trs[l], T[l], rb);
+            const double c = single[i] + (cj > cl ? cj : cl) + 25.0;
+            if (c < alt) alt = c;
+        }
+    }
+    double best = alt * 0.92;
+    bool found = false;
+    for (int r0 = 1; r0 < budget; ++r0)
+        for (int r1 = 1; r0 + r1 < budget; ++r1) {
+            int r[3] = {r0, r1, budget - r0 - r1};
+            bool ok = true;
+            double c = 0.0;
+            for (int i = 0; i < 3 && ok; ++i) {
+                if (r[i] > trs[i]) r[i] = trs[i];
+                ok = r[i] >= 1 && (trs[i] + r[i] - 1) / r[i] <= PS_NRS_MAX;
+                const double ci = ps_bwd_cost(trs[i], T[i], r[i]);
+                if (ci > c) c = ci;
+            }
+            if (ok && c + 25.0 < best) { best = c + 25.0; R[0] = r[0]; R[1] = r[1]; R[2] = r[2]; found = true; }
+        }
+    return found;
+}
+bool d2p_lstm_persist_bwd_triple_ok(const int M[3], const int T[3], int U) {
+    if (!g_persist) return false;
+    int trs[3], R[3];
+    for (int i = 0; i < 3; ++i) {
+        if (!d2p_lstm_persist_bwd_ok(M[i], U, T[i])) return false;
+        trs[i] = (M[i] + 15) / 16;
+    }
+    return ps_plan_triple_bwd(trs, T, U / 16, R);
+}
+int d2p_lstm_persist_bwd_triple(const PsBwdCall q[3], hipStream_t st) {
+    int trs[3], T[3], R[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i) { trs[i] = (q[i].M + 15) / 16; T[i] = q[i].n_steps; }
+    if (!ps_plan_triple_bwd(trs, T, q[0].U / 16, R)) return D2P_EINVAL;
+    PsBwdArgs a[3];
+    int bid0 = 0;
+    double flops = 0.0;
+    for (int i = 0; i < 3; ++i) {
+        int rc = ps_bwd_setup(q[i], R[i], bid0, a[i], st);
+        if (rc) return rc;
+        bid0 += a[i].gsz;
+        flops += ps_bwd_flops(q[i]);
+    }
+    g_ps_pair_launches += 2;          // counts as two fusions (tests: the fused path must not be skipped silently)
+    return ps_bwd_launch(a[0], a[1], a[2], q[0].U, flops, st);
 }

@@ -688,6 +688,48 @@ def test_lstm_two_sequences_in_one_persistent_launch(K, specs, pairs):
             assert torch.equal(a[n], b[n]), n
 
 
+def test_lstm_three_backward_sequences_in_one_persistent_launch(K):
+    """d2p_lstm_seq_bwd_multi with the three decoders (2 x 320 rows x 20 steps, 32 rows x 50 steps): one launch with
+    3 + 3 + 2 row domains; bit-identical to three launches."""
+    from demo2program_amd.lib import load
+    lib = load()
+    U = 512
+    g = torch.Generator().manual_seed(23)
+    specs = [(320, 20), (320, 20), (32, 50)]
+    base = []
+    for (M, n) in specs:
+        base.append(dict(M=M, n=n, z0=(torch.rand(n * M, 4 * U, generator=g) * 2 - 1).cuda(),
+                         Wh=((torch.rand(U, 4 * U, generator=g) * 2 - 1) * 0.05).cuda(),
+                         h0=(torch.rand(M, U, generator=g) * 2 - 1).cuda(), c0=(torch.rand(M, U, generator=g) * 2 - 1).cuda(),
+                         dhout=(torch.rand(n, M, U, generator=g) * 2 - 1).cuda()))
+    results = []
+    K.lstm_persist_error(True)
+    before = lib.d2p_lstm_persist_pair_launches()
+    for multi in (True, False):
+        bw, outs = [], []
+        for b in base:
+            M, n = b['M'], b['n']
+            o = dict(z=b['z0'].clone(), hout=torch.zeros(n, M, U, device='cuda'), cs=torch.zeros(n, M, U, device='cuda'),
+                     dz=torch.zeros(n * M, 4 * U, device='cuda'), dh0=torch.zeros(M, U, device='cuda'),
+                     dc0=torch.zeros(M, U, device='cuda'))
+            K.lstm_seq_fwd_multi([dict(M=M, U=U, n_steps=n, z=o['z'], Wh=b['Wh'], h0=b['h0'], c0=b['c0'],
+                                       hout=o['hout'], cs=o['cs'])])
+            outs.append(o)
+            bw.append(dict(M=M, U=U, n_steps=n, z=o['z'], Wh=b['Wh'], c0=b['c0'], cs=o['cs'], dhout=b['dhout'],
+                           dz=o['dz'], dh0=o['dh0'], dc0=o['dc0']))
+        if multi:
+            K.lstm_seq_bwd_multi(bw)
+        else:
+            for b_ in bw:
+                K.lstm_seq_bwd_multi([b_])
+        results.append(outs)
+    assert K.lstm_persist_error(True) == 0
+    assert lib.d2p_lstm_persist_pair_launches() == before + 2
+    for a, b in zip(*results):
+        for n in ('dz', 'dh0', 'dc0'):
+            assert torch.equal(a[n], b[n]), n
+
+
 def test_gate_nonlinearities_are_fp32_accurate(K):
     """The gate math runs on the hardware exp2 / rcp units (common.h d2p_sigmoid / d2p_tanh): over the
     whole useful range, including saturation and tiny arguments, c' and h' of one cell step stay

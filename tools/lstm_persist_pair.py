@@ -51,5 +51,20 @@ def main():
               '  '.join('%s %.0f us' % kv for kv in res.items()) + ' | err %d' % K.lstm_persist_error(True))
 
 
+def triple():
+    """backward of the three decoders: perception + action (320 rows x 20 steps) + program (32 rows x 50 steps)"""
+    qs = [mk(320, 20, seed=1), mk(320, 20, seed=3), mk(32, 50, seed=2)]
+    for f, _ in qs:
+        K.lstm_seq_fwd_multi([f])
+    b = [q[1] for q in qs]
+    t_single = [timed(lambda i=i: K.lstm_seq_bwd_multi([b[i]])) for i in range(3)]
+    t_pair = timed(lambda: K.lstm_seq_bwd_multi([b[1], b[2]]))
+    t_triple = timed(lambda: K.lstm_seq_bwd_multi(b))
+    print('bwd three decoders: singles %.0f + %.0f + %.0f us; one + pair %.0f + %.0f = %.0f us; all three in one launch '
+          '%.0f us | err %d' % (t_single[0], t_single[1], t_single[2], t_single[0], t_pair, t_single[0] + t_pair,
+                               t_triple, K.lstm_persist_error(True)))
+
+
 if __name__ == '__main__':
     main()
+    triple()
