@@ -85,6 +85,27 @@ extern "C" int d2p_gemm_f32_nt(int M, int N, int K, const float* A, long lda, co
     return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_nt");
 }
 
+// Products over a LIST of rows: row x of the result is computed from row rows[x] of A and stored at row rows[x]
+// of C (M = number of listed rows; rows of C that are not listed are left untouched).  kind 0: C = A . B (B [K, N]),
+// kind 1: C = A . B^T (B [N, K]).  For the active rows of padded time-major batches.
+extern "C" int d2p_gemm_f32_rows(int kind, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                                 float* C, long ldc, const float* bias, const int* rows, void* ws, size_t ws_bytes,
+                                 d2p_stream_t stream) {
+    int rc = check_gemm_args(M, N, K, A, B, C, 0);
+    if (rc) return rc;
+    D2P_REQUIRE(kind == 0 || kind == 1, D2P_EINVAL, "gemm_rows: kind %d", kind);
+    if (M == 0 || N == 0) return D2P_OK;
+    D2P_REQUIRE(rows != nullptr, D2P_EINVAL, "gemm_rows: null row list");
+    GatherKC al{A, lda, M, vec_ok(A, lda), rows};
+    EpiScatterRows ep{C, ldc, bias, rows};
+    if (kind == 0) {
+        DenseXC bl{B, ldb, N, vec_ok(B, ldb)};
+        return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_rows_nn");
+    }
+    DenseKC bl{B, ldb, N, vec_ok(B, ldb)};
+    return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_rows_nt");
+}
+
 extern "C" int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, const float* B,
                                long ldb, float* C, long ldc, const float* bias, int act,
                                int accumulate, void* ws, size_t ws_bytes, d2p_stream_t stream) {

@@ -43,6 +43,7 @@ struct DenseKC {  // elem(x,k) = p[x*ld + k]
     // FAST: vec && K % 4 == 0: one unconditional 16-byte load from a clamped address, then a
     // select -- no control flow, so hipcc keeps counted vmcnt waits across the K loop.
     bool fast_ok(int K) const { return vec && K >= 4 && (K % 4) == 0 && X > 0; }
+    __device__ __forceinline__ const float* row_ptr(int x) const { return p + (long)x * ld; }
     // Returns false when the caller must treat v as zeros (FAST defers the select to the
     // LDS-store point so that nothing consumes the load result early).
     template <bool FAST>
@@ -58,6 +59,43 @@ struct DenseKC {  // elem(x,k) = p[x*ld + k]
             return true;
         }
         const float* q = p + (long)x * ld + k;
+        if (vec && k + 3 < klim) {
+            float4 t = *reinterpret_cast<const float4*>(q);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (k + j < klim) ? q[j] : 0.f;
+        }
+        return true;
+    }
+};
+
+// Rows through an index list: elem(x,k) = p[idx[x]*ld + k].  For products over the ACTIVE rows of a padded
+// time-major batch (rows past a sequence's length are zeros and their outputs are never read): the GEMM runs over
+// the listed rows only, its epilogue (EpiScatterRows) puts row x of the result at idx[x].
+struct GatherKC {
+    static constexpr bool KCONTIG = true;
+    const float* p;
+    long ld;
+    int X;
+    int vec;
+    const int* idx;
+    __device__ __forceinline__ void shift(int) {}
+    bool fast_ok(int K) const { return vec && K >= 4 && (K % 4) == 0 && X > 0; }
+    __device__ __forceinline__ const float* row_ptr(int x) const { return p + (long)idx[x] * ld; }
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
+        if (FAST) {
+            const bool ok = (x < X) & (k < klim);
+            const float4 t = *reinterpret_cast<const float4*>(ok ? row_ptr(x) + k : p);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            return ok;
+        }
+        if (x >= X) {
+            v[0] = v[1] = v[2] = v[3] = 0.f;
+            return true;
+        }
+        const float* q = row_ptr(x) + k;
         if (vec && k + 3 < klim) {
             float4 t = *reinterpret_cast<const float4*>(q);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -109,6 +147,7 @@ struct DenseXC {  // elem(x,k) = p[k*ld + x]
 template <class L> struct d2p_nosel_ok { static constexpr bool value = false; };
 template <> struct d2p_nosel_ok<DenseKC> { static constexpr bool value = true; };
 template <> struct d2p_nosel_ok<DenseXC> { static constexpr bool value = true; };
+template <> struct d2p_nosel_ok<GatherKC> { static constexpr bool value = true; };
 // strided-batched launches (grid.y > 1) exist for dense operands with the dense epilogue only
 template <class EP> struct d2p_batch_ok { static constexpr bool value = false; };
 
@@ -144,6 +183,20 @@ struct EpiDense {
         if (accumulate) v += c_value(row, col);
         store(row, col, v + col_value(col));
     }
+};
+
+// Row x of the product lands at row idx[x] of C (see GatherKC); bias, no accumulate.
+struct EpiScatterRows {
+    float* C;
+    long ldc;
+    const float* bias;
+    const int* idx;
+    __device__ __forceinline__ void shift(int) {}
+    __device__ __forceinline__ float col_value(int col) const { return bias ? bias[col] : 0.f; }
+    __device__ __forceinline__ bool has_c() const { return false; }
+    __device__ __forceinline__ float c_value(int, int) const { return 0.f; }
+    __device__ __forceinline__ void store(int row, int col, float v) const { C[(long)idx[row] * ldc + col] = v; }
+    __device__ __forceinline__ void operator()(int row, int col, float v) const { store(row, col, v + col_value(col)); }
 };
 
 // ------------------------------------------------------------------------------------
@@ -225,7 +278,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             const int q = tid + i * 256;
             pa[i] = al.p;
             if (CA % 256 == 0 || q < CA) {
-                if (AL::KCONTIG) pa[i] = al.p + (long)min(m0 + q / (BK / 4), al.X - 1) * al.ld + kbeg + (q % (BK / 4)) * 4;
+                if constexpr (AL::KCONTIG) pa[i] = al.row_ptr(min(m0 + q / (BK / 4), al.X - 1)) + kbeg + (q % (BK / 4)) * 4;
                 else pa[i] = al.p + (long)(kbeg + q / (BM / 4)) * al.ld + min(m0 + (q % (BM / 4)) * 4, al.X - 4);
             }
         }
@@ -234,7 +287,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             const int q = tid + i * 256;
             pb[i] = bl.p;
             if (CB % 256 == 0 || q < CB) {
-                if (BL::KCONTIG) pb[i] = bl.p + (long)min(n0 + q / (BK / 4), bl.X - 1) * bl.ld + kbeg + (q % (BK / 4)) * 4;
+                if constexpr (BL::KCONTIG) pb[i] = bl.row_ptr(min(n0 + q / (BK / 4), bl.X - 1)) + kbeg + (q % (BK / 4)) * 4;
                 else pb[i] = bl.p + (long)(kbeg + q / (BN / 4)) * bl.ld + min(n0 + (q % (BN / 4)) * 4, bl.X - 4);
             }
         }

@@ -80,6 +80,13 @@ def gemm_raw(kind, M, N, K, A, lda, B, ldb, C, ldc, bias=None, act=0, accumulate
        ws, wsb, current_stream())
 
 
+def gemm_rows(kind, n_rows, N, K, A, lda, B, ldb, C, ldc, rows, bias=None):
+    """C[rows[x]] = A[rows[x]] . B (kind 'nn', B [K, N]) or A[rows[x]] . B^T ('nt', B [N, K]) for x < n_rows."""
+    ws, wsb = SCRATCH.get(call.d2p_gemm_ws_bytes(n_rows, N, K))
+    call.d2p_gemm_f32_rows({'nn': 0, 'nt': 1}[kind], n_rows, N, K, _p(A), lda, _p(B), ldb, _p(C), ldc, _p(bias),
+                           _p(rows), ws, wsb, current_stream())
+
+
 def gemm_batched(kind, nb1, nb0, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, bias=None, sbias=(0, 0), act=0,
                  accumulate=False):
     """nb1 x nb0 problems of one shape in one launch; sA / sB / sC / sbias = (stride over the first batch

@@ -184,6 +184,10 @@ class Model(object):
         # launches.  D2P_NO_SIDE_STREAM=1 / D2P_SIDE_STREAM=0 switch it off.
         # two decoders per persistent launch (d2p_lstm_seq_*_multi with two sequences)
         self.pair_decoders = os.environ.get('D2P_PAIR_DECODERS', '1') == '1'
+        # the second encoder's input projection and dX run over the rows inside their sequences only (the rows past
+        # a demonstration's length are zeros in its input and in dz); off under hipGraph capture, where the row
+        # count would have to be part of the graph key
+        self.compact_rows = os.environ.get('D2P_COMPACT_ROWS', '1') == '1'
         # perception decoder: its batch-normed fc features are never multiplied by Wx row by row (forward _per_xproj)
         self.per_factored = os.environ.get('D2P_PER_FACTORED', '1') == '1' and config.per_dim <= 8
         self.per_cols = (config.k * (config.per_dim + 1) + 3) // 4 * 4
@@ -223,7 +227,8 @@ class Model(object):
         K.SCRATCH.reserve(max(need))
 
     # ------------------------------------------------------------------ feed
-    FEED_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'per_rows', 'per_gram', 'program_len',
+    FEED_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'per_rows', 'per_gram', 'active_rows',
+                 'program_len',
                  'demo_len')
 
     def alloc_feed(self, frames_dtype=torch.float32):
@@ -242,6 +247,8 @@ class Model(object):
                 # factored perception decoder multiplies instead of [rows, U] features (d2p.h: d2p_per_affine_rows)
                 ('per_rows', torch.float32, (T * B * k, self.per_cols)),
                 ('per_gram', torch.float32, (self.per_cols, self.per_cols)),
+                # time-major row indices t*M + m of the demonstration steps inside their sequence (t < demo_len[m])
+                ('active_rows', torch.int32, (T * B * k,)),
                 ('program_len', torch.int32, (B,)), ('demo_len', torch.int32, (B * k,))]
         offs, total = [], 0
         for _, dt, shape in spec:
@@ -311,6 +318,11 @@ class Model(object):
         dlen = host_np(batch_chunk['demo_len']).astype(np.int32).reshape(B * k)
         put('program_len', plen)
         put('demo_len', dlen)
+        act = np.nonzero(np.arange(T, dtype=np.int32)[:, None] < dlen[None, :])
+        act_rows = (act[0].astype(np.int64) * (B * k) + act[1]).astype(np.int32)
+        feed['n_active'] = int(act_rows.size)
+        if act_rows.size:
+            feed['active_rows'][:act_rows.size].copy_(torch.from_numpy(act_rows), non_blocking=True)
         # dynamic_decode runs until the longest sequence of the batch
         feed['n_prog'] = int(min(int(plen.max()) if B else 0, L))
         feed['n_demo'] = int(min(int(dlen.max()) if B * k else 0, T))
@@ -431,8 +443,15 @@ class Model(object):
             # the final states of all demonstrations, h then c, in one buffer: the two relation networks
             # (separate weights, same shapes) then run as strided-batched launches
             demo_hc = self._buf('demo_hc', (2, M, U))
+            z_e2 = None
+            ctx['rows'] = None
+            if self.compact_rows and feed.get('n_active') is not None and 0 < feed['n_active'] < T * M:
+                ctx['rows'] = (feed['active_rows'], feed['n_active'])
+                z_e2 = self._buf('second_lstm/z', (T * M, 4 * U))
+                K.gemm_rows('nn', feed['n_active'], 4 * U, U, e1['hout'], U, p['second_lstm/kernel'][:U], 4 * U,
+                            z_e2, 4 * U, feed['active_rows'], bias=p['second_lstm/bias'])
             e2 = self._lstm_fwd('second_lstm', e1['hout'].view(T * M, U), U, M, T, T, h0_2, c0_2, lens_d,
-                                want_final=True, final_out=(demo_hc[0], demo_hc[1]))
+                                want_final=True, final_out=(demo_hc[0], demo_hc[1]), z=z_e2)
             demo_h, demo_c = demo_hc[0], demo_hc[1]
             # ---- SummarizeFeature('rn') = mean_k + rn_pool (the summarizer baseline: rn_pool alone)
             rn_h = rn_c = self._rn_fwd(demo_hc, B, k, U, add_mean=self.multitask)
@@ -908,7 +927,13 @@ class Model(object):
             dh0_2, dc0_2 = dhc0_2[0], dhc0_2[1]
             # (its weight gradients go to the side stream: two large GEMMs beside the next recurrence)
             dz2 = self._lstm_bwd_rec(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2)
-            d_hout1 = self._lstm_bwd_dx(e2, dz2)
+            if ctx.get('rows') is not None:
+                rows_idx, n_act = ctx['rows']
+                d_hout1 = self._buf(e2['name'] + '/dx', (T * M, U))
+                d_hout1.zero_()                       # rows past their sequence: no gradient
+                K.gemm_rows('nt', n_act, U, 4 * U, dz2, 4 * U, e2['Wx'], 4 * U, d_hout1, U, rows_idx)
+            else:
+                d_hout1 = self._lstm_bwd_dx(e2, dz2)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 self._lstm_bwd_weights(e2, dz2)

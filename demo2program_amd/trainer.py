@@ -229,7 +229,8 @@ class Trainer(object):
         return bool(getattr(load(), '_d2p_prof_on', False))
 
     MAX_GRAPHS = 128      # distinct (n_prog, n_demo) pairs kept as instantiated graphs
-    _STATIC_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'per_rows', 'per_gram', 'program_len',
+    _STATIC_KEYS = ('s_h', 'program', 'program_tokens', 'a_h', 'a_h_tokens', 'per', 'per_rows', 'per_gram', 'active_rows',
+                    'program_len',
                     'demo_len')
 
     def _graphed_forward_backward(self, feed, split_cb=None):

@@ -92,6 +92,13 @@ int d2p_gemm_f32_nt(int M, int N, int K, const float* A, long lda, const float* 
 int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                     float* C, long ldc, const float* bias, int act, int accumulate,
                     void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* Products over a list of rows (the ACTIVE rows of a padded, time-major batch: rows past a sequence's length hold
+ * zeros and nothing reads their results): row x of the product is computed from row rows[x] of A and stored at row
+ * rows[x] of C; M = number of listed rows, unlisted rows of C are untouched.  kind 0: C = A . B + bias (B [K, N]);
+ * kind 1: C = A . B^T + bias (B [N, K]).  Same summation order per element as d2p_gemm_f32_nn / _nt on the same
+ * tile plan.  Workspace: d2p_gemm_ws_bytes(M, N, K). */
+int d2p_gemm_f32_rows(int kind, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
+                      long ldc, const float* bias, const int* rows, void* ws, size_t ws_bytes, d2p_stream_t stream);
 /* out[c] = sum_r X[r*ld + c]  (bias gradients).  ws >= d2p_colsum_ws_bytes. */
 size_t d2p_colsum_ws_bytes(int rows, int cols);
 int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float* out,

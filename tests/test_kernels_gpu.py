@@ -196,6 +196,25 @@ def test_gemm_lds_dma_pipeline_equals_staged_kernel(K, tile, M, N, K_, splits):
     close(dma[0], oracle.lrelu(A @ B + bias), atol=2e-6 * K_ + 1e-5, rtol=1e-5)
 
 
+@pytest.mark.parametrize('R,N,K_,frac', [(6400, 2048, 512, 0.7), (6400, 512, 2048, 0.7), (100, 72, 48, 0.5), (640, 64, 37, 0.9)])
+def test_gemm_over_a_list_of_rows(K, R, N, K_, frac):
+    """d2p_gemm_f32_rows: the product for the listed rows only (rows of a padded batch past their sequence's length
+    are skipped), result rows scattered to their places, the others untouched; same values as the dense product."""
+    g = torch.Generator().manual_seed(3)
+    A, B, bias = rnd(R, K_, seed=71), rnd(K_, N, seed=72), rnd(N, seed=73)
+    keep = torch.rand(R, generator=g) < frac
+    rows = torch.nonzero(keep).flatten().to(torch.int32)
+    n = rows.numel()
+    dA, dB, dBt, drows = dev(A), dev(B), dev(B.t().contiguous()), rows.cuda()
+    tol = dict(atol=2e-6 * K_ + 1e-5, rtol=1e-5)
+    for kind, Bm, ldb in (('nn', dB, N), ('nt', dBt, K_)):
+        C = torch.full((R, N), 7.0, device='cuda')
+        K.gemm_rows(kind, n, N, K_, dA, K_, Bm, ldb, C, N, drows, bias=dev(bias))
+        ref = A @ B + bias
+        close(C[keep.cuda()], ref[keep], **tol)
+        assert (C[~keep.cuda()] == 7.0).all()
+
+
 def test_gemm_is_transpose_detecting(K):
     # A = I with an asymmetric B catches a swapped C layout (cdna guide §3)
     n = 96
