@@ -260,7 +260,7 @@ def north_star_targets(config, table):
 
 def recurrent_step_microbench(M, U, T):
     """The recurrent kernels on the encoder / action-decoder shape (M = B*k rows, T steps) outside the step:
-    one persistent launch per sequence timed at T and 2T steps, so that the per-call cost (preparation launch,
+    one persistent launch per sequence timed at T and 4T steps, so that the per-call cost (preparation launch,
     kernel prologue: weights into registers, launch latency) separates from the per-time-step rate.  flops per
     time step = 2 * M * 4U * U (the h.Wh / dz.Wh^T product; the input projection is a separate GEMM)."""
     from demo2program_amd import kernels as K
@@ -288,18 +288,18 @@ def recurrent_step_microbench(M, U, T):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps           # us per call
     res = {'rows': M, 'units': U, 'note': 'standalone: one persistent launch per sequence (+ its preparation launch) '
-                                           'at T and 2T steps; peak = fp32 MFMA'}
+                                           'at T and 4T steps; peak = fp32 MFMA'}
     flop_step = 2.0 * M * 4 * U * U
     for name, key in (('forward', 0), ('backward', 1)):
         ts = []
-        for Tn in (T, 2 * T):
+        for Tn in (T, 4 * T):                 # a long second point: the slope is the steady per-step time
             q = seq(Tn)
             if key == 0:
-                ts.append(min(timed(lambda: K.lstm_seq_fwd_multi([q[0]])) for _ in range(2)))
+                ts.append(min(timed(lambda: K.lstm_seq_fwd_multi([q[0]])) for _ in range(3)))
             else:
                 K.lstm_seq_fwd_multi([q[0]])
-                ts.append(min(timed(lambda: K.lstm_seq_bwd_multi([q[1]])) for _ in range(2)))
-        steady = (ts[1] - ts[0]) / T
+                ts.append(min(timed(lambda: K.lstm_seq_bwd_multi([q[1]])) for _ in range(3)))
+        steady = (ts[1] - ts[0]) / (3 * T)
         res[name] = {'us_per_call_at_T': round(ts[0], 1), 'T': T,
                      'us_per_time_step_at_T': round(ts[0] / T, 2),
                      'frac_at_T': round(flop_step / (ts[0] / T * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
