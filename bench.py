@@ -389,6 +389,33 @@ def cpu_baseline_leg(config, batch, params, steps=2):
             'cpu_model': model}
 
 
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (one process per GPU) through
+    torch.distributed.run on 127.0.0.1 and a free port, pass the command line on unchanged, and exit with the
+    launcher's status.  Rank 0 of the children prints the one JSON line on the inherited stdout.  The
+    `python -m torch.distributed.run ... bench.py --gpus N` form keeps working: it sets WORLD_SIZE, so this is
+    skipped."""
+    import socket
+    import subprocess
+    from demo2program_amd import build
+    build.build_library()                      # once, before N ranks ask for it
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    argv = [a for a in sys.argv[1:] if a != '--self-spawn']
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL across processes)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    env['D2P_BENCH_SELF_SPAWNED'] = '1'
+    if args.gpus == 1:
+        env['D2P_FORCE_DIST'] = '1'            # a one-rank RCCL group: the exchange step runs, as an identity
+    sys.stderr.write('[bench] no launcher: spawning %d rank(s): %s\n' % (args.gpus, ' '.join(cmd)))
+    sys.stderr.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def log(msg):
     if os.environ.get('RANK', '0') == '0':
         sys.stderr.write('[bench %.1fs] %s\n' % (time.time() - _T0, msg))
@@ -410,10 +437,15 @@ def main():
                     'no prefetch); the prefetched PCIe-inclusive rate is always reported')
     ap.add_argument('--no-h2d', action='store_true', help='skip the PCIe-inclusive leg')
     ap.add_argument('--no-config4', action='store_true', help='skip the ViZDoom (BASELINE config 4) leg')
+    ap.add_argument('--self-spawn', action='store_true',
+                    help='start the N ranks from this process even for N = 1 (the path `python bench.py --gpus N` takes '
+                         'for N > 1 when it was not launched by torch.distributed.run)')
     ap.add_argument('--frames', default='uint8', choices=['uint8', 'float32'],
                     help='precision the demonstration frames are staged in: uint8 = the dataset\'s own (Karel states are '
                          'booleans, ViZDoom frames bytes), widened on load inside conv1; float32 = the reference\'s feed dtype')
     args = ap.parse_args()
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.self_spawn):
+        self_spawn(args)
 
     from demo2program_amd import build
     from demo2program_amd.config import make_config
@@ -424,7 +456,8 @@ def main():
     dp = DataParallel.from_env()
     if dp.world_size != args.gpus:
         raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run '
-                         '--nproc-per-node %d' % (args.gpus, dp.world_size, args.gpus))
+                         '--nproc-per-node %d (or without a launcher: bench.py starts the ranks itself)'
+                         % (args.gpus, dp.world_size, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X; there is no CPU fallback')
     if dp.rank == 0:
@@ -451,6 +484,7 @@ def main():
     log('warmup done; timing %d steps' % args.steps)
     dp.barrier()
     torch.cuda.synchronize()
+    waited0 = trainer.guard.waited if trainer.guard is not None else 0.0
     t0 = time.perf_counter()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     marks[0].record()
@@ -458,13 +492,19 @@ def main():
         loss = trainer.train_step(feeds[i % len(feeds)])
         marks[i + 1].record()             # device-side step boundaries (no host sync inside the region)
     host_enqueue = time.perf_counter() - t0   # host time to ENQUEUE the K steps (device may still be running)
+    if trainer.guard is not None:
+        # the step guard lets the host run at most StepGuard.DEPTH steps ahead: time it spent WAITING for the device
+        # is not enqueue work
+        host_enqueue -= trainer.guard.waited - waited0
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
     elapsed = dp.max_over_ranks(time.perf_counter() - t0)
     final_loss = float(loss.item())
     log('timed region done: %.3f s' % elapsed)
-    trainer.check_device_status()          # a persistent LSTM launch that gave up a hand-off voids the run
+    # a persistent LSTM launch that gave up a hand-off: the guarded step skipped it on the device and the trainer
+    # re-ran it on the per-step kernels INSIDE the timed region (count reported; 0 on a dedicated GPU)
+    persist_fallbacks = trainer.settle()
 
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     step_stats = {'median': round(per_step[len(per_step) // 2], 4), 'p10': round(per_step[len(per_step) // 10], 4),
@@ -493,6 +533,13 @@ def main():
         'device_step_ms': step_stats,
         'host_enqueue_ms_per_step': round(host_enqueue * 1e3 / args.steps, 4),
         'final_loss': round(final_loss, 5),
+        # ranks that took part in the gradient exchange: an all-reduce of ones over the job's process group
+        # (None: one rank without a process group, no collective issued)
+        'persistent_lstm_fallbacks': persist_fallbacks,
+        'rccl_ranks_seen': dp.ranks_seen(),
+        'launcher': 'self-spawned' if os.environ.get('D2P_BENCH_SELF_SPAWNED') == '1' else
+                    ('torch.distributed.run' if 'TORCHELASTIC_RUN_ID' in os.environ or 'WORLD_SIZE' in os.environ
+                     else 'none (one process)'),
     }
 
     if not args.no_h2d:

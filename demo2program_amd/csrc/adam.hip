@@ -62,10 +62,42 @@ extern "C" int d2p_l2norm_flat(size_t n, const float* g, float prescale, double*
     return D2P_OK;
 }
 
+// The status word of the persistent recurrent kernels (lstm_persist.hip): non-zero once a launch gave up a
+// hand-off -- the gradients of that step, and of every step until the host resets the word, are invalid.
+unsigned* d2p_persist_err_ptr();
+
+__global__ void step_status_publish_kernel(const unsigned* err, float* slot) {
+    if (threadIdx.x == 0) slot[0] = (*err != 0u) ? 1.f : 0.f;
+}
+
+extern "C" int d2p_step_status_publish(float* slot, d2p_stream_t stream) {
+    D2P_REQUIRE(slot, D2P_EINVAL, "step status: null slot");
+    hipLaunchKernelGGL(step_status_publish_kernel, dim3(1), dim3(64), 0, as_stream(stream), d2p_persist_err_ptr(), slot);
+    D2P_LAUNCH_CHECK("step_status_publish");
+    return D2P_OK;
+}
+
+// err / fail_slot / counters: the guarded form (d2p_adam_clip_flat_guarded).  The update is SKIPPED -- parameters
+// and moments untouched -- when this device's status word is set or the (all-reduced) slot says some rank's is;
+// counters[0] counts applied steps, counters[1] skipped ones; mirror (optional, host-mapped pinned memory): a copy of
+// both after this step, so that the host can follow them without a copy operation on the stream.
 __global__ void __launch_bounds__(256)
 adam_clip_kernel(size_t n, float* p, const float* g, float* m, float* v, const double* sumsq,
                  float prescale, float clip, float lr_t_host, const float* lr_t_dev, float b1,
-                 float b2, float eps) {
+                 float b2, float eps, const unsigned* err, const float* fail_slot, unsigned long long* counters,
+                 unsigned long long* mirror) {
+    const bool bad = (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ||
+                     (fail_slot && !(fail_slot[0] == 0.f));          // NaN counts as set
+    if (counters && blockIdx.x == 0 && threadIdx.x == 0) {
+        const unsigned long long a = counters[0] + (bad ? 0ULL : 1ULL), k = counters[1] + (bad ? 1ULL : 0ULL);
+        counters[0] = a;
+        counters[1] = k;
+        if (mirror) {
+            mirror[0] = a;
+            mirror[1] = k;
+        }
+    }
+    if (bad) return;
     const float lr_t = lr_t_dev ? lr_t_dev[0] : lr_t_host;
     const double norm = sqrt(sumsq[0]);
     // [TF-1.3] clip_by_global_norm: g * clip / max(norm, clip)
@@ -109,7 +141,26 @@ extern "C" int d2p_adam_clip_flat(size_t n, float* p, const float* g, float* m, 
     size_t want = (n / 4 + 255) / 256;
     int nb = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
     hipLaunchKernelGGL(adam_clip_kernel, dim3(nb), dim3(256), 0, as_stream(stream), n, p, g, m, v,
-                       sumsq, prescale, clip, lr_t, lr_t_dev, beta1, beta2, eps);
+                       sumsq, prescale, clip, lr_t, lr_t_dev, beta1, beta2, eps, (const unsigned*)nullptr,
+                       (const float*)nullptr, (unsigned long long*)nullptr, (unsigned long long*)nullptr);
     D2P_LAUNCH_CHECK("adam_clip");
+    return D2P_OK;
+}
+
+extern "C" int d2p_adam_clip_flat_guarded(size_t n, float* p, const float* g, float* m, float* v,
+                                          const double* sumsq, float prescale, float clip, float lr_t,
+                                          const float* lr_t_dev, float beta1, float beta2, float eps,
+                                          const float* fail_slot, unsigned long long* counters,
+                                          unsigned long long* mirror, d2p_stream_t stream) {
+    D2P_REQUIRE(counters, D2P_EINVAL, "adam guarded: null counters");
+    D2P_REQUIRE(n == 0 || (p && g && m && v && sumsq), D2P_EINVAL, "adam: null pointer");
+    D2P_REQUIRE(((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0), D2P_EALIGN,
+                "adam: buffers must be 16-byte aligned");
+    size_t want = (n / 4 + 255) / 256;
+    int nb = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(adam_clip_kernel, dim3(nb), dim3(256), 0, as_stream(stream), n, p, g, m, v,
+                       sumsq, prescale, clip, lr_t, lr_t_dev, beta1, beta2, eps,
+                       (const unsigned*)d2p_persist_err_ptr(), fail_slot, counters, mirror);
+    D2P_LAUNCH_CHECK("adam_clip_guarded");
     return D2P_OK;
 }

@@ -11,6 +11,11 @@
 
 #define BN_EPS 1e-3   // [TF-1.3] contrib.layers.batch_norm default epsilon
 
+// status word of the persistent recurrent kernels: while it is set (a launch gave up a hand-off and the
+// activations downstream of it are garbage) the moving statistics are left alone -- the guarded optimizer
+// step skips its update under the same condition (adam.hip) and the trainer re-runs the step
+unsigned* d2p_persist_err_ptr();
+
 struct BnPlan {
     int lanes_c;    // threads along channels
     int row_lanes;  // threads along rows
@@ -150,7 +155,8 @@ bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, co
 // dgamma / dbeta (sums over the groups) in the backward kernel.
 __global__ void __launch_bounds__(256)
 bn_finalize_fwd_kernel(int n, int C, int G, int S, const double* partial, float* mean, float* rstd,
-                       float* var_out, float* moving_mean, float* moving_var, float decay, BnBatch bb) {
+                       float* var_out, float* moving_mean, float* moving_var, float decay, const unsigned* err,
+                       BnBatch bb) {
     BN_SHIFT_WS(partial, const double); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss); BN_SHIFT(var_out, bb.ss);
     BN_SHIFT(moving_mean, bb.ms); BN_SHIFT(moving_var, bb.ms);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -179,7 +185,7 @@ bn_finalize_fwd_kernel(int n, int C, int G, int S, const double* partial, float*
         mm = decay * mm + (1.f - decay) * (float)mu;
         mv = decay * mv + (1.f - decay) * (float)var;
     }
-    if (lane == 0 && moving_mean) {
+    if (lane == 0 && moving_mean && *err == 0u) {
         moving_mean[c] = mm;
         moving_var[c] = mv;
     }
@@ -386,7 +392,8 @@ static int bn_fwd_impl(int nb, long xs, long ys, long ps, long ms, int R, int C,
                            (const float*)nullptr, (const float*)nullptr, partial, bb);
     D2P_LAUNCH_CHECK("bn_partial_fwd");
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, n, C, G,
-                       p.S, partial, mean, rstd, var_out, moving_mean, moving_var, decay, bb);
+                       p.S, partial, mean, rstd, var_out, moving_mean, moving_var, decay,
+                       (const unsigned*)d2p_persist_err_ptr(), bb);
     D2P_LAUNCH_CHECK("bn_finalize_fwd");
     const bool vec = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma |
                                               (uintptr_t)beta | (uintptr_t)mean | (uintptr_t)rstd) & 15) == 0);

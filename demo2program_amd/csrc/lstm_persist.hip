@@ -60,6 +60,12 @@ static unsigned* ps_err_ptr() {
     if (!p) (void)hipGetSymbolAddress((void**)&p, HIP_SYMBOL(g_ps_err));
     return p;
 }
+unsigned* d2p_persist_err_ptr() { return ps_err_ptr(); }     // adam.hip, bn.hip: the guarded optimizer step
+// Test hook: sets the status word as a timed-out hand-off would (code 0x7f), without a real failure.
+extern "C" int d2p_lstm_persist_inject_error(void) {
+    const unsigned v = (0x7fu << 24) | 0x800000u;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ps_err), &v, sizeof(v)) == hipSuccess ? D2P_OK : D2P_EINVAL;
+}
 extern "C" int d2p_lstm_persist_error(int reset) {
     unsigned v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_ps_err), sizeof(v)) != hipSuccess) return -1;

@@ -429,38 +429,66 @@ extern "C" int d2p_per_affine_rows(int G, int P, int U, int NCp, const float* W,
 //   m1_g = t_g / n, m2_g = rstd_g (w_g - mean_g t_g) / n              (batch-norm backward means)
 //   dW[j] = sum_g alpha_g ( Q_g[j] - p_g[j] m1_g - m2_g rstd_g ( sum_i C_g[j,i] W[i] + p_g[j] (b - mean_g) ) )
 //   db = 0 (a bias in front of a batch norm has no gradient: sum xhat = 0 and t_g = n m1_g)
+// One thread per (channel, group): block = 16 channels x 16 group lanes, the per-group terms meet in LDS and are
+// summed in group order (round 2 ran one thread per channel over all groups -- 8 wavefronts walking 10 groups of
+// dependent loads: 63 us on two workgroups; this form: U/16 workgroups, one group per thread).
+#define PFB_CH 16
+#define PFB_GL 16
 __global__ void __launch_bounds__(256)
 per_fc_bn_bwd_kernel(int G, int P, int U, int NCp, float n, const float* __restrict__ W, const float* __restrict__ b,
                      const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
                      const float* __restrict__ Q, const float* __restrict__ gram, float* __restrict__ dW,
                      float* __restrict__ db, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= U) return;
+    __shared__ float red[PFB_GL][10][PFB_CH];          // [group lane][dw[0..7], dgamma, dbeta][channel]
+    const int cl = threadIdx.x & (PFB_CH - 1), gl = threadIdx.x / PFB_CH;
+    const int c = blockIdx.x * PFB_CH + cl;
+    const bool on = c < U;
+    const int cc = on ? c : U - 1;
     float w[8], dw[8];
-    for (int j = 0; j < P; ++j) { w[j] = W[j * U + c]; dw[j] = 0.f; }
-    const float bc = b[c], gm = gamma[c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { w[j] = j < P ? W[j * U + cc] : 0.f; dw[j] = 0.f; }
+    const float bc = b[cc], gm = gamma[cc];
     float dg = 0.f, dbt = 0.f;
-    for (int g = 0; g < G; ++g) {
+    for (int g = gl; g < G; g += PFB_GL) {
         const int q0 = g * (P + 1);
-        const float mu = mean[g * U + c], rs = rstd[g * U + c];
-        const float t = Q[(long)(q0 + P) * U + c];
+        const float mu = mean[g * U + cc], rs = rstd[g * U + cc];
+        const float t = Q[(long)(q0 + P) * U + cc];
+        float qv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qv[j] = j < P ? Q[(long)(q0 + j) * U + cc] : 0.f;
         float ww = bc * t;
-        for (int j = 0; j < P; ++j) ww += w[j] * Q[(long)(q0 + j) * U + c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ww += w[j] * qv[j];
         const float s = rs * (ww - mu * t);          // sum dpe * xhat
         dg += s;
         dbt += t;
         const float m1 = t / n, m2 = s / n, alpha = gm * rs;
-        for (int j = 0; j < P; ++j) {
-            const float pj = gram[(long)(q0 + j) * NCp + q0 + P];
-            float cw = pj * (bc - mu);
-            for (int i = 0; i < P; ++i) cw += gram[(long)(q0 + j) * NCp + q0 + i] * w[i];
-            dw[j] += alpha * (Q[(long)(q0 + j) * U + c] - pj * m1 - m2 * rs * cw);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < P) {
+                const float* gr = gram + (long)(q0 + j) * NCp + q0;
+                const float pj = gr[P];
+                float cw = pj * (bc - mu);
+                for (int i = 0; i < P; ++i) cw += gr[i] * w[i];
+                dw[j] += alpha * (qv[j] - pj * m1 - m2 * rs * cw);
+            }
         }
     }
-    for (int j = 0; j < P; ++j) dW[j * U + c] = dw[j];
-    db[c] = 0.f;
-    dgamma[c] = dg;
-    dbeta[c] = dbt;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[gl][j][cl] = dw[j];
+    red[gl][8][cl] = dg;
+    red[gl][9][cl] = dbt;
+    __syncthreads();
+    // item i of channel cl: summed over the group lanes in lane order (= group order for G <= 16)
+    const int item = gl;
+    if (item < 10 && on) {
+        float acc = 0.f;
+        for (int l = 0; l < PFB_GL; ++l) acc += red[l][item][cl];
+        if (item < P) dW[item * U + c] = acc;
+        else if (item == 8) dgamma[c] = acc;
+        else if (item == 9) dbeta[c] = acc;
+    }
+    if (gl == 10 && on) db[c] = 0.f;
 }
 extern "C" int d2p_per_fc_bn_bwd(int G, int P, int U, int NCp, int rows_per_group, const float* W, const float* b,
                                  const float* gamma, const float* mean, const float* rstd, const float* Q,
@@ -470,7 +498,7 @@ extern "C" int d2p_per_fc_bn_bwd(int G, int P, int U, int NCp, int rows_per_grou
                 "per_fc_bn_bwd: bad sizes (P <= 8)");
     D2P_REQUIRE(W && b && gamma && mean && rstd && Q && gram && dW && db && dgamma && dbeta, D2P_EINVAL,
                 "per_fc_bn_bwd: null pointer");
-    hipLaunchKernelGGL(per_fc_bn_bwd_kernel, dim3(ceil_div(U, 256)), dim3(256), 0, as_stream(stream), G, P, U, NCp,
+    hipLaunchKernelGGL(per_fc_bn_bwd_kernel, dim3(ceil_div(U, PFB_CH)), dim3(256), 0, as_stream(stream), G, P, U, NCp,
                        (float)rows_per_group, W, b, gamma, mean, rstd, Q, gram, dW, db, dgamma, dbeta);
     D2P_LAUNCH_CHECK("per_fc_bn_bwd");
     return D2P_OK;

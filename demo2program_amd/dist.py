@@ -142,6 +142,17 @@ class DataParallel(object):
             import torch.distributed as dist
             dist.barrier()
 
+    def ranks_seen(self):
+        """Number of ranks that answer a SUM all-reduce of ones on the job's process group (RCCL on GPUs);
+        None when no collective is issued (one rank, no group)."""
+        if not self.active:
+            return None
+        import torch.distributed as dist
+        dev = 'cuda' if torch.cuda.is_available() and dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return int(round(float(t.item())))
+
     def max_over_ranks(self, value):
         """max of a python float across ranks (bench timing)."""
         if self.world_size <= 1 and not self.initialized:

@@ -21,6 +21,7 @@ import time
 import numpy as np
 import torch
 
+from . import kernels as K
 from .config import config_from_dataset, dataset_module, has_dataset, input_ops_module, make_config
 
 
@@ -102,6 +103,18 @@ class Evaler(object):
         feed = m.get_feed_dict(batch_chunk, is_training=False)
         m.forward(feed)
         loss, acc = m.report(with_greedy=True)
+        # report() has synchronised.  A persistent recurrent launch that gave up a hand-off (shared device, a
+        # workgroup not resident) leaves a STICKY status word and invalid results -- for this batch and every later
+        # one until it is reset: switch to the per-step kernels for the rest of the evaluation and redo the batch
+        err = K.lstm_persist_error(reset=True)
+        if err:
+            import sys
+            print('[demo2program_amd] persistent LSTM kernel gave up a hand-off (status 0x%08x): evaluating on the '
+                  'per-step kernels from here on, batch redone' % (err & 0xffffffff), file=sys.stderr)
+            K.lstm_set_persistent(False)
+            self.persist_fallbacks = getattr(self, 'persist_fallbacks', 0) + 1
+            m.forward(feed)
+            loss, acc = m.report(with_greedy=True)
         hist = dict(m.report_hist)
         have_rows = bool(getattr(m, '_program_rows', None))
         have_exec = have_rows and 'program_num_execution_correct' in m._program_rows   # needs an environment

@@ -283,9 +283,25 @@ def set_lstm_fused(on):
     call.d2p_lstm_set_fused(1 if on else 0)
 
 
+_LSTM_PERSISTENT = [True]
+
+
 def set_lstm_persistent(on):
     """Process-global knob: one persistent launch per sequence (default) vs one fused launch per step."""
     call.d2p_lstm_set_persistent(1 if on else 0)
+    _LSTM_PERSISTENT[0] = bool(on)
+
+
+lstm_set_persistent = set_lstm_persistent
+
+
+def lstm_is_persistent():
+    return _LSTM_PERSISTENT[0]
+
+
+def lstm_persist_inject_error():
+    """Test hook: sets the persistent kernels' status word as a timed-out hand-off would."""
+    call.d2p_lstm_persist_inject_error()
 
 
 def lstm_persist_error(reset=True):
@@ -527,6 +543,21 @@ def l2norm_flat(g, prescale, sumsq):
     call.d2p_l2norm_flat(g.numel(), ptr(g), prescale, ptr(sumsq), ws, wsb, current_stream())
 
 
-def adam_clip_flat(p, g, m, v, sumsq, prescale, clip, lr_t, b1=0.9, b2=0.999, eps=1e-8, lr_t_dev=None):
-    call.d2p_adam_clip_flat(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(sumsq), prescale, clip,
-                            lr_t, ptr(lr_t_dev), b1, b2, eps, current_stream())
+def adam_clip_flat(p, g, m, v, sumsq, prescale, clip, lr_t, b1=0.9, b2=0.999, eps=1e-8, lr_t_dev=None,
+                   counters=None, fail_slot=None, mirror=None):
+    """counters (int64[2], device): the guarded form -- the update is skipped while the persistent recurrent
+    kernels' status word is set (or fail_slot[0] != 0); counters[0] / [1] count applied / skipped steps; mirror
+    (int64[2], PINNED host memory): receives both after this step."""
+    if counters is None:
+        call.d2p_adam_clip_flat(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(sumsq), prescale, clip,
+                                lr_t, ptr(lr_t_dev), b1, b2, eps, current_stream())
+    else:
+        assert counters.dtype == torch.int64 and counters.numel() >= 2
+        call.d2p_adam_clip_flat_guarded(p.numel(), ptr(p), ptr(g), ptr(m), ptr(v), ptr(sumsq), prescale, clip,
+                                        lr_t, ptr(lr_t_dev), b1, b2, eps, ptr(fail_slot), ptr(counters),
+                                        ptr(mirror), current_stream())
+
+
+def step_status_publish(slot):
+    """slot[0] = 1.0 if the persistent recurrent kernels' status word is set, else 0.0 (stream-async)."""
+    call.d2p_step_status_publish(ptr(slot), current_stream())

@@ -57,6 +57,7 @@ SIGNATURES = {
     'd2p_lstm_set_fused': (c_int, [c_int]),
     'd2p_lstm_set_persistent': (c_int, [c_int]),
     'd2p_lstm_persist_error': (c_int, [c_int]),
+    'd2p_lstm_persist_inject_error': (c_int, []),
     'd2p_lstm_persist_set_trace': (c_int, [P, c_size_t, c_int]),
     'd2p_lstm_persist_set_wgs_per_cu': (c_int, [c_int, c_int]),
     'd2p_lstm_persist_pair_launches': (c_int, []),
@@ -98,6 +99,9 @@ SIGNATURES = {
     'd2p_prof_set_tag': (c_int, [c_int]),
     'd2p_prof_read': (c_int, [c_int, P, P, P]),
     'd2p_adam_clip_flat': (c_int, [c_size_t, P, P, P, P, P, c_float, c_float, c_float, P, c_float, c_float, c_float, S]),
+    'd2p_step_status_publish': (c_int, [P, S]),
+    'd2p_adam_clip_flat_guarded': (c_int, [c_size_t, P, P, P, P, P, c_float, c_float, c_float, P, c_float, c_float, c_float,
+                                           P, P, P, S]),
 }
 
 

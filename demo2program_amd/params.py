@@ -109,7 +109,12 @@ class FlatParams(object):
             off += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         self.size = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=device)
-        self.grad = torch.zeros(off, dtype=torch.float32, device=device)
+        # the gradient buffer carries ONE spare 16-byte slot behind the parameters' gradients: the step-status word
+        # of the guarded optimizer step travels through the data-parallel all-reduce in it (`grad_all` is what the
+        # exchange step reduces; `grad` -- the norm, the clip, Adam -- never sees the slot)
+        self.grad_all = torch.zeros(off + self.ALIGN, dtype=torch.float32, device=device)
+        self.grad = self.grad_all[:off]
+        self.status_slot = self.grad_all[off:]
         self.m = torch.zeros(off, dtype=torch.float32, device=device)
         self.v = torch.zeros(off, dtype=torch.float32, device=device)
         self.p = OrderedDict()

@@ -101,6 +101,72 @@ class FeedPrefetcher(object):
         pass
 
 
+class StepGuard(object):
+    """Host side of the guarded optimizer step (include/d2p.h: d2p_adam_clip_flat_guarded).
+
+    The persistent recurrent kernels never hang: a hand-off that does not arrive within a bounded wait (a
+    workgroup that was not resident -- a shared device, a collective's kernels holding CUs) sets a sticky device
+    word and the launch runs to completion with invalid results.  The clip + Adam kernel reads that word ON THE
+    DEVICE and skips its update while it is set, counting applied / skipped steps in `counters`; nothing has to
+    synchronise for the parameters to stay intact.  The kernel also writes both counters into a slot of a pinned
+    host ring (one slot per step in flight, no copy operation on the stream) and the feed is remembered; `poll`
+    looks at the slots whose step has finished (an event recorded behind the kernel).  When one shows a skipped step the trainer synchronises, resets the word, switches
+    the recurrences to the per-step kernels and re-runs exactly the skipped steps (they are the LAST ones: the
+    word is sticky) -- see Trainer._recover.
+
+    The ring is DEPTH steps deep: before a slot is reused the host waits for its copy, i.e. it runs at most DEPTH
+    steps ahead of the device (the device never idles for that: DEPTH - 1 steps are still queued).  With several
+    ranks only that oldest copy is consulted, so that every rank detects a failure at the same step index (the
+    skip decision itself is identical on all ranks: it travels through the gradient all-reduce)."""
+    DEPTH = 4
+
+    def __init__(self):
+        self.counters = torch.zeros(2, dtype=torch.int64, device='cuda')      # applied, skipped
+        self.host = torch.zeros(self.DEPTH, 2, dtype=torch.int64).pin_memory()
+        self.events = [None] * self.DEPTH
+        self.records = [None] * self.DEPTH        # (feed, global_step, adam_step) of the step in that slot
+        self.n = 0                                # guarded steps launched
+        self.handled = 0                          # skipped steps already re-run
+        self.failures = 0
+        self.waited = 0.0                         # seconds the host spent waiting for a ring slot (it was DEPTH steps ahead)
+
+    def mirror(self):
+        """The pinned slot the NEXT guarded step writes its counters into."""
+        return self.host[self.n % self.DEPTH]
+
+    def launched(self, record):
+        slot = self.n % self.DEPTH
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
+        self.records[slot] = record
+        self.n += 1
+
+    def poll(self, deterministic, wait_all=False):
+        """True when a copy that has arrived shows skipped steps that were not re-run yet.  Waits for the copy of
+        the slot the next step will reuse; `deterministic` (several ranks): looks at nothing else."""
+        slot = self.n % self.DEPTH
+        worst = 0
+        for i, ev in enumerate(self.events):
+            if ev is None:
+                continue
+            if i == slot or wait_all:
+                if not ev.query():
+                    t0 = time.perf_counter()
+                    ev.synchronize()
+                    self.waited += time.perf_counter() - t0
+            elif deterministic or not ev.query():
+                continue
+            worst = max(worst, int(self.host[i, 1]))
+        return worst > self.handled
+
+    def last(self, k):
+        return [self.records[(self.n - k + i) % self.DEPTH] for i in range(k)]
+
+    def forget(self):
+        self.events = [None] * self.DEPTH
+
+
 class Trainer(object):
 
     @staticmethod
@@ -161,6 +227,9 @@ class Trainer(object):
         self.write_summary_step = config.write_summary_step
         self._sumsq = torch.zeros(1, dtype=torch.float64, device='cuda')
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device='cuda')
+        # guarded optimizer step (StepGuard); D2P_STEP_GUARD=0 restores the unguarded kernel + check_device_status
+        self.guard = StepGuard() if os.environ.get('D2P_STEP_GUARD', '1') == '1' else None
+        self._recovering = False
 
         if config.checkpoint is not None:
             self.load_checkpoint(config.checkpoint)
@@ -192,6 +261,9 @@ class Trainer(object):
         graph launch.  The all-reduce, norm and Adam stay outside the graph (RCCL call; the
         Adam rate changes per step and is read from device memory)."""
         m = self.model
+        g = self.guard
+        if g is not None and not self._recovering and g.poll(self.dp.active):
+            self._recover()
         if m.scheduled_sampling:
             m.set_sampling_step(self.global_step)     # sampling probability + noise counter of this step
         P = m.params
@@ -199,16 +271,34 @@ class Trainer(object):
         # the rest of backward runs; one message for everything when that is switched off
         overlap = self.dp.active and self.dp_overlap and not (m.use_side_stream and self.use_graph)
         dec = m.decoder_grad_offset() if overlap else 0
-        start = (lambda: self.dp.all_reduce_start(P.grad[dec:])) if overlap else None
+        start = None
+        persist_was = K.lstm_is_persistent()
+        if overlap:
+            def start():
+                self.dp.all_reduce_start(P.grad[dec:])
+                # EXPERIMENTAL (never run on more than one GPU): the encoder recurrences that follow run beside the
+                # collective's kernels; the persistent kernels need every workgroup resident at once, which a
+                # collective waiting for a late peer can prevent -- per-step launches need no co-residency
+                K.lstm_set_persistent(False)
         if self.use_graph and not self._profiling():
             loss = self._graphed_forward_backward(feed, start)
         else:
             loss = m.forward(feed)
             m.backward(split_cb=start)
+        if overlap and persist_was:
+            K.lstm_set_persistent(True)
+        slot = None
+        if g is not None and self.dp.active:
+            # this rank's status word joins the exchange: after the SUM every rank skips the step together
+            slot = P.status_slot
+            K.step_status_publish(slot)
         if overlap:
             self.dp.all_reduce_finish(P.grad[:dec])
+            if slot is not None:
+                self.dp.all_reduce_grads(slot)
         else:
-            self.dp.all_reduce_grads(P.grad)        # SUM over ranks; mean folded into prescale
+            # SUM over ranks; mean folded into prescale (grad_all = grad + the status slot behind it)
+            self.dp.all_reduce_grads(P.grad_all if slot is not None else P.grad)
         pre = self.dp.prescale
         K.l2norm_flat(P.grad, pre, self._sumsq)
         # bias correction from the number of steps the MOMENTS have seen, not from global_step: the
@@ -217,11 +307,66 @@ class Trainer(object):
         t = self.adam_step + 1
         lr = learning_rate_at(self.config, self.global_step)
         lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
-        K.adam_clip_flat(P.flat, P.grad, P.m, P.v, self._sumsq, pre, CLIP_GRADIENTS, lr_t,
-                         ADAM_B1, ADAM_B2, ADAM_EPS)
+        if g is None:
+            K.adam_clip_flat(P.flat, P.grad, P.m, P.v, self._sumsq, pre, CLIP_GRADIENTS, lr_t,
+                             ADAM_B1, ADAM_B2, ADAM_EPS)
+        else:
+            K.adam_clip_flat(P.flat, P.grad, P.m, P.v, self._sumsq, pre, CLIP_GRADIENTS, lr_t,
+                             ADAM_B1, ADAM_B2, ADAM_EPS, counters=g.counters, fail_slot=slot, mirror=g.mirror())
+            g.launched((feed, self.global_step, self.adam_step))
         self.adam_step = t
         self.global_step += 1
         return loss
+
+    MAX_PERSIST_FAILURES = 2      # after that many the run stays on the per-step recurrent kernels
+
+    def _recover(self):
+        """A guarded step was skipped on the device: the persistent recurrent kernels gave up a hand-off.  The
+        parameters, the Adam moments and the batch-norm moving statistics downstream of the recurrences are as
+        they were before the first skipped step (the device skipped every step since: the word is sticky).
+        Synchronise, reset the word, re-run the skipped steps on the per-step kernels (lstm_step.hip)."""
+        import sys
+        g = self.guard
+        torch.cuda.synchronize()
+        applied, skipped = (int(v) for v in g.counters.tolist())
+        k = skipped - g.handled
+        err = K.lstm_persist_error(reset=True)
+        g.handled = skipped
+        g.forget()
+        if k <= 0:
+            return None
+        g.failures += 1
+        records = g.last(min(k, g.DEPTH))
+        print('[demo2program_amd] persistent LSTM kernel gave up a hand-off (status 0x%08x): %d step(s) skipped on the '
+              'device, re-running them on the per-step kernels%s' %
+              (err & 0xffffffff, k, '' if g.failures < self.MAX_PERSIST_FAILURES else
+               '; staying on the per-step kernels for the rest of the run'), file=sys.stderr)
+        if k > g.DEPTH:          # cannot happen while poll() runs before every step; refuse to guess
+            raise RuntimeError('%d skipped steps but only %d feeds kept' % (k, g.DEPTH))
+        K.lstm_set_persistent(False)
+        self._graphs.clear()     # captured graphs hold the persistent launches
+        self.global_step, self.adam_step = records[0][1], records[0][2]
+        self._recovering = True
+        loss = None
+        try:
+            for feed, _, _ in records:
+                loss = self.train_step(feed)
+            torch.cuda.synchronize()
+        finally:
+            self._recovering = False
+        if g.failures < self.MAX_PERSIST_FAILURES:
+            K.lstm_set_persistent(True)
+            self._graphs.clear()
+        g.handled = int(g.counters[1].item())       # (nothing is skipped on the per-step kernels)
+        return loss
+
+    def settle(self):
+        """Synchronising: waits for every launched step and re-runs skipped ones.  Returns the number of
+        hand-off failures recovered so far."""
+        g = self.guard
+        if g is not None and not self._recovering and g.poll(self.dp.active, wait_all=True):
+            self._recover()
+        return 0 if g is None else g.failures
 
     @staticmethod
     def _profiling():
@@ -316,6 +461,12 @@ class Trainer(object):
             feed = self.model.get_feed_dict(batch_chunk, step=step, is_training=is_train)
             loss = self.train_step(feed)
         loss_value = float(loss.item())             # the reference fetches the loss every step
+        if self.guard is not None and not self.dp.active and self.guard.poll(False, wait_all=True):
+            # this step was skipped on the device (single rank: detected right here; several ranks detect it
+            # together StepGuard.DEPTH steps later): re-run it, report the re-run's loss
+            redo = self._recover()
+            if redo is not None:
+                loss_value = float(redo.item())
         _end_time = time.time()
         return self.global_step, None, loss_value, None, (_end_time - _start_time)
 
@@ -343,18 +494,23 @@ class Trainer(object):
                 self.run_single_step(source, step=s, is_train=True)
             if s % self.log_step == 0:
                 self.log_step_message(step, loss, step_time)
-                self.check_device_status()
             if s % self.test_sample_step == 0:
                 test_step, _, test_loss, _, test_step_time = self.run_test(self.batch_test)
                 self.log_step_message(step, test_loss, test_step_time, is_train=False)
-            if s % ckpt_save_step == 0 and self.dp.rank == 0:
-                self.save_checkpoint(os.path.join(self.train_dir, 'model-%d.npz' % step))
+            if s % ckpt_save_step == 0:
+                # every rank settles (re-runs steps the device skipped) before rank 0 writes the parameters
+                self.check_device_status()
+                if self.dp.rank == 0:
+                    self.save_checkpoint(os.path.join(self.train_dir, 'model-%d.npz' % step))
 
-    @staticmethod
-    def check_device_status():
+    def check_device_status(self):
         """The persistent LSTM kernels give up a hand-off after a bounded wait instead of hanging (a
         workgroup that was not resident, e.g. a shared device) and record it; their results are then
-        invalid.  Synchronising: called at the logging cadence, not per step."""
+        invalid.  Synchronising.  With the step guard (default) skipped steps are re-run here and nothing is
+        raised; without it (D2P_STEP_GUARD=0) a set status word raises."""
+        if self.guard is not None:
+            self.settle()
+            return
         err = K.lstm_persist_error(reset=True)
         if err:
             raise RuntimeError('persistent LSTM kernel gave up a hand-off (status 0x%08x): the device was shared or '

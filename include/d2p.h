@@ -231,6 +231,8 @@ int d2p_lstm_set_persistent(int on);
  * workgroup was not resident, e.g. the device was shared) and the results of that launch are
  * invalid: (code << 24) | 0x800000 | block.  reset != 0 clears the word. */
 int d2p_lstm_persist_error(int reset);
+/* Test hook (synchronising): sets the status word as a timed-out hand-off would (code 0x7f). */
+int d2p_lstm_persist_inject_error(void);
 /* Debugging (tools/trace_lstm_persist.py): workgroup `block` of every following persistent launch
  * writes shader-clock stamps of each phase into buf (device memory, >= 2*512*8 uint64; NULL = off):
  * [role][tick][8] with role 0 = MFMA wave 0 {start, first half issued, flags seen, partials written,
@@ -427,6 +429,25 @@ int d2p_adam_clip_flat(size_t n, float* p, const float* g, float* m, float* v,
                        const double* sumsq, float prescale, float clip, float lr_t,
                        const float* lr_t_dev, float beta1, float beta2, float eps,
                        d2p_stream_t stream);
+/* The guarded optimizer step (no reference counterpart: TF's session either runs a step or raises).
+ * The persistent recurrent kernels report a hand-off they gave up in a device status word
+ * (d2p_lstm_persist_error); the gradients of that step are then invalid.  The guarded form reads the
+ * word ON THE DEVICE and SKIPS the update -- parameters and both moments untouched -- while it is set,
+ * or while fail_slot[0] != 0 (NULL: not consulted).  fail_slot is one float the caller appends to the
+ * buffer it all-reduces: d2p_step_status_publish writes 1.0 / 0.0 into it after backward, so after the
+ * SUM every rank of a data-parallel job takes the same decision.  counters (device, two uint64,
+ * caller-zeroed): [0] += 1 per applied step, [1] += 1 per skipped step; mirror (optional, two uint64 of
+ * pinned HOST memory the device can write): receives both values after this step -- the host reads them
+ * there once an event recorded behind this call has completed, resets the word, switches the recurrences
+ * to the per-step kernels
+ * (d2p_lstm_set_persistent(0)) and re-runs the skipped steps (demo2program_amd/trainer.py).
+ * The batch-norm moving statistics are likewise left alone while the word is set. */
+int d2p_step_status_publish(float* slot, d2p_stream_t stream);
+int d2p_adam_clip_flat_guarded(size_t n, float* p, const float* g, float* m, float* v,
+                               const double* sumsq, float prescale, float clip, float lr_t,
+                               const float* lr_t_dev, float beta1, float beta2, float eps,
+                               const float* fail_slot, unsigned long long* counters,
+                               unsigned long long* mirror, d2p_stream_t stream);
 
 /* ---- optional per-launch HIP-event timing (used by bench.py's roofline leg) -------------
  * When enabled, every GEMM / conv / LSTM-gate launch is bracketed by hipEvents recorded on

@@ -112,3 +112,33 @@ def test_product_never_imports_the_oracle():
             if f.endswith('.py'):
                 src = open(os.path.join(d, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_bench_without_a_launcher_starts_the_ranks_itself(monkeypatch):
+    """`python bench.py --gpus 8` (no torch.distributed.run around it, no WORLD_SIZE) must not die: it re-launches
+    itself under torch.distributed.run with N ranks on 127.0.0.1 and passes its flags through."""
+    import argparse
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    from demo2program_amd import build
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(subprocess, 'call', fake_call)
+    monkeypatch.setattr(build, 'build_library', lambda *a, **k: None)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '8', '--steps', '20', '--warmup', '5'])
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.self_spawn(argparse.Namespace(gpus=8))
+    assert e.value.code == 7                                  # the launcher's status is the bench's
+    cmd = seen['cmd']
+    assert cmd[1:4] == ['-m', 'torch.distributed.run', '--nnodes=1']
+    assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert cmd[-6:] == ['--gpus', '8', '--steps', '20', '--warmup', '5'] and cmd[-7].endswith('bench.py')
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and 'D2P_FORCE_DIST' not in seen['env']

@@ -1024,3 +1024,143 @@ def test_perception_decoder_factored_input_equals_row_wise_form(kind, over, monk
             continue
         scale = g0[n].abs().max().item() + 1e-12
         assert (g1[n] - g0[n]).abs().max().item() <= 1e-4 * scale, n
+
+
+@pytest.mark.gpu
+def test_greedy_exact_match_on_1k_generated_programs():
+    """north_star: "decoded program-token exact-match equal to the reference on a fixed 1k-example shard".
+    32 batches x 32 generated Karel programs at BASELINE config 2's full size (k = 10, U = 512), weights after
+    300 optimizer steps: the HIP greedy decoder against the fp64 oracle's (GreedyEmbeddingHelper semantics,
+    models/model_full.py:424-435,513-523; evaler.py:444-449 scores these tokens).  Every row must be token- and
+    length-exact unless the ORACLE's top-2 logit gap at the first differing step is below 1e-4 (an fp32 / fp64
+    argmax tie; such rows are listed).  "Reference" = the CPU oracle: TF-1.3 cannot run here."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import exact_match_1k
+    res = exact_match_1k.run(n_batches=32, train_steps=300, verbose=False)
+    assert res['programs'] == 1024
+    assert res['persistent_lstm_status'] == 0
+    assert res['unexcused_mismatches'] == 0, res['mismatches']
+    assert res['token_exact_rows'] + res['mismatches_excused_as_fp_ties'] == 1024
+    assert res['token_exact_rows'] >= 1014                 # ties are rare: more than 1 % of them is a bug
+    assert res['max_abs_logit_err_on_exact_rows'] <= 1e-4
+    assert res['rows_that_emit_the_end_token'] > 512       # the trained decoder ends its programs: a non-trivial argmax
+    assert res['action_token_exact_sequences'] >= res['action_sequences'] - 10
+
+
+@pytest.mark.gpu
+def test_step_guard_skips_and_reruns_a_failed_step(monkeypatch):
+    """The guarded optimizer step: with the persistent kernels' status word set (injected, as a timed-out hand-off
+    sets it) the clip + Adam kernel skips its update ON THE DEVICE -- parameters, moments and the batch-norm moving
+    statistics stay as they were -- and the trainer then resets the word, re-runs exactly the skipped steps on
+    the per-step kernels and ends where an undisturbed run ends."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.trainer import Trainer
+    cfg, params, batch = small_case('karel', seed=41)
+    batches = [batch, small_case('karel', seed=42)[2], small_case('karel', seed=43)[2]]
+
+    def fresh():
+        tr = Trainer(cfg, make_train_dir=False)
+        tr.model.params.load(params)
+        return tr, [tr.model.get_feed_dict(b) for b in batches]
+
+    # undisturbed: 6 steps
+    tr, feeds = fresh()
+    for i in range(6):
+        tr.train_step(feeds[i % 3])
+    assert tr.settle() == 0
+    want = tr.model.params.flat.clone()
+    want_m = tr.model.params.m.clone()
+    want_mov = {n: (a.clone(), b.clone()) for n, (a, b) in tr.model.moving.items()}
+    # disturbed: the word is set before step 2; the device skips steps 2.. until the host notices
+    tr, feeds = fresh()
+    for i in range(2):
+        tr.train_step(feeds[i % 3])
+    torch.cuda.synchronize()
+    before = tr.model.params.flat.clone()
+    mov_before = {n: (a.clone(), b.clone()) for n, (a, b) in tr.model.moving.items()}
+    K.lstm_persist_inject_error()
+    tr.train_step(feeds[2])
+    torch.cuda.synchronize()
+    assert torch.equal(tr.model.params.flat, before)                     # skipped on the device
+    assert tr.guard.counters.tolist() == [2, 1]
+    for n in ('rn_h/fc1', 'rn_c/fc2'):                                    # downstream of the recurrences: untouched
+        assert torch.equal(tr.model.moving[n][0], mov_before[n][0]) and torch.equal(tr.model.moving[n][1], mov_before[n][1])
+    tr.train_step(feeds[0])          # detects (single rank: any arrived copy), re-runs step 2, then runs step 3
+    for i in (4, 5):
+        tr.train_step(feeds[i % 3])
+    assert tr.settle() == 1
+    assert K.lstm_is_persistent()                                         # one failure: persistent kernels back on
+    assert tr.global_step == 6 and tr.adam_step == 6
+    assert K.lstm_persist_error(reset=True) == 0
+    # the re-run used the per-step kernels (forward bit-identical, backward equal to fp32 round-off)
+    assert (tr.model.params.flat - want).abs().max().item() <= 2e-5 * want.abs().max().item()
+    assert (tr.model.params.m - want_m).abs().max().item() <= 1e-4 * want_m.abs().max().item() + 1e-9
+    # the recurrence-dependent moving statistics saw each batch once; the conv layers' saw the failed batch twice
+    for n in ('rn_h/fc1', 'rn_c/fc2'):
+        assert (tr.model.moving[n][0] - want_mov[n][0]).abs().max().item() <= 1e-5
+    # run_single_step: detected in the same call, and the loss it reports is the re-run's
+    class Src(object):
+        def next(self):
+            return batches[0]
+    tr3, _ = fresh()
+    clean_loss = tr3.run_single_step(Src())[2]
+    tr4, _ = fresh()
+    K.lstm_persist_inject_error()
+    hurt_loss = tr4.run_single_step(Src())[2]
+    assert tr4.guard.failures == 1 and tr4.global_step == 1
+    assert abs(hurt_loss - clean_loss) <= 1e-6 * abs(clean_loss)
+    assert (tr4.model.params.flat - tr3.model.params.flat).abs().max().item() <= 2e-5
+    K.lstm_set_persistent(True)
+
+
+@pytest.mark.gpu
+def test_evaler_redoes_a_batch_on_the_per_step_kernels(tmp_path):
+    """A persistent launch that gave up a hand-off during evaluation: the batch is redone on the per-step kernels
+    and the reported numbers equal an undisturbed evaluation (the sticky word used to corrupt every
+    later batch silently)."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.evaler import Evaler, GeneratedKarelBatches
+    cfg, params, _ = small_case('karel', seed=47)
+    cfg.checkpoint, cfg.train_dir, cfg.output_dir = '', '', str(tmp_path)
+    cfg.max_steps, cfg.pred_program, cfg.quiet, cfg.write_summary = 3, False, True, False
+    cfg.dataset_split, cfg.no_loss = 'test', False
+
+    def run(inject):
+        ev = Evaler(cfg, GeneratedKarelBatches(cfg, seed=5))
+        ev.model.params.load(params)
+        if inject:
+            K.lstm_persist_inject_error()
+        ev.eval_run()
+        return ev
+    try:
+        clean = run(False)
+        hurt = run(True)
+        assert getattr(hurt, 'persist_fallbacks', 0) == 1
+        assert K.lstm_persist_error(reset=True) == 0
+        for kk, v in clean.final['loss'].items():
+            assert abs(hurt.final['loss'][kk] - v) <= 1e-6 * max(1.0, abs(v))
+        assert hurt.final['acc'] == clean.final['acc']
+    finally:
+        K.lstm_set_persistent(True)
+        K.lstm_persist_error(reset=True)
+
+
+@pytest.mark.gpu
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus N` without torch.distributed.run must start the N ranks itself (the driver's
+    multi-GPU command may have either shape).  N = 1 through that path: a one-rank RCCL group, one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--self-spawn', '--steps', '4',
+                          '--warmup', '2', '--no-cpu-baseline', '--no-roofline', '--no-h2d', '--no-config4'],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 1 and d['steps'] == 4 and d['value'] > 0
+    assert d['rccl_ranks_seen'] == 1 and d['launcher'] == 'self-spawned'
