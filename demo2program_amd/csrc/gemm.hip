@@ -117,6 +117,24 @@ extern "C" int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, co
     return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_tn");
 }
 
+// C = A^T B over a LIST of K rows: C[m, n] (+)= sum_x A[rowsA[x], m] * B[rowsB[x], n], x < K (A and B row-major,
+// M resp. N contiguous).  Weight gradients X^T dZ of a padded time-major batch run over the rows inside their
+// sequences only (the others are zeros in dZ); rowsA != rowsB serves dWh = sum_t h[t-1]^T dz[t] (rowsA = rowsB - M).
+// Fast path (16-byte loads, no select in the K loop) when K is a multiple of 32: callers pad the lists with the
+// index of a row that is zero in B and finite in A.
+extern "C" int d2p_gemm_f32_tn_rows(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B,
+                                    long ldb, const int* rowsB, float* C, long ldc, int accumulate, void* ws,
+                                    size_t ws_bytes, d2p_stream_t stream) {
+    int rc = check_gemm_args(M, N, K, A, B, C, 0);
+    if (rc) return rc;
+    if (M == 0 || N == 0) return D2P_OK;
+    D2P_REQUIRE(K == 0 || (rowsA && rowsB), D2P_EINVAL, "gemm_tn_rows: null row list");
+    GatherXC al{A, lda, M, vec_ok(A, lda), rowsA};
+    GatherXC bl{B, ldb, N, vec_ok(B, ldb), rowsB};
+    EpiDense ep{C, ldc, nullptr, 0, accumulate};
+    return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_tn_rows");
+}
+
 // ---- column sum (bias gradients): two-stage, deterministic --------------------------
 // stage 1: block (cb, s) sums rows r = s*4+rl, step S*4, of 64 columns -> part[s][c];
 // stage 2: block per 16 columns x 16 lanes over the S partials, fixed-order tree.

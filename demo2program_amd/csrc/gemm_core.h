@@ -141,6 +141,46 @@ struct DenseXC {  // elem(x,k) = p[k*ld + x]
     }
 };
 
+// K through an index list: elem(x,k) = p[idx[k]*ld + x].  For 'tn' products (C = A^T B: weight gradients
+// X^T dZ) over the ACTIVE rows of a padded time-major batch only: both operands are read through the SAME list of
+// K row indices; the rows it leaves out are zeros in dZ and would add nothing (30 % of the demonstration rows, 45 %
+// of the program rows in the bench's batches).  The list is padded by the caller to whole K slabs with the index
+// of any such zero row.
+struct GatherXC {
+    static constexpr bool KCONTIG = false;
+    const float* p;
+    long ld;
+    int X;
+    int vec;
+    const int* idx;
+    __device__ __forceinline__ void shift(int) {}
+    bool fast_ok(int K) const { return vec && X >= 4 && (X % 4) == 0 && K > 0; }
+    template <bool FAST>
+    __device__ __forceinline__ bool load4(int x, int k, int klim, float (&v)[4]) const {
+        if (FAST) {
+            const bool ok = (x < X) & (k < klim);
+            const float4 t = *reinterpret_cast<const float4*>(p + (ok ? (long)idx[k] * ld + x : 0L));
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            return ok;
+        }
+        if (k >= klim) {
+            v[0] = v[1] = v[2] = v[3] = 0.f;
+            return true;
+        }
+        const float* q = p + (long)idx[k] * ld + x;
+        if (vec && x + 3 < X) {
+            float4 t = *reinterpret_cast<const float4*>(q);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (x + j < X) ? q[j] : 0.f;
+        }
+        return true;
+    }
+};
+template <class L> struct d2p_kgather { static constexpr bool value = false; };
+template <> struct d2p_kgather<GatherXC> { static constexpr bool value = true; };
+
 // Loaders whose out-of-range rows / columns may hold ANYTHING (they only feed output rows /
 // columns that are never stored) and whose only zeros are k >= klim: with K a multiple of the
 // slab depth such a loader needs no select at all between the global load and the LDS store.
@@ -148,6 +188,7 @@ template <class L> struct d2p_nosel_ok { static constexpr bool value = false; };
 template <> struct d2p_nosel_ok<DenseKC> { static constexpr bool value = true; };
 template <> struct d2p_nosel_ok<DenseXC> { static constexpr bool value = true; };
 template <> struct d2p_nosel_ok<GatherKC> { static constexpr bool value = true; };
+template <> struct d2p_nosel_ok<GatherXC> { static constexpr bool value = true; };
 // strided-batched launches (grid.y > 1) exist for dense operands with the dense epilogue only
 template <class EP> struct d2p_batch_ok { static constexpr bool value = false; };
 
@@ -272,6 +313,10 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     const float* pa[IA];
     const float* pb[IB];
     long astep = 0, bstep = 0;                                   // floats per K slab
+    // K-gathering loaders (GatherXC): this thread's k index in slab 0 and two sets of row indices -- the set of
+    // slab kt+1 is requested at the START of the loads of slab kt (before its data loads, so that waiting for it
+    // one call later does not wait for them); the two sets swap roles like the staging registers
+    int ka[IA], kb[IB], ja0[IA], jb0[IB], ja1[IA], jb1[IB];
     if constexpr (NOSEL) {
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
@@ -279,8 +324,11 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             pa[i] = al.p;
             if (CA % 256 == 0 || q < CA) {
                 if constexpr (AL::KCONTIG) pa[i] = al.row_ptr(min(m0 + q / (BK / 4), al.X - 1)) + kbeg + (q % (BK / 4)) * 4;
+                else if constexpr (d2p_kgather<AL>::value) pa[i] = al.p + min(m0 + (q % (BM / 4)) * 4, al.X - 4);
                 else pa[i] = al.p + (long)(kbeg + q / (BM / 4)) * al.ld + min(m0 + (q % (BM / 4)) * 4, al.X - 4);
             }
+            ka[i] = kbeg + ((CA % 256 == 0 || q < CA) ? q / (BM / 4) : 0);
+            if constexpr (d2p_kgather<AL>::value) ja0[i] = al.idx[ka[i]];
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
@@ -288,22 +336,37 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             pb[i] = bl.p;
             if (CB % 256 == 0 || q < CB) {
                 if constexpr (BL::KCONTIG) pb[i] = bl.row_ptr(min(n0 + q / (BK / 4), bl.X - 1)) + kbeg + (q % (BK / 4)) * 4;
+                else if constexpr (d2p_kgather<BL>::value) pb[i] = bl.p + min(n0 + (q % (BN / 4)) * 4, bl.X - 4);
                 else pb[i] = bl.p + (long)(kbeg + q / (BN / 4)) * bl.ld + min(n0 + (q % (BN / 4)) * 4, bl.X - 4);
             }
+            kb[i] = kbeg + ((CB % 256 == 0 || q < CB) ? q / (BN / 4) : 0);
+            if constexpr (d2p_kgather<BL>::value) jb0[i] = bl.idx[kb[i]];
         }
         astep = AL::KCONTIG ? (long)BK : (long)BK * al.ld;
         bstep = BL::KCONTIG ? (long)BK : (long)BK * bl.ld;
     }
 
-#define D2P_GLOAD(RA, RB, OA, OB, kt)                                                              \
+#define D2P_GLOAD(RA, RB, OA, OB, kt, JAC, JBC, JAN, JBN)                                          \
     if constexpr (NOSEL) {                                                                         \
         const long so_ = (long)min((int)(kt), nk - 1);          /* prefetches past the end re-read the last slab */ \
+        if constexpr (d2p_kgather<AL>::value) {                                                    \
+            const int sn_ = min((int)(kt) + 1, nk - 1) * BK;                                       \
+            _Pragma("unroll") for (int i = 0; i < IA; ++i) JAN[i] = al.idx[ka[i] + sn_];           \
+        }                                                                                          \
+        if constexpr (d2p_kgather<BL>::value) {                                                    \
+            const int sn_ = min((int)(kt) + 1, nk - 1) * BK;                                       \
+            _Pragma("unroll") for (int i = 0; i < IB; ++i) JBN[i] = bl.idx[kb[i] + sn_];           \
+        }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
-            const float4 t_ = *reinterpret_cast<const float4*>(pa[i] + so_ * astep);               \
+            const float* src_ = pa[i] + so_ * astep;                                               \
+            if constexpr (d2p_kgather<AL>::value) src_ = pa[i] + (long)JAC[i] * al.ld;             \
+            const float4 t_ = *reinterpret_cast<const float4*>(src_);                              \
             RA[i][0] = t_.x; RA[i][1] = t_.y; RA[i][2] = t_.z; RA[i][3] = t_.w; OA[i] = true;      \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < IB; ++i) {                                           \
-            const float4 t_ = *reinterpret_cast<const float4*>(pb[i] + so_ * bstep);               \
+            const float* src_ = pb[i] + so_ * bstep;                                               \
+            if constexpr (d2p_kgather<BL>::value) src_ = pb[i] + (long)JBC[i] * bl.ld;             \
+            const float4 t_ = *reinterpret_cast<const float4*>(src_);                              \
             RB[i][0] = t_.x; RB[i][1] = t_.y; RB[i][2] = t_.z; RB[i][3] = t_.w; OB[i] = true;      \
         }                                                                                          \
     } else {                                                                                       \
@@ -401,19 +464,19 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     // equal on small grids and 5-15 % slower on large ones: left to the scheduler.)
     // The general loaders (scalar tails, branches inside) keep the guarded form.
     if (nk > 0) {
-        D2P_GLOAD(ra0, rb0, oa0, ob0, 0)
+        D2P_GLOAD(ra0, rb0, oa0, ob0, 0, ja0, jb0, ja1, jb1)
         D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
-        D2P_GLOAD(ra1, rb1, oa1, ob1, 1)
+        D2P_GLOAD(ra1, rb1, oa1, ob1, 1, ja1, jb1, ja0, jb0)
         __syncthreads();
         if constexpr (FAST) {
             const int npairs = nk >> 1;
             for (int pr = 0; pr < npairs; ++pr) {
                 const int kt = 2 * pr;
-                D2P_GLOAD(ra0, rb0, oa0, ob0, kt + 2)  // in flight during compute(kt) and compute(kt+1)
+                D2P_GLOAD(ra0, rb0, oa0, ob0, kt + 2, ja0, jb0, ja1, jb1)  // in flight during compute(kt) and compute(kt+1)
                 compute(0);
                 D2P_SSTORE(ra1, rb1, oa1, ob1, 1)
                 __syncthreads();
-                D2P_GLOAD(ra1, rb1, oa1, ob1, kt + 3)
+                D2P_GLOAD(ra1, rb1, oa1, ob1, kt + 3, ja1, jb1, ja0, jb0)
                 compute(1);
                 D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
                 __syncthreads();
@@ -423,12 +486,12 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             // loads past the end of K return zeros (klim checks): prefetch unconditionally;
             // slabs nk and nk+1 are never stored
             for (int kt = 0; kt < nk; kt += 2) {
-                D2P_GLOAD(ra0, rb0, oa0, ob0, kt + 2)
+                D2P_GLOAD(ra0, rb0, oa0, ob0, kt + 2, ja0, jb0, ja1, jb1)
                 compute(0);
                 if (kt + 1 < nk) D2P_SSTORE(ra1, rb1, oa1, ob1, 1)
                 __syncthreads();
                 if (kt + 1 < nk) {
-                    D2P_GLOAD(ra1, rb1, oa1, ob1, kt + 3)
+                    D2P_GLOAD(ra1, rb1, oa1, ob1, kt + 3, ja1, jb1, ja0, jb0)
                     compute(1);
                     if (kt + 2 < nk) D2P_SSTORE(ra0, rb0, oa0, ob0, 0)
                     __syncthreads();

@@ -224,7 +224,7 @@ bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc) 
     for (int i = 0; i < 2; ++i)
         c[i] = PsBwdCall{d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh, d[i].c0,
                          d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final, d[i].dc_final, d[i].dz, d[i].dh0, d[i].dc0,
-                         (float*)d[i].ws};
+                         (float*)d[i].ws, d[i].db};
     *rc = d2p_lstm_persist_bwd_pair(c[0], c[1], st);
     return true;
 }
@@ -245,7 +245,7 @@ bool d2p_lstm_try_triple_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc
     for (int i = 0; i < 3; ++i)
         c[i] = PsBwdCall{d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh, d[i].c0,
                          d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final, d[i].dc_final, d[i].dz, d[i].dh0, d[i].dc0,
-                         (float*)d[i].ws};
+                         (float*)d[i].ws, d[i].db};
     *rc = d2p_lstm_persist_bwd_triple(c, st);
     return true;
 }
@@ -292,11 +292,51 @@ extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_
     return copy_or_zero(c_final, c_prev, MU, st);
 }
 
+static int seq_bwd_impl(int M, int U, int n_steps, const float* z, long z_row_stride,
+                        long z_t_stride, const float* Wh, const float* c0, const int* lens,
+                        const float* cs, const float* dhout, const float* dh_final,
+                        const float* dc_final, float* dz, float* dh0, float* dc0, void* ws,
+                        size_t ws_bytes, d2p_stream_t stream, float* db, bool* db_done);
+
 extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long z_row_stride,
                                 long z_t_stride, const float* Wh, const float* c0, const int* lens,
                                 const float* cs, const float* dhout, const float* dh_final,
                                 const float* dc_final, float* dz, float* dh0, float* dc0, void* ws,
                                 size_t ws_bytes, d2p_stream_t stream) {
+    bool done = false;
+    return seq_bwd_impl(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout, dh_final, dc_final, dz,
+                        dh0, dc0, ws, ws_bytes, stream, nullptr, &done);
+}
+
+// The bias gradient of a sequence whose back end did not produce it inside its launches (per-step kernels,
+// GEMM + gate path): db = column sums of dz over the n_steps*M rows.
+int d2p_lstm_db_colsum(const d2p_lstm_bwd_desc* q, d2p_stream_t stream) {
+    if (!q->db) return D2P_OK;
+    if (q->M <= 0 || q->n_steps <= 0) {
+        D2P_HIP(hipMemsetAsync(q->db, 0, (size_t)4 * q->U * sizeof(float), as_stream(stream)));
+        return D2P_OK;
+    }
+    D2P_REQUIRE(q->z_t_stride == (long)q->M * q->z_row_stride, D2P_EINVAL,
+                "lstm bwd: the bias gradient needs dz rows at one stride across steps");
+    const int rows = q->n_steps * q->M, cols = 4 * q->U;
+    D2P_REQUIRE(q->ws_bytes >= d2p_colsum_ws_bytes(rows, cols), D2P_EWS, "lstm bwd: workspace too small for the bias gradient");
+    return d2p_colsum_f32(rows, cols, q->dz, q->z_row_stride, q->db, q->ws, q->ws_bytes, stream);
+}
+
+int d2p_lstm_seq_bwd_desc(const d2p_lstm_bwd_desc* q, d2p_stream_t stream) {
+    bool done = false;
+    int rc = seq_bwd_impl(q->M, q->U, q->n_steps, q->z, q->z_row_stride, q->z_t_stride, q->Wh, q->c0, q->lens, q->cs,
+                          q->dhout, q->dh_final, q->dc_final, q->dz, q->dh0, q->dc0, q->ws, q->ws_bytes, stream, q->db,
+                          &done);
+    if (rc || done) return rc;
+    return d2p_lstm_db_colsum(q, stream);
+}
+
+static int seq_bwd_impl(int M, int U, int n_steps, const float* z, long z_row_stride,
+                        long z_t_stride, const float* Wh, const float* c0, const int* lens,
+                        const float* cs, const float* dhout, const float* dh_final,
+                        const float* dc_final, float* dz, float* dh0, float* dc0, void* ws,
+                        size_t ws_bytes, d2p_stream_t stream, float* db, bool* db_done) {
     D2P_REQUIRE(M >= 0 && U > 0 && n_steps >= 0, D2P_EINVAL, "lstm seq bwd: bad sizes");
     hipStream_t st = as_stream(stream);
     const size_t MU = (size_t)M * U;
@@ -305,9 +345,11 @@ extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long 
     D2P_REQUIRE(ws && ws_bytes >= unfused_ws_bytes(M, U), D2P_EWS,
                 "lstm seq bwd: workspace too small (%zu < %zu)", ws_bytes, d2p_lstm_ws_bytes(M, U));
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && (((uintptr_t)dz & 15) == 0) &&
-        d2p_lstm_persist_bwd_ok(M, U, n_steps) && ws_bytes >= d2p_lstm_persist_ws_bytes(M, U))
+        d2p_lstm_persist_bwd_ok(M, U, n_steps) && ws_bytes >= d2p_lstm_persist_ws_bytes(M, U)) {
+        *db_done = true;
         return d2p_lstm_persist_bwd(PsBwdCall{M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
-                                              dh_final, dc_final, dz, dh0, dc0, (float*)ws}, st);
+                                              dh_final, dc_final, dz, dh0, dc0, (float*)ws, db}, st);
+    }
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && (((uintptr_t)dz & 15) == 0))
         return d2p_lstm_fused_bwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
                                   dh_final, dc_final, dz, dh0, dc0, (float*)ws, st);

@@ -71,6 +71,7 @@ struct PsBwdCall {
     const float* dhout; const float* dh_final; const float* dc_final;
     float* dz; float* dh0; float* dc0;
     float* ws;
+    float* db;          // optional: bias gradient [4U] = column sums of dz, produced inside the launch
 };
 int d2p_lstm_persist_fwd(const PsFwdCall& q, hipStream_t st);
 int d2p_lstm_persist_bwd(const PsBwdCall& q, hipStream_t st);
@@ -87,3 +88,6 @@ int d2p_lstm_persist_bwd_triple(const PsBwdCall q[3], hipStream_t st);
 bool d2p_lstm_try_pair_fwd(const d2p_lstm_fwd_desc* d, hipStream_t st, int* rc);
 bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc);
 bool d2p_lstm_try_triple_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc);
+// one sequence by descriptor (d2p_lstm_seq_bwd + the optional bias gradient)
+int d2p_lstm_seq_bwd_desc(const d2p_lstm_bwd_desc* d, d2p_stream_t stream);
+int d2p_lstm_db_colsum(const d2p_lstm_bwd_desc* d, d2p_stream_t stream);

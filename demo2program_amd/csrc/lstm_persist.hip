@@ -638,6 +638,10 @@ struct PsBwdArgs {
     float* dump;
     unsigned* err;
     unsigned long long* trace; int trace_block;
+    // bias gradient db[4U] = column sums of dz over all rows and steps (optional): every workgroup sums its own
+    // 64 columns over its domain's rows, the last of a column tile's RT workgroups (a ticket) adds the RT partial
+    // sums in domain order -- no separate column-sum pass over the 52 MB of dz
+    float* db; float* dbpart; unsigned* dbtick;
 };
 
 template <int CB, int CPWB>
@@ -686,7 +690,7 @@ __device__ __forceinline__ void ps_bwd_epilogue_pre(const PsBwdArgs& a, const Ps
     pre.dcv = e.stdc[(p * 16 + e.rr) * 16 + e.un];
 }
 __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const PsBwdEpi& e, int rs0, int p, int j,
-                                                     const PsBwdEpiPre& pre) {
+                                                     const PsBwdEpiPre& pre, float (&dbacc)[4]) {
     const int U = a.U;
     const int t = a.T - 1 - j;
     const int row = (rs0 + p) * 16 + e.rr;
@@ -701,9 +705,11 @@ __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const P
     float g[4], dcn;
     lstm_cell_bwd_post(pre.q, dH, pre.dcv, g[0], g[1], g[2], g[3], dcn);
     e.stdc[sidx] = pre.cur_active ? dcn : pre.dcv;
+    const bool act = pre.cur_active && valid;     // (rows past M repeat row M-1's operands: not part of any sum)
 #pragma unroll
     for (int gg = 0; gg < 4; ++gg) {
-        g[gg] = pre.cur_active ? g[gg] : 0.f;
+        g[gg] = act ? g[gg] : 0.f;
+        dbacc[gg] += g[gg];
         // staged fragment-major per gate: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
         e.stage[gg * 256 + (((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = g[gg];
     }
@@ -726,7 +732,8 @@ __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const P
 template <int CPW, bool LA>
 __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwdEpi& e, const f32x4 (&bw)[4 * CPW],
                                                  __amdgpu_buffer_rsrc_t dres, const unsigned* fl, int nnt, int rs0,
-                                                 int nrs, int nticks, int lane_off, float* P, int wave, int lane) {
+                                                 int nrs, int nticks, int lane_off, float* P, int wave, int lane,
+                                                 float (&dbacc)[4]) {
     constexpr int CPWB = 4 * CPW;                // chunks per wave
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
@@ -797,7 +804,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         for (int r = 0; r < 4; ++r) Pw[((lane >> 4) * 4 + r) * PS_PLD + (lane & 15)] = acc0[r] + acc1[r];
         ps_barrier();          // A: the four partial tiles are in LDS
         tr.stamp(3);
-        ps_bwd_epilogue_post(a, e, rs0, k0.p, k0.t, pre);
+        ps_bwd_epilogue_post(a, e, rs0, k0.p, k0.t, pre, dbacc);
         ps_barrier();          // B: dz of the phase staged, P and the ring slot free again
         tr.stamp(4);
         if (wave == 0) tr.flush(0, n, lane);
@@ -856,8 +863,40 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             stdc[(p * 16 + e.rr) * 16 + e.un] = d;
             if (e.un == 0) stl[p * 16 + e.rr] = len;
         }
-        if (nrs >= 2) ps_bwd_mfma_wave<CPW, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane);
-        else ps_bwd_mfma_wave<CPW, false>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane);
+        float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nrs >= 2) ps_bwd_mfma_wave<CPW, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
+        else ps_bwd_mfma_wave<CPW, false>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
+        if (a.db) {
+            // this workgroup's 4 gates x 16 units: the four row lanes of a wave by two shuffles, the four waves
+            // through LDS in wave order (P is free: the last tick's barrier B is behind every wave)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                float v = dbacc[gg];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (lane < 16) P[(wave * 4 + gg) * 16 + lane] = v;
+            }
+            ps_barrier();
+            if (wave == 0) {
+                const int gg = lane >> 4, un = lane & 15;
+                const float v = ((P[(0 * 4 + gg) * 16 + un] + P[(1 * 4 + gg) * 16 + un]) + P[(2 * 4 + gg) * 16 + un]) +
+                                P[(3 * 4 + gg) * 16 + un];
+                const __amdgpu_buffer_rsrc_t pres = ps_rsrc(a.dbpart, (unsigned)(a.RT * nnt * 64 * sizeof(float)));
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), pres, ((rt * nnt + nt) * 64 + lane) * 4, 0,
+                                                      PS_AUX_SC1);
+                ps_wait_vmcnt<0>();                                    // the write-through store is out
+                unsigned ticket = 0;
+                if (lane == 0) ticket = __hip_atomic_fetch_add(a.dbtick + nt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
+                if (ticket == (unsigned)(a.RT - 1)) {                  // last of this column tile: fold, in domain order
+                    float sum = 0.f;
+                    for (int r = 0; r < a.RT; ++r)
+                        sum += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             pres, ((r * nnt + nt) * 64 + lane) * 4, 0, PS_AUX_SC1));
+                    a.db[(long)gg * U + nt * 16 + un] = sum;
+                }
+            }
+        }
         if (a.dc0)
             for (int qq = 0; qq < nrs; ++qq) {
                 const int row = (rs0 + qq) * 16 + e.rr;
@@ -924,6 +963,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             k.next(nrs);
         }
         ps_wait_vmcnt<0>();
+        if (a.db) ps_barrier();                      // the MFMA waves' bias-gradient exchange
     }
 }
 
@@ -974,12 +1014,15 @@ bool d2p_lstm_persist_bwd_ok(int M, int U, int n_steps) {
 }
 
 #define PS_FLAG_WORDS 4096   // >= RT * PS_NRS_MAX * ncol for any grid <= 512 workgroups
+#define PS_TICKET_WORDS 64   // bias-gradient tickets of the backward kernel, one per column tile (zeroed with the flags)
 #define PS_DUMP_FLOATS 64
+#define PS_DBPART_FLOATS (512 * 64)   // backward: one 64-float partial bias gradient per workgroup
 
 size_t d2p_lstm_persist_ws_bytes(int M, int U) {
     const size_t Mp = (size_t)((M + 15) / 16) * 16;
     // packed weight + 2 fragment buffers over K = 4U (backward; forward needs U) + flags
-    return ((size_t)4 * U * U + 2 * Mp * 4 * U) * sizeof(float) + PS_FLAG_WORDS * sizeof(unsigned) + PS_DUMP_FLOATS * sizeof(float);
+    return ((size_t)4 * U * U + 2 * Mp * 4 * U) * sizeof(float) + (PS_FLAG_WORDS + PS_TICKET_WORDS) * sizeof(unsigned) +
+           (PS_DUMP_FLOATS + PS_DBPART_FLOATS) * sizeof(float);
 }
 
 // Everything a persistent launch needs prepared, in ONE launch instead of three (weight pack, initial-state
@@ -1031,7 +1074,7 @@ static int ps_fwd_setup(const PsFwdCall& q, int RT, int bid0, PsFwdArgs& a, hipS
     a.hfrag = Wf + (size_t)4 * U * U;
     a.hfrag_bytes = (unsigned)(Mp * U * sizeof(float));
     a.flags = (unsigned*)(a.hfrag + 2 * Mp * U);
-    a.dump = (float*)(a.flags + PS_FLAG_WORDS);
+    a.dump = (float*)(a.flags + PS_FLAG_WORDS + PS_TICKET_WORDS);
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.h0 = q.h0; a.c0 = q.c0; a.lens = q.lens;
@@ -1129,15 +1172,19 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     a.dzfrag = Wb + (size_t)4 * U * U;
     a.dzfrag_bytes = (unsigned)(Mp * 4 * U * sizeof(float));
     a.flags = (unsigned*)(a.dzfrag + 2 * Mp * 4 * U);
-    a.dump = (float*)(a.flags + PS_FLAG_WORDS);
+    a.dbtick = a.flags + PS_FLAG_WORDS;
+    a.dump = (float*)(a.flags + PS_FLAG_WORDS + PS_TICKET_WORDS);
+    a.dbpart = a.dump + PS_DUMP_FLOATS;
+    a.db = q.db;
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.c0 = q.c0; a.cs = q.cs; a.lens = q.lens;
     a.dhout = q.dhout; a.dh_final = q.dh_final; a.dc_final = q.dc_final;
     a.dz = q.dz; a.dh0 = q.dh0; a.dc0 = q.dc0;
     // packed Wh^T; pass 0 has no product -- the chain runs on an all-zero dz[T]; flags reset
+    // (the whole flag area + the bias-gradient tickets behind it: 1040 uint4 next to 262144 weight float4s)
     return ps_prep(1, U, q.Wh, Wb, M, nullptr, (float*)((char*)a.dzfrag + (size_t)(n_steps & 1) * a.dzfrag_bytes),
-                   a.dzfrag_bytes, a.flags, (size_t)RT * PS_NRS_MAX * nnt, st);
+                   a.dzfrag_bytes, a.flags, (size_t)PS_FLAG_WORDS + PS_TICKET_WORDS, st);
 }
 static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdArgs& a2, int U, double flops,
                          hipStream_t st) {

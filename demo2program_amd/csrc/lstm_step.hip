@@ -867,7 +867,9 @@ extern "C" int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* d, d2p_
             q[i].dh0 = d[i].dh0; q[i].dc0 = d[i].dc0;
             ws[i] = (float*)d[i].ws;
         }
-        return d2p_lstm_fused_bwd_multi(nseq, q, ws, as_stream(stream));
+        int rc = d2p_lstm_fused_bwd_multi(nseq, q, ws, as_stream(stream));
+        for (int i = 0; !rc && i < nseq; ++i) rc = d2p_lstm_db_colsum(d + i, stream);
+        return rc;
     }
     if (nseq == 2 && d2p_lstm_is_persistent_enabled()) {
         int rc = D2P_OK;
@@ -876,23 +878,17 @@ extern "C" int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* d, d2p_
     if (nseq == 3 && d2p_lstm_is_persistent_enabled()) {      // all three in one launch, else the first alone + a pair
         int rc = D2P_OK;
         if (d2p_lstm_try_triple_bwd(d, as_stream(stream), &rc)) return rc;
-        rc = d2p_lstm_seq_bwd(d[0].M, d[0].U, d[0].n_steps, d[0].z, d[0].z_row_stride, d[0].z_t_stride, d[0].Wh,
-                              d[0].c0, d[0].lens, d[0].cs, d[0].dhout, d[0].dh_final, d[0].dc_final, d[0].dz, d[0].dh0,
-                              d[0].dc0, d[0].ws, d[0].ws_bytes, stream);
+        rc = d2p_lstm_seq_bwd_desc(d, stream);
         if (rc) return rc;
         if (d2p_lstm_try_pair_bwd(d + 1, as_stream(stream), &rc)) return rc;
         for (int i = 1; i < 3; ++i) {
-            rc = d2p_lstm_seq_bwd(d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh,
-                                  d[i].c0, d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final, d[i].dc_final, d[i].dz,
-                                  d[i].dh0, d[i].dc0, d[i].ws, d[i].ws_bytes, stream);
+            rc = d2p_lstm_seq_bwd_desc(d + i, stream);
             if (rc) return rc;
         }
         return D2P_OK;
     }
     for (int i = 0; i < nseq; ++i) {
-        int rc = d2p_lstm_seq_bwd(d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride,
-                                  d[i].Wh, d[i].c0, d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final,
-                                  d[i].dc_final, d[i].dz, d[i].dh0, d[i].dc0, d[i].ws, d[i].ws_bytes, stream);
+        int rc = d2p_lstm_seq_bwd_desc(d + i, stream);
         if (rc) return rc;
     }
     return D2P_OK;

@@ -87,6 +87,13 @@ def gemm_rows(kind, n_rows, N, K, A, lda, B, ldb, C, ldc, rows, bias=None):
                            _p(rows), ws, wsb, current_stream())
 
 
+def gemm_tn_rows(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate=False):
+    """C[M, N] (+)= sum_{x < K} A[rowsA[x], :M]^T B[rowsB[x], :N] (both operands through lists of K row indices)."""
+    ws, wsb = SCRATCH.get(call.d2p_gemm_ws_bytes(M, N, K))
+    call.d2p_gemm_f32_tn_rows(M, N, K, _p(A), lda, _p(rowsA), _p(B), ldb, _p(rowsB), _p(C), ldc,
+                              1 if accumulate else 0, ws, wsb, current_stream())
+
+
 def gemm_batched(kind, nb1, nb0, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, bias=None, sbias=(0, 0), act=0,
                  accumulate=False):
     """nb1 x nb0 problems of one shape in one launch; sA / sB / sC / sbias = (stride over the first batch
@@ -375,6 +382,7 @@ def lstm_seq_bwd_multi(seqs):
         d.dhout, d.dh_final, d.dc_final = ptr(q.get('dhout')), ptr(q.get('dh_final')), ptr(q.get('dc_final'))
         d.dz, d.dh0, d.dc0 = ptr(q['dz']), ptr(q.get('dh0')), ptr(q.get('dc0'))
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+        d.db = ptr(q.get('db'))            # optional: the bias gradient (column sums of dz), produced with the launch
     call.d2p_lstm_seq_bwd_multi(len(seqs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
 
 

@@ -25,6 +25,7 @@ SIGNATURES = {
     'd2p_gemm_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'd2p_gemm_set_option': (c_int, [c_int]),
     'd2p_gemm_f32_rows': (c_int, [c_int, c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, P, P, c_size_t, S]),
+    'd2p_gemm_f32_tn_rows': (c_int, [c_int, c_int, c_int, P, c_long, P, P, c_long, P, P, c_long, c_int, P, c_size_t, S]),
     'd2p_gemm_f32_batched': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_long, c_long, c_long, P, c_long, c_long,
                                      c_long, P, c_long, c_long, c_long, P, c_long, c_long, c_int, c_int, S]),
     'd2p_gemm_force_plan': (c_int, [c_int, c_int]),
@@ -122,7 +123,7 @@ class LstmBwdDesc(ctypes.Structure):
                 ('Wh', c_void_p), ('c0', c_void_p), ('lens', c_void_p), ('cs', c_void_p),
                 ('dhout', c_void_p), ('dh_final', c_void_p), ('dc_final', c_void_p),
                 ('dz', c_void_p), ('dh0', c_void_p), ('dc0', c_void_p),
-                ('ws', c_void_p), ('ws_bytes', c_size_t)]
+                ('ws', c_void_p), ('ws_bytes', c_size_t), ('db', c_void_p)]
 
 
 _lib = None

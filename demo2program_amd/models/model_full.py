@@ -247,8 +247,13 @@ class Model(object):
                 # factored perception decoder multiplies instead of [rows, U] features (d2p.h: d2p_per_affine_rows)
                 ('per_rows', torch.float32, (T * B * k, self.per_cols)),
                 ('per_gram', torch.float32, (self.per_cols, self.per_cols)),
-                # time-major row indices t*M + m of the demonstration steps inside their sequence (t < demo_len[m])
-                ('active_rows', torch.int32, (T * B * k,)),
+                # time-major row indices t*M + m of the demonstration steps inside their sequence (t < demo_len[m]),
+                # padded to whole 32-row K slabs with the index of a row PAST its sequence (zeros in every dz)
+                ('active_rows', torch.int32, (T * B * k + 32,)),
+                # the same for the steps t >= 1, and those indices minus M (row t-1 of the same sequence): the two
+                # operand lists of dWh = sum_t h[t-1]^T dz[t]; then both for the program decoder's rows
+                ('rows_t1', torch.int32, (T * B * k + 32,)), ('rows_t1_prev', torch.int32, (T * B * k + 32,)),
+                ('prog_rows_t1', torch.int32, (L * B + 32,)), ('prog_rows_t1_prev', torch.int32, (L * B + 32,)),
                 ('program_len', torch.int32, (B,)), ('demo_len', torch.int32, (B * k,))]
         offs, total = [], 0
         for _, dt, shape in spec:
@@ -276,6 +281,34 @@ class Model(object):
         blk[:, :, ar, ar, :P_] = feed['per'].permute(2, 0, 1, 3)
         blk[:, :, ar, ar, P_] = 1.0
         K.matmul_tn(rows, rows, out=feed['per_gram'])
+
+    @staticmethod
+    def row_lists(lens, R, cap, n_steps):
+        """Time-major indices t*R + r of the rows inside their sequences (t < lens[r]), all of them and those with
+        t >= 1, each padded to a multiple of 32 with the index of a row of the decoded steps that is PAST its sequence
+        (zero in every dz; t >= 1) -- the K lists of d2p_gemm_f32_tn_rows.  -> (rows, rows_t1, n_pad, n_t1_pad); a
+        padded count of 0 means "no list" (nothing to skip, or no pad row and a count that is not a multiple of 32)."""
+        lens = np.minimum(np.asarray(lens, np.int64), cap)
+        tt = np.arange(cap, dtype=np.int64)[:, None]
+        inside = tt < lens[None, :]
+        t_idx, r_idx = np.nonzero(inside)
+        rows = (t_idx * R + r_idx).astype(np.int32)
+        rows_t1 = rows[t_idx >= 1]
+        past = np.nonzero((~inside) & (tt < n_steps) & (tt >= 1))
+        pad = int(past[0][-1] * R + past[1][-1]) if past[0].size else -1
+
+        def padded(a):
+            if a.size == 0 or pad < 0 and a.size % 32:
+                return a, 0
+            n = (a.size + 31) // 32 * 32
+            if n > a.size:
+                a = np.concatenate([a, np.full(n - a.size, pad, np.int32)])
+            return a, int(n)
+        if pad < 0:                              # every row runs to the last decoded step: nothing to skip
+            return rows, rows_t1, 0, 0
+        rows, n_pad = padded(rows)
+        rows_t1, n_t1_pad = padded(rows_t1)
+        return rows, rows_t1, n_pad, n_t1_pad
 
     def get_feed_dict(self, batch_chunk, step=None, is_training=True):
         """batch_chunk (numpy arrays or torch tensors, keys of models/model_full.py:185-206)
@@ -318,14 +351,20 @@ class Model(object):
         dlen = host_np(batch_chunk['demo_len']).astype(np.int32).reshape(B * k)
         put('program_len', plen)
         put('demo_len', dlen)
-        act = np.nonzero(np.arange(T, dtype=np.int32)[:, None] < dlen[None, :])
-        act_rows = (act[0].astype(np.int64) * (B * k) + act[1]).astype(np.int32)
-        feed['n_active'] = int(act_rows.size)
-        if act_rows.size:
-            feed['active_rows'][:act_rows.size].copy_(torch.from_numpy(act_rows), non_blocking=True)
         # dynamic_decode runs until the longest sequence of the batch
         feed['n_prog'] = int(min(int(plen.max()) if B else 0, L))
         feed['n_demo'] = int(min(int(dlen.max()) if B * k else 0, T))
+        for key, lens_np, R, cap, n_steps in (('', dlen, B * k, T, feed['n_demo']), ('prog_', plen, B, L, feed['n_prog'])):
+            rows, rows_t1, n_pad, n_t1_pad = self.row_lists(lens_np, R, cap, n_steps)
+            if key == '':
+                feed['n_active'] = int(np.minimum(lens_np, cap).clip(0).sum())       # (without the padding)
+                feed['n_active_pad'] = n_pad
+                if rows.size:
+                    feed['active_rows'][:rows.size].copy_(torch.from_numpy(rows), non_blocking=True)
+            feed[key + 'n_t1_pad'] = n_t1_pad
+            if rows_t1.size:
+                feed[key + 'rows_t1'][:rows_t1.size].copy_(torch.from_numpy(rows_t1), non_blocking=True)
+                feed[key + 'rows_t1_prev'][:rows_t1.size].copy_(torch.from_numpy(rows_t1 - R), non_blocking=True)
         feed['id'] = batch_chunk.get('id') if hasattr(batch_chunk, 'get') else None
         feed['host'] = {n: batch_chunk[n] for n in ('test_s_h', 'test_demo_len', 'test_per', 'init_pos',
                                                     'init_pos_len', 'test_init_pos', 'test_init_pos_len')
@@ -528,6 +567,18 @@ class Model(object):
         else:
             K.loss_assemble([1], nums, dens, loss, terms)
 
+        # K lists of the weight-gradient GEMMs (rows inside their sequences only); absent from the graph-static feed
+        self.k_rows = os.environ.get('D2P_K_ROWS', '1') == '1'
+        ctx['klists'] = {}
+        if self.k_rows and feed.get('n_active_pad') is not None:
+            if feed['n_active_pad'] and feed['n_t1_pad']:
+                ctx['klists']['demo'] = (feed['active_rows'], feed['n_active_pad'], feed['rows_t1'],
+                                         feed['rows_t1_prev'], feed['n_t1_pad'])
+            if feed['prog_n_t1_pad']:
+                ctx['klists']['prog'] = (None, 0, feed['prog_rows_t1'], feed['prog_rows_t1_prev'], feed['prog_n_t1_pad'])
+        for e_, space in ((e1, 'demo'), (e2, 'demo'), (dp, 'prog'), (da, 'demo'), (dq, 'demo')):
+            if e_ is not None:
+                e_['rowspace'] = space
         ctx.update(e1=e1, e2=e2, rn_h=rn_h, rn_c=rn_c, dp=dp, feats_tm=feats_tm, ids_p=ids_p, emb_p=emb_p,
                    dens=dens, h0_2=h0_2, c0_2=c0_2, demo_h=demo_h, demo_c=demo_c, init_h=init_h, init_c=init_c)
         self._ctx = ctx
@@ -981,8 +1032,17 @@ class Model(object):
         name, M, T, n = e['name'], e['M'], e['T'], e['n']
         U = self.num_lstm_cell_units
         dz = self._buf(name + '/dz', (T * M, 4 * U))
-        K.lstm_seq_bwd(e['z'], 4 * U, M * 4 * U, M, U, n, e['Wh'], e['c0'], e['lens'], e['cs'],
-                       dhout, dh_final, dc_final, dz, dh0, dc0)
+        gb = self.params.g[name + '/bias']
+        if n > 0:
+            # (the bias gradient -- the column sums of dz -- comes out of the same launch)
+            K.lstm_seq_bwd_multi([dict(M=M, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], lens=e['lens'],
+                                       cs=e['cs'], dhout=dhout, dh_final=dh_final, dc_final=dc_final, dz=dz,
+                                       dh0=dh0, dc0=dc0, db=gb)])
+        else:
+            K.lstm_seq_bwd(e['z'], 4 * U, M * 4 * U, M, U, n, e['Wh'], e['c0'], e['lens'], e['cs'],
+                           dhout, dh_final, dc_final, dz, dh0, dc0)
+            gb.zero_()
+        e['db_done'] = True
         return dz
 
     def _lstm_bwd_params(self, e, dz, want_dx):
@@ -1038,6 +1098,8 @@ class Model(object):
         gk, gb = g[name + '/kernel'], g[name + '/bias']
         rows = n * M
         dz_n = dz[:rows] if rows > 0 else dz[:0]
+        # the rows inside their sequences, as K lists (d2p_gemm_f32_tn_rows): the others are zeros in dz
+        kl = self._ctx.get('klists', {}).get(e.get('rowspace')) if rows > 0 else None
         # dWx = X^T dZ ; db = colsum(dZ)
         if e.get('token_ids') is not None:
             # x = embedding[id]: S[v] = sum of the dz rows whose input token was v (one-hot GEMM, tok+2 rows),
@@ -1054,18 +1116,27 @@ class Model(object):
                 gk[:I].zero_()
                 g[scope + '/embedding'].zero_()
         elif e['x'] is not None:
-            K.gemm_raw('tn', I, 4 * U, rows, e['x'], e['x'].stride(0), dz_n, 4 * U, gk[:I], 4 * U)
+            if kl is not None and kl[1]:
+                K.gemm_tn_rows(I, 4 * U, kl[1], e['x'], e['x'].stride(0), kl[0], dz, 4 * U, kl[0], gk[:I], 4 * U)
+            else:
+                K.gemm_raw('tn', I, 4 * U, rows, e['x'], e['x'].stride(0), dz_n, 4 * U, gk[:I], 4 * U)
         # (x None without token ids: the factored perception decoder -- its dWx is written by _per_factored_grads)
-        K.colsum(dz_n, out=gb, rows=rows) if rows > 0 else gb.zero_()
+        if not e.get('db_done'):             # (the backward recurrence's launch normally leaves it behind)
+            K.colsum(dz_n, out=gb, rows=rows) if rows > 0 else gb.zero_()
         # dWh = sum_t h_{t-1}^T dZ_t : h_{-1} = h0 (skipped when zero), then hout[t-1]
         hout2d = e['hout'].view(T * M, U)
+
+        def dwh(accumulate):
+            if kl is not None and kl[4]:
+                K.gemm_tn_rows(U, 4 * U, kl[4], hout2d, U, kl[3], dz, 4 * U, kl[2], gk[I:], 4 * U, accumulate=accumulate)
+            else:
+                K.gemm_raw('tn', U, 4 * U, (n - 1) * M, hout2d, U, dz[M:], 4 * U, gk[I:], 4 * U, accumulate=accumulate)
         if e['h0'] is not None and n > 0:
             K.gemm_raw('tn', U, 4 * U, M, e['h0'], U, dz, 4 * U, gk[I:], 4 * U)
             if n > 1:
-                K.gemm_raw('tn', U, 4 * U, (n - 1) * M, hout2d, U, dz[M:], 4 * U, gk[I:], 4 * U,
-                           accumulate=True)
+                dwh(True)
         elif n > 1:
-            K.gemm_raw('tn', U, 4 * U, (n - 1) * M, hout2d, U, dz[M:], 4 * U, gk[I:], 4 * U)
+            dwh(False)
         else:
             gk[I:].zero_()
 
@@ -1090,11 +1161,13 @@ class Model(object):
                 K.gemm_raw('tn', U, V, rows, e['hout'].view(T * R, U), U, dlogits, V, g[scope + '/proj'], V)
                 K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
                 seqs.append(dict(M=R, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], cs=e['cs'],
-                                 dhout=dhout, dz=dz, dh0=dh0, dc0=dc0))
+                                 dhout=dhout, dz=dz, dh0=dh0, dc0=dc0, db=g[e['name'] + '/bias']))
             else:
                 g[scope + '/proj'].zero_()
+                g[e['name'] + '/bias'].zero_()
                 dh0.zero_()
                 dc0.zero_()
+            e['db_done'] = True
         if seqs:
             K.lstm_seq_bwd_multi(seqs)
         return dzs

@@ -99,6 +99,14 @@ int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, const float* 
  * tile plan.  Workspace: d2p_gemm_ws_bytes(M, N, K). */
 int d2p_gemm_f32_rows(int kind, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                       long ldc, const float* bias, const int* rows, void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* C[m, n] (+)= sum_{x < K} A[rowsA[x]*lda + m] * B[rowsB[x]*ldb + n]: the 'tn' product (d2p_gemm_f32_tn: C = A^T B)
+ * with BOTH operands read through lists of K row indices.  For the weight gradients X^T dZ / h[t-1]^T dz[t] of a
+ * padded time-major batch over the rows inside their sequences only (rows past a sequence's length are zeros in
+ * dZ; the reference multiplies them in, tf.gradients of models/model_full.py:243-277).  K % 32 == 0 takes the
+ * select-free loaders: pad the lists with a row that is zero in B and finite in A. */
+int d2p_gemm_f32_tn_rows(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
+                         const int* rowsB, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes,
+                         d2p_stream_t stream);
 /* out[c] = sum_r X[r*ld + c]  (bias gradients).  ws >= d2p_colsum_ws_bytes. */
 size_t d2p_colsum_ws_bytes(int rows, int cols);
 int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float* out,
@@ -285,6 +293,10 @@ typedef struct {
     const float* dhout; const float* dh_final; const float* dc_final;
     float* dz; float* dh0; float* dc0;
     void* ws; size_t ws_bytes;
+    float* db;      /* optional [4U]: the cell's bias gradient = column sums of dz over all n_steps*M rows
+                     * (needs z_t_stride == M * z_row_stride).  The persistent kernels produce it inside
+                     * their launch (per-workgroup sums, folded by each column tile's last workgroup in a
+                     * fixed order); the other back ends run d2p_colsum_f32 over dz behind the recurrence. */
 } d2p_lstm_bwd_desc;
 int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* descs, d2p_stream_t stream);
 int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* descs, d2p_stream_t stream);

@@ -955,3 +955,85 @@ def test_adam_prescale_is_gradient_average(K):
 def test_missing_gpu_tensor_fails_loudly(K):
     with pytest.raises(RuntimeError):
         K.matmul_nn(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('specs', [[(320, 20)], [(320, 20), (32, 50)], [(320, 6), (320, 6), (32, 9)], [(40, 5)],
+                                   [(400, 4)], [(16, 3)]])
+def test_lstm_bias_gradient_comes_out_of_the_backward_launch(K, specs):
+    """d2p_lstm_bwd_desc.db: the cell's bias gradient (column sums of dz over every row and step) produced by the
+    backward recurrence itself -- inside the persistent launch (per-workgroup sums folded by each column tile's last
+    workgroup in domain order), or by a column-sum pass behind the per-step back ends.  Against the fp64 column
+    sums of the dz the same call wrote; ragged row counts (40, 400 rows), sequence lengths, one / two / three
+    sequences per launch; deterministic (two runs bit-identical)."""
+    U = 512
+    g = torch.Generator().manual_seed(29)
+    K.lstm_persist_error(True)
+
+    def run(persistent):
+        K.set_lstm_persistent(persistent)
+        fw, bw, outs = [], [], []
+        gg = torch.Generator().manual_seed(31)
+        for (M, n) in specs:
+            lens = torch.randint(1, n + 1, (M,), generator=gg).int().cuda() if M != 32 else None
+            o = dict(z=(torch.rand(n * M, 4 * U, generator=gg) * 2 - 1).cuda(), hout=torch.zeros(n, M, U, device='cuda'),
+                     cs=torch.zeros(n, M, U, device='cuda'), dz=torch.zeros(n * M, 4 * U, device='cuda'),
+                     dh0=torch.zeros(M, U, device='cuda'), dc0=torch.zeros(M, U, device='cuda'),
+                     db=torch.full((4 * U,), 7.0, device='cuda'))
+            Wh = ((torch.rand(U, 4 * U, generator=gg) * 2 - 1) * 0.05).cuda()
+            h0 = (torch.rand(M, U, generator=gg) * 2 - 1).cuda()
+            c0 = (torch.rand(M, U, generator=gg) * 2 - 1).cuda()
+            dhout = (torch.rand(n, M, U, generator=gg) * 2 - 1).cuda()
+            dhf = (torch.rand(M, U, generator=gg) * 2 - 1).cuda() if lens is not None else None
+            outs.append(o)
+            fw.append(dict(M=M, U=U, n_steps=n, z=o['z'], Wh=Wh, h0=h0, c0=c0, lens=lens, hout=o['hout'], cs=o['cs']))
+            bw.append(dict(M=M, U=U, n_steps=n, z=o['z'], Wh=Wh, c0=c0, lens=lens, cs=o['cs'], dhout=dhout,
+                           dh_final=dhf, dz=o['dz'], dh0=o['dh0'], dc0=o['dc0'], db=o['db']))
+        K.lstm_seq_fwd_multi(fw)
+        K.lstm_seq_bwd_multi(bw)
+        torch.cuda.synchronize()
+        return outs
+    try:
+        for persistent in (True, False):
+            a = run(persistent)
+            b = run(persistent)
+            for o, o2 in zip(a, b):
+                ref = o['dz'].double().sum(dim=0)
+                scale = max(1.0, float(o['dz'].abs().double().sum(dim=0).max()))
+                assert (o['db'].double() - ref).abs().max().item() <= 2e-6 * scale, persistent
+                assert torch.equal(o['db'], o2['db']) and torch.equal(o['dz'], o2['dz'])
+        assert K.lstm_persist_error(True) == 0
+    finally:
+        K.set_lstm_persistent(True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('M,N,R,Kn', [(512, 2048, 6400, 4480), (48, 2048, 6400, 4512), (512, 2048, 1600, 864),
+                                     (60, 256, 700, 333), (512, 512, 300, 64), (20, 36, 90, 50)])
+def test_gemm_tn_over_lists_of_k_rows(K, M, N, R, Kn):
+    """d2p_gemm_f32_tn_rows: C = A[rowsA]^T B[rowsB] (+ C) with both operands read through lists of K row indices
+    (weight gradients over the rows inside their sequences; rowsA = rowsB - shift for dWh).  Against fp64, incl. a
+    K that is not a multiple of the slab depth (the generic loaders), the accumulate form, and -- for lists padded
+    with the index of a zero row -- equality with the dense product over all rows."""
+    g = torch.Generator().manual_seed(M + N + Kn)
+    shift = 7
+    A = (torch.rand(R, M, generator=g) * 2 - 1).cuda()
+    B = (torch.rand(R, N, generator=g) * 2 - 1).cuda()
+    rowsB = (torch.randperm(R - shift, generator=g)[:Kn].sort().values + shift).int()
+    rowsA = rowsB - shift
+    C0 = (torch.rand(M, N, generator=g) * 2 - 1).cuda()
+    ref = A.double().cpu()[rowsA.long()].t() @ B.double().cpu()[rowsB.long()]
+    for acc in (False, True):
+        C = C0.clone()
+        K.gemm_tn_rows(M, N, Kn, A, M, rowsA.cuda(), B, N, rowsB.cuda(), C, N, accumulate=acc)
+        want = ref + (C0.double().cpu() if acc else 0)
+        assert (C.double().cpu() - want).abs().max().item() <= 2e-5 * max(1.0, float(Kn) ** 0.5)
+    # zero rows of B left out of the list: same as the dense product (up to the summation order)
+    Bz = B.clone()
+    keep = torch.zeros(R, dtype=torch.bool)
+    keep[rowsB.long()] = True
+    Bz[~keep.cuda()] = 0
+    Cl = torch.empty(M, N, device='cuda')
+    K.gemm_tn_rows(M, N, Kn, A, M, rowsB.cuda(), Bz, N, rowsB.cuda(), Cl, N)
+    full = K.matmul_tn(A, Bz)
+    assert (Cl - full).abs().max().item() <= 2e-5 * max(1.0, float(Kn) ** 0.5)
