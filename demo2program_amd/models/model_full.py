@@ -253,6 +253,7 @@ class Model(object):
                 # the same for the steps t >= 1, and those indices minus M (row t-1 of the same sequence): the two
                 # operand lists of dWh = sum_t h[t-1]^T dz[t]; then both for the program decoder's rows
                 ('rows_t1', torch.int32, (T * B * k + 32,)), ('rows_t1_prev', torch.int32, (T * B * k + 32,)),
+                ('prog_rows', torch.int32, (L * B + 32,)),
                 ('prog_rows_t1', torch.int32, (L * B + 32,)), ('prog_rows_t1_prev', torch.int32, (L * B + 32,)),
                 ('program_len', torch.int32, (B,)), ('demo_len', torch.int32, (B * k,))]
         offs, total = [], 0
@@ -358,9 +359,10 @@ class Model(object):
             rows, rows_t1, n_pad, n_t1_pad = self.row_lists(lens_np, R, cap, n_steps)
             if key == '':
                 feed['n_active'] = int(np.minimum(lens_np, cap).clip(0).sum())       # (without the padding)
-                feed['n_active_pad'] = n_pad
-                if rows.size:
-                    feed['active_rows'][:rows.size].copy_(torch.from_numpy(rows), non_blocking=True)
+            feed[key + 'n_active_pad'] = n_pad
+            if rows.size:
+                feed['active_rows' if key == '' else 'prog_rows'][:rows.size].copy_(torch.from_numpy(rows),
+                                                                                    non_blocking=True)
             feed[key + 'n_t1_pad'] = n_t1_pad
             if rows_t1.size:
                 feed[key + 'rows_t1'][:rows_t1.size].copy_(torch.from_numpy(rows_t1), non_blocking=True)
@@ -497,6 +499,14 @@ class Model(object):
             init_h, init_c = rn_h['out'][0], rn_h['out'][1]
 
         main.wait_stream(side)
+        # the initial states in front of the saved outputs (hbuf[0]): second encoder, the three decoders
+        stage = [('prog/lstm', L, B, init_h)]
+        if e2 is not None:
+            stage.append(('second_lstm', T, M, h0_2))
+        if self.multitask:
+            stage += [('act/lstm', T, M, demo_h), ('per/lstm', T, M, demo_h)]
+        if not (self.scheduled_sampling and self.is_train) and self.is_train:
+            self._stage_h0(ctx, stage)
         # ---- Program decoder (teacher forcing; <s> = out-of-range id -> zero vector),
         #      action decoders (all k in one batch), perception decoders
         #      The three decoders are independent LSTMs.  fuse_decoders=True advances them
@@ -574,8 +584,9 @@ class Model(object):
             if feed['n_active_pad'] and feed['n_t1_pad']:
                 ctx['klists']['demo'] = (feed['active_rows'], feed['n_active_pad'], feed['rows_t1'],
                                          feed['rows_t1_prev'], feed['n_t1_pad'])
-            if feed['prog_n_t1_pad']:
-                ctx['klists']['prog'] = (None, 0, feed['prog_rows_t1'], feed['prog_rows_t1_prev'], feed['prog_n_t1_pad'])
+            if feed['prog_n_active_pad'] and feed['prog_n_t1_pad']:
+                ctx['klists']['prog'] = (feed['prog_rows'], feed['prog_n_active_pad'], feed['prog_rows_t1'],
+                                         feed['prog_rows_t1_prev'], feed['prog_n_t1_pad'])
         for e_, space in ((e1, 'demo'), (e2, 'demo'), (dp, 'prog'), (da, 'demo'), (dq, 'demo')):
             if e_ is not None:
                 e_['rowspace'] = space
@@ -607,6 +618,31 @@ class Model(object):
         K.bn_fwd(x2d, gamma, beta, G, inner, y=y, mean=mean, rstd=rstd,
                  moving=self.moving[name] if self.track_moving else None)
         return y, mean, rstd
+
+    def _hbuf(self, name, T, M):
+        """Outputs of a recurrence with one more slab in front: hbuf [T+1, M, U], hout = hbuf[1:].  hbuf[t] is the
+        state the step-t product multiplied (hbuf[0] = the initial state, zeros without one), so the recurrent
+        weight gradient is ONE product over the rows of all steps, dWh = sum_t hbuf[t]^T dz[t] -- round 2 ran the
+        initial state's term as a separate K = M GEMM (26 us alone, 160-260 us beside a persistent launch)."""
+        hb = self._buf(name + '/hbuf', (T + 1, M, self.num_lstm_cell_units), zero=True)
+        return hb, hb[1:]
+
+    def _stage_h0(self, ctx, items):
+        """hbuf[0] <- h0 for every (name, T, M, h0): device copies on the side stream, forked where the initial
+        states exist (read by the weight-gradient GEMMs of backward, which run on that stream too)."""
+        items = [it for it in items if it[3] is not None]
+        if not items:
+            return
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        # (buffers are created -- and zero-filled -- on the MAIN stream: a first-use allocation inside the side-stream
+        #  block would run its fill there, racing with the recurrence that writes the other slabs)
+        dst = [self._hbuf(name, T, M)[0][0] for name, T, M, _ in items]
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            for d, (name, _, _, h0) in zip(dst, items):
+                d.copy_(h0)
+                ctx.setdefault('h0_staged', set()).add(name)
 
     def _lstm_xproj(self, name, x2d, I, M, T, n_steps):
         """Hoisted input projection z = x·Wx + b for all steps (one GEMM)."""
@@ -643,7 +679,7 @@ class Model(object):
         Wx, Wh = kernel[:I], kernel[I:]
         if z is None:
             z = self._lstm_xproj(name, x2d, I, M, T, n_steps)
-        hout = self._buf(name + '/hout', (T, M, U))
+        hbuf, hout = self._hbuf(name, T, M)
         cs = self._buf(name + '/cs', (T, M, U))
         if final_out is not None:
             hf, cf = final_out
@@ -652,7 +688,7 @@ class Model(object):
             cf = self._buf(name + '/c_final', (M, U)) if want_final else None
         K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, n_steps, Wh, h0, c0, lens, hout, cs, hf, cf)
         return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
-                    hout=hout, cs=cs, h_final=hf, c_final=cf, Wx=Wx, Wh=Wh)
+                    hout=hout, hbuf=hbuf, cs=cs, h_final=hf, c_final=cf, Wx=Wx, Wh=Wh)
 
     def _decoders_fwd(self, specs, logits=True):
         """BasicDecoder + TrainingHelper + Dense(no bias) (models/model_full.py:440-490) for
@@ -664,10 +700,10 @@ class Model(object):
         for (scope, x2d, I, R, T, n_steps, h0, c0, token_dim, z) in specs:
             name = scope + '/lstm'
             kernel = p[name + '/kernel']
-            hout = self._buf(name + '/hout', (T, R, U))
+            hbuf, hout = self._hbuf(name, T, R)
             cs = self._buf(name + '/cs', (T, R, U))
             e = dict(name=name, x=x2d, I=I, M=R, T=T, n=n_steps, h0=h0, c0=c0, lens=None, z=z,
-                     hout=hout, cs=cs, h_final=None, c_final=None, Wx=kernel[:I], Wh=kernel[I:],
+                     hout=hout, hbuf=hbuf, cs=cs, h_final=None, c_final=None, Wx=kernel[:I], Wh=kernel[I:],
                      token_dim=token_dim, scope=scope)
             if x2d is None and scope in ('prog', 'act'):      # token-input decoder on the projected-table path
                 e['token_ids'] = self._bufs['ids_p' if scope == 'prog' else 'ids_a']
@@ -1125,6 +1161,14 @@ class Model(object):
             K.colsum(dz_n, out=gb, rows=rows) if rows > 0 else gb.zero_()
         # dWh = sum_t h_{t-1}^T dZ_t : h_{-1} = h0 (skipped when zero), then hout[t-1]
         hout2d = e['hout'].view(T * M, U)
+        if e['name'] in self._ctx.get('h0_staged', ()) and e.get('hbuf') is not None and n > 0:
+            # hbuf[t] = the state step t multiplied (hbuf[0] = h0): one product over the rows of all steps
+            hb2d = e['hbuf'].view((T + 1) * M, U)
+            if kl is not None and kl[1]:
+                K.gemm_tn_rows(U, 4 * U, kl[1], hb2d, U, kl[0], dz, 4 * U, kl[0], gk[I:], 4 * U)
+            else:
+                K.gemm_raw('tn', U, 4 * U, rows, hb2d, U, dz_n, 4 * U, gk[I:], 4 * U)
+            return
 
         def dwh(accumulate):
             if kl is not None and kl[4]:

@@ -841,7 +841,12 @@ def test_rccl_single_rank_self_test(monkeypatch):
         dp.barrier()
     finally:
         dp.shutdown()
-    assert with_group == plain and one_message == plain and eager == plain and two_streams == plain
+    # the one-message form runs the very same kernels; the overlap forms run the encoder recurrences on the per-step
+    # kernels (beside a collective the persistent ones are not used) and the graph form multiplies the padded rows in
+    # its weight gradients (no row lists in a captured step): equal to fp32 round-off, not bit for bit
+    assert one_message == plain
+    for other in (with_group, eager, two_streams):
+        assert all(abs(a - b) <= 2e-5 * abs(b) for a, b in zip(other, plain)), (other, plain)
 
 
 def test_tf_checkpoint_export_import_round_trip(tmp_path):
