@@ -957,10 +957,12 @@ class Model(object):
             elif self.pair_decoders:
                 # perception first, then action + program as one launch (as in forward); each group's gradient
                 # GEMMs are forked right behind its recurrence
-                # (all three backward recurrences as ONE launch -- 3 + 3 + 2 row domains, D2P_TRIPLE_BWD=1 -- take
-                #  444 us against 218 + 334 in isolation, tools/lstm_persist_pair.py, but the step does not gain:
-                #  the perception decoder's gradient GEMMs then no longer run beside the other two recurrences)
-                groups = ((2, 1, 0),) if os.environ.get('D2P_TRIPLE_BWD', '0') == '1' else ((2,), (1, 0))
+                # (all three backward recurrences as ONE launch -- 3 + 3 + 2 row domains -- take 444 us against
+                #  218 + 334 in isolation, tools/lstm_persist_pair.py.  Round 2 measured no gain in the step: the
+                #  perception decoder's gradient GEMMs then no longer ran beside the other two recurrences.  With the
+                #  lighter side stream of round 3 -- no column-sum passes, weight gradients over the active rows only
+                #  -- the triple wins: 3.27 -> 3.20 ms per step; D2P_TRIPLE_BWD=0 restores one + pair)
+                groups = ((2, 1, 0),) if os.environ.get('D2P_TRIPLE_BWD', '1') == '1' else ((2,), (1, 0))
                 # (the projections' small weight-gradient GEMMs stay in front of the recurrences: on the side
                 #  stream they cost 0.06 ms per step -- measured twice)
                 for grp in groups:
