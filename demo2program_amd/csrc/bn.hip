@@ -71,6 +71,67 @@ extern "C" size_t d2p_bn_ws_bytes(int R, int C, int G) {
     return stats + (size_t)bn_sum_blocks(R, C, vec) * C * sizeof(float);
 }
 
+// ---- finalize folded into the partial-sum launch (round 3) ------------------------------------------------------
+// The separate finalize kernels ran ONE wavefront per channel over all groups: 9-11 us each for the conv layers (16-48
+// channels, 10 groups) on the step's critical path, six per step.  With few partials per group (S * C small) the LAST
+// workgroup of a group to arrive (a ticket, cdna_hip_programming.md Guideline 16: stores -> vmcnt(0) -> barrier ->
+// agent release -> relaxed fetch_add; the last arriver acquires) folds that group's S partials in s order -- the
+// same fp64 sums in a fixed order, deterministic -- and the last GROUP to finish (a second ticket) does what needs
+// every group: the moving-average updates in group order (forward), dgamma / dbeta (backward).
+// Tickets live in a small device-global pool, one slot per call in flight (round-robin), zero at load and reset by
+// each last arriver.
+#define BN_TICKET_SLOTS 64
+#define BN_TICKET_WORDS 64
+__device__ unsigned g_bn_tickets[BN_TICKET_SLOTS * BN_TICKET_WORDS];
+static unsigned* bn_ticket_slot() {
+    static unsigned* base = nullptr;
+    static unsigned next = 0;
+    if (!base) (void)hipGetSymbolAddress((void**)&base, HIP_SYMBOL(g_bn_tickets));
+    return base ? base + (size_t)(next++ % BN_TICKET_SLOTS) * BN_TICKET_WORDS : nullptr;
+}
+static int g_bn_gc = 1;          // one wavefront per (group, channel) in the finalize launches (bit 1 of d2p_bn_set_fold: off)
+static int g_bn_fold = 0;        // 1: fold the finalize steps (d2p_bn_set_fold); measured equal-to-slower, off by default
+extern "C" int d2p_bn_set_fold(int on) {
+    g_bn_fold = (on & 1) ? 1 : 0;
+    g_bn_gc = (on & 2) ? 0 : 1;
+    return D2P_OK;
+}
+static inline bool bn_fold_ok(int nb, int G, int S, int C) {
+    return g_bn_fold && (long)S * C <= 4096 && nb * (G + 1) <= BN_TICKET_WORDS;
+}
+
+struct BnFold {
+    unsigned* tickets;          // null: no fold (a finalize launch follows)
+    // forward
+    float* mean; float* rstd; float* var_out; float* moving_mean; float* moving_var; float decay;
+    const unsigned* err;
+    // backward
+    float* m12; float* dgamma; float* dbeta; double* gsum;
+};
+
+// Ticket of this workgroup for counter `t` out of `total` arrivals; true for the last arriver (whole workgroup
+// agrees).  `flag` is a spare LDS word of the caller's one shared array.
+// Everything a later arriver reads travels as WRITE-THROUGH (sc1) stores and is read with sc1 loads (bn_st / bn_ld:
+// relaxed agent-scope atomics of <= 8 bytes lower to exactly that), so no release / acquire fence is needed -- a
+// fence here writes back the whole L2 of the XCD, once per workgroup, right after a conv kernel left megabytes of
+// dirty activations in it (measured: the fenced form made the step 0.05 ms SLOWER than the separate launches).
+template <typename T>
+__device__ __forceinline__ void bn_st(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T bn_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool bn_last_arriver(unsigned* t, unsigned total, double* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned k = __hip_atomic_fetch_add(t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = (k == total - 1u);
+        if (last) __hip_atomic_store(t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the slot's next call
+        *flag = last ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    return *flag != 0.0;
+}
+
 // partial[((g*S + s)*C + c)*2 + {0,1}] = sum over this block's rows of (a, b) where
 //   MODE 0 (fwd):  a = x,   b = x*x
 //   MODE 1 (bwd):  a = dy,  b = dy * xhat
@@ -78,9 +139,9 @@ extern "C" size_t d2p_bn_ws_bytes(int R, int C, int G) {
 template <int MODE, int VEC>
 __global__ void __launch_bounds__(256)
 bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, const float* x,
-                  const float* dy, const float* mean, const float* rstd, double* partial, BnBatch bb) {
+                  const float* dy, const float* mean, const float* rstd, double* partial, BnBatch bb, BnFold fo) {
     BN_SHIFT(x, bb.xs); BN_SHIFT(dy, bb.xs); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss); BN_SHIFT_WS(partial, double);
-    __shared__ double red[2][VEC][256];
+    __shared__ double red[2][VEC][256 + 1];
     const int g = blockIdx.x, s = blockIdx.y, S = gridDim.y;
     const int tid = threadIdx.x;
     const int cl = tid % lanes_c, rl = tid / lanes_c;
@@ -98,29 +159,43 @@ bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, co
                 mu[e] = MODE == 1 ? mean[g * C + c + e] : 0.f;
                 rs[e] = MODE == 1 ? rstd[g * C + c + e] : 0.f;
             }
-            for (int j = s * row_lanes + rl; j < n; j += S * row_lanes) {
-                const int o = j / inner, ii = j - o * inner;
-                const long r = ((long)o * G + g) * inner + ii;
-                float xv[VEC], dv[VEC];
-                if (VEC == 4) {
-                    const float4 t = *reinterpret_cast<const float4*>(x + r * C + c);
-                    xv[0] = t.x; xv[1 % VEC] = t.y; xv[2 % VEC] = t.z; xv[3 % VEC] = t.w;
-                    if (MODE == 1) {
-                        const float4 d = *reinterpret_cast<const float4*>(dy + r * C + c);
-                        dv[0] = d.x; dv[1 % VEC] = d.y; dv[2 % VEC] = d.z; dv[3 % VEC] = d.w;
+            // rows in batches of four: the four loads are independent and in flight together (one load per trip
+            // left every row's ~1 us of latency exposed: 8 trips = most of this kernel's 8-10 us)
+            const int step = S * row_lanes;
+            for (int j0 = s * row_lanes + rl; j0 < n; j0 += 4 * step) {
+                float xv[4][VEC], dv[4][VEC];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int j = j0 + u * step;
+                    ok[u] = j < n;
+                    const int jc = ok[u] ? j : j0;
+                    const int o = jc / inner, ii = jc - o * inner;
+                    const long r = ((long)o * G + g) * inner + ii;
+                    if (VEC == 4) {
+                        const float4 t = *reinterpret_cast<const float4*>(x + r * C + c);
+                        xv[u][0] = t.x; xv[u][1 % VEC] = t.y; xv[u][2 % VEC] = t.z; xv[u][3 % VEC] = t.w;
+                        if (MODE == 1) {
+                            const float4 d = *reinterpret_cast<const float4*>(dy + r * C + c);
+                            dv[u][0] = d.x; dv[u][1 % VEC] = d.y; dv[u][2 % VEC] = d.z; dv[u][3 % VEC] = d.w;
+                        }
+                    } else {
+                        xv[u][0] = x[r * C + c];
+                        if (MODE == 1) dv[u][0] = dy[r * C + c];
                     }
-                } else {
-                    xv[0] = x[r * C + c];
-                    if (MODE == 1) dv[0] = dy[r * C + c];
                 }
 #pragma unroll
-                for (int e = 0; e < VEC; ++e) {
-                    if (MODE == 0) {
-                        a[e] += (double)xv[e];
-                        b[e] += (double)xv[e] * (double)xv[e];
-                    } else {
-                        a[e] += (double)dv[e];
-                        b[e] += (double)dv[e] * (double)((xv[e] - mu[e]) * rs[e]);
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) {
+                        if (MODE == 0) {
+                            a[e] += (double)xv[u][e];
+                            b[e] += (double)xv[u][e] * (double)xv[u][e];
+                        } else {
+                            a[e] += (double)dv[u][e];
+                            b[e] += (double)dv[u][e] * (double)((xv[u][e] - mu[e]) * rs[e]);
+                        }
                     }
                 }
             }
@@ -131,20 +206,125 @@ bn_partial_kernel(int n, int C, int G, int inner, int lanes_c, int row_lanes, co
             red[1][e][tid] = b[e];
         }
         __syncthreads();
+        // block reduction over the row lanes in a fixed order; with many row lanes (narrow layers: 64 of them for 16
+        // channels) in two levels -- eight lanes per channel lane sum every eighth partial, then one sums the eight --
+        // instead of one thread walking 64 dependent LDS reads
+        const int RG = row_lanes >= 16 ? 8 : 1;
+        double aa[VEC], bb[VEC];
+        if (rl < RG && c < C) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                aa[e] = 0.0; bb[e] = 0.0;
+                for (int q = rl; q < row_lanes; q += RG) {
+                    aa[e] += red[0][e][q * lanes_c + cl];
+                    bb[e] += red[1][e][q * lanes_c + cl];
+                }
+            }
+        }
+        if (RG > 1) {
+            __syncthreads();
+            if (rl < RG && c < C) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    red[0][e][rl * lanes_c + cl] = aa[e];
+                    red[1][e][rl * lanes_c + cl] = bb[e];
+                }
+            }
+            __syncthreads();
+            if (rl == 0 && c < C) {
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) {
+                    aa[e] = 0.0; bb[e] = 0.0;
+                    for (int q = 0; q < RG; ++q) {
+                        aa[e] += red[0][e][q * lanes_c + cl];
+                        bb[e] += red[1][e][q * lanes_c + cl];
+                    }
+                }
+            }
+        }
         if (rl == 0 && c < C) {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
-                double aa = a[e], bb = b[e];
-                for (int q = 1; q < row_lanes; ++q) {
-                    aa += red[0][e][q * lanes_c + cl];
-                    bb += red[1][e][q * lanes_c + cl];
-                }
                 double* out = partial + (((long)g * S + s) * C + c + e) * 2;
-                out[0] = aa;
-                out[1] = bb;
+                if (fo.tickets) {
+                    bn_st(out, aa[e]);
+                    bn_st(out + 1, bb[e]);
+                } else {
+                    out[0] = aa[e];
+                    out[1] = bb[e];
+                }
             }
         }
         __syncthreads();
+    }
+    if (!fo.tickets) return;
+    // ---- folded finalize: last workgroup of group g, then last group of the problem
+    unsigned* tk = fo.tickets + (long)blockIdx.z * (G + 1);
+    double* flag = &red[0][0][256];
+    if (!bn_last_arriver(tk + g, (unsigned)S, flag)) return;
+    if (MODE == 0) {
+        float* mean_o = fo.mean + (long)blockIdx.z * bb.ss;
+        float* rstd_o = fo.rstd + (long)blockIdx.z * bb.ss;
+        float* var_o = fo.var_out ? fo.var_out + (long)blockIdx.z * bb.ss : nullptr;
+        double* gs = fo.gsum + (long)blockIdx.z * (bb.wsb / (long)sizeof(double));       // [G][C][2]: (mean, var) in fp64
+        for (int c = tid; c < C; c += 256) {
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < S; ++q) {
+                const double* p = partial + (((long)g * S + q) * C + c) * 2;
+                a += bn_ld(p);
+                b += bn_ld(p + 1);
+            }
+            const double mu = a / n;
+            double var = b / n - mu * mu;   // biased variance
+            if (var < 0.0) var = 0.0;
+            mean_o[g * C + c] = (float)mu;
+            rstd_o[g * C + c] = (float)(1.0 / sqrt(var + BN_EPS));
+            if (var_o) var_o[g * C + c] = (float)var;
+            bn_st(gs + ((long)g * C + c) * 2 + 0, mu);
+            bn_st(gs + ((long)g * C + c) * 2 + 1, var);
+        }
+        if (!fo.moving_mean) return;
+        if (!bn_last_arriver(tk + G, (unsigned)G, flag)) return;
+        // one moving-average update per group, in group order (same arithmetic as bn_update_moving_kernel)
+        if (*fo.err != 0u) return;
+        float* mmp = fo.moving_mean + (long)blockIdx.z * bb.ms;
+        float* mvp = fo.moving_var + (long)blockIdx.z * bb.ms;
+        for (int c = tid; c < C; c += 256) {
+            float mm = mmp[c], mv = mvp[c];
+            for (int q = 0; q < G; ++q) {
+                mm = fo.decay * mm + (1.f - fo.decay) * (float)bn_ld(gs + ((long)q * C + c) * 2 + 0);
+                mv = fo.decay * mv + (1.f - fo.decay) * (float)bn_ld(gs + ((long)q * C + c) * 2 + 1);
+            }
+            mmp[c] = mm;
+            mvp[c] = mv;
+        }
+    } else {
+        float* m12 = (float*)((char*)fo.m12 + (long)blockIdx.z * bb.wsb);
+        double* gs = (double*)((char*)fo.gsum + (long)blockIdx.z * bb.wsb);               // [G][C][2]: the group sums
+        for (int c = tid; c < C; c += 256) {
+            double a = 0.0, b = 0.0;
+            for (int q = 0; q < S; ++q) {
+                const double* p = partial + (((long)g * S + q) * C + c) * 2;
+                a += bn_ld(p);
+                b += bn_ld(p + 1);
+            }
+            m12[((long)g * C + c) * 2 + 0] = (float)(a / n);
+            m12[((long)g * C + c) * 2 + 1] = (float)(b / n);
+            bn_st(gs + ((long)g * C + c) * 2 + 0, a);
+            bn_st(gs + ((long)g * C + c) * 2 + 1, b);
+        }
+        if (!bn_last_arriver(tk + G, (unsigned)G, flag)) return;
+        float* dgp = fo.dgamma ? fo.dgamma + (long)blockIdx.z * bb.ps : nullptr;
+        float* dbp = fo.dbeta ? fo.dbeta + (long)blockIdx.z * bb.ps : nullptr;
+        for (int c = tid; c < C; c += 256) {
+            double sb = 0.0, sg = 0.0;
+            for (int q = 0; q < G; ++q) {
+                sb += bn_ld(gs + ((long)q * C + c) * 2 + 0);
+                sg += bn_ld(gs + ((long)q * C + c) * 2 + 1);
+            }
+            if (dgp) dgp[c] = (float)sg;
+            if (dbp) dbp[c] = (float)sb;
+        }
     }
 }
 
@@ -222,13 +402,92 @@ bn_finalize_bwd_kernel(int n, int C, int G, int S, const double* partial, float*
     }
 }
 
+// Round 3: one wavefront per (group, channel) instead of one per channel walking the groups in turn (10 dependent
+// rounds of loads + two fp64 wave reductions: 9-11 us for the conv layers, six of them per step on the critical
+// path).  What needs the groups in order -- the moving-average updates -- moves to one extra workgroup of the
+// apply launch, which reads the (mean, var) pairs this kernel leaves in fp64 at gs[(g*C + c)*2].
+__global__ void __launch_bounds__(256)
+bn_finalize_fwd_gc_kernel(int n, int C, int G, int S, const double* partial, float* mean, float* rstd,
+                          float* var_out, double* gs, BnBatch bb) {
+    BN_SHIFT_WS(partial, const double); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss); BN_SHIFT(var_out, bb.ss);
+    BN_SHIFT_WS(gs, double);
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (idx >= G * C) return;
+    const int g = idx / C, c = idx - g * C;
+    double a = 0.0, b = 0.0;
+    for (int s = lane; s < S; s += 64) {
+        const double* p = partial + (((long)g * S + s) * C + c) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    a = wave_reduce_sum(a);
+    b = wave_reduce_sum(b);
+    const double mu = a / n;
+    double var = b / n - mu * mu;   // biased variance
+    if (var < 0.0) var = 0.0;
+    if (lane == 0) {
+        mean[idx] = (float)mu;
+        rstd[idx] = (float)(1.0 / sqrt(var + BN_EPS));
+        if (var_out) var_out[idx] = (float)var;
+        gs[(long)idx * 2 + 0] = mu;
+        gs[(long)idx * 2 + 1] = var;
+    }
+}
+// the extra workgroup of the apply launch: one moving-average update per group, in group order
+__device__ __forceinline__ void bn_moving_update(int C, int G, const double* gs, float* moving_mean, float* moving_var,
+                                                 float decay, const unsigned* err) {
+    if (*err != 0u) return;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mm = moving_mean[c], mv = moving_var[c];
+        for (int g = 0; g < G; ++g) {
+            mm = decay * mm + (1.f - decay) * (float)gs[((long)g * C + c) * 2 + 0];
+            mv = decay * mv + (1.f - decay) * (float)gs[((long)g * C + c) * 2 + 1];
+        }
+        moving_mean[c] = mm;
+        moving_var[c] = mv;
+    }
+}
+struct BnMoving {        // null moving_mean: no update (the extra workgroup is not launched)
+    const double* gs; float* moving_mean; float* moving_var; float decay; const unsigned* err; int nblk;
+};
+// backward: m12 per (group, channel) + the group sums in fp64 at gs; dgamma / dbeta = sums over the groups are
+// taken by the column-sum finalize launch that follows the apply pass
+__global__ void __launch_bounds__(256)
+bn_finalize_bwd_gc_kernel(int n, int C, int G, int S, const double* partial, float* m12, double* gs, BnBatch bb) {
+    BN_SHIFT_WS(partial, const double); BN_SHIFT_WS(m12, float); BN_SHIFT_WS(gs, double);
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (idx >= G * C) return;
+    const int g = idx / C, c = idx - g * C;
+    double a = 0.0, b = 0.0;
+    for (int s = lane; s < S; s += 64) {
+        const double* p = partial + (((long)g * S + s) * C + c) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    a = wave_reduce_sum(a);
+    b = wave_reduce_sum(b);
+    if (lane == 0) {
+        m12[(long)idx * 2 + 0] = (float)(a / n);
+        m12[(long)idx * 2 + 1] = (float)(b / n);
+        gs[(long)idx * 2 + 0] = a;
+        gs[(long)idx * 2 + 1] = b;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 bn_apply_fwd_kernel(long R, int C, int G, int inner, const float* x, const float* gamma,
-                    const float* beta, const float* mean, const float* rstd, float* y, BnBatch bb) {
+                    const float* beta, const float* mean, const float* rstd, float* y, BnBatch bb, BnMoving mo) {
+    if ((int)blockIdx.x == mo.nblk) {
+        bn_moving_update(C, G, (const double*)((const char*)mo.gs + (long)blockIdx.z * bb.wsb),
+                         mo.moving_mean + (long)blockIdx.z * bb.ms, mo.moving_var + (long)blockIdx.z * bb.ms, mo.decay, mo.err);
+        return;
+    }
     BN_SHIFT(x, bb.xs); BN_SHIFT(gamma, bb.ps); BN_SHIFT(beta, bb.ps); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss);
     BN_SHIFT(y, bb.ys);
     const long total = R * C;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)mo.nblk * 256L) {
         const long r = idx / C;
         const int c = (int)(idx - r * C);
         const int g = (int)((r / inner) % G);
@@ -238,12 +497,17 @@ bn_apply_fwd_kernel(long R, int C, int G, int inner, const float* x, const float
 
 __global__ void __launch_bounds__(256)
 bn_apply_fwd_vec4_kernel(long R, int C, int G, int inner, const float* x, const float* gamma,
-                         const float* beta, const float* mean, const float* rstd, float* y, BnBatch bb) {
+                         const float* beta, const float* mean, const float* rstd, float* y, BnBatch bb, BnMoving mo) {
+    if ((int)blockIdx.x == mo.nblk) {
+        bn_moving_update(C, G, (const double*)((const char*)mo.gs + (long)blockIdx.z * bb.wsb),
+                         mo.moving_mean + (long)blockIdx.z * bb.ms, mo.moving_var + (long)blockIdx.z * bb.ms, mo.decay, mo.err);
+        return;
+    }
     BN_SHIFT(x, bb.xs); BN_SHIFT(gamma, bb.ps); BN_SHIFT(beta, bb.ps); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss);
     BN_SHIFT(y, bb.ys);
     const int C4 = C >> 2;
     const long total = R * C4;
-    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)gridDim.x * 256L) {
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < total; idx += (long)mo.nblk * 256L) {
         const long r = idx / C4;
         const int c = (int)(idx - r * C4) * 4;
         const int g = (int)((r / inner) % G);
@@ -273,7 +537,7 @@ bn_apply_bwd_kernel(int R, int C, int G, int inner, const float* __restrict__ x,
                     const float* __restrict__ dy, const float* __restrict__ gamma,
                     const float* __restrict__ mean, const float* __restrict__ rstd,
                     const float* __restrict__ m12, int act_bwd, float* __restrict__ dx,
-                    float* __restrict__ colpart, BnBatch bb) {
+                    float* __restrict__ colpart, BnBatch bb, unsigned* sum_ticket, float* __restrict__ colsum_out) {
     BN_SHIFT(x, bb.xs); BN_SHIFT(dy, bb.xs); BN_SHIFT(gamma, bb.ps); BN_SHIFT(mean, bb.ss); BN_SHIFT(rstd, bb.ss);
     BN_SHIFT_WS(m12, const float); BN_SHIFT(dx, bb.ys);
     if (colpart) BN_SHIFT_WS(colpart, float);
@@ -328,14 +592,36 @@ bn_apply_bwd_kernel(int R, int C, int G, int inner, const float* __restrict__ x,
             const int cvv = c / VEC, j = c % VEC;
             float t = 0.f;
             for (int tt = (cvv - base + CV) % CV; tt < 256; tt += CV) t += red[tt][j];
-            colpart[(long)blockIdx.x * C + c] = t;
+            if (sum_ticket) bn_st(colpart + (long)blockIdx.x * C + c, t);
+            else colpart[(long)blockIdx.x * C + c] = t;
+        }
+        if (!sum_ticket) return;
+        // folded column-sum finalize (few blocks x channels): the last workgroup adds the per-block rows in block
+        // order -- thread (c, j) takes blocks j, j + P, ..., the P strided sums of a channel meet in LDS, fixed order
+        __shared__ double red2[256 + 1];
+        if (!bn_last_arriver(sum_ticket + blockIdx.z, gridDim.x, &red2[256])) return;
+        float* out = colsum_out + (long)blockIdx.z * bb.ps;
+        int Cp = 1;
+        while (Cp < C) Cp <<= 1;                          // C <= 256 (host checks)
+        const int P = 256 / Cp;
+        const int c = threadIdx.x % Cp, j = threadIdx.x / Cp;
+        double acc = 0.0;
+        if (c < C)
+            for (int b = j; b < (int)gridDim.x; b += P) acc += (double)bn_ld(colpart + (long)b * C + c);
+        red2[threadIdx.x] = acc;
+        __syncthreads();
+        if (j == 0 && c < C) {
+            double t = 0.0;
+            for (int q = 0; q < P; ++q) t += red2[q * Cp + c];
+            out[c] = (float)t;
         }
     }
 }
 
 // out[c] = sum over blocks of colpart[block][c] (fixed order: deterministic)
 __global__ void __launch_bounds__(256)
-bn_colsum_finalize_kernel(int C, int nblocks, const float* __restrict__ colpart, float* __restrict__ out, BnBatch bb) {
+bn_colsum_finalize_kernel(int C, int nblocks, const float* __restrict__ colpart, float* __restrict__ out, BnBatch bb,
+                          int G, const double* gs, float* dgamma, float* dbeta) {
     BN_SHIFT_WS(colpart, const float); BN_SHIFT(out, bb.ps);
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -344,6 +630,16 @@ bn_colsum_finalize_kernel(int C, int nblocks, const float* __restrict__ colpart,
     for (int b = lane; b < nblocks; b += 64) acc += (double)colpart[(long)b * C + c];
     acc = wave_reduce_sum(acc);
     if (lane == 0) out[c] = (float)acc;
+    if (gs && lane == 0) {            // dgamma / dbeta: the group sums of bn_finalize_bwd_gc_kernel, in group order
+        BN_SHIFT_WS(gs, const double);
+        double sb = 0.0, sg = 0.0;
+        for (int g = 0; g < G; ++g) {
+            sb += gs[((long)g * C + c) * 2 + 0];
+            sg += gs[((long)g * C + c) * 2 + 1];
+        }
+        if (dgamma) (dgamma + (long)blockIdx.z * bb.ps)[c] = (float)sg;
+        if (dbeta) (dbeta + (long)blockIdx.z * bb.ps)[c] = (float)sb;
+    }
 }
 
 static int bn_check(int R, int C, int G, int inner) {
@@ -382,27 +678,49 @@ static int bn_fwd_impl(int nb, long xs, long ys, long ps, long ms, int R, int C,
     double* partial = (double*)ws;
     const bool al = ((xs | ys | ps) % 4) == 0;
     const bool vec4 = (C % 4 == 0) && (((uintptr_t)x & 15) == 0) && al;
+    // (the workspace stride of a single problem is 0 in bb: the fold needs none, it has one problem)
+    BnFold fo{};
+    if (bn_fold_ok(nb, G, p.S, C)) {
+        fo.tickets = bn_ticket_slot();
+        fo.mean = mean; fo.rstd = rstd; fo.var_out = var_out; fo.moving_mean = moving_mean; fo.moving_var = moving_var;
+        fo.decay = decay; fo.err = (const unsigned*)d2p_persist_err_ptr();
+        fo.gsum = partial + (size_t)G * p.S * C * 2;
+    }
     if (vec4)
         hipLaunchKernelGGL((bn_partial_kernel<0, 4>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
                            p.lanes_c, p.row_lanes, x, (const float*)nullptr, (const float*)nullptr,
-                           (const float*)nullptr, partial, bb);
+                           (const float*)nullptr, partial, bb, fo);
     else
         hipLaunchKernelGGL((bn_partial_kernel<0, 1>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
                            (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, (const float*)nullptr,
-                           (const float*)nullptr, (const float*)nullptr, partial, bb);
+                           (const float*)nullptr, (const float*)nullptr, partial, bb, fo);
     D2P_LAUNCH_CHECK("bn_partial_fwd");
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, n, C, G,
-                       p.S, partial, mean, rstd, var_out, moving_mean, moving_var, decay,
-                       (const unsigned*)d2p_persist_err_ptr(), bb);
-    D2P_LAUNCH_CHECK("bn_finalize_fwd");
+    double* gsum = partial + (size_t)G * p.S * C * 2;
+    BnMoving mo{gsum, nullptr, nullptr, decay, (const unsigned*)d2p_persist_err_ptr(), 0};
+    if (!fo.tickets) {
+        if (g_bn_gc) {
+            hipLaunchKernelGGL(bn_finalize_fwd_gc_kernel, dim3(ceil_div(G * C, 4), 1, nb), dim3(256), 0, st, n, C, G, p.S,
+                               partial, mean, rstd, var_out, gsum, bb);
+            mo.moving_mean = moving_mean;           // the apply launch's extra workgroup updates them
+            mo.moving_var = moving_var;
+        } else {
+            hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, n, C, G,
+                               p.S, partial, mean, rstd, var_out, moving_mean, moving_var, decay,
+                               (const unsigned*)d2p_persist_err_ptr(), bb);
+        }
+        D2P_LAUNCH_CHECK("bn_finalize_fwd");
+    }
     const bool vec = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma |
                                               (uintptr_t)beta | (uintptr_t)mean | (uintptr_t)rstd) & 15) == 0);
+    const int extra = mo.moving_mean ? 1 : 0;
     if (vec) {
-        hipLaunchKernelGGL(bn_apply_fwd_vec4_kernel, dim3(ew_blocks((long)R * C / 4), 1, nb), dim3(256), 0,
-                           st, (long)R, C, G, inner, x, gamma, beta, mean, rstd, y, bb);
+        mo.nblk = ew_blocks((long)R * C / 4);
+        hipLaunchKernelGGL(bn_apply_fwd_vec4_kernel, dim3(mo.nblk + extra, 1, nb), dim3(256), 0,
+                           st, (long)R, C, G, inner, x, gamma, beta, mean, rstd, y, bb, mo);
     } else {
-        hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(ew_blocks((long)R * C), 1, nb), dim3(256), 0, st,
-                           (long)R, C, G, inner, x, gamma, beta, mean, rstd, y, bb);
+        mo.nblk = ew_blocks((long)R * C);
+        hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(mo.nblk + extra, 1, nb), dim3(256), 0, st,
+                           (long)R, C, G, inner, x, gamma, beta, mean, rstd, y, bb, mo);
     }
     D2P_LAUNCH_CHECK("bn_apply_fwd");
     return D2P_OK;
@@ -447,38 +765,62 @@ static int bn_bwd_impl(int nb, long xs, long ys, long ps, int R, int C, int G, i
     float* m12 = (float*)(gsum + (size_t)G * C * 2);
     const bool al = ((xs | ys | ps) % 4) == 0;
     const bool vec4 = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
+    BnFold fo{};
+    unsigned* tickets = nullptr;
+    if (bn_fold_ok(nb, G, p.S, C)) {
+        tickets = fo.tickets = bn_ticket_slot();
+        fo.m12 = m12; fo.dgamma = dgamma; fo.dbeta = dbeta; fo.gsum = gsum;
+    }
     if (vec4)
         hipLaunchKernelGGL((bn_partial_kernel<1, 4>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
-                           p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial, bb);
+                           p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial, bb, fo);
     else
         hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
-                           (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, dy, mean, rstd, partial, bb);
+                           (C < 256 ? C : 256), 256 / (C < 256 ? C : 256), x, dy, mean, rstd, partial, bb, fo);
     D2P_LAUNCH_CHECK("bn_partial_bwd");
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, n, C, G,
-                       p.S, partial, m12, dgamma, dbeta, bb);
-    D2P_LAUNCH_CHECK("bn_finalize_bwd");
+    // dgamma / dbeta by the column-sum finalize launch (it exists when the bias gradient is asked for) from the fp64
+    // group sums, m12 by one wavefront per (group, channel)
+    const bool gc = !fo.tickets && g_bn_gc && dx_colsum != nullptr;
+    if (gc) {
+        hipLaunchKernelGGL(bn_finalize_bwd_gc_kernel, dim3(ceil_div(G * C, 4), 1, nb), dim3(256), 0, st, n, C, G, p.S,
+                           partial, m12, gsum, bb);
+        D2P_LAUNCH_CHECK("bn_finalize_bwd");
+    } else if (!fo.tickets) {
+        hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, n, C, G,
+                           p.S, partial, m12, dgamma, dbeta, bb);
+        D2P_LAUNCH_CHECK("bn_finalize_bwd");
+    }
     const bool v4 = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
     float* colpart = (float*)((char*)m12 + align_up((size_t)G * C * 2 * sizeof(float), 16));
     if (dx_colsum) {
         const int vec = v4 ? 4 : 1;
         const int blocks = bn_sum_blocks(R, C, vec);
+        // column-sum finalize folded into the apply launch when its input is small (conv layers: <= 1024 blocks x
+        // 16-48 channels); the ticket sits behind the partial-sum tickets of the same slot (or in a slot of its own)
+        unsigned* sum_ticket = nullptr;
+        if (g_bn_fold && C <= 256 && (long)blocks * C <= 65536 && nb * (G + 2) <= BN_TICKET_WORDS)
+            sum_ticket = (tickets ? tickets : bn_ticket_slot()) + nb * (G + 1);
         if (v4)
             hipLaunchKernelGGL((bn_apply_bwd_kernel<4, true>), dim3(blocks, 1, nb), dim3(256), 0, st, R, C, G, inner, x,
-                               dy, gamma, mean, rstd, m12, act_bwd, dx, colpart, bb);
+                               dy, gamma, mean, rstd, m12, act_bwd, dx, colpart, bb, sum_ticket, dx_colsum);
         else
             hipLaunchKernelGGL((bn_apply_bwd_kernel<1, true>), dim3(blocks, 1, nb), dim3(256), 0, st, R, C, G, inner, x,
-                               dy, gamma, mean, rstd, m12, act_bwd, dx, colpart, bb);
+                               dy, gamma, mean, rstd, m12, act_bwd, dx, colpart, bb, sum_ticket, dx_colsum);
         D2P_LAUNCH_CHECK("bn_apply_bwd");
-        hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, C, blocks, colpart,
-                           dx_colsum, bb);
-        D2P_LAUNCH_CHECK("bn_colsum_finalize");
+        if (!sum_ticket) {
+            hipLaunchKernelGGL(bn_colsum_finalize_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, C, blocks, colpart,
+                               dx_colsum, bb, G, gc ? (const double*)gsum : (const double*)nullptr, dgamma, dbeta);
+            D2P_LAUNCH_CHECK("bn_colsum_finalize");
+        }
     } else {
         if (v4)
             hipLaunchKernelGGL((bn_apply_bwd_kernel<4, false>), dim3(ew_blocks((long)R * C / 4), 1, nb), dim3(256), 0, st,
-                               R, C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr, bb);
+                               R, C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr, bb,
+                               (unsigned*)nullptr, (float*)nullptr);
         else
             hipLaunchKernelGGL((bn_apply_bwd_kernel<1, false>), dim3(ew_blocks((long)R * C), 1, nb), dim3(256), 0, st, R,
-                               C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr, bb);
+                               C, G, inner, x, dy, gamma, mean, rstd, m12, act_bwd, dx, (float*)nullptr, bb,
+                               (unsigned*)nullptr, (float*)nullptr);
         D2P_LAUNCH_CHECK("bn_apply_bwd");
     }
     return D2P_OK;

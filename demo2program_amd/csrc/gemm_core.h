@@ -963,6 +963,7 @@ static inline GemmPlan d2p_plan_gemm_base(int M, int N, int K, bool allow_split)
 }
 
 static int g_gemm_small_ksr = 1;   // 0: never pick the 32x32 wave-split tile automatically
+static int g_gemm_dma_big = 0;     // experiment: large dense GEMMs (>= 2 GFLOP) on the persistent LDS-DMA kernel
 
 static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
     GemmPlan p = d2p_plan_gemm_base(M, N, K, allow_split);
@@ -1049,6 +1050,8 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
     D2pProfScope prof(st, prof_family, 2.0 * M * N * K * batch);
     // a strided batch (grid.y) never splits K: the slabs of different problems would need their own scratch
     GemmPlan p = d2p_plan_gemm(M, N, K, ws != nullptr && batch == 1);
+    if (g_gemm_dma_big && g_gemm_force_tile < 0 && 2.0 * M * N * K >= 2e9 && p.bm == 64 && p.bn == 64)
+        p.tile = TILE_DMA_64x64_S4;
     float* partial = nullptr;
     if (p.slabs > 1) {
         const size_t need = (size_t)p.slabs * M * N * sizeof(float);

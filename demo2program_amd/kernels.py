@@ -284,6 +284,13 @@ def bn_update_moving(mean, var, moving_mean, moving_var, decay=0.9):
                               current_stream())
 
 
+def bn_set_fold(bits):
+    """Process-global A/B switch (d2p_bn_set_fold): bit 0 = batch-norm finalize steps folded into the partial-sum /
+    apply launches by tickets (off by default: no gain), bit 1 = the round-2 finalize kernels (one wavefront per
+    channel walking the groups) instead of one wavefront per (group, channel)."""
+    call.d2p_bn_set_fold(int(bits))
+
+
 # ---------------------------------------------------------------- LSTM
 def set_lstm_fused(on):
     """Process-global knob: fused recurrent-step kernels (default) vs GEMM + gate per step."""

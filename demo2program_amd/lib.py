@@ -51,6 +51,7 @@ SIGNATURES = {
     'd2p_bn_group_fwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_float, P, c_size_t, S]),
     'd2p_bn_group_bwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, c_size_t, S]),
     'd2p_bn_inference_fwd': (c_int, [c_int, c_int, P, P, P, P, P, P, S]),
+    'd2p_bn_set_fold': (c_int, [c_int]),
     'd2p_bn_update_moving': (c_int, [c_int, c_int, c_float, P, P, P, P, S]),
     'd2p_lstm_gate_fwd': (c_int, [c_int, c_int, P, c_long, P, P, P, c_int, P, P, P, S]),
     'd2p_lstm_gate_bwd': (c_int, [c_int, c_int, P, c_long, P, P, P, P, P, c_int, P, P, c_long, P, S]),

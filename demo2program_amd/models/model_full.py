@@ -195,6 +195,10 @@ class Model(object):
         self.token_projection = os.environ.get('D2P_TOKEN_PROJECTION', '1') == '1'
         self.use_side_stream = (os.environ.get('D2P_SIDE_STREAM', '1') == '1' and
                                 os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1')
+        if os.environ.get('D2P_GEMM_OPTION') is not None:          # experiments (d2p_gemm_set_option bits)
+            from ..lib import call
+            call.d2p_gemm_set_option(int(os.environ['D2P_GEMM_OPTION']))
+        K.bn_set_fold(int(os.environ.get('D2P_BN_FOLD', '0')))   # bit 0: ticket fold (no gain), bit 1: round-2 finalize
         self._reserve_scratch()
 
     # ------------------------------------------------------------------ plumbing
@@ -1196,7 +1200,7 @@ class Model(object):
         advancing together (one launch per step for all of them).  Returns their dz buffers."""
         p, g = self.params.p, self.params.g
         U = self.num_lstm_cell_units
-        seqs, dzs = [], []
+        seqs, dzs, wproj = [], [], []
         for (e, dlogits, dh0, dc0) in specs:
             scope, R, T, n, V = e['scope'], e['M'], e['T'], e['n'], e['token_dim']
             rows = n * R
@@ -1204,7 +1208,7 @@ class Model(object):
             dz = self._buf(e['name'] + '/dz', (T * R, 4 * U))
             dzs.append(dz)
             if rows > 0:
-                K.gemm_raw('tn', U, V, rows, e['hout'].view(T * R, U), U, dlogits, V, g[scope + '/proj'], V)
+                wproj.append((U, V, rows, e['hout'].view(T * R, U), dlogits, g[scope + '/proj']))
                 K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
                 seqs.append(dict(M=R, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], cs=e['cs'],
                                  dhout=dhout, dz=dz, dh0=dh0, dc0=dc0, db=g[e['name'] + '/bias']))
@@ -1214,6 +1218,16 @@ class Model(object):
                 dh0.zero_()
                 dc0.zero_()
             e['db_done'] = True
+        # the projections' weight gradients (K = all rows: split-K launches + their combine passes) feed nothing in
+        # backward: on the side stream, beside the recurrences (D2P_WPROJ_SIDE=0: in front of them, round 2's place)
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        on_side = side != main and os.environ.get('D2P_WPROJ_SIDE', '1') == '1'
+        if on_side and wproj:
+            side.wait_stream(main)
+        with torch.cuda.stream(side if on_side else main):
+            for (U_, V, rows, hout2d, dlogits, gproj) in wproj:
+                K.gemm_raw('tn', U_, V, rows, hout2d, U_, dlogits, V, gproj, V)
         if seqs:
             K.lstm_seq_bwd_multi(seqs)
         return dzs

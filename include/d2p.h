@@ -193,6 +193,11 @@ int d2p_bn_inference_fwd(int R, int C, const float* x, const float* gamma, const
  * reference updates once per Demo_Encoder call).  moving_mean/var: [C]. */
 int d2p_bn_update_moving(int C, int G, float decay, const float* mean, const float* var,
                          float* moving_mean, float* moving_var, d2p_stream_t stream);
+/* Tuning / A-B switch (process-global, default 0 -- measured equal to slightly slower on MI355X): 1 = the finalize step of a training-mode batch norm with few
+ * partial sums per group (the conv layers) runs inside the partial-sum launch -- the last workgroup of each group
+ * folds that group, the last group updates the moving statistics / dgamma, dbeta -- and the bias-gradient column
+ * sums inside the backward apply launch; 0 (default) = separate finalize launches.  Same sums in a fixed order either way. */
+int d2p_bn_set_fold(int bits);   /* bit 1 set: the round-2 finalize kernels (one wavefront per channel over all groups) */
 
 /* ---- K3/K4: LSTM gate pointwise, standalone ----------------------------------------
  * Replaces the elementwise tail of rnn.BasicLSTMCell.call (models/model_full.py:244-246):
