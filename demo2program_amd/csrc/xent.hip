@@ -123,6 +123,101 @@ xent_bwd_kernel(int R, int V, int G, int n_steps, const float* logits, LabelView
     }
 }
 
+// ---- loss backward of several decoders in ONE launch, through the output projection -------------------------------
+// dlogits = d loss / d logits (as xent_bwd_kernel) AND dhout = dlogits . proj^T (the Dense(use_bias=False) projection
+// of models/model_full.py:463-464, proj [U, V]) for up to three decoders: round 2 ran three xent_bwd launches and
+// three K = V (5 / 6 / 50) GEMMs in front of the backward recurrences.  A workgroup takes 16 logits rows: each wave
+// turns 4 of them into dlogits (one lane per token, cross-lane reductions), the rows meet in LDS, then every thread
+// owns 2 units x 16 rows of dhout (V multiply-adds each; proj rows stay in registers).
+#define XB_ROWS 16
+#define XB_MAXV 64
+struct XbProb {
+    int mode, R, V, G, n_steps, U;
+    const float* logits; LabelView lab; const int* lens; const float* den; float scale;
+    float* dlogits; const float* proj; float* dhout;
+    int blk0;             // first workgroup of this problem
+};
+struct XbArgs { int n; XbProb p[3]; };
+
+__global__ void __launch_bounds__(256)
+xent_bwd_dhout_kernel(XbArgs a) {
+    __shared__ float dl[XB_ROWS][XB_MAXV];
+    int pi = 0;
+    if (a.n > 1 && (int)blockIdx.x >= a.p[1].blk0) pi = 1;
+    if (a.n > 2 && (int)blockIdx.x >= a.p[2].blk0) pi = 2;
+    const XbProb& q = a.p[pi];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long nrows = (long)q.n_steps * q.R;
+    const long row0 = ((long)blockIdx.x - q.blk0) * XB_ROWS;
+    const int V = q.V;
+    for (int i = 0; i < 4; ++i) {
+        const int lr = wave * 4 + i;
+        const long row = row0 + lr;
+        float out = 0.f;
+        if (row < nrows) {
+            const int t = (int)(row / q.R), r = (int)(row - (long)t * q.R);
+            const float* x = q.logits + row * V;
+            if (t < q.lens[r]) {
+                const float w = q.scale / ((float)q.G * q.den[r % q.G]);
+                if (q.mode == 0) {
+                    float mx = lane < V ? x[lane] : -INFINITY;
+                    mx = wave_reduce_max(mx);
+                    const float ex = lane < V ? expf(x[lane] - mx) : 0.f;
+                    const float se = wave_reduce_sum(ex);
+                    // [TF-1.3] SoftmaxCrossEntropyWithLogits backprop = softmax - labels
+                    if (lane < V) out = w * (ex * (1.f / se) - q.lab.at(r, t, lane));
+                } else if (lane < V) {
+                    out = (w / (float)V) * (d2p_sigmoid(x[lane]) - q.lab.at(r, t, lane));
+                }
+            }
+            if (lane < V) q.dlogits[row * V + lane] = out;
+        }
+        dl[lr][lane] = lane < V ? out : 0.f;
+    }
+    __syncthreads();
+    const int U = q.U;
+    for (int u = threadIdx.x; u < U; u += 256) {
+        float acc[XB_ROWS];
+#pragma unroll
+        for (int r = 0; r < XB_ROWS; ++r) acc[r] = 0.f;
+        const float* pr = q.proj + (long)u * V;
+        for (int v = 0; v < V; ++v) {
+            const float w = pr[v];
+#pragma unroll
+            for (int r = 0; r < XB_ROWS; ++r) acc[r] += dl[r][v] * w;
+        }
+#pragma unroll
+        for (int r = 0; r < XB_ROWS; ++r)
+            if (row0 + r < nrows) q.dhout[(row0 + r) * U + u] = acc[r];
+    }
+}
+
+extern "C" int d2p_xent_bwd_dhout_multi(int nprob, const d2p_xent_bwd_desc* d, d2p_stream_t stream) {
+    D2P_REQUIRE(nprob >= 1 && nprob <= 3 && d, D2P_EINVAL, "xent_bwd_dhout: 1..3 problems");
+    XbArgs a;
+    a.n = 0;
+    int blocks = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const d2p_xent_bwd_desc& q = d[i];
+        D2P_REQUIRE(q.R >= 0 && q.V > 0 && q.V <= XB_MAXV && q.G > 0 && q.n_steps >= 0 && q.U > 0 && q.R % q.G == 0,
+                    D2P_EINVAL, "xent_bwd_dhout: bad sizes R=%d V=%d G=%d n_steps=%d U=%d", q.R, q.V, q.G, q.n_steps, q.U);
+        if (q.n_steps == 0 || q.R == 0) continue;
+        D2P_REQUIRE(q.logits && q.labels && q.lens && q.den && q.dlogits && q.proj && q.dhout, D2P_EINVAL,
+                    "xent_bwd_dhout: null pointer");
+        XbProb& o = a.p[a.n++];
+        o.mode = q.sigmoid ? 1 : 0; o.R = q.R; o.V = q.V; o.G = q.G; o.n_steps = q.n_steps; o.U = q.U;
+        o.logits = q.logits; o.lab = LabelView{q.labels, q.label_rs, q.label_ts, q.label_vs}; o.lens = q.lens;
+        o.den = q.den; o.scale = q.scale; o.dlogits = q.dlogits; o.proj = q.proj; o.dhout = q.dhout;
+        o.blk0 = blocks;
+        blocks += (int)(((long)q.n_steps * q.R + XB_ROWS - 1) / XB_ROWS);
+    }
+    if (a.n == 0) return D2P_OK;
+    for (int i = a.n; i < 3; ++i) a.p[i] = a.p[0];
+    hipLaunchKernelGGL(xent_bwd_dhout_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    D2P_LAUNCH_CHECK("xent_bwd_dhout");
+    return D2P_OK;
+}
+
 static int xent_check(int T, int R, int V, int G, int n_steps) {
     D2P_REQUIRE(T >= 0 && R >= 0 && V > 0 && G > 0 && n_steps >= 0 && n_steps <= T, D2P_EINVAL,
                 "xent: bad sizes T=%d R=%d V=%d G=%d n_steps=%d", T, R, V, G, n_steps);

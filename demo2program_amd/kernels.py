@@ -478,6 +478,22 @@ def xent_bwd(mode, logits, labels, lab_kind, lens, T, R, V, G, n_steps, den, sca
        ptr(dlogits), current_stream())
 
 
+def xent_bwd_dhout_multi(probs):
+    """One launch: dlogits and dhout = dlogits . proj^T of up to three decoders.  probs: dicts with mode
+    ('softmax' | 'sigmoid'), logits, labels, lab_kind, lens, T, R, V, G, n_steps, den, scale, dlogits, proj, dhout, U."""
+    import ctypes
+    from .lib import XentBwdDesc
+    arr = (XentBwdDesc * len(probs))()
+    for d, q in zip(arr, probs):
+        rs, ts, vs = _lab_strides(q['lab_kind'], q['V'], q['T'])
+        d.sigmoid = 1 if q['mode'] == 'sigmoid' else 0
+        d.R, d.V, d.G, d.n_steps, d.U = q['R'], q['V'], q['G'], q['n_steps'], q['U']
+        d.logits, d.labels, d.label_rs, d.label_ts, d.label_vs = ptr(q['logits']), ptr(q['labels']), rs, ts, vs
+        d.lens, d.den, d.scale = ptr(q['lens']), ptr(q['den']), q['scale']
+        d.dlogits, d.proj, d.dhout = ptr(q['dlogits']), ptr(q['proj']), ptr(q['dhout'])
+    call.d2p_xent_bwd_dhout_multi(len(probs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
+
+
 def loss_assemble(groups, nums, dens, loss, term_losses):
     import ctypes
     arr = (ctypes.c_int * len(groups))(*groups)

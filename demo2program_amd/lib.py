@@ -82,6 +82,7 @@ SIGNATURES = {
     'd2p_softmax_xent_masked_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, c_float, P, S]),
     'd2p_sigmoid_xent_masked_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, P, P, c_size_t, S]),
     'd2p_sigmoid_xent_masked_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, c_float, P, S]),
+    'd2p_xent_bwd_dhout_multi': (c_int, [c_int, P, S]),
     'd2p_loss_assemble': (c_int, [c_int, P, P, P, P, P, S]),
     'd2p_group_mean': (c_int, [c_int, c_int, c_int, P, P, P, S]),
     'd2p_group_mean_bwd': (c_int, [c_int, c_int, c_int, P, P, P, c_int, S]),
@@ -125,6 +126,14 @@ class LstmBwdDesc(ctypes.Structure):
                 ('dhout', c_void_p), ('dh_final', c_void_p), ('dc_final', c_void_p),
                 ('dz', c_void_p), ('dh0', c_void_p), ('dc0', c_void_p),
                 ('ws', c_void_p), ('ws_bytes', c_size_t), ('db', c_void_p)]
+
+
+class XentBwdDesc(ctypes.Structure):
+    """d2p_xent_bwd_desc (include/d2p.h)."""
+    _fields_ = [('sigmoid', c_int), ('R', c_int), ('V', c_int), ('G', c_int), ('n_steps', c_int), ('U', c_int),
+                ('logits', c_void_p), ('labels', c_void_p), ('label_rs', c_long), ('label_ts', c_long),
+                ('label_vs', c_long), ('lens', c_void_p), ('den', c_void_p), ('scale', c_float),
+                ('dlogits', c_void_p), ('proj', c_void_p), ('dhout', c_void_p)]
 
 
 _lib = None

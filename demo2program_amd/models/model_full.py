@@ -906,8 +906,16 @@ class Model(object):
 
         # ---- losses -> dlogits (time-major, first n_steps*R rows)
         dl_p = self._buf('prog/dlogits', (L * B, V))
-        K.xent_bwd('softmax', ctx['dp']['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
-                   dens[0:1], loss_scale, dl_p)
+        # one launch for the loss backward of all decoders AND their dhout = dlogits . proj^T (D2P_FUSED_XENT_BWD=0:
+        # one launch per loss + one K = V GEMM per decoder, round 2's form)
+        fused_xb = os.environ.get('D2P_FUSED_XENT_BWD', '1') == '1' and max(V, A, P) <= 64
+        ctx['fused_xb'] = fused_xb
+        xb = [dict(mode='softmax', logits=ctx['dp']['logits'], labels=feed['program'], lab_kind='bvl', lens=lens_p, T=L,
+                   R=B, V=V, G=1, n_steps=n_p, den=dens[0:1], scale=loss_scale, dlogits=dl_p, proj=p['prog/proj'],
+                   dhout=self._buf('prog/dhout', (L * B, U)), U=U)]
+        if not fused_xb:
+            K.xent_bwd('softmax', ctx['dp']['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
+                       dens[0:1], loss_scale, dl_p)
         d_init = self._buf('d_rn', (2, B, U))
         d_init_h, d_init_c = d_init[0], d_init[1]
         main = torch.cuda.current_stream()
@@ -915,10 +923,19 @@ class Model(object):
         if self.multitask:
             dl_a = self._buf('act/dlogits', (T * M, A))
             dl_q = self._buf('per/dlogits', (T * M, P))
-            K.xent_bwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
-                       dens[1:1 + k], loss_scale, dl_a)
-            K.xent_bwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
-                       dens[1 + k:], loss_scale, dl_q)
+            if fused_xb:
+                xb += [dict(mode='softmax', logits=ctx['da']['logits'], labels=feed['a_h'], lab_kind='rtv', lens=lens_d,
+                            T=T, R=M, V=A, G=k, n_steps=n_d, den=dens[1:1 + k], scale=loss_scale, dlogits=dl_a,
+                            proj=p['act/proj'], dhout=self._buf('act/dhout', (T * M, U)), U=U),
+                       dict(mode='sigmoid', logits=ctx['dq']['logits'], labels=feed['per'], lab_kind='rtv', lens=lens_d,
+                            T=T, R=M, V=P, G=k, n_steps=n_d, den=dens[1 + k:], scale=loss_scale, dlogits=dl_q,
+                            proj=p['per/proj'], dhout=self._buf('per/dhout', (T * M, U)), U=U)]
+                K.xent_bwd_dhout_multi(xb)
+            else:
+                K.xent_bwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                           dens[1:1 + k], loss_scale, dl_a)
+                K.xent_bwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                           dens[1 + k:], loss_scale, dl_q)
 
             d_demo = self._buf('d_demo', (2, M, U))
             d_demo_h, d_demo_c = d_demo[0], d_demo[1]
@@ -988,6 +1005,8 @@ class Model(object):
                 self._call_split(split_cb, main, side)
         else:
             # baselines: the program decoder is the only one
+            if fused_xb:
+                K.xent_bwd_dhout_multi(xb)
             dz_p = self._decoders_bwd_rec([(ctx['dp'], dl_p, d_init_h, d_init_c)])[0]
             side.wait_stream(main)
             with torch.cuda.stream(side):
@@ -1209,7 +1228,8 @@ class Model(object):
             dzs.append(dz)
             if rows > 0:
                 wproj.append((U, V, rows, e['hout'].view(T * R, U), dlogits, g[scope + '/proj']))
-                K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
+                if not self._ctx.get('fused_xb'):       # (else: written with dlogits by d2p_xent_bwd_dhout_multi)
+                    K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
                 seqs.append(dict(M=R, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], cs=e['cs'],
                                  dhout=dhout, dz=dz, dh0=dh0, dc0=dc0, db=g[e['name'] + '/bias']))
             else:

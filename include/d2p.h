@@ -378,6 +378,20 @@ int d2p_sigmoid_xent_masked_bwd(int T, int R, int V, int G, int n_steps, const f
                                 const float* labels, long lab_r_stride, long lab_t_stride,
                                 long lab_v_stride, const int* lens, const float* loss_den,
                                 float scale, float* dlogits, d2p_stream_t stream);
+/* Loss backward of up to three decoders in ONE launch, through their output projections: per problem
+ *   dlogits = d loss / d logits   (exactly d2p_softmax_ / d2p_sigmoid_xent_masked_bwd; first n_steps*R rows), and
+ *   dhout   = dlogits . proj^T    (proj [U, V]: the Dense(use_bias=False) projection, models/model_full.py:463-464;
+ *                                  dhout [n_steps*R, U] is what the backward recurrence reads)
+ * -- the three loss-backward launches and the three K = V products of a training step as one.  V <= 64. */
+typedef struct {
+    int sigmoid;                  /* 0: softmax cross-entropy, 1: sigmoid cross-entropy (mean over V) */
+    int R, V, G, n_steps, U;
+    const float* logits; const float* labels; long label_rs, label_ts, label_vs;
+    const int* lens; const float* den; float scale;
+    float* dlogits; const float* proj; float* dhout;
+} d2p_xent_bwd_desc;
+int d2p_xent_bwd_dhout_multi(int nprob, const d2p_xent_bwd_desc* descs, d2p_stream_t stream);
+
 /* loss[0] = sum_terms (1/G_j) * sum_g num_j[g]/den_j[g]   (models/model_full.py:932,1035-1038,
  * 1078-1079).  nums/dens: concatenated [G_0 + G_1 + ...]; groups: HOST array of n_terms ints. */
 int d2p_loss_assemble(int n_terms, const int* groups, const float* nums, const float* dens,

@@ -1037,3 +1037,40 @@ def test_gemm_tn_over_lists_of_k_rows(K, M, N, R, Kn):
     K.gemm_tn_rows(M, N, Kn, A, M, rowsB.cuda(), Bz, N, rowsB.cuda(), Cl, N)
     full = K.matmul_tn(A, Bz)
     assert (Cl - full).abs().max().item() <= 2e-5 * max(1.0, float(Kn) ** 0.5)
+
+
+@pytest.mark.gpu
+def test_loss_backward_of_three_decoders_and_their_projection_in_one_launch(K):
+    """d2p_xent_bwd_dhout_multi: dlogits of a softmax ('bvl' labels), a grouped softmax and a grouped sigmoid loss
+    AND dhout = dlogits . proj^T of each, in one launch -- dlogits equal to the per-loss kernels' (1e-7), dhout
+    against the fp64 product; ragged row counts, n_steps below T."""
+    g = torch.Generator().manual_seed(41)
+    U = 96
+    probs, refs = [], []
+    for (mode, kind, T, R, V, G) in (('softmax', 'bvl', 9, 5, 50, 1), ('softmax', 'rtv', 7, 12, 6, 3),
+                                     ('sigmoid', 'rtv', 7, 12, 5, 3)):
+        lens = torch.randint(1, T, (R,), generator=g)
+        n_steps = int(lens.max())
+        logits = (torch.rand(T, R, V, generator=g) * 6 - 3).cuda()
+        if mode == 'softmax':
+            lab = F.one_hot(torch.randint(0, V, (R, T), generator=g), V).float()
+        else:
+            lab = torch.randint(0, 2, (R, T, V), generator=g).float()
+        lab = lab * (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
+        labels = (lab.permute(0, 2, 1) if kind == 'bvl' else lab).contiguous().cuda()       # [B,V,L] or [R,T,V]
+        den = (torch.rand(G, generator=g) * 5 + 1).cuda()
+        proj = (torch.rand(U, V, generator=g) * 2 - 1).cuda()
+        dl = torch.full((T * R, V), 9.0, device='cuda')
+        dh = torch.full((T * R, U), 9.0, device='cuda')
+        probs.append(dict(mode=mode, logits=logits, labels=labels, lab_kind=kind, lens=lens.int().cuda(), T=T, R=R, V=V,
+                          G=G, n_steps=n_steps, den=den, scale=0.7, dlogits=dl, proj=proj, dhout=dh, U=U))
+        ref = torch.zeros(T * R, V, device='cuda')
+        K.xent_bwd(mode, logits, labels, kind, lens.int().cuda(), T, R, V, G, n_steps, den, 0.7, ref)
+        refs.append((ref, n_steps * R))
+    K.xent_bwd_dhout_multi(probs)
+    for q, (ref, rows) in zip(probs, refs):
+        assert (q['dlogits'][:rows] - ref[:rows]).abs().max().item() <= 1e-7, q['mode']
+        want = ref[:rows].double().cpu() @ q['proj'].double().cpu().t()
+        assert (q['dhout'][:rows].double().cpu() - want).abs().max().item() <= 1e-5
+        if rows < q['dhout'].shape[0]:                              # rows past n_steps: untouched
+            assert float(q['dhout'][rows:].min()) == 9.0 and float(q['dlogits'][rows:].min()) == 9.0
