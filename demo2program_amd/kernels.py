@@ -381,6 +381,8 @@ def lstm_seq_bwd_multi(seqs):
     for i, q in enumerate(seqs):
         M, U = q['M'], q['U']
         nb = call.d2p_lstm_ws_bytes(M, U)
+        if q.get('db') is not None:      # the per-step back ends take the bias gradient by a column-sum pass over dz
+            nb = max(nb, call.d2p_colsum_ws_bytes(q['n_steps'] * M, 4 * U))
         ws = _MULTI_WS.get(('b', i, torch.cuda.current_stream().cuda_stream), nb)
         d = arr[i]
         d.M, d.U, d.n_steps = M, U, q['n_steps']

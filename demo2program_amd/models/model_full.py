@@ -259,6 +259,9 @@ class Model(object):
                 ('rows_t1', torch.int32, (T * B * k + 32,)), ('rows_t1_prev', torch.int32, (T * B * k + 32,)),
                 ('prog_rows', torch.int32, (L * B + 32,)),
                 ('prog_rows_t1', torch.int32, (L * B + 32,)), ('prog_rows_t1_prev', torch.int32, (L * B + 32,)),
+                # mask counts of the 1 + 2k loss terms (program, action per demo index, perception per demo index):
+                # the denominators of Sequence_Loss (models/model_full.py:656-657), known with the lengths
+                ('loss_dens', torch.float32, (1 + 2 * k,)),
                 ('program_len', torch.int32, (B,)), ('demo_len', torch.int32, (B * k,))]
         offs, total = [], 0
         for _, dt, shape in spec:
@@ -356,6 +359,8 @@ class Model(object):
         dlen = host_np(batch_chunk['demo_len']).astype(np.int32).reshape(B * k)
         put('program_len', plen)
         put('demo_len', dlen)
+        per_index = np.minimum(dlen, T).clip(0).reshape(B, k).sum(axis=0).astype(np.float32)
+        put('loss_dens', np.concatenate([[np.float32(np.minimum(plen, L).clip(0).sum())], per_index, per_index]))
         # dynamic_decode runs until the longest sequence of the batch
         feed['n_prog'] = int(min(int(plen.max()) if B else 0, L))
         feed['n_demo'] = int(min(int(dlen.max()) if B * k else 0, T))
@@ -378,7 +383,10 @@ class Model(object):
         return feed
 
     # ------------------------------------------------------------------ forward
-    def forward(self, feed):
+    def forward(self, feed, defer_loss=False):
+        """defer_loss (Trainer.train_step: a backward pass follows at once): the loss VALUE -- the cross-entropy sums
+        and their assembly, which nothing in backward reads: its denominators are mask counts that come with the feed
+        -- is left on the side stream and joined where backward joins the streams."""
         c, p = self.config, self.params.p
         B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len
         U, V, A, P = c.num_lstm_cell_units, c.dim_program_token, c.action_space, c.per_dim
@@ -571,11 +579,19 @@ class Model(object):
             if not side_loss:
                 K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
                            nums[1:1 + k], dens[1:1 + k])
-            K.xent_fwd('sigmoid', dq['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
-                       nums[1 + k:], dens[1 + k:])
-            if side_loss:
-                main.wait_stream(side)
-            K.loss_assemble([1, k, k], nums, dens, loss, terms)
+            if side_loss and defer_loss and feed.get('loss_dens') is not None:
+                side.wait_stream(main)                      # the perception decoder's logits
+                with torch.cuda.stream(side):
+                    K.xent_fwd('sigmoid', dq['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                               nums[1 + k:], dens[1 + k:])
+                    K.loss_assemble([1, k, k], nums, dens, loss, terms)
+                dens = feed['loss_dens']                    # what backward divides by (the same counts)
+            else:
+                K.xent_fwd('sigmoid', dq['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                           nums[1 + k:], dens[1 + k:])
+                if side_loss:
+                    main.wait_stream(side)
+                K.loss_assemble([1, k, k], nums, dens, loss, terms)
             ctx.update(da=da, dq=dq, ids_a=ids_a, emb_a=emb_a, per_tm=per_tm, pe_a=pe_a, pe=pe,
                        pe_mean=pe_mean, pe_rstd=pe_rstd)
         else:

@@ -283,7 +283,7 @@ class Trainer(object):
         if self.use_graph and not self._profiling():
             loss = self._graphed_forward_backward(feed, start)
         else:
-            loss = m.forward(feed)
+            loss = m.forward(feed, defer_loss=os.environ.get('D2P_DEFER_LOSS', '1') == '1')
             m.backward(split_cb=start)
         if overlap and persist_was:
             K.lstm_set_persistent(True)
