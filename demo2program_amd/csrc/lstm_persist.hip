@@ -642,6 +642,7 @@ struct PsBwdArgs {
     // 64 columns over its domain's rows, the last of a column tile's RT workgroups (a ticket) adds the RT partial
     // sums in domain order -- no separate column-sum pass over the 52 MB of dz
     float* db; float* dbpart; unsigned* dbtick;
+    int defer_from;         // phases per domain from which the deferred form runs (a large value: never)
 };
 
 template <int CB, int CPWB>
@@ -689,15 +690,17 @@ __device__ __forceinline__ void ps_bwd_epilogue_pre(const PsBwdArgs& a, const Ps
     pre.q = lstm_cell_bwd_pre(rs[0], rs[256], rs[512], rs[768], cp, rs[5 * 256]);
     pre.dcv = e.stdc[(p * 16 + e.rr) * 16 + e.un];
 }
+#define PS_BWD_P_FLOATS (4 * 16 * PS_PLD)
 __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const PsBwdEpi& e, int rs0, int p, int j,
-                                                     const PsBwdEpiPre& pre, float (&dbacc)[4]) {
+                                                     const PsBwdEpiPre& pre, float (&dbacc)[4], int par = 0,
+                                                     bool live = true) {
     const int U = a.U;
     const int t = a.T - 1 - j;
     const int row = (rs0 + p) * 16 + e.rr;
-    const bool valid = row < a.M;
+    const bool valid = row < a.M && live;        // (!live: the deferred form's dummy in front of tick 0 -- dump line only)
     float dH = pre.dhx;
     {   // the partial tiles are zero in pass 0 (the host zero-fills dz[T])
-        const float* Pb = e.P + e.rr * PS_PLD + e.un;
+        const float* Pb = e.P + par * PS_BWD_P_FLOATS + e.rr * PS_PLD + e.un;
 #pragma unroll
         for (int w = 0; w < 4; ++w) dH += Pb[w * 16 * PS_PLD];
     }
@@ -711,7 +714,7 @@ __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const P
         g[gg] = act ? g[gg] : 0.f;
         dbacc[gg] += g[gg];
         // staged fragment-major per gate: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
-        e.stage[gg * 256 + (((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = g[gg];
+        e.stage[par * 1024 + gg * 256 + (((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = g[gg];
     }
     // unconditional stores: dz[t] row-major (the dh0 pass writes dh0 with the first and dumps the rest);
     // addresses for a clamped row, only the final offset selected (see the forward epilogue)
@@ -729,7 +732,10 @@ __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const P
 
 // All ticks of one backward MFMA wave (LA: look-ahead, i.e. the domain has >= 2 phases).  Pass 0 has
 // no product (there is no dz[T]): the host zero-fills that buffer and the chain runs unconditionally.
-template <int CPW, bool LA>
+// DEFER (domains with >= 5 phases, as in the forward kernel): the product-DEPENDENT half of the previous phase's gate
+// backward (partial-tile sum, six multiplies, state / staging writes, the dz stores) runs inside this phase's first
+// MFMA stage instead of behind its own product -- one barrier per phase, the new rows published one phase later.
+template <int CPW, bool LA, bool DEFER = false>
 __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwdEpi& e, const f32x4 (&bw)[4 * CPW],
                                                  __amdgpu_buffer_rsrc_t dres, const unsigned* fl, int nnt, int rs0,
                                                  int nrs, int nticks, int lane_off, float* P, int wave, int lane,
@@ -752,9 +758,14 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
     }
     unsigned fv = ps_ld_flag(fl + k1.p * nnt);
     int slot = 0;
-    float* Pw = P + wave * 16 * PS_PLD;
+    PsBwdEpiPre pre_prev;
+    pre_prev.q = LstmCellBwdPre{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    pre_prev.dhx = 0.f; pre_prev.dcv = 0.f; pre_prev.cur_active = false;
+    PsTick kprev = {0, 0};
 #pragma unroll 1
     for (int n = 0; n < nticks; ++n) {
+        const int par = DEFER ? (n & 1) : 0;
+        float* Pw = P + par * PS_BWD_P_FLOATS + wave * 16 * PS_PLD;
         const bool e1 = n + 1 >= nticks, e2 = n + 2 >= nticks;
         const PsTick q1 = e1 ? k0 : k1, q2 = e2 ? (e1 ? k0 : k1) : k2;
         const unsigned need1 = e1 ? 0u : (unsigned)q1.t;
@@ -780,6 +791,11 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
             if ((st & 1) == 0) {
 #pragma unroll
                 for (int c = 0; c < CB; ++c) s1[c] = ps_ld_sc1(dres, noff + c * 1024);
+                // deferred: the previous phase's product-dependent half, spread over this stage's MFMAs (tick 0: a
+                // dummy on zeros whose stores go to the dump line -- no branch in the chain)
+                // (phase index PS_NRS_MAX = a spare state slot nobody reads)
+                if (DEFER && st == 0)
+                    ps_bwd_epilogue_post(a, e, rs0, n > 0 ? kprev.p : PS_NRS_MAX, kprev.t, pre_prev, dbacc, par ^ 1, n > 0);
                 ps_bwd_stage<CB, CPWB>(s0, bw, st * CB, acc0, acc1);
             } else {
 #pragma unroll
@@ -802,15 +818,22 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) Pw[((lane >> 4) * 4 + r) * PS_PLD + (lane & 15)] = acc0[r] + acc1[r];
-        ps_barrier();          // A: the four partial tiles are in LDS
+        ps_barrier();          // A: the four partial tiles are in LDS (deferred: and the previous phase's dz is staged)
         tr.stamp(3);
-        ps_bwd_epilogue_post(a, e, rs0, k0.p, k0.t, pre, dbacc);
-        ps_barrier();          // B: dz of the phase staged, P and the ring slot free again
+        if (!DEFER) {
+            ps_bwd_epilogue_post(a, e, rs0, k0.p, k0.t, pre, dbacc);
+            ps_barrier();          // B: dz of the phase staged, P and the ring slot free again
+        } else {
+            pre_prev = pre;
+            kprev = k0;
+        }
         tr.stamp(4);
         if (wave == 0) tr.flush(0, n, lane);
         k0 = k1; k1 = k2; k2.next(nrs);
         if (++slot == PS_PF_R) slot = 0;
     }
+    // the last phase's product-dependent half (its rows go nowhere: no publication)
+    if (DEFER) ps_bwd_epilogue_post(a, e, rs0, kprev.p, kprev.t, pre_prev, dbacc, (nticks - 1) & 1);
 }
 
 template <int CPW>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16
@@ -821,12 +844,13 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
     constexpr int KC4 = 4 * CPWB;                // chunks over K = 4U
-    __shared__ __attribute__((aligned(16))) float lds[4 * 16 * PS_PLD + PS_NRS_MAX * 256 + PS_NRS_MAX * 16 + 1024 + PS_PF_R * PS_BWD_SLOT];
-    float* P = lds;                                            // [4][16][PS_PLD] (16 columns used)
-    float* stdc = lds + 4 * 16 * PS_PLD;                       // [NRS][16 rows][16 units] dC state
-    int* stl = reinterpret_cast<int*>(stdc + PS_NRS_MAX * 256);     // [NRS][16] row length
-    float* stage = stdc + PS_NRS_MAX * 256 + PS_NRS_MAX * 16;  // [4 gates][4 quads][16 rows][4]: dz of the phase
-    float* ring = stage + 1024;                                // [PS_PF_R][8][16 rows][16 units]
+    __shared__ __attribute__((aligned(16))) float lds[2 * PS_BWD_P_FLOATS + (PS_NRS_MAX + 1) * 256 + PS_NRS_MAX * 16 + 2 * 1024 +
+                                                      PS_PF_R * PS_BWD_SLOT];
+    float* P = lds;                                            // [2][4][16][PS_PLD] (16 columns used; tick parity)
+    float* stdc = lds + 2 * PS_BWD_P_FLOATS;                   // [NRS + 1 spare][16 rows][16 units] dC state
+    int* stl = reinterpret_cast<int*>(stdc + (PS_NRS_MAX + 1) * 256);     // [NRS][16] row length
+    float* stage = stdc + (PS_NRS_MAX + 1) * 256 + PS_NRS_MAX * 16;  // [2][4 gates][4 quads][16 rows][4]: dz of a phase
+    float* ring = stage + 2 * 1024;                            // [PS_PF_R][8][16 rows][16 units]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int U = a.U, nnt = U >> 4;
@@ -837,6 +861,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
     const int J = a.T + (a.want_dh0 ? 1 : 0);    // passes: t = T-1 .. 0 (, -1)
     const int nticks = nrs * J;
     unsigned* fbase = a.flags + (long)rt * PS_NRS_MAX * nnt;
+    const bool defer = nrs >= a.defer_from;
 
     if (wave < 4) {
         // ---------------- MFMA waves ----------------
@@ -864,7 +889,10 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             if (e.un == 0) stl[p * 16 + e.rr] = len;
         }
         float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
-        if (nrs >= 2) ps_bwd_mfma_wave<CPW, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
+        // slack between a publication and the phase that asks for it: nrs - 2 phases with look-ahead, nrs - 3 with the
+        // deferred epilogue on top; a hand-off takes ~1.5 phases (as in the forward kernel: deferred from 5 phases)
+        if (defer) ps_bwd_mfma_wave<CPW, true, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
+        else if (nrs >= 2) ps_bwd_mfma_wave<CPW, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
         else ps_bwd_mfma_wave<CPW, false>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
         if (a.db) {
             // this workgroup's 4 gates x 16 units: the four row lanes of a wave by two shuffles, the four waves
@@ -937,17 +965,20 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         PsTick k = {0, 0};
         for (int n = 0; n < nticks; ++n) {
             tr.stamp(0);
-            ps_barrier();          // A
-            ps_barrier();          // B: dz of the phase is staged
+            ps_barrier();          // A (deferred form: the only barrier of the tick)
+            if (!defer) ps_barrier();          // B: dz of the phase is staged
             tr.stamp(1);
+            // deferred form: tick n-1's rows were staged during tick n and are published now
+            const bool pub = !defer || n > 0;
+            const int par = defer ? ((n - 1) & 1) : 0;
             const int t = a.T - 1 - k.t;
             const int row = (rs0 + k.p) * 16 + (lane & 15);
             const int fo = (int)((t & 1) * a.dzfrag_bytes);
             f32x4 gv[4];
 #pragma unroll
-            for (int gg = 0; gg < 4; ++gg) gv[gg] = *reinterpret_cast<const f32x4*>(stage + gg * 256 + lane * 4);
+            for (int gg = 0; gg < 4; ++gg) gv[gg] = *reinterpret_cast<const f32x4*>(stage + par * 1024 + gg * 256 + lane * 4);
             asm volatile("" ::: "memory");
-            if (t >= 0) {
+            if (t >= 0 && pub) {
 #pragma unroll
                 for (int gg = 0; gg < 4; ++gg)
                     ps_st_sc1(dres, fo + (int)(d2p_frag_off(row, gg * U + nt * 16 + (lane >> 4) * 4, KCx) * 4), gv[gg][0],
@@ -956,11 +987,11 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             tr.stamp(2);
             ps_wait_vmcnt<0>();                      // the stores are out (and the loads of the last tick have landed)
             tr.stamp(3);
-            if (lane == 0) ps_st_flag(fbase + k.p * nnt + nt, (unsigned)(k.t + 1));
+            if (lane == 0 && pub) ps_st_flag(fbase + k.p * nnt + nt, (unsigned)(k.t + 1));
             asm volatile("" ::: "memory");
             issue();                                 // off the hand-off path
             tr.flush(1, n, lane);
-            k.next(nrs);
+            if (pub) k.next(nrs);
         }
         ps_wait_vmcnt<0>();
         if (a.db) ps_barrier();                      // the MFMA waves' bias-gradient exchange
@@ -986,6 +1017,12 @@ static int ps_num_cus() {
 }
 
 // row domains for `ncol` column tiles: as many as fit the chip, at most one per 16-row sub-tile
+static int g_ps_bwd_defer_from = 1 << 20;    // backward: deferred form from this many phases per domain (d2p_lstm_persist_set_bwd_defer);
+                                             // measured -4 % per phase at 5-7 phases in isolation, nothing in the step: off by default
+extern "C" int d2p_lstm_persist_set_bwd_defer(int from_phases) {
+    g_ps_bwd_defer_from = from_phases > 0 ? from_phases : 1 << 20;
+    return D2P_OK;
+}
 static int g_ps_wgs_per_cu[2] = {1, 1};      // forward, backward (experiment knob)
 extern "C" int d2p_lstm_persist_set_wgs_per_cu(int fwd, int bwd) {
     if (fwd > 0) g_ps_wgs_per_cu[0] = fwd;
@@ -1176,6 +1213,7 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     a.dump = (float*)(a.flags + PS_FLAG_WORDS + PS_TICKET_WORDS);
     a.dbpart = a.dump + PS_DUMP_FLOATS;
     a.db = q.db;
+    a.defer_from = g_ps_bwd_defer_from;
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.c0 = q.c0; a.cs = q.cs; a.lens = q.lens;

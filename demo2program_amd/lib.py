@@ -60,6 +60,7 @@ SIGNATURES = {
     'd2p_lstm_set_persistent': (c_int, [c_int]),
     'd2p_lstm_persist_error': (c_int, [c_int]),
     'd2p_lstm_persist_inject_error': (c_int, []),
+    'd2p_lstm_persist_set_bwd_defer': (c_int, [c_int]),
     'd2p_lstm_persist_set_trace': (c_int, [P, c_size_t, c_int]),
     'd2p_lstm_persist_set_wgs_per_cu': (c_int, [c_int, c_int]),
     'd2p_lstm_persist_pair_launches': (c_int, []),

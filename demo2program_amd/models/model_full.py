@@ -198,6 +198,9 @@ class Model(object):
         if os.environ.get('D2P_GEMM_OPTION') is not None:          # experiments (d2p_gemm_set_option bits)
             from ..lib import call
             call.d2p_gemm_set_option(int(os.environ['D2P_GEMM_OPTION']))
+        if os.environ.get('D2P_BWD_DEFER_FROM') is not None:       # experiment: d2p_lstm_persist_set_bwd_defer
+            from ..lib import call
+            call.d2p_lstm_persist_set_bwd_defer(int(os.environ['D2P_BWD_DEFER_FROM']))
         K.bn_set_fold(int(os.environ.get('D2P_BN_FOLD', '0')))   # bit 0: ticket fold (no gain), bit 1: round-2 finalize
         self._reserve_scratch()
 

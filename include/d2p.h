@@ -251,6 +251,11 @@ int d2p_lstm_persist_inject_error(void);
  * [role][tick][8] with role 0 = MFMA wave 0 {start, first half issued, flags seen, partials written,
  * barrier passed}, role 1 = epilogue wave {start, barrier passed, stores issued, stores drained}. */
 int d2p_lstm_persist_set_trace(void* buf, size_t bytes, int block);
+/* Tuning knob (process-global): the backward persistent kernel runs a row domain in the deferred form -- the
+ * product-dependent half of a phase's gate backward inside the NEXT phase's MFMA chain, one barrier per phase, rows
+ * published one phase later -- when the domain has at least `from_phases` 16-row phases per step (<= 0: never, the
+ * default: measured -4 % per phase at 5-7 phases in isolation and nothing in the training step).  Same results. */
+int d2p_lstm_persist_set_bwd_defer(int from_phases);
 /* Tuning knob (process-global): workgroups per CU the persistent forward / backward kernels are
  * sized for (0 keeps the current value; default 1).  2 cuts the rows into twice as many domains so
  * that two workgroups share a CU and overlap each other's MFMA and epilogue phases. */
