@@ -963,6 +963,7 @@ static inline GemmPlan d2p_plan_gemm_base(int M, int N, int K, bool allow_split)
 }
 
 static int g_gemm_small_ksr = 1;   // 0: never pick the 32x32 wave-split tile automatically
+static int g_gemm_no_bk32 = 0;     // experiment: never the 32-deep slabs (16 KB of LDS per workgroup instead of 32)
 static int g_gemm_dma_big = 0;     // experiment: large dense GEMMs (>= 2 GFLOP) on the persistent LDS-DMA kernel
 
 static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
@@ -1093,7 +1094,7 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         default:
             // 32-deep slabs (half the barriers, 128-byte runs): +3-5 % on the large grids, a loss when
             // the workgroups are few (each then walks its K loop with less overlap)
-            if ((g_gemm_bk32 || (long)ceil_div(M, 64) * ceil_div(N, 64) * p.splits >= 1024) && K >= 256 && fast)
+            if (!g_gemm_no_bk32 && (g_gemm_bk32 || (long)ceil_div(M, 64) * ceil_div(N, 64) * p.splits >= 1024) && K >= 256 && fast)
                 d2p_launch_tile<64, 64, 2, 2, 32>(al, bl, ep, M, N, K, p, fast, partial, st, batch);
             else
                 d2p_launch_tile<64, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch);

@@ -643,6 +643,7 @@ struct PsBwdArgs {
     // sums in domain order -- no separate column-sum pass over the 52 MB of dz
     float* db; float* dbpart; unsigned* dbtick;
     int defer_from;         // phases per domain from which the deferred form runs (a large value: never)
+    int lds_nb;             // 1, or 2 when the launch may defer (double-buffered partial tiles / staged rows)
 };
 
 template <int CB, int CPWB>
@@ -844,13 +845,16 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
     constexpr int KC4 = 4 * CPWB;                // chunks over K = 4U
-    __shared__ __attribute__((aligned(16))) float lds[2 * PS_BWD_P_FLOATS + (PS_NRS_MAX + 1) * 256 + PS_NRS_MAX * 16 + 2 * 1024 +
-                                                      PS_PF_R * PS_BWD_SLOT];
-    float* P = lds;                                            // [2][4][16][PS_PLD] (16 columns used; tick parity)
-    float* stdc = lds + 2 * PS_BWD_P_FLOATS;                   // [NRS + 1 spare][16 rows][16 units] dC state
+    // dynamic LDS, sized by the host: the partial tiles and the staged rows are double-buffered only when some domain of
+    // the launch runs the deferred form (a.lds_nb = 2: 77 KB; else 64 KB -- what this kernel leaves of the CU's 160 KB
+    // decides how many GEMM workgroups of the side stream fit beside it)
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nb = a.lds_nb;
+    float* P = lds;                                            // [nb][4][16][PS_PLD] (16 columns used; tick parity)
+    float* stdc = lds + nb * PS_BWD_P_FLOATS;                  // [NRS + 1 spare][16 rows][16 units] dC state
     int* stl = reinterpret_cast<int*>(stdc + (PS_NRS_MAX + 1) * 256);     // [NRS][16] row length
-    float* stage = stdc + (PS_NRS_MAX + 1) * 256 + PS_NRS_MAX * 16;  // [2][4 gates][4 quads][16 rows][4]: dz of a phase
-    float* ring = stage + 2 * 1024;                            // [PS_PF_R][8][16 rows][16 units]
+    float* stage = stdc + (PS_NRS_MAX + 1) * 256 + PS_NRS_MAX * 16;  // [nb][4 gates][4 quads][16 rows][4]: dz of a phase
+    float* ring = stage + nb * 1024;                           // [PS_PF_R][8][16 rows][16 units]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int U = a.U, nnt = U >> 4;
@@ -861,7 +865,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
     const int J = a.T + (a.want_dh0 ? 1 : 0);    // passes: t = T-1 .. 0 (, -1)
     const int nticks = nrs * J;
     unsigned* fbase = a.flags + (long)rt * PS_NRS_MAX * nnt;
-    const bool defer = nrs >= a.defer_from;
+    const bool defer = nrs >= a.defer_from && a.lds_nb == 2;
 
     if (wave < 4) {
         // ---------------- MFMA waves ----------------
@@ -1214,6 +1218,7 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     a.dbpart = a.dump + PS_DUMP_FLOATS;
     a.db = q.db;
     a.defer_from = g_ps_bwd_defer_from;
+    a.lds_nb = (a.total_rs + RT - 1) / RT >= g_ps_bwd_defer_from ? 2 : 1;
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.c0 = q.c0; a.cs = q.cs; a.lens = q.lens;
@@ -1227,13 +1232,30 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
 static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdArgs& a2, int U, double flops,
                          hipStream_t st) {
     const int blocks = a0.gsz + a1.gsz + a2.gsz;
+    // every sequence of the launch gets the same LDS layout (one dynamic size per launch)
+    PsBwdArgs b0 = a0, b1 = a1, b2 = a2;
+    const int nb = ((a0.gsz > 0 && a0.lds_nb == 2) || (a1.gsz > 0 && a1.lds_nb == 2) || (a2.gsz > 0 && a2.lds_nb == 2)) ? 2 : 1;
+    b0.lds_nb = b1.lds_nb = b2.lds_nb = nb;
+    const size_t lds = (size_t)(nb * PS_BWD_P_FLOATS + (PS_NRS_MAX + 1) * 256 + PS_NRS_MAX * 16 + nb * 1024 +
+                                PS_PF_R * PS_BWD_SLOT) * sizeof(float);
     D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, flops);
-    switch (U) {
-        case 64: hipLaunchKernelGGL((lstm_persist_bwd_kernel<1>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1, a2); break;
-        case 128: hipLaunchKernelGGL((lstm_persist_bwd_kernel<2>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1, a2); break;
-        case 256: hipLaunchKernelGGL((lstm_persist_bwd_kernel<4>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1, a2); break;
-        default: hipLaunchKernelGGL((lstm_persist_bwd_kernel<8>), dim3(blocks), dim3(PS_THREADS), 0, st, a0, a1, a2); break;
+#define PS_BWD_LAUNCH(CPW)                                                                                              \
+    {                                                                                                                   \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel<CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      96 * 1024);                                                                       \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW>), dim3(blocks), dim3(PS_THREADS), lds, st, b0, b1, b2);         \
     }
+    switch (U) {
+        case 64: PS_BWD_LAUNCH(1) break;
+        case 128: PS_BWD_LAUNCH(2) break;
+        case 256: PS_BWD_LAUNCH(4) break;
+        default: PS_BWD_LAUNCH(8) break;
+    }
+#undef PS_BWD_LAUNCH
     D2P_LAUNCH_CHECK("lstm_persist_bwd");
     return D2P_OK;
 }
