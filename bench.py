@@ -48,7 +48,8 @@ EMPTY_LAUNCH_US = 2.7          # a dependent empty launch on one stream (DESIGN.
 # kernel family -> key in profiles/*_pmc_traffic.json (tools/pmc_summary.py)
 PMC_KEYS = {1: 'gemm_mfma_kernel', 2: 'gemm_mfma_kernel<conv>', 7: 'lstm_persist_fwd_kernel',
             8: 'lstm_persist_bwd_kernel', 3: 'lstm_gate_fwd_kernel', 4: 'lstm_gate_bwd_kernel'}
-PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r02_pmc_traffic.json', 'r01_pmc_traffic.json')]
+PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json',
+                                                         'r01_pmc_traffic.json')]
 
 # profiling key (include/d2p.h) -> (name, roofline that bounds it, reporting group)
 PROF_FAMILIES = {
@@ -79,6 +80,21 @@ def pmc_traffic(family):
             return round(d[PMC_KEYS[family]]['hbm_bytes_per_launch'], 1)
         except (OSError, KeyError, ValueError):
             continue
+    return None
+
+
+def pmc_traffic_source():
+    """`traffic` is NOT measured in this run (hardware counters need rocprofv3 around the process): it is read from
+    the committed summary of separate PMC passes of this same command.  This names the file and the commit its
+    passes were collected at, so that a kernel changed since then is visible in the line."""
+    for path in PMC_FILES:
+        try:
+            d = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        meta = d.get('_meta', {})
+        return {'file': os.path.relpath(path, ROOT), 'source_commit': meta.get('source_commit', 'unknown'),
+                'note': 'counters collected in separate rocprofv3 --pmc passes (tools/profile_pmc.sh), not in this run'}
     return None
 
 
@@ -133,6 +149,7 @@ def roofline_leg(trainer, feeds, steps=2):
              'unit': 'TFLOP/s' if g['bound'] == 'mfma' else 'GB/s', 'frac': round(achieved / peak, 4),
              'traffic': traffic[0] if len(traffic) == 1 else (None if any(t is None for t in traffic) else
                                                               round(sum(t * r['launches'] for t, r in zip(traffic, g['families'])) / g['launches'], 1)),
+             'traffic_source': pmc_traffic_source(),
              'launches_per_step': g['launches'] / steps,
              'avg_launch_us': round(g['total_ms'] * 1e3 / g['launches'], 3),
              'work_per_launch': g['work'] / g['launches'],
@@ -350,7 +367,7 @@ def config4_leg(steps=10, warmup=3):
     return res
 
 
-def cpu_baseline_leg(config, batch, params, steps=2):
+def cpu_baseline_leg(config, batch, params, steps=5):
     """The CPU oracle (torch-CPU fp32 restatement of the TF-1.3 graph + torch autograd) on the
     host cores of this box, same batch, same weights.  Reported, never the target."""
     import oracle
@@ -366,10 +383,12 @@ def cpu_baseline_leg(config, batch, params, steps=2):
     tb = to_torch(batch)
     tp = {n: torch.from_numpy(v) for n, v in params.items()}
     oracle.loss_and_grads(tp, tb, ocfg, dtype=torch.float32)       # warm-up
-    t0 = time.time()
+    samples = []
     for _ in range(steps):
+        t0 = time.time()
         oracle.loss_and_grads(tp, tb, ocfg, dtype=torch.float32)
-    dt = (time.time() - t0) / steps
+        samples.append(time.time() - t0)
+    dt = sum(samples) / steps
     model = ''
     try:
         for line in open('/proc/cpuinfo'):
@@ -380,6 +399,9 @@ def cpu_baseline_leg(config, batch, params, steps=2):
         pass
     return {'value': round(config.batch_size / dt, 3), 'unit': 'instances/s',
             'cores': torch.get_num_threads(), 'host_cores': os.cpu_count(), 'kind': 'port',
+            'samples_s': [round(x, 3) for x in samples],
+            'thread_sweep': 'profiles/r03_cpu_thread_sweep.json (tools/cpu_baseline_sweep.py: 16 threads is the fastest '
+                            'setting for this op mix on the 256-thread host)',
             'caveat': 'forward + backward only (no clip / Adam), %d of %d host threads, %d samples; a CPU restatement '
                       'in torch, not TensorFlow 1.3' % (torch.get_num_threads(), os.cpu_count() or 0, steps),
             'sample': '%d full forward+backward steps (no optimizer) of the torch-CPU oracle on the '

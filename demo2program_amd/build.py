@@ -25,8 +25,19 @@ def _newest_header():
     return max(_mtime(os.path.join(CSRC, h)) for h in HEADERS)
 
 
+def _hipcc():
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    return hipcc if os.path.exists(hipcc) else 'hipcc'
+
+
+def _stamp():
+    """Compiler + flags: objects built with other flags (or another hipcc) are stale whatever their mtime."""
+    import hashlib
+    return hashlib.sha1((' '.join([_hipcc()] + FLAGS)).encode()).hexdigest()[:12]
+
+
 def _obj(src):
-    return os.path.join(OBJDIR, os.path.splitext(src)[0] + '.o')
+    return os.path.join(OBJDIR, '%s.%s.o' % (os.path.splitext(src)[0], _stamp()))
 
 
 def _stale_objects():
@@ -54,17 +65,23 @@ def build_library(force=False, verbose=False):
         try:
             if not force and not _stale():
                 return OUT
-            hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-            if not os.path.exists(hipcc):
-                hipcc = 'hipcc'
+            hipcc = _hipcc()
             os.makedirs(OBJDIR, exist_ok=True)
             todo = list(SOURCES) if force else _stale_objects()
 
             def compile_one(src):
-                cmd = [hipcc] + FLAGS + ['-c', src, '-o', _obj(src)]
+                # to a temporary name, renamed on success: a compile that is killed part-way must not leave a
+                # truncated object that looks newer than its source
+                tmp = '%s.tmp.%d' % (_obj(src), os.getpid())
+                cmd = [hipcc] + FLAGS + ['-c', src, '-o', tmp]
                 if verbose:
                     print(' '.join(cmd), flush=True)
-                subprocess.run(cmd, cwd=CSRC, check=True)
+                try:
+                    subprocess.run(cmd, cwd=CSRC, check=True)
+                    os.replace(tmp, _obj(src))
+                finally:
+                    if os.path.exists(tmp):
+                        os.remove(tmp)
 
             jobs = int(os.environ.get('D2P_BUILD_JOBS', str(min(8, os.cpu_count() or 1))))
             with ThreadPoolExecutor(max_workers=max(1, jobs)) as pool:

@@ -394,6 +394,12 @@ class Model(object):
         B, k, T, L = c.batch_size, c.k, c.max_demo_len, c.max_program_len
         U, V, A, P = c.num_lstm_cell_units, c.dim_program_token, c.action_space, c.per_dim
         M, NF, F = B * k, B * k * T, self.feature_dim
+        if self.multitask and self.per_factored and 'per_rows' not in feed:
+            # a hand-built feed (get_feed_dict derives these with the batch): same derivation, buffers of the model
+            feed = dict(feed)
+            feed['per_rows'] = self._buf('feed/per_rows', (T * M, self.per_cols))
+            feed['per_gram'] = self._buf('feed/per_gram', (self.per_cols, self.per_cols))
+            self.derive_per_rows(feed)
         ctx = {'feed': feed}
         lens_d, lens_p = feed['demo_len'], feed['program_len']
         n_p, n_d = feed['n_prog'], feed['n_demo']

@@ -553,6 +553,7 @@ class Trainer(object):
             # like the reference's pretrain_saver (trainer.py:100,115): trainable variables only --
             # global_step, the learning-rate / sampling schedules and Adam all restart at 0
             tf_checkpoint.import_checkpoint(path, self.model)
+            self._restart_optimizer()
             return
         z = np.load(path)
         P = self.model.params
@@ -573,6 +574,16 @@ class Trainer(object):
             # a full resume of this build's own checkpoint; a parameters-only file restarts the schedules
             self.global_step = int(z['global_step'])
             self.adam_step = int(z['adam_step']) if 'adam_step' in z else self.global_step
+        elif not has_moments:
+            self._restart_optimizer()
+
+    def _restart_optimizer(self):
+        """Parameters came without optimizer state (a parameters-only file, a TensorFlow checkpoint): zero moments,
+        restarted beta powers and schedules -- also when this trainer has already stepped."""
+        P = self.model.params
+        P.m.zero_()
+        P.v.zero_()
+        self.global_step = self.adam_step = 0
 
 
 def build_arg_parser():

@@ -705,11 +705,14 @@ def test_headline_config_matches_oracle_at_full_size():
     assert _maxerr(model.pred_action, out['pred_action'].permute(0, 1, 3, 2)) <= 1e-4
     assert _maxerr(model.pred_per, out['pred_per'].permute(0, 1, 3, 2)) <= 1e-4
     got = model.params.to_numpy('g')
-    # fp32 sums over 3 200 - 6 400 rows vs fp64: 1e-3 of the tensor's scale plus an absolute floor for the
-    # tensors whose true gradient is ~0 by cancellation (biases under a batch norm: exactly 0 for per/fc/b)
+    # every gradient tensor within 2e-4 of its own scale (the bound of the small cases) plus an absolute floor of 5e-7:
+    # the floor is what fp32 sums over 3 200 pair rows / 6 400 step rows leave (measured 2e-7 at most,
+    # tools/grad_error_full_size.py) and matters only for the two tensors whose true gradient is ~1e-4 by
+    # cancellation (rn_h/fc2/W, rn_h/fc2/b: 3.6e-4 / 7.3e-4 of their scale) and for per/fc/b (exactly 0 in exact
+    # arithmetic: a bias under a batch norm); everything else is within 8e-5 of its scale
     for n in grads:
         ref = grads[n].numpy()
-        assert np.abs(got[n] - ref).max() <= 1e-3 * np.abs(ref).max() + 2e-6, (n, float(np.abs(ref).max()))
+        assert np.abs(got[n] - ref).max() <= 2e-4 * np.abs(ref).max() + 5e-7, (n, float(np.abs(ref).max()))
 
 
 def test_headline_config_properties():
@@ -920,6 +923,16 @@ def test_parameters_only_checkpoint_restarts_adam_and_schedules(tmp_path):
     c = Trainer(cfg, make_train_dir=False)
     c.load_checkpoint(full)
     assert c.global_step == 3 and c.adam_step == 3
+    # ... and a parameters-only file loaded into a trainer that HAS stepped leaves no stale moments or counters
+    # behind: same first update as the fresh trainer's
+    c.train_step(c.model.get_feed_dict(batch))
+    c.load_checkpoint(bare)
+    assert c.global_step == 0 and c.adam_step == 0
+    assert float(c.model.params.m.abs().max()) == 0.0 and float(c.model.params.v.abs().max()) == 0.0
+    c.train_step(c.model.get_feed_dict(batch))
+    pc = c.model.params.to_numpy('p')
+    for n in pa:
+        assert np.array_equal(pa[n], pc[n]), n
 
 
 def test_run_test_moves_the_batch_norm_moving_statistics():
@@ -1169,3 +1182,21 @@ def test_bench_starts_its_own_ranks():
     d = json.loads(lines[0])
     assert d['n_gpus'] == 1 and d['steps'] == 4 and d['value'] > 0
     assert d['rccl_ranks_seen'] == 1 and d['launcher'] == 'self-spawned'
+
+
+@pytest.mark.gpu
+def test_hand_built_feed_without_the_derived_perception_rows():
+    """A feed assembled by hand (the tensors of the reference's placeholders only) goes through Model.forward /
+    backward in eager mode like one from get_feed_dict: the factored perception decoder derives its row matrix and
+    Gram matrix itself (it used to raise KeyError)."""
+    from demo2program_amd.models.model_full import Model
+    cfg, params, batch = small_case('karel', seed=51)
+    m = Model(cfg, params=params)
+    full = m.get_feed_dict(batch)
+    l1 = float(m.forward(full).item())
+    m.backward()
+    g1 = m.params.grad.clone()
+    bare = {k_: v for k_, v in full.items() if k_ not in ('per_rows', 'per_gram', '_flat')}
+    l2 = float(m.forward(bare).item())
+    m.backward()
+    assert l1 == l2 and torch.equal(g1, m.params.grad)

@@ -54,7 +54,14 @@ def main():
             r['kernel'][:80], r['launches'], r['fetch_bytes_per_launch'] / 1e6,
             r['write_bytes_per_launch'] / 1e6, r['hbm_bytes_per_launch'] / 1e6, r['total_mb']))
     if len(sys.argv) > 2:
-        json.dump({r['kernel']: r for r in rows}, open(sys.argv[2], 'w'), indent=1)
+        out = {r['kernel']: r for r in rows}
+        # where the numbers come from: bench.py quotes this in roofline.traffic_source
+        out['_meta'] = {'collected_by': 'tools/profile_pmc.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, '
+                                        'one counter per pass, eager one-stream launches)',
+                        'source_commit': os.environ.get('D2P_COMMIT', 'unknown'),
+                        'correction': 'HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half '
+                                      'of wide coalesced reads; WRITE_SIZE uncalibrated)'}
+        json.dump(out, open(sys.argv[2], 'w'), indent=1)
 
 
 if __name__ == '__main__':

@@ -14,8 +14,12 @@ bash tools/profile_bench.sh ${TAG}g > /dev/null 2>&1
 DB=$(find gpurun_out/prof_${TAG}g -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_default.md
 python tools/rocpd_streams.py $DB 5 --seq > gpurun_out/${TAG}_streams_timeline.txt
-# HBM traffic counters, one counter per pass
+# HBM traffic counters, one counter per pass (D2P_COMMIT: the commit these sources are at -- .git does not travel)
 bash tools/profile_pmc.sh $TAG > /dev/null 2>&1
 python tools/pmc_summary.py gpurun_out/pmc_$TAG gpurun_out/${TAG}_pmc_traffic.json > gpurun_out/${TAG}_pmc_traffic.md
+# MFMA-pipe busy cycles per kernel, own pass
+bash tools/profile_mfma.sh ${TAG}m > /dev/null 2>&1
+DB=$(find gpurun_out/pmc_${TAG}m -name "*.db" | head -1)
+python tools/mfma_summary.py $DB 2.4 gpurun_out/${TAG}_mfma_util.json > gpurun_out/${TAG}_mfma_util.md
 find gpurun_out -name "*.db" -size +1M -delete
 ls -la gpurun_out/ | tail -12
