@@ -63,6 +63,9 @@ struct PsFwdCall {
     const float* Wh; const float* h0; const float* c0; const int* lens;
     float* hout; float* cs; float* h_final; float* c_final;
     float* ws;
+    // optional ("direct" launch: no preparation launch): a dedicated flag buffer of D2P_LSTM_FLAG_WORDS words,
+    // zeroed ONCE by the caller, and the caller's epoch for it (raised by more than n_steps per launch)
+    unsigned* flags; unsigned epoch;
 };
 struct PsBwdCall {
     int M, U, n_steps;
@@ -72,6 +75,7 @@ struct PsBwdCall {
     float* dz; float* dh0; float* dc0;
     float* ws;
     float* db;          // optional: bias gradient [4U] = column sums of dz, produced inside the launch
+    unsigned* flags; unsigned epoch;      // as PsFwdCall
 };
 int d2p_lstm_persist_fwd(const PsFwdCall& q, hipStream_t st);
 int d2p_lstm_persist_bwd(const PsBwdCall& q, hipStream_t st);
@@ -90,4 +94,5 @@ bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc);
 bool d2p_lstm_try_triple_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc);
 // one sequence by descriptor (d2p_lstm_seq_bwd + the optional bias gradient)
 int d2p_lstm_seq_bwd_desc(const d2p_lstm_bwd_desc* d, d2p_stream_t stream);
+int d2p_lstm_seq_fwd_desc(const d2p_lstm_fwd_desc* d, d2p_stream_t stream);
 int d2p_lstm_db_colsum(const d2p_lstm_bwd_desc* d, d2p_stream_t stream);

@@ -52,6 +52,8 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define PS_PF_R (PS_PF_D + 2)   // LDS ring slots (one more than the distance: a deferred epilogue reads its slot a tick late)
 #define PS_SPIN_LIMIT 60000 // ~50 ms of polling before giving up
 #define PS_AUX_SC1 16       // buffer-instruction cache policy: sc1 (agent scope, bypasses the CU's L1)
+#define PS_FLAG_WORDS 4096   // >= RT * PS_NRS_MAX * ncol for any grid <= 512 workgroups
+#define PS_TICKET_WORDS 64   // bias-gradient tickets of the backward kernel, one per column tile (zeroed with the flags)
 
 // ---- error word ---------------------------------------------------------------------------
 __device__ unsigned g_ps_err;          // sticky: 0 ok, else (code << 24) | block
@@ -217,7 +219,34 @@ struct PsFwdArgs {
     float* dump;            // 64 floats nobody reads: target of masked lanes' stores
     unsigned* err;
     unsigned long long* trace; int trace_block;
+    // "direct" launches (round 3: no preparation launch in front of the kernel):
+    //   * the recurrent weight is read straight from the row-major Wh (wh_raw) into the registers,
+    //   * the operands of step 0 come from the row-major initial state through a second buffer descriptor (h0_raw,
+    //     h0_bytes = M*U*4; 0 bytes without an initial state: every load returns zero, as do rows >= M),
+    //   * the flags are never reset: every launch publishes epoch + t + 1 and waits for epoch + t, and the caller
+    //     raises the epoch by more than T from launch to launch (a dedicated, once-zeroed flag buffer).
+    int direct;
+    const float* wh_raw; const float* h0_raw; unsigned h0_bytes; unsigned epoch;
 };
+
+// where a phase's 16 rows of the running state are read from: descriptor, byte offset of chunk 0, bytes per chunk
+struct PsSrc {
+    __amdgpu_buffer_rsrc_t r;
+    int off, cs;
+};
+__device__ __forceinline__ f32x4 ps_ld_src(const PsSrc& s, int c) { return ps_ld_sc1(s.r, s.off + c * s.cs); }
+// step t, phase p of a forward sequence: the fragment-major ping-pong buffer, or (direct launches, t = 0) the
+// row-major initial state: lane l = (row l&15, k 4*(l>>4)..+3) of chunk kc = wave*CPW + c -- a select, no branch
+__device__ __forceinline__ PsSrc ps_fwd_src(const PsFwdArgs& a, __amdgpu_buffer_rsrc_t hres, __amdgpu_buffer_rsrc_t hres0,
+                                            int t, int rs, int KC, int lane_off, int rm_off) {
+    const bool first = a.direct && t == 0;
+    PsSrc s;
+    s.r = first ? hres0 : hres;
+    s.off = first ? rs * 16 * a.U * 4 + rm_off : (int)((t & 1) * a.hfrag_bytes) + rs * KC * 1024 + lane_off;
+    s.cs = first ? 64 : 1024;
+    return s;
+}
+__device__ __forceinline__ unsigned ps_need(unsigned epoch, int t) { return t == 0 ? 0u : epoch + (unsigned)t; }
 
 template <int CPW>
 __device__ __forceinline__ void ps_fwd_chain(const f32x4 (&av)[CPW], const f32x4 (&bv)[CPW][2], f32x4& acc0,
@@ -329,21 +358,20 @@ __device__ __forceinline__ void ps_fwd_write_partials(float* Pw, int lane, const
 template <int CPW, bool la>
 __device__ __forceinline__ void ps_fwd_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][2],
                                             const PsFwdArgs& a, const PsFwdEpi& e, PsTick k0,
-                                            const unsigned* fl_cur, int cur_off, const unsigned* fl1, unsigned need1,
-                                            int off1, const unsigned* fl2, unsigned& fv,
-                                            __amdgpu_buffer_rsrc_t hres, int wave, int rs0, int slot, int lane,
-                                            PsTrace& tr) {
+                                            const unsigned* fl_cur, const PsSrc& cur_src, const unsigned* fl1,
+                                            unsigned need1, const PsSrc& src1, const unsigned* fl2, unsigned& fv,
+                                            int wave, int rs0, int slot, int lane, PsTrace& tr) {
     tr.stamp(0);
     if (la) {
         ps_wait_flags(fl1, need1, fv, a.err, 1);
     } else {
-        ps_wait_flags(fl_cur, (unsigned)k0.t, ps_ld_flag(fl_cur), a.err, 3);
+        ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3);
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) cur[c] = ps_ld_sc1(hres, cur_off + c * 1024);
+        for (int c = 0; c < CPW; ++c) cur[c] = ps_ld_src(cur_src, c);
     }
     tr.stamp(1);
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_sc1(hres, off1 + c * 1024);
+    for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_src(src1, c);
     fv = ps_ld_flag(fl2);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -366,8 +394,8 @@ __device__ __forceinline__ void ps_fwd_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW]
 template <int CPW>
 __device__ __forceinline__ void ps_fwd_tick_defer(const f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][2],
                                                   const PsFwdArgs& a, const PsFwdEpi& e, PsTick kprev, int slot_prev,
-                                                  const unsigned* fl1, unsigned need1, int off1, const unsigned* fl2,
-                                                  unsigned& fv, __amdgpu_buffer_rsrc_t hres, int wave, int rs0,
+                                                  const unsigned* fl1, unsigned need1, const PsSrc& src1,
+                                                  const unsigned* fl2, unsigned& fv, int wave, int rs0,
                                                   int par, int lane, PsTrace& tr) {
     tr.stamp(0);
     ps_wait_flags(fl1, need1, fv, a.err, 1);
@@ -378,7 +406,7 @@ __device__ __forceinline__ void ps_fwd_tick_defer(const f32x4 (&cur)[CPW], f32x4
     // first quarter of the chain with the next phase's operand loads (~60 clocks of issue each) and
     // the previous phase's LDS reads issued into it ...
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_sc1(hres, off1 + c * 1024);
+    for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_src(src1, c);
     fv = ps_ld_flag(fl2);
     PsFwdEpiIn in;
     ps_fwd_epilogue_load(e, kprev.p, slot_prev, par ^ 1, in);
@@ -414,14 +442,18 @@ __device__ __forceinline__ void ps_fwd_tick_defer(const f32x4 (&cur)[CPW], f32x4
 // deferred epilogue (>= 4 phases).
 template <int CPW, int MODE>
 __device__ __forceinline__ void ps_fwd_mfma_wave(const PsFwdArgs& a, const PsFwdEpi& e, const f32x4 (&bv)[CPW][2],
-                                                 __amdgpu_buffer_rsrc_t hres, const unsigned* fl, int nct, int rs0,
-                                                 int nrs, int nticks, int lane_off, int wave, int lane) {
+                                                 __amdgpu_buffer_rsrc_t hres, __amdgpu_buffer_rsrc_t hres0,
+                                                 const unsigned* fl, int nct, int rs0,
+                                                 int nrs, int nticks, int lane_off, int rm_off, int wave, int lane) {
     constexpr int KC = 4 * CPW;
     PsTrace tr;
     tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
     f32x4 a0[CPW], a1[CPW];
+    {
+        const PsSrc s0 = ps_fwd_src(a, hres, hres0, 0, rs0, KC, lane_off, rm_off);
 #pragma unroll
-    for (int c = 0; c < CPW; ++c) a0[c] = ps_ld_sc1(hres, rs0 * KC * 1024 + lane_off + c * 1024);
+        for (int c = 0; c < CPW; ++c) a0[c] = ps_ld_src(s0, c);
+    }
     PsTick kp = {0, 0}, k0 = {0, 0}, k1 = {0, 0}, k2 = {0, 0};      // ticks n-1, n, n+1, n+2
     k1.next(nrs);
     k2.next(nrs); k2.next(nrs);
@@ -432,15 +464,15 @@ __device__ __forceinline__ void ps_fwd_mfma_wave(const PsFwdArgs& a, const PsFwd
         /* ticks past the end are clamped to the last one: their loads are issued unconditionally */         \
         const bool e1 = (m) + 1 >= nticks, e2 = (m) + 2 >= nticks;                                            \
         const PsTick q1 = e1 ? k0 : k1, q2 = e2 ? (e1 ? k0 : k1) : k2;                                        \
-        const unsigned need1 = e1 ? 0u : (unsigned)q1.t;     /* version t = published after step t-1 */       \
-        const int cur_off = (int)((k0.t & 1) * a.hfrag_bytes) + (rs0 + k0.p) * KC * 1024 + lane_off;          \
-        const int off1 = (int)((q1.t & 1) * a.hfrag_bytes) + (rs0 + q1.p) * KC * 1024 + lane_off;             \
+        const unsigned need1 = e1 ? 0u : ps_need(a.epoch, q1.t);     /* version t = published after step t-1 */ \
+        const PsSrc cur_src = ps_fwd_src(a, hres, hres0, k0.t, rs0 + k0.p, KC, lane_off, rm_off);             \
+        const PsSrc src1 = ps_fwd_src(a, hres, hres0, q1.t, rs0 + q1.p, KC, lane_off, rm_off);                \
         if (MODE == 2)                                                                                        \
-            ps_fwd_tick_defer<CPW>(CUR, NXT, bv, a, e, kp, slot_prev, fl + q1.p * nct, need1, off1, fl + q2.p * nct, \
-                                   fv, hres, wave, rs0, (m) & 1, lane, tr);                                   \
+            ps_fwd_tick_defer<CPW>(CUR, NXT, bv, a, e, kp, slot_prev, fl + q1.p * nct, need1, src1, fl + q2.p * nct, \
+                                   fv, wave, rs0, (m) & 1, lane, tr);                                         \
         else                                                                                                  \
-            ps_fwd_tick<CPW, MODE != 0>(CUR, NXT, bv, a, e, k0, fl + k0.p * nct, cur_off, fl + q1.p * nct, need1, \
-                                        off1, fl + q2.p * nct, fv, hres, wave, rs0, slot, lane, tr);          \
+            ps_fwd_tick<CPW, MODE != 0>(CUR, NXT, bv, a, e, k0, fl + k0.p * nct, cur_src, fl + q1.p * nct, need1, \
+                                        src1, fl + q2.p * nct, fv, wave, rs0, slot, lane, tr);                \
         if (wave == 0) tr.flush(0, (m), lane);                                                                \
         kp = k0; k0 = k1; k1 = k2; k2.next(nrs);                                                              \
         slot_prev = slot;                                                                                     \
@@ -449,11 +481,11 @@ __device__ __forceinline__ void ps_fwd_mfma_wave(const PsFwdArgs& a, const PsFwd
     int n = 0;
     if (MODE == 2) {
         // first tick: nothing to finish yet (plain product, one barrier)
-        const unsigned need1 = (unsigned)k1.t;
-        const int off1 = (int)((k1.t & 1) * a.hfrag_bytes) + (rs0 + k1.p) * KC * 1024 + lane_off;
+        const unsigned need1 = ps_need(a.epoch, k1.t);
+        const PsSrc src1 = ps_fwd_src(a, hres, hres0, k1.t, rs0 + k1.p, KC, lane_off, rm_off);
         ps_wait_flags(fl + k1.p * nct, need1, fv, a.err, 1);
 #pragma unroll
-        for (int c = 0; c < CPW; ++c) a1[c] = ps_ld_sc1(hres, off1 + c * 1024);
+        for (int c = 0; c < CPW; ++c) a1[c] = ps_ld_src(src1, c);
         fv = ps_ld_flag(fl + k2.p * nct);
         __builtin_amdgcn_sched_barrier(0);
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -519,13 +551,28 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
         // ---------------- MFMA waves ----------------
         f32x4 bv[CPW][2];
         const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wf);
+        if (a.direct) {
+            // straight from the row-major Wh: the element the packed image would hold at this index (four 4-byte loads
+            // per register instead of one 16-byte load, once per launch -- and no pack pass over 4 MB in front of it)
 #pragma unroll
-        for (int c = 0; c < CPW; ++c)
+            for (int c = 0; c < CPW; ++c)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) bv[c][s] = Bf[(((long)ct * KC + wave * CPW + c) * 2 + s) * 64 + lane];
+                for (int s = 0; s < 2; ++s) {
+                    const float4 w = d2p_pack_w_fwd_elem(U, a.wh_raw, (((long)ct * KC + wave * CPW + c) * 2 + s) * 64 + lane);
+                    bv[c][s] = f32x4{w.x, w.y, w.z, w.w};
+                }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPW; ++c)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) bv[c][s] = Bf[(((long)ct * KC + wave * CPW + c) * 2 + s) * 64 + lane];
+        }
         const __amdgpu_buffer_rsrc_t hres = ps_rsrc(a.hfrag, 2u * a.hfrag_bytes);
+        const __amdgpu_buffer_rsrc_t hres0 = ps_rsrc(a.h0_raw ? (const void*)a.h0_raw : (const void*)a.hfrag, a.h0_bytes);
         // byte offset of this lane's float4 in block (rs = 0, kc = wave*CPW)
         const int lane_off = (wave * CPW * 64 + lane) * 16;
+        // ... and in the row-major initial state: row lane&15 of the phase, k = (wave*CPW + c)*16 + 4*(lane>>4)
+        const int rm_off = ((lane & 15) * U + wave * CPW * 16 + 4 * (lane >> 4)) * 4;
         // the 2*CPW producers (column tiles) whose units this wave's K slice covers
         const unsigned* fl = fbase + 2 * CPW * wave + (lane & (2 * CPW - 1));
         PsFwdEpi e;
@@ -549,13 +596,13 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
                 stl[(p * 16 + e.rr) * 8 + e.un] = len;
             }
         }
-        if (defer) ps_fwd_mfma_wave<CPW, 2>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
+        if (defer) ps_fwd_mfma_wave<CPW, 2>(a, e, bv, hres, hres0, fl, nct, rs0, nrs, nticks, lane_off, rm_off, wave, lane);
         // look-ahead asks for the NEXT phase's rows at the start of a phase: with two phases those were
         // published by the phase just finished, so the full hand-off latency sat in front of every phase
         // (3.8 us per phase); 1- and 2-phase domains poll for their own rows instead (3 phases: look-ahead
         // measured better, 8.9 against 13.1 us per step for a 3,2,2,2-phase split)
-        else if (nrs >= 3) ps_fwd_mfma_wave<CPW, 1>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
-        else ps_fwd_mfma_wave<CPW, 0>(a, e, bv, hres, fl, nct, rs0, nrs, nticks, lane_off, wave, lane);
+        else if (nrs >= 3) ps_fwd_mfma_wave<CPW, 1>(a, e, bv, hres, hres0, fl, nct, rs0, nrs, nticks, lane_off, rm_off, wave, lane);
+        else ps_fwd_mfma_wave<CPW, 0>(a, e, bv, hres, hres0, fl, nct, rs0, nrs, nticks, lane_off, rm_off, wave, lane);
         if (e.lane_on)
             for (int q = 0; q < nrs; ++q) {
                 const int row = (rs0 + q) * 16 + e.rr;
@@ -611,7 +658,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
             tr.stamp(2);
             ps_wait_vmcnt<0>();                      // the store is out (and the loads of the last tick have landed)
             tr.stamp(3);
-            if (lane == 0 && pub) ps_st_flag(fbase + k.p * nct + ct, (unsigned)(k.t + 1));
+            if (lane == 0 && pub) ps_st_flag(fbase + k.p * nct + ct, a.epoch + (unsigned)(k.t + 1));
             asm volatile("" ::: "memory");
             issue();                                 // tick n + D into a free ring slot, off the hand-off path
             tr.flush(1, n, lane);
@@ -644,6 +691,11 @@ struct PsBwdArgs {
     float* db; float* dbpart; unsigned* dbtick;
     int defer_from;         // phases per domain from which the deferred form runs (a large value: never)
     int lds_nb;             // 1, or 2 when the launch may defer (double-buffered partial tiles / staged rows)
+    // "direct" launches (no preparation launch, as PsFwdArgs): Wh^T fragments straight from the row-major Wh (one
+    // 16-byte load each: the packed image is a permutation of its float4s), pass 0's all-zero operand from a
+    // zero-length buffer descriptor, flags on epochs, bias-gradient tickets reset by their last arriver
+    int direct;
+    const float* wh_raw; unsigned epoch;
 };
 
 template <int CB, int CPWB>
@@ -752,10 +804,12 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
     k1.next(nrs);
     k2.next(nrs); k2.next(nrs);
     // pass j consumes dz[t+1] with t = T-1-j, i.e. the buffer written in pass j-1: (T-j) & 1
+    // (pass 0 has no dz[T]: legacy launches read a zero-filled buffer, direct ones a zero-length descriptor)
+    const __amdgpu_buffer_rsrc_t dres0 = a.direct ? ps_rsrc(a.dzfrag, 0u) : dres;
     {
         const int off0 = (int)((a.T & 1) * a.dzfrag_bytes) + rs0 * KC4 * 1024 + lane_off;
 #pragma unroll
-        for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, off0 + c * 1024);
+        for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres0, off0 + c * 1024);
     }
     unsigned fv = ps_ld_flag(fl + k1.p * nnt);
     int slot = 0;
@@ -769,16 +823,17 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         float* Pw = P + par * PS_BWD_P_FLOATS + wave * 16 * PS_PLD;
         const bool e1 = n + 1 >= nticks, e2 = n + 2 >= nticks;
         const PsTick q1 = e1 ? k0 : k1, q2 = e2 ? (e1 ? k0 : k1) : k2;
-        const unsigned need1 = e1 ? 0u : (unsigned)q1.t;
+        const unsigned need1 = e1 ? 0u : ps_need(a.epoch, q1.t);
         const int off = (int)(((a.T - k0.t) & 1) * a.dzfrag_bytes) + (rs0 + k0.p) * KC4 * 1024 + lane_off;
         const int off1 = (int)(((a.T - q1.t) & 1) * a.dzfrag_bytes) + (rs0 + q1.p) * KC4 * 1024 + lane_off;
+        const __amdgpu_buffer_rsrc_t rk0 = k0.t == 0 ? dres0 : dres, rq1 = q1.t == 0 ? dres0 : dres;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         PsBwdEpiPre pre;
         tr.stamp(0);
         if (!LA) {
-            ps_wait_flags(fl + k0.p * nnt, (unsigned)k0.t, ps_ld_flag(fl + k0.p * nnt), a.err, 4);
+            ps_wait_flags(fl + k0.p * nnt, ps_need(a.epoch, k0.t), ps_ld_flag(fl + k0.p * nnt), a.err, 4);
 #pragma unroll
-            for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, off + c * 1024);
+            for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(rk0, off + c * 1024);
         }
 #pragma unroll
         for (int st = 0; st < NB; ++st) {
@@ -789,9 +844,10 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
                 tr.stamp(2);
             }
             const int noff = (st < NB - 1) ? off + (st + 1) * CB * 1024 : off1;
+            const __amdgpu_buffer_rsrc_t rn = (st < NB - 1) ? rk0 : rq1;
             if ((st & 1) == 0) {
 #pragma unroll
-                for (int c = 0; c < CB; ++c) s1[c] = ps_ld_sc1(dres, noff + c * 1024);
+                for (int c = 0; c < CB; ++c) s1[c] = ps_ld_sc1(rn, noff + c * 1024);
                 // deferred: the previous phase's product-dependent half, spread over this stage's MFMAs (tick 0: a
                 // dummy on zeros whose stores go to the dump line -- no branch in the chain)
                 // (phase index PS_NRS_MAX = a spare state slot nobody reads)
@@ -800,7 +856,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
                 ps_bwd_stage<CB, CPWB>(s0, bw, st * CB, acc0, acc1);
             } else {
 #pragma unroll
-                for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(dres, noff + c * 1024);
+                for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(rn, noff + c * 1024);
                 if (st == NB - 1) {
                     fv = ps_ld_flag(fl + q2.p * nnt);
                     ps_bwd_epilogue_pre(a, e, k0.p, k0.t, slot, pre);      // interleaved with this stage's MFMAs
@@ -871,8 +927,16 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         // ---------------- MFMA waves ----------------
         f32x4 bw[CPWB];
         const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wb) + ((long)nt * KC4 + wave * CPWB) * 64;
+        if (a.direct) {
 #pragma unroll
-        for (int c = 0; c < CPWB; ++c) bw[c] = Bf[(long)c * 64 + lane];
+            for (int c = 0; c < CPWB; ++c) {
+                const float4 w = d2p_pack_w_bwd_elem(U, a.wh_raw, ((long)nt * KC4 + wave * CPWB + c) * 64 + lane);
+                bw[c] = f32x4{w.x, w.y, w.z, w.w};
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < CPWB; ++c) bw[c] = Bf[(long)c * 64 + lane];
+        }
         const __amdgpu_buffer_rsrc_t dres = ps_rsrc(a.dzfrag, 2u * a.dzfrag_bytes);
         const int lane_off = (wave * CPWB * 64 + lane) * 16;
         const unsigned* fl = fbase + (lane & (nnt - 1));      // every producer of the domain writes this gate
@@ -921,6 +985,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
                 if (lane == 0) ticket = __hip_atomic_fetch_add(a.dbtick + nt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ticket = (unsigned)__builtin_amdgcn_readfirstlane((int)ticket);
                 if (ticket == (unsigned)(a.RT - 1)) {                  // last of this column tile: fold, in domain order
+                    if (lane == 0) __hip_atomic_store(a.dbtick + nt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     float sum = 0.f;
                     for (int r = 0; r < a.RT; ++r)
                         sum += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
@@ -991,7 +1056,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             tr.stamp(2);
             ps_wait_vmcnt<0>();                      // the stores are out (and the loads of the last tick have landed)
             tr.stamp(3);
-            if (lane == 0 && pub) ps_st_flag(fbase + k.p * nnt + nt, (unsigned)(k.t + 1));
+            if (lane == 0 && pub) ps_st_flag(fbase + k.p * nnt + nt, a.epoch + (unsigned)(k.t + 1));
             asm volatile("" ::: "memory");
             issue();                                 // off the hand-off path
             tr.flush(1, n, lane);
@@ -1021,6 +1086,12 @@ static int ps_num_cus() {
 }
 
 // row domains for `ncol` column tiles: as many as fit the chip, at most one per 16-row sub-tile
+static int g_ps_direct = 1;                  // 0: always the preparation launch (d2p_lstm_persist_set_direct: A/B switch)
+extern "C" int d2p_lstm_persist_set_direct(int on) {
+    g_ps_direct = on ? 1 : 0;
+    return D2P_OK;
+}
+extern "C" size_t d2p_lstm_flag_words(void) { return (size_t)PS_FLAG_WORDS + PS_TICKET_WORDS; }
 static int g_ps_bwd_defer_from = 1 << 20;    // backward: deferred form from this many phases per domain (d2p_lstm_persist_set_bwd_defer);
                                              // measured -4 % per phase at 5-7 phases in isolation, nothing in the step: off by default
 extern "C" int d2p_lstm_persist_set_bwd_defer(int from_phases) {
@@ -1054,8 +1125,6 @@ bool d2p_lstm_persist_bwd_ok(int M, int U, int n_steps) {
     return g_persist && ps_shape_ok(M, U, n_steps, U / 16, 1);
 }
 
-#define PS_FLAG_WORDS 4096   // >= RT * PS_NRS_MAX * ncol for any grid <= 512 workgroups
-#define PS_TICKET_WORDS 64   // bias-gradient tickets of the backward kernel, one per column tile (zeroed with the flags)
 #define PS_DUMP_FLOATS 64
 #define PS_DBPART_FLOATS (512 * 64)   // backward: one 64-float partial bias gradient per workgroup
 
@@ -1120,6 +1189,16 @@ static int ps_fwd_setup(const PsFwdCall& q, int RT, int bid0, PsFwdArgs& a, hipS
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.h0 = q.h0; a.c0 = q.c0; a.lens = q.lens;
     a.hout = q.hout; a.cs = q.cs; a.h_final = q.h_final; a.c_final = q.c_final;
+    a.direct = 0; a.wh_raw = q.Wh; a.h0_raw = q.h0; a.h0_bytes = 0; a.epoch = 0;
+    if (q.flags && g_ps_direct) {
+        // direct launch: nothing to prepare -- weights and the initial state are read where they lie, the flags
+        // (the caller's once-zeroed buffer) run on epochs
+        a.direct = 1;
+        a.flags = q.flags;
+        a.epoch = q.epoch;
+        a.h0_bytes = q.h0 ? (unsigned)((size_t)M * U * sizeof(float)) : 0u;
+        return D2P_OK;
+    }
     // packed weights; h0 in fragment order (without one the deferred-epilogue form still multiplies in step 0:
     // an all-zero operand makes that product an exact zero); flags reset
     return ps_prep(0, U, q.Wh, Wf, M, q.h0, a.hfrag, a.hfrag_bytes, a.flags, (size_t)RT * PS_NRS_MAX * nct, st);
@@ -1219,11 +1298,19 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     a.db = q.db;
     a.defer_from = g_ps_bwd_defer_from;
     a.lds_nb = (a.total_rs + RT - 1) / RT >= g_ps_bwd_defer_from ? 2 : 1;
+    a.direct = 0; a.wh_raw = q.Wh; a.epoch = 0;
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.c0 = q.c0; a.cs = q.cs; a.lens = q.lens;
     a.dhout = q.dhout; a.dh_final = q.dh_final; a.dc_final = q.dc_final;
     a.dz = q.dz; a.dh0 = q.dh0; a.dc0 = q.dc0;
+    if (q.flags && g_ps_direct) {
+        a.direct = 1;
+        a.flags = q.flags;
+        a.dbtick = q.flags + PS_FLAG_WORDS;
+        a.epoch = q.epoch;
+        return D2P_OK;
+    }
     // packed Wh^T; pass 0 has no product -- the chain runs on an all-zero dz[T]; flags reset
     // (the whole flag area + the bias-gradient tickets behind it: 1040 uint4 next to 262144 weight float4s)
     return ps_prep(1, U, q.Wh, Wb, M, nullptr, (float*)((char*)a.dzfrag + (size_t)(n_steps & 1) * a.dzfrag_bytes),

@@ -837,9 +837,7 @@ extern "C" int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* d, d2p_
         if (d2p_lstm_try_pair_fwd(d, as_stream(stream), &rc)) return rc;
     }
     for (int i = 0; i < nseq; ++i) {     // generic path: one sequence after the other
-        int rc = d2p_lstm_seq_fwd(d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride,
-                                  d[i].Wh, d[i].h0, d[i].c0, d[i].lens, d[i].hout, d[i].cs, d[i].h_final,
-                                  d[i].c_final, d[i].ws, d[i].ws_bytes, stream);
+        int rc = d2p_lstm_seq_fwd_desc(d + i, stream);
         if (rc) return rc;
     }
     return D2P_OK;

@@ -355,6 +355,31 @@ class _MultiWs(object):
 _MULTI_WS = _MultiWs()
 
 
+class _LstmFlags(object):
+    """Flag buffers of the "direct" persistent launches (d2p_lstm_*_desc.flags / .epoch): one per (direction, sequence
+    slot, stream), zeroed once; the epoch of a buffer rises by n_steps + 2 with every launch that got it.  Not under
+    hipGraph capture (the epoch would be baked into the graph): those launches keep their preparation launch."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def take(self, key, n_steps):
+        if torch.cuda.is_current_stream_capturing():
+            return None, 0
+        ent = self.bufs.get(key)
+        if ent is None:
+            ent = self.bufs[key] = [torch.zeros(int(call.d2p_lstm_flag_words()), dtype=torch.int32, device='cuda'), 0]
+        if ent[1] + n_steps + 2 >= (1 << 31):
+            ent[0].zero_()                       # stream-ordered: behind every launch that used the buffer
+            ent[1] = 0
+        epoch = ent[1]
+        ent[1] += n_steps + 2
+        return ent[0].data_ptr(), epoch
+
+
+_LSTM_FLAGS = _LstmFlags()
+
+
 def lstm_seq_fwd_multi(seqs):
     """seqs: list (<= 3) of dicts with the d2p_lstm_seq_fwd arguments (time-major z)."""
     import ctypes
@@ -371,6 +396,7 @@ def lstm_seq_fwd_multi(seqs):
         d.hout, d.cs = ptr(q['hout']), ptr(q['cs'])
         d.h_final, d.c_final = ptr(q.get('h_final')), ptr(q.get('c_final'))
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+        d.flags, d.epoch = _LSTM_FLAGS.take(('f', i, torch.cuda.current_stream().cuda_stream), q['n_steps'])
     call.d2p_lstm_seq_fwd_multi(len(seqs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
 
 
@@ -392,6 +418,7 @@ def lstm_seq_bwd_multi(seqs):
         d.dz, d.dh0, d.dc0 = ptr(q['dz']), ptr(q.get('dh0')), ptr(q.get('dc0'))
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         d.db = ptr(q.get('db'))            # optional: the bias gradient (column sums of dz), produced with the launch
+        d.flags, d.epoch = _LSTM_FLAGS.take(('b', i, torch.cuda.current_stream().cuda_stream), q['n_steps'] + 1)
     call.d2p_lstm_seq_bwd_multi(len(seqs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
 
 

@@ -61,6 +61,8 @@ SIGNATURES = {
     'd2p_lstm_persist_error': (c_int, [c_int]),
     'd2p_lstm_persist_inject_error': (c_int, []),
     'd2p_lstm_persist_set_bwd_defer': (c_int, [c_int]),
+    'd2p_lstm_flag_words': (c_size_t, []),
+    'd2p_lstm_persist_set_direct': (c_int, [c_int]),
     'd2p_lstm_persist_set_trace': (c_int, [P, c_size_t, c_int]),
     'd2p_lstm_persist_set_wgs_per_cu': (c_int, [c_int, c_int]),
     'd2p_lstm_persist_pair_launches': (c_int, []),
@@ -116,7 +118,7 @@ class LstmFwdDesc(ctypes.Structure):
                 ('z', c_void_p), ('z_row_stride', c_long), ('z_t_stride', c_long),
                 ('Wh', c_void_p), ('h0', c_void_p), ('c0', c_void_p), ('lens', c_void_p),
                 ('hout', c_void_p), ('cs', c_void_p), ('h_final', c_void_p), ('c_final', c_void_p),
-                ('ws', c_void_p), ('ws_bytes', c_size_t)]
+                ('ws', c_void_p), ('ws_bytes', c_size_t), ('flags', c_void_p), ('epoch', ctypes.c_uint)]
 
 
 class LstmBwdDesc(ctypes.Structure):
@@ -126,7 +128,8 @@ class LstmBwdDesc(ctypes.Structure):
                 ('Wh', c_void_p), ('c0', c_void_p), ('lens', c_void_p), ('cs', c_void_p),
                 ('dhout', c_void_p), ('dh_final', c_void_p), ('dc_final', c_void_p),
                 ('dz', c_void_p), ('dh0', c_void_p), ('dc0', c_void_p),
-                ('ws', c_void_p), ('ws_bytes', c_size_t), ('db', c_void_p)]
+                ('ws', c_void_p), ('ws_bytes', c_size_t), ('db', c_void_p), ('flags', c_void_p),
+                ('epoch', ctypes.c_uint)]
 
 
 class XentBwdDesc(ctypes.Structure):

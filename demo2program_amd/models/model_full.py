@@ -198,6 +198,9 @@ class Model(object):
         if os.environ.get('D2P_GEMM_OPTION') is not None:          # experiments (d2p_gemm_set_option bits)
             from ..lib import call
             call.d2p_gemm_set_option(int(os.environ['D2P_GEMM_OPTION']))
+        if os.environ.get('D2P_LSTM_DIRECT') is not None:           # A/B: 0 = a preparation launch in front of every recurrence
+            from ..lib import call
+            call.d2p_lstm_persist_set_direct(int(os.environ['D2P_LSTM_DIRECT']))
         if os.environ.get('D2P_BWD_DEFER_FROM') is not None:       # experiment: d2p_lstm_persist_set_bwd_defer
             from ..lib import call
             call.d2p_lstm_persist_set_bwd_defer(int(os.environ['D2P_BWD_DEFER_FROM']))
@@ -715,7 +718,11 @@ class Model(object):
         else:
             hf = self._buf(name + '/h_final', (M, U)) if want_final else None
             cf = self._buf(name + '/c_final', (M, U)) if want_final else None
-        K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, n_steps, Wh, h0, c0, lens, hout, cs, hf, cf)
+        if n_steps > 0:
+            K.lstm_seq_fwd_multi([dict(M=M, U=U, n_steps=n_steps, z=z, Wh=Wh, h0=h0, c0=c0, lens=lens, hout=hout, cs=cs,
+                                       h_final=hf, c_final=cf)])
+        else:
+            K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, n_steps, Wh, h0, c0, lens, hout, cs, hf, cf)
         return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
                     hout=hout, hbuf=hbuf, cs=cs, h_final=hf, c_final=cf, Wx=Wx, Wh=Wh)
 

@@ -256,6 +256,10 @@ int d2p_lstm_persist_set_trace(void* buf, size_t bytes, int block);
  * published one phase later -- when the domain has at least `from_phases` 16-row phases per step (<= 0: never, the
  * default: measured -4 % per phase at 5-7 phases in isolation and nothing in the training step).  Same results. */
 int d2p_lstm_persist_set_bwd_defer(int from_phases);
+/* Words of a d2p_lstm_*_desc.flags buffer; and the A/B switch of the direct launches (1 default; 0: every persistent
+ * launch gets its preparation launch whatever the descriptor says). */
+size_t d2p_lstm_flag_words(void);
+int d2p_lstm_persist_set_direct(int on);
 /* Tuning knob (process-global): workgroups per CU the persistent forward / backward kernels are
  * sized for (0 keeps the current value; default 1).  2 cuts the rows into twice as many domains so
  * that two workgroups share a CU and overlap each other's MFMA and epilogue phases. */
@@ -295,6 +299,13 @@ typedef struct {
     const float* Wh; const float* h0; const float* c0; const int* lens;
     float* hout; float* cs; float* h_final; float* c_final;
     void* ws; size_t ws_bytes;
+    /* Optional -- a "direct" persistent launch, without the preparation launch (weight pack, initial-state pack,
+     * flag reset) in front of it: `flags` = a device buffer of d2p_lstm_flag_words() 32-bit words that the caller
+     * zeroes ONCE and then hands to this library only (one buffer per sequence slot and stream); `epoch` = a counter
+     * the caller keeps per buffer, starting at 0 and raised by at least n_steps + 2 after every call that got the
+     * buffer (wrap: zero the buffer again, restart at 0).  NULL: the preparation launch runs (needed under hipGraph
+     * capture, where the epoch would be baked into the graph).  Ignored by the per-step back ends. */
+    unsigned* flags; unsigned epoch;
 } d2p_lstm_fwd_desc;
 typedef struct {
     int M, U, n_steps;
@@ -307,6 +318,7 @@ typedef struct {
                      * (needs z_t_stride == M * z_row_stride).  The persistent kernels produce it inside
                      * their launch (per-workgroup sums, folded by each column tile's last workgroup in a
                      * fixed order); the other back ends run d2p_colsum_f32 over dz behind the recurrence. */
+    unsigned* flags; unsigned epoch;   /* as d2p_lstm_fwd_desc */
 } d2p_lstm_bwd_desc;
 int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* descs, d2p_stream_t stream);
 int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* descs, d2p_stream_t stream);
