@@ -20,6 +20,7 @@ extern "C" int d2p_gemm_set_option(int bk32) {
     g_gemm_small_ksr = (bk32 & 2) ? 0 : 1;     // bit 1: switch the small-problem 32x32 tile off
     g_gemm_nosel = (bk32 & 4) ? 0 : 1;         // bit 2: keep the select-at-store loaders for every K
     g_gemm_no_bk32 = (bk32 & 16) ? 1 : 0;      // bit 4 (experiment): never the 32-deep slabs
+    g_gemm_fold = (bk32 & 32) ? 0 : 1;         // bit 5: split-K combine as a separate launch (round 2's form)
     g_gemm_dma_big = (bk32 & 8) ? 1 : 0;       // bit 3 (experiment): large dense GEMMs on the persistent LDS-DMA kernel
     g_gemm_dma_grid = bk32 >> 8;               // bits 8..: persistent grid of the LDS-DMA kernel (0 = automatic)
     return D2P_OK;

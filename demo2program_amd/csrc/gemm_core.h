@@ -253,9 +253,44 @@ struct EpiScatterRows {
 // each consumes one 8-deep chunk of every 32-deep K slab; every wave writes its own split-K
 // slab (slab index blockIdx.z*4 + wave), so the ordinary deterministic combine kernel finishes
 // the job.  Without it 3 of 4 waves idle on a one-tile output.
+// ---- split-K combine inside the GEMM launch (round 3) -------------------------------------------------------------
+// A split-K launch used to be followed by a combine launch (gemm_splitk_reduce_*): 22 of them per training step, 5 us
+// each alone -- but 20-60 us (up to 350) on the side stream beside a persistent recurrent kernel, i.e. 0.6 ms of
+// side-stream time per step.  With `tickets` the K slices of an output tile write their partial tiles with
+// WRITE-THROUGH stores, take a ticket (cdna_hip_programming.md Guideline 16, the sc1 form: stores -> vmcnt(0) ->
+// barrier -> relaxed agent fetch_add), and the LAST one to arrive adds all slices of the tile in slice order (sc1
+// loads; the same order as the flat combine kernel, whichever slice happens to be last: deterministic) and applies
+// the epilogue.  Tickets come from a zero-initialised per-module pool and are reset by their last arriver.
+#define D2P_GEMM_TICKETS 65536
+static __device__ unsigned g_gemm_tickets[D2P_GEMM_TICKETS];
+// (buffer instructions with the sc1 policy, not relaxed atomics: the compiler keeps atomic loads in program order, one
+//  L2 round trip after the other -- 64 of them per lane made the folded launch SLOWER than launch + combine)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t d2p_wt_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void d2p_st_wt(__amdgpu_buffer_rsrc_t r, int idx, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, idx * 4, 0, 16);
+}
+__device__ __forceinline__ float d2p_ld_wt(__amdgpu_buffer_rsrc_t r, int idx) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 16));
+}
+// true in every thread of the workgroup that drew the last ticket of its tile (flag: one LDS word that is free)
+__device__ __forceinline__ bool d2p_last_slice(unsigned* ticket, unsigned nz, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool last = t == nz - 1u;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+
 template <int BM, int BN, int WM, int WN, int BK, bool FAST, bool KS, class AL, class BL, class EP, bool NOSEL = false>
 __global__ void __launch_bounds__(256)
-gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial) {
+gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial, unsigned* tickets) {
     static_assert(!NOSEL || FAST, "NOSEL is a refinement of the fast loaders");
     static_assert(KS || WM * WN == 4, "4 waves per workgroup");
     static_assert(!KS || (WM == 1 && WN == 1 && BK == 32), "KS: one tile for all waves, 4 chunks per slab");
@@ -517,8 +552,35 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             const int col = n0 + (ln & 31);
             const int row = m0 + 4 * (ln >> 5) + (r & 3) + 8 * (r >> 2);
             if (row < M && col < N) {
-                if (to_partial) partial[((long)blockIdx.z * M + row) * N + col] = s;
-                else ep.store(row, col, s + (ep.has_c() ? ep.c_value(row, col) : 0.f) + ep.col_value(col));
+                if (to_partial) {
+                    if (tickets) d2p_st_wt(d2p_wt_rsrc(partial, (unsigned)gridDim.z * M * N * 4u), ((int)blockIdx.z * M + row) * N + col, s);
+                    else partial[((long)blockIdx.z * M + row) * N + col] = s;
+                } else ep.store(row, col, s + (ep.has_c() ? ep.c_value(row, col) : 0.f) + ep.col_value(col));
+            }
+        }
+        if (to_partial && tickets) {
+            __syncthreads();                               // smem is read above: free from here
+            if (!d2p_last_slice(tickets + blockIdx.x, gridDim.z, reinterpret_cast<int*>(smem))) return;
+            const int nz = gridDim.z;
+            const __amdgpu_buffer_rsrc_t pr = d2p_wt_rsrc(partial, (unsigned)nz * M * N * 4u);
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < nz; ++z) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int idx = tid + e * 256;
+                    const int r = idx >> 6, ln = idx & 63;
+                    const int col = min(n0 + (ln & 31), N - 1);
+                    const int row = min(m0 + 4 * (ln >> 5) + (r & 3) + 8 * (r >> 2), M - 1);
+                    s4[e] += d2p_ld_wt(pr, (z * M + row) * N + col);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int idx = tid + e * 256;
+                const int r = idx >> 6, ln = idx & 63;
+                const int col = n0 + (ln & 31);
+                const int row = m0 + 4 * (ln >> 5) + (r & 3) + 8 * (r >> 2);
+                if (row < M && col < N) ep(row, col, s4[e]);
             }
         }
         return;
@@ -546,11 +608,44 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             for (int r = 0; r < 16; ++r) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < M) {
-                    if (split) partial[((long)slab * M + row) * N + col] = acc[i][j][r];
-                    else ep.store(row, col, acc[i][j][r] + (with_c ? cold[r] : 0.f) + cv);
+                    if (split) {
+                        if (!KS && tickets) d2p_st_wt(d2p_wt_rsrc(partial, (unsigned)gridDim.z * M * N * 4u), (slab * M + row) * N + col, acc[i][j][r]);
+                        else partial[((long)slab * M + row) * N + col] = acc[i][j][r];
+                    } else ep.store(row, col, acc[i][j][r] + (with_c ? cold[r] : 0.f) + cv);
                 }
             }
         }
+    if constexpr (!KS) {
+        if (split && tickets) {
+            if (!d2p_last_slice(tickets + blockIdx.x, gridDim.z, reinterpret_cast<int*>(smem))) return;
+            const int nz = gridDim.z;
+            const __amdgpu_buffer_rsrc_t pr = d2p_wt_rsrc(partial, (unsigned)nz * M * N * 4u);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = n0 + wn * (BN / WN) + j * 32 + l32;
+                    const int rbase = m0 + wm * (BM / WM) + i * 32 + 4 * hi;
+                    if (col >= N) continue;
+                    // slice by slice, the 16 rows of a slice in flight together (clamped rows: loaded, never stored)
+                    float s16[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s16[r] = 0.f;
+                    for (int z = 0; z < nz; ++z) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = min(rbase + (r & 3) + 8 * (r >> 2), M - 1);
+                            s16[r] += d2p_ld_wt(pr, (z * M + row) * N + col);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < M) ep(row, col, s16[r]);
+                    }
+                }
+        }
+    }
 }
 
 template <> struct d2p_batch_ok<EpiDense> { static constexpr bool value = true; };
@@ -963,6 +1058,19 @@ static inline GemmPlan d2p_plan_gemm_base(int M, int N, int K, bool allow_split)
 }
 
 static int g_gemm_small_ksr = 1;   // 0: never pick the 32x32 wave-split tile automatically
+static int g_gemm_fold = 1;        // split-K combine inside the GEMM launch (0: the separate combine launches)
+// a slice of this module's ticket pool (ONE cursor for every instantiation of the launcher: GEMMs of two streams may be
+// in flight together and must not share tickets; a slice is reused after the pool has gone round once)
+static inline unsigned* d2p_gemm_take_tickets(unsigned ntiles) {
+    static unsigned* pool = nullptr;
+    static unsigned next = 0;
+    if (!pool) (void)hipGetSymbolAddress((void**)&pool, HIP_SYMBOL(g_gemm_tickets));
+    if (!pool || ntiles > D2P_GEMM_TICKETS / 4) return nullptr;
+    if (next + ntiles > D2P_GEMM_TICKETS) next = 0;
+    unsigned* t = pool + next;
+    next += ntiles;
+    return t;
+}
 static int g_gemm_no_bk32 = 0;     // experiment: never the 32-deep slabs (16 KB of LDS per workgroup instead of 32)
 static int g_gemm_dma_big = 0;     // experiment: large dense GEMMs (>= 2 GFLOP) on the persistent LDS-DMA kernel
 
@@ -997,19 +1105,20 @@ static inline size_t d2p_plan_ws_bytes(int M, int N, int K) {
 
 template <int BM, int BN, int WM, int WN, int BK, bool KS = false, class AL, class BL, class EP>
 static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int N, int K,
-                            const GemmPlan& p, bool fast, float* partial, hipStream_t st, int batch = 1) {
+                            const GemmPlan& p, bool fast, float* partial, hipStream_t st, int batch = 1,
+                            unsigned* tickets = nullptr) {
     dim3 grid(ceil_div(M, BM) * ceil_div(N, BN), batch, p.splits);
     constexpr bool NOSEL_OK = d2p_nosel_ok<AL>::value && d2p_nosel_ok<BL>::value;
     if (NOSEL_OK && fast && g_gemm_nosel && K % BK == 0 && (p.splits == 1 || p.k_per_split % BK == 0)) {
         if constexpr (NOSEL_OK)
             hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP, true>), grid, dim3(256), 0,
-                               st, al, bl, ep, M, N, K, p.k_per_split, partial);
+                               st, al, bl, ep, M, N, K, p.k_per_split, partial, tickets);
     } else if (fast)
         hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP>), grid, dim3(256), 0, st,
-                           al, bl, ep, M, N, K, p.k_per_split, partial);
+                           al, bl, ep, M, N, K, p.k_per_split, partial, tickets);
     else
         hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, false, KS, AL, BL, EP>), grid, dim3(256), 0, st,
-                           al, bl, ep, M, N, K, p.k_per_split, partial);
+                           al, bl, ep, M, N, K, p.k_per_split, partial, tickets);
 }
 
 template <int BM, int BN, int WM, int WN, int STAGES, class AL, class BL, class EP>
@@ -1063,6 +1172,13 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         }
     }
     const bool fast = al.fast_ok(K) && bl.fast_ok(K);
+    // split-K combine inside the launch: plain and 32x32 wave-split tiles (the KS tiles write one slab per WAVE and keep
+    // the combine pass); a slice of the module's ticket pool, round-robin
+    unsigned* tickets = nullptr;
+    if (p.slabs > 1 && p.slabs <= 16 && (double)p.slabs * M * N * 4.0 < 2e9 && g_gemm_fold && !d2p_tile_is_dma(p.tile) &&
+        p.tile != TILE_64x32_KS && p.tile != TILE_64x64_KS) {
+        tickets = d2p_gemm_take_tickets((unsigned)(ceil_div(M, p.bm) * ceil_div(N, p.bn)));
+    }
     if (d2p_tile_is_dma(p.tile)) {
         bool done = false;
         if constexpr (d2p_nosel_ok<AL>::value && d2p_nosel_ok<BL>::value && d2p_batch_ok<EP>::value) {
@@ -1084,24 +1200,24 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
     switch (p.tile) {
         case TILE_DMA_64x64_S4: case TILE_DMA_64x64_S3: case TILE_DMA_128x64_S3: case TILE_DMA_128x128_S2:
         case TILE_DMA_128x128_S3: break;            // launched above
-        case TILE_128x128: d2p_launch_tile<128, 128, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
-        case TILE_128x32: d2p_launch_tile<128, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
-        case TILE_256x32: d2p_launch_tile<256, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
-        case TILE_128x64: d2p_launch_tile<128, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
+        case TILE_128x128: d2p_launch_tile<128, 128, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets); break;
+        case TILE_128x32: d2p_launch_tile<128, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets); break;
+        case TILE_256x32: d2p_launch_tile<256, 32, 4, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets); break;
+        case TILE_128x64: d2p_launch_tile<128, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets); break;
         case TILE_64x32_KS: d2p_launch_tile<64, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
         case TILE_64x64_KS: d2p_launch_tile<64, 64, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
-        case TILE_32x32_KSR: d2p_launch_tile<32, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
+        case TILE_32x32_KSR: d2p_launch_tile<32, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets); break;
         default:
             // 32-deep slabs (half the barriers, 128-byte runs): +3-5 % on the large grids, a loss when
             // the workgroups are few (each then walks its K loop with less overlap)
             if (!g_gemm_no_bk32 && (g_gemm_bk32 || (long)ceil_div(M, 64) * ceil_div(N, 64) * p.splits >= 1024) && K >= 256 && fast)
-                d2p_launch_tile<64, 64, 2, 2, 32>(al, bl, ep, M, N, K, p, fast, partial, st, batch);
+                d2p_launch_tile<64, 64, 2, 2, 32>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets);
             else
-                d2p_launch_tile<64, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch);
+                d2p_launch_tile<64, 64, 2, 2, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets);
             break;
     }
     D2P_LAUNCH_CHECK(name);
-    if (p.slabs > 1) {
+    if (p.slabs > 1 && !tickets) {
         const long total = (long)M * N;
         if (p.slabs <= 16) {
             int blocks = (int)((total + 255) / 256);
