@@ -207,7 +207,7 @@ bool d2p_lstm_try_pair_fwd(const d2p_lstm_fwd_desc* d, hipStream_t st, int* rc) 
     for (int i = 0; i < 2; ++i)
         c[i] = PsFwdCall{d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh, d[i].h0,
                          d[i].c0, d[i].lens, d[i].hout, d[i].cs, d[i].h_final, d[i].c_final, (float*)d[i].ws,
-                         d[i].flags, d[i].epoch};
+                         d[i].flags, d[i].epoch, d[i].wpack};
     *rc = d2p_lstm_persist_fwd_pair(c[0], c[1], st);
     return true;
 }
@@ -225,7 +225,8 @@ bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc) 
     for (int i = 0; i < 2; ++i)
         c[i] = PsBwdCall{d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh, d[i].c0,
                          d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final, d[i].dc_final, d[i].dz, d[i].dh0, d[i].dc0,
-                         (float*)d[i].ws, d[i].db, d[i].flags, d[i].epoch};
+                         (float*)d[i].ws, d[i].db, d[i].flags, d[i].epoch, d[i].wpack, d[i].rowmap,
+                         d[i].slab_steps};
     *rc = d2p_lstm_persist_bwd_pair(c[0], c[1], st);
     return true;
 }
@@ -246,7 +247,8 @@ bool d2p_lstm_try_triple_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc
     for (int i = 0; i < 3; ++i)
         c[i] = PsBwdCall{d[i].M, d[i].U, d[i].n_steps, d[i].z, d[i].z_row_stride, d[i].z_t_stride, d[i].Wh, d[i].c0,
                          d[i].lens, d[i].cs, d[i].dhout, d[i].dh_final, d[i].dc_final, d[i].dz, d[i].dh0, d[i].dc0,
-                         (float*)d[i].ws, d[i].db, d[i].flags, d[i].epoch};
+                         (float*)d[i].ws, d[i].db, d[i].flags, d[i].epoch, d[i].wpack, d[i].rowmap,
+                         d[i].slab_steps};
     *rc = d2p_lstm_persist_bwd_triple(c, st);
     return true;
 }
@@ -254,7 +256,8 @@ bool d2p_lstm_try_triple_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc
 static int seq_fwd_impl(int M, int U, int n_steps, float* z, long z_row_stride,
                         long z_t_stride, const float* Wh, const float* h0, const float* c0,
                         const int* lens, float* hout, float* cs, float* h_final,
-                        float* c_final, void* ws, size_t ws_bytes, d2p_stream_t stream, unsigned* flags, unsigned epoch);
+                        float* c_final, void* ws, size_t ws_bytes, d2p_stream_t stream, unsigned* flags, unsigned epoch,
+                        const float* wpack = nullptr);
 
 extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_stride,
                                 long z_t_stride, const float* Wh, const float* h0, const float* c0,
@@ -265,13 +268,14 @@ extern "C" int d2p_lstm_seq_fwd(int M, int U, int n_steps, float* z, long z_row_
 }
 int d2p_lstm_seq_fwd_desc(const d2p_lstm_fwd_desc* q, d2p_stream_t stream) {
     return seq_fwd_impl(q->M, q->U, q->n_steps, q->z, q->z_row_stride, q->z_t_stride, q->Wh, q->h0, q->c0, q->lens,
-                        q->hout, q->cs, q->h_final, q->c_final, q->ws, q->ws_bytes, stream, q->flags, q->epoch);
+                        q->hout, q->cs, q->h_final, q->c_final, q->ws, q->ws_bytes, stream, q->flags, q->epoch, q->wpack);
 }
 
 static int seq_fwd_impl(int M, int U, int n_steps, float* z, long z_row_stride,
                         long z_t_stride, const float* Wh, const float* h0, const float* c0,
                         const int* lens, float* hout, float* cs, float* h_final,
-                        float* c_final, void* ws, size_t ws_bytes, d2p_stream_t stream, unsigned* flags, unsigned epoch) {
+                        float* c_final, void* ws, size_t ws_bytes, d2p_stream_t stream, unsigned* flags, unsigned epoch,
+                        const float* wpack) {
     D2P_REQUIRE(M >= 0 && U > 0 && n_steps >= 0, D2P_EINVAL, "lstm seq fwd: bad sizes");
     hipStream_t st = as_stream(stream);
     const size_t MU = (size_t)M * U;
@@ -282,7 +286,7 @@ static int seq_fwd_impl(int M, int U, int n_steps, float* z, long z_row_stride,
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && d2p_lstm_persist_fwd_ok(M, U, n_steps) &&
         ws_bytes >= d2p_lstm_persist_ws_bytes(M, U))
         return d2p_lstm_persist_fwd(PsFwdCall{M, U, n_steps, z, z_row_stride, z_t_stride, Wh, h0, c0, lens, hout, cs,
-                                              h_final, c_final, (float*)ws, flags, epoch}, st);
+                                              h_final, c_final, (float*)ws, flags, epoch, wpack}, st);
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes))
         return d2p_lstm_fused_fwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, h0, c0, lens, hout,
                                   cs, h_final, c_final, (float*)ws, st);
@@ -315,7 +319,8 @@ static int seq_bwd_impl(int M, int U, int n_steps, const float* z, long z_row_st
                         const float* cs, const float* dhout, const float* dh_final,
                         const float* dc_final, float* dz, float* dh0, float* dc0, void* ws,
                         size_t ws_bytes, d2p_stream_t stream, float* db, bool* db_done, unsigned* flags = nullptr,
-                        unsigned epoch = 0u);
+                        unsigned epoch = 0u, const float* wpack = nullptr, const int* rowmap = nullptr,
+                        const int* slab_steps = nullptr);
 
 extern "C" int d2p_lstm_seq_bwd(int M, int U, int n_steps, const float* z, long z_row_stride,
                                 long z_t_stride, const float* Wh, const float* c0, const int* lens,
@@ -346,7 +351,7 @@ int d2p_lstm_seq_bwd_desc(const d2p_lstm_bwd_desc* q, d2p_stream_t stream) {
     bool done = false;
     int rc = seq_bwd_impl(q->M, q->U, q->n_steps, q->z, q->z_row_stride, q->z_t_stride, q->Wh, q->c0, q->lens, q->cs,
                           q->dhout, q->dh_final, q->dc_final, q->dz, q->dh0, q->dc0, q->ws, q->ws_bytes, stream, q->db,
-                          &done, q->flags, q->epoch);
+                          &done, q->flags, q->epoch, q->wpack, q->rowmap, q->slab_steps);
     if (rc || done) return rc;
     return d2p_lstm_db_colsum(q, stream);
 }
@@ -355,7 +360,8 @@ static int seq_bwd_impl(int M, int U, int n_steps, const float* z, long z_row_st
                         long z_t_stride, const float* Wh, const float* c0, const int* lens,
                         const float* cs, const float* dhout, const float* dh_final,
                         const float* dc_final, float* dz, float* dh0, float* dc0, void* ws,
-                        size_t ws_bytes, d2p_stream_t stream, float* db, bool* db_done, unsigned* flags, unsigned epoch) {
+                        size_t ws_bytes, d2p_stream_t stream, float* db, bool* db_done, unsigned* flags, unsigned epoch,
+                        const float* wpack, const int* rowmap, const int* slab_steps) {
     D2P_REQUIRE(M >= 0 && U > 0 && n_steps >= 0, D2P_EINVAL, "lstm seq bwd: bad sizes");
     hipStream_t st = as_stream(stream);
     const size_t MU = (size_t)M * U;
@@ -367,7 +373,8 @@ static int seq_bwd_impl(int M, int U, int n_steps, const float* z, long z_row_st
         d2p_lstm_persist_bwd_ok(M, U, n_steps) && ws_bytes >= d2p_lstm_persist_ws_bytes(M, U)) {
         *db_done = true;
         return d2p_lstm_persist_bwd(PsBwdCall{M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,
-                                              dh_final, dc_final, dz, dh0, dc0, (float*)ws, db, flags, epoch}, st);
+                                              dh_final, dc_final, dz, dh0, dc0, (float*)ws, db, flags, epoch, wpack,
+                                              rowmap, slab_steps}, st);
     }
     if (n_steps > 0 && use_fused(M, U, z_row_stride, z, ws_bytes) && (((uintptr_t)dz & 15) == 0))
         return d2p_lstm_fused_bwd(M, U, n_steps, z, z_row_stride, z_t_stride, Wh, c0, lens, cs, dhout,

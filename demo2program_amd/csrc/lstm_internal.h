@@ -66,6 +66,7 @@ struct PsFwdCall {
     // optional ("direct" launch: no preparation launch): a dedicated flag buffer of D2P_LSTM_FLAG_WORDS words,
     // zeroed ONCE by the caller, and the caller's epoch for it (raised by more than n_steps per launch)
     unsigned* flags; unsigned epoch;
+    const float* wpack;      // optional with flags: the caller's packed forward image of Wh (d2p_lstm_pack_weights)
 };
 struct PsBwdCall {
     int M, U, n_steps;
@@ -76,6 +77,11 @@ struct PsBwdCall {
     float* ws;
     float* db;          // optional: bias gradient [4U] = column sums of dz, produced inside the launch
     unsigned* flags; unsigned epoch;      // as PsFwdCall
+    const float* wpack;                   // ... the packed backward (Wh^T) image
+    // optional with flags (length-sorted launch): rowmap[v] (device, M entries) = the caller's row at position v of the
+    // order by decreasing length; slab_steps (HOST, ceil(M/16) entries) = the longest length among rows 16s .. 16s+15 of
+    // that order.  Domains then run only as many passes as their longest row needs.
+    const int* rowmap; const int* slab_steps;
 };
 int d2p_lstm_persist_fwd(const PsFwdCall& q, hipStream_t st);
 int d2p_lstm_persist_bwd(const PsBwdCall& q, hipStream_t st);

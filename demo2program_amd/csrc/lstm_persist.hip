@@ -54,6 +54,7 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define PS_AUX_SC1 16       // buffer-instruction cache policy: sc1 (agent scope, bypasses the CU's L1)
 #define PS_FLAG_WORDS 4096   // >= RT * PS_NRS_MAX * ncol for any grid <= 512 workgroups
 #define PS_TICKET_WORDS 64   // bias-gradient tickets of the backward kernel, one per column tile (zeroed with the flags)
+#define PS_RT_TAB 8          // row domains a length-sorted launch can describe (backward, U = 512: 8 domains)
 
 // ---- error word ---------------------------------------------------------------------------
 __device__ unsigned g_ps_err;          // sticky: 0 ok, else (code << 24) | block
@@ -227,6 +228,7 @@ struct PsFwdArgs {
     //     raises the epoch by more than T from launch to launch (a dedicated, once-zeroed flag buffer).
     int direct;
     const float* wh_raw; const float* h0_raw; unsigned h0_bytes; unsigned epoch;
+    int packed;             // direct launch with a caller-kept packed weight image in Wf (d2p_lstm_pack_weights)
 };
 
 // where a phase's 16 rows of the running state are read from: descriptor, byte offset of chunk 0, bytes per chunk
@@ -551,7 +553,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
         // ---------------- MFMA waves ----------------
         f32x4 bv[CPW][2];
         const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wf);
-        if (a.direct) {
+        if (a.direct && !a.packed) {
             // straight from the row-major Wh: the element the packed image would hold at this index (four 4-byte loads
             // per register instead of one 16-byte load, once per launch -- and no pack pass over 4 MB in front of it)
 #pragma unroll
@@ -696,6 +698,16 @@ struct PsBwdArgs {
     // zero-length buffer descriptor, flags on epochs, bias-gradient tickets reset by their last arriver
     int direct;
     const float* wh_raw; unsigned epoch;
+    int packed;             // as PsFwdArgs: Wb is the caller's packed Wh^T image
+    // Length-sorted launches (direct ones only).  The kernel works on VIRTUAL rows -- the caller's rows ordered by
+    // decreasing length, rowmap[v] = the row of the caller's arrays -- so that a domain (a contiguous range of
+    // 16-row sub-tiles, rs_start[d] .. rs_start[d+1]) holds rows of similar length and runs only tdom[d] = its
+    // longest row's passes; the host sizes the domains so that (phases x passes) is balanced.  Everything the
+    // caller sees stays in ITS row order; dz of the passes a domain skips is zero-filled (what the masked passes
+    // would have written).
+    const int* rowmap;
+    int sorted, Tfull;
+    int rs_start[PS_RT_TAB + 1], tdom[PS_RT_TAB];
 };
 
 template <int CB, int CPWB>
@@ -727,11 +739,14 @@ struct PsBwdEpiPre {
     LstmCellBwdPre q;
     float dhx, dcv;
     bool cur_active;
+    int prow;               // the row of the caller's arrays (clamped into range)
 };
 __device__ __forceinline__ void ps_bwd_epilogue_pre(const PsBwdArgs& a, const PsBwdEpi& e, int p, int j, int slot,
                                                     PsBwdEpiPre& pre) {
     const int t = a.T - 1 - j;
-    const int len = e.stl[p * 16 + e.rr];
+    const int lw = e.stl[p * 16 + e.rr];         // length | row << 16
+    const int len = lw & 0xffff;
+    pre.prow = lw >> 16;
     const bool next_active = (t + 1 < a.T) && (t + 1 < len);
     pre.cur_active = (t >= 0) && (t < len);
     const float* rs = e.ring + slot * PS_BWD_SLOT + e.rr * 16 + e.un;
@@ -772,7 +787,7 @@ __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const P
     // unconditional stores: dz[t] row-major (the dh0 pass writes dh0 with the first and dumps the rest);
     // addresses for a clamped row, only the final offset selected (see the forward epilogue)
     const bool fin = t < 0;
-    const int rowc = min(row, a.M - 1);
+    const int rowc = pre.prow;
     const long zo = (long)max(t, 0) * a.zts + (long)rowc * a.zrs + e.u;
     const long dd = a.dump - a.dz;
     float* dzr = a.dz + ((valid && !fin) ? zo : dd);
@@ -815,7 +830,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
     int slot = 0;
     PsBwdEpiPre pre_prev;
     pre_prev.q = LstmCellBwdPre{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    pre_prev.dhx = 0.f; pre_prev.dcv = 0.f; pre_prev.cur_active = false;
+    pre_prev.dhx = 0.f; pre_prev.dcv = 0.f; pre_prev.cur_active = false; pre_prev.prow = 0;
     PsTick kprev = {0, 0};
 #pragma unroll 1
     for (int n = 0; n < nticks; ++n) {
@@ -896,7 +911,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
 template <int CPW>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16
 __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs a0, PsBwdArgs a1, PsBwdArgs a2) {
     // up to three independent sequences per launch (the three decoders), on disjoint workgroups as in the forward kernel
-    const PsBwdArgs a = ((int)blockIdx.x >= a0.gsz + a1.gsz) ? a2 : (((int)blockIdx.x >= a0.gsz) ? a1 : a0);
+    PsBwdArgs a = ((int)blockIdx.x >= a0.gsz + a1.gsz) ? a2 : (((int)blockIdx.x >= a0.gsz) ? a1 : a0);
     constexpr int CPWB = 4 * CPW;                // chunks per wave
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
@@ -908,8 +923,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
     const int nb = a.lds_nb;
     float* P = lds;                                            // [nb][4][16][PS_PLD] (16 columns used; tick parity)
     float* stdc = lds + nb * PS_BWD_P_FLOATS;                  // [NRS + 1 spare][16 rows][16 units] dC state
-    int* stl = reinterpret_cast<int*>(stdc + (PS_NRS_MAX + 1) * 256);     // [NRS][16] row length
-    float* stage = stdc + (PS_NRS_MAX + 1) * 256 + PS_NRS_MAX * 16;  // [nb][4 gates][4 quads][16 rows][4]: dz of a phase
+    int* stl = reinterpret_cast<int*>(stdc + (PS_NRS_MAX + 1) * 256);     // [NRS][16] row length | row << 16
+    int* strow = stl + PS_NRS_MAX * 16;                               // [NRS][16] the prefetch wave's copy of the rows
+    float* stage = stdc + (PS_NRS_MAX + 1) * 256 + 2 * PS_NRS_MAX * 16;  // [nb][4 gates][4 quads][16 rows][4]: dz of a phase
     float* ring = stage + nb * 1024;                           // [PS_PF_R][8][16 rows][16 units]
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -918,6 +934,18 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
     ps_block_tile((int)blockIdx.x - a.bid0, a.gsz, nnt, rt, nt);
     int rs0, nrs;
     ps_rt_range(rt, a.total_rs, a.RT, rs0, nrs);
+    if (a.sorted) {
+        // this domain's range and pass count (selects, not a dynamic index into the argument block)
+        int r0 = 0, r1 = 0, td = 1;
+#pragma unroll
+        for (int i = 0; i < PS_RT_TAB; ++i) {
+            r0 = (i == rt) ? a.rs_start[i] : r0;
+            r1 = (i == rt) ? a.rs_start[i + 1] : r1;
+            td = (i == rt) ? a.tdom[i] : td;
+        }
+        rs0 = r0; nrs = r1 - r0;
+        a.T = td;
+    }
     const int J = a.T + (a.want_dh0 ? 1 : 0);    // passes: t = T-1 .. 0 (, -1)
     const int nticks = nrs * J;
     unsigned* fbase = a.flags + (long)rt * PS_NRS_MAX * nnt;
@@ -927,7 +955,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         // ---------------- MFMA waves ----------------
         f32x4 bw[CPWB];
         const f32x4* Bf = reinterpret_cast<const f32x4*>(a.Wb) + ((long)nt * KC4 + wave * CPWB) * 64;
-        if (a.direct) {
+        if (a.direct && !a.packed) {
 #pragma unroll
             for (int c = 0; c < CPWB; ++c) {
                 const float4 w = d2p_pack_w_bwd_elem(U, a.wh_raw, ((long)nt * KC4 + wave * CPWB + c) * 64 + lane);
@@ -946,15 +974,17 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         e.u = nt * 16 + e.un;
         e.P = P; e.stdc = stdc; e.stl = stl; e.stage = stage; e.ring = ring;
         for (int p = 0; p < nrs; ++p) {
-            const int row = (rs0 + p) * 16 + e.rr;
+            const int vrow = (rs0 + p) * 16 + e.rr;
+            int row = min(vrow, a.M - 1);
+            if (a.rowmap && vrow < a.M) row = a.rowmap[vrow];
             float d = 0.f;
             int len = a.T;
-            if (row < a.M) {
+            if (vrow < a.M) {
                 if (a.dc_final) d = a.dc_final[(long)row * U + e.u];
                 if (a.lens) len = a.lens[row];
             }
             stdc[(p * 16 + e.rr) * 16 + e.un] = d;
-            if (e.un == 0) stl[p * 16 + e.rr] = len;
+            if (e.un == 0) stl[p * 16 + e.rr] = min(len, 0xffff) | (row << 16);
         }
         float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
         // slack between a publication and the phase that asks for it: nrs - 2 phases with look-ahead, nrs - 3 with the
@@ -996,8 +1026,21 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         }
         if (a.dc0)
             for (int qq = 0; qq < nrs; ++qq) {
-                const int row = (rs0 + qq) * 16 + e.rr;
-                if (row < a.M) a.dc0[(long)row * U + e.u] = stdc[(qq * 16 + e.rr) * 16 + e.un];
+                const int vrow = (rs0 + qq) * 16 + e.rr;
+                const int row = stl[qq * 16 + e.rr] >> 16;
+                if (vrow < a.M) a.dc0[(long)row * U + e.u] = stdc[(qq * 16 + e.rr) * 16 + e.un];
+            }
+        if (a.sorted && a.T < a.Tfull)
+            // the passes this domain did not run: every row is past its length there, dz = 0
+            for (int qq = 0; qq < nrs; ++qq) {
+                const int vrow = (rs0 + qq) * 16 + e.rr;
+                const int row = stl[qq * 16 + e.rr] >> 16;
+                if (vrow < a.M)
+                    for (int t = a.T; t < a.Tfull; ++t) {
+                        float* zr = a.dz + (long)t * a.zts + (long)row * a.zrs + e.u;
+#pragma unroll
+                        for (int gg = 0; gg < 4; ++gg) zr[(long)gg * U] = 0.f;
+                    }
             }
     } else {
         // ---------------- publish + prefetch wave ----------------
@@ -1005,12 +1048,19 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         // step, c after it, dhout, dh_final.  Absent operands fetch a valid dummy (never read).
         const int r = lane >> 2, q = lane & 3;
         const int u = nt * 16 + q * 4;
+        for (int i = lane; i < nrs * 16; i += 64) {        // this wave's own table of the domain's rows
+            const int vrow = rs0 * 16 + i;
+            int row = min(vrow, a.M - 1);
+            if (a.rowmap && vrow < a.M) row = a.rowmap[vrow];
+            strow[i] = row;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         PsTick kp = {0, 0};
         int pslot = 0;
         auto issue = [&]() {
             const PsTick kk = kp;
             const int t = max(a.T - 1 - kk.t, 0);                       // the dh0 pass fetches step 0 again (unused)
-            const int row = min((rs0 + kk.p) * 16 + r, a.M - 1);
+            const int row = strow[kk.p * 16 + r];
             const long o = (long)row * U + u;
             float* dst = ring + pslot * PS_BWD_SLOT;
             const float* zr = a.z + (long)t * a.zts + (long)row * a.zrs + u;
@@ -1086,12 +1136,51 @@ static int ps_num_cus() {
 }
 
 // row domains for `ncol` column tiles: as many as fit the chip, at most one per 16-row sub-tile
+// Packed weight images of up to 8 cells in ONE launch: forward (B operand of h.Wh) and backward (Wh^T) fragments of
+// each Wh [U, 4U].  The trainer's model runs it on the side stream at the start of a step, beside the conv / batch-norm
+// chain, and hands the images to the recurrences through d2p_lstm_*_desc.wpack: their prologues then read contiguous
+// 16-byte fragments instead of gathering from the row-major matrix.
+struct PsPackArgs { int n, U; const float* wh[8]; float4* wf[8]; float4* wb[8]; };
+__global__ void __launch_bounds__(256) ps_pack_weights_kernel(PsPackArgs a) {
+    const long per = (long)a.U * a.U;                   // float4s per image
+    const int cell = blockIdx.y;
+    for (long idx = blockIdx.x * 256L + threadIdx.x; idx < 2 * per; idx += (long)gridDim.x * 256L) {
+        if (idx < per) {
+            if (a.wf[cell]) a.wf[cell][idx] = d2p_pack_w_fwd_elem(a.U, a.wh[cell], idx);
+        } else if (a.wb[cell]) {
+            a.wb[cell][idx - per] = d2p_pack_w_bwd_elem(a.U, a.wh[cell], idx - per);
+        }
+    }
+}
+extern "C" int d2p_lstm_pack_weights(int n, int U, const float* const* Wh, float* const* Wf, float* const* Wb,
+                                     d2p_stream_t stream) {
+    D2P_REQUIRE(n >= 1 && n <= 8 && (U == 64 || U == 128 || U == 256 || U == 512) && Wh && Wf && Wb, D2P_EINVAL,
+                "lstm pack weights: 1..8 cells, U in {64,128,256,512}");
+    PsPackArgs a;
+    a.n = n; a.U = U;
+    for (int i = 0; i < 8; ++i) {
+        a.wh[i] = i < n ? Wh[i] : nullptr;
+        a.wf[i] = i < n ? (float4*)Wf[i] : nullptr;
+        a.wb[i] = i < n ? (float4*)Wb[i] : nullptr;
+        D2P_REQUIRE(i >= n || a.wh[i], D2P_EINVAL, "lstm pack weights: null Wh");
+    }
+    long blocks = (2L * U * U + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(ps_pack_weights_kernel, dim3((unsigned)blocks, n), dim3(256), 0, as_stream(stream), a);
+    D2P_LAUNCH_CHECK("lstm_pack_weights");
+    return D2P_OK;
+}
 static int g_ps_direct = 1;                  // 0: always the preparation launch (d2p_lstm_persist_set_direct: A/B switch)
 extern "C" int d2p_lstm_persist_set_direct(int on) {
     g_ps_direct = on ? 1 : 0;
     return D2P_OK;
 }
 extern "C" size_t d2p_lstm_flag_words(void) { return (size_t)PS_FLAG_WORDS + PS_TICKET_WORDS; }
+static int g_ps_sorted = 1;                  // 0: ignore the length-sorted description of a launch (A/B switch)
+extern "C" int d2p_lstm_persist_set_sorted(int on) {
+    g_ps_sorted = on ? 1 : 0;
+    return D2P_OK;
+}
 static int g_ps_bwd_defer_from = 1 << 20;    // backward: deferred form from this many phases per domain (d2p_lstm_persist_set_bwd_defer);
                                              // measured -4 % per phase at 5-7 phases in isolation, nothing in the step: off by default
 extern "C" int d2p_lstm_persist_set_bwd_defer(int from_phases) {
@@ -1189,7 +1278,7 @@ static int ps_fwd_setup(const PsFwdCall& q, int RT, int bid0, PsFwdArgs& a, hipS
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.h0 = q.h0; a.c0 = q.c0; a.lens = q.lens;
     a.hout = q.hout; a.cs = q.cs; a.h_final = q.h_final; a.c_final = q.c_final;
-    a.direct = 0; a.wh_raw = q.Wh; a.h0_raw = q.h0; a.h0_bytes = 0; a.epoch = 0;
+    a.direct = 0; a.wh_raw = q.Wh; a.h0_raw = q.h0; a.h0_bytes = 0; a.epoch = 0; a.packed = 0;
     if (q.flags && g_ps_direct) {
         // direct launch: nothing to prepare -- weights and the initial state are read where they lie, the flags
         // (the caller's once-zeroed buffer) run on epochs
@@ -1197,6 +1286,10 @@ static int ps_fwd_setup(const PsFwdCall& q, int RT, int bid0, PsFwdArgs& a, hipS
         a.flags = q.flags;
         a.epoch = q.epoch;
         a.h0_bytes = q.h0 ? (unsigned)((size_t)M * U * sizeof(float)) : 0u;
+        if (q.wpack) {               // the caller's packed image (kept up to date off the critical path)
+            a.packed = 1;
+            a.Wf = (const float4*)q.wpack;
+        }
         return D2P_OK;
     }
     // packed weights; h0 in fragment order (without one the deferred-epilogue form still multiplies in step 0:
@@ -1278,7 +1371,45 @@ int d2p_lstm_persist_fwd_pair(const PsFwdCall& qa, const PsFwdCall& qb, hipStrea
     return ps_fwd_launch(a, b, qa.U, ps_fwd_flops(qa) + ps_fwd_flops(qb), st);
 }
 
-static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipStream_t st) {
+// Length-sorted launch: cut the (sorted, longest first) sub-tiles into RT contiguous domains so that the slowest
+// domain -- passes of its first sub-tile x the per-pass cost of its phases -- is as fast as possible (dynamic
+// programme over the cut positions; steps[s] = passes sub-tile s needs = the length of its longest row).
+static bool ps_plan_sorted(int trs, int RT, const int* steps, int extra_pass, double ph, double fl, int* rs_start,
+                           int* tdom) {
+    if (RT < 1 || RT > PS_RT_TAB || trs < RT || trs > 256) return false;
+    auto cost = [&](int s0, int s1) {          // domain of sub-tiles [s0, s1)
+        const double step = ph * (s1 - s0);
+        return (double)(steps[s0] + extra_pass) * (step > fl ? step : fl);
+    };
+    // best[d][s]: smallest possible maximum over the first d domains covering sub-tiles [0, s)
+    static thread_local double best[PS_RT_TAB + 1][257];
+    static thread_local int cut[PS_RT_TAB + 1][257];
+    for (int d = 0; d <= RT; ++d)
+        for (int s2 = 0; s2 <= trs; ++s2) best[d][s2] = 1e30;
+    best[0][0] = 0.0;
+    for (int d = 1; d <= RT; ++d)
+        for (int s2 = d; s2 <= trs - (RT - d); ++s2)
+            for (int s1 = (s2 - PS_NRS_MAX > d - 1 ? s2 - PS_NRS_MAX : d - 1); s1 < s2; ++s1) {
+                if (best[d - 1][s1] >= 1e30) continue;
+                const double c = cost(s1, s2), m = c > best[d - 1][s1] ? c : best[d - 1][s1];
+                if (m < best[d][s2]) { best[d][s2] = m; cut[d][s2] = s1; }
+            }
+    if (best[RT][trs] >= 1e30) return false;
+    int s2 = trs;
+    for (int d = RT; d >= 1; --d) {
+        rs_start[d] = s2;
+        s2 = cut[d][s2];
+    }
+    rs_start[0] = 0;
+    for (int d = 0; d < RT; ++d) {
+        int t = steps[rs_start[d]];
+        tdom[d] = t < 1 ? 1 : t;
+    }
+    for (int d = RT; d < PS_RT_TAB; ++d) { rs_start[d + 1] = trs; tdom[d] = 1; }
+    return true;
+}
+
+static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipStream_t st, double* flops = nullptr) {
     const int M = q.M, U = q.U, n_steps = q.n_steps;
     a.M = M; a.U = U; a.T = n_steps;
     a.total_rs = (M + 15) / 16;
@@ -1298,17 +1429,45 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     a.db = q.db;
     a.defer_from = g_ps_bwd_defer_from;
     a.lds_nb = (a.total_rs + RT - 1) / RT >= g_ps_bwd_defer_from ? 2 : 1;
-    a.direct = 0; a.wh_raw = q.Wh; a.epoch = 0;
+    a.direct = 0; a.wh_raw = q.Wh; a.epoch = 0; a.packed = 0;
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.c0 = q.c0; a.cs = q.cs; a.lens = q.lens;
     a.dhout = q.dhout; a.dh_final = q.dh_final; a.dc_final = q.dc_final;
     a.dz = q.dz; a.dh0 = q.dh0; a.dc0 = q.dc0;
+    a.rowmap = nullptr; a.sorted = 0; a.Tfull = n_steps;
+    for (int d = 0; d <= PS_RT_TAB; ++d) a.rs_start[d] = 0;
+    for (int d = 0; d < PS_RT_TAB; ++d) a.tdom[d] = 1;
+    if (flops) *flops = 2.0 * M * 4.0 * U * U * (n_steps - 1 + (q.dh0 ? 1 : 0));
     if (q.flags && g_ps_direct) {
         a.direct = 1;
         a.flags = q.flags;
         a.dbtick = q.flags + PS_FLAG_WORDS;
         a.epoch = q.epoch;
+        if (q.wpack) {
+            a.packed = 1;
+            a.Wb = (const float4*)q.wpack;
+        }
+        if (q.rowmap && q.slab_steps && g_ps_sorted &&
+            ps_plan_sorted(a.total_rs, RT, q.slab_steps, q.dh0 ? 1 : 0, 3.3, 6.3, a.rs_start, a.tdom)) {
+            a.rowmap = q.rowmap;
+            a.sorted = 1;
+            for (int d = 0; d < RT; ++d)
+                if (a.tdom[d] > n_steps) a.tdom[d] = n_steps;
+            // the deferred form's LDS follows the longest domain of THIS cut
+            int nmax = 0;
+            for (int d = 0; d < RT; ++d) nmax = a.rs_start[d + 1] - a.rs_start[d] > nmax ? a.rs_start[d + 1] - a.rs_start[d] : nmax;
+            a.lds_nb = nmax >= g_ps_bwd_defer_from ? 2 : 1;
+            if (flops) {                     // executed: each domain's rows x its own passes
+                double f = 0.0;
+                for (int d = 0; d < RT; ++d) {
+                    int rows = (a.rs_start[d + 1] - a.rs_start[d]) * 16;
+                    if (a.rs_start[d + 1] * 16 > M) rows -= a.rs_start[d + 1] * 16 - M;
+                    f += 2.0 * rows * 4.0 * U * U * (a.tdom[d] - 1 + (q.dh0 ? 1 : 0));
+                }
+                *flops = f;
+            }
+        }
         return D2P_OK;
     }
     // packed Wh^T; pass 0 has no product -- the chain runs on an all-zero dz[T]; flags reset
@@ -1323,7 +1482,7 @@ static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdAr
     PsBwdArgs b0 = a0, b1 = a1, b2 = a2;
     const int nb = ((a0.gsz > 0 && a0.lds_nb == 2) || (a1.gsz > 0 && a1.lds_nb == 2) || (a2.gsz > 0 && a2.lds_nb == 2)) ? 2 : 1;
     b0.lds_nb = b1.lds_nb = b2.lds_nb = nb;
-    const size_t lds = (size_t)(nb * PS_BWD_P_FLOATS + (PS_NRS_MAX + 1) * 256 + PS_NRS_MAX * 16 + nb * 1024 +
+    const size_t lds = (size_t)(nb * PS_BWD_P_FLOATS + (PS_NRS_MAX + 1) * 256 + 2 * PS_NRS_MAX * 16 + nb * 1024 +
                                 PS_PF_R * PS_BWD_SLOT) * sizeof(float);
     D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, flops);
 #define PS_BWD_LAUNCH(CPW)                                                                                              \
@@ -1346,17 +1505,15 @@ static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdAr
     D2P_LAUNCH_CHECK("lstm_persist_bwd");
     return D2P_OK;
 }
-static inline double ps_bwd_flops(const PsBwdCall& q) {
-    return 2.0 * q.M * 4.0 * q.U * q.U * (q.n_steps - 1 + (q.dh0 ? 1 : 0));
-}
 
 int d2p_lstm_persist_bwd(const PsBwdCall& q, hipStream_t st) {
     PsBwdArgs a, none;
-    int rc = ps_bwd_setup(q, ps_pick_rt((q.M + 15) / 16, q.U / 16, 1), 0, a, st);
+    double flops = 0.0;
+    int rc = ps_bwd_setup(q, ps_pick_rt((q.M + 15) / 16, q.U / 16, 1), 0, a, st, &flops);
     if (rc) return rc;
     none = a;
     none.gsz = 0;
-    return ps_bwd_launch(a, none, none, q.U, ps_bwd_flops(q), st);
+    return ps_bwd_launch(a, none, none, q.U, flops, st);
 }
 bool d2p_lstm_persist_bwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U) {
     int ra, rb;
@@ -1368,14 +1525,15 @@ int d2p_lstm_persist_bwd_pair(const PsBwdCall& qa, const PsBwdCall& qb, hipStrea
     if (!ps_plan_pair((qa.M + 15) / 16, qa.n_steps, (qb.M + 15) / 16, qb.n_steps, qa.U / 16, 1, ra, rb))
         return D2P_EINVAL;
     PsBwdArgs a, b;
-    int rc = ps_bwd_setup(qa, ra, 0, a, st);
+    double fa = 0.0, fb = 0.0;
+    int rc = ps_bwd_setup(qa, ra, 0, a, st, &fa);
     if (rc) return rc;
-    rc = ps_bwd_setup(qb, rb, a.gsz, b, st);
+    rc = ps_bwd_setup(qb, rb, a.gsz, b, st, &fb);
     if (rc) return rc;
     ++g_ps_pair_launches;
     PsBwdArgs none = b;
     none.gsz = 0;
-    return ps_bwd_launch(a, b, none, qa.U, ps_bwd_flops(qa) + ps_bwd_flops(qb), st);
+    return ps_bwd_launch(a, b, none, qa.U, fa + fb, st);
 }
 
 // three sequences (the three decoders' backward recurrences): row domains dealt out by the same cost model; taken
@@ -1437,10 +1595,11 @@ int d2p_lstm_persist_bwd_triple(const PsBwdCall q[3], hipStream_t st) {
     int bid0 = 0;
     double flops = 0.0;
     for (int i = 0; i < 3; ++i) {
-        int rc = ps_bwd_setup(q[i], R[i], bid0, a[i], st);
+        double f = 0.0;
+        int rc = ps_bwd_setup(q[i], R[i], bid0, a[i], st, &f);
         if (rc) return rc;
         bid0 += a[i].gsz;
-        flops += ps_bwd_flops(q[i]);
+        flops += f;
     }
     g_ps_pair_launches += 2;          // counts as two fusions (tests: the fused path must not be skipped silently)
     return ps_bwd_launch(a[0], a[1], a[2], q[0].U, flops, st);

@@ -4,6 +4,7 @@ torch is used here only for device memory (``torch.empty``), the current stream 
 views; every arithmetic operation is a call into libd2p_hip.so.  All tensors must be
 CUDA (ROCm) fp32 / int32 and contiguous unless a stride is passed explicitly.
 """
+import numpy as np
 import torch
 
 from .lib import call, current_stream, load as _load_lib, ptr
@@ -380,6 +381,31 @@ class _LstmFlags(object):
 _LSTM_FLAGS = _LstmFlags()
 
 
+def lstm_row_order(lens, pad_to=16):
+    """(rowmap, slab_steps) of d2p_lstm_bwd_desc for host lengths `lens` (numpy, one per row): the rows by decreasing
+    length (stable) as a device int32 tensor, and the longest length of every 16 consecutive rows of that order as a
+    host int32 array."""
+    lens = np.asarray(lens).reshape(-1).astype(np.int64)
+    order = np.argsort(-lens, kind='stable').astype(np.int32)
+    steps = np.ascontiguousarray(lens[order][::pad_to].astype(np.int32))
+    return torch.from_numpy(order).cuda(), steps
+
+
+def lstm_set_sorted(on):
+    call.d2p_lstm_persist_set_sorted(1 if on else 0)
+
+
+def lstm_pack_weights(cells):
+    """cells: list (<= 8) of (Wh [U, 4U], Wf image or None, Wb image or None): the packed weight images of the persistent
+    kernels in one launch."""
+    import ctypes
+    n = len(cells)
+    U = cells[0][0].shape[0]
+    arrs = [(ctypes.c_void_p * n)(*[ptr(c[j]) for c in cells]) for j in range(3)]
+    call.d2p_lstm_pack_weights(n, U, ctypes.cast(arrs[0], ctypes.c_void_p), ctypes.cast(arrs[1], ctypes.c_void_p),
+                               ctypes.cast(arrs[2], ctypes.c_void_p), current_stream())
+
+
 def lstm_seq_fwd_multi(seqs):
     """seqs: list (<= 3) of dicts with the d2p_lstm_seq_fwd arguments (time-major z)."""
     import ctypes
@@ -397,6 +423,7 @@ def lstm_seq_fwd_multi(seqs):
         d.h_final, d.c_final = ptr(q.get('h_final')), ptr(q.get('c_final'))
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         d.flags, d.epoch = _LSTM_FLAGS.take(('f', i, torch.cuda.current_stream().cuda_stream), q['n_steps'])
+        d.wpack = ptr(q.get('wpack'))
     call.d2p_lstm_seq_fwd_multi(len(seqs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
 
 
@@ -404,6 +431,7 @@ def lstm_seq_bwd_multi(seqs):
     import ctypes
     from .lib import LstmBwdDesc
     arr = (LstmBwdDesc * len(seqs))()
+    keep = []
     for i, q in enumerate(seqs):
         M, U = q['M'], q['U']
         nb = call.d2p_lstm_ws_bytes(M, U)
@@ -419,6 +447,14 @@ def lstm_seq_bwd_multi(seqs):
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         d.db = ptr(q.get('db'))            # optional: the bias gradient (column sums of dz), produced with the launch
         d.flags, d.epoch = _LSTM_FLAGS.take(('b', i, torch.cuda.current_stream().cuda_stream), q['n_steps'] + 1)
+        d.wpack = ptr(q.get('wpack'))
+        order = q.get('row_order')          # (rowmap: device int32 [M], slab_steps: host numpy int32 [ceil(M/16)])
+        if order is not None:
+            rowmap, steps = order
+            assert rowmap.dtype == torch.int32 and rowmap.numel() == q['M'] and steps.dtype == np.int32
+            assert steps.size == (q['M'] + 15) // 16 and steps.flags['C_CONTIGUOUS']
+            keep.append(steps)
+            d.rowmap, d.slab_steps = ptr(rowmap), steps.ctypes.data
     call.d2p_lstm_seq_bwd_multi(len(seqs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
 
 

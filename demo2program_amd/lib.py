@@ -62,6 +62,8 @@ SIGNATURES = {
     'd2p_lstm_persist_inject_error': (c_int, []),
     'd2p_lstm_persist_set_bwd_defer': (c_int, [c_int]),
     'd2p_lstm_flag_words': (c_size_t, []),
+    'd2p_lstm_persist_set_sorted': (c_int, [c_int]),
+    'd2p_lstm_pack_weights': (c_int, [c_int, c_int, P, P, P, S]),
     'd2p_lstm_persist_set_direct': (c_int, [c_int]),
     'd2p_lstm_persist_set_trace': (c_int, [P, c_size_t, c_int]),
     'd2p_lstm_persist_set_wgs_per_cu': (c_int, [c_int, c_int]),
@@ -118,7 +120,8 @@ class LstmFwdDesc(ctypes.Structure):
                 ('z', c_void_p), ('z_row_stride', c_long), ('z_t_stride', c_long),
                 ('Wh', c_void_p), ('h0', c_void_p), ('c0', c_void_p), ('lens', c_void_p),
                 ('hout', c_void_p), ('cs', c_void_p), ('h_final', c_void_p), ('c_final', c_void_p),
-                ('ws', c_void_p), ('ws_bytes', c_size_t), ('flags', c_void_p), ('epoch', ctypes.c_uint)]
+                ('ws', c_void_p), ('ws_bytes', c_size_t), ('flags', c_void_p), ('epoch', ctypes.c_uint),
+                ('wpack', c_void_p)]
 
 
 class LstmBwdDesc(ctypes.Structure):
@@ -129,7 +132,7 @@ class LstmBwdDesc(ctypes.Structure):
                 ('dhout', c_void_p), ('dh_final', c_void_p), ('dc_final', c_void_p),
                 ('dz', c_void_p), ('dh0', c_void_p), ('dc0', c_void_p),
                 ('ws', c_void_p), ('ws_bytes', c_size_t), ('db', c_void_p), ('flags', c_void_p),
-                ('epoch', ctypes.c_uint)]
+                ('epoch', ctypes.c_uint), ('wpack', c_void_p), ('rowmap', c_void_p), ('slab_steps', c_void_p)]
 
 
 class XentBwdDesc(ctypes.Structure):

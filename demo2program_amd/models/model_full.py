@@ -268,6 +268,9 @@ class Model(object):
                 # mask counts of the 1 + 2k loss terms (program, action per demo index, perception per demo index):
                 # the denominators of Sequence_Loss (models/model_full.py:656-657), known with the lengths
                 ('loss_dens', torch.float32, (1 + 2 * k,)),
+                # the demonstrations by decreasing length: the backward recurrences group rows of similar length into
+                # their row domains and stop each domain at its longest row (d2p_lstm_bwd_desc.rowmap)
+                ('demo_order', torch.int32, (B * k,)),
                 ('program_len', torch.int32, (B,)), ('demo_len', torch.int32, (B * k,))]
         offs, total = [], 0
         for _, dt, shape in spec:
@@ -382,6 +385,10 @@ class Model(object):
             if rows_t1.size:
                 feed[key + 'rows_t1'][:rows_t1.size].copy_(torch.from_numpy(rows_t1), non_blocking=True)
                 feed[key + 'rows_t1_prev'][:rows_t1.size].copy_(torch.from_numpy(rows_t1 - R), non_blocking=True)
+        dl = np.minimum(dlen, T).clip(0).astype(np.int64)
+        order = np.argsort(-dl, kind='stable').astype(np.int32)
+        put('demo_order', order)
+        feed['demo_slab_steps'] = np.ascontiguousarray(dl[order][::16].astype(np.int32))     # (host: longest row per 16)
         feed['id'] = batch_chunk.get('id') if hasattr(batch_chunk, 'get') else None
         feed['host'] = {n: batch_chunk[n] for n in ('test_s_h', 'test_demo_len', 'test_per', 'init_pos',
                                                     'init_pos_len', 'test_init_pos', 'test_init_pos_len')
@@ -413,6 +420,7 @@ class Model(object):
         #      whose step kernels leave most of the matrix pipe idle.
         main = torch.cuda.current_stream()
         side = self._side_stream()
+        self._pack_lstm_weights(main, side)
 
         # ---- State_Encoder: conv -> +bias -> lrelu -> BN(train), per demo-index statistics
         x = feed['s_h']
@@ -442,6 +450,8 @@ class Model(object):
         #  these GEMMs only took the CUs the chain was waiting for -- 320 us instead of 100 for the chain;
         #  beside the first recurrence they fill matrix-pipe time its hand-offs leave)
         side.wait_stream(main)
+        if self._wpack_ev is not None:
+            main.wait_event(self._wpack_ev)
         with torch.cuda.stream(side):
             # Token-input decoders: x = embedding[id], so x.Wx + b takes one of tok+2 values per row -- the
             # projected TABLE (a [tok+1, U] x [U, 4U] GEMM: 7 or 51 rows) is gathered instead of projecting
@@ -619,15 +629,55 @@ class Model(object):
             if feed['prog_n_active_pad'] and feed['prog_n_t1_pad']:
                 ctx['klists']['prog'] = (feed['prog_rows'], feed['prog_n_active_pad'], feed['prog_rows_t1'],
                                          feed['prog_rows_t1_prev'], feed['prog_n_t1_pad'])
+        order = None
+        if feed.get('demo_slab_steps') is not None and os.environ.get('D2P_LSTM_SORTED', '1') == '1':
+            order = (feed['demo_order'], feed['demo_slab_steps'])
         for e_, space in ((e1, 'demo'), (e2, 'demo'), (dp, 'prog'), (da, 'demo'), (dq, 'demo')):
             if e_ is not None:
                 e_['rowspace'] = space
+                e_['row_order'] = order if space == 'demo' else None
         ctx.update(e1=e1, e2=e2, rn_h=rn_h, rn_c=rn_c, dp=dp, feats_tm=feats_tm, ids_p=ids_p, emb_p=emb_p,
                    dens=dens, h0_2=h0_2, c0_2=c0_2, demo_h=demo_h, demo_c=demo_c, init_h=init_h, init_c=init_c)
         self._ctx = ctx
         self._feed = feed
         self._loss, self._terms = loss, terms
         return loss
+
+    def _pack_lstm_weights(self, main, side):
+        """The persistent kernels' packed weight images (forward, and in training backward) of every recurrent cell in
+        ONE launch on the side stream, beside the conv / batch-norm chain: the recurrences' prologues then read
+        contiguous 16-byte fragments instead of gathering them from the row-major kernel (d2p_lstm_pack_weights).
+        Off by default (D2P_LSTM_WPACK=1 turns it on): measured on one box, 3 alternating runs each -- 3.104 / 3.155 /
+        3.139 ms per step gathering, 3.124 / 3.146 / 3.102 with the images; the kernels' averages 205.4 / 294.0 us against
+        205.1 / 289.9 (profiles/r03_wpack_ab.txt): the prologue is not what the launches wait for."""
+        self._wpack, self._wpack_ev = {}, None
+        U = self.num_lstm_cell_units
+        if (os.environ.get('D2P_LSTM_WPACK', '0') != '1' or side == main or U not in (64, 128, 256, 512)
+                or not K.lstm_is_persistent() or torch.cuda.is_current_stream_capturing()):
+            return
+        names = ['demo_lstm', 'prog/lstm']
+        if self.variant != 'synthesis_baseline':
+            names.append('second_lstm')
+        if self.multitask:
+            names += ['act/lstm', 'per/lstm']
+        p = self.params.p
+        cells = []
+        for name in names:
+            kernel = p[name + '/kernel']
+            Wh = kernel[kernel.shape[0] - U:]
+            wf = self._buf(name + '/wpack_f', (4 * U * U,))
+            wb = self._buf(name + '/wpack_b', (4 * U * U,)) if self.is_train else None
+            cells.append((Wh, wf, wb))
+            self._wpack[name] = (wf, wb)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            K.lstm_pack_weights(cells)
+            self._wpack_ev = torch.cuda.Event()
+            self._wpack_ev.record(side)
+
+    def _wp(self, name, which):
+        w = getattr(self, '_wpack', {}).get(name)
+        return None if w is None else w[which]
 
     def _side_stream(self):
         if not self.use_side_stream:
@@ -720,7 +770,7 @@ class Model(object):
             cf = self._buf(name + '/c_final', (M, U)) if want_final else None
         if n_steps > 0:
             K.lstm_seq_fwd_multi([dict(M=M, U=U, n_steps=n_steps, z=z, Wh=Wh, h0=h0, c0=c0, lens=lens, hout=hout, cs=cs,
-                                       h_final=hf, c_final=cf)])
+                                       h_final=hf, c_final=cf, wpack=self._wp(name, 0))])
         else:
             K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, n_steps, Wh, h0, c0, lens, hout, cs, hf, cf)
         return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
@@ -745,7 +795,8 @@ class Model(object):
                 e['token_ids'] = self._bufs['ids_p' if scope == 'prog' else 'ids_a']
             es.append(e)
             if n_steps > 0:
-                seqs.append(dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs))
+                seqs.append(dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs,
+                                 wpack=self._wp(name, 0)))
         if seqs:
             K.lstm_seq_fwd_multi(seqs)
         if logits:
@@ -1130,7 +1181,8 @@ class Model(object):
             # (the bias gradient -- the column sums of dz -- comes out of the same launch)
             K.lstm_seq_bwd_multi([dict(M=M, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], lens=e['lens'],
                                        cs=e['cs'], dhout=dhout, dh_final=dh_final, dc_final=dc_final, dz=dz,
-                                       dh0=dh0, dc0=dc0, db=gb)])
+                                       dh0=dh0, dc0=dc0, db=gb, wpack=self._wp(name, 1),
+                                       row_order=e.get('row_order'))])
         else:
             K.lstm_seq_bwd(e['z'], 4 * U, M * 4 * U, M, U, n, e['Wh'], e['c0'], e['lens'], e['cs'],
                            dhout, dh_final, dc_final, dz, dh0, dc0)
@@ -1263,7 +1315,8 @@ class Model(object):
                 if not self._ctx.get('fused_xb'):       # (else: written with dlogits by d2p_xent_bwd_dhout_multi)
                     K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
                 seqs.append(dict(M=R, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], cs=e['cs'],
-                                 dhout=dhout, dz=dz, dh0=dh0, dc0=dc0, db=g[e['name'] + '/bias']))
+                                 dhout=dhout, dz=dz, dh0=dh0, dc0=dc0, db=g[e['name'] + '/bias'],
+                                 wpack=self._wp(e['name'], 1), row_order=e.get('row_order')))
             else:
                 g[scope + '/proj'].zero_()
                 g[e['name'] + '/bias'].zero_()

@@ -259,6 +259,12 @@ int d2p_lstm_persist_set_bwd_defer(int from_phases);
 /* Words of a d2p_lstm_*_desc.flags buffer; and the A/B switch of the direct launches (1 default; 0: every persistent
  * launch gets its preparation launch whatever the descriptor says). */
 size_t d2p_lstm_flag_words(void);
+/* A/B switch: 0 = ignore rowmap / slab_steps of d2p_lstm_bwd_desc (every domain runs all steps); default 1 */
+int d2p_lstm_persist_set_sorted(int on);
+/* The packed weight images of n <= 8 cells (Wh[i]: [U, 4U] row-major) in one launch: Wf[i] / Wb[i] (4*U*U floats each,
+ * NULL: skip) are what d2p_lstm_fwd_desc.wpack / d2p_lstm_bwd_desc.wpack take.  Wh, Wf, Wb: HOST arrays of device
+ * pointers. */
+int d2p_lstm_pack_weights(int n, int U, const float* const* Wh, float* const* Wf, float* const* Wb, d2p_stream_t stream);
 int d2p_lstm_persist_set_direct(int on);
 /* Tuning knob (process-global): workgroups per CU the persistent forward / backward kernels are
  * sized for (0 keeps the current value; default 1).  2 cuts the rows into twice as many domains so
@@ -306,6 +312,8 @@ typedef struct {
      * buffer (wrap: zero the buffer again, restart at 0).  NULL: the preparation launch runs (needed under hipGraph
      * capture, where the epoch would be baked into the graph).  Ignored by the per-step back ends. */
     unsigned* flags; unsigned epoch;
+    const float* wpack;   /* optional, with flags: the packed forward image of Wh (d2p_lstm_pack_weights, 4*U*U floats),
+                           * kept up to date by the caller -- the kernel's prologue then reads contiguous fragments */
 } d2p_lstm_fwd_desc;
 typedef struct {
     int M, U, n_steps;
@@ -319,6 +327,14 @@ typedef struct {
                      * their launch (per-workgroup sums, folded by each column tile's last workgroup in a
                      * fixed order); the other back ends run d2p_colsum_f32 over dz behind the recurrence. */
     unsigned* flags; unsigned epoch;   /* as d2p_lstm_fwd_desc */
+    const float* wpack;                /* ... the packed backward (Wh^T) image */
+    /* optional, with flags -- a length-sorted launch: rowmap (DEVICE, M ints) lists the rows by decreasing length,
+     * slab_steps (HOST, ceil(M/16) ints) holds the longest length among rows 16s .. 16s+15 of that order.  The kernel
+     * then groups rows of similar length into its row domains and runs each domain only for its longest row's
+     * steps (a masked step leaves nothing behind but zeros in dz, which are still written): results unchanged.
+     * For a sequence without lens (a decoder whose loss masks the steps past a row's length, so that dhout is zero
+     * there) the lengths are those of the loss mask. */
+    const int* rowmap; const int* slab_steps;
 } d2p_lstm_bwd_desc;
 int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* descs, d2p_stream_t stream);
 int d2p_lstm_seq_bwd_multi(int nseq, const d2p_lstm_bwd_desc* descs, d2p_stream_t stream);

@@ -1008,6 +1008,101 @@ def test_lstm_bias_gradient_comes_out_of_the_backward_launch(K, specs):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('specs', [[(320, 20)], [(320, 20), (32, 50)], [(320, 6), (320, 6), (32, 9)], [(40, 5)]])
+def test_lstm_packed_weight_images_kept_by_the_caller(K, specs):
+    """d2p_lstm_pack_weights + d2p_lstm_*_desc.wpack: the persistent launches read the caller's packed weight images
+    (one pack launch for all cells, off the critical path) instead of gathering fragments from the row-major Wh --
+    bit-identical to the gathering form, forward and backward, one / two / three sequences per launch."""
+    U = 512
+    K.lstm_persist_error(True)
+
+    def run(packed):
+        fw, bw, outs, cells = [], [], [], []
+        gg = torch.Generator().manual_seed(37)
+        for (M, n) in specs:
+            lens = torch.randint(1, n + 1, (M,), generator=gg).int().cuda() if M != 32 else None
+            o = dict(z=(torch.rand(n * M, 4 * U, generator=gg) * 2 - 1).cuda(), hout=torch.zeros(n, M, U, device='cuda'),
+                     cs=torch.zeros(n, M, U, device='cuda'), dz=torch.zeros(n * M, 4 * U, device='cuda'),
+                     dh0=torch.zeros(M, U, device='cuda'), dc0=torch.zeros(M, U, device='cuda'),
+                     db=torch.zeros(4 * U, device='cuda'))
+            Wh = ((torch.rand(U, 4 * U, generator=gg) * 2 - 1) * 0.05).cuda()
+            h0 = (torch.rand(M, U, generator=gg) * 2 - 1).cuda()
+            c0 = (torch.rand(M, U, generator=gg) * 2 - 1).cuda()
+            dhout = (torch.rand(n, M, U, generator=gg) * 2 - 1).cuda()
+            wf = wb = None
+            if packed:
+                wf, wb = torch.zeros(4 * U * U, device='cuda'), torch.zeros(4 * U * U, device='cuda')
+                cells.append((Wh, wf, wb))
+            outs.append(o)
+            fw.append(dict(M=M, U=U, n_steps=n, z=o['z'], Wh=Wh, h0=h0, c0=c0, lens=lens, hout=o['hout'], cs=o['cs'],
+                           wpack=wf))
+            bw.append(dict(M=M, U=U, n_steps=n, z=o['z'], Wh=Wh, c0=c0, lens=lens, cs=o['cs'], dhout=dhout,
+                           dz=o['dz'], dh0=o['dh0'], dc0=o['dc0'], db=o['db'], wpack=wb))
+        if cells:
+            K.lstm_pack_weights(cells)
+        K.lstm_seq_fwd_multi(fw)
+        K.lstm_seq_bwd_multi(bw)
+        torch.cuda.synchronize()
+        return outs
+    a, b = run(False), run(True)
+    for o, o2 in zip(a, b):
+        assert float(o['hout'].abs().max()) > 0 and float(o['dz'].abs().max()) > 0
+        for name in ('hout', 'cs', 'dz', 'dh0', 'dc0', 'db'):
+            assert torch.equal(o[name], o2[name]), name
+    assert K.lstm_persist_error(True) == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('specs', [[(320, 20, 'lens')], [(320, 20, 'mask')], [(320, 6, 'mask'), (320, 6, 'mask'), (32, 9, None)],
+                                   [(40, 5, 'lens')], [(400, 20, 'lens')], [(320, 20, 'lens'), (32, 50, None)]])
+def test_lstm_backward_over_rows_sorted_by_length(K, specs):
+    """d2p_lstm_bwd_desc.rowmap / slab_steps: the backward recurrence groups rows of similar length into its row domains
+    and runs each domain only for its longest row's steps.  'lens': a dynamic_rnn recurrence (lengths given, gradients of
+    the final states); 'mask': a decoder (no lengths -- the incoming dhout is zero past each row's length, as behind a
+    masked loss).  dz, dh0, dc0 bit-identical to the launch that runs every step for every row (incl. the zeros of the
+    skipped steps, over a dz buffer pre-filled with garbage); the bias gradient within summation-order round-off."""
+    U = 512
+    K.lstm_persist_error(True)
+
+    def run(sort):
+        fw, bw, outs = [], [], []
+        gg = torch.Generator().manual_seed(41)
+        for (M, n, mode) in specs:
+            lens_h = torch.randint(max(1, n // 3), n + 1, (M,), generator=gg).int()
+            lens = lens_h.cuda() if mode == 'lens' else None
+            o = dict(z=(torch.rand(n * M, 4 * U, generator=gg) * 2 - 1).cuda(), hout=torch.zeros(n, M, U, device='cuda'),
+                     cs=torch.zeros(n, M, U, device='cuda'), dz=torch.full((n * M, 4 * U), 3.0, device='cuda'),
+                     dh0=torch.zeros(M, U, device='cuda'), dc0=torch.zeros(M, U, device='cuda'),
+                     db=torch.zeros(4 * U, device='cuda'))
+            Wh = ((torch.rand(U, 4 * U, generator=gg) * 2 - 1) * 0.05).cuda()
+            h0 = (torch.rand(M, U, generator=gg) * 2 - 1).cuda()
+            c0 = (torch.rand(M, U, generator=gg) * 2 - 1).cuda()
+            dhout = (torch.rand(n, M, U, generator=gg) * 2 - 1)
+            if mode == 'mask':
+                dhout = dhout * (torch.arange(n)[:, None] < lens_h[None, :]).float()[:, :, None]
+            dhf = (torch.rand(M, U, generator=gg) * 2 - 1).cuda() if mode == 'lens' else None
+            dcf = (torch.rand(M, U, generator=gg) * 2 - 1).cuda() if mode == 'lens' else None
+            outs.append(o)
+            fw.append(dict(M=M, U=U, n_steps=n, z=o['z'], Wh=Wh, h0=h0, c0=c0, lens=lens, hout=o['hout'], cs=o['cs']))
+            bw.append(dict(M=M, U=U, n_steps=n, z=o['z'], Wh=Wh, c0=c0, lens=lens, cs=o['cs'], dhout=dhout.cuda(),
+                           dh_final=dhf, dc_final=dcf, dz=o['dz'], dh0=o['dh0'], dc0=o['dc0'], db=o['db'],
+                           row_order=K.lstm_row_order(lens_h.numpy()) if (sort and mode) else None))
+        K.lstm_seq_fwd_multi(fw)
+        K.lstm_seq_bwd_multi(bw)
+        torch.cuda.synchronize()
+        return outs
+    a, b, c = run(False), run(True), run(True)
+    for o, o2, o3 in zip(a, b, c):
+        assert float(o['dz'].abs().max()) > 0
+        for name in ('dz', 'dh0', 'dc0'):
+            assert torch.equal(o[name], o2[name]), name
+        scale = max(1.0, float(o['dz'].abs().double().sum(dim=0).max()))
+        assert (o['db'].double() - o2['db'].double()).abs().max().item() <= 2e-6 * scale
+        assert torch.equal(o2['db'], o3['db'])                       # deterministic
+    assert K.lstm_persist_error(True) == 0
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize('M,N,R,Kn', [(512, 2048, 6400, 4480), (48, 2048, 6400, 4512), (512, 2048, 1600, 864),
                                      (60, 256, 700, 333), (512, 512, 300, 64), (20, 36, 90, 50)])
 def test_gemm_tn_over_lists_of_k_rows(K, M, N, R, Kn):
