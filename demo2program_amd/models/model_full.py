@@ -445,7 +445,19 @@ class Model(object):
         feats = x.view(M, T, F)
         feats_tm = K.transpose_rt(feats, M, T, F, out=self._buf('feats_tm', (T, M, F)))
 
-        z_e1 = self._lstm_xproj('demo_lstm', feats_tm.view(T * M, F), F, M, T, T)
+        # (rows past their sequence: neither their projection nor, in backward, their input gradient is computed --
+        #  the recurrence selects around what it reads there, D2P_ACTIVE_XPROJ=0: all rows)
+        act_rows = None
+        if (self.compact_rows and feed.get('n_active') is not None and 0 < feed['n_active'] < T * M
+                and os.environ.get('D2P_ACTIVE_XPROJ', '1') == '1'):
+            act_rows = (feed['active_rows'], feed['n_active'])
+        ctx['rows_e1'] = act_rows
+        if act_rows is not None:
+            z_e1 = self._buf('demo_lstm/z', (T * M, 4 * U), zero=True)
+            K.gemm_rows('nn', act_rows[1], 4 * U, F, feats_tm.view(T * M, F), F, p['demo_lstm/kernel'][:F], 4 * U,
+                        z_e1, 4 * U, act_rows[0], bias=p['demo_lstm/bias'])
+        else:
+            z_e1 = self._lstm_xproj('demo_lstm', feats_tm.view(T * M, F), F, M, T, T)
         # (forked here, not at the start of the step: beside the chain of small conv / batch-norm launches
         #  these GEMMs only took the CUs the chain was waiting for -- 320 us instead of 100 for the chain;
         #  beside the first recurrence they fill matrix-pipe time its hand-offs leave)
@@ -1136,7 +1148,14 @@ class Model(object):
             K.group_mean_bwd(None, dhc0_2, d_hc1f, 2 * B, k, U, False)
         # ---- Demo_Encoder LSTM backward
         dz1 = self._lstm_bwd_rec(ctx['e1'], d_hout1, d_h1f, d_c1f, None, None)
-        d_feats_tm = self._lstm_bwd_dx(ctx['e1'], dz1)
+        if ctx.get('rows_e1') is not None:
+            e1_ = ctx['e1']
+            d_feats_tm = self._buf(e1_['name'] + '/dx', (T * M, e1_['I']))
+            d_feats_tm.zero_()                        # rows past their sequence: no gradient
+            K.gemm_rows('nt', ctx['rows_e1'][1], e1_['I'], 4 * U, dz1, 4 * U, e1_['Wx'], 4 * U, d_feats_tm, e1_['I'],
+                        ctx['rows_e1'][0])
+        else:
+            d_feats_tm = self._lstm_bwd_dx(ctx['e1'], dz1)
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._lstm_bwd_weights(ctx['e1'], dz1)
