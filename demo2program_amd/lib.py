@@ -159,11 +159,12 @@ def load():
     # library before it would pull in the system runtime instead and leave the process with two --
     # kernels then fail with "no ROCm-capable device is detected"
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get('D2P_LIB_PATH', LIB_PATH)       # (an alternative build of the same sources, for A/B runs)
+    if not os.path.exists(path):
         raise D2PError(
             'libd2p_hip.so not found at %s -- run `python -c "import __graft_entry__ as g; '
-            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
-    lib = ctypes.CDLL(LIB_PATH)
+            'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
+    lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
@@ -186,7 +187,18 @@ class _Caller(object):
         lib = load()
         fn = getattr(lib, name)
         res = SIGNATURES[name][0]
-        if res is c_int and name != 'd2p_version':
+        delay = float(os.environ.get('D2P_HOST_DELAY_US', '0')) * 1e-6
+        if res is c_int and name != 'd2p_version' and delay > 0:
+            # measurement hook: every entry point costs the host `delay` more -- if the step time follows, the host's
+            # enqueue rate is on the critical path somewhere (tools/ab_env.sh D2P_HOST_DELAY_US 0 3)
+            import time
+
+            def wrapped(*args):
+                t_end = time.perf_counter() + delay
+                while time.perf_counter() < t_end:
+                    pass
+                _check(name, fn(*args))
+        elif res is c_int and name != 'd2p_version':
             def wrapped(*args):
                 _check(name, fn(*args))
         else:
