@@ -158,6 +158,14 @@ def roofline_leg(trainer, feeds, steps=2):
         if g['group'] == 'recurrent':
             cfgm = trainer.config
             flop_step = 2.0 * cfgm.batch_size * cfgm.k * 4 * cfgm.num_lstm_cell_units ** 2
+            # `work` is what the launches EXECUTE: the length-sorted backward launches stop each row domain at its
+            # longest row, so the row-steps past a sequence's length are mostly not multiplied any more.  Rounds 1-2
+            # multiplied (and counted) every row at every step -- the same count for this round's launches:
+            dense = sum(recurrent_dense_flops(cfgm, feeds[i % len(feeds)]) for i in range(steps))
+            d['work_counts'] = 'executed row-steps (a row domain of a length-sorted backward launch runs only its longest row\'s steps)'
+            d['frac_dense_rows'] = round(_rate(dense, g['total_ms'], 'mfma') / PEAK_F32_MFMA_TFLOPS, 4)
+            d['frac_dense_rows_note'] = ('every row at every decoded step, the count of rounds 1-2 '
+                                         '(2*M*4U*U per time step): comparable with their roofline.frac')
             d['parts'] = [{'kernel': r['name'], 'launches_per_step': r['launches'] / steps,
                            'ms_per_step': round(r['total_ms'] / steps, 4),
                            'achieved': round(_rate(r['work'], r['total_ms'], 'mfma'), 2),
@@ -178,6 +186,18 @@ def roofline_leg(trainer, feeds, steps=2):
                   rate=round(_rate(r['work'], r['total_ms'], r['bound']), 2),
                   unit='TFLOP/s' if r['bound'] == 'mfma' else 'GB/s') for r in rows]
     return roof, furthest, table
+
+
+def recurrent_dense_flops(config, feed):
+    """fp32 flops of one step's recurrences when every row is multiplied at every decoded step (what dynamic_rnn /
+    dynamic_decode execute, models/model_full.py:243-258,465-471): forward h.Wh, backward dz.Wh^T."""
+    U = config.num_lstm_cell_units
+    M, B = config.batch_size * config.k, config.batch_size
+    T, n_d, n_p = config.max_demo_len, feed['n_demo'], feed['n_prog']
+    per_row_step = 2.0 * 4 * U * U
+    fwd = M * (T - 1) + M * T + 2 * M * n_d + B * n_p          # encoder 1 (zero state: no product in step 0), 2, decoders
+    bwd = M * (T - 1) + M * T + 2 * M * n_d + B * n_p          # (encoder 1 has no dh0 pass; the others one each)
+    return per_row_step * (fwd + bwd)
 
 
 def conv_binding_roofline(config, measured_ms, launches):
