@@ -489,19 +489,37 @@ class Trainer(object):
     def train(self, max_steps=1000000, prefetch=True):
         ckpt_save_step = 1000
         source = FeedPrefetcher(self.model, self.batch_train) if prefetch else self.batch_train
+        # scalar summaries as TensorBoard event files in train_dir (trainer.py:116,170-178), rank 0 only
+        writer = None
+        if self.dp.rank == 0 and os.path.isdir(self.train_dir) and os.environ.get('D2P_SUMMARIES', '1') == '1':
+            from .summary import SummaryWriter
+            writer = SummaryWriter(self.train_dir)
         for s in range(max_steps):
             step, train_summary, loss, output, step_time = \
                 self.run_single_step(source, step=s, is_train=True)
             if s % self.log_step == 0:
                 self.log_step_message(step, loss, step_time)
+            if writer is not None and s % self.write_summary_step == 0:
+                # the 'train' collection (models/model_full.py:1144-1173) of the step that just ran
+                tl, ta = self.model.report(with_greedy=False)
+                writer.add_scalars(dict({'loss/loss': loss}, **{'loss/' + n: v for n, v in list(tl.items()) + list(ta.items())
+                                                                  if isinstance(v, float)}), step)
             if s % self.test_sample_step == 0:
-                test_step, _, test_loss, _, test_step_time = self.run_test(self.batch_test)
+                test_step, test_report, test_loss, _, test_step_time = self.run_test(self.batch_test)
                 self.log_step_message(step, test_loss, test_step_time, is_train=False)
+                if writer is not None:
+                    tl, ta = test_report
+                    writer.add_scalars(dict({'test_loss/loss': test_loss},
+                                            **{'test_loss/' + n: v for n, v in list(tl.items()) + list(ta.items())
+                                               if isinstance(v, float)}), step)
+                    writer.flush()
             if s % ckpt_save_step == 0:
                 # every rank settles (re-runs steps the device skipped) before rank 0 writes the parameters
                 self.check_device_status()
                 if self.dp.rank == 0:
                     self.save_checkpoint(os.path.join(self.train_dir, 'model-%d.npz' % step))
+        if writer is not None:
+            writer.close()
 
     def check_device_status(self):
         """The persistent LSTM kernels give up a hand-off after a bounded wait instead of hanging (a

@@ -142,3 +142,25 @@ def test_bench_without_a_launcher_starts_the_ranks_itself(monkeypatch):
     assert cmd[cmd.index('--nproc-per-node') + 1] == '8' and cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
     assert cmd[-6:] == ['--gpus', '8', '--steps', '20', '--warmup', '5'] and cmd[-7].endswith('bench.py')
     assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0' and 'D2P_FORCE_DIST' not in seen['env']
+
+
+def test_scalar_summaries_are_tensorboard_event_files(tmp_path):
+    """demo2program_amd/summary.py: TFRecord-framed Event messages with masked CRC-32C (the format of
+    tf.summary.FileWriter, trainer.py:116): the CRC's published check value, the framing of a known record, and a
+    round trip of scalar values under the reference's tags (models/model_full.py:1144-1173)."""
+    import struct
+    from demo2program_amd import summary as S
+    assert S.crc32c(b'123456789') == 0xE3069283                       # CRC-32C check value (RFC 3720, B.4)
+    assert S.crc32c(bytes(32)) == 0x8A9136AA                          # 32 zero bytes (RFC 3720, B.4)
+    rec = S.frame_record(b'abc')
+    assert rec[:8] == struct.pack('<Q', 3) and rec[12:15] == b'abc' and len(rec) == 8 + 4 + 3 + 4
+    w = S.SummaryWriter(str(tmp_path))
+    w.add_scalars({'loss/loss': 1.5, 'loss/program_token_acc': 0.25}, 7)
+    w.add_scalars({'test_loss/greedy_program_seq_acc': 0.125}, 300)
+    w.close()
+    ev = S.read_events(w.path)
+    assert ev == [(7, {'loss/loss': 1.5, 'loss/program_token_acc': 0.25}), (300, {'test_loss/greedy_program_seq_acc': 0.125})]
+    # the first record is the version header TensorBoard looks for
+    with open(w.path, 'rb') as f:
+        head = f.read(64)
+    assert b'brain.Event:2' in head

@@ -473,6 +473,18 @@ def test_trainer_and_evaler_command_lines(tmp_path, monkeypatch, capsys):
     assert ' [train step' in out and 'instances/sec' in out and ' [val   step' in out
     dirs = glob.glob(str(tmp_path / 'train_dir' / 'karel-*clitest*'))
     assert len(dirs) == 1 and os.path.exists(os.path.join(dirs[0], 'model-1.npz'))
+    # scalar summaries under the reference's tags, as a TensorBoard event file in train_dir (trainer.py:116,170-178)
+    from demo2program_amd.summary import read_events
+    ev_files = glob.glob(os.path.join(dirs[0], 'events.out.tfevents.*'))
+    assert len(ev_files) == 1
+    tags = {}
+    for step, sc in read_events(ev_files[0]):
+        for t, v in sc.items():
+            tags.setdefault(t, []).append((step, v))
+    for t in ('loss/loss', 'loss/program_loss', 'loss/program_token_acc', 'loss/program_syntax_acc', 'loss/avg_action_loss',
+              'loss/avg_per_loss', 'test_loss/loss', 'test_loss/greedy_program_token_acc',
+              'test_loss/greedy_avg_action_seq_acc'):
+        assert t in tags and all(np.isfinite(v) for _, v in tags[t]), t
     evaler.main(['--train_dir', dirs[0], '--batch_size', '4', '--num_k', '3', '--num_lstm_cell_units', '64',
                  '--max_steps', '2', '--output_dir', str(tmp_path / 'eval')])
     out = capsys.readouterr().out
