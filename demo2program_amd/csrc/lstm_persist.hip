@@ -1181,6 +1181,12 @@ extern "C" int d2p_lstm_persist_set_sorted(int on) {
     g_ps_sorted = on ? 1 : 0;
     return D2P_OK;
 }
+static double g_ps_cost_ph = 3.3, g_ps_cost_fl = 6.3;   // backward: us per phase and the hand-off floor per pass (the planners' model)
+extern "C" int d2p_lstm_persist_set_plan_cost(double us_per_phase, double floor_us) {
+    if (us_per_phase > 0.0) g_ps_cost_ph = us_per_phase;
+    if (floor_us > 0.0) g_ps_cost_fl = floor_us;
+    return D2P_OK;
+}
 static int g_ps_bwd_defer_from = 1 << 20;    // backward: deferred form from this many phases per domain (d2p_lstm_persist_set_bwd_defer);
                                              // measured -4 % per phase at 5-7 phases in isolation, nothing in the step: off by default
 extern "C" int d2p_lstm_persist_set_bwd_defer(int from_phases) {
@@ -1449,7 +1455,7 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
             a.Wb = (const float4*)q.wpack;
         }
         if (q.rowmap && q.slab_steps && g_ps_sorted &&
-            ps_plan_sorted(a.total_rs, RT, q.slab_steps, q.dh0 ? 1 : 0, 3.3, 6.3, a.rs_start, a.tdom)) {
+            ps_plan_sorted(a.total_rs, RT, q.slab_steps, q.dh0 ? 1 : 0, g_ps_cost_ph, g_ps_cost_fl, a.rs_start, a.tdom)) {
             a.rowmap = q.rowmap;
             a.sorted = 1;
             for (int d = 0; d < RT; ++d)

@@ -261,6 +261,9 @@ int d2p_lstm_persist_set_bwd_defer(int from_phases);
 size_t d2p_lstm_flag_words(void);
 /* A/B switch: 0 = ignore rowmap / slab_steps of d2p_lstm_bwd_desc (every domain runs all steps); default 1 */
 int d2p_lstm_persist_set_sorted(int on);
+/* Tuning knob of the length-sorted planner: cost model of a backward row domain per pass, max(us_per_phase * phases,
+ * floor_us); defaults 3.3 / 6.3 (values <= 0 leave a parameter unchanged) */
+int d2p_lstm_persist_set_plan_cost(double us_per_phase, double floor_us);
 /* The packed weight images of n <= 8 cells (Wh[i]: [U, 4U] row-major) in one launch: Wf[i] / Wb[i] (4*U*U floats each,
  * NULL: skip) are what d2p_lstm_fwd_desc.wpack / d2p_lstm_bwd_desc.wpack take.  Wh, Wf, Wb: HOST arrays of device
  * pointers. */
