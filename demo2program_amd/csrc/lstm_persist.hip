@@ -146,10 +146,38 @@ __device__ __forceinline__ void ps_barrier() {
 // Wave-uniform: wait until every polled flag is >= need.  `fv` is the value of an earlier
 // (asynchronous) read of this lane's flag.  Gives up after PS_SPIN_LIMIT polls or as soon as any
 // workgroup reported an error.
+// The polls are PIPELINED: two reads of the flag are in flight at any time (write-through-scope buffer loads, which the
+// compiler lets overlap -- relaxed atomic loads are completed one by one), so a flag that is raised between two polls is
+// seen half a round trip earlier than by read / wait / sleep / read.  `base`: the flag area (for the descriptor).
+static int g_ps_poll_pipelined = 0;      // off: faster kernels in isolation, a slower training step
+__device__ __forceinline__ unsigned ps_ld_flag_buf(__amdgpu_buffer_rsrc_t r, int off) {
+    const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, PS_AUX_SC1);
+    asm volatile("" ::: "memory");          // a new read every time: never merged with the previous one
+    return v;
+}
 __device__ __forceinline__ void ps_wait_flags(const unsigned* f, unsigned need, unsigned fv, unsigned* err,
-                                              unsigned code) {
+                                              unsigned code, const unsigned* base, int pipelined) {
     if (__all((int)(fv >= need))) return;
     unsigned spins = 0;
+    if (pipelined) {
+        const __amdgpu_buffer_rsrc_t r = ps_rsrc(base, (unsigned)((PS_FLAG_WORDS + PS_TICKET_WORDS) * sizeof(unsigned)));
+        const int off = (int)((const char*)f - (const char*)base);
+        unsigned a = ps_ld_flag_buf(r, off);
+        for (;;) {
+            const unsigned b = ps_ld_flag_buf(r, off);
+            if (__all((int)(a >= need))) return;
+            a = ps_ld_flag_buf(r, off);
+            if (__all((int)(b >= need))) return;
+            spins += 2;
+            if ((spins & 63u) == 0u) {
+                if (ps_ld_flag(err) != 0u) return;
+                if (spins > PS_SPIN_LIMIT) {
+                    if ((threadIdx.x & 63) == 0) ps_st_flag(err, (code << 24) | (blockIdx.x & 0xffffffu) | 0x800000u);
+                    return;
+                }
+            }
+        }
+    }
     for (;;) {
         __builtin_amdgcn_s_sleep(4);
         fv = ps_ld_flag(f);
@@ -229,6 +257,7 @@ struct PsFwdArgs {
     int direct;
     const float* wh_raw; const float* h0_raw; unsigned h0_bytes; unsigned epoch;
     int packed;             // direct launch with a caller-kept packed weight image in Wf (d2p_lstm_pack_weights)
+    int poll;               // bit 0: pipelined flag polls (ps_wait_flags) in domains that look ahead, bit 1: in single-phase ones too
 };
 
 // where a phase's 16 rows of the running state are read from: descriptor, byte offset of chunk 0, bytes per chunk
@@ -365,9 +394,9 @@ __device__ __forceinline__ void ps_fwd_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW]
                                             int wave, int rs0, int slot, int lane, PsTrace& tr) {
     tr.stamp(0);
     if (la) {
-        ps_wait_flags(fl1, need1, fv, a.err, 1);
+        ps_wait_flags(fl1, need1, fv, a.err, 1, a.flags, a.poll);
     } else {
-        ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3);
+        ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3, a.flags, a.poll & 2);
 #pragma unroll
         for (int c = 0; c < CPW; ++c) cur[c] = ps_ld_src(cur_src, c);
     }
@@ -400,7 +429,7 @@ __device__ __forceinline__ void ps_fwd_tick_defer(const f32x4 (&cur)[CPW], f32x4
                                                   const unsigned* fl2, unsigned& fv, int wave, int rs0,
                                                   int par, int lane, PsTrace& tr) {
     tr.stamp(0);
-    ps_wait_flags(fl1, need1, fv, a.err, 1);
+    ps_wait_flags(fl1, need1, fv, a.err, 1, a.flags, a.poll);
     tr.stamp(1);
     __builtin_amdgcn_sched_barrier(0);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -485,7 +514,7 @@ __device__ __forceinline__ void ps_fwd_mfma_wave(const PsFwdArgs& a, const PsFwd
         // first tick: nothing to finish yet (plain product, one barrier)
         const unsigned need1 = ps_need(a.epoch, k1.t);
         const PsSrc src1 = ps_fwd_src(a, hres, hres0, k1.t, rs0 + k1.p, KC, lane_off, rm_off);
-        ps_wait_flags(fl + k1.p * nct, need1, fv, a.err, 1);
+        ps_wait_flags(fl + k1.p * nct, need1, fv, a.err, 1, a.flags, a.poll);
 #pragma unroll
         for (int c = 0; c < CPW; ++c) a1[c] = ps_ld_src(src1, c);
         fv = ps_ld_flag(fl + k2.p * nct);
@@ -708,6 +737,7 @@ struct PsBwdArgs {
     const int* rowmap;
     int sorted, Tfull;
     int rs_start[PS_RT_TAB + 1], tdom[PS_RT_TAB];
+    int poll;               // bit 0: pipelined flag polls (ps_wait_flags) in domains that look ahead, bit 1: in single-phase ones too
 };
 
 template <int CB, int CPWB>
@@ -846,7 +876,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         PsBwdEpiPre pre;
         tr.stamp(0);
         if (!LA) {
-            ps_wait_flags(fl + k0.p * nnt, ps_need(a.epoch, k0.t), ps_ld_flag(fl + k0.p * nnt), a.err, 4);
+            ps_wait_flags(fl + k0.p * nnt, ps_need(a.epoch, k0.t), ps_ld_flag(fl + k0.p * nnt), a.err, 4, a.flags, a.poll & 2);
 #pragma unroll
             for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(rk0, off + c * 1024);
         }
@@ -855,7 +885,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
             if (st == NB - 1) {
                 // the next tick's first stage: behind its flags, read one tick ago
                 tr.stamp(1);
-                if (LA) ps_wait_flags(fl + q1.p * nnt, need1, fv, a.err, 2);
+                if (LA) ps_wait_flags(fl + q1.p * nnt, need1, fv, a.err, 2, a.flags, a.poll);
                 tr.stamp(2);
             }
             const int noff = (st < NB - 1) ? off + (st + 1) * CB * 1024 : off1;
@@ -1176,6 +1206,10 @@ extern "C" int d2p_lstm_persist_set_direct(int on) {
     return D2P_OK;
 }
 extern "C" size_t d2p_lstm_flag_words(void) { return (size_t)PS_FLAG_WORDS + PS_TICKET_WORDS; }
+extern "C" int d2p_lstm_persist_set_poll(int pipelined) {
+    g_ps_poll_pipelined = pipelined & 3;
+    return D2P_OK;
+}
 static int g_ps_sorted = 1;                  // 0: ignore the length-sorted description of a launch (A/B switch)
 extern "C" int d2p_lstm_persist_set_sorted(int on) {
     g_ps_sorted = on ? 1 : 0;
@@ -1285,6 +1319,7 @@ static int ps_fwd_setup(const PsFwdCall& q, int RT, int bid0, PsFwdArgs& a, hipS
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.h0 = q.h0; a.c0 = q.c0; a.lens = q.lens;
     a.hout = q.hout; a.cs = q.cs; a.h_final = q.h_final; a.c_final = q.c_final;
     a.direct = 0; a.wh_raw = q.Wh; a.h0_raw = q.h0; a.h0_bytes = 0; a.epoch = 0; a.packed = 0;
+    a.poll = g_ps_poll_pipelined;
     if (q.flags && g_ps_direct) {
         // direct launch: nothing to prepare -- weights and the initial state are read where they lie, the flags
         // (the caller's once-zeroed buffer) run on epochs
@@ -1436,6 +1471,7 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     a.defer_from = g_ps_bwd_defer_from;
     a.lds_nb = (a.total_rs + RT - 1) / RT >= g_ps_bwd_defer_from ? 2 : 1;
     a.direct = 0; a.wh_raw = q.Wh; a.epoch = 0; a.packed = 0;
+    a.poll = g_ps_poll_pipelined;
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.c0 = q.c0; a.cs = q.cs; a.lens = q.lens;

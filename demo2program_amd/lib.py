@@ -63,6 +63,7 @@ SIGNATURES = {
     'd2p_lstm_persist_set_bwd_defer': (c_int, [c_int]),
     'd2p_lstm_flag_words': (c_size_t, []),
     'd2p_lstm_persist_set_sorted': (c_int, [c_int]),
+    'd2p_lstm_persist_set_poll': (c_int, [c_int]),
     'd2p_lstm_persist_set_plan_cost': (c_int, [ctypes.c_double, ctypes.c_double]),
     'd2p_lstm_pack_weights': (c_int, [c_int, c_int, P, P, P, S]),
     'd2p_lstm_persist_set_direct': (c_int, [c_int]),

@@ -201,6 +201,9 @@ class Model(object):
         if os.environ.get('D2P_LSTM_DIRECT') is not None:           # A/B: 0 = a preparation launch in front of every recurrence
             from ..lib import call
             call.d2p_lstm_persist_set_direct(int(os.environ['D2P_LSTM_DIRECT']))
+        if os.environ.get('D2P_LSTM_POLL') is not None:             # A/B: 0 = read / sleep / read flag polls
+            from ..lib import call
+            call.d2p_lstm_persist_set_poll(int(os.environ['D2P_LSTM_POLL']))
         if os.environ.get('D2P_BWD_DEFER_FROM') is not None:       # experiment: d2p_lstm_persist_set_bwd_defer
             from ..lib import call
             call.d2p_lstm_persist_set_bwd_defer(int(os.environ['D2P_BWD_DEFER_FROM']))

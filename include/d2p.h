@@ -261,6 +261,10 @@ int d2p_lstm_persist_set_bwd_defer(int from_phases);
 size_t d2p_lstm_flag_words(void);
 /* A/B switch: 0 = ignore rowmap / slab_steps of d2p_lstm_bwd_desc (every domain runs all steps); default 1 */
 int d2p_lstm_persist_set_sorted(int on);
+/* A/B switch (default 0: off -- the kernels gain 5-9 % in isolation, the training step loses 1 %), bits: 1 = in row domains of two and more phases a waiting wave keeps two reads of its flag in
+ * flight instead of read / sleep / read; 2 = in single-phase domains as well (measured slower: the 32-row program
+ * decoder's 256 waves then poll without a pause and delay the rows they are waiting for) */
+int d2p_lstm_persist_set_poll(int pipelined);
 /* Tuning knob of the length-sorted planner: cost model of a backward row domain per pass, max(us_per_phase * phases,
  * floor_us); defaults 3.3 / 6.3 (values <= 0 leave a parameter unchanged) */
 int d2p_lstm_persist_set_plan_cost(double us_per_phase, double floor_us);
