@@ -149,7 +149,8 @@ __device__ __forceinline__ void ps_barrier() {
 // The polls are PIPELINED: two reads of the flag are in flight at any time (write-through-scope buffer loads, which the
 // compiler lets overlap -- relaxed atomic loads are completed one by one), so a flag that is raised between two polls is
 // seen half a round trip earlier than by read / wait / sleep / read.  `base`: the flag area (for the descriptor).
-static int g_ps_poll_pipelined = 0;      // off: faster kernels in isolation, a slower training step
+static int g_ps_poll_pipelined = 16;     // bits 0-1 (pipelined polls): off -- faster kernels in isolation, a slower training step;
+                                         // bits 2-4 (extra pauses between polls): 4 -- fewer polls leave the other queue's GEMMs more of L2
 __device__ __forceinline__ unsigned ps_ld_flag_buf(__amdgpu_buffer_rsrc_t r, int off) {
     const unsigned v = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(r, off, 0, PS_AUX_SC1);
     asm volatile("" ::: "memory");          // a new read every time: never merged with the previous one
@@ -159,7 +160,7 @@ __device__ __forceinline__ void ps_wait_flags(const unsigned* f, unsigned need, 
                                               unsigned code, const unsigned* base, int pipelined) {
     if (__all((int)(fv >= need))) return;
     unsigned spins = 0;
-    if (pipelined) {
+    if (pipelined & 3) {
         const __amdgpu_buffer_rsrc_t r = ps_rsrc(base, (unsigned)((PS_FLAG_WORDS + PS_TICKET_WORDS) * sizeof(unsigned)));
         const int off = (int)((const char*)f - (const char*)base);
         unsigned a = ps_ld_flag_buf(r, off);
@@ -178,8 +179,10 @@ __device__ __forceinline__ void ps_wait_flags(const unsigned* f, unsigned need, 
             }
         }
     }
+    const int naps = (pipelined >> 2) & 7;        // pauses between two polls: (1 + naps) x s_sleep(4) (bits 2-4 of the poll word)
     for (;;) {
         __builtin_amdgcn_s_sleep(4);
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(4);
         fv = ps_ld_flag(f);
         if (__all((int)(fv >= need))) return;
         ++spins;
@@ -396,7 +399,7 @@ __device__ __forceinline__ void ps_fwd_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW]
     if (la) {
         ps_wait_flags(fl1, need1, fv, a.err, 1, a.flags, a.poll);
     } else {
-        ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3, a.flags, a.poll & 2);
+        ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3, a.flags, a.poll & ~1);
 #pragma unroll
         for (int c = 0; c < CPW; ++c) cur[c] = ps_ld_src(cur_src, c);
     }
@@ -876,7 +879,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         PsBwdEpiPre pre;
         tr.stamp(0);
         if (!LA) {
-            ps_wait_flags(fl + k0.p * nnt, ps_need(a.epoch, k0.t), ps_ld_flag(fl + k0.p * nnt), a.err, 4, a.flags, a.poll & 2);
+            ps_wait_flags(fl + k0.p * nnt, ps_need(a.epoch, k0.t), ps_ld_flag(fl + k0.p * nnt), a.err, 4, a.flags, a.poll & ~1);
 #pragma unroll
             for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(rk0, off + c * 1024);
         }
@@ -1207,7 +1210,7 @@ extern "C" int d2p_lstm_persist_set_direct(int on) {
 }
 extern "C" size_t d2p_lstm_flag_words(void) { return (size_t)PS_FLAG_WORDS + PS_TICKET_WORDS; }
 extern "C" int d2p_lstm_persist_set_poll(int pipelined) {
-    g_ps_poll_pipelined = pipelined & 3;
+    g_ps_poll_pipelined = pipelined & 31;
     return D2P_OK;
 }
 static int g_ps_sorted = 1;                  // 0: ignore the length-sorted description of a launch (A/B switch)

@@ -261,9 +261,12 @@ int d2p_lstm_persist_set_bwd_defer(int from_phases);
 size_t d2p_lstm_flag_words(void);
 /* A/B switch: 0 = ignore rowmap / slab_steps of d2p_lstm_bwd_desc (every domain runs all steps); default 1 */
 int d2p_lstm_persist_set_sorted(int on);
-/* A/B switch (default 0: off -- the kernels gain 5-9 % in isolation, the training step loses 1 %), bits: 1 = in row domains of two and more phases a waiting wave keeps two reads of its flag in
- * flight instead of read / sleep / read; 2 = in single-phase domains as well (measured slower: the 32-row program
- * decoder's 256 waves then poll without a pause and delay the rows they are waiting for) */
+/* How a wave of the persistent kernels waits for a hand-off flag (default 16).  Bits 0-1: pipelined polls -- 1 = in row
+ * domains of two and more phases a waiting wave keeps two reads of its flag in flight instead of read / pause / read,
+ * 2 = in single-phase domains as well (the kernels gain 5-9 % in isolation, the training step loses 1 %: off).  Bits
+ * 2-4: n extra pauses between two polls, (1 + n) x s_sleep(4) -- n = 4 by default: fewer polls cost a waiting wave
+ * little and leave the L2 to the GEMMs of the other queue (training step -1 %; n = 0: 3.010 ms, 3: 2.981, 4: 2.974 -
+ * 2.982, 5: 2.981, 7: 3.027). */
 int d2p_lstm_persist_set_poll(int pipelined);
 /* Tuning knob of the length-sorted planner: cost model of a backward row domain per pass, max(us_per_phase * phases,
  * floor_us); defaults 3.3 / 6.3 (values <= 0 leave a parameter unchanged) */
