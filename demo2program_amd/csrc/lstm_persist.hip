@@ -149,6 +149,11 @@ __device__ __forceinline__ void ps_barrier() {
 // The polls are PIPELINED: two reads of the flag are in flight at any time (write-through-scope buffer loads, which the
 // compiler lets overlap -- relaxed atomic loads are completed one by one), so a flag that is raised between two polls is
 // seen half a round trip earlier than by read / wait / sleep / read.  `base`: the flag area (for the descriptor).
+// the poll word of a single-phase domain's waits: bit 1 -> bit 0, and the pauses of bits 5-7 instead of 2-4 when bit 8 is set
+__device__ __forceinline__ int ps_poll_single(int w) {
+    const int naps = (w & 256) ? ((w >> 5) & 7) : ((w >> 2) & 7);
+    return ((w >> 1) & 1) | (naps << 2);
+}
 static int g_ps_poll_pipelined = 16;     // bits 0-1 (pipelined polls): off -- faster kernels in isolation, a slower training step;
                                          // bits 2-4 (extra pauses between polls): 4 -- fewer polls leave the other queue's GEMMs more of L2
 __device__ __forceinline__ unsigned ps_ld_flag_buf(__amdgpu_buffer_rsrc_t r, int off) {
@@ -399,7 +404,7 @@ __device__ __forceinline__ void ps_fwd_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW]
     if (la) {
         ps_wait_flags(fl1, need1, fv, a.err, 1, a.flags, a.poll);
     } else {
-        ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3, a.flags, a.poll & ~1);
+        ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3, a.flags, ps_poll_single(a.poll));
 #pragma unroll
         for (int c = 0; c < CPW; ++c) cur[c] = ps_ld_src(cur_src, c);
     }
@@ -879,7 +884,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         PsBwdEpiPre pre;
         tr.stamp(0);
         if (!LA) {
-            ps_wait_flags(fl + k0.p * nnt, ps_need(a.epoch, k0.t), ps_ld_flag(fl + k0.p * nnt), a.err, 4, a.flags, a.poll & ~1);
+            ps_wait_flags(fl + k0.p * nnt, ps_need(a.epoch, k0.t), ps_ld_flag(fl + k0.p * nnt), a.err, 4, a.flags, ps_poll_single(a.poll));
 #pragma unroll
             for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(rk0, off + c * 1024);
         }
@@ -1210,7 +1215,7 @@ extern "C" int d2p_lstm_persist_set_direct(int on) {
 }
 extern "C" size_t d2p_lstm_flag_words(void) { return (size_t)PS_FLAG_WORDS + PS_TICKET_WORDS; }
 extern "C" int d2p_lstm_persist_set_poll(int pipelined) {
-    g_ps_poll_pipelined = pipelined & 31;
+    g_ps_poll_pipelined = pipelined & 511;
     return D2P_OK;
 }
 static int g_ps_sorted = 1;                  // 0: ignore the length-sorted description of a launch (A/B switch)
