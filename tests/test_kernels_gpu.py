@@ -1054,21 +1054,26 @@ def test_lstm_packed_weight_images_kept_by_the_caller(K, specs):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('specs', [[(320, 20, 'lens')], [(320, 20, 'mask')], [(320, 6, 'mask'), (320, 6, 'mask'), (32, 9, None)],
-                                   [(40, 5, 'lens')], [(400, 20, 'lens')], [(320, 20, 'lens'), (32, 50, None)]])
+                                   [(40, 5, 'lens')], [(400, 20, 'lens')], [(320, 20, 'lens'), (32, 50, None)],
+                                   [(320, 20, 'lens0')], [(12, 7, 'lens')], [(320, 12, 'lens', 256)]])
 def test_lstm_backward_over_rows_sorted_by_length(K, specs):
     """d2p_lstm_bwd_desc.rowmap / slab_steps: the backward recurrence groups rows of similar length into its row domains
     and runs each domain only for its longest row's steps.  'lens': a dynamic_rnn recurrence (lengths given, gradients of
     the final states); 'mask': a decoder (no lengths -- the incoming dhout is zero past each row's length, as behind a
-    masked loss).  dz, dh0, dc0 bit-identical to the launch that runs every step for every row (incl. the zeros of the
+    masked loss); 'lens0': lengths from 0, none reaching the step count; 12 rows: one ragged sub-tile; U = 256: more row
+    domains than the sorted description takes (the order is then ignored).  dz, dh0, dc0 bit-identical to the launch that runs every step for every row (incl. the zeros of the
     skipped steps, over a dz buffer pre-filled with garbage); the bias gradient within summation-order round-off."""
-    U = 512
     K.lstm_persist_error(True)
 
     def run(sort):
         fw, bw, outs = [], [], []
         gg = torch.Generator().manual_seed(41)
-        for (M, n, mode) in specs:
+        for spec in specs:
+            (M, n, mode), U = spec[:3], (spec[3] if len(spec) > 3 else 512)
             lens_h = torch.randint(max(1, n // 3), n + 1, (M,), generator=gg).int()
+            if mode == 'lens0':      # rows of length 0 (nothing but their state passes through) and a batch whose
+                mode = 'lens'        # longest row is shorter than the launch's step count
+                lens_h = torch.clamp(lens_h - n // 3, max=n - 3)
             lens = lens_h.cuda() if mode == 'lens' else None
             o = dict(z=(torch.rand(n * M, 4 * U, generator=gg) * 2 - 1).cuda(), hout=torch.zeros(n, M, U, device='cuda'),
                      cs=torch.zeros(n, M, U, device='cuda'), dz=torch.full((n * M, 4 * U), 3.0, device='cuda'),

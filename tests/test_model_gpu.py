@@ -752,6 +752,35 @@ def test_headline_config_properties():
     assert torch.isfinite(g1).all() and float(g1.norm()) > 0
     n = feed['n_prog']
     assert model.pred_program[:, :, n:].abs().max().item() == 0 if n < cfg.max_program_len else True
+    # the backward recurrences run over rows sorted by length and stop each row domain at its longest row: every dz row
+    # past its sequence's length is still an exact zero, and the gradients are those of the launches that run every row
+    # for all steps (d2p_lstm_persist_set_sorted(0)) up to the summation order of the bias gradients
+    from demo2program_amd import kernels as K
+    T, M, U = cfg.max_demo_len, cfg.batch_size * cfg.k, cfg.num_lstm_cell_units
+    lens = feed['demo_len'].view(1, M).long()
+    past = (torch.arange(T, device='cuda').view(T, 1) >= lens).view(T * M)
+    assert bool(past.any())
+    for name in ('demo_lstm', 'second_lstm', 'act/lstm', 'per/lstm'):
+        dz = model._bufs[name + '/dz'].view(T * M, 4 * U)
+        assert dz[past].abs().max().item() == 0, name
+        assert dz[~past].abs().max().item() > 0, name
+    K.lstm_set_sorted(False)
+    try:
+        l3 = float(model.forward(feed).item())
+        model.backward()
+        g3 = model.params.grad.clone()
+    finally:
+        K.lstm_set_sorted(True)
+    assert l3 == l1
+    P = model.params
+    names = [n_ for n_ in P.shapes if n_.endswith('/bias') and 'lstm' in n_]
+    for n_, sh in P.shapes.items():
+        o, cnt = P.offsets[n_], int(np.prod(sh))
+        a, b = g1[o:o + cnt], g3[o:o + cnt]
+        if n_ in names:
+            assert (a - b).abs().max().item() <= 2e-6 * max(1.0, float(b.abs().max())), n_
+        else:
+            assert torch.equal(a, b), n_
 
 
 def test_vizdoom_80x80_frames_match_oracle():
