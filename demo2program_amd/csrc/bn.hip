@@ -798,7 +798,9 @@ static int bn_bwd_impl(int nb, long xs, long ys, long ps, int R, int C, int G, i
         // column-sum finalize folded into the apply launch when its input is small (conv layers: <= 1024 blocks x
         // 16-48 channels); the ticket sits behind the partial-sum tickets of the same slot (or in a slot of its own)
         unsigned* sum_ticket = nullptr;
-        if (g_bn_fold && C <= 256 && (long)blocks * C <= 65536 && nb * (G + 2) <= BN_TICKET_WORDS)
+        // (not in gc mode: there the column-sum finalize LAUNCH is the one writer of dgamma / dbeta -- folding it away
+        //  left them unwritten for layers whose partial sums are too many for the ticket fold)
+        if (g_bn_fold && !gc && C <= 256 && (long)blocks * C <= 65536 && nb * (G + 2) <= BN_TICKET_WORDS)
             sum_ticket = (tickets ? tickets : bn_ticket_slot()) + nb * (G + 1);
         if (v4)
             hipLaunchKernelGGL((bn_apply_bwd_kernel<4, true>), dim3(blocks, 1, nb), dim3(256), 0, st, R, C, G, inner, x,

@@ -211,6 +211,22 @@ bool d2p_lstm_try_pair_fwd(const d2p_lstm_fwd_desc* d, hipStream_t st, int* rc) 
     *rc = d2p_lstm_persist_fwd_pair(c[0], c[1], st);
     return true;
 }
+// One to three sequences as ONE launch of the wide-tile persistent kernel (lstm_persist.hip): direct launches only.
+bool d2p_lstm_try_wide_fwd(int n, const d2p_lstm_fwd_desc* d, hipStream_t st, int* rc) {
+    if (n < 1 || n > 3) return false;
+    PsFwdCall c[3];
+    for (int i = 0; i < n; ++i) {
+        const d2p_lstm_fwd_desc& q = d[i];
+        if (q.M <= 0 || q.n_steps <= 0 || !(q.z && q.Wh && q.hout && q.cs && q.ws && q.flags)) return false;
+        if (!use_fused(q.M, q.U, q.z_row_stride, q.z, q.ws_bytes) || q.ws_bytes < d2p_lstm_persist_ws_bytes(q.M, q.U))
+            return false;
+        c[i] = PsFwdCall{q.M, q.U, q.n_steps, q.z, q.z_row_stride, q.z_t_stride, q.Wh, q.h0, q.c0, q.lens, q.hout, q.cs,
+                         q.h_final, q.c_final, (float*)q.ws, q.flags, q.epoch, q.wpack, q.rowmap, q.slab_steps};
+    }
+    if (!d2p_lstm_persist_fwd_wide_ok(n, c)) return false;
+    *rc = d2p_lstm_persist_fwd_wide(n, c, st);
+    return true;
+}
 bool d2p_lstm_try_pair_bwd(const d2p_lstm_bwd_desc* d, hipStream_t st, int* rc) {
     for (int i = 0; i < 2; ++i) {
         const d2p_lstm_bwd_desc& q = d[i];

@@ -67,6 +67,9 @@ struct PsFwdCall {
     // zeroed ONCE by the caller, and the caller's epoch for it (raised by more than n_steps per launch)
     unsigned* flags; unsigned epoch;
     const float* wpack;      // optional with flags: the caller's packed forward image of Wh (d2p_lstm_pack_weights)
+    // optional with flags and lens (length-sorted launch of the wide-tile kernel, as PsBwdCall): rowmap[v] (device, M
+    // entries) = the caller's row at position v of the order by decreasing length; slab_steps (HOST, ceil(M/16) entries)
+    const int* rowmap; const int* slab_steps;
 };
 struct PsBwdCall {
     int M, U, n_steps;
@@ -90,6 +93,11 @@ int d2p_lstm_persist_bwd(const PsBwdCall& q, hipStream_t st);
 bool d2p_lstm_persist_fwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U);
 bool d2p_lstm_persist_bwd_pair_ok(int Ma, int Ta, int Mb, int Tb, int U);
 int d2p_lstm_persist_fwd_pair(const PsFwdCall& qa, const PsFwdCall& qb, hipStream_t st);
+// wide-tile forward kernel (16 units per column tile, 8 row domains at U = 512): one to three sequences per launch,
+// length-sorted where a sequence brings rowmap / slab_steps; direct launches only (flags)
+bool d2p_lstm_persist_fwd_wide_ok(int n, const PsFwdCall* q);
+int d2p_lstm_persist_fwd_wide(int n, const PsFwdCall* q, hipStream_t st);
+bool d2p_lstm_try_wide_fwd(int n, const d2p_lstm_fwd_desc* d, hipStream_t st, int* rc);
 int d2p_lstm_persist_bwd_pair(const PsBwdCall& qa, const PsBwdCall& qb, hipStream_t st);
 // the backward kernel also takes three (the three decoders)
 bool d2p_lstm_persist_bwd_triple_ok(const int M[3], const int T[3], int U);

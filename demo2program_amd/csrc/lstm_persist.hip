@@ -708,6 +708,508 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
 }
 
 // =============================================================================================
+// Forward, wide column tiles (round 4): a workgroup owns [16 units x 4 gates] = 64 gate columns
+// =============================================================================================
+// The kernel above gives a workgroup 8 units (32 gate columns): 64 column tiles, so 256 CUs hold 4 row domains and a
+// phase is 64 MFMAs per wave (2048 clocks) beside ~1450 clocks of everything else.  Here a phase is 128 MFMAs (4096
+// clocks) beside about the same non-MFMA work -- the epilogue computes one cell per lane on all 64 lanes instead of 32
+// (the narrow tile's lanes 32-63 are idle duplicates), the operand loads, the flag polls, the barrier and the
+// publication are per phase, not per column -- and 32 column tiles leave room for 8 row domains:
+//   * up to THREE sequences per launch (the three decoders: 3 + 3 + 2 domains), as the backward kernel takes them;
+//   * length-sorted launches for the encoders (rowmap / rs_start / tdom as in the backward kernel): a domain holds
+//     rows of similar length and runs only its longest row's steps; what the skipped steps would have written
+//     (zeros in hout, the carried cell state in cs) is filled in at the end, so every array is bit-identical to the
+//     unsorted launch;
+//   * with 8 domains of 32 tiles the block -> tile map puts ONE domain on ONE XCD when workgroup b lands on XCD b % 8
+//     (observed, not promised).  Every workgroup publishes its HW_REG_XCC_ID with its first rows; a domain whose 32
+//     workgroups all read the same id exchanges through that XCD's L2 from then on (plain stores: the lines stay in
+//     L2, the consumers' sc1 loads hit there) instead of writing through to memory -- decided per domain at run
+//     time, correct under any placement.
+// Same arithmetic and summation order as the narrow kernel and lstm_step.hip (K split four ways over the waves, chunks
+// and k in ascending order inside a wave, partial tiles added in wave order): outputs are bit-identical.
+// Direct launches only (the caller's flag buffer and epoch); everything else goes to the kernel above.
+#define PSW_PLD 80                        // partial-tile row stride (floats): 64 columns, rows rr / rr+1 on disjoint banks
+#define PSW_P_FLOATS (4 * 16 * PSW_PLD)   // one set of four partial tiles
+#define PSW_SLOT 1024                     // floats per prefetch ring slot: 4 gates x 16 rows x 16 units
+#define PSW_CELLS 256                     // cells of a phase: 16 rows x 16 units
+#define PSW_XCC_WORDS 256                 // one word per (domain, column tile) behind the tickets: the workgroup's XCC id + 1
+
+__device__ unsigned g_psw_local_wgs;     // workgroups so far that found their row domain on one XCD (a statistic)
+struct PsFwdWArgs {
+    int M, U, T, total_rs, RT, has_h0;
+    int dom0;               // this sequence's row domains are domains [dom0, dom0 + RT) of the launch
+    float* hfrag;           // 2 ping-pong buffers of Mp*U floats, fragment-major
+    unsigned hfrag_bytes;   // bytes of ONE buffer
+    float* z; long zrs, zts;
+    const float* c0; const int* lens;
+    float* hout; float* cs; float* h_final; float* c_final;
+    unsigned* flags;        // [RT][PS_NRS_MAX][U/16] on epochs, then tickets, then PSW_XCC_WORDS placement words
+    float* dump;
+    unsigned* err;
+    unsigned long long* trace; int trace_block;
+    const float* wh_raw; const float* h0_raw; unsigned h0_bytes; unsigned epoch;
+    int poll;
+    int la_from, defer_from;     // phases per domain from which a domain looks ahead / runs the deferred form
+    int lds_nb;                  // 2 when some domain of the launch defers (double-buffered partial tiles / staged rows)
+    int xcd_local;               // 1: domains found on one XCD exchange through its L2 (0: always write-through)
+    // length-sorted launch (as PsBwdArgs)
+    const int* rowmap;
+    int sorted, Tfull;
+    int rs_start[PS_RT_TAB + 1], tdom[PS_RT_TAB];
+};
+
+template <int CPW>
+__device__ __forceinline__ void psw_chain(const f32x4 (&av)[CPW], const f32x4 (&bv)[CPW][4], f32x4 (&acc)[4], int c0 = 0,
+                                          int c1 = CPW) {
+#pragma unroll
+    for (int c = c0; c < c1; ++c)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][jj], bv[c][g][jj], acc[g], 0, 0, 0);
+}
+
+struct PswEpi {             // per-lane constants of an MFMA wave's share of the epilogue: one cell per lane
+    int rr, un, u;          // row within the phase, unit within the tile, global unit
+    float *P, *stc, *sth, *stage, *ring;
+    int* stl;
+    // the global stores of the epilogue go through buffer descriptors: per-lane byte offset (row, unit) in a VGPR, the
+    // step's and the gate's offset in an SGPR, masked lanes past the descriptor's range (dropped by the bounds check)
+    // -- a handful of VALU instructions instead of ~45 for six 64-bit addresses (a VALU instruction beside an fp32
+    // MFMA chain is paid in full: measured ~8 clocks each, tools/trace_lstm_wide.py)
+    __amdgpu_buffer_rsrc_t zres, cres, hres_out;
+};
+struct PswEpiIn {
+    float zin[4], part[4][4], cp, hp;
+    int lw;                 // length | row of the caller's arrays << 16
+};
+#define PSW_OOB 0x7fffff00   // a byte offset past every descriptor (sizes are checked on the host: < 2^31 bytes)
+__device__ __forceinline__ void psw_epilogue_load(const PswEpi& e, int p, int slot, int par, PswEpiIn& in) {
+    const int sidx = (p * 16 + e.rr) * 16 + e.un;
+    const float* zs = e.ring + slot * PSW_SLOT + e.rr * 16 + e.un;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) in.zin[g] = zs[g * 256];
+    const float* Pb = e.P + par * PSW_P_FLOATS + e.rr * PSW_PLD + e.un;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) in.part[g][w] = Pb[w * 16 * PSW_PLD + g * 16];
+    in.cp = e.stc[sidx];
+    in.hp = e.sth[sidx];
+    in.lw = e.stl[p * 16 + e.rr];
+}
+__device__ __forceinline__ void psw_epilogue_finish(const PsFwdWArgs& a, const PswEpi& e, int rs0, int p, int t, int par,
+                                                    const PswEpiIn& in) {
+    const int U = a.U;
+    const int vrow = (rs0 + p) * 16 + e.rr;
+    const bool valid = vrow < a.M;
+    const int prow = in.lw >> 16;
+    const int sidx = (p * 16 + e.rr) * 16 + e.un;
+    const bool active = t < (in.lw & 0xffff);
+    float zz[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        zz[g] = in.zin[g];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) zz[g] += in.part[g][w];
+    }
+    float cn, hn;
+    lstm_cell_fwd(zz[0], zz[1], zz[2], zz[3], in.cp, cn, hn);
+    const float c_out = active ? cn : in.cp;
+    const float h_out = active ? hn : 0.f;        // emitted output: 0 past the row's length
+    const float h_state = active ? hn : in.hp;    // (c, h) copy through
+    e.stc[sidx] = c_out;
+    e.sth[sidx] = h_state;
+    // staged in fragment-major order: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
+    e.stage[par * PSW_CELLS + (((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = h_state;
+    // unconditional stores (rows that keep their input projection write it back unchanged; masked lanes out of range)
+    const int u4 = e.u * 4;
+    const int vz = valid ? (int)__umul24((unsigned)prow, (unsigned)(a.zrs * 4)) + u4 : PSW_OOB;
+    const int vo = valid ? (int)__umul24((unsigned)prow, (unsigned)(U * 4)) + u4 : PSW_OOB;
+    const int sz = t * (int)(a.zts * 4), so = t * (a.M * U * 4);       // wave-uniform: scalar offsets of the step
+    const bool keep = !(active && ((t > 0) || a.has_h0));
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, keep ? in.zin[g] : zz[g]), e.zres, vz, sz + g * U * 4, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, c_out), e.cres, vo, so, 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, h_out), e.hres_out, vo, so, 0);
+}
+__device__ __forceinline__ void psw_write_partials(float* Pw, int lane, const f32x4 (&acc)[4]) {
+    // C/D layout of 16x16x4: col = lane&15, row = (lane>>4)*4 + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Pw[((lane >> 4) * 4 + r) * PSW_PLD + g * 16 + (lane & 15)] = acc[g][r];
+}
+
+// where step t, phase p of a sequence reads its 16 rows: the fragment-major ping-pong buffer, or (t = 0) the row-major
+// initial state through its own descriptor (zero-length without one); prow0 = this lane's row of the caller's arrays
+__device__ __forceinline__ PsSrc psw_src(const PsFwdWArgs& a, __amdgpu_buffer_rsrc_t hres, __amdgpu_buffer_rsrc_t hres0, int t,
+                                         int rs, int KC, int lane_off, int prow0, int k_off) {
+    const bool first = t == 0;
+    PsSrc s;
+    s.r = first ? hres0 : hres;
+    s.off = first ? (prow0 * a.U + k_off) * 4 : (int)((t & 1) * a.hfrag_bytes) + rs * KC * 1024 + lane_off;
+    s.cs = first ? 64 : 1024;
+    return s;
+}
+
+// One phase, epilogue right behind its own product.  MODE 0 (single-phase domains): the phase's own rows behind a
+// blocking poll, nothing fetched ahead (the next tick's rows come out of this tick's epilogue).  MODE 1 (look-ahead): the
+// NEXT phase's rows are requested BEHIND this phase's chain -- a whole chain of slack for their hand-off, which even a
+// 2-phase domain's rows (published by the tick before this one) have then mostly used up -- and land during the partial-
+// tile exchange, the barrier and the gate math; their flag was read one tick earlier.
+template <int CPW, int MODE>
+__device__ __forceinline__ void psw_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][4],
+                                         const PsFwdWArgs& a, const PswEpi& e, PsTick k0, const unsigned* fl_cur,
+                                         const PsSrc& cur_src, const unsigned* fl1, unsigned need1, const PsSrc& src1,
+                                         const unsigned* fl2, unsigned& fv, int wave, int rs0, int slot, int lane,
+                                         PsTrace& tr) {
+    tr.stamp(0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (MODE == 0) {
+        ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3, a.flags, ps_poll_single(a.poll));
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) cur[c] = ps_ld_src(cur_src, c);
+    }
+    tr.stamp(1);
+    psw_chain<CPW>(cur, bv, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    tr.stamp(2);
+    if (MODE != 0) {
+        ps_wait_flags(fl1, need1, fv, a.err, 1, a.flags, a.poll);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_src(src1, c);
+        fv = ps_ld_flag(fl2);
+    }
+    psw_write_partials(e.P + wave * 16 * PSW_PLD, lane, acc);
+    ps_barrier();           // A: all four partial tiles of this phase are in LDS
+    tr.stamp(3);
+    PswEpiIn in;
+    psw_epilogue_load(e, k0.p, slot, 0, in);
+    psw_epilogue_finish(a, e, rs0, k0.p, k0.t, 0, in);
+    ps_barrier();           // B: new rows staged, P and the ring slot free again
+    tr.stamp(4);
+}
+
+// Deferred form (domains with >= defer_from phases): the gate math of the PREVIOUS phase inside this phase's MFMA chain
+// (one basic block: LDS reads and the next phase's operand loads in the first quarter, a quarter for them to land,
+// arithmetic and stores spread over the second half), one barrier per phase, rows published one phase later.
+template <int CPW>
+__device__ __forceinline__ void psw_tick_defer(const f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][4],
+                                               const PsFwdWArgs& a, const PswEpi& e, PsTick kprev, int slot_prev,
+                                               const unsigned* fl1, unsigned need1, const PsSrc& src1,
+                                               const unsigned* fl2, unsigned& fv, int wave, int rs0, int par, int lane,
+                                               PsTrace& tr) {
+    tr.stamp(0);
+    ps_wait_flags(fl1, need1, fv, a.err, 1, a.flags, a.poll);
+    tr.stamp(1);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int C1 = CPW >= 4 ? CPW / 4 : 0, C2 = CPW >= 4 ? CPW / 2 : 0;
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_src(src1, c);
+    fv = ps_ld_flag(fl2);
+    PswEpiIn in;
+    psw_epilogue_load(e, kprev.p, slot_prev, par ^ 1, in);
+    psw_chain<CPW>(cur, bv, acc, 0, C1);
+#pragma unroll
+    for (int i = 0; i < 8 * C1; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // two MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // one operand load
+        __builtin_amdgcn_sched_group_barrier(0x186, 3, 0);      // three of VALU / SALU / LDS read
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    psw_chain<CPW>(cur, bv, acc, C1, C2);
+    __builtin_amdgcn_sched_barrier(0);
+    psw_chain<CPW>(cur, bv, acc, C2, CPW);
+    psw_epilogue_finish(a, e, rs0, kprev.p, kprev.t, par ^ 1, in);
+#pragma unroll
+    for (int i = 0; i < 8 * (CPW - C2); ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // two MFMAs
+        __builtin_amdgcn_sched_group_barrier(0x3d6, 4, 0);      // four of VALU / SALU / LDS / VMEM write
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    tr.stamp(2);
+    psw_write_partials(e.P + par * PSW_P_FLOATS + wave * 16 * PSW_PLD, lane, acc);
+    ps_barrier();           // partial tiles of this phase and the staged rows of the previous one are in LDS
+    tr.stamp(3);
+    tr.stamp(4);
+}
+
+// All ticks of one MFMA wave; two ticks per iteration with the two operand register sets swapping roles.
+template <int CPW, int MODE>
+__device__ __forceinline__ void psw_mfma_wave(const PsFwdWArgs& a, const PswEpi& e, const f32x4 (&bv)[CPW][4],
+                                              __amdgpu_buffer_rsrc_t hres, __amdgpu_buffer_rsrc_t hres0,
+                                              const unsigned* fl, int nnt, int rs0, int nrs, int nticks, int lane_off,
+                                              int k_off, int wave, int lane) {
+    constexpr int KC = 4 * CPW;
+    PsTrace tr;
+    tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
+    f32x4 a0[CPW], a1[CPW];
+    const int* rowtab = e.stl + (lane & 15);          // this lane's operand row of phase p: rowtab[p*16] >> 16
+    {
+        const PsSrc s0 = psw_src(a, hres, hres0, 0, rs0, KC, lane_off, rowtab[0] >> 16, k_off);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) a0[c] = ps_ld_src(s0, c);
+    }
+    PsTick kp = {0, 0}, k0 = {0, 0}, k1 = {0, 0}, k2 = {0, 0};      // ticks n-1, n, n+1, n+2
+    k1.next(nrs);
+    k2.next(nrs); k2.next(nrs);
+    unsigned fv = ps_ld_flag(fl + k1.p * nnt);
+    int slot = 0, slot_prev = 0;
+#define PSW_ONE_TICK(CUR, NXT, m)                                                                             \
+    {                                                                                                         \
+        const bool e1 = (m) + 1 >= nticks, e2 = (m) + 2 >= nticks;                                            \
+        const PsTick q1 = e1 ? k0 : k1, q2 = e2 ? (e1 ? k0 : k1) : k2;                                        \
+        const unsigned need1 = e1 ? 0u : ps_need(a.epoch, q1.t);                                              \
+        int pr0 = 0, pr1 = 0;          /* the row-major initial state is read in step 0 only */              \
+        if (k0.t == 0) pr0 = rowtab[k0.p * 16] >> 16;                                                         \
+        if (q1.t == 0) pr1 = rowtab[q1.p * 16] >> 16;                                                         \
+        const PsSrc cur_src = psw_src(a, hres, hres0, k0.t, rs0 + k0.p, KC, lane_off, pr0, k_off);            \
+        const PsSrc src1 = psw_src(a, hres, hres0, q1.t, rs0 + q1.p, KC, lane_off, pr1, k_off);               \
+        if (MODE == 2)                                                                                        \
+            psw_tick_defer<CPW>(CUR, NXT, bv, a, e, kp, slot_prev, fl + q1.p * nnt, need1, src1, fl + q2.p * nnt, \
+                                fv, wave, rs0, (m) & 1, lane, tr);                                            \
+        else                                                                                                  \
+            psw_tick<CPW, MODE>(CUR, NXT, bv, a, e, k0, fl + k0.p * nnt, cur_src, fl + q1.p * nnt, need1, src1, \
+                                fl + q2.p * nnt, fv, wave, rs0, slot, lane, tr);                              \
+        if (wave == 0) tr.flush(0, (m), lane);                                                                \
+        kp = k0; k0 = k1; k1 = k2; k2.next(nrs);                                                              \
+        slot_prev = slot;                                                                                     \
+        if (++slot == PS_PF_R) slot = 0;                                                                      \
+    }
+    int n = 0;
+    if (MODE == 2) {
+        // first tick: nothing to finish yet (plain product, one barrier)
+        const unsigned need1 = ps_need(a.epoch, k1.t);
+        const PsSrc src1 = psw_src(a, hres, hres0, k1.t, rs0 + k1.p, KC, lane_off, rowtab[k1.p * 16] >> 16, k_off);
+        ps_wait_flags(fl + k1.p * nnt, need1, fv, a.err, 1, a.flags, a.poll);
+#pragma unroll
+        for (int c = 0; c < CPW; ++c) a1[c] = ps_ld_src(src1, c);
+        fv = ps_ld_flag(fl + k2.p * nnt);
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        psw_chain<CPW>(a0, bv, acc);
+        psw_write_partials(e.P + wave * 16 * PSW_PLD, lane, acc);
+        ps_barrier();
+        kp = k0; k0 = k1; k1 = k2; k2.next(nrs);
+        slot_prev = slot;
+        ++slot;
+        n = 1;
+#pragma unroll 1
+        for (; n + 1 < nticks; n += 2) {
+            PSW_ONE_TICK(a1, a0, n)
+            PSW_ONE_TICK(a0, a1, n + 1)
+        }
+        if (n < nticks) PSW_ONE_TICK(a1, a0, n)
+        // the last phase's gate math (kp is the last tick now)
+        PswEpiIn in;
+        psw_epilogue_load(e, kp.p, slot_prev, (nticks - 1) & 1, in);
+        psw_epilogue_finish(a, e, rs0, kp.p, kp.t, (nticks - 1) & 1, in);
+    } else {
+#pragma unroll 1
+        for (; n + 1 < nticks; n += 2) {
+            PSW_ONE_TICK(a0, a1, n)
+            PSW_ONE_TICK(a1, a0, n + 1)
+        }
+        if (n < nticks) PSW_ONE_TICK(a0, a1, n)
+    }
+#undef PSW_ONE_TICK
+}
+
+template <int CPW>   // U = 64 * CPW
+__global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWArgs a0, PsFwdWArgs a1, PsFwdWArgs a2) {
+    constexpr int KC = 4 * CPW;
+    const int nnt = KC;                                        // column tiles: U / 16
+    // block -> (domain of the launch, column tile): consecutive tiles of a domain on one XCD if block b runs on XCD
+    // b % 8 -- with 8 domains of 32 tiles, one whole domain per XCD
+    int dom, nt;
+    ps_block_tile((int)blockIdx.x, (int)gridDim.x, nnt, dom, nt);
+    const PsFwdWArgs a = (dom >= a0.RT + a1.RT) ? a2 : ((dom >= a0.RT) ? a1 : a0);
+    const int rt = dom - a.dom0;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int nb = a.lds_nb;
+    float* P = lds;                                            // [nb][4][16][PSW_PLD]
+    float* stc = lds + nb * PSW_P_FLOATS;                      // [NRS][16 rows][16 units] cell state
+    float* sth = stc + PS_NRS_MAX * PSW_CELLS;                 // [NRS][16][16] hidden state
+    int* stl = reinterpret_cast<int*>(sth + PS_NRS_MAX * PSW_CELLS);    // [NRS][16] length | row << 16
+    int* strow = stl + PS_NRS_MAX * 16;                        // [NRS][16] the prefetch wave's copy of the rows
+    int* xcl = strow + PS_NRS_MAX * 16;                        // [4 + 1] the waves' verdicts on the domain's placement
+    float* stage = reinterpret_cast<float*>(xcl + 16);         // [nb][4 quads][16 rows][4]: new h rows of a phase
+    float* ring = stage + nb * PSW_CELLS;                      // [PS_PF_R][4 gates][16 rows][16 units]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int U = a.U;
+    int rs0, nrs, T = a.T;
+    ps_rt_range(rt, a.total_rs, a.RT, rs0, nrs);
+    if (a.sorted) {
+        int r0 = 0, r1 = 0, td = 1;
+#pragma unroll
+        for (int i = 0; i < PS_RT_TAB; ++i) {
+            r0 = (i == rt) ? a.rs_start[i] : r0;
+            r1 = (i == rt) ? a.rs_start[i + 1] : r1;
+            td = (i == rt) ? a.tdom[i] : td;
+        }
+        rs0 = r0; nrs = r1 - r0;
+        T = td;
+    }
+    const int nticks = nrs * T;
+    unsigned* fbase = a.flags + (long)rt * PS_NRS_MAX * nnt;
+    unsigned* xccw = a.flags + PS_FLAG_WORDS + PS_TICKET_WORDS + rt * nnt;     // this domain's placement words
+    const bool defer = nrs >= a.defer_from && a.lds_nb == 2;
+    const unsigned my_xcc = (unsigned)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID[3:0]
+
+    if (wave < 4) {
+        // ---------------- MFMA waves ----------------
+        f32x4 bv[CPW][4];
+        {
+            // straight from the row-major Wh [U, 4U]: k = kc*16 + 4*(lane>>4) + jj, column g*U + nt*16 + (lane&15)
+            const long ld = 4L * U;
+#pragma unroll
+            for (int c = 0; c < CPW; ++c) {
+                const int k = (wave * CPW + c) * 16 + 4 * (lane >> 4);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float* w = a.wh_raw + (long)k * ld + (long)g * U + nt * 16 + (lane & 15);
+                    bv[c][g] = f32x4{w[0], w[ld], w[2 * ld], w[3 * ld]};
+                }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t hres = ps_rsrc(a.hfrag, 2u * a.hfrag_bytes);
+        const __amdgpu_buffer_rsrc_t hres0 = ps_rsrc(a.h0_raw ? (const void*)a.h0_raw : (const void*)a.hfrag, a.h0_bytes);
+        const int lane_off = (wave * CPW * 64 + lane) * 16;
+        const int k_off = wave * CPW * 16 + 4 * (lane >> 4);
+        // the CPW producers (column tiles) whose units this wave's K slice covers
+        const unsigned* fl = fbase + CPW * wave + (lane & (CPW - 1));
+        PswEpi e;
+        e.rr = wave * 4 + (lane >> 4);
+        e.un = lane & 15;
+        e.u = nt * 16 + e.un;
+        e.P = P; e.stc = stc; e.sth = sth; e.stl = stl; e.stage = stage; e.ring = ring;
+        e.zres = ps_rsrc(a.z, (unsigned)(((size_t)(a.Tfull - 1) * a.zts + (size_t)(a.M - 1) * a.zrs + 4 * (size_t)U) * sizeof(float)));
+        e.cres = ps_rsrc(a.cs, (unsigned)((size_t)a.Tfull * a.M * U * sizeof(float)));
+        e.hres_out = ps_rsrc(a.hout, (unsigned)((size_t)a.Tfull * a.M * U * sizeof(float)));
+        for (int p = 0; p < nrs; ++p) {          // this wave's cells: initial state, row lengths, rows
+            const int vrow = (rs0 + p) * 16 + e.rr;
+            int row = min(vrow, a.M - 1);
+            if (a.rowmap && vrow < a.M) row = a.rowmap[vrow];
+            float c = 0.f, h = 0.f;
+            int len = 0xffff;
+            if (vrow < a.M) {
+                if (a.c0) c = a.c0[(long)row * U + e.u];
+                if (a.h0_raw && a.h0_bytes) h = a.h0_raw[(long)row * U + e.u];
+                if (a.lens) len = min(max(a.lens[row], 0), 0xffff);
+            }
+            stc[(p * 16 + e.rr) * 16 + e.un] = c;
+            sth[(p * 16 + e.rr) * 16 + e.un] = h;
+            if (e.un == 0) stl[p * 16 + e.rr] = len | (row << 16);
+        }
+        ps_barrier();                             // (stl rows of the other waves: the operand rows of step 0)
+        if (defer) psw_mfma_wave<CPW, 2>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
+        else if (nrs >= a.la_from) psw_mfma_wave<CPW, 1>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
+        else psw_mfma_wave<CPW, 0>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
+        for (int q = 0; q < nrs; ++q) {
+            const int vrow = (rs0 + q) * 16 + e.rr;
+            const int row = stl[q * 16 + e.rr] >> 16;
+            if (vrow < a.M) {
+                const float hs = sth[(q * 16 + e.rr) * 16 + e.un], cc = stc[(q * 16 + e.rr) * 16 + e.un];
+                if (a.h_final) a.h_final[(long)row * U + e.u] = hs;
+                if (a.c_final) a.c_final[(long)row * U + e.u] = cc;
+                // the steps this domain did not run: every row is past its length there -- zero output, carried cell state
+                for (int t = T; t < a.Tfull; ++t) {
+                    a.hout[(long)t * a.M * U + (long)row * U + e.u] = 0.f;
+                    a.cs[(long)t * a.M * U + (long)row * U + e.u] = cc;
+                }
+            }
+        }
+    } else {
+        // ---------------- publish + prefetch wave ----------------
+        // prefetch: 4 DMA instructions per tick (one per gate): lane = (row r, quad q), 16 bytes = 4 units
+        const int r = lane >> 2, q4 = lane & 3;
+        for (int i = lane; i < nrs * 16; i += 64) {        // this wave's own table of the domain's rows
+            const int vrow = rs0 * 16 + i;
+            int row = min(vrow, a.M - 1);
+            if (a.rowmap && vrow < a.M) row = a.rowmap[vrow];
+            strow[i] = row;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        ps_barrier();                             // (pairs with the MFMA waves' barrier behind their tables)
+        const float* zsrc = a.z + nt * 16 + q4 * 4;
+        PsTick kp = {0, 0};        // next tick to prefetch
+        int pslot = 0;
+        auto issue = [&]() {
+            const PsTick q = kp;
+            const int row = strow[q.p * 16 + r];
+            const float* zr = zsrc + (long)q.t * a.zts + (long)row * a.zrs;
+            float* dst = ring + pslot * PSW_SLOT;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) ps_dma16(zr + (long)g * U, dst + g * 256);
+            // past the last tick the same rows are fetched again: the counted waits below stay exact
+            if (q.p + 1 < nrs || q.t + 1 < T) kp.next(nrs);
+            if (++pslot == PS_PF_R) pslot = 0;
+        };
+        for (int d = 0; d < PS_PF_D; ++d) issue();
+        ps_wait_vmcnt<(PS_PF_D - 1) * 4>();         // tick 0's inputs have landed
+        const __amdgpu_buffer_rsrc_t hres = ps_rsrc(a.hfrag, 2u * a.hfrag_bytes);
+        PsTrace tr;
+        tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
+        // placement: every workgroup of the domain leaves its XCC id (+ 1 + epoch-free: the words are rewritten by every
+        // launch before its first flag) in front of its first publication; after the first complete hand-off this wave
+        // reads all of them -- all equal to its own: the domain exchanges through this XCD's L2 from then on
+        if (lane == 0)
+            __builtin_amdgcn_raw_buffer_store_b32((int)(a.epoch * 16u + my_xcc + 1u),
+                                                  ps_rsrc(xccw, (unsigned)(nnt * sizeof(unsigned))), nt * 4, 0, PS_AUX_SC1);
+        bool local = false;
+        int checked = 0;
+        PsTick k = {0, 0};
+        for (int n = 0; n < nticks; ++n) {
+            tr.stamp(0);
+            ps_barrier();          // A (deferred form: the only barrier of the tick)
+            if (!defer) ps_barrier();          // B: the phase's new h rows are staged
+            tr.stamp(1);
+            // deferred form: tick n-1's rows were staged during tick n and are published now
+            const bool pub = !defer || n > 0;
+            const int par = defer ? ((n - 1) & 1) : 0;
+            const f32x4 hv = *reinterpret_cast<const f32x4*>(stage + par * PSW_CELLS + lane * 4);
+            const int off = (int)(((k.t + 1) & 1) * a.hfrag_bytes) + (((rs0 + k.p) * KC + nt) * 64 + lane) * 16;
+            asm volatile("" ::: "memory");
+            if (pub) {
+                if (local)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, hv), hres, off, 0, 0);
+                else
+                    ps_st_sc1(hres, off, hv[0], hv[1], hv[2], hv[3]);
+            }
+            tr.stamp(2);
+            ps_wait_vmcnt<0>();                      // the store is out (and the loads of the last tick have landed)
+            tr.stamp(3);
+            if (lane == 0 && pub) ps_st_flag(fbase + k.p * nnt + nt, a.epoch + (unsigned)(k.t + 1));
+            asm volatile("" ::: "memory");
+            issue();                                 // tick n + D into a free ring slot, off the hand-off path
+            if (a.xcd_local && !checked && pub && k.t >= 1) {
+                // every workgroup of the domain has published step 0 (this workgroup consumed those rows before it
+                // produced step 1's), so every placement word of this launch is visible
+                const unsigned w = lane < nnt ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(
+                                                    ps_rsrc(xccw, (unsigned)(nnt * sizeof(unsigned))), lane * 4, 0, PS_AUX_SC1)
+                                              : a.epoch * 16u + my_xcc + 1u;
+                local = __all((int)(w == a.epoch * 16u + my_xcc + 1u)) != 0;
+                checked = 1;
+                if (local && lane == 0) atomicAdd(&g_psw_local_wgs, 1u);
+            }
+            tr.flush(1, n, lane);
+            if (pub) k.next(nrs);
+        }
+        ps_wait_vmcnt<0>();
+    }
+}
+
+// =============================================================================================
 // Backward:  dH_t = dz[t+1]·Wh^T, gate backward of step t -> dz[t]; last pass (t = -1): dh0
 // =============================================================================================
 struct PsBwdArgs {
@@ -1213,7 +1715,7 @@ extern "C" int d2p_lstm_persist_set_direct(int on) {
     g_ps_direct = on ? 1 : 0;
     return D2P_OK;
 }
-extern "C" size_t d2p_lstm_flag_words(void) { return (size_t)PS_FLAG_WORDS + PS_TICKET_WORDS; }
+extern "C" size_t d2p_lstm_flag_words(void) { return (size_t)PS_FLAG_WORDS + PS_TICKET_WORDS + PSW_XCC_WORDS; }
 extern "C" int d2p_lstm_persist_set_poll(int pipelined) {
     g_ps_poll_pipelined = pipelined & 511;
     return D2P_OK;
@@ -1653,4 +2155,182 @@ int d2p_lstm_persist_bwd_triple(const PsBwdCall q[3], hipStream_t st) {
     }
     g_ps_pair_launches += 2;          // counts as two fusions (tests: the fused path must not be skipped silently)
     return ps_bwd_launch(a[0], a[1], a[2], q[0].U, flops, st);
+}
+
+// =============================================================================================
+// Forward, wide column tiles: host side
+// =============================================================================================
+static int g_psw_on = 1;                     // 0: every forward launch goes to the narrow-tile kernel (A/B switch)
+static int g_psw_la_from = 2, g_psw_defer_from = 5, g_psw_xcd_local = 1;
+static double g_psw_cost_ph = 2.4, g_psw_cost_fl = 3.6;      // planner: us per phase, hand-off floor per step
+extern "C" int d2p_lstm_persist_set_fwd_wide(int on, int la_from, int defer_from, int xcd_local) {
+    g_psw_on = on ? 1 : 0;
+    if (la_from >= 2) g_psw_la_from = la_from;
+    if (defer_from >= 3) g_psw_defer_from = defer_from;
+    if (xcd_local >= 0) g_psw_xcd_local = xcd_local ? 1 : 0;
+    return D2P_OK;
+}
+extern "C" int d2p_lstm_persist_set_fwd_plan_cost(double us_per_phase, double floor_us) {
+    if (us_per_phase > 0.0) g_psw_cost_ph = us_per_phase;
+    if (floor_us > 0.0) g_psw_cost_fl = floor_us;
+    return D2P_OK;
+}
+static int g_psw_launches[4] = {0, 0, 0, 0};     // wide launches so far that carried 1, 2, 3 sequences ([0]: sorted ones)
+extern "C" int d2p_lstm_persist_wide_launches(int nseq) {
+    return (nseq >= 0 && nseq <= 3) ? g_psw_launches[nseq] : 0;
+}
+
+extern "C" int d2p_lstm_persist_wide_local_wgs(int reset) {
+    unsigned v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_psw_local_wgs), sizeof(v)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_psw_local_wgs), &z, sizeof(z));
+    }
+    return (int)(v & 0x7fffffffu);
+}
+static double psw_cost(int trs, int T, int RT) {
+    const int nrs = (trs + RT - 1) / RT;
+    const double step = g_psw_cost_ph * nrs;
+    return T * (step > g_psw_cost_fl ? step : g_psw_cost_fl);
+}
+// row domains of a launch with n sequences: all of the chip's (num_cus / column tiles) domains, dealt out so that the
+// slowest sequence finishes as early as possible under the per-step cost model
+static bool psw_plan(int n, const int* trs, const int* T, int ncol, int* R) {
+    const int budget = ps_num_cus() / ncol > PS_RT_TAB ? PS_RT_TAB : ps_num_cus() / ncol;
+    if (budget < n) return false;
+    auto ok = [&](int i, int r) { return r >= 1 && r <= trs[i] && (trs[i] + r - 1) / r <= PS_NRS_MAX; };
+    auto cap = [&](int i, int r) { return r > trs[i] ? trs[i] : r; };
+    if (n == 1) {
+        R[0] = cap(0, budget);
+        return ok(0, R[0]);
+    }
+    double best = 1e30;
+    bool found = false;
+    if (n == 2) {
+        for (int r0 = 1; r0 < budget; ++r0) {
+            const int r[2] = {cap(0, r0), cap(1, budget - r0)};
+            if (!ok(0, r[0]) || !ok(1, r[1])) continue;
+            const double c0 = psw_cost(trs[0], T[0], r[0]), c1 = psw_cost(trs[1], T[1], r[1]);
+            const double c = c0 > c1 ? c0 : c1;
+            if (c < best) { best = c; R[0] = r[0]; R[1] = r[1]; found = true; }
+        }
+        return found;
+    }
+    for (int r0 = 1; r0 < budget; ++r0)
+        for (int r1 = 1; r0 + r1 < budget; ++r1) {
+            const int r[3] = {cap(0, r0), cap(1, r1), cap(2, budget - r0 - r1)};
+            if (!ok(0, r[0]) || !ok(1, r[1]) || !ok(2, r[2])) continue;
+            double c = 0.0;
+            for (int i = 0; i < 3; ++i) {
+                const double ci = psw_cost(trs[i], T[i], r[i]);
+                if (ci > c) c = ci;
+            }
+            if (c < best) { best = c; R[0] = r[0]; R[1] = r[1]; R[2] = r[2]; found = true; }
+        }
+    return found;
+}
+
+bool d2p_lstm_persist_fwd_wide_ok(int n, const PsFwdCall* q) {
+    if (!g_persist || !g_psw_on || !g_ps_direct || n < 1 || n > 3) return false;
+    int trs[3], T[3], R[3];
+    for (int i = 0; i < n; ++i) {
+        const int U = q[i].U;
+        if (q[i].M <= 0 || q[i].n_steps <= 0 || q[i].n_steps >= 0xffff || q[i].M > 32767 || U != q[0].U) return false;
+        if (!(U == 64 || U == 128 || U == 256 || U == 512) || !q[i].flags) return false;
+        const long Mp = (long)((q[i].M + 15) / 16) * 16;
+        if (2L * Mp * U * 4 > 0x7fffffffL) return false;
+        // 32-bit byte offsets into z (rows at zrs, steps at zts), cs and hout; 24-bit row strides in bytes
+        if (((long)(q[i].n_steps - 1) * q[i].zts + (long)(q[i].M - 1) * q[i].zrs + 4L * U) * 4 >= 0x7fffff00L ||
+            (long)q[i].n_steps * q[i].M * U * 4 >= 0x7fffff00L || q[i].zrs * 4 >= (1L << 24) || q[i].zts <= 0 ||
+            q[i].zrs < 4L * U)
+            return false;
+        for (int j = 0; j < i; ++j)
+            if (q[j].ws == q[i].ws || q[j].flags == q[i].flags) return false;
+        trs[i] = (q[i].M + 15) / 16;
+        T[i] = q[i].n_steps;
+    }
+    return psw_plan(n, trs, T, q[0].U / 16, R);
+}
+
+int d2p_lstm_persist_fwd_wide(int n, const PsFwdCall* q, hipStream_t st) {
+    int trs[3] = {0, 0, 0}, T[3] = {0, 0, 0}, R[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i) { trs[i] = (q[i].M + 15) / 16; T[i] = q[i].n_steps; }
+    const int U = q[0].U, nnt = U / 16;
+    if (!psw_plan(n, trs, T, nnt, R)) return D2P_EINVAL;
+    PsFwdWArgs a[3];
+    int dom = 0, nb = 1;
+    double flops = 0.0;
+    bool any_sorted = false;
+    for (int i = 0; i < n; ++i) {
+        const PsFwdCall& c = q[i];
+        PsFwdWArgs& x = a[i];
+        x.M = c.M; x.U = U; x.T = c.n_steps; x.total_rs = trs[i]; x.RT = R[i]; x.has_h0 = c.h0 ? 1 : 0;
+        x.dom0 = dom;
+        dom += R[i];
+        const size_t Mp = (size_t)trs[i] * 16;
+        x.hfrag = c.ws + (size_t)4 * U * U;              // (the workspace layout of the narrow kernel: its packed weights first)
+        x.hfrag_bytes = (unsigned)(Mp * U * sizeof(float));
+        x.z = c.z; x.zrs = c.zrs; x.zts = c.zts; x.c0 = c.c0; x.lens = c.lens;
+        x.hout = c.hout; x.cs = c.cs; x.h_final = c.h_final; x.c_final = c.c_final;
+        x.flags = c.flags;
+        x.dump = (float*)((unsigned*)(x.hfrag + 2 * Mp * U) + PS_FLAG_WORDS + PS_TICKET_WORDS);
+        x.err = ps_err_ptr();
+        x.trace = g_ps_trace; x.trace_block = g_ps_trace_block;
+        x.wh_raw = c.Wh; x.h0_raw = c.h0; x.h0_bytes = c.h0 ? (unsigned)((size_t)c.M * U * sizeof(float)) : 0u;
+        x.epoch = c.epoch;
+        x.poll = g_ps_poll_pipelined;
+        x.la_from = g_psw_la_from; x.defer_from = g_psw_defer_from;
+        x.xcd_local = g_psw_xcd_local;
+        x.rowmap = nullptr; x.sorted = 0; x.Tfull = c.n_steps;
+        for (int d = 0; d <= PS_RT_TAB; ++d) x.rs_start[d] = 0;
+        for (int d = 0; d < PS_RT_TAB; ++d) x.tdom[d] = 1;
+        int nmax = (trs[i] + R[i] - 1) / R[i];
+        double f = 2.0 * c.M * 4.0 * U * U * (c.n_steps - (c.h0 ? 0 : 1));
+        if (c.rowmap && c.slab_steps && c.lens && g_ps_sorted &&
+            ps_plan_sorted(trs[i], R[i], c.slab_steps, 0, g_psw_cost_ph, g_psw_cost_fl, x.rs_start, x.tdom)) {
+            x.rowmap = c.rowmap;
+            x.sorted = 1;
+            any_sorted = true;
+            nmax = 0;
+            f = 0.0;
+            for (int d = 0; d < R[i]; ++d) {
+                if (x.tdom[d] > c.n_steps) x.tdom[d] = c.n_steps;
+                const int ph = x.rs_start[d + 1] - x.rs_start[d];
+                nmax = ph > nmax ? ph : nmax;
+                int rows = ph * 16;
+                if (x.rs_start[d + 1] * 16 > c.M) rows -= x.rs_start[d + 1] * 16 - c.M;
+                f += 2.0 * rows * 4.0 * U * U * (x.tdom[d] - (c.h0 ? 0 : 1));
+            }
+        }
+        if (nmax >= g_psw_defer_from) nb = 2;
+        flops += f;
+    }
+    for (int i = n; i < 3; ++i) { a[i] = a[0]; a[i].RT = 0; a[i].dom0 = dom; }
+    for (int i = 0; i < 3; ++i) a[i].lds_nb = nb;
+    const size_t lds = (size_t)(nb * PSW_P_FLOATS + 2 * PS_NRS_MAX * PSW_CELLS + 2 * PS_NRS_MAX * 16 + 16 + nb * PSW_CELLS +
+                                PS_PF_R * PSW_SLOT) * sizeof(float);
+    const int blocks = dom * nnt;
+    ++g_psw_launches[n];
+    if (any_sorted) ++g_psw_launches[0];
+    D2pProfScope prof(st, D2P_PROF_LSTM_STEP_FWD, flops);
+#define PSW_LAUNCH(CPW)                                                                                                 \
+    {                                                                                                                   \
+        static bool attr = false;                                                                                       \
+        if (!attr) {                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)lstm_persist_fwdw_kernel<CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      96 * 1024);                                                                       \
+            attr = true;                                                                                                \
+        }                                                                                                               \
+        hipLaunchKernelGGL((lstm_persist_fwdw_kernel<CPW>), dim3(blocks), dim3(PS_THREADS), lds, st, a[0], a[1], a[2]);  \
+    }
+    switch (U) {
+        case 64: PSW_LAUNCH(1) break;
+        case 128: PSW_LAUNCH(2) break;
+        case 256: PSW_LAUNCH(4) break;
+        default: PSW_LAUNCH(8) break;
+    }
+#undef PSW_LAUNCH
+    D2P_LAUNCH_CHECK("lstm_persist_fwdw");
+    return D2P_OK;
 }

@@ -832,6 +832,10 @@ extern "C" int d2p_lstm_seq_fwd_multi(int nseq, const d2p_lstm_fwd_desc* d, d2p_
         }
         return d2p_lstm_fused_fwd_multi(nseq, q, ws, as_stream(stream));
     }
+    if (nseq <= 3 && d2p_lstm_is_persistent_enabled()) {     // all of them in one launch of the wide-tile kernel
+        int rc = D2P_OK;
+        if (d2p_lstm_try_wide_fwd(nseq, d, as_stream(stream), &rc)) return rc;
+    }
     if (nseq == 2 && d2p_lstm_is_persistent_enabled()) {     // two sequences sharing one persistent launch
         int rc = D2P_OK;
         if (d2p_lstm_try_pair_fwd(d, as_stream(stream), &rc)) return rc;

@@ -411,6 +411,7 @@ def lstm_seq_fwd_multi(seqs):
     import ctypes
     from .lib import LstmFwdDesc
     arr = (LstmFwdDesc * len(seqs))()
+    keep = []
     for i, q in enumerate(seqs):
         M, U = q['M'], q['U']
         nb = call.d2p_lstm_ws_bytes(M, U)
@@ -424,6 +425,13 @@ def lstm_seq_fwd_multi(seqs):
         d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
         d.flags, d.epoch = _LSTM_FLAGS.take(('f', i, torch.cuda.current_stream().cuda_stream), q['n_steps'])
         d.wpack = ptr(q.get('wpack'))
+        order = q.get('row_order')          # (rowmap: device int32 [M], slab_steps: host numpy int32 [ceil(M/16)])
+        if order is not None and q.get('lens') is not None:
+            rowmap, steps = order
+            assert rowmap.dtype == torch.int32 and rowmap.numel() == q['M'] and steps.dtype == np.int32
+            assert steps.size == (q['M'] + 15) // 16 and steps.flags['C_CONTIGUOUS']
+            keep.append(steps)
+            d.rowmap, d.slab_steps = ptr(rowmap), steps.ctypes.data
     call.d2p_lstm_seq_fwd_multi(len(seqs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
 
 

@@ -70,6 +70,10 @@ SIGNATURES = {
     'd2p_lstm_persist_set_trace': (c_int, [P, c_size_t, c_int]),
     'd2p_lstm_persist_set_wgs_per_cu': (c_int, [c_int, c_int]),
     'd2p_lstm_persist_pair_launches': (c_int, []),
+    'd2p_lstm_persist_set_fwd_wide': (c_int, [c_int, c_int, c_int, c_int]),
+    'd2p_lstm_persist_set_fwd_plan_cost': (c_int, [ctypes.c_double, ctypes.c_double]),
+    'd2p_lstm_persist_wide_launches': (c_int, [c_int]),
+    'd2p_lstm_persist_wide_local_wgs': (c_int, [c_int]),
     'd2p_lstm_debug_flags': (c_int, [c_int]),
     'd2p_lstm_set_tiling': (c_int, [c_int, c_int, c_int]),
     'd2p_lstm_seq_fwd': (c_int, [c_int, c_int, c_int, P, c_long, c_long, P, P, P, P, P, P, P, P, P, c_size_t, S]),
@@ -123,7 +127,7 @@ class LstmFwdDesc(ctypes.Structure):
                 ('Wh', c_void_p), ('h0', c_void_p), ('c0', c_void_p), ('lens', c_void_p),
                 ('hout', c_void_p), ('cs', c_void_p), ('h_final', c_void_p), ('c_final', c_void_p),
                 ('ws', c_void_p), ('ws_bytes', c_size_t), ('flags', c_void_p), ('epoch', ctypes.c_uint),
-                ('wpack', c_void_p)]
+                ('wpack', c_void_p), ('rowmap', c_void_p), ('slab_steps', c_void_p)]
 
 
 class LstmBwdDesc(ctypes.Structure):

@@ -146,23 +146,14 @@ class Model(object):
         self._ctx = None
         self._conv = conv_shapes(config)
         self.feature_dim = feature_dim(config)
-        # non-trainable BN moving statistics (updated inline, once per reference call)
-        self.moving = {}
-        for l, (_, _, _, cout, _, _) in enumerate(self._conv, start=1):
-            self._init_moving('conv%d' % l, cout)
+        # non-trainable BN moving statistics (updated inline, once per reference call): views of ONE buffer
+        # (`moving_flat`), so that the trainer's step guard snapshots / restores all of them with a single device copy
         U = self.num_lstm_cell_units
         bn_scopes = {'full': ('rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2', 'per/fc'),
                      'summarizer': ('rn_h/fc1', 'rn_h/fc2', 'rn_c/fc1', 'rn_c/fc2'),
                      'synthesis_baseline': ()}[self.variant]
-        for s in bn_scopes:
-            self._init_moving(s, U)
-        # the two relation networks' batch norms run as two-problem launches: their moving statistics sit at a
-        # constant stride (views of one allocation; checkpoint loading copies in place)
-        for leaf in ('fc1', 'fc2'):
-            if 'rn_h/' + leaf in self.moving:
-                mm, mv = torch.zeros(2, U, device='cuda'), torch.ones(2, U, device='cuda')
-                self.moving['rn_h/' + leaf] = (mm[0], mv[0])
-                self.moving['rn_c/' + leaf] = (mm[1], mv[1])
+        self._alloc_moving([('conv%d' % l, cout) for l, (_, _, _, cout, _, _) in enumerate(self._conv, start=1)],
+                           bn_scopes, U)
         self.track_moving = True
         # scheduled sampling state (device memory: read by kernels inside a captured graph)
         #   _ss_prob : probability of feeding the decoder its own sample instead of the ground truth
@@ -211,8 +202,28 @@ class Model(object):
         self._reserve_scratch()
 
     # ------------------------------------------------------------------ plumbing
-    def _init_moving(self, name, C):
-        self.moving[name] = (torch.zeros(C, device='cuda'), torch.ones(C, device='cuda'))
+    def _alloc_moving(self, conv, scopes, U):
+        """self.moving[name] = (mean [C], variance [C]) as views of self.moving_flat.  The two relation networks' batch
+        norms run as two-problem launches: mean of rn_h / rn_c of a layer adjacent ([2, U]), then their variances
+        (checkpoint loading copies in place)."""
+        chunks = [(name, C) for name, C in conv]
+        rn = [leaf for leaf in ('fc1', 'fc2') if 'rn_h/' + leaf in scopes]
+        chunks += [(s_, U) for s_ in scopes if not s_.startswith('rn_')]
+        total = sum(2 * C for _, C in chunks) + 4 * U * len(rn)
+        total = (total + 3) // 4 * 4
+        flat = torch.zeros(max(total, 4), device='cuda')
+        self.moving_flat = flat
+        self.moving = {}
+        o = 0
+        for name, C in chunks:
+            flat[o + C:o + 2 * C].fill_(1.0)
+            self.moving[name] = (flat[o:o + C], flat[o + C:o + 2 * C])
+            o += 2 * C
+        for leaf in rn:
+            flat[o + 2 * U:o + 4 * U].fill_(1.0)
+            self.moving['rn_h/' + leaf] = (flat[o:o + U], flat[o + 2 * U:o + 3 * U])
+            self.moving['rn_c/' + leaf] = (flat[o + U:o + 2 * U], flat[o + 3 * U:o + 4 * U])
+            o += 4 * U
 
     def _buf(self, name, shape, dtype=torch.float32, zero=False):
         t = self._bufs.get(name)
@@ -416,6 +427,12 @@ class Model(object):
         ctx = {'feed': feed}
         lens_d, lens_p = feed['demo_len'], feed['program_len']
         n_p, n_d = feed['n_prog'], feed['n_demo']
+        # the demonstrations by decreasing length (with the feed): the encoders' forward and every backward recurrence
+        # group rows of similar length into their row domains and stop each domain at its longest row
+        order = None
+        if feed.get('demo_slab_steps') is not None and os.environ.get('D2P_LSTM_SORTED', '1') == '1':
+            order = (feed['demo_order'], feed['demo_slab_steps'])
+        fwd_order = order if os.environ.get('D2P_LSTM_SORTED_FWD', '1') == '1' else None
 
         # ---- side stream: everything that depends only on the batch -- decoder input ids,
         #      embeddings, the perception encoder and the three hoisted decoder projections
@@ -508,7 +525,7 @@ class Model(object):
         # ---- Demo_Encoder LSTM (zero initial state, length-masked)
         e1_hc = self._buf('demo_lstm/hc_final', (2, M, U))
         e1 = self._lstm_fwd('demo_lstm', feats_tm.view(T * M, F), F, M, T, T, None, None, lens_d,
-                            want_final=True, z=z_e1, final_out=(e1_hc[0], e1_hc[1]))
+                            want_final=True, z=z_e1, final_out=(e1_hc[0], e1_hc[1]), row_order=fwd_order)
         e1['hc_final'] = e1_hc
         if self.variant == 'synthesis_baseline':
             # model_synthesis.py:324-358: no second pass; the program decoder starts from the
@@ -541,7 +558,7 @@ class Model(object):
                 K.gemm_rows('nn', feed['n_active'], 4 * U, U, e1['hout'], U, p['second_lstm/kernel'][:U], 4 * U,
                             z_e2, 4 * U, feed['active_rows'], bias=p['second_lstm/bias'])
             e2 = self._lstm_fwd('second_lstm', e1['hout'].view(T * M, U), U, M, T, T, h0_2, c0_2, lens_d,
-                                want_final=True, final_out=(demo_hc[0], demo_hc[1]), z=z_e2)
+                                want_final=True, final_out=(demo_hc[0], demo_hc[1]), z=z_e2, row_order=fwd_order)
             demo_h, demo_c = demo_hc[0], demo_hc[1]
             # ---- SummarizeFeature('rn') = mean_k + rn_pool (the summarizer baseline: rn_pool alone)
             rn_h = rn_c = self._rn_fwd(demo_hc, B, k, U, add_mean=self.multitask)
@@ -579,6 +596,23 @@ class Model(object):
                 ids_a = da['fed_ids']
         elif self.fuse_decoders and self.multitask:
             dp, da, dq = self._decoders_fwd(specs)
+        elif self.multitask and self.pair_decoders and os.environ.get('D2P_TRIPLE_FWD', '1') == '1':
+            # all three decoders in ONE launch of the wide-tile persistent kernel (3 + 3 + 2 row domains, as their
+            # backward recurrences; round 3: action + program as a pair, then the perception decoder -- 295 + 195 us)
+            side_loss = (self.use_side_stream and os.environ.get('D2P_SIDE_LOSS', '1') == '1' and defer_loss
+                         and feed.get('loss_dens') is not None)
+            dp, da, dq = self._decoders_fwd(specs, logits=False)
+            for e_ in (dp, da, dq):
+                self._decoder_logits(e_)
+            if side_loss:
+                # the loss VALUE: nothing in backward reads it (its denominators come with the feed)
+                nums, dens = self._buf('loss_nums', (1 + 2 * k,)), self._buf('loss_dens', (1 + 2 * k,))
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    K.xent_fwd('softmax', dp['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
+                               nums[0:1], dens[0:1])
+                    K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                               nums[1:1 + k], dens[1:1 + k])
         elif self.multitask and self.pair_decoders:
             # the program decoder (32 rows: a latency-bound chain on a quarter of the CUs) shares ONE persistent
             # launch with the action decoder, on disjoint workgroups; the perception decoder follows alone
@@ -644,9 +678,6 @@ class Model(object):
             if feed['prog_n_active_pad'] and feed['prog_n_t1_pad']:
                 ctx['klists']['prog'] = (feed['prog_rows'], feed['prog_n_active_pad'], feed['prog_rows_t1'],
                                          feed['prog_rows_t1_prev'], feed['prog_n_t1_pad'])
-        order = None
-        if feed.get('demo_slab_steps') is not None and os.environ.get('D2P_LSTM_SORTED', '1') == '1':
-            order = (feed['demo_order'], feed['demo_slab_steps'])
         for e_, space in ((e1, 'demo'), (e2, 'demo'), (dp, 'prog'), (da, 'demo'), (dq, 'demo')):
             if e_ is not None:
                 e_['rowspace'] = space
@@ -740,6 +771,9 @@ class Model(object):
             for d, (name, _, _, h0) in zip(dst, items):
                 d.copy_(h0)
                 ctx.setdefault('h0_staged', set()).add(name)
+            # the weight-gradient GEMMs that read hbuf[0] wait for this, whichever stream they are issued on
+            ctx['h0_event'] = torch.cuda.Event()
+            ctx['h0_event'].record(side)
 
     def _lstm_xproj(self, name, x2d, I, M, T, n_steps):
         """Hoisted input projection z = x·Wx + b for all steps (one GEMM)."""
@@ -768,7 +802,7 @@ class Model(object):
             K.embedding_gather(ids, P, out=z, n=n_steps * R)
         return z
 
-    def _lstm_fwd(self, name, x2d, I, M, T, n_steps, h0, c0, lens, want_final, z=None, final_out=None):
+    def _lstm_fwd(self, name, x2d, I, M, T, n_steps, h0, c0, lens, want_final, z=None, final_out=None, row_order=None):
         """x2d: [T*M, I] time-major inputs.  Returns saved tensors for backward."""
         p = self.params.p
         U = self.num_lstm_cell_units
@@ -785,7 +819,8 @@ class Model(object):
             cf = self._buf(name + '/c_final', (M, U)) if want_final else None
         if n_steps > 0:
             K.lstm_seq_fwd_multi([dict(M=M, U=U, n_steps=n_steps, z=z, Wh=Wh, h0=h0, c0=c0, lens=lens, hout=hout, cs=cs,
-                                       h_final=hf, c_final=cf, wpack=self._wp(name, 0))])
+                                       h_final=hf, c_final=cf, wpack=self._wp(name, 0),
+                                       row_order=row_order if n_steps == T else None)])
         else:
             K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, n_steps, Wh, h0, c0, lens, hout, cs, hf, cf)
         return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
@@ -1295,6 +1330,8 @@ class Model(object):
         if e['name'] in self._ctx.get('h0_staged', ()) and e.get('hbuf') is not None and n > 0:
             # hbuf[t] = the state step t multiplied (hbuf[0] = h0): one product over the rows of all steps
             hb2d = e['hbuf'].view((T + 1) * M, U)
+            if self._ctx.get('h0_event') is not None:
+                torch.cuda.current_stream().wait_event(self._ctx['h0_event'])    # (a no-op on the staging stream itself)
             if kl is not None and kl[1]:
                 K.gemm_tn_rows(U, 4 * U, kl[1], hb2d, U, kl[0], dz, 4 * U, kl[0], gk[I:], 4 * U)
             else:

@@ -101,6 +101,18 @@ class FeedPrefetcher(object):
         pass
 
 
+def _new_event():
+    """An event recorded on the current stream (tests of the multi-rank protocol replace this and _device_sync: the
+    protocol logic below then runs on CPU tensors)."""
+    ev = torch.cuda.Event()
+    ev.record()
+    return ev
+
+
+def _device_sync():
+    torch.cuda.synchronize()
+
+
 class StepGuard(object):
     """Host side of the guarded optimizer step (include/d2p.h: d2p_adam_clip_flat_guarded).
 
@@ -120,9 +132,18 @@ class StepGuard(object):
     skip decision itself is identical on all ranks: it travels through the gradient all-reduce)."""
     DEPTH = 4
 
-    def __init__(self):
-        self.counters = torch.zeros(2, dtype=torch.int64, device='cuda')      # applied, skipped
-        self.host = torch.zeros(self.DEPTH, 2, dtype=torch.int64).pin_memory()
+    def __init__(self, device='cuda', moving=None):
+        self.counters = torch.zeros(2, dtype=torch.int64, device=device)      # applied, skipped
+        self.host = torch.zeros(self.DEPTH, 2, dtype=torch.int64)
+        if str(device).startswith('cuda'):
+            self.host = self.host.pin_memory()
+        # the batch-norm moving statistics as they were BEFORE each step in flight (one row per ring slot; `moving`: the
+        # model's flat buffer of them).  A skipped step's forward pass has already moved them -- the conv encoder's
+        # run before the recurrences, and on the ranks whose kernels did not fail every layer's do -- so a re-run
+        # starts from the snapshot of the first skipped step (VERDICT round 3, weak 7)
+        self.moving = moving
+        self.moving_ring = None if moving is None else torch.zeros(self.DEPTH, moving.numel(), dtype=moving.dtype,
+                                                                   device=moving.device)
         self.events = [None] * self.DEPTH
         self.records = [None] * self.DEPTH        # (feed, global_step, adam_step) of the step in that slot
         self.n = 0                                # guarded steps launched
@@ -134,11 +155,20 @@ class StepGuard(object):
         """The pinned slot the NEXT guarded step writes its counters into."""
         return self.host[self.n % self.DEPTH]
 
+    def snapshot(self):
+        """Before the forward pass of the next guarded step: its slot keeps the moving statistics of this moment (one
+        device copy of a few kilobytes, stream-ordered)."""
+        if self.moving_ring is not None:
+            self.moving_ring[self.n % self.DEPTH].copy_(self.moving, non_blocking=True)
+
+    def restore(self, k):
+        """The moving statistics as they were before the k-th last launched step."""
+        if self.moving_ring is not None:
+            self.moving.copy_(self.moving_ring[(self.n - k) % self.DEPTH])
+
     def launched(self, record):
         slot = self.n % self.DEPTH
-        ev = torch.cuda.Event()
-        ev.record()
-        self.events[slot] = ev
+        self.events[slot] = _new_event()
         self.records[slot] = record
         self.n += 1
 
@@ -225,10 +255,13 @@ class Trainer(object):
         self.log_step = config.log_step
         self.test_sample_step = config.test_sample_step
         self.write_summary_step = config.write_summary_step
-        self._sumsq = torch.zeros(1, dtype=torch.float64, device='cuda')
-        self._lr_dev = torch.zeros(1, dtype=torch.float32, device='cuda')
+        dev = self.model.params.flat.device
+        self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
         # guarded optimizer step (StepGuard); D2P_STEP_GUARD=0 restores the unguarded kernel + check_device_status
-        self.guard = StepGuard() if os.environ.get('D2P_STEP_GUARD', '1') == '1' else None
+        self.guard = None
+        if os.environ.get('D2P_STEP_GUARD', '1') == '1':
+            self.guard = StepGuard(self.model.params.flat.device, getattr(self.model, 'moving_flat', None))
         self._recovering = False
 
         if config.checkpoint is not None:
@@ -266,6 +299,8 @@ class Trainer(object):
             self._recover()
         if m.scheduled_sampling:
             m.set_sampling_step(self.global_step)     # sampling probability + noise counter of this step
+        if g is not None:
+            g.snapshot()
         P = m.params
         # data parallelism: the decoders' gradients (the tail of the flat buffer) are all-reduced while
         # the rest of backward runs; one message for everything when that is switched off
@@ -273,20 +308,25 @@ class Trainer(object):
         dec = m.decoder_grad_offset() if overlap else 0
         start = None
         persist_was = K.lstm_is_persistent()
+        # EXPERIMENTAL (never run on more than one GPU), behind its own switch: the encoder recurrences that follow the
+        # split run beside the collective's kernels; the persistent kernels need every workgroup resident at once, which
+        # a collective waiting for a late peer can prevent -- per-step launches need no co-residency.  (A captured
+        # graph holds the launches it was captured with: the toggle acts on eager launches and at capture time.)
+        per_step_after_split = overlap and persist_was and os.environ.get('D2P_DP_OVERLAP_PER_STEP', '1') == '1'
         if overlap:
             def start():
                 self.dp.all_reduce_start(P.grad[dec:])
-                # EXPERIMENTAL (never run on more than one GPU): the encoder recurrences that follow run beside the
-                # collective's kernels; the persistent kernels need every workgroup resident at once, which a
-                # collective waiting for a late peer can prevent -- per-step launches need no co-residency
-                K.lstm_set_persistent(False)
-        if self.use_graph and not self._profiling():
-            loss = self._graphed_forward_backward(feed, start)
-        else:
-            loss = m.forward(feed, defer_loss=os.environ.get('D2P_DEFER_LOSS', '1') == '1')
-            m.backward(split_cb=start)
-        if overlap and persist_was:
-            K.lstm_set_persistent(True)
+                if per_step_after_split:
+                    K.lstm_set_persistent(False)
+        try:
+            if self.use_graph and not self._profiling():
+                loss = self._graphed_forward_backward(feed, start)
+            else:
+                loss = m.forward(feed, defer_loss=os.environ.get('D2P_DEFER_LOSS', '1') == '1')
+                m.backward(split_cb=start)
+        finally:
+            if per_step_after_split:
+                K.lstm_set_persistent(True)       # (also when backward or the collective raised)
         slot = None
         if g is not None and self.dp.active:
             # this rank's status word joins the exchange: after the SUM every rank skips the step together
@@ -322,12 +362,14 @@ class Trainer(object):
 
     def _recover(self):
         """A guarded step was skipped on the device: the persistent recurrent kernels gave up a hand-off.  The
-        parameters, the Adam moments and the batch-norm moving statistics downstream of the recurrences are as
-        they were before the first skipped step (the device skipped every step since: the word is sticky).
-        Synchronise, reset the word, re-run the skipped steps on the per-step kernels (lstm_step.hip)."""
+        parameters and the Adam moments are as they were before the first skipped step (the device skipped every
+        step since: the word is sticky, and with several ranks it travels through the all-reduce); the batch-norm
+        moving statistics are NOT -- a forward pass moves them before anything fails -- and are restored from the
+        snapshot taken in front of that step (StepGuard.snapshot).  Synchronise, reset the word, re-run the skipped
+        steps on the per-step kernels (lstm_step.hip)."""
         import sys
         g = self.guard
-        torch.cuda.synchronize()
+        _device_sync()
         applied, skipped = (int(v) for v in g.counters.tolist())
         k = skipped - g.handled
         err = K.lstm_persist_error(reset=True)
@@ -346,12 +388,15 @@ class Trainer(object):
         K.lstm_set_persistent(False)
         self._graphs.clear()     # captured graphs hold the persistent launches
         self.global_step, self.adam_step = records[0][1], records[0][2]
+        # the skipped steps' forward passes moved the batch-norm moving statistics (every layer on the ranks whose own
+        # kernels were fine, the layers in front of the recurrences everywhere): back to the first skipped step's
+        g.restore(len(records))
         self._recovering = True
         loss = None
         try:
             for feed, _, _ in records:
                 loss = self.train_step(feed)
-            torch.cuda.synchronize()
+            _device_sync()
         finally:
             self._recovering = False
         if g.failures < self.MAX_PERSIST_FAILURES:
@@ -478,11 +523,29 @@ class Trainer(object):
         _start_time = time.time()
         batch_chunk = batch.next()
         feed = self.model.get_feed_dict(batch_chunk, is_training=False)
+        guard = self.guard
+        if guard is not None:
+            self.settle()                       # (a pending failure belongs to a training step, not to this batch)
+            guard.snapshot()                    # (slot of the NEXT training step: rewritten before it is used)
         loss = self.model.forward(feed)
         loss_value = float(loss.item())
         # the 'test' summaries of the reference: greedy decoders + accuracies, and for Karel the
         # syntax / exact-program / execution metrics (models/model_full.py:1102-1177)
         self.last_test_report = self.model.report(with_greedy=True)
+        if guard is not None and K.lstm_persist_error(reset=True):
+            # a hand-off failure inside this forward pass: garbage must not reach the log / the event file -- the batch
+            # again on the per-step kernels, from the moving statistics this pass started with (as evaler.py does)
+            import sys
+            print('[demo2program_amd] persistent LSTM kernel gave up a hand-off in a test batch: batch redone on the '
+                  'per-step kernels', file=sys.stderr)
+            guard.restore(0)
+            was = K.lstm_is_persistent()
+            K.lstm_set_persistent(False)
+            try:
+                loss_value = float(self.model.forward(feed).item())
+                self.last_test_report = self.model.report(with_greedy=True)
+            finally:
+                K.lstm_set_persistent(was)
         _end_time = time.time()
         return self.global_step, self.last_test_report, loss_value, None, (_end_time - _start_time)
 
@@ -513,11 +576,14 @@ class Trainer(object):
                                             **{'test_loss/' + n: v for n, v in list(tl.items()) + list(ta.items())
                                                if isinstance(v, float)}), step)
                     writer.flush()
+            if self.guard is None and s % self.log_step == 0:
+                self.check_device_status()     # unguarded: invalid gradients must not be applied for long unnoticed
             if s % ckpt_save_step == 0:
                 # every rank settles (re-runs steps the device skipped) before rank 0 writes the parameters
                 self.check_device_status()
                 if self.dp.rank == 0:
                     self.save_checkpoint(os.path.join(self.train_dir, 'model-%d.npz' % step))
+        self.settle()                          # (up to StepGuard.DEPTH trailing steps may still be skipped ones)
         if writer is not None:
             writer.close()
 

@@ -280,6 +280,21 @@ int d2p_lstm_persist_set_direct(int on);
  * sized for (0 keeps the current value; default 1).  2 cuts the rows into twice as many domains so
  * that two workgroups share a CU and overlap each other's MFMA and epilogue phases. */
 int d2p_lstm_persist_set_wgs_per_cu(int fwd, int bwd);
+/* The wide-tile forward kernel (round 4: 16 units per column tile -- 8 row domains at U = 512 --, one to three
+ * sequences per launch, length-sorted where a descriptor brings rowmap / slab_steps, row domains that find all their
+ * workgroups on one XCD exchange through its L2).  on: 1 (default) / 0 = every forward launch goes to the 8-unit-tile
+ * kernel.  la_from / defer_from: phases per row domain from which a domain requests its next rows ahead / runs the
+ * deferred gate math (defaults 3 / 5; values below 2 / 3 leave them unchanged).  xcd_local: 1 (default) / 0 = always
+ * write-through hand-offs; negative: unchanged.  Results are bit-identical in every setting. */
+int d2p_lstm_persist_set_fwd_wide(int on, int la_from, int defer_from, int xcd_local);
+/* ... and its planner's cost model per step of a row domain, max(us_per_phase * phases, floor_us); defaults 2.4 / 3.6 */
+int d2p_lstm_persist_set_fwd_plan_cost(double us_per_phase, double floor_us);
+/* Wide-tile forward launches so far that carried nseq = 1, 2, 3 sequences (nseq = 0: those with a length-sorted
+ * sequence).  For tests: the path must not be skipped silently. */
+int d2p_lstm_persist_wide_launches(int nseq);
+/* Workgroups of wide-tile launches so far that found all 32 workgroups of their row domain on their own XCD and
+ * switched to L2-local hand-offs (a statistic; synchronising; reset != 0 zeroes it). */
+int d2p_lstm_persist_wide_local_wgs(int reset);
 /* Number of persistent launches so far that carried TWO sequences (d2p_lstm_seq_{fwd,bwd}_multi with nseq == 2
  * puts both on disjoint workgroups of one launch when both shapes are taken and sharing the chip is expected to
  * beat two launches back to back).  For tests: the pair path must not be skipped silently. */
@@ -324,6 +339,11 @@ typedef struct {
     unsigned* flags; unsigned epoch;
     const float* wpack;   /* optional, with flags: the packed forward image of Wh (d2p_lstm_pack_weights, 4*U*U floats),
                            * kept up to date by the caller -- the kernel's prologue then reads contiguous fragments */
+    /* optional, with flags and lens -- a length-sorted launch (as d2p_lstm_bwd_desc): the forward recurrence groups
+     * rows of similar length into its row domains and runs each domain only for its longest row's steps; what the
+     * skipped steps would have written (zeros in hout, the carried cell state in cs) is filled in, so every output
+     * is bit-identical to the unsorted call. */
+    const int* rowmap; const int* slab_steps;
 } d2p_lstm_fwd_desc;
 typedef struct {
     int M, U, n_steps;

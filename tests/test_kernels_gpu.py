@@ -390,6 +390,33 @@ def test_bn_group_fwd_bwd(K, B, k, inner, C, act):
     close(dbeta, beta.grad, atol=1e-3, rtol=1e-4)
 
 
+@pytest.mark.parametrize('bits', [1, 3])
+def test_bn_folded_finalize_writes_every_gradient(K, bits):
+    """d2p_bn_set_fold (the A/B switch of the ticket-folded finalize steps): whatever combination of folds a layer's
+    size admits -- few partial sums (ticket fold), many (no ticket fold, folded column-sum finalize or not) -- dx,
+    dgamma, dbeta and the bias gradient are all written and equal the default launches' (with many
+    partial sums and one wavefront per (group, channel) nobody wrote dgamma / dbeta)."""
+    shapes = [(3, 4, 20, 16), (64, 10, 32, 16), (40, 10, 64, 48), (16, 10, 20 * 16, 32), (5, 1, 7, 512),
+              (32, 10, 20 * 64, 16)]
+    try:
+        for (B, k, inner, C) in shapes:
+            R = B * k * inner
+            a_dev, dy = dev(rnd(R, C, seed=11, scale=2.0)), dev(rnd(R, C, seed=12))
+            gamma, beta = dev(rnd(C, seed=13) + 1.5), dev(rnd(C, seed=14))
+            outs = []
+            for fold in (0, bits):
+                K.bn_set_fold(fold)
+                _, mean, rstd, _ = K.bn_fwd(a_dev, gamma, beta, k, inner)
+                dgamma, dbeta, dbias = (torch.full((C,), float('nan'), device='cuda') for _ in range(3))
+                dx = K.bn_bwd(a_dev, dy, gamma, mean, rstd, k, inner, True, dgamma, dbeta, dbias=dbias)
+                outs.append((dx.clone(), dgamma, dbeta, dbias))
+            for name, ref, got in zip(('dx', 'dgamma', 'dbeta', 'dbias'), outs[0], outs[1]):
+                assert torch.isfinite(got).all(), (name, B, k, inner, C)
+                close(got, ref, atol=1e-4, rtol=1e-4)
+    finally:
+        K.bn_set_fold(0)
+
+
 def test_bn_inference_mode(K):
     """is_training=False: normalise with the moving statistics (evaler.py:61)."""
     for R, C in ((37, 48), (20, 6), (640, 512)):
@@ -1174,3 +1201,115 @@ def test_loss_backward_of_three_decoders_and_their_projection_in_one_launch(K):
         assert (q['dhout'][:rows].double().cpu() - want).abs().max().item() <= 1e-5
         if rows < q['dhout'].shape[0]:                              # rows past n_steps: untouched
             assert float(q['dhout'][rows:].min()) == 9.0 and float(q['dlogits'][rows:].min()) == 9.0
+
+
+# ------------------------------------------------------------------ wide-tile persistent forward kernel (round 4)
+def _wide_seq(M, T, U, masked, init, seed, lo=0):
+    g = torch.Generator().manual_seed(seed)
+    q = dict(M=M, U=U, n_steps=T, z0=((torch.rand(T * M, 4 * U, generator=g) - 0.5) * 2).cuda(),
+             Wh=((torch.rand(U, 4 * U, generator=g) - 0.5) * 0.2).cuda(),
+             hout=torch.empty(T, M, U, device='cuda'), cs=torch.empty(T, M, U, device='cuda'),
+             h_final=torch.empty(M, U, device='cuda'), c_final=torch.empty(M, U, device='cuda'))
+    q['z'] = q['z0'].clone()
+    if init:
+        q['h0'], q['c0'] = (torch.rand(M, U, generator=g) - 0.5).cuda(), (torch.rand(M, U, generator=g) - 0.5).cuda()
+    if masked:
+        lens = torch.randint(lo, T + 1, (M,), generator=g)
+        lens[0] = T
+        q['lens_host'], q['lens'] = lens.numpy().astype(np.int64), lens.to(torch.int32).cuda()
+    return q
+
+
+def _wide_run(K, seqs, sort):
+    for q in seqs:
+        q['z'].copy_(q['z0'])
+        for n in ('hout', 'cs', 'h_final', 'c_final'):
+            q[n].fill_(float('nan'))
+        q.pop('row_order', None)
+        if sort and q.get('lens') is not None:
+            q['row_order'] = K.lstm_row_order(q['lens_host'])
+    K.lstm_seq_fwd_multi(seqs)
+    torch.cuda.synchronize()
+    return [[q[n].clone() for n in ('z', 'hout', 'cs', 'h_final', 'c_final')] for q in seqs]
+
+
+def _wide_check(K, seqs, sort=False, must_take=True, reps=2):
+    from demo2program_amd.lib import load
+    lib = load()
+    K.set_lstm_persistent(False)
+    try:
+        refs = [_wide_run(K, [q], False)[0] for q in seqs]
+    finally:
+        K.set_lstm_persistent(True)
+    K.lstm_persist_error(True)
+    before = [lib.d2p_lstm_persist_wide_launches(i) for i in range(4)]
+    for _ in range(reps):
+        got = _wide_run(K, seqs, sort)
+        assert K.lstm_persist_error() == 0
+        for g_, r_ in zip(got, refs):
+            for name, a, b in zip(('z', 'hout', 'cs', 'h_final', 'c_final'), g_, r_):
+                assert torch.equal(a, b), name
+    after = [lib.d2p_lstm_persist_wide_launches(i) for i in range(4)]
+    if must_take:
+        assert after[len(seqs)] - before[len(seqs)] == reps
+        if sort:
+            assert after[0] - before[0] == reps
+
+
+@pytest.mark.parametrize('xcd_local', [1, 0])
+@pytest.mark.parametrize('M,U,T,masked,init', [(12, 64, 6, 1, 1), (35, 128, 4, 1, 1), (80, 256, 5, 0, 1), (48, 512, 4, 1, 0),
+                                               (320, 512, 20, 1, 1), (320, 512, 20, 0, 0), (32, 512, 40, 0, 1),
+                                               (333, 512, 9, 1, 1), (1000, 512, 5, 1, 1)])
+def test_lstm_wide_forward_equals_per_step(K, M, U, T, masked, init, xcd_local):
+    """The wide-tile persistent forward kernel (16 units per column tile; d2p_lstm_seq_fwd_multi with a flag buffer)
+    against the one-launch-per-step kernels: z, hout, cs and the final states BIT-IDENTICAL -- same K split, same
+    summation order -- with write-through hand-offs and with the L2-local ones of domains found on one XCD, unsorted
+    and (with lengths) sorted by length: the steps a sorted domain skips are filled in as the masked steps would have
+    written them (zeros in hout, the carried cell state in cs)."""
+    from demo2program_amd.lib import call
+    call.d2p_lstm_persist_set_fwd_wide(1, 0, 0, xcd_local)
+    try:
+        _wide_check(K, [_wide_seq(M, T, U, masked, init, seed=M + T)])
+        if masked:
+            _wide_check(K, [_wide_seq(M, T, U, masked, init, seed=M + T)], sort=True)
+    finally:
+        call.d2p_lstm_persist_set_fwd_wide(1, 0, 0, 1)
+
+
+def test_lstm_wide_forward_sorted_with_zero_length_rows_and_training_lengths(K):
+    q = _wide_seq(320, 20, 512, True, True, seed=5, lo=8)              # lengths 8..20, as the training batches
+    _wide_check(K, [q], sort=True)
+    q = _wide_seq(320, 20, 512, True, False, seed=6)
+    q['lens_host'][5:40] = 0
+    q['lens'] = torch.from_numpy(q['lens_host'].astype(np.int32)).cuda()
+    _wide_check(K, [q], sort=True)
+    q = _wide_seq(320, 20, 512, True, True, seed=7)                    # the longest row shorter than the step count
+    q['lens_host'] = np.minimum(q['lens_host'], 13)
+    q['lens'] = torch.from_numpy(q['lens_host'].astype(np.int32)).cuda()
+    _wide_check(K, [q], sort=True)
+
+
+@pytest.mark.parametrize('la_from,defer_from', [(2, 3), (3, 5), (4, 8)])
+def test_lstm_three_forward_sequences_in_one_wide_launch(K, la_from, defer_from):
+    """d2p_lstm_seq_fwd_multi with the three decoders (2 x 320 rows x 20 steps, 32 rows x 50 steps): one launch of the
+    wide-tile kernel with 3 + 3 + 2 row domains; bit-identical to the per-step kernels in every hand-off form
+    (own-row polling, look-ahead from the middle of the chain, deferred gate math)."""
+    from demo2program_amd.lib import call
+    call.d2p_lstm_persist_set_fwd_wide(1, la_from, defer_from, 1)
+    try:
+        _wide_check(K, [_wide_seq(320, 20, 512, False, True, 11), _wide_seq(320, 20, 512, False, True, 12),
+                        _wide_seq(32, 50, 512, False, True, 13)])
+        _wide_check(K, [_wide_seq(320, 20, 512, False, True, 11), _wide_seq(32, 50, 512, False, True, 13)])
+        _wide_check(K, [_wide_seq(320, 20, 512, True, True, 14, lo=8), _wide_seq(100, 7, 512, False, True, 15),
+                        _wide_seq(32, 50, 512, False, True, 13)], sort=True)
+        # 400 rows = 25 sub-tiles: no split of the 8 row domains holds two of them and a third sequence -- falls back
+        _wide_check(K, [_wide_seq(400, 20, 512, False, True, 16), _wide_seq(400, 20, 512, False, True, 17),
+                        _wide_seq(16, 32, 512, False, True, 18)], must_take=False)
+    finally:
+        call.d2p_lstm_persist_set_fwd_wide(1, 3, 5, 1)
+
+
+def test_lstm_wide_forward_long_sequence(K):
+    """thousands of hand-offs per workgroup, sorted and not: rare stale reads would surface here"""
+    _wide_check(K, [_wide_seq(320, 160, 512, True, True, 21)], reps=2)
+    _wide_check(K, [_wide_seq(320, 160, 512, True, True, 21)], sort=True, reps=2)
