@@ -161,9 +161,15 @@ __device__ __forceinline__ unsigned ps_ld_flag_buf(__amdgpu_buffer_rsrc_t r, int
     asm volatile("" ::: "memory");          // a new read every time: never merged with the previous one
     return v;
 }
+template <bool REREAD = false>
 __device__ __forceinline__ void ps_wait_flags(const unsigned* f, unsigned need, unsigned fv, unsigned* err,
                                               unsigned code, const unsigned* base, int pipelined) {
     if (__all((int)(fv >= need))) return;
+    if (REREAD) {
+        // `fv` was read a while ago: look again before the first pause (a pause is ~0.5 us)
+        fv = ps_ld_flag(f);
+        if (__all((int)(fv >= need))) return;
+    }
     unsigned spins = 0;
     if (pipelined & 3) {
         const __amdgpu_buffer_rsrc_t r = ps_rsrc(base, (unsigned)((PS_FLAG_WORDS + PS_TICKET_WORDS) * sizeof(unsigned)));
@@ -750,6 +756,7 @@ struct PsFwdWArgs {
     const float* wh_raw; const float* h0_raw; unsigned h0_bytes; unsigned epoch;
     int poll;
     int la_from, defer_from;     // phases per domain from which a domain looks ahead / runs the deferred form
+    int la_q;                    // quarters of a phase's chain in front of the look-ahead request (2 or 3)
     int lds_nb;                  // 2 when some domain of the launch defers (double-buffered partial tiles / staged rows)
     int xcd_local;               // 1: domains found on one XCD exchange through its L2 (0: always write-through)
     // length-sorted launch (as PsBwdArgs)
@@ -856,15 +863,16 @@ __device__ __forceinline__ PsSrc psw_src(const PsFwdWArgs& a, __amdgpu_buffer_rs
 
 // One phase, epilogue right behind its own product.  MODE 0 (single-phase domains): the phase's own rows behind a
 // blocking poll, nothing fetched ahead (the next tick's rows come out of this tick's epilogue).  MODE 1 (look-ahead): the
-// NEXT phase's rows are requested BEHIND this phase's chain -- a whole chain of slack for their hand-off, which even a
-// 2-phase domain's rows (published by the tick before this one) have then mostly used up -- and land during the partial-
-// tile exchange, the barrier and the gate math; their flag was read one tick earlier.
-template <int CPW, int MODE>
+// NEXT phase's rows are requested three quarters into this phase's chain -- their flag is read at the start of the
+// chain and looked at again if it was not up yet (a 2-phase domain's rows were published by the tick before this one:
+// that much slack their hand-off needs) -- and the loads go between the MFMAs of the last quarter (a VMEM issue beside
+// an MFMA costs ~15 clocks, behind the chain ~60); they land during the partial-tile exchange and the gate math.
+template <int CPW, int MODE>     // MODE 3: as 1, with the request in the middle of the chain
 __device__ __forceinline__ void psw_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], const f32x4 (&bv)[CPW][4],
                                          const PsFwdWArgs& a, const PswEpi& e, PsTick k0, const unsigned* fl_cur,
                                          const PsSrc& cur_src, const unsigned* fl1, unsigned need1, const PsSrc& src1,
-                                         const unsigned* fl2, unsigned& fv, int wave, int rs0, int slot, int lane,
-                                         PsTrace& tr) {
+                                         int wave, int rs0, int slot, int lane, PsTrace& tr) {
+    constexpr int C3 = CPW >= 4 ? (MODE == 3 ? CPW / 2 : (3 * CPW) / 4) : CPW;
     tr.stamp(0);
     f32x4 acc[4];
 #pragma unroll
@@ -873,17 +881,27 @@ __device__ __forceinline__ void psw_tick(f32x4 (&cur)[CPW], f32x4 (&nxt)[CPW], c
         ps_wait_flags(fl_cur, ps_need(a.epoch, k0.t), ps_ld_flag(fl_cur), a.err, 3, a.flags, ps_poll_single(a.poll));
 #pragma unroll
         for (int c = 0; c < CPW; ++c) cur[c] = ps_ld_src(cur_src, c);
-    }
-    tr.stamp(1);
-    psw_chain<CPW>(cur, bv, acc);
-    __builtin_amdgcn_sched_barrier(0);
-    tr.stamp(2);
-    if (MODE != 0) {
-        ps_wait_flags(fl1, need1, fv, a.err, 1, a.flags, a.poll);
+        tr.stamp(1);
+        psw_chain<CPW>(cur, bv, acc);
+    } else {
+        const unsigned fvn = ps_ld_flag(fl1);
+        psw_chain<CPW>(cur, bv, acc, 0, C3);
+        __builtin_amdgcn_sched_barrier(0);
+        ps_wait_flags<true>(fl1, need1, fvn, a.err, 1, a.flags, a.poll);
+        tr.stamp(1);
 #pragma unroll
         for (int c = 0; c < CPW; ++c) nxt[c] = ps_ld_src(src1, c);
-        fv = ps_ld_flag(fl2);
+        if (C3 < CPW) {
+            psw_chain<CPW>(cur, bv, acc, C3, CPW);
+#pragma unroll
+            for (int i = 0; i < CPW; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, (16 * (CPW - C3)) / CPW, 0);      // MFMAs
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                            // one operand load
+            }
+        }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    tr.stamp(2);
     psw_write_partials(e.P + wave * 16 * PSW_PLD, lane, acc);
     ps_barrier();           // A: all four partial tiles of this phase are in LDS
     tr.stamp(3);
@@ -977,7 +995,7 @@ __device__ __forceinline__ void psw_mfma_wave(const PsFwdWArgs& a, const PswEpi&
                                 fv, wave, rs0, (m) & 1, lane, tr);                                            \
         else                                                                                                  \
             psw_tick<CPW, MODE>(CUR, NXT, bv, a, e, k0, fl + k0.p * nnt, cur_src, fl + q1.p * nnt, need1, src1, \
-                                fl + q2.p * nnt, fv, wave, rs0, slot, lane, tr);                              \
+                                wave, rs0, slot, lane, tr);                                                   \
         if (wave == 0) tr.flush(0, (m), lane);                                                                \
         kp = k0; k0 = k1; k1 = k2; k2.next(nrs);                                                              \
         slot_prev = slot;                                                                                     \
@@ -1024,15 +1042,18 @@ __device__ __forceinline__ void psw_mfma_wave(const PsFwdWArgs& a, const PswEpi&
 #undef PSW_ONE_TICK
 }
 
+struct PsFwdWLaunch { PsFwdWArgs s[3]; };   // (indexed in the kernel-argument segment: selecting between three by-value
+                                            //  argument blocks costs ~100 scalar selects per field group at kernel entry)
 template <int CPW>   // U = 64 * CPW
-__global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWArgs a0, PsFwdWArgs a1, PsFwdWArgs a2) {
+__global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWLaunch L) {
     constexpr int KC = 4 * CPW;
     const int nnt = KC;                                        // column tiles: U / 16
     // block -> (domain of the launch, column tile): consecutive tiles of a domain on one XCD if block b runs on XCD
     // b % 8 -- with 8 domains of 32 tiles, one whole domain per XCD
     int dom, nt;
     ps_block_tile((int)blockIdx.x, (int)gridDim.x, nnt, dom, nt);
-    const PsFwdWArgs a = (dom >= a0.RT + a1.RT) ? a2 : ((dom >= a0.RT) ? a1 : a0);
+    const int seq = (dom >= L.s[0].RT + L.s[1].RT) ? 2 : ((dom >= L.s[0].RT) ? 1 : 0);
+    const PsFwdWArgs& a = L.s[seq];
     const int rt = dom - a.dom0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int nb = a.lds_nb;
@@ -1113,6 +1134,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWArg
         }
         ps_barrier();                             // (stl rows of the other waves: the operand rows of step 0)
         if (defer) psw_mfma_wave<CPW, 2>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
+        else if (nrs >= a.la_from && a.la_q == 2) psw_mfma_wave<CPW, 3>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
         else if (nrs >= a.la_from) psw_mfma_wave<CPW, 1>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
         else psw_mfma_wave<CPW, 0>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
         for (int q = 0; q < nrs; ++q) {
@@ -1141,16 +1163,21 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWArg
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         ps_barrier();                             // (pairs with the MFMA waves' barrier behind their tables)
-        const float* zsrc = a.z + nt * 16 + q4 * 4;
+        // (through a buffer descriptor: the lane's byte offset (row, quad) in one VGPR, step and gate in the scalar offset
+        //  -- this wave shares a SIMD with an MFMA wave, whose chain pays for every VALU instruction issued here)
+        const __amdgpu_buffer_rsrc_t zres =
+            ps_rsrc(a.z, (unsigned)(((size_t)(a.Tfull - 1) * a.zts + (size_t)(a.M - 1) * a.zrs + 4 * (size_t)U) * sizeof(float)));
+        const int vbase = (nt * 16 + q4 * 4) * 4, zrs4 = (int)(a.zrs * 4), zts4 = (int)(a.zts * 4);
         PsTick kp = {0, 0};        // next tick to prefetch
         int pslot = 0;
         auto issue = [&]() {
             const PsTick q = kp;
-            const int row = strow[q.p * 16 + r];
-            const float* zr = zsrc + (long)q.t * a.zts + (long)row * a.zrs;
+            const int voff = (int)__umul24((unsigned)strow[q.p * 16 + r], (unsigned)zrs4) + vbase;
+            const int soff = q.t * zts4;
             float* dst = ring + pslot * PSW_SLOT;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) ps_dma16(zr + (long)g * U, dst + g * 256);
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(zres, (ps_lds_void*)(dst + g * 256), 16, voff, soff + g * U * 4, 0, 0);
             // past the last tick the same rows are fetched again: the counted waits below stay exact
             if (q.p + 1 < nrs || q.t + 1 < T) kp.next(nrs);
             if (++pslot == PS_PF_R) pslot = 0;
@@ -1248,6 +1275,7 @@ struct PsBwdArgs {
     int sorted, Tfull;
     int rs_start[PS_RT_TAB + 1], tdom[PS_RT_TAB];
     int poll;               // bit 0: pipelined flag polls (ps_wait_flags) in domains that look ahead, bit 1: in single-phase ones too
+    int use_desc;           // 1: stores and prefetches through buffer descriptors with 32-bit offsets (sizes checked on the host)
 };
 
 template <int CB, int CPWB>
@@ -1269,6 +1297,10 @@ struct PsBwdEpi {
     int rr, un, u;
     float *P, *stdc, *stage, *ring;
     int* stl;
+    // global stores through buffer descriptors (round 4, as the wide forward kernel): the lane's byte offset (row, unit)
+    // in a VGPR, pass and gate in the scalar offset, masked lanes out of the descriptor's range
+    __amdgpu_buffer_rsrc_t dzres, dh0res;
+    int use_desc;
 };
 
 // Gate backward of this wave's 4 rows x 16 units of phase p, pass j (t = T-1-j; t = -1: dh0 pass), in
@@ -1328,6 +1360,17 @@ __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const P
     // addresses for a clamped row, only the final offset selected (see the forward epilogue)
     const bool fin = t < 0;
     const int rowc = pre.prow;
+    if (e.use_desc) {
+        const int u4 = e.u * 4;
+        const int vz = (valid && !fin) ? (int)__umul24((unsigned)rowc, (unsigned)(a.zrs * 4)) + u4 : PSW_OOB;
+        const int vh = (valid && fin) ? (int)__umul24((unsigned)rowc, (unsigned)(U * 4)) + u4 : PSW_OOB;
+        const int sz = max(t, 0) * (int)(a.zts * 4);
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, g[gg]), e.dzres, vz, sz + gg * U * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, dH), e.dh0res, vh, 0, 0);
+        return;
+    }
     const long zo = (long)max(t, 0) * a.zts + (long)rowc * a.zrs + e.u;
     const long dd = a.dump - a.dz;
     float* dzr = a.dz + ((valid && !fin) ? zo : dd);
@@ -1448,10 +1491,12 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
     if (DEFER) ps_bwd_epilogue_post(a, e, rs0, kprev.p, kprev.t, pre_prev, dbacc, (nticks - 1) & 1);
 }
 
+struct PsBwdLaunch { PsBwdArgs s[3]; };     // (indexed in the kernel-argument segment, as PsFwdWLaunch)
 template <int CPW>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16
-__global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs a0, PsBwdArgs a1, PsBwdArgs a2) {
+__global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdLaunch L) {
     // up to three independent sequences per launch (the three decoders), on disjoint workgroups as in the forward kernel
-    PsBwdArgs a = ((int)blockIdx.x >= a0.gsz + a1.gsz) ? a2 : (((int)blockIdx.x >= a0.gsz) ? a1 : a0);
+    const int seq = ((int)blockIdx.x >= L.s[0].gsz + L.s[1].gsz) ? 2 : (((int)blockIdx.x >= L.s[0].gsz) ? 1 : 0);
+    PsBwdArgs a = L.s[seq];
     constexpr int CPWB = 4 * CPW;                // chunks per wave
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
@@ -1498,7 +1543,10 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         if (a.direct && !a.packed) {
 #pragma unroll
             for (int c = 0; c < CPWB; ++c) {
-                const float4 w = d2p_pack_w_bwd_elem(U, a.wh_raw, ((long)nt * KC4 + wave * CPWB + c) * 64 + lane);
+                // the element d2p_pack_w_bwd_elem would put at ((nt*KC4 + wave*CPWB + c)*64 + lane), without its 64-bit
+                // divisions (32 of them per wave at kernel entry): unit n = nt*16 + (lane&15), gate column k
+                const int n = nt * 16 + (lane & 15), k = (wave * CPWB + c) * 16 + 4 * (lane >> 4);
+                const float4 w = *reinterpret_cast<const float4*>(a.wh_raw + (long)n * 4 * U + k);
                 bw[c] = f32x4{w.x, w.y, w.z, w.w};
             }
         } else {
@@ -1513,6 +1561,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         e.un = lane & 15;
         e.u = nt * 16 + e.un;
         e.P = P; e.stdc = stdc; e.stl = stl; e.stage = stage; e.ring = ring;
+        e.use_desc = a.use_desc;
+        e.dzres = ps_rsrc(a.dz, (unsigned)(((size_t)(a.Tfull - 1) * a.zts + (size_t)(a.M - 1) * a.zrs + 4 * (size_t)U) * sizeof(float)));
+        e.dh0res = ps_rsrc(a.dh0 ? a.dh0 : a.dump, a.dh0 ? (unsigned)((size_t)a.M * U * sizeof(float)) : 0u);
         for (int p = 0; p < nrs; ++p) {
             const int vrow = (rs0 + p) * 16 + e.rr;
             int row = min(vrow, a.M - 1);
@@ -1597,7 +1648,36 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         PsTick kp = {0, 0};
         int pslot = 0;
-        auto issue = [&]() {
+        const __amdgpu_buffer_rsrc_t zres_b =
+            ps_rsrc(a.z, (unsigned)(((size_t)(a.Tfull - 1) * a.zts + (size_t)(a.M - 1) * a.zrs + 4 * (size_t)U) * sizeof(float)));
+        const unsigned mu_bytes = (unsigned)((size_t)a.M * U * sizeof(float));
+        const __amdgpu_buffer_rsrc_t cres_b = ps_rsrc(a.cs, (unsigned)((size_t)a.Tfull * a.M * U * sizeof(float)));
+        const __amdgpu_buffer_rsrc_t c0res_b = ps_rsrc(a.c0 ? a.c0 : a.cs, mu_bytes);
+        const __amdgpu_buffer_rsrc_t dhres_b =
+            ps_rsrc(a.dhout ? a.dhout : a.cs, (unsigned)((size_t)(a.dhout ? a.Tfull : 1) * a.M * U * sizeof(float)));
+        const __amdgpu_buffer_rsrc_t dhfres_b = ps_rsrc(a.dh_final ? a.dh_final : a.cs, mu_bytes);
+        const int zrs4 = (int)(a.zrs * 4), zts4 = (int)(a.zts * 4);
+        auto issue_desc = [&]() {
+            const PsTick kk = kp;
+            const int t = max(a.T - 1 - kk.t, 0);                       // the dh0 pass fetches step 0 again (unused)
+            const unsigned row = (unsigned)strow[kk.p * 16 + r];
+            const int vz = (int)__umul24(row, (unsigned)zrs4) + u * 4, vo = (int)__umul24(row, (unsigned)(U * 4)) + u * 4;
+            float* dst = ring + pslot * PS_BWD_SLOT;
+            const int sz = t * zts4, sc = t * (int)mu_bytes;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(zres_b, (ps_lds_void*)(dst + g * 256), 16, vz, sz + g * U * 4, 0, 0);
+            // c before the step: cs[t-1], or c0, or (no initial state) a valid dummy
+            const bool first = t == 0;
+            const __amdgpu_buffer_rsrc_t cpres = first ? c0res_b : cres_b;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cpres, (ps_lds_void*)(dst + 4 * 256), 16, vo, first ? 0 : sc - (int)mu_bytes, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(cres_b, (ps_lds_void*)(dst + 5 * 256), 16, vo, sc, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dhres_b, (ps_lds_void*)(dst + 6 * 256), 16, vo, a.dhout ? sc : 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(dhfres_b, (ps_lds_void*)(dst + 7 * 256), 16, vo, 0, 0, 0);
+            if (kk.p + 1 < nrs || kk.t + 1 < J) kp.next(nrs);
+            if (++pslot == PS_PF_R) pslot = 0;
+        };
+        auto issue_ptr = [&]() {
             const PsTick kk = kp;
             const int t = max(a.T - 1 - kk.t, 0);                       // the dh0 pass fetches step 0 again (unused)
             const int row = strow[kk.p * 16 + r];
@@ -1614,6 +1694,11 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             ps_dma16(a.dh_final ? a.dh_final + o : cc, dst + 7 * 256);
             if (kk.p + 1 < nrs || kk.t + 1 < J) kp.next(nrs);
             if (++pslot == PS_PF_R) pslot = 0;
+        };
+        const bool use_desc = a.use_desc != 0;
+        auto issue = [&]() {
+            if (use_desc) issue_desc();
+            else issue_ptr();
         };
         for (int d = 0; d < PS_PF_D; ++d) issue();
         ps_wait_vmcnt<(PS_PF_D - 1) * PS_BWD_NOP>();
@@ -1729,6 +1814,11 @@ static double g_ps_cost_ph = 3.3, g_ps_cost_fl = 6.3;   // backward: us per phas
 extern "C" int d2p_lstm_persist_set_plan_cost(double us_per_phase, double floor_us) {
     if (us_per_phase > 0.0) g_ps_cost_ph = us_per_phase;
     if (floor_us > 0.0) g_ps_cost_fl = floor_us;
+    return D2P_OK;
+}
+static int g_ps_bwd_desc = 1;                // 0: the backward kernel's stores / prefetches by 64-bit pointers (round 3's form; A/B switch)
+extern "C" int d2p_lstm_persist_set_bwd_desc(int on) {
+    g_ps_bwd_desc = on ? 1 : 0;
     return D2P_OK;
 }
 static int g_ps_bwd_defer_from = 1 << 20;    // backward: deferred form from this many phases per domain (d2p_lstm_persist_set_bwd_defer);
@@ -1926,11 +2016,12 @@ int d2p_lstm_persist_fwd_pair(const PsFwdCall& qa, const PsFwdCall& qb, hipStrea
 // domain -- passes of its first sub-tile x the per-pass cost of its phases -- is as fast as possible (dynamic
 // programme over the cut positions; steps[s] = passes sub-tile s needs = the length of its longest row).
 static bool ps_plan_sorted(int trs, int RT, const int* steps, int extra_pass, double ph, double fl, int* rs_start,
-                           int* tdom) {
+                           int* tdom, double (*step_cost)(int) = nullptr) {
     if (RT < 1 || RT > PS_RT_TAB || trs < RT || trs > 256) return false;
     auto cost = [&](int s0, int s1) {          // domain of sub-tiles [s0, s1)
         const double step = ph * (s1 - s0);
-        return (double)(steps[s0] + extra_pass) * (step > fl ? step : fl);
+        const double per = step_cost ? step_cost(s1 - s0) : (step > fl ? step : fl);
+        return (double)(steps[s0] + extra_pass) * per;
     };
     // best[d][s]: smallest possible maximum over the first d domains covering sub-tiles [0, s)
     static thread_local double best[PS_RT_TAB + 1][257];
@@ -1982,6 +2073,10 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     a.lds_nb = (a.total_rs + RT - 1) / RT >= g_ps_bwd_defer_from ? 2 : 1;
     a.direct = 0; a.wh_raw = q.Wh; a.epoch = 0; a.packed = 0;
     a.poll = g_ps_poll_pipelined;
+    // 32-bit byte offsets into z / dz (rows at zrs, steps at zts), cs, dhout; 24-bit row strides in bytes; rows < 2^15
+    a.use_desc = (g_ps_bwd_desc && M <= 32767 && q.zrs * 4 < (1L << 24) && q.zts > 0 && q.zrs >= 4L * U &&
+                  ((long)(n_steps - 1) * q.zts + (long)(M - 1) * q.zrs + 4L * U) * 4 < 0x7fffff00L &&
+                  (long)n_steps * M * U * 4 < 0x7fffff00L) ? 1 : 0;
     a.err = ps_err_ptr();
     a.trace = g_ps_trace; a.trace_block = g_ps_trace_block;
     a.z = q.z; a.zrs = q.zrs; a.zts = q.zts; a.c0 = q.c0; a.cs = q.cs; a.lens = q.lens;
@@ -2034,6 +2129,8 @@ static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdAr
     PsBwdArgs b0 = a0, b1 = a1, b2 = a2;
     const int nb = ((a0.gsz > 0 && a0.lds_nb == 2) || (a1.gsz > 0 && a1.lds_nb == 2) || (a2.gsz > 0 && a2.lds_nb == 2)) ? 2 : 1;
     b0.lds_nb = b1.lds_nb = b2.lds_nb = nb;
+    PsBwdLaunch L;
+    L.s[0] = b0; L.s[1] = b1; L.s[2] = b2;
     const size_t lds = (size_t)(nb * PS_BWD_P_FLOATS + (PS_NRS_MAX + 1) * 256 + 2 * PS_NRS_MAX * 16 + nb * 1024 +
                                 PS_PF_R * PS_BWD_SLOT) * sizeof(float);
     D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, flops);
@@ -2045,7 +2142,7 @@ static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdAr
                                       96 * 1024);                                                                       \
             attr = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW>), dim3(blocks), dim3(PS_THREADS), lds, st, b0, b1, b2);         \
+        hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW>), dim3(blocks), dim3(PS_THREADS), lds, st, L);                 \
     }
     switch (U) {
         case 64: PS_BWD_LAUNCH(1) break;
@@ -2161,13 +2258,14 @@ int d2p_lstm_persist_bwd_triple(const PsBwdCall q[3], hipStream_t st) {
 // Forward, wide column tiles: host side
 // =============================================================================================
 static int g_psw_on = 1;                     // 0: every forward launch goes to the narrow-tile kernel (A/B switch)
-static int g_psw_la_from = 2, g_psw_defer_from = 5, g_psw_xcd_local = 1;
-static double g_psw_cost_ph = 2.4, g_psw_cost_fl = 3.6;      // planner: us per phase, hand-off floor per step
+static int g_psw_la_from = 3, g_psw_defer_from = 5, g_psw_xcd_local = 1, g_psw_la_q = 2;
+static double g_psw_cost_ph = 2.7, g_psw_cost_fl = 4.6;      // planner knobs: scale of the per-phase costs / of the single-phase step (psw_step_cost)
 extern "C" int d2p_lstm_persist_set_fwd_wide(int on, int la_from, int defer_from, int xcd_local) {
     g_psw_on = on ? 1 : 0;
     if (la_from >= 2) g_psw_la_from = la_from;
     if (defer_from >= 3) g_psw_defer_from = defer_from;
-    if (xcd_local >= 0) g_psw_xcd_local = xcd_local ? 1 : 0;
+    if (xcd_local >= 0) g_psw_xcd_local = (xcd_local & 1) ? 1 : 0;
+    if (xcd_local >= 0 && (xcd_local & 6)) g_psw_la_q = (xcd_local & 2) ? 2 : 3;      // bits 1 / 2: request after 2 / 3 quarters
     return D2P_OK;
 }
 extern "C" int d2p_lstm_persist_set_fwd_plan_cost(double us_per_phase, double floor_us) {
@@ -2189,11 +2287,17 @@ extern "C" int d2p_lstm_persist_wide_local_wgs(int reset) {
     }
     return (int)(v & 0x7fffffffu);
 }
-static double psw_cost(int trs, int T, int RT) {
-    const int nrs = (trs + RT - 1) / RT;
-    const double step = g_psw_cost_ph * nrs;
-    return T * (step > g_psw_cost_fl ? step : g_psw_cost_fl);
+// us per step of a row domain with nrs phases (measured, tools/check_lstm_wide.py --sweep and the traces: a single
+// phase is the bare hand-off chain; two phases poll for their own rows with nothing fetched ahead; from three the next
+// rows are requested ahead; from defer_from the gate math rides in the next phase's chain), scaled by the two knobs
+static double psw_step_cost(int nrs) {
+    const double ph = g_psw_cost_ph / 2.7, fl = g_psw_cost_fl / 4.6;
+    if (nrs <= 1) return 4.6 * fl;
+    if (nrs == 2) return 7.0 * ph;
+    if (nrs < g_psw_defer_from) return 2.83 * nrs * ph;
+    return 2.65 * nrs * ph;
 }
+static double psw_cost(int trs, int T, int RT) { return T * psw_step_cost((trs + RT - 1) / RT); }
 // row domains of a launch with n sequences: all of the chip's (num_cus / column tiles) domains, dealt out so that the
 // slowest sequence finishes as early as possible under the per-step cost model
 static bool psw_plan(int n, const int* trs, const int* T, int ncol, int* R) {
@@ -2280,7 +2384,7 @@ int d2p_lstm_persist_fwd_wide(int n, const PsFwdCall* q, hipStream_t st) {
         x.wh_raw = c.Wh; x.h0_raw = c.h0; x.h0_bytes = c.h0 ? (unsigned)((size_t)c.M * U * sizeof(float)) : 0u;
         x.epoch = c.epoch;
         x.poll = g_ps_poll_pipelined;
-        x.la_from = g_psw_la_from; x.defer_from = g_psw_defer_from;
+        x.la_from = g_psw_la_from; x.defer_from = g_psw_defer_from; x.la_q = g_psw_la_q;
         x.xcd_local = g_psw_xcd_local;
         x.rowmap = nullptr; x.sorted = 0; x.Tfull = c.n_steps;
         for (int d = 0; d <= PS_RT_TAB; ++d) x.rs_start[d] = 0;
@@ -2288,7 +2392,7 @@ int d2p_lstm_persist_fwd_wide(int n, const PsFwdCall* q, hipStream_t st) {
         int nmax = (trs[i] + R[i] - 1) / R[i];
         double f = 2.0 * c.M * 4.0 * U * U * (c.n_steps - (c.h0 ? 0 : 1));
         if (c.rowmap && c.slab_steps && c.lens && g_ps_sorted &&
-            ps_plan_sorted(trs[i], R[i], c.slab_steps, 0, g_psw_cost_ph, g_psw_cost_fl, x.rs_start, x.tdom)) {
+            ps_plan_sorted(trs[i], R[i], c.slab_steps, 0, g_psw_cost_ph, g_psw_cost_fl, x.rs_start, x.tdom, psw_step_cost)) {
             x.rowmap = c.rowmap;
             x.sorted = 1;
             any_sorted = true;
@@ -2308,6 +2412,8 @@ int d2p_lstm_persist_fwd_wide(int n, const PsFwdCall* q, hipStream_t st) {
     }
     for (int i = n; i < 3; ++i) { a[i] = a[0]; a[i].RT = 0; a[i].dom0 = dom; }
     for (int i = 0; i < 3; ++i) a[i].lds_nb = nb;
+    PsFwdWLaunch L;
+    for (int i = 0; i < 3; ++i) L.s[i] = a[i];
     const size_t lds = (size_t)(nb * PSW_P_FLOATS + 2 * PS_NRS_MAX * PSW_CELLS + 2 * PS_NRS_MAX * 16 + 16 + nb * PSW_CELLS +
                                 PS_PF_R * PSW_SLOT) * sizeof(float);
     const int blocks = dom * nnt;
@@ -2322,7 +2428,7 @@ int d2p_lstm_persist_fwd_wide(int n, const PsFwdCall* q, hipStream_t st) {
                                       96 * 1024);                                                                       \
             attr = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((lstm_persist_fwdw_kernel<CPW>), dim3(blocks), dim3(PS_THREADS), lds, st, a[0], a[1], a[2]);  \
+        hipLaunchKernelGGL((lstm_persist_fwdw_kernel<CPW>), dim3(blocks), dim3(PS_THREADS), lds, st, L);                \
     }
     switch (U) {
         case 64: PSW_LAUNCH(1) break;

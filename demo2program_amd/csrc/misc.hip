@@ -503,3 +503,35 @@ extern "C" int d2p_per_fc_bn_bwd(int G, int P, int U, int NCp, int rows_per_grou
     D2P_LAUNCH_CHECK("per_fc_bn_bwd");
     return D2P_OK;
 }
+
+// ---- measurement hook (tools/corun_probe.py): when do the workgroups of a launch really start? ----------------------
+// Every workgroup leaves the constant-rate wall clock (100 MHz) of its first instruction; `regs` > 0 makes every wave
+// hold about that many live VGPRs (the register footprint decides where the dispatcher can place a wave beside the
+// persistent recurrent kernels' 256-register waves), `lds_bytes` of dynamic LDS likewise.
+template <int NV>
+__global__ void probe_clock_kernel(unsigned long long* out, const float* src, float* sink) {
+    const unsigned long long t = wall_clock64();
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = src[(threadIdx.x + i * 64) & 1023];
+    float acc = 0.f;
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { v[i] = v[i] * 1.0001f + (float)r; acc += v[i]; }
+    }
+    if (acc == 12345.678f) sink[threadIdx.x] = acc;       // (never: keeps the registers live)
+    if (threadIdx.x == 0) out[blockIdx.x] = t;
+}
+extern "C" int d2p_probe_clock(int blocks, int threads, int regs, int lds_bytes, void* out, const float* src, float* sink,
+                               d2p_stream_t stream) {
+    D2P_REQUIRE(blocks > 0 && threads > 0 && threads <= 1024 && out && src && sink, D2P_EINVAL, "probe: bad arguments");
+    hipStream_t st = as_stream(stream);
+    unsigned long long* o = (unsigned long long*)out;
+    if (regs >= 200) hipLaunchKernelGGL((probe_clock_kernel<200>), dim3(blocks), dim3(threads), lds_bytes, st, o, src, sink);
+    else if (regs >= 120) hipLaunchKernelGGL((probe_clock_kernel<120>), dim3(blocks), dim3(threads), lds_bytes, st, o, src, sink);
+    else if (regs >= 80) hipLaunchKernelGGL((probe_clock_kernel<80>), dim3(blocks), dim3(threads), lds_bytes, st, o, src, sink);
+    else if (regs >= 48) hipLaunchKernelGGL((probe_clock_kernel<48>), dim3(blocks), dim3(threads), lds_bytes, st, o, src, sink);
+    else hipLaunchKernelGGL((probe_clock_kernel<4>), dim3(blocks), dim3(threads), lds_bytes, st, o, src, sink);
+    D2P_LAUNCH_CHECK("probe_clock");
+    return D2P_OK;
+}

@@ -61,6 +61,7 @@ SIGNATURES = {
     'd2p_lstm_persist_error': (c_int, [c_int]),
     'd2p_lstm_persist_inject_error': (c_int, []),
     'd2p_lstm_persist_set_bwd_defer': (c_int, [c_int]),
+    'd2p_lstm_persist_set_bwd_desc': (c_int, [c_int]),
     'd2p_lstm_flag_words': (c_size_t, []),
     'd2p_lstm_persist_set_sorted': (c_int, [c_int]),
     'd2p_lstm_persist_set_poll': (c_int, [c_int]),
@@ -106,6 +107,7 @@ SIGNATURES = {
     'd2p_axpy': (c_int, [c_size_t, c_float, P, P, c_int, S]),
     'd2p_transpose_rt': (c_int, [c_int, c_int, c_int, P, P, S]),
     'd2p_pad_axis': (c_int, [c_long, c_int, c_int, c_int, P, P, c_int, c_int, S]),
+    'd2p_probe_clock': (c_int, [c_int, c_int, c_int, c_int, P, P, P, S]),
     'd2p_zero_past_group_steps': (c_int, [c_int, c_int, c_int, c_int, P, P, S]),
     'd2p_l2norm_ws_bytes': (c_size_t, [c_size_t]),
     'd2p_l2norm_flat': (c_int, [c_size_t, P, c_float, P, P, c_size_t, S]),

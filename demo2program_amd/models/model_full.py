@@ -774,6 +774,7 @@ class Model(object):
             # the weight-gradient GEMMs that read hbuf[0] wait for this, whichever stream they are issued on
             ctx['h0_event'] = torch.cuda.Event()
             ctx['h0_event'].record(side)
+            ctx['h0_stream'] = side
 
     def _lstm_xproj(self, name, x2d, I, M, T, n_steps):
         """Hoisted input projection z = x·Wx + b for all steps (one GEMM)."""
@@ -1330,8 +1331,11 @@ class Model(object):
         if e['name'] in self._ctx.get('h0_staged', ()) and e.get('hbuf') is not None and n > 0:
             # hbuf[t] = the state step t multiplied (hbuf[0] = h0): one product over the rows of all steps
             hb2d = e['hbuf'].view((T + 1) * M, U)
-            if self._ctx.get('h0_event') is not None:
-                torch.cuda.current_stream().wait_event(self._ctx['h0_event'])    # (a no-op on the staging stream itself)
+            ev = self._ctx.get('h0_event')
+            if ev is not None and torch.cuda.current_stream() != self._ctx.get('h0_stream'):
+                # (issued on another stream than the staging copies: wait for them; on the staging stream itself stream
+                #  order already holds -- and a wait for an event of the same capturing stream crashed hipStreamEndCapture)
+                torch.cuda.current_stream().wait_event(ev)
             if kl is not None and kl[1]:
                 K.gemm_tn_rows(U, 4 * U, kl[1], hb2d, U, kl[0], dz, 4 * U, kl[0], gk[I:], 4 * U)
             else:

@@ -256,6 +256,10 @@ int d2p_lstm_persist_set_trace(void* buf, size_t bytes, int block);
  * published one phase later -- when the domain has at least `from_phases` 16-row phases per step (<= 0: never, the
  * default: measured -4 % per phase at 5-7 phases in isolation and nothing in the training step).  Same results. */
 int d2p_lstm_persist_set_bwd_defer(int from_phases);
+/* A/B switch (default 1): the persistent backward kernel's global stores and operand prefetches go through buffer
+ * descriptors with scalar step / gate offsets (a few VALU instructions per phase instead of ~60: beside an fp32 MFMA
+ * chain every VALU instruction is paid in full); 0 = 64-bit pointers, round 3's form.  Same results. */
+int d2p_lstm_persist_set_bwd_desc(int on);
 /* Words of a d2p_lstm_*_desc.flags buffer; and the A/B switch of the direct launches (1 default; 0: every persistent
  * launch gets its preparation launch whatever the descriptor says). */
 size_t d2p_lstm_flag_words(void);
@@ -284,10 +288,12 @@ int d2p_lstm_persist_set_wgs_per_cu(int fwd, int bwd);
  * sequences per launch, length-sorted where a descriptor brings rowmap / slab_steps, row domains that find all their
  * workgroups on one XCD exchange through its L2).  on: 1 (default) / 0 = every forward launch goes to the 8-unit-tile
  * kernel.  la_from / defer_from: phases per row domain from which a domain requests its next rows ahead / runs the
- * deferred gate math (defaults 3 / 5; values below 2 / 3 leave them unchanged).  xcd_local: 1 (default) / 0 = always
- * write-through hand-offs; negative: unchanged.  Results are bit-identical in every setting. */
+ * deferred gate math (defaults 3 / 5; values below 2 / 3 leave them unchanged).  xcd_local (negative: unchanged): bit 0
+ * = L2-local hand-offs in domains found on one XCD (default 1; 0: always write-through); bits 1 / 2 (experiments): the
+ * look-ahead request after 2 (default) / 3 quarters of a phase's MFMA chain.  Results are bit-identical in every setting. */
 int d2p_lstm_persist_set_fwd_wide(int on, int la_from, int defer_from, int xcd_local);
-/* ... and its planner's cost model per step of a row domain, max(us_per_phase * phases, floor_us); defaults 2.4 / 3.6 */
+/* ... and two scale knobs of its planner's per-step cost table (psw_step_cost in lstm_persist.hip): the per-phase
+ * costs (default 2.7 = as measured) and the single-phase step (default 4.6 us); values <= 0 leave a knob unchanged */
 int d2p_lstm_persist_set_fwd_plan_cost(double us_per_phase, double floor_us);
 /* Wide-tile forward launches so far that carried nseq = 1, 2, 3 sequences (nseq = 0: those with a length-sorted
  * sequence).  For tests: the path must not be skipped silently. */
@@ -491,6 +497,12 @@ int d2p_transpose_rt(int R, int T, int C, const float* in, float* out, d2p_strea
  * Brings 3-channel frames / conv1 weights to 4 channels for 16-byte (uint8x4) tap gathers. */
 int d2p_pad_axis(long outer, int C, int Cp, int inner, const void* in, void* out, int is_u8,
                  int unpad, d2p_stream_t stream);
+/* Measurement hook (tools/corun_probe.py): a launch of `blocks` x `threads` whose workgroups each write the 100 MHz
+ * wall clock of their first instruction to out[block] (unsigned 64-bit); every wave holds about `regs` live VGPRs
+ * (4 / 48 / 80 / 120 / 200) and the launch asks for lds_bytes of dynamic LDS -- shows when and where workgroups of a
+ * second queue become resident beside a persistent recurrent launch.  src: >= 1024 floats, sink: >= threads floats. */
+int d2p_probe_clock(int blocks, int threads, int regs, int lds_bytes, void* out, const float* src, float* sink,
+                    d2p_stream_t stream);
 /* zero logits rows (t, r) with t >= nsteps_g[r % G]  (per-demo dynamic padding,
  * models/model_full.py:476-484); nsteps_g[g] = min(T, max_{r%G==g} lens[r]) computed on device. */
 int d2p_zero_past_group_steps(int T, int R, int V, int G, const int* lens, float* logits, d2p_stream_t stream);

@@ -148,8 +148,35 @@ def timing():
     return res
 
 
+def sweep():
+    """us per launch over the hand-off knobs: la_from x defer_from x request position (quarters of the chain)"""
+    K.set_lstm_persistent(True)
+    enc = mk(320, 20, masked=True, init=True, seed=12)
+    lens = bench_lens(320, 20)
+    enc['lens_host'], enc['lens'] = lens, torch.from_numpy(lens.astype(np.int32)).cuda()
+    act, per, prog = mk(320, 20, seed=13), mk(320, 20, seed=14), mk(32, 50, seed=15)
+    order = K.lstm_row_order(lens)
+    print('la_from defer_from quarters | enc unsorted | enc sorted | triple | act alone')
+    for la in (2, 3, 4):
+        for df in (4, 5, 6, 8):
+            for q in (2, 3):
+                call.d2p_lstm_persist_set_fwd_wide(1, la, df, 1 | (2 if q == 2 else 4))
+                enc.pop('row_order', None)
+                t0 = timed(lambda: K.lstm_seq_fwd_multi([enc]))
+                enc['row_order'] = order
+                t1 = timed(lambda: K.lstm_seq_fwd_multi([enc]))
+                t2 = timed(lambda: K.lstm_seq_fwd_multi([act, per, prog]))
+                t3 = timed(lambda: K.lstm_seq_fwd_multi([act]))
+                print('   %d %d %d | %6.1f | %6.1f | %6.1f | %6.1f' % (la, df, q, t0, t1, t2, t3))
+    call.d2p_lstm_persist_set_fwd_wide(1, 3, 5, 1 | 4)
+    print('   error word: 0x%x' % K.lstm_persist_error())
+
+
 if __name__ == '__main__':
     build.build_library()
+    if '--sweep' in sys.argv:
+        sweep()
+        sys.exit(0)
     quick = '--quick' in sys.argv
     bad = 0
     if '--time-only' not in sys.argv:
