@@ -550,7 +550,7 @@ def main():
 
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     step_stats = {'median': round(per_step[len(per_step) // 2], 4), 'p10': round(per_step[len(per_step) // 10], 4),
-                  'p90': round(per_step[(len(per_step) * 9) // 10], 4)} if per_step else None
+                  'p90': round(per_step[(len(per_step) * 9) // 10], 4), 'max': round(per_step[-1], 4)} if per_step else None
     global_batch = config.batch_size * dp.world_size
     value = global_batch * args.steps / elapsed
     out = {
@@ -563,10 +563,12 @@ def main():
         'dtype': 'f32', 'data': 'synthetic',
         'config': {
             'workload': '%s full model, k=%d, %dx%dx%d frames, T=%d, L=%d, batch=%d programs per GPU; '
-                        'one step = forward + backward + grad all-reduce + clip(20) + Adam; '
+                        'one step = forward + backward + %s + clip(20) + Adam; '
                         'inputs resident in HBM' %
                         (args.preset, config.k, config.h, config.w, config.depth, config.max_demo_len,
-                         config.max_program_len, config.batch_size),
+                         config.max_program_len, config.batch_size,
+                         ('RCCL all-reduce of the flat gradient buffer over %d ranks' % dp.world_size) if dp.active
+                         else 'no collective (one rank, no process group)'),
             'global_batch': global_batch, 'parallelism': 'dp%d' % dp.world_size,
             'frames': args.frames,
             'lstm_units': config.num_lstm_cell_units,

@@ -24,13 +24,14 @@ struct BnPlan {
 
 // With C % 4 == 0 each thread owns 4 consecutive channels (one 16-byte load per row), so the
 // "channel lanes" count is C/4; otherwise one channel per thread.
+static int g_bn_wg_target = 1024;   // workgroups a partial-sum launch aims at (d2p_bn_set_fold bits 8..: experiment)
 static inline BnPlan bn_plan(int R, int C, int G) {
     BnPlan p;
     const int cl = (C % 4 == 0) ? C / 4 : C;
     p.lanes_c = cl < 256 ? cl : 256;
     p.row_lanes = 256 / p.lanes_c;
     const int n = G > 0 ? R / G : 0;                      // rows per group
-    int s = 1024 / (G > 0 ? G : 1);
+    int s = g_bn_wg_target / (G > 0 ? G : 1);
     if (s < 1) s = 1;
     if (s > 256) s = 256;
     int cap = (n + p.row_lanes * 8 - 1) / (p.row_lanes * 8);
@@ -94,6 +95,7 @@ static int g_bn_fold = 0;        // 1: fold the finalize steps (d2p_bn_set_fold)
 extern "C" int d2p_bn_set_fold(int on) {
     g_bn_fold = (on & 1) ? 1 : 0;
     g_bn_gc = (on & 2) ? 0 : 1;
+    g_bn_wg_target = (on >> 8) > 0 ? (on >> 8) : 1024;
     return D2P_OK;
 }
 static inline bool bn_fold_ok(int nb, int G, int S, int C) {

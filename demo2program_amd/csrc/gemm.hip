@@ -1,4 +1,5 @@
 // K5: dense fp32 MFMA GEMM entry points + column sum (include/d2p.h).
+#define D2P_GEMM_CORUN_TILES
 #include "gemm_core.h"
 
 static inline int vec_ok(const float* p, long ld) {
@@ -23,6 +24,10 @@ extern "C" int d2p_gemm_set_option(int bk32) {
     g_gemm_fold = (bk32 & 32) ? 0 : 1;         // bit 5: split-K combine as a separate launch (round 2's form)
     g_gemm_dma_big = (bk32 & 8) ? 1 : 0;       // bit 3 (experiment): large dense GEMMs on the persistent LDS-DMA kernel
     g_gemm_dma_grid = bk32 >> 8;               // bits 8..: persistent grid of the LDS-DMA kernel (0 = automatic)
+    return D2P_OK;
+}
+extern "C" int d2p_gemm_set_corun(int on) {
+    g_gemm_corun = on ? 1 : 0;
     return D2P_OK;
 }
 extern "C" int d2p_gemm_force_plan(int tile, int splits) {

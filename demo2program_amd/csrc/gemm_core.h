@@ -292,7 +292,12 @@ template <int BM, int BN, int WM, int WN, int BK, bool FAST, bool KS, class AL, 
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial, unsigned* tickets) {
     static_assert(!NOSEL || FAST, "NOSEL is a refinement of the fast loaders");
-    static_assert(KS || WM * WN == 4, "4 waves per workgroup");
+    static_assert(KS || WM * WN == 4 || WM * WN == 2, "4 waves per workgroup, or 2 (the co-run tiles)");
+    // threads: one wave per wave tile.  Two-wave workgroups exist for launches that run BESIDE a persistent recurrent
+    // kernel (round 4, tools/corun_probe.py): such a kernel holds five 256-register waves per CU, i.e. one SIMD
+    // completely, and the dispatcher then places no FOUR-wave workgroup on that CU whatever its size (it starts when
+    // the recurrence ends), while two-wave workgroups start at once on the other three SIMDs.
+    constexpr int NT = KS ? 256 : 64 * WM * WN;
     static_assert(!KS || (WM == 1 && WN == 1 && BK == 32), "KS: one tile for all waves, 4 chunks per slab");
     static_assert(BK % 8 == 0, "K slab is consumed in chunks of 8");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -305,7 +310,7 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     constexpr int A_SZ = AL::KCONTIG ? BM * (BK + 4) : BK * BM;
     constexpr int B_SZ = BL::KCONTIG ? BN * (BK + 4) : BK * BN;
     constexpr int CA = BM * BK / 4, CB = BN * BK / 4;           // float4 slots per slab
-    constexpr int IA = (CA + 255) / 256, IB = (CB + 255) / 256; // per-thread staging loads
+    constexpr int IA = (CA + NT - 1) / NT, IB = (CB + NT - 1) / NT; // per-thread staging loads
     __shared__ __attribute__((aligned(16))) float smem[2 * (A_SZ + B_SZ)];
 
     if constexpr (d2p_nosel_ok<AL>::value && d2p_nosel_ok<BL>::value && d2p_batch_ok<EP>::value) {
@@ -355,26 +360,26 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     if constexpr (NOSEL) {
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
-            const int q = tid + i * 256;
+            const int q = tid + i * NT;
             pa[i] = al.p;
-            if (CA % 256 == 0 || q < CA) {
+            if (CA % NT == 0 || q < CA) {
                 if constexpr (AL::KCONTIG) pa[i] = al.row_ptr(min(m0 + q / (BK / 4), al.X - 1)) + kbeg + (q % (BK / 4)) * 4;
                 else if constexpr (d2p_kgather<AL>::value) pa[i] = al.p + min(m0 + (q % (BM / 4)) * 4, al.X - 4);
                 else pa[i] = al.p + (long)(kbeg + q / (BM / 4)) * al.ld + min(m0 + (q % (BM / 4)) * 4, al.X - 4);
             }
-            ka[i] = kbeg + ((CA % 256 == 0 || q < CA) ? q / (BM / 4) : 0);
+            ka[i] = kbeg + ((CA % NT == 0 || q < CA) ? q / (BM / 4) : 0);
             if constexpr (d2p_kgather<AL>::value) ja0[i] = al.idx[ka[i]];
         }
 #pragma unroll
         for (int i = 0; i < IB; ++i) {
-            const int q = tid + i * 256;
+            const int q = tid + i * NT;
             pb[i] = bl.p;
-            if (CB % 256 == 0 || q < CB) {
+            if (CB % NT == 0 || q < CB) {
                 if constexpr (BL::KCONTIG) pb[i] = bl.row_ptr(min(n0 + q / (BK / 4), bl.X - 1)) + kbeg + (q % (BK / 4)) * 4;
                 else if constexpr (d2p_kgather<BL>::value) pb[i] = bl.p + min(n0 + (q % (BN / 4)) * 4, bl.X - 4);
                 else pb[i] = bl.p + (long)(kbeg + q / (BN / 4)) * bl.ld + min(n0 + (q % (BN / 4)) * 4, bl.X - 4);
             }
-            kb[i] = kbeg + ((CB % 256 == 0 || q < CB) ? q / (BN / 4) : 0);
+            kb[i] = kbeg + ((CB % NT == 0 || q < CB) ? q / (BN / 4) : 0);
             if constexpr (d2p_kgather<BL>::value) jb0[i] = bl.idx[kb[i]];
         }
         astep = AL::KCONTIG ? (long)BK : (long)BK * al.ld;
@@ -407,15 +412,15 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
     } else {                                                                                       \
         const int k0 = kbeg + (kt) * BK;                                                           \
         _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
-            const int q = tid + i * 256;                                                           \
-            if (CA % 256 == 0 || q < CA) {                                                         \
+            const int q = tid + i * NT;                                                           \
+            if (CA % NT == 0 || q < CA) {                                                         \
                 if (AL::KCONTIG) OA[i] = al.template load4<FAST>(m0 + q / (BK / 4), k0 + (q % (BK / 4)) * 4, kend, RA[i]); \
                 else OA[i] = al.template load4<FAST>(m0 + (q % (BM / 4)) * 4, k0 + q / (BM / 4), kend, RA[i]); \
             }                                                                                      \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < IB; ++i) {                                           \
-            const int q = tid + i * 256;                                                           \
-            if (CB % 256 == 0 || q < CB) {                                                         \
+            const int q = tid + i * NT;                                                           \
+            if (CB % NT == 0 || q < CB) {                                                         \
                 if (BL::KCONTIG) OB[i] = bl.template load4<FAST>(n0 + q / (BK / 4), k0 + (q % (BK / 4)) * 4, kend, RB[i]); \
                 else OB[i] = bl.template load4<FAST>(n0 + (q % (BN / 4)) * 4, k0 + q / (BN / 4), kend, RB[i]); \
             }                                                                                      \
@@ -426,8 +431,8 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
         float* As = smem + (buf) * (A_SZ + B_SZ);                                                  \
         float* Bs = As + A_SZ;                                                                     \
         _Pragma("unroll") for (int i = 0; i < IA; ++i) {                                           \
-            const int q = tid + i * 256;                                                           \
-            if (CA % 256 == 0 || q < CA) {                                                         \
+            const int q = tid + i * NT;                                                           \
+            if (CA % NT == 0 || q < CA) {                                                         \
                 const bool k_ = NOSEL || OA[i];                                                    \
                 float4 t = make_float4(k_ ? RA[i][0] : 0.f, k_ ? RA[i][1] : 0.f,                   \
                                        k_ ? RA[i][2] : 0.f, k_ ? RA[i][3] : 0.f);                  \
@@ -436,8 +441,8 @@ gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, floa
             }                                                                                      \
         }                                                                                          \
         _Pragma("unroll") for (int i = 0; i < IB; ++i) {                                           \
-            const int q = tid + i * 256;                                                           \
-            if (CB % 256 == 0 || q < CB) {                                                         \
+            const int q = tid + i * NT;                                                           \
+            if (CB % NT == 0 || q < CB) {                                                         \
                 const bool k_ = NOSEL || OB[i];                                                    \
                 float4 t = make_float4(k_ ? RB[i][0] : 0.f, k_ ? RB[i][1] : 0.f,                   \
                                        k_ ? RB[i][2] : 0.f, k_ ? RB[i][3] : 0.f);                  \
@@ -945,6 +950,7 @@ gemm_dma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, int s
 // ------------------------------------------------------------------------------------
 static int g_gemm_bk32 = 0;   // per translation unit; toggled through d2p_gemm_set_option
 static int g_gemm_nosel = 1;  // 0: always keep the select between global load and LDS store
+static int g_gemm_corun = 0;         // 1: the launches that follow run beside a persistent recurrent kernel -- two-wave workgroups (d2p_gemm_set_corun)
 static int g_gemm_force_tile = -1;   // -1: automatic; else a GemmTile value (tuning experiments)
 static int g_gemm_force_split = 0;   // 0: automatic
 static int g_gemm_dma_grid = 0;      // 0: CUs x resident workgroups per CU; else the persistent grid (tuning)
@@ -1001,6 +1007,9 @@ static inline GemmPlan d2p_plan_gemm_base(int M, int N, int K, bool allow_split)
         (long)ceil_div(M, 64) * ceil_div(N, N <= 32 ? 32 : 64) <= 8) {
         if (N <= 32) { p.tile = TILE_64x32_KS; p.bm = 64; p.bn = 32; }
         else { p.tile = TILE_64x64_KS; p.bm = 64; p.bn = 64; }
+    }
+    if (g_gemm_corun && (p.tile == TILE_128x64 || p.tile == TILE_128x128)) {    // (the two-wave co-run form is a 64x64 tile)
+        p.tile = TILE_64x64; p.bm = 64; p.bn = 64;
     }
     if (g_gemm_force_tile >= 0) {
         p.tile = g_gemm_force_tile;
@@ -1108,16 +1117,17 @@ static void d2p_launch_tile(const AL& al, const BL& bl, const EP& ep, int M, int
                             const GemmPlan& p, bool fast, float* partial, hipStream_t st, int batch = 1,
                             unsigned* tickets = nullptr) {
     dim3 grid(ceil_div(M, BM) * ceil_div(N, BN), batch, p.splits);
+    constexpr int NT = KS ? 256 : 64 * WM * WN;
     constexpr bool NOSEL_OK = d2p_nosel_ok<AL>::value && d2p_nosel_ok<BL>::value;
     if (NOSEL_OK && fast && g_gemm_nosel && K % BK == 0 && (p.splits == 1 || p.k_per_split % BK == 0)) {
         if constexpr (NOSEL_OK)
-            hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP, true>), grid, dim3(256), 0,
+            hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP, true>), grid, dim3(NT), 0,
                                st, al, bl, ep, M, N, K, p.k_per_split, partial, tickets);
     } else if (fast)
-        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, true, KS, AL, BL, EP>), grid, dim3(NT), 0, st,
                            al, bl, ep, M, N, K, p.k_per_split, partial, tickets);
     else
-        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, false, KS, AL, BL, EP>), grid, dim3(256), 0, st,
+        hipLaunchKernelGGL((gemm_mfma_kernel<BM, BN, WM, WN, BK, false, KS, AL, BL, EP>), grid, dim3(NT), 0, st,
                            al, bl, ep, M, N, K, p.k_per_split, partial, tickets);
 }
 
@@ -1208,6 +1218,14 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         case TILE_64x64_KS: d2p_launch_tile<64, 64, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
         case TILE_32x32_KSR: d2p_launch_tile<32, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets); break;
         default:
+#ifdef D2P_GEMM_CORUN_TILES           // (gemm.hip only: the conv translation units never launch beside a recurrence)
+            if (g_gemm_corun) {
+                // 64x64 tile on TWO waves (32x64 each, 16-deep slabs: ~100 registers, 16 KB of LDS): the form that
+                // becomes resident beside a persistent recurrent kernel
+                d2p_launch_tile<64, 64, 2, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets);
+                break;
+            }
+#endif
             // 32-deep slabs (half the barriers, 128-byte runs): +3-5 % on the large grids, a loss when
             // the workgroups are few (each then walks its K loop with less overlap)
             if (!g_gemm_no_bk32 && (g_gemm_bk32 || (long)ceil_div(M, 64) * ceil_div(N, 64) * p.splits >= 1024) && K >= 256 && fast)

@@ -734,6 +734,12 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwd_kernel(PsFwdArgs 
 // Same arithmetic and summation order as the narrow kernel and lstm_step.hip (K split four ways over the waves, chunks
 // and k in ascending order inside a wave, partial tiles added in wave order): outputs are bit-identical.
 // Direct launches only (the caller's flag buffer and epoch); everything else goes to the kernel above.
+#ifndef PSW_DESC_PREFETCH
+#define PSW_DESC_PREFETCH 1               // the z prefetch through a buffer descriptor (0: 64-bit pointers; build-time A/B)
+#endif
+#ifndef PSW_DESC_STORES
+#define PSW_DESC_STORES 1                 // the epilogue's global stores through buffer descriptors (0: 64-bit pointers)
+#endif
 #define PSW_PLD 80                        // partial-tile row stride (floats): 64 columns, rows rr / rr+1 on disjoint banks
 #define PSW_P_FLOATS (4 * 16 * PSW_PLD)   // one set of four partial tiles
 #define PSW_SLOT 1024                     // floats per prefetch ring slot: 4 gates x 16 rows x 16 units
@@ -829,6 +835,20 @@ __device__ __forceinline__ void psw_epilogue_finish(const PsFwdWArgs& a, const P
     e.sth[sidx] = h_state;
     // staged in fragment-major order: the publish wave's lane l = (quad l>>4, row l&15) reads a float4
     e.stage[par * PSW_CELLS + (((e.un >> 2) << 4) + e.rr) * 4 + (e.un & 3)] = h_state;
+    if constexpr (!PSW_DESC_STORES) {
+        const long o = (long)prow * U + e.u;
+        const long zo = (long)t * a.zts + (long)prow * a.zrs + e.u;
+        const long so = (long)t * a.M * U + o;
+        const long dz = a.dump - a.z, dc = a.dump - a.cs, dh = a.dump - a.hout;    // wave-uniform
+        float* zr = a.z + (valid ? zo : dz);
+        const long zg = valid ? (long)U : 0L;
+        const bool keep_ = !(active && ((t > 0) || a.has_h0));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zr[g * zg] = keep_ ? in.zin[g] : zz[g];
+        a.cs[valid ? so : dc] = c_out;
+        a.hout[valid ? so : dh] = h_out;
+        return;
+    }
     // unconditional stores (rows that keep their input projection write it back unchanged; masked lanes out of range)
     const int u4 = e.u * 4;
     const int vz = valid ? (int)__umul24((unsigned)prow, (unsigned)(a.zrs * 4)) + u4 : PSW_OOB;
@@ -1170,14 +1190,21 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWLau
         const int vbase = (nt * 16 + q4 * 4) * 4, zrs4 = (int)(a.zrs * 4), zts4 = (int)(a.zts * 4);
         PsTick kp = {0, 0};        // next tick to prefetch
         int pslot = 0;
+        const float* zsrc = a.z + nt * 16 + q4 * 4;
         auto issue = [&]() {
             const PsTick q = kp;
-            const int voff = (int)__umul24((unsigned)strow[q.p * 16 + r], (unsigned)zrs4) + vbase;
-            const int soff = q.t * zts4;
             float* dst = ring + pslot * PSW_SLOT;
+            if constexpr (PSW_DESC_PREFETCH) {
+                const int voff = (int)__umul24((unsigned)strow[q.p * 16 + r], (unsigned)zrs4) + vbase;
+                const int soff = q.t * zts4;
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(zres, (ps_lds_void*)(dst + g * 256), 16, voff, soff + g * U * 4, 0, 0);
+                for (int g = 0; g < 4; ++g)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(zres, (ps_lds_void*)(dst + g * 256), 16, voff, soff + g * U * 4, 0, 0);
+            } else {
+                const float* zr = zsrc + (long)q.t * a.zts + (long)strow[q.p * 16 + r] * a.zrs;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ps_dma16(zr + (long)g * U, dst + g * 256);
+            }
             // past the last tick the same rows are fetched again: the counted waits below stay exact
             if (q.p + 1 < nrs || q.t + 1 < T) kp.next(nrs);
             if (++pslot == PS_PF_R) pslot = 0;
@@ -1300,7 +1327,6 @@ struct PsBwdEpi {
     // global stores through buffer descriptors (round 4, as the wide forward kernel): the lane's byte offset (row, unit)
     // in a VGPR, pass and gate in the scalar offset, masked lanes out of the descriptor's range
     __amdgpu_buffer_rsrc_t dzres, dh0res;
-    int use_desc;
 };
 
 // Gate backward of this wave's 4 rows x 16 units of phase p, pass j (t = T-1-j; t = -1: dh0 pass), in
@@ -1331,6 +1357,7 @@ __device__ __forceinline__ void ps_bwd_epilogue_pre(const PsBwdArgs& a, const Ps
     pre.dcv = e.stdc[(p * 16 + e.rr) * 16 + e.un];
 }
 #define PS_BWD_P_FLOATS (4 * 16 * PS_PLD)
+template <bool DESC>
 __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const PsBwdEpi& e, int rs0, int p, int j,
                                                      const PsBwdEpiPre& pre, float (&dbacc)[4], int par = 0,
                                                      bool live = true) {
@@ -1360,7 +1387,7 @@ __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const P
     // addresses for a clamped row, only the final offset selected (see the forward epilogue)
     const bool fin = t < 0;
     const int rowc = pre.prow;
-    if (e.use_desc) {
+    if constexpr (DESC) {
         const int u4 = e.u * 4;
         const int vz = (valid && !fin) ? (int)__umul24((unsigned)rowc, (unsigned)(a.zrs * 4)) + u4 : PSW_OOB;
         const int vh = (valid && fin) ? (int)__umul24((unsigned)rowc, (unsigned)(U * 4)) + u4 : PSW_OOB;
@@ -1386,7 +1413,7 @@ __device__ __forceinline__ void ps_bwd_epilogue_post(const PsBwdArgs& a, const P
 // DEFER (domains with >= 5 phases, as in the forward kernel): the product-DEPENDENT half of the previous phase's gate
 // backward (partial-tile sum, six multiplies, state / staging writes, the dz stores) runs inside this phase's first
 // MFMA stage instead of behind its own product -- one barrier per phase, the new rows published one phase later.
-template <int CPW, bool LA, bool DEFER = false>
+template <int CPW, bool DESC, bool LA, bool DEFER = false>
 __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwdEpi& e, const f32x4 (&bw)[4 * CPW],
                                                  __amdgpu_buffer_rsrc_t dres, const unsigned* fl, int nnt, int rs0,
                                                  int nrs, int nticks, int lane_off, float* P, int wave, int lane,
@@ -1450,7 +1477,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
                 // dummy on zeros whose stores go to the dump line -- no branch in the chain)
                 // (phase index PS_NRS_MAX = a spare state slot nobody reads)
                 if (DEFER && st == 0)
-                    ps_bwd_epilogue_post(a, e, rs0, n > 0 ? kprev.p : PS_NRS_MAX, kprev.t, pre_prev, dbacc, par ^ 1, n > 0);
+                    ps_bwd_epilogue_post<DESC>(a, e, rs0, n > 0 ? kprev.p : PS_NRS_MAX, kprev.t, pre_prev, dbacc, par ^ 1, n > 0);
                 ps_bwd_stage<CB, CPWB>(s0, bw, st * CB, acc0, acc1);
             } else {
 #pragma unroll
@@ -1476,7 +1503,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         ps_barrier();          // A: the four partial tiles are in LDS (deferred: and the previous phase's dz is staged)
         tr.stamp(3);
         if (!DEFER) {
-            ps_bwd_epilogue_post(a, e, rs0, k0.p, k0.t, pre, dbacc);
+            ps_bwd_epilogue_post<DESC>(a, e, rs0, k0.p, k0.t, pre, dbacc);
             ps_barrier();          // B: dz of the phase staged, P and the ring slot free again
         } else {
             pre_prev = pre;
@@ -1488,15 +1515,17 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         if (++slot == PS_PF_R) slot = 0;
     }
     // the last phase's product-dependent half (its rows go nowhere: no publication)
-    if (DEFER) ps_bwd_epilogue_post(a, e, rs0, kprev.p, kprev.t, pre_prev, dbacc, (nticks - 1) & 1);
+    if (DEFER) ps_bwd_epilogue_post<DESC>(a, e, rs0, kprev.p, kprev.t, pre_prev, dbacc, (nticks - 1) & 1);
 }
 
-struct PsBwdLaunch { PsBwdArgs s[3]; };     // (indexed in the kernel-argument segment, as PsFwdWLaunch)
-template <int CPW>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16
-__global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdLaunch L) {
+template <int CPW, bool DESC>   // U = 64 * CPW; each MFMA wave owns one gate's K range = 4*CPW chunks of 16; DESC: stores and
+                                // prefetches through buffer descriptors (a compile-time choice: a run-time branch around the
+                                // prefetch loads makes the compiler wait for them at the join)
+__global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs a0, PsBwdArgs a1, PsBwdArgs a2) {
     // up to three independent sequences per launch (the three decoders), on disjoint workgroups as in the forward kernel
-    const int seq = ((int)blockIdx.x >= L.s[0].gsz + L.s[1].gsz) ? 2 : (((int)blockIdx.x >= L.s[0].gsz) ? 1 : 0);
-    PsBwdArgs a = L.s[seq];
+    // (selected between three by-value argument blocks: indexing one array of them in the kernel-argument segment, as the
+    //  wide forward kernel does, measured 35 us SLOWER per three-decoder launch here -- tools/lstm_bwd_desc_ab.py)
+    PsBwdArgs a = ((int)blockIdx.x >= a0.gsz + a1.gsz) ? a2 : (((int)blockIdx.x >= a0.gsz) ? a1 : a0);
     constexpr int CPWB = 4 * CPW;                // chunks per wave
     constexpr int NB = CPWB >= 32 ? 4 : 2;       // register stages per phase (even)
     constexpr int CB = CPWB / NB;                // chunks per stage
@@ -1543,10 +1572,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdLaunc
         if (a.direct && !a.packed) {
 #pragma unroll
             for (int c = 0; c < CPWB; ++c) {
-                // the element d2p_pack_w_bwd_elem would put at ((nt*KC4 + wave*CPWB + c)*64 + lane), without its 64-bit
-                // divisions (32 of them per wave at kernel entry): unit n = nt*16 + (lane&15), gate column k
-                const int n = nt * 16 + (lane & 15), k = (wave * CPWB + c) * 16 + 4 * (lane >> 4);
-                const float4 w = *reinterpret_cast<const float4*>(a.wh_raw + (long)n * 4 * U + k);
+                const float4 w = d2p_pack_w_bwd_elem(U, a.wh_raw, ((long)nt * KC4 + wave * CPWB + c) * 64 + lane);
                 bw[c] = f32x4{w.x, w.y, w.z, w.w};
             }
         } else {
@@ -1561,7 +1587,6 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdLaunc
         e.un = lane & 15;
         e.u = nt * 16 + e.un;
         e.P = P; e.stdc = stdc; e.stl = stl; e.stage = stage; e.ring = ring;
-        e.use_desc = a.use_desc;
         e.dzres = ps_rsrc(a.dz, (unsigned)(((size_t)(a.Tfull - 1) * a.zts + (size_t)(a.M - 1) * a.zrs + 4 * (size_t)U) * sizeof(float)));
         e.dh0res = ps_rsrc(a.dh0 ? a.dh0 : a.dump, a.dh0 ? (unsigned)((size_t)a.M * U * sizeof(float)) : 0u);
         for (int p = 0; p < nrs; ++p) {
@@ -1580,9 +1605,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdLaunc
         float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
         // slack between a publication and the phase that asks for it: nrs - 2 phases with look-ahead, nrs - 3 with the
         // deferred epilogue on top; a hand-off takes ~1.5 phases (as in the forward kernel: deferred from 5 phases)
-        if (defer) ps_bwd_mfma_wave<CPW, true, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
-        else if (nrs >= 2) ps_bwd_mfma_wave<CPW, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
-        else ps_bwd_mfma_wave<CPW, false>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
+        if (defer) ps_bwd_mfma_wave<CPW, DESC, true, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
+        else if (nrs >= 2) ps_bwd_mfma_wave<CPW, DESC, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
+        else ps_bwd_mfma_wave<CPW, DESC, false>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
         if (a.db) {
             // this workgroup's 4 gates x 16 units: the four row lanes of a wave by two shuffles, the four waves
             // through LDS in wave order (P is free: the last tick's barrier B is behind every wave)
@@ -1695,9 +1720,8 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdLaunc
             if (kk.p + 1 < nrs || kk.t + 1 < J) kp.next(nrs);
             if (++pslot == PS_PF_R) pslot = 0;
         };
-        const bool use_desc = a.use_desc != 0;
         auto issue = [&]() {
-            if (use_desc) issue_desc();
+            if constexpr (DESC) issue_desc();
             else issue_ptr();
         };
         for (int d = 0; d < PS_PF_D; ++d) issue();
@@ -1816,7 +1840,7 @@ extern "C" int d2p_lstm_persist_set_plan_cost(double us_per_phase, double floor_
     if (floor_us > 0.0) g_ps_cost_fl = floor_us;
     return D2P_OK;
 }
-static int g_ps_bwd_desc = 1;                // 0: the backward kernel's stores / prefetches by 64-bit pointers (round 3's form; A/B switch)
+static int g_ps_bwd_desc = 0;                // 1: descriptors (measured 5-10 % SLOWER per launch: off); 0: the backward kernel's stores / prefetches by 64-bit pointers (round 3's form; A/B switch)
 extern "C" int d2p_lstm_persist_set_bwd_desc(int on) {
     g_ps_bwd_desc = on ? 1 : 0;
     return D2P_OK;
@@ -2129,8 +2153,7 @@ static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdAr
     PsBwdArgs b0 = a0, b1 = a1, b2 = a2;
     const int nb = ((a0.gsz > 0 && a0.lds_nb == 2) || (a1.gsz > 0 && a1.lds_nb == 2) || (a2.gsz > 0 && a2.lds_nb == 2)) ? 2 : 1;
     b0.lds_nb = b1.lds_nb = b2.lds_nb = nb;
-    PsBwdLaunch L;
-    L.s[0] = b0; L.s[1] = b1; L.s[2] = b2;
+    const bool desc = (a0.gsz == 0 || a0.use_desc) && (a1.gsz == 0 || a1.use_desc) && (a2.gsz == 0 || a2.use_desc);
     const size_t lds = (size_t)(nb * PS_BWD_P_FLOATS + (PS_NRS_MAX + 1) * 256 + 2 * PS_NRS_MAX * 16 + nb * 1024 +
                                 PS_PF_R * PS_BWD_SLOT) * sizeof(float);
     D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, flops);
@@ -2138,11 +2161,14 @@ static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdAr
     {                                                                                                                   \
         static bool attr = false;                                                                                       \
         if (!attr) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel<CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel<CPW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      96 * 1024);                                                                       \
+            (void)hipFuncSetAttribute((const void*)lstm_persist_bwd_kernel<CPW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       96 * 1024);                                                                       \
             attr = true;                                                                                                \
         }                                                                                                               \
-        hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW>), dim3(blocks), dim3(PS_THREADS), lds, st, L);                 \
+        if (desc) hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW, true>), dim3(blocks), dim3(PS_THREADS), lds, st, b0, b1, b2);  \
+        else hipLaunchKernelGGL((lstm_persist_bwd_kernel<CPW, false>), dim3(blocks), dim3(PS_THREADS), lds, st, b0, b1, b2);      \
     }
     switch (U) {
         case 64: PS_BWD_LAUNCH(1) break;

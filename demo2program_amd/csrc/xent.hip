@@ -136,8 +136,63 @@ struct XbProb {
     const float* logits; LabelView lab; const int* lens; const float* den; float scale;
     float* dlogits; const float* proj; float* dhout;
     int blk0;             // first workgroup of this problem
+    const float* hout; float* logits_out;     // optional (round 4): the logits themselves, hout . proj, in front
 };
 struct XbArgs { int n; XbProb p[3]; };
+
+// logits = hout . proj of a workgroup's 16 rows (round 4: the Dense(use_bias=False) projection of
+// models/model_full.py:463-464 in FRONT of the loss backward, in the same launch).  The 5- / 6- / 50-column products
+// were three skinny GEMM launches of 17 us each on the critical path between the decoders' forward and backward
+// recurrences -- 50 workgroups each walking K = 512 alone; here ~900 workgroups do 16 rows each.
+// The 16 hout rows are staged in LDS (coalesced 16-byte loads); thread = (column v, K slice): VP = V rounded up to a
+// power of two (>= 8), 256 / VP slices of U; a thread multiplies its slice for ALL 16 rows (one coalesced proj load
+// feeds 16 multiply-adds, the hout values are LDS broadcasts), the slices meet in LDS and are added in slice order.
+__device__ __forceinline__ void xb_logits16(const XbProb& q, long row0, long nrows, float* hs, float* part,
+                                            float (*lg)[XB_MAXV]) {
+    const int V = q.V, U = q.U, tid = threadIdx.x;
+    // stage hout[row0 .. row0+15][0 .. U): rows past the end as zeros
+    for (int i = tid; i < XB_ROWS * U / 4; i += 256) {
+        const int r = i / (U / 4), c = i - r * (U / 4);
+        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < nrows) v4 = *reinterpret_cast<const float4*>(q.hout + (row0 + r) * U + c * 4);
+        *reinterpret_cast<float4*>(hs + r * U + c * 4) = v4;
+    }
+    __syncthreads();
+    int VP = 8;
+    while (VP < V) VP <<= 1;
+    const int KS = 256 / VP, v = tid & (VP - 1), ks = tid / VP;
+    const int ulen = U / KS, u0 = ks * ulen;           // (U % 32 == 0 and KS <= 32: whole multiples of 4... checked on the host)
+    float acc[XB_ROWS];
+#pragma unroll
+    for (int r = 0; r < XB_ROWS; ++r) acc[r] = 0.f;
+    if (v < V) {
+        const float* pr = q.proj + (long)u0 * V + v;
+#pragma unroll 2
+        for (int u = 0; u < ulen; u += 4) {
+            const float p0 = pr[(long)(u + 0) * V], p1 = pr[(long)(u + 1) * V], p2 = pr[(long)(u + 2) * V],
+                        p3 = pr[(long)(u + 3) * V];
+#pragma unroll
+            for (int r = 0; r < XB_ROWS; ++r) {
+                const float4 h = *reinterpret_cast<const float4*>(hs + r * U + u0 + u);
+                acc[r] = fmaf(h.w, p3, fmaf(h.z, p2, fmaf(h.y, p1, fmaf(h.x, p0, acc[r]))));
+            }
+        }
+    }
+    // part[ks][r][VP]
+#pragma unroll
+    for (int r = 0; r < XB_ROWS; ++r) part[(ks * XB_ROWS + r) * VP + v] = acc[r];
+    __syncthreads();
+    for (int i = tid; i < XB_ROWS * VP; i += 256) {
+        const int r = i / VP, vv = i - r * VP;
+        float sum = 0.f;
+        for (int k2 = 0; k2 < KS; ++k2) sum += part[(k2 * XB_ROWS + r) * VP + vv];
+        if (vv < V) {
+            lg[r][vv] = sum;
+            if (row0 + r < nrows) q.logits_out[(row0 + r) * V + vv] = sum;
+        }
+    }
+    __syncthreads();
+}
 
 __global__ void __launch_bounds__(256)
 xent_bwd_dhout_kernel(XbArgs a) {
@@ -150,24 +205,30 @@ xent_bwd_dhout_kernel(XbArgs a) {
     const long nrows = (long)q.n_steps * q.R;
     const long row0 = ((long)blockIdx.x - q.blk0) * XB_ROWS;
     const int V = q.V;
+    const bool own_logits = q.hout != nullptr;
+    if (own_logits) {
+        extern __shared__ __attribute__((aligned(16))) float xb_dyn[];      // [16][U] staged hout rows + [256 / VP][16][VP] partial sums
+        xb_logits16(q, row0, nrows, xb_dyn, xb_dyn + XB_ROWS * q.U, dl);     // dl holds the 16 rows' logits
+    }
     for (int i = 0; i < 4; ++i) {
         const int lr = wave * 4 + i;
         const long row = row0 + lr;
         float out = 0.f;
         if (row < nrows) {
             const int t = (int)(row / q.R), r = (int)(row - (long)t * q.R);
-            const float* x = q.logits + row * V;
+            float xl = 0.f;                                        // this lane's logit of the row
+            if (lane < V) xl = own_logits ? dl[lr][lane] : q.logits[row * V + lane];
             if (t < q.lens[r]) {
                 const float w = q.scale / ((float)q.G * q.den[r % q.G]);
                 if (q.mode == 0) {
-                    float mx = lane < V ? x[lane] : -INFINITY;
+                    float mx = lane < V ? xl : -INFINITY;
                     mx = wave_reduce_max(mx);
-                    const float ex = lane < V ? expf(x[lane] - mx) : 0.f;
+                    const float ex = lane < V ? expf(xl - mx) : 0.f;
                     const float se = wave_reduce_sum(ex);
                     // [TF-1.3] SoftmaxCrossEntropyWithLogits backprop = softmax - labels
                     if (lane < V) out = w * (ex * (1.f / se) - q.lab.at(r, t, lane));
                 } else if (lane < V) {
-                    out = (w / (float)V) * (d2p_sigmoid(x[lane]) - q.lab.at(r, t, lane));
+                    out = (w / (float)V) * (d2p_sigmoid(xl) - q.lab.at(r, t, lane));
                 }
             }
             if (lane < V) q.dlogits[row * V + lane] = out;
@@ -202,18 +263,27 @@ extern "C" int d2p_xent_bwd_dhout_multi(int nprob, const d2p_xent_bwd_desc* d, d
         D2P_REQUIRE(q.R >= 0 && q.V > 0 && q.V <= XB_MAXV && q.G > 0 && q.n_steps >= 0 && q.U > 0 && q.R % q.G == 0,
                     D2P_EINVAL, "xent_bwd_dhout: bad sizes R=%d V=%d G=%d n_steps=%d U=%d", q.R, q.V, q.G, q.n_steps, q.U);
         if (q.n_steps == 0 || q.R == 0) continue;
-        D2P_REQUIRE(q.logits && q.labels && q.lens && q.den && q.dlogits && q.proj && q.dhout, D2P_EINVAL,
+        D2P_REQUIRE((q.logits || q.hout) && q.labels && q.lens && q.den && q.dlogits && q.proj && q.dhout, D2P_EINVAL,
                     "xent_bwd_dhout: null pointer");
+        D2P_REQUIRE(!q.hout || (q.logits_out && q.U % 128 == 0 && q.U <= 512 && (((uintptr_t)q.hout & 15) == 0)), D2P_EINVAL,
+                    "xent_bwd_dhout: hout needs logits_out, U %% 128 == 0, U <= 512 and 16-byte alignment");
         XbProb& o = a.p[a.n++];
         o.mode = q.sigmoid ? 1 : 0; o.R = q.R; o.V = q.V; o.G = q.G; o.n_steps = q.n_steps; o.U = q.U;
         o.logits = q.logits; o.lab = LabelView{q.labels, q.label_rs, q.label_ts, q.label_vs}; o.lens = q.lens;
         o.den = q.den; o.scale = q.scale; o.dlogits = q.dlogits; o.proj = q.proj; o.dhout = q.dhout;
+        o.hout = q.hout; o.logits_out = q.logits_out;
         o.blk0 = blocks;
         blocks += (int)(((long)q.n_steps * q.R + XB_ROWS - 1) / XB_ROWS);
     }
     if (a.n == 0) return D2P_OK;
     for (int i = a.n; i < 3; ++i) a.p[i] = a.p[0];
-    hipLaunchKernelGGL(xent_bwd_dhout_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), a);
+    size_t dyn = 0;
+    for (int i = 0; i < a.n; ++i)
+        if (a.p[i].hout) {
+            const size_t need = ((size_t)XB_ROWS * a.p[i].U + (size_t)XB_ROWS * 256) * sizeof(float);
+            dyn = need > dyn ? need : dyn;
+        }
+    hipLaunchKernelGGL(xent_bwd_dhout_kernel, dim3(blocks), dim3(256), dyn, as_stream(stream), a);
     D2P_LAUNCH_CHECK("xent_bwd_dhout");
     return D2P_OK;
 }

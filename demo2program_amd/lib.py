@@ -29,6 +29,7 @@ SIGNATURES = {
     'd2p_gemm_f32_batched': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_long, c_long, c_long, P, c_long, c_long,
                                      c_long, P, c_long, c_long, c_long, P, c_long, c_long, c_int, c_int, S]),
     'd2p_gemm_force_plan': (c_int, [c_int, c_int]),
+    'd2p_gemm_set_corun': (c_int, [c_int]),
     'd2p_gemm_f32_nn': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
     'd2p_gemm_f32_nt': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
     'd2p_gemm_f32_tn': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
@@ -148,7 +149,8 @@ class XentBwdDesc(ctypes.Structure):
     _fields_ = [('sigmoid', c_int), ('R', c_int), ('V', c_int), ('G', c_int), ('n_steps', c_int), ('U', c_int),
                 ('logits', c_void_p), ('labels', c_void_p), ('label_rs', c_long), ('label_ts', c_long),
                 ('label_vs', c_long), ('lens', c_void_p), ('den', c_void_p), ('scale', c_float),
-                ('dlogits', c_void_p), ('proj', c_void_p), ('dhout', c_void_p)]
+                ('dlogits', c_void_p), ('proj', c_void_p), ('dhout', c_void_p), ('hout', c_void_p),
+                ('logits_out', c_void_p)]
 
 
 _lib = None
@@ -174,6 +176,8 @@ def load():
             'g.build()"` (hipcc --offload-arch=gfx950). There is no CPU fallback.' % path)
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
+        if 'D2P_LIB_PATH' in os.environ and not hasattr(lib, name):
+            continue                     # (an older build of the sources, loaded for an A/B run: newer entry points absent)
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -199,7 +199,15 @@ class Model(object):
             from ..lib import call
             call.d2p_lstm_persist_set_bwd_defer(int(os.environ['D2P_BWD_DEFER_FROM']))
         K.bn_set_fold(int(os.environ.get('D2P_BN_FOLD', '0')))   # bit 0: ticket fold (no gain), bit 1: round-2 finalize
+        # measurement hook (tools/step_ablation.py): D2P_ABLATE=conv_fwd,rn_bwd,... leaves pieces of the step out from the
+        # second forward pass on (their outputs go stale: timing only, results invalid) -- what a piece is worth in
+        # the real two-queue schedule is the step time without it
+        self._ablate = set(filter(None, os.environ.get('D2P_ABLATE', '').split(',')))
+        self._abl_cache = {}
         self._reserve_scratch()
+
+    def _abl(self, name):
+        return name in self._ablate and self._abl_cache.get('ready', False)
 
     # ------------------------------------------------------------------ plumbing
     def _alloc_moving(self, conv, scopes, U):
@@ -446,6 +454,9 @@ class Model(object):
         x = feed['s_h']
         ctx['conv'] = []
         for l, (h, w, cin, cout, ho, wo) in enumerate(self._conv, start=1):
+            if self._abl('conv_fwd'):
+                ctx['conv'], x = self._abl_cache['conv']
+                break
             Wl = p['conv%d/W' % l]
             if l == 1 and cin % 4 != 0:
                 # 3-channel (ViZDoom) frames: frames (once per batch, in get_feed_dict) and
@@ -462,6 +473,7 @@ class Model(object):
                                          p['conv%d/gamma' % l], p['conv%d/beta' % l], k, T * ho * wo)
             ctx['conv'].append((x, a, mean, rstd))
             x = y.view(NF, ho, wo, cout)
+        self._abl_cache['conv'] = (ctx['conv'], x)
         feats = x.view(M, T, F)
         feats_tm = K.transpose_rt(feats, M, T, F, out=self._buf('feats_tm', (T, M, F)))
 
@@ -484,7 +496,7 @@ class Model(object):
         side.wait_stream(main)
         if self._wpack_ev is not None:
             main.wait_event(self._wpack_ev)
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), self._corun(side != main):
             # Token-input decoders: x = embedding[id], so x.Wx + b takes one of tok+2 values per row -- the
             # projected TABLE (a [tok+1, U] x [U, 4U] GEMM: 7 or 51 rows) is gathered instead of projecting
             # 6400 gathered rows (13.4 GFLOP per decoder and direction; backward: _lstm_bwd_weights).  The
@@ -561,7 +573,10 @@ class Model(object):
                                 want_final=True, final_out=(demo_hc[0], demo_hc[1]), z=z_e2, row_order=fwd_order)
             demo_h, demo_c = demo_hc[0], demo_hc[1]
             # ---- SummarizeFeature('rn') = mean_k + rn_pool (the summarizer baseline: rn_pool alone)
-            rn_h = rn_c = self._rn_fwd(demo_hc, B, k, U, add_mean=self.multitask)
+            if self._abl('rn_fwd'):
+                rn_h = rn_c = self._abl_cache['rn']
+            else:
+                rn_h = rn_c = self._abl_cache['rn'] = self._rn_fwd(demo_hc, B, k, U, add_mean=self.multitask)
             init_h, init_c = rn_h['out'][0], rn_h['out'][1]
 
         main.wait_stream(side)
@@ -602,9 +617,21 @@ class Model(object):
             side_loss = (self.use_side_stream and os.environ.get('D2P_SIDE_LOSS', '1') == '1' and defer_loss
                          and feed.get('loss_dens') is not None)
             dp, da, dq = self._decoders_fwd(specs, logits=False)
+            # a training step (a backward pass follows at once): the logits themselves are left to backward's first
+            # launch -- d2p_xent_bwd_dhout_multi computes hout . proj in front of the loss backward -- and the loss
+            # value follows it on the side stream: three skinny GEMM launches (17 us each, K = 512 walked by 50
+            # workgroups) leave the critical path between the forward and the backward recurrences
+            defer_logits = (side_loss and os.environ.get('D2P_FUSED_LOGITS', '1') == '1' and max(V, A, P) <= 64
+                            and os.environ.get('D2P_FUSED_XENT_BWD', '1') == '1' and U % 128 == 0 and U <= 512 and self.is_train)
+            ctx['logits_deferred'] = defer_logits
             for e_ in (dp, da, dq):
-                self._decoder_logits(e_)
-            if side_loss:
+                if self._abl('logits'):
+                    e_['logits'] = self._bufs[e_['scope'] + '/logits']
+                elif defer_logits:
+                    e_['logits'] = self._buf(e_['scope'] + '/logits', (e_['T'], e_['M'], e_['token_dim']), zero=True)
+                else:
+                    self._decoder_logits(e_)
+            if side_loss and not defer_logits:
                 # the loss VALUE: nothing in backward reads it (its denominators come with the feed)
                 nums, dens = self._buf('loss_nums', (1 + 2 * k,)), self._buf('loss_dens', (1 + 2 * k,))
                 side.wait_stream(main)
@@ -650,7 +677,10 @@ class Model(object):
             if not side_loss:
                 K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
                            nums[1:1 + k], dens[1:1 + k])
-            if side_loss and defer_loss and feed.get('loss_dens') is not None:
+            if ctx.get('logits_deferred'):
+                ctx['loss_bufs'] = (nums, dens, loss, terms)  # (filled behind backward's first launch)
+                dens = feed['loss_dens']
+            elif side_loss and defer_loss and feed.get('loss_dens') is not None:
                 side.wait_stream(main)                      # the perception decoder's logits
                 with torch.cuda.stream(side):
                     K.xent_fwd('sigmoid', dq['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
@@ -687,6 +717,7 @@ class Model(object):
         self._ctx = ctx
         self._feed = feed
         self._loss, self._terms = loss, terms
+        self._abl_cache['ready'] = True
         return loss
 
     def _pack_lstm_weights(self, main, side):
@@ -724,6 +755,15 @@ class Model(object):
     def _wp(self, name, which):
         w = getattr(self, '_wpack', {}).get(name)
         return None if w is None else w[which]
+
+    def _corun(self, on_side=True):
+        """Context for the GEMMs of a side-stream block that runs beside persistent recurrent launches of the main
+        stream: two-wave workgroups (kernels.gemm_corun) -- four-wave ones are not placed on a CU while a recurrence
+        holds one of its SIMDs completely (tools/corun_probe.py)."""
+        import contextlib
+        if on_side and self.use_side_stream and K.lstm_is_persistent() and not torch.cuda.is_current_stream_capturing():
+            return K.gemm_corun()
+        return contextlib.nullcontext()
 
     def _side_stream(self):
         if not self.use_side_stream:
@@ -1064,7 +1104,24 @@ class Model(object):
                        dict(mode='sigmoid', logits=ctx['dq']['logits'], labels=feed['per'], lab_kind='rtv', lens=lens_d,
                             T=T, R=M, V=P, G=k, n_steps=n_d, den=dens[1 + k:], scale=loss_scale, dlogits=dl_q,
                             proj=p['per/proj'], dhout=self._buf('per/dhout', (T * M, U)), U=U)]
+                if ctx.get('logits_deferred'):
+                    for q_, e_ in zip(xb, (ctx['dp'], ctx['da'], ctx['dq'])):
+                        q_['hout'] = e_['hout']                # logits <- hout . proj inside the launch
                 K.xent_bwd_dhout_multi(xb)
+                if ctx.get('logits_deferred'):
+                    for e_ in (ctx['dp'], ctx['da'], ctx['dq']):
+                        if e_['n'] < e_['T']:
+                            e_['logits'][e_['n']:].zero_()      # dynamic zero padding (:476-484)
+                    nums, dens_v, loss_, terms_ = ctx['loss_bufs']
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):              # the loss VALUE (joined where backward joins the streams)
+                        K.xent_fwd('softmax', ctx['dp']['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
+                                   nums[0:1], dens_v[0:1])
+                        K.xent_fwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                                   nums[1:1 + k], dens_v[1:1 + k])
+                        K.xent_fwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                                   nums[1 + k:], dens_v[1 + k:])
+                        K.loss_assemble([1, k, k], nums, dens_v, loss_, terms_)
             else:
                 K.xent_bwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
                            dens[1:1 + k], loss_scale, dl_a)
@@ -1106,7 +1163,7 @@ class Model(object):
             if self.fuse_decoders:
                 dzs = self._decoders_bwd_rec(bspecs)
                 side.wait_stream(main)
-                with torch.cuda.stream(side):
+                with torch.cuda.stream(side), self._corun(side != main):
                     for fn, dz in zip(grads, dzs):
                         fn(dz)
             elif self.pair_decoders:
@@ -1123,7 +1180,7 @@ class Model(object):
                 for grp in groups:
                     dzs = self._decoders_bwd_rec([bspecs[i] for i in grp])
                     side.wait_stream(main)
-                    with torch.cuda.stream(side):
+                    with torch.cuda.stream(side), self._corun(side != main):
                         for i, dz in zip(grp, dzs):
                             grads[i](dz)
             else:
@@ -1132,7 +1189,7 @@ class Model(object):
                 for i in (1, 2, 0):
                     dz = self._decoders_bwd_rec([bspecs[i]])[0]
                     side.wait_stream(main)
-                    with torch.cuda.stream(side):
+                    with torch.cuda.stream(side), self._corun(side != main):
                         grads[i](dz)
             K.axpy(1.0, tmp_hc, d_demo)
             if split_cb is not None:
@@ -1143,7 +1200,7 @@ class Model(object):
                 K.xent_bwd_dhout_multi(xb)
             dz_p = self._decoders_bwd_rec([(ctx['dp'], dl_p, d_init_h, d_init_c)])[0]
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), self._corun(side != main):
                 self._token_decoder_grads(ctx['dp'], dz_p, ctx['ids_p'], n_p * B)
             if split_cb is not None:
                 self._call_split(split_cb, main, side)
@@ -1165,7 +1222,8 @@ class Model(object):
                 d_demo_h, d_demo_c = d_demo[0], d_demo[1]
                 d_demo.zero_()
             # ---- SummarizeFeature('rn') backward, both summaries (adds into d_demo)
-            self._rn_bwd(ctx['rn_h'], d_init, d_demo, B, k, U)
+            if not self._abl('rn_bwd'):
+                self._rn_bwd(ctx['rn_h'], d_init, d_demo, B, k, U)
 
             # ---- SecondPathEncoder backward: only the final states carry gradient
             e2 = ctx['e2']
@@ -1181,7 +1239,7 @@ class Model(object):
             else:
                 d_hout1 = self._lstm_bwd_dx(e2, dz2)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), self._corun(side != main):
                 self._lstm_bwd_weights(e2, dz2)
             # summary = mean_k(step-1 final states), broadcast to every demo of the program
             K.group_mean_bwd(None, dhc0_2, d_hc1f, 2 * B, k, U, False)
@@ -1196,13 +1254,15 @@ class Model(object):
         else:
             d_feats_tm = self._lstm_bwd_dx(ctx['e1'], dz1)
         side.wait_stream(main)
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), self._corun(side != main):
             self._lstm_bwd_weights(ctx['e1'], dz1)
         d_feats = K.transpose_rt(d_feats_tm.view(T, M, F), T, M, F, out=self._buf('d_feats', (M, T, F)))
 
         # ---- State_Encoder backward
         dy = d_feats
         for l in range(len(self._conv), 0, -1):
+            if self._abl('conv_bwd'):
+                break
             (h, w, cin, cout, ho, wo) = self._conv[l - 1]
             x_in, a, mean, rstd = ctx['conv'][l - 1]
             da_ = K.bn_bwd(a.view(NF * ho * wo, cout), dy.view(NF * ho * wo, cout), p['conv%d/gamma' % l],
@@ -1295,6 +1355,8 @@ class Model(object):
 
     def _lstm_bwd_weights(self, e, dz):
         """Kernel / bias gradients from dz: nothing downstream reads them before the optimizer."""
+        if self._abl('wgrad') or self._abl('wgrad:' + e['name']):
+            return
         g = self.params.g
         name, M, T, n, I = e['name'], e['M'], e['T'], e['n'], e['I']
         U = self.num_lstm_cell_units
@@ -1393,7 +1455,7 @@ class Model(object):
         on_side = side != main and os.environ.get('D2P_WPROJ_SIDE', '1') == '1'
         if on_side and wproj:
             side.wait_stream(main)
-        with torch.cuda.stream(side if on_side else main):
+        with torch.cuda.stream(side if on_side else main), self._corun(on_side):
             for (U_, V, rows, hout2d, dlogits, gproj) in wproj:
                 K.gemm_raw('tn', U_, V, rows, hout2d, U_, dlogits, V, gproj, V)
         if seqs:
@@ -1459,7 +1521,7 @@ class Model(object):
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
-        with torch.cuda.stream(side):
+        with torch.cuda.stream(side), self._corun(side != main):
             for i, sc in enumerate(self.RN_SCOPES):
                 K.matmul_tn(r['y1'][i], dy2a[i], out=g[sc + '/fc2/W'])   # K = B*k*k: split-K, one call each
             # gW1[:U] = feat^T dP, gW1[U:] = feat^T dQ for both scopes: four problems, one launch

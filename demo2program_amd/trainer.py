@@ -340,6 +340,10 @@ class Trainer(object):
             # SUM over ranks; mean folded into prescale (grad_all = grad + the status slot behind it)
             self.dp.all_reduce_grads(P.grad_all if slot is not None else P.grad)
         pre = self.dp.prescale
+        if getattr(m, '_abl', None) is not None and m._abl('adam'):      # (timing experiment: tools/step_ablation.py)
+            self.adam_step += 1
+            self.global_step += 1
+            return loss
         K.l2norm_flat(P.grad, pre, self._sumsq)
         # bias correction from the number of steps the MOMENTS have seen, not from global_step: the
         # two differ when parameters are loaded without optimizer state (zero moments, restarted

@@ -83,6 +83,13 @@ int d2p_gemm_set_option(int bk32);
  * falls back to the staged kernel of the same tile when the operands are not 16-byte aligned or K is not a
  * multiple of 32; -1 auto) and the split-K factor (0 auto) of the dense entry points. */
 int d2p_gemm_force_plan(int tile, int splits);
+/* Process-global hint (default 0), set by a caller around the GEMMs it issues on a second stream BESIDE a persistent
+ * recurrent launch (d2p_lstm_seq_*_multi): 1 = those products run as two-wave workgroups (64x64 tile, 32x64 per wave).
+ * A persistent recurrent kernel holds five 256-register waves per CU -- one SIMD completely -- and the dispatcher then
+ * places no four-wave workgroup on that CU until the recurrence ends, whereas two-wave workgroups become resident at
+ * once on the other three SIMDs (tools/corun_probe.py).  Results are identical up to the summation order of a split K.
+ * The workspace query d2p_gemm_ws_bytes follows the hint: query and launch under the same setting. */
+int d2p_gemm_set_corun(int on);
 int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                     float* C, long ldc, const float* bias, int act, int accumulate,
                     void* ws, size_t ws_bytes, d2p_stream_t stream);
@@ -458,6 +465,11 @@ typedef struct {
     const float* logits; const float* labels; long label_rs, label_ts, label_vs;
     const int* lens; const float* den; float scale;
     float* dlogits; const float* proj; float* dhout;
+    /* optional (round 4): hout [n_steps*R, U] != NULL -- the launch first computes the logits themselves, logits_out
+     * [n_steps*R, V] = hout . proj (the Dense(use_bias=False) projection of models/model_full.py:463-464: three skinny
+     * GEMM launches between the decoders' forward and backward recurrences otherwise), and differentiates those;
+     * `logits` is then not read. */
+    const float* hout; float* logits_out;
 } d2p_xent_bwd_desc;
 int d2p_xent_bwd_dhout_multi(int nprob, const d2p_xent_bwd_desc* descs, d2p_stream_t stream);
 

@@ -1205,6 +1205,47 @@ def test_loss_backward_of_three_decoders_and_their_projection_in_one_launch(K):
             assert float(q['dhout'][rows:].min()) == 9.0 and float(q['dlogits'][rows:].min()) == 9.0
 
 
+@pytest.mark.parametrize('U', [128, 512])
+def test_logits_computed_inside_the_loss_backward_launch(K, U):
+    """d2p_xent_bwd_desc.hout / .logits_out (round 4): the launch first computes logits = hout . proj (V = 50, 6, 5, 16
+    columns: every lane layout of the in-launch product -- one column group, K split across lane groups) and then
+    differentiates them.  logits against the fp64 product, dlogits / dhout against the same launch fed with those
+    logits (bit-identical), rows past n_steps untouched."""
+    g = torch.Generator().manual_seed(43 + U)
+    probs, fed = [], []
+    for (mode, kind, T, R, V, G) in (('softmax', 'bvl', 9, 5, 50, 1), ('softmax', 'rtv', 7, 12, 6, 3),
+                                     ('sigmoid', 'rtv', 7, 12, 5, 3)):
+        lens = torch.randint(1, T, (R,), generator=g)
+        n_steps = int(lens.max())
+        hout = (torch.rand(T, R, U, generator=g) * 2 - 1).cuda()
+        if mode == 'softmax':
+            lab = F.one_hot(torch.randint(0, V, (R, T), generator=g), V).float()
+        else:
+            lab = torch.randint(0, 2, (R, T, V), generator=g).float()
+        lab = lab * (torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)).unsqueeze(-1)
+        labels = (lab.permute(0, 2, 1) if kind == 'bvl' else lab).contiguous().cuda()
+        den = (torch.rand(G, generator=g) * 5 + 1).cuda()
+        proj = ((torch.rand(U, V, generator=g) * 2 - 1) * 0.3).cuda()
+        base = dict(mode=mode, labels=labels, lab_kind=kind, lens=lens.int().cuda(), T=T, R=R, V=V, G=G, n_steps=n_steps,
+                    den=den, scale=0.7, proj=proj, U=U)
+        probs.append(dict(base, logits=torch.full((T, R, V), 9.0, device='cuda'), hout=hout,
+                          dlogits=torch.full((T * R, V), 9.0, device='cuda'), dhout=torch.full((T * R, U), 9.0, device='cuda')))
+        fed.append(dict(base, dlogits=torch.full((T * R, V), 9.0, device='cuda'),
+                        dhout=torch.full((T * R, U), 9.0, device='cuda')))
+    K.xent_bwd_dhout_multi(probs)
+    for q, f in zip(probs, fed):
+        rows = q['n_steps'] * q['R']
+        lg = q['logits'].view(-1, q['V'])
+        want = q['hout'].view(-1, U)[:rows].double().cpu() @ q['proj'].double().cpu()
+        assert (lg[:rows].double().cpu() - want).abs().max().item() <= 2e-6 * max(1.0, want.abs().max().item()), q['V']
+        if rows < lg.shape[0]:
+            assert float(lg[rows:].min()) == 9.0
+        f['logits'] = q['logits']
+    K.xent_bwd_dhout_multi(fed)
+    for q, f in zip(probs, fed):
+        assert torch.equal(q['dlogits'], f['dlogits']) and torch.equal(q['dhout'], f['dhout'])
+
+
 # ------------------------------------------------------------------ wide-tile persistent forward kernel (round 4)
 def _wide_seq(M, T, U, masked, init, seed, lo=0):
     g = torch.Generator().manual_seed(seed)

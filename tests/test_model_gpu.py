@@ -100,6 +100,26 @@ def test_baseline_variants_match_oracle(kind, model, agg):
     assert _maxerr(m.greedy_pred_program, gref['greedy_pred_program']) <= 1e-4
 
 
+def test_config1_karel_synthesis_baseline_at_its_own_shape():
+    """BASELINE.json configs[0] at its own size: Karel synthesis_baseline, k = 2 demonstrations, batch 4, U = 512,
+    T = 20, L = 50 (the reference's CPU-runnable case) -- loss, logits and every gradient against the fp64 oracle."""
+    from demo2program_amd.models.model_full import Model
+    cfg, params, batch = small_case('karel', seed=41, model='synthesis_baseline', demo_aggregation='avgpool',
+                                    batch_size=4, k=2, max_demo_len=20, max_program_len=50, num_lstm_cell_units=512)
+    out, grads = run_oracle(cfg, params, batch, dtype=torch.float64)
+    m = Model(cfg, params=params)
+    loss = m.forward(m.get_feed_dict(batch))
+    m.backward()
+    ref = float(out['loss'])
+    assert abs(float(loss.item()) - ref) <= 1e-5 * abs(ref) + 1e-6
+    assert _maxerr(m.pred_program, out['pred_program']) <= 1e-4
+    g = m.params.to_numpy('g')
+    assert set(g) == set(grads)
+    for n, r in grads.items():
+        r = r.double().numpy()
+        assert np.abs(g[n] - r).max() <= 2e-4 * np.abs(r).max() + 1e-6, n
+
+
 def test_baseline_trains_through_the_trainer():
     from demo2program_amd.trainer import Trainer
     cfg, params, batch = small_case('karel', seed=31, model='summarizer')
@@ -1108,6 +1128,23 @@ def test_greedy_exact_match_on_1k_generated_programs():
 
 
 @pytest.mark.gpu
+def test_greedy_exact_match_at_the_vizdoom_geometry():
+    """The same exact-match check at BASELINE config 4's geometry (ViZDoom full model, k = 10, 80x80x3 frames, B = 32,
+    U = 512): 4 synthetic batches = 128 programs and 1 280 action sequences, weights after 40 optimizer steps, HIP
+    greedy decoders against the fp64 oracle's."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import exact_match_1k
+    res = exact_match_1k.run(n_batches=4, train_steps=40, n_train_batches=4, verbose=False, preset='vizdoom')
+    assert res['programs'] == 128
+    assert res['persistent_lstm_status'] == 0
+    assert res['unexcused_mismatches'] == 0, res['mismatches']
+    assert res['token_exact_rows'] + res['mismatches_excused_as_fp_ties'] == 128
+    assert res['max_abs_logit_err_on_exact_rows'] <= 1e-4
+    assert res['action_token_exact_sequences'] >= res['action_sequences'] - 13      # (1 % may be fp argmax ties)
+
+
+@pytest.mark.gpu
 def test_step_guard_skips_and_reruns_a_failed_step(monkeypatch):
     """The guarded optimizer step: with the persistent kernels' status word set (injected, as a timed-out hand-off
     sets it) the clip + Adam kernel skips its update ON THE DEVICE -- parameters, moments and the batch-norm moving
@@ -1155,9 +1192,11 @@ def test_step_guard_skips_and_reruns_a_failed_step(monkeypatch):
     # the re-run used the per-step kernels (forward bit-identical, backward equal to fp32 round-off)
     assert (tr.model.params.flat - want).abs().max().item() <= 2e-5 * want.abs().max().item()
     assert (tr.model.params.m - want_m).abs().max().item() <= 1e-4 * want_m.abs().max().item() + 1e-9
-    # the recurrence-dependent moving statistics saw each batch once; the conv layers' saw the failed batch twice
-    for n in ('rn_h/fc1', 'rn_c/fc2'):
-        assert (tr.model.moving[n][0] - want_mov[n][0]).abs().max().item() <= 1e-5
+    # every moving statistic saw each batch once: the conv layers' too, which had moved in the skipped step's forward pass
+    # and were restored from the guard's snapshot before the re-run (round 4)
+    for n in want_mov:
+        for q in (0, 1):
+            assert (tr.model.moving[n][q] - want_mov[n][q]).abs().max().item() <= 1e-5 * (1.0 + want_mov[n][q].abs().max().item()), n
     # run_single_step: detected in the same call, and the loss it reports is the re-run's
     class Src(object):
         def next(self):

@@ -29,7 +29,9 @@ TIE_GAP = 1e-4
 
 
 def run(n_batches=32, train_steps=300, n_train_batches=16, batch_size=32, k=10, units=512, verbose=True,
-        threads=16):
+        threads=16, preset='karel'):
+    """preset 'vizdoom': BASELINE config 4's geometry (80x80x3 frames) on synthetic batches -- the game engine is not
+    shipped, so there are no generated programs to execute; the decoders are compared all the same."""
     import oracle
     from helpers import oracle_config
     from demo2program_amd import build
@@ -45,8 +47,11 @@ def run(n_batches=32, train_steps=300, n_train_batches=16, batch_size=32, k=10, 
 
     build.build_library()
     torch.set_num_threads(min(os.cpu_count() or 1, threads))
-    cfg = make_config('karel', batch_size=batch_size, k=k, num_lstm_cell_units=units)
+    cfg = make_config(preset, batch_size=batch_size, k=k, num_lstm_cell_units=units)
     t0 = time.time()
+    if preset != 'karel':
+        from demo2program_amd.synthetic import make_batch
+        sample_batch = make_batch           # noqa: F811  (seeded synthetic batches of the preset's shape)
     train = [sample_batch(cfg, seed=9000 + i) for i in range(n_train_batches)]
     shard = [sample_batch(cfg, seed=5000 + i) for i in range(n_batches)]
     say('generated %d + %d batches in %.1f s' % (len(train), len(shard), time.time() - t0))
@@ -115,8 +120,8 @@ def run(n_batches=32, train_steps=300, n_train_batches=16, batch_size=32, k=10, 
             'action_sequences': act_rows, 'action_token_exact_sequences': act_exact,
             'max_abs_logit_err_on_exact_rows': max_logit_err,
             'rows_that_emit_the_end_token': ended,
-            'config': 'karel full model, B=%d, k=%d, U=%d, T=%d, L=%d' % (cfg.batch_size, cfg.k, units,
-                                                                         cfg.max_demo_len, cfg.max_program_len),
+            'config': '%s full model, B=%d, k=%d, U=%d, T=%d, L=%d' % (preset, cfg.batch_size, cfg.k, units,
+                                                                      cfg.max_demo_len, cfg.max_program_len),
             'weights': '%d Adam steps on %d other generated batches (final train loss %s)' %
                        (train_steps, n_train_batches, None if final_loss is None else round(final_loss, 4)),
             'checker': 'oracle.greedy_program_and_actions in fp64 (CPU restatement; TF-1.3 itself cannot run here)',

@@ -23,8 +23,15 @@ def main():
               (short, calls, tot / 1e6, avg / 1e3, mn / 1e3, mx / 1e3, 100.0 * tot / total, vg, ag, lds))
     print()
     print('total kernel time: %.3f ms over %d launches' % (total / 1e6, sum(r[1] for r in rows)))
+    # the number of optimizer steps in the trace is what the trace says, not what the caller remembers: one
+    # adam_clip_kernel launch per step (round 3's ViZDoom summary divided 21 traced steps by an argument of 8)
+    adam = sum(r[1] for r in rows if r[0].startswith('adam_clip'))
+    if adam:
+        if steps and abs(steps - adam) > 0.5:
+            print('(argument says %g steps, the trace holds %d optimizer steps: using the trace)' % (steps, adam))
+        steps = float(adam)
     if steps:
-        print('per training step (%g steps incl. warm-up): %.3f ms of kernel time, %.0f launches' %
+        print('per training step (%g steps incl. warm-up and extra legs): %.3f ms of kernel time, %.0f launches' %
               (steps, total / 1e6 / steps, sum(r[1] for r in rows) / steps))
 
 
