@@ -48,7 +48,7 @@ EMPTY_LAUNCH_US = 2.7          # a dependent empty launch on one stream (DESIGN.
 # kernel family -> key in profiles/*_pmc_traffic.json (tools/pmc_summary.py)
 PMC_KEYS = {1: 'gemm_mfma_kernel', 2: 'gemm_mfma_kernel<conv>', 7: 'lstm_persist_fwd_kernel',
             8: 'lstm_persist_bwd_kernel', 3: 'lstm_gate_fwd_kernel', 4: 'lstm_gate_bwd_kernel'}
-PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r03_pmc_traffic.json', 'r02_pmc_traffic.json',
+PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json',
                                                          'r01_pmc_traffic.json')]
 
 # profiling key (include/d2p.h) -> (name, roofline that bounds it, reporting group)
@@ -57,14 +57,14 @@ PROF_FAMILIES = {
     2: ('conv kernels (whole-frame / direct 16x16x4 MFMA / row-strip, implicit-GEMM fallback)', 'mfma', 'conv'),
     3: ('lstm_gate_fwd_kernel', 'hbm', 'gate'),
     4: ('lstm_gate_bwd_kernel', 'hbm', 'gate'),
-    7: ('recurrent forward (lstm_persist_fwd_kernel: one launch per sequence; lstm_step_fwd_kernel per step '
+    7: ('recurrent forward (lstm_persist_fwdw_kernel: one launch for up to three sequences; lstm_step_fwd_kernel per step '
         'for shapes it does not take)', 'mfma', 'recurrent'),
     8: ('recurrent backward (lstm_persist_bwd_kernel / lstm_step_bwd_kernel)', 'mfma', 'recurrent'),
 }
 GROUP_NAMES = {
     'gemm': 'gemm_mfma_kernel (dense fp32 MFMA GEMM, all instantiations)',
     'conv': 'conv kernels (forward + dgrad + wgrad of every encoder layer)',
-    'recurrent': 'recurrent LSTM kernels, forward + backward (lstm_persist_fwd_kernel + lstm_persist_bwd_kernel: '
+    'recurrent': 'recurrent LSTM kernels, forward + backward (lstm_persist_fwdw_kernel + lstm_persist_bwd_kernel: '
                  'h.Wh / dz.Wh^T fp32 MFMA + gate math for all time steps of a sequence in one launch)',
     'gate': 'standalone LSTM gate kernels',
 }

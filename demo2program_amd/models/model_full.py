@@ -198,6 +198,9 @@ class Model(object):
         if os.environ.get('D2P_BWD_DEFER_FROM') is not None:       # experiment: d2p_lstm_persist_set_bwd_defer
             from ..lib import call
             call.d2p_lstm_persist_set_bwd_defer(int(os.environ['D2P_BWD_DEFER_FROM']))
+        if os.environ.get('D2P_LSTM_XCD_LOCAL') is not None:       # A/B: 0 = write-through hand-offs in the wide forward kernel too
+            from ..lib import call
+            call.d2p_lstm_persist_set_fwd_wide(1, 0, 0, int(os.environ['D2P_LSTM_XCD_LOCAL']) & 1)
         K.bn_set_fold(int(os.environ.get('D2P_BN_FOLD', '0')))   # bit 0: ticket fold (no gain), bit 1: round-2 finalize
         # measurement hook (tools/step_ablation.py): D2P_ABLATE=conv_fwd,rn_bwd,... leaves pieces of the step out from the
         # second forward pass on (their outputs go stale: timing only, results invalid) -- what a piece is worth in

@@ -142,8 +142,11 @@ class StepGuard(object):
         # run before the recurrences, and on the ranks whose kernels did not fail every layer's do -- so a re-run
         # starts from the snapshot of the first skipped step
         self.moving = moving
-        self.moving_ring = None if moving is None else torch.zeros(self.DEPTH, moving.numel(), dtype=moving.dtype,
+        # (DEPTH + 1 rows: `snapshot_ahead` fills step n + 1's row during step n, BEFORE the poll in front of step n + 1
+        #  has looked at step n + 1 - DEPTH -- whose row must survive until then)
+        self.moving_ring = None if moving is None else torch.zeros(self.DEPTH + 1, moving.numel(), dtype=moving.dtype,
                                                                    device=moving.device)
+        self.ahead = -1                           # step index whose slot `snapshot_ahead` has filled
         self.events = [None] * self.DEPTH
         self.records = [None] * self.DEPTH        # (feed, global_step, adam_step) of the step in that slot
         self.n = 0                                # guarded steps launched
@@ -157,14 +160,30 @@ class StepGuard(object):
 
     def snapshot(self):
         """Before the forward pass of the next guarded step: its slot keeps the moving statistics of this moment (one
-        device copy of a few kilobytes, stream-ordered)."""
-        if self.moving_ring is not None:
-            self.moving_ring[self.n % self.DEPTH].copy_(self.moving, non_blocking=True)
+        device copy of a few kilobytes, stream-ordered).  Skipped when `snapshot_ahead` already filled the slot."""
+        if self.moving_ring is not None and self.ahead != self.n:
+            self.moving_ring[self.n % (self.DEPTH + 1)].copy_(self.moving, non_blocking=True)
+
+    def snapshot_ahead(self, stream):
+        """The NEXT step's snapshot, taken on `stream` (the model's side stream, behind this step's forward pass: nothing
+        moves the statistics until the next forward pass) instead of as a 4-us copy in front of the next step's first
+        kernel; the caller joins `stream` before that step starts (Model.backward does)."""
+        if self.moving_ring is None:
+            return
+        row = self.moving_ring[(self.n + 1) % (self.DEPTH + 1)]
+        if stream is None:                   # (the CPU protocol test: no streams)
+            row.copy_(self.moving)
+        else:
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                row.copy_(self.moving, non_blocking=True)
+        self.ahead = self.n + 1
 
     def restore(self, k):
         """The moving statistics as they were before the k-th last launched step."""
         if self.moving_ring is not None:
-            self.moving.copy_(self.moving_ring[(self.n - k) % self.DEPTH])
+            self.moving.copy_(self.moving_ring[(self.n - k) % (self.DEPTH + 1)])
+        self.ahead = -1                      # (a snapshot taken ahead saw the statistics this call just replaced)
 
     def launched(self, record):
         slot = self.n % self.DEPTH
@@ -323,6 +342,8 @@ class Trainer(object):
                 loss = self._graphed_forward_backward(feed, start)
             else:
                 loss = m.forward(feed, defer_loss=os.environ.get('D2P_DEFER_LOSS', '1') == '1')
+                if g is not None and getattr(m, 'use_side_stream', False) and not self._recovering:
+                    g.snapshot_ahead(m._side_stream())          # the next step's moving-statistics snapshot, off the critical path
                 m.backward(split_cb=start)
         finally:
             if per_step_after_split:
@@ -530,6 +551,7 @@ class Trainer(object):
         guard = self.guard
         if guard is not None:
             self.settle()                       # (a pending failure belongs to a training step, not to this batch)
+            guard.ahead = -1                    # (this forward pass moves the statistics: the next step snapshots afresh)
             guard.snapshot()                    # (slot of the NEXT training step: rewritten before it is used)
         loss = self.model.forward(feed)
         loss_value = float(loss.item())

@@ -79,9 +79,12 @@ class FakeModel(object):
         self.moving_flat = torch.zeros(64)
         self.moving = {'conv1': (self.moving_flat[:32], self.moving_flat[32:])}
         self.scheduled_sampling = False
-        self.use_side_stream = False
+        self.use_side_stream = True           # (so that the trainer takes the moving-statistics snapshots AHEAD, as on the GPU)
         self.calls = 0
         self.K = None
+
+    def _side_stream(self):
+        return None
 
     def decoder_grad_offset(self):
         return self.params.offsets['prog/embedding']

@@ -25,5 +25,6 @@ if __name__ == '__main__':
             a, b = timed(lambda: K.lstm_seq_bwd_multi(one)), timed(lambda: K.lstm_seq_bwd_multi(three))
             outs[on] = [t.clone() for t in (one[0]['dz'], one[0]['dh0'], one[0]['dc0'], one[0]['db'], three[2]['dz'])]
             print('descriptors %d: one sorted sequence %.1f us, three decoders %.1f us' % (on, a, b), flush=True)
+    lib.d2p_lstm_persist_set_bwd_desc(0)
     same = all(torch.equal(x, y) for x, y in zip(outs[0], outs[1]))
     print('results bit-identical: %s; error word 0x%x' % (same, K.lstm_persist_error(True)))
