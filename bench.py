@@ -130,7 +130,7 @@ def roofline_leg(trainer, feeds, steps=2):
     lib._d2p_prof_on = False
     trainer.model.use_side_stream = side
     if not rows:
-        return None, None, []
+        return None, None, [], []
     total_ms = sum(r['total_ms'] for r in rows)
     groups = {}
     for r in rows:
@@ -185,7 +185,9 @@ def roofline_leg(trainer, feeds, steps=2):
                   ms_per_step=round(r['total_ms'] / steps, 4),
                   rate=round(_rate(r['work'], r['total_ms'], r['bound']), 2),
                   unit='TFLOP/s' if r['bound'] == 'mfma' else 'GB/s') for r in rows]
-    return roof, furthest, table
+    # (the GEMM family and the recurrent family are within a few per cent of each other's summed time since round 4:
+    #  which of them `roofline` names changes from run to run -- every sizeable group is described here)
+    return roof, furthest, table, [describe(g) for g in sizeable]
 
 
 def recurrent_dense_flops(config, feed):
@@ -373,7 +375,7 @@ def config4_leg(steps=10, warmup=3):
                        % (cfg.k, cfg.h, cfg.w, cfg.depth, cfg.max_demo_len, cfg.batch_size),
            'steps': steps, 'ms_per_step': round(dt * 1e3, 4), 'value': round(cfg.batch_size / dt, 2),
            'unit': 'instances/s'}
-    _, _, table = roofline_leg(tr, feeds)
+    _, _, table, _ = roofline_leg(tr, feeds)
     conv = [r for r in table if r['group'] == 'conv']
     if conv:
         res['conv_encoder'] = {'achieved': conv[0]['rate'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
@@ -623,8 +625,9 @@ def main():
 
     if not args.no_roofline:
         log('roofline leg')
-        roof, furthest, table = roofline_leg(trainer, feeds)
+        roof, furthest, table, every = roofline_leg(trainer, feeds)
         out['roofline'] = roof
+        out['roofline_every_group'] = every
         out['furthest_below_roofline'] = furthest
         out['kernel_table'] = table
         if dp.rank == 0:

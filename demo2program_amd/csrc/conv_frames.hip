@@ -20,6 +20,8 @@
 #include "gemm_core.h"
 #include "prof.h"
 
+unsigned* d2p_persist_err_ptr();       // lstm_persist.hip: the status word of the guarded optimizer step
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define D2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
@@ -424,6 +426,430 @@ struct WgradLaunch {
         return 1;
     }
 };
+
+
+// ------------------------------------------------------------------------------------------
+// The whole Karel State_Encoder forward in ONE launch (round 4): three layers of
+// conv3x3 s2 SAME + bias + lrelu + batch norm (training mode, statistics per demonstration index: models/ops.py:14-33,
+// models/model_full.py:216-231,373-379), 8x8x16 -> 4x4x16 -> 2x2x32 -> 1x1x48, and the transpose to the time-major
+// feature rows the first LSTM reads.  The chain it replaces is 13 launches (3 conv + 3 x (partial sums, finalize,
+// apply) + transpose) of 5-10 us each: launch-bound (0.12 of the fp32 MFMA peak over the conv launches alone).
+//
+// A workgroup owns the frames of ONE demonstration index g for a few programs b (frames (b*G + g)*T .. +T-1): the
+// batch-norm statistics of a layer mix all frames of an index, so the S workgroups of an index meet at a barrier per
+// layer -- partial sums as write-through stores, an arrival counter per (launch slot, layer, index), every workgroup
+// adds the S partial sums in slice order (fp64: the same statistics as the bn_partial / finalize launches up to the
+// order of an fp64 sum).  A layer's activations never leave the CU on the way to the next layer: the epilogue writes
+// them into the next layer's LDS image (the padded pixel-major form conv_frames_fwd_kernel stages from memory), the
+// barrier's tail normalises that image in place.  What backward needs goes to memory on the way: a_l (pre-norm), y_l
+// (post-norm, the next layer's input), mean / rstd / var per (index, channel).
+// Needs the G*S workgroups co-resident (grid <= CUs, checked on the host); every spin is bounded and reports through the
+// persistent kernels' status word (the guarded optimizer step then skips the step and the trainer re-runs it on the
+// separate launches).
+#define ENC_SLOTS 64
+#define ENC_MAXG 32
+__device__ unsigned g_enc_counters[ENC_SLOTS][3][ENC_MAXG];
+
+struct EncArgs {
+    const void* x;
+    const float *w[3], *bias[3], *gamma[3], *beta[3];
+    float *a[3], *y[2];              // a_l [NF, Ho, Wo, C_l]; y_1, y_2 (y_3 only as feats_tm)
+    float* feats_tm;                 // [T, B*G, 48]
+    float *mean[3], *rstd[3], *var[3];   // [G, C_l]
+    double* part;                    // [3][G][S][48][2]
+    unsigned* counters;              // g_enc_counters
+    unsigned* err;
+    int B, G, T, S, nb, slot;
+};
+
+template <class SH>
+__device__ __forceinline__ void enc_filter(const float* __restrict__ w, int p, int q, float (&wr)[SH::NCH][4][SH::NB]) {
+#pragma unroll
+    for (int ch = 0; ch < SH::NCH; ++ch)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int b = 0; b < SH::NB; ++b)
+                wr[ch][j][b] = w[(nth_tap(SH::MASK, ch / SH::CB) * SH::CIN_ + (ch % SH::CB) * 16 + 4 * q + j) * (SH::NB * 16) + b * 16 + p];
+}
+template <class SH>
+__device__ __forceinline__ void enc_toff(int p, int q, int H, int W, int (&toff)[SH::NCH]) {
+    const int f = p / SH::HW, r = p % SH::HW, oy = r / SH::Wo, ox = r % SH::Wo;
+#pragma unroll
+    for (int ch = 0; ch < SH::NCH; ++ch) {
+        const int tap = nth_tap(SH::MASK, ch / SH::CB), ky = tap / 3, kx = tap % 3;
+        const int iy = 2 * oy - SH::PT + ky, ix = 2 * ox - SH::PL + kx;
+        const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        toff[ch] = ok ? ((f * H + iy) * W + ix) * SH::PSF + (ch % SH::CB) * 16 + 4 * q : -1;
+    }
+}
+
+// the barrier of layer `layer` among the S workgroups of index g: publish this workgroup's channel sums, wait for all
+// S, add them in slice order -> mean / rstd of (g, c) in LDS (and, from slice 0, in memory for backward)
+template <int C>
+__device__ __forceinline__ void enc_stats(const EncArgs& a, int layer, int g, int s, int n_per_group, const double* wsum,
+                                          float* mean_l, float* rstd_l, int* flag) {
+    const int tid = threadIdx.x;
+    double* mine = a.part + ((((long)layer * a.G + g) * a.S + s) * 48) * 2;
+    if (tid < C) {
+        // wsum: [4 waves][C][2] in LDS, added in wave order
+        double s0 = 0.0, s1 = 0.0;
+        for (int w = 0; w < 4; ++w) { s0 += wsum[(w * C + tid) * 2]; s1 += wsum[(w * C + tid) * 2 + 1]; }
+        __hip_atomic_store(mine + tid * 2, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + tid * 2 + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned* cnt = a.counters + ((long)a.slot * 3 + layer) * ENC_MAXG + g;
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.S) {
+            __builtin_amdgcn_s_sleep(2);
+            if (++spins > 400000u || ((spins & 1023u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(a.err, (0x7eu << 24) | 0x800000u | (blockIdx.x & 0xffffu), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    if (tid < C) {
+        double s0 = 0.0, s1 = 0.0;
+        const double* base = a.part + (((long)layer * a.G + g) * a.S * 48) * 2;
+        for (int s2 = 0; s2 < a.S; ++s2) {
+            s0 += __hip_atomic_load(base + ((long)s2 * 48 + tid) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s1 += __hip_atomic_load(base + ((long)s2 * 48 + tid) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        const double mu = s0 / n_per_group;
+        double var = s1 / n_per_group - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mu, r = (float)(1.0 / sqrt(var + 1e-3));
+        mean_l[tid] = m;
+        rstd_l[tid] = r;
+        if (s == 0) {
+            a.mean[layer][g * C + tid] = m;
+            a.rstd[layer][g * C + tid] = r;
+            a.var[layer][g * C + tid] = (float)var;
+        }
+    }
+    __syncthreads();
+}
+
+// per-lane channel sums of a wave's epilogue values -> wsum[wave][C][2]: lanes (p, q) hold channels 16b + 4q + r of
+// pixel p; the 16 pixel lanes of a quad are added by xor-shuffles (fixed order), lane p == 0 writes
+template <int NB>
+__device__ __forceinline__ void enc_fold_sums(const double (&sa)[NB][4], const double (&sb)[NB][4], int C, int wid, int p, int q,
+                                              double* wsum) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double u = sa[b][r], v = sb[b][r];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                u += __shfl_xor(u, off, 64);
+                v += __shfl_xor(v, off, 64);
+            }
+            if (p == 0) {
+                wsum[(wid * C + b * 16 + 4 * q + r) * 2] = u;
+                wsum[(wid * C + b * 16 + 4 * q + r) * 2 + 1] = v;
+            }
+        }
+}
+
+template <typename XT>
+__global__ void __launch_bounds__(256)
+karel_encoder_fwd_kernel(EncArgs a) {
+    using S1 = FrameShape<16, 16, 8, 8>;
+    using S2 = FrameShape<16, 32, 4, 4>;
+    using S3 = FrameShape<32, 48, 2, 2>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, q = lane >> 4, wid = tid >> 6;
+    const int g = blockIdx.x / a.S, s = blockIdx.x % a.S;
+    const int b0 = s * a.nb, nbl = min(a.nb, a.B - b0);
+    const int T = a.T, nfr = nbl > 0 ? nbl * T : 0;              // frames of this workgroup (local frame lf = bl*T + t)
+    const int nfr16 = (a.nb * T + 15) / 16 * 16;
+    // LDS: [conv1 staging: 4 waves x 2 images][IMG2: y1 of nfr frames][IMG3: y2][A3: a3][wsum][mean, rstd][flag]
+    float* stage1 = lds;
+    float* img2 = stage1 + 4 * 2 * S1::BUF;                       // nfr16 x 16 px x PSF2 (+ zero slot)
+    float* img3 = img2 + (size_t)nfr16 * 16 * S2::PSF + 4;        // nfr16 x 4 px x PSF3 (+ zero slot)
+    float* a3s = img3 + (size_t)nfr16 * 4 * S3::PSF + 4;          // nfr16 x 48
+    double* wsum = reinterpret_cast<double*>(a3s + (size_t)nfr16 * 48);      // [4][48][2]
+    float* mean_l = reinterpret_cast<float*>(wsum + 4 * 48 * 2);  // [48]
+    float* rstd_l = mean_l + 48;                                  // [48]
+    int* flag = reinterpret_cast<int*>(rstd_l + 48);
+    const int n1 = a.B * T * 16, n2 = a.B * T * 4, n3 = a.B * T;  // values per (index, channel) of each layer
+    auto frame_of = [&](int lf) { return ((long)(b0 + lf / T) * a.G + g) * T + (lf % T); };
+
+    // ================= layer 1: 8x8x16 -> 4x4x16, one frame per tile =================
+    {
+        float wr[S1::NCH][4][S1::NB];
+        enc_filter<S1>(a.w[0], p, q, wr);
+        int toff[S1::NCH];
+        enc_toff<S1>(p, q, 8, 8, toff);
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias[0] + 4 * q);
+        float* const im0 = stage1 + (size_t)wid * 2 * S1::BUF;
+        float* const im1 = im0 + S1::BUF;
+        if (lane == 0) {
+            *reinterpret_cast<f32x4*>(im0 + S1::NPIX * S1::PSF) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(im1 + S1::NPIX * S1::PSF) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int ch = 0; ch < S1::NCH; ++ch) if (toff[ch] < 0) toff[ch] = S1::NPIX * S1::PSF;
+        Stager<XT, S1> st;
+        st.init(lane);
+        const long total = (long)a.B * a.G * T * S1::CHUNK;
+        double sa[1][4] = {{0.0, 0.0, 0.0, 0.0}}, sb[1][4] = {{0.0, 0.0, 0.0, 0.0}};
+        int lf = wid;
+        if (lf < nfr) {
+            st.load(reinterpret_cast<const XT*>(a.x), (int)frame_of(lf), total, lane);
+            st.store(im0);
+        }
+        int par = 0;
+        while (lf < nfr) {
+            const float* rimg = par ? im1 : im0;
+            float* wimg = par ? im0 : im1;
+            const int nlf = lf + 4;
+            st.load(reinterpret_cast<const XT*>(a.x), (int)frame_of(nlf < nfr ? nlf : lf), total, lane);
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ch = 0; ch < S1::NCH; ++ch) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(rimg + toff[ch]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j & 1] = D2P_MFMA16(wr[ch][j][0], bb[j], acc[j & 1]);
+            }
+            f32x4 o = (acc[0] + acc[1]) + bv;
+            o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w);
+            *reinterpret_cast<f32x4*>(a.a[0] + (frame_of(lf) * 16 + p) * 16 + 4 * q) = o;
+            *reinterpret_cast<f32x4*>(img2 + ((size_t)lf * 16 + p) * S2::PSF + 4 * q) = o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sa[0][r] += (double)o[r]; sb[0][r] += (double)o[r] * (double)o[r]; }
+            st.store(wimg);
+            lf = nlf;
+            par ^= 1;
+        }
+        enc_fold_sums<1>(sa, sb, 16, wid, p, q, wsum);
+    }
+    __syncthreads();
+    enc_stats<16>(a, 0, g, s, n1, wsum, mean_l, rstd_l, flag);
+    // normalise IMG2 in place (-> y1, also to memory)
+    for (int i = tid; i < nfr * 16 * 4; i += 256) {
+        const int px = i >> 2, c4 = (i & 3) * 4, lf = px >> 4;
+        float* v = img2 + (size_t)px * S2::PSF + c4;
+        f32x4 x4 = *reinterpret_cast<f32x4*>(v), o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = a.gamma[0][c4 + r] * (x4[r] - mean_l[c4 + r]) * rstd_l[c4 + r] + a.beta[0][c4 + r];
+        *reinterpret_cast<f32x4*>(v) = o;
+        *reinterpret_cast<f32x4*>(a.y[0] + (frame_of(lf) * 16 + (px & 15)) * 16 + c4) = o;
+    }
+    if (tid == 0) *reinterpret_cast<f32x4*>(img2 + (size_t)nfr16 * 16 * S2::PSF) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // ================= layer 2: 4x4x16 -> 2x2x32, four frames per tile =================
+    {
+        float wr[S2::NCH][4][S2::NB];
+        enc_filter<S2>(a.w[1], p, q, wr);
+        int toff[S2::NCH];
+        enc_toff<S2>(p, q, 4, 4, toff);
+        f32x4 bv[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) bv[b] = *reinterpret_cast<const f32x4*>(a.bias[1] + b * 16 + 4 * q);
+        const int zero2 = nfr16 * 16 * S2::PSF;                      // the zero slot, relative to img2
+        double sa[2][4], sb[2][4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sa[b][r] = sb[b][r] = 0.0;
+        const int ntile = (nfr + 3) / 4;
+        for (int tile = wid; tile < ntile; tile += 4) {
+            f32x4 acc[2][2];
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[0][b] = acc[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < S2::NCH; ++ch) {
+                const int o_ = toff[ch] >= 0 ? tile * 4 * 16 * S2::PSF + toff[ch] : zero2;      // (a select of the offset, not of the load)
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(img2 + o_);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) acc[j & 1][b] = D2P_MFMA16(wr[ch][j][b], bb[j], acc[j & 1][b]);
+            }
+            const int lf = tile * 4 + p / 4, opx = p % 4;                 // this lane's frame and output pixel
+            if (lf < nfr) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    f32x4 o = (acc[0][b] + acc[1][b]) + bv[b];
+                    o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w);
+                    *reinterpret_cast<f32x4*>(a.a[1] + (frame_of(lf) * 4 + opx) * 32 + b * 16 + 4 * q) = o;
+                    *reinterpret_cast<f32x4*>(img3 + ((size_t)lf * 4 + opx) * S3::PSF + b * 16 + 4 * q) = o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sa[b][r] += (double)o[r]; sb[b][r] += (double)o[r] * (double)o[r]; }
+                }
+            }
+        }
+        enc_fold_sums<2>(sa, sb, 32, wid, p, q, wsum);
+    }
+    __syncthreads();
+    enc_stats<32>(a, 1, g, s, n2, wsum, mean_l, rstd_l, flag);
+    for (int i = tid; i < nfr * 4 * 8; i += 256) {
+        const int px = i >> 3, c4 = (i & 7) * 4, lf = px >> 2;
+        float* v = img3 + (size_t)px * S3::PSF + c4;
+        f32x4 x4 = *reinterpret_cast<f32x4*>(v), o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = a.gamma[1][c4 + r] * (x4[r] - mean_l[c4 + r]) * rstd_l[c4 + r] + a.beta[1][c4 + r];
+        *reinterpret_cast<f32x4*>(v) = o;
+        *reinterpret_cast<f32x4*>(a.y[1] + (frame_of(lf) * 4 + (px & 3)) * 32 + c4) = o;
+    }
+    if (tid == 0) *reinterpret_cast<f32x4*>(img3 + (size_t)nfr16 * 4 * S3::PSF) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    // ================= layer 3: 2x2x32 -> 1x1x48, sixteen frames per tile =================
+    {
+        float wr[S3::NCH][4][S3::NB];
+        enc_filter<S3>(a.w[2], p, q, wr);
+        int toff[S3::NCH];
+        enc_toff<S3>(p, q, 2, 2, toff);
+        f32x4 bv[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) bv[b] = *reinterpret_cast<const f32x4*>(a.bias[2] + b * 16 + 4 * q);
+        const int zero3 = nfr16 * 4 * S3::PSF;
+        double sa[3][4], sb[3][4];
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sa[b][r] = sb[b][r] = 0.0;
+        const int ntile = (nfr + 15) / 16;
+        for (int tile = wid; tile < ntile; tile += 4) {
+            f32x4 acc[2][3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) acc[0][b] = acc[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < S3::NCH; ++ch) {
+                const int o_ = toff[ch] >= 0 ? tile * 16 * 4 * S3::PSF + toff[ch] : zero3;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(img3 + o_);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) acc[j & 1][b] = D2P_MFMA16(wr[ch][j][b], bb[j], acc[j & 1][b]);
+            }
+            const int lf = tile * 16 + p;
+            if (lf < nfr) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    f32x4 o = (acc[0][b] + acc[1][b]) + bv[b];
+                    o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w);
+                    *reinterpret_cast<f32x4*>(a.a[2] + frame_of(lf) * 48 + b * 16 + 4 * q) = o;
+                    *reinterpret_cast<f32x4*>(a3s + (size_t)lf * 48 + b * 16 + 4 * q) = o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sa[b][r] += (double)o[r]; sb[b][r] += (double)o[r] * (double)o[r]; }
+                }
+            }
+        }
+        enc_fold_sums<3>(sa, sb, 48, wid, p, q, wsum);
+    }
+    __syncthreads();
+    enc_stats<48>(a, 2, g, s, n3, wsum, mean_l, rstd_l, flag);
+    // y3, time-major: feats_tm[t][m = b*G + g][48]
+    const long M = (long)a.B * a.G;
+    for (int i = tid; i < nfr * 12; i += 256) {
+        const int lf = i / 12, c4 = (i - lf * 12) * 4;
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(a3s + (size_t)lf * 48 + c4);
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = a.gamma[2][c4 + r] * (x4[r] - mean_l[c4 + r]) * rstd_l[c4 + r] + a.beta[2][c4 + r];
+        const long m = (long)(b0 + lf / T) * a.G + g;
+        *reinterpret_cast<f32x4*>(a.feats_tm + ((long)(lf % T) * M + m) * 48 + c4) = o;
+    }
+    // the counters of the slot ENC_SLOTS / 2 launches ahead are zeroed by this launch (one thread): a slot is reused
+    // ENC_SLOTS launches later, long after; a launch that gave up leaves garbage only in its own slot
+    if (blockIdx.x == 0 && tid < 3 * ENC_MAXG) {
+        unsigned* c = a.counters + (long)((a.slot + ENC_SLOTS / 2) % ENC_SLOTS) * 3 * ENC_MAXG;
+        __hip_atomic_store(c + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+static size_t enc_lds_bytes(int nb, int T) {
+    using S1 = FrameShape<16, 16, 8, 8>;
+    using S2 = FrameShape<16, 32, 4, 4>;
+    using S3 = FrameShape<32, 48, 2, 2>;
+    const size_t nfr16 = (size_t)(nb * T + 15) / 16 * 16;
+    return (4 * 2 * S1::BUF + nfr16 * 16 * S2::PSF + 4 + nfr16 * 4 * S3::PSF + 4 + nfr16 * 48 + 4 * 48 * 2 * 2 + 96 + 4) * sizeof(float);
+}
+static bool enc_plan(int B, int G, int T, int& S, int& nb) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return false;
+    if (B < 1 || G < 1 || G > ENC_MAXG || T < 4 || T % 4 != 0 || G > cus) return false;
+    S = cus / G < B ? cus / G : B;
+    nb = (B + S - 1) / S;
+    S = (B + nb - 1) / nb;                       // no empty slices
+    while (enc_lds_bytes(nb, T) > 150 * 1024) return false;
+    return true;
+}
+
+}   // namespace
+
+extern "C" size_t d2p_karel_encoder_ws_bytes(int B, int G, int T) {
+    int S = 0, nb = 0;
+    if (!enc_plan(B, G, T, S, nb)) return 0;
+    return (size_t)3 * G * S * 48 * 2 * sizeof(double);
+}
+
+// (declared in include/d2p.h)
+extern "C" int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_is_u8, const float* const* w,
+                                     const float* const* bias, const float* const* gamma, const float* const* beta,
+                                     float* const* a, float* const* y, float* feats_tm, float* const* mean,
+                                     float* const* rstd, float* const* var, void* ws, size_t ws_bytes,
+                                     d2p_stream_t stream) {
+    int S = 0, nb = 0;
+    D2P_REQUIRE(enc_plan(B, G, T, S, nb), D2P_EINVAL,
+                "karel encoder: B=%d G=%d T=%d does not fit one launch (T %% 4 == 0, G <= 32, G*S workgroups co-resident)", B, G, T);
+    D2P_REQUIRE(x && w && bias && gamma && beta && a && y && feats_tm && mean && rstd && var, D2P_EINVAL,
+                "karel encoder: null pointer");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_karel_encoder_ws_bytes(B, G, T), D2P_EWS, "karel encoder: workspace too small");
+    EncArgs e;
+    e.x = x;
+    for (int l = 0; l < 3; ++l) {
+        D2P_REQUIRE(w[l] && bias[l] && gamma[l] && beta[l] && a[l] && mean[l] && rstd[l] && var[l] && (l == 2 || y[l]),
+                    D2P_EINVAL, "karel encoder: null pointer (layer %d)", l + 1);
+        e.w[l] = w[l]; e.bias[l] = bias[l]; e.gamma[l] = gamma[l]; e.beta[l] = beta[l];
+        e.a[l] = a[l]; e.mean[l] = mean[l]; e.rstd[l] = rstd[l]; e.var[l] = var[l];
+        if (l < 2) e.y[l] = y[l];
+        D2P_REQUIRE((((uintptr_t)a[l] | (uintptr_t)bias[l]) & 15) == 0 && (l == 2 || ((uintptr_t)y[l] & 15) == 0), D2P_EALIGN,
+                    "karel encoder: 16-byte alignment (layer %d)", l + 1);
+    }
+    D2P_REQUIRE((((uintptr_t)x | (uintptr_t)feats_tm) & 15) == 0, D2P_EALIGN, "karel encoder: 16-byte alignment");
+    e.feats_tm = feats_tm;
+    e.part = (double*)ws;
+    static unsigned* counters = nullptr;
+    if (!counters) D2P_HIP(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_enc_counters)));
+    e.counters = counters;
+    e.err = d2p_persist_err_ptr();
+    e.B = B; e.G = G; e.T = T; e.S = S; e.nb = nb;
+    static unsigned seq = 0;
+    e.slot = (int)(seq++ % ENC_SLOTS);
+    const size_t lds = enc_lds_bytes(nb, T);
+    hipStream_t st = as_stream(stream);
+    // conv flops of the three layers (as the separate launches count them)
+    const double nf = (double)B * G * T;
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * nf * (16 * 144 * 16 + 4 * 144 * 32 + 1 * 288 * 48));
+    static bool attr = false;
+    if (!attr) {
+        D2P_HIP(hipFuncSetAttribute((const void*)karel_encoder_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        D2P_HIP(hipFuncSetAttribute((const void*)karel_encoder_fwd_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (x_is_u8) hipLaunchKernelGGL(karel_encoder_fwd_kernel<uint8_t>, dim3(G * S), dim3(256), lds, st, e);
+    else hipLaunchKernelGGL(karel_encoder_fwd_kernel<float>, dim3(G * S), dim3(256), lds, st, e);
+    D2P_LAUNCH_CHECK("karel_encoder_fwd");
+    return D2P_OK;
+}
+
+namespace {
 
 }   // namespace
 

@@ -195,6 +195,22 @@ def conv_fwd(x, w, bias, act=1, out=None):
     return out
 
 
+def karel_encoder_ok(B, G, T):
+    """whether the one-launch State_Encoder forward (d2p_karel_encoder_fwd) takes this batch geometry"""
+    return _load_lib().d2p_karel_encoder_ws_bytes(B, G, T) > 0
+
+
+def karel_encoder_fwd(x, B, G, T, w, bias, gamma, beta, a, y, feats_tm, mean, rstd, var, ws):
+    """x [B*G*T, 8, 8, 16] fp32 / uint8; w, bias, gamma, beta, a, mean, rstd, var: three tensors each (layers 1-3),
+    y: two (layers 1-2); feats_tm [T, B*G, 48]; ws: a uint8 buffer of d2p_karel_encoder_ws_bytes(B, G, T)."""
+    _require_gpu(x, feats_tm, ws)
+    import ctypes
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[ptr(t) for t in ts])        # noqa: E731
+    call.d2p_karel_encoder_fwd(B, G, T, ptr(x), 1 if x.dtype == torch.uint8 else 0, arr(w), arr(bias), arr(gamma),
+                               arr(beta), arr(a), arr(y), ptr(feats_tm), arr(mean), arr(rstd), arr(var), ptr(ws),
+                               ws.numel() * ws.element_size(), current_stream())
+
+
 def conv_wgrad(x, dy, dw):
     _require_gpu(x, dy, dw)
     N, H, W, Cin = x.shape

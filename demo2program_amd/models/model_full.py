@@ -145,6 +145,7 @@ class Model(object):
         self._feed = None
         self._ctx = None
         self._conv = conv_shapes(config)
+        self._fused_enc_ok = {}
         self.feature_dim = feature_dim(config)
         # non-trainable BN moving statistics (updated inline, once per reference call): views of ONE buffer
         # (`moving_flat`), so that the trainer's step guard snapshots / restores all of them with a single device copy
@@ -456,7 +457,12 @@ class Model(object):
         # ---- State_Encoder: conv -> +bias -> lrelu -> BN(train), per demo-index statistics
         x = feed['s_h']
         ctx['conv'] = []
+        feats_tm = None
+        if self._fused_encoder(B, k, T) and not self._abl('conv_fwd'):
+            feats_tm = self._encoder_fwd_fused(x, ctx, main, side)
         for l, (h, w, cin, cout, ho, wo) in enumerate(self._conv, start=1):
+            if feats_tm is not None:
+                break
             if self._abl('conv_fwd'):
                 ctx['conv'], x = self._abl_cache['conv']
                 break
@@ -476,9 +482,10 @@ class Model(object):
                                          p['conv%d/gamma' % l], p['conv%d/beta' % l], k, T * ho * wo)
             ctx['conv'].append((x, a, mean, rstd))
             x = y.view(NF, ho, wo, cout)
-        self._abl_cache['conv'] = (ctx['conv'], x)
-        feats = x.view(M, T, F)
-        feats_tm = K.transpose_rt(feats, M, T, F, out=self._buf('feats_tm', (T, M, F)))
+        if feats_tm is None:
+            self._abl_cache['conv'] = (ctx['conv'], x)
+            feats = x.view(M, T, F)
+            feats_tm = K.transpose_rt(feats, M, T, F, out=self._buf('feats_tm', (T, M, F)))
 
         # (rows past their sequence: neither their projection nor, in backward, their input gradient is computed --
         #  the recurrence selects around what it reads there, D2P_ACTIVE_XPROJ=0: all rows)
@@ -774,6 +781,48 @@ class Model(object):
         if getattr(self, '_side', None) is None:
             self._side = pick_concurrent_stream()
         return self._side
+
+    _KAREL_CONV = [(8, 8, 16, 16, 4, 4), (4, 4, 16, 32, 2, 2), (2, 2, 32, 48, 1, 1)]
+
+    def _fused_encoder(self, B, k, T):
+        """the State_Encoder's forward pass as ONE launch (d2p_karel_encoder_fwd): training mode, Karel's 8x8x16
+        frames, a batch whose workgroups are co-resident (D2P_FUSED_ENCODER=0: the 13 separate launches)"""
+        if not self.is_train or os.environ.get('D2P_FUSED_ENCODER', '1') != '1':
+            return False
+        if [tuple(c) for c in self._conv] != self._KAREL_CONV:
+            return False
+        key = (B, k, T)
+        if key not in self._fused_enc_ok:
+            self._fused_enc_ok[key] = K.karel_encoder_ok(B, k, T)
+        return self._fused_enc_ok[key]
+
+    def _encoder_fwd_fused(self, x, ctx, main, side):
+        c, p = self.config, self.params.p
+        B, k, T = c.batch_size, c.k, c.max_demo_len
+        M, NF = B * k, B * k * T
+        names = ['conv%d' % l for l in (1, 2, 3)]
+        a = [self._buf(n + '/a', (NF, ho, wo, cout)) for n, (_, _, _, cout, ho, wo) in zip(names, self._conv)]
+        y = [self._buf(n + '/bn_y', (NF * ho * wo, cout)) for n, (_, _, _, cout, ho, wo) in zip(names[:2], self._conv)]
+        mean = [self._buf(n + '/bn_mean', (k, cv[3])) for n, cv in zip(names, self._conv)]
+        rstd = [self._buf(n + '/bn_rstd', (k, cv[3])) for n, cv in zip(names, self._conv)]
+        var = [self._buf(n + '/bn_var', (k, cv[3])) for n, cv in zip(names, self._conv)]
+        feats_tm = self._buf('feats_tm', (T, M, self.feature_dim))
+        ws = self._buf('enc/ws', (K._load_lib().d2p_karel_encoder_ws_bytes(B, k, T),), torch.uint8)
+        K.karel_encoder_fwd(x, B, k, T, [p[n + '/W'] for n in names], [p[n + '/b'] for n in names],
+                            [p[n + '/gamma'] for n in names], [p[n + '/beta'] for n in names], a, y, feats_tm,
+                            mean, rstd, var, ws)
+        if self.track_moving:
+            # the k moving-average updates of each layer (one per reference BN call, in group order): nothing in the
+            # step reads them -- beside the recurrences
+            st = side if self.use_side_stream else main
+            if st is not main:
+                st.wait_stream(main)
+            with torch.cuda.stream(st):
+                for n, m_, v_ in zip(names, mean, var):
+                    K.bn_update_moving(m_, v_, *self.moving[n])
+        xin = [x, y[0].view(NF, 4, 4, 16), y[1].view(NF, 2, 2, 32)]
+        ctx['conv'] = [(xin[l], a[l], mean[l], rstd[l]) for l in range(3)]
+        return feats_tm
 
     def _bn_fwd(self, name, x2d, gamma, beta, G, inner, y=None):
         R, C = x2d.shape

@@ -188,6 +188,23 @@ int d2p_bn_group_bwd_batched(int nb, long xs, long ys, long ps, int R, int C, in
                              const float* dy, const float* gamma, const float* mean, const float* rstd,
                              int act_bwd, float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* ws,
                              size_t ws_bytes, d2p_stream_t stream);
+/* The Karel State_Encoder's forward pass in ONE launch (models/model_full.py:362-381 of the reference: three times
+ * conv 3x3 stride 2 SAME -> +bias -> leaky ReLU 0.2 -> batch norm with the statistics of one demonstration index, on
+ * 8x8x16 frames): frames x [B, G, T, 8, 8, 16] (fp32, or uint8 with x_is_u8), layer l's filters w[l] [3,3,Cin,Cout]
+ * (16->16, 16->32, 32->48), bias / gamma / beta [Cout].  Writes what the separate launches write: a[l] the
+ * activations before normalisation ([NF,4,4,16], [NF,2,2,32], [NF,48]; NF = B*G*T), y[0], y[1] the normalised
+ * outputs of layers 1 and 2, feats_tm [T, B*G, 48] the normalised features time-major, mean / rstd / var [l] [G, Cout]
+ * (biased variance; feed d2p_bn_update_moving).  w .. var are HOST arrays of three device pointers (y: two).
+ * One workgroup holds the frames of a slice of the programs of one demonstration index in LDS through all three
+ * layers; the workgroups of an index exchange their fp64 partial sums through ws (d2p_karel_encoder_ws_bytes)
+ * and an arrival counter, so all G*S workgroups must be co-resident: D2P_EINVAL when B, G, T do not allow that
+ * (T % 4 != 0, G > 32, more frames per workgroup than LDS holds) -- callers fall back to the separate launches.
+ * A workgroup that waits too long for its group sets the status word of d2p_lstm_persist_error (code 0x7e). */
+size_t d2p_karel_encoder_ws_bytes(int B, int G, int T);   /* 0: geometry not supported */
+int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_is_u8, const float* const* w,
+                          const float* const* bias, const float* const* gamma, const float* const* beta,
+                          float* const* a, float* const* y, float* feats_tm, float* const* mean,
+                          float* const* rstd, float* const* var, void* ws, size_t ws_bytes, d2p_stream_t stream);
 /* d2p_bn_group_fwd's moving_mean / moving_var ([C], nullable together): the G moving-average
  * updates of this call (one per group = one per reference BN call, in group order) are applied
  * by the statistics kernel itself; d2p_bn_update_moving below is the same update stand-alone. */

@@ -1356,3 +1356,75 @@ def test_lstm_wide_forward_long_sequence(K):
     """thousands of hand-offs per workgroup, sorted and not: rare stale reads would surface here"""
     _wide_check(K, [_wide_seq(320, 160, 512, True, True, 21)], reps=2)
     _wide_check(K, [_wide_seq(320, 160, 512, True, True, 21)], sort=True, reps=2)
+
+
+# ---------------------------------------------------------------- the Karel State_Encoder forward in one launch
+def _encoder_chain(K, x, B, G, T, prm):
+    """the separate launches: conv -> bn(train) three times, then the time-major transpose"""
+    NF = B * G * T
+    out = dict(a=[], y=[], mean=[], rstd=[], var=[])
+    cur = x
+    for l, (cout, hw) in enumerate(((16, 4), (32, 2), (48, 1))):
+        a = K.conv_fwd(cur, prm['w'][l], prm['b'][l], act=1)
+        var = torch.empty(G, cout, device='cuda')
+        y, mean, rstd, _ = K.bn_fwd(a.view(NF * hw * hw, cout), prm['gamma'][l], prm['beta'][l], G, T * hw * hw, var=var)
+        out['a'].append(a); out['y'].append(y); out['mean'].append(mean); out['rstd'].append(rstd); out['var'].append(var)
+        cur = y.view(NF, hw, hw, cout)
+    out['feats_tm'] = out['y'][2].view(B * G, T, 48).transpose(0, 1).contiguous()
+    return out
+
+
+@pytest.mark.parametrize('B,G,T,u8', [(32, 10, 20, True), (32, 10, 20, False), (5, 3, 8, True), (1, 1, 4, False),
+                                     (40, 10, 20, True), (7, 32, 12, True), (64, 10, 8, False)])
+def test_karel_encoder_one_launch_matches_the_separate_launches(K, B, G, T, u8):
+    """d2p_karel_encoder_fwd against conv -> batch norm x 3 (models/model_full.py:362-381 of the reference): the
+    same values to fp32 summation order, and the statistics / normalised outputs consistent with the activations
+    the launch itself wrote (checked in fp64 on the host)."""
+    if not K.karel_encoder_ok(B, G, T):
+        pytest.skip('geometry not taken by the one-launch kernel on this device')
+    g = torch.Generator().manual_seed(B * 1000 + G * 10 + T)
+    NF = B * G * T
+    if u8:
+        x = (torch.rand(NF, 8, 8, 16, generator=g) < 0.15).to(torch.uint8).cuda()
+    else:
+        x = torch.randn(NF, 8, 8, 16, generator=g).cuda()
+    prm = dict(w=[], b=[], gamma=[], beta=[])
+    for cin, cout in ((16, 16), (16, 32), (32, 48)):
+        prm['w'].append((torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda())
+        prm['b'].append((torch.randn(cout, generator=g) * 0.1).cuda())
+        prm['gamma'].append((1 + 0.2 * torch.randn(cout, generator=g)).cuda())
+        prm['beta'].append((0.1 * torch.randn(cout, generator=g)).cuda())
+    ref = _encoder_chain(K, x, B, G, T, prm)
+    nan = float('nan')
+    a = [torch.full((NF, 4, 4, 16), nan, device='cuda'), torch.full((NF, 2, 2, 32), nan, device='cuda'),
+         torch.full((NF, 1, 1, 48), nan, device='cuda')]
+    y = [torch.full((NF * 16, 16), nan, device='cuda'), torch.full((NF * 4, 32), nan, device='cuda')]
+    stat = lambda: [torch.full((G, c), nan, device='cuda') for c in (16, 32, 48)]       # noqa: E731
+    mean, rstd, var = stat(), stat(), stat()
+    feats_tm = torch.full((T, B * G, 48), nan, device='cuda')
+    ws = torch.empty(K._load_lib().d2p_karel_encoder_ws_bytes(B, G, T), dtype=torch.uint8, device='cuda')
+    for rep in range(3):                                      # (the arrival counters of three slots)
+        K.karel_encoder_fwd(x, B, G, T, prm['w'], prm['b'], prm['gamma'], prm['beta'], a, y, feats_tm, mean, rstd,
+                            var, ws)
+        torch.cuda.synchronize()
+        assert K.lstm_persist_error() == 0
+        for l in range(3):
+            # (the separate launches pick their conv kernel by shape -- not the same summation order everywhere)
+            torch.testing.assert_close(a[l], ref['a'][l], rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(mean[l], ref['mean'][l], rtol=1e-5, atol=1e-5)
+            torch.testing.assert_close(var[l], ref['var'][l], rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(rstd[l], ref['rstd'][l], rtol=1e-4, atol=0)
+        for l in range(2):
+            torch.testing.assert_close(y[l], ref['y'][l], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(feats_tm, ref['feats_tm'], rtol=1e-4, atol=1e-4)
+        # the statistics are those of the activations this launch wrote (fp64 on the host)
+        for l, hw in enumerate((4, 2, 1)):
+            c = a[l].shape[-1]
+            v = a[l].double().view(B, G, T * hw * hw, c).permute(1, 0, 2, 3).reshape(G, -1, c)
+            torch.testing.assert_close(mean[l].double(), v.mean(1), rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(var[l].double(), v.var(1, unbiased=False), rtol=1e-5, atol=1e-8)
+            yl = (prm['gamma'][l].double() * (v - mean[l].double()[:, None]) * rstd[l].double()[:, None]
+                  + prm['beta'][l].double()).view(G, B, T * hw * hw, c).permute(1, 0, 2, 3)
+            got = y[l].view(B, G, T * hw * hw, c) if l < 2 else feats_tm.transpose(0, 1).reshape(B, G, T, c)
+            torch.testing.assert_close(got.double(), yl, rtol=1e-5, atol=1e-5)
+        feats_tm.fill_(nan)

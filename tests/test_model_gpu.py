@@ -1280,3 +1280,32 @@ def test_hand_built_feed_without_the_derived_perception_rows():
     l2 = float(m.forward(bare).item())
     m.backward()
     assert l1 == l2 and torch.equal(g1, m.params.grad)
+
+
+def test_one_launch_state_encoder_equals_the_separate_launches(monkeypatch):
+    """D2P_FUSED_ENCODER (d2p_karel_encoder_fwd: the three conv -> batch-norm layers of the Karel State_Encoder in one
+    launch) against the 13 separate launches at the headline geometry: same loss and gradients to fp32 rounding of the
+    batch statistics, same moving statistics."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.config import make_config
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.synthetic import make_batch
+    cfg = make_config('karel', batch_size=32, k=10, num_lstm_cell_units=128)
+    if not K.karel_encoder_ok(32, 10, cfg.max_demo_len):
+        pytest.skip('geometry not taken by the one-launch kernel on this device')
+    batch = make_batch(cfg, seed=3)
+    res = []
+    m = Model(cfg, seed=5)
+    mov0 = m.moving_flat.clone()
+    for fused in ('0', '1'):
+        monkeypatch.setenv('D2P_FUSED_ENCODER', fused)
+        m.moving_flat.copy_(mov0)
+        loss = float(m.forward(m.get_feed_dict(batch)).item())
+        m.backward()
+        torch.cuda.synchronize()
+        assert K.lstm_persist_error() == 0
+        res.append((loss, m.params.grad.clone(), m.moving_flat.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0])
+    scale = float(res[0][1].abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * scale
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-6, atol=1e-7)

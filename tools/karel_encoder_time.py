@@ -1,0 +1,63 @@
+#!/usr/bin/env python
+"""Microseconds per call of the one-launch Karel State_Encoder forward (d2p_karel_encoder_fwd) and of the separate
+launches it replaces (conv -> batch norm x 3 + transpose), at the headline geometry (B=32, k=10, T=20, uint8 frames).
+
+  python tools/karel_encoder_time.py [B] [G] [T]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from demo2program_amd import build, kernels as K  # noqa: E402
+
+
+def timed(fn, reps=50):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps
+
+
+def main():
+    build.build_library()
+    B, G, T = [int(v) for v in sys.argv[1:4]] if len(sys.argv) > 3 else (32, 10, 20)
+    NF = B * G * T
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(NF, 8, 8, 16, generator=g) < 0.15).to(torch.uint8).cuda()
+    w = [(torch.randn(3, 3, ci, co, generator=g) * 0.1).cuda() for ci, co in ((16, 16), (16, 32), (32, 48))]
+    b = [torch.zeros(c, device='cuda') for c in (16, 32, 48)]
+    gam = [torch.ones(c, device='cuda') for c in (16, 32, 48)]
+    bet = [torch.zeros(c, device='cuda') for c in (16, 32, 48)]
+    a = [torch.empty(NF, 4, 4, 16, device='cuda'), torch.empty(NF, 2, 2, 32, device='cuda'),
+         torch.empty(NF, 1, 1, 48, device='cuda')]
+    y = [torch.empty(NF * 16, 16, device='cuda'), torch.empty(NF * 4, 32, device='cuda'), torch.empty(NF, 48, device='cuda')]
+    stat = lambda: [torch.empty(G, c, device='cuda') for c in (16, 32, 48)]       # noqa: E731
+    mean, rstd, var = stat(), stat(), stat()
+    feats_tm = torch.empty(T, B * G, 48, device='cuda')
+    ws = torch.empty(max(1, K._load_lib().d2p_karel_encoder_ws_bytes(B, G, T)), dtype=torch.uint8, device='cuda')
+
+    def fused():
+        K.karel_encoder_fwd(x, B, G, T, w, b, gam, bet, a, y[:2], feats_tm, mean, rstd, var, ws)
+
+    def chain():
+        cur = x
+        for l, (cout, hw) in enumerate(((16, 4), (32, 2), (48, 1))):
+            K.conv_fwd(cur, w[l], b[l], act=1, out=a[l])
+            K.bn_fwd(a[l].view(NF * hw * hw, cout), gam[l], bet[l], G, T * hw * hw, y=y[l], mean=mean[l], rstd=rstd[l])
+            cur = y[l].view(NF, hw, hw, cout)
+        K.transpose_rt(y[2].view(B * G, T, 48), B * G, T, 48, out=feats_tm)
+    print('separate launches: %.1f us' % timed(chain))
+    if K.karel_encoder_ok(B, G, T):
+        print('one launch:        %.1f us' % timed(fused))
+    print('error word: 0x%x' % K.lstm_persist_error())
+
+
+if __name__ == '__main__':
+    main()
