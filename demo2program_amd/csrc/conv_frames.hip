@@ -23,6 +23,7 @@
 unsigned* d2p_persist_err_ptr();       // lstm_persist.hip: the status word of the guarded optimizer step
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 #define D2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 namespace {
@@ -460,6 +461,7 @@ struct EncArgs {
     unsigned* counters;              // g_enc_counters
     unsigned* err;
     int B, G, T, S, nb, slot;
+    unsigned long long* trace;       // diagnostic (d2p_karel_encoder_set_trace): [workgroup][10] wall-clock stamps, or null
 };
 
 template <class SH>
@@ -486,17 +488,28 @@ __device__ __forceinline__ void enc_toff(int p, int q, int H, int W, int (&toff)
 
 // the barrier of layer `layer` among the S workgroups of index g: publish this workgroup's channel sums, wait for all
 // S, add them in slice order -> mean / rstd of (g, c) in LDS (and, from slice 0, in memory for backward)
+#define ENC_AUX_SC1 16          // buffer-instruction cache policy: sc1 (agent scope: the partial sums cross XCDs)
+#define ENC_OOB 0x7fffff00      // an offset past every buffer: the load returns zeros
+
+// Statistics of layer `layer`, index g, from the S workgroups of the index: each writes its fp64 partial sums (write-through),
+// counts itself in and waits for the others; then the S x C pairs are read by the whole workgroup at once (R = 256 / C
+// threads per channel, each summing the slices r, r + R, ... -- independent loads in flight -- then the R sums in order:
+// the same order in every workgroup, so all of them normalise with the same bits).
 template <int C>
-__device__ __forceinline__ void enc_stats(const EncArgs& a, int layer, int g, int s, int n_per_group, const double* wsum,
+__device__ __forceinline__ void enc_stats(const EncArgs& a, int layer, int g, int s, int n_per_group, double* wsum,
                                           float* mean_l, float* rstd_l, int* flag) {
+    constexpr int R = 256 / C;
     const int tid = threadIdx.x;
-    double* mine = a.part + ((((long)layer * a.G + g) * a.S + s) * 48) * 2;
+    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
+        a.part + ((long)layer * a.G + g) * a.S * 96, 0, a.S * 96 * (int)sizeof(double), 0x00020000);
     if (tid < C) {
         // wsum: [4 waves][C][2] in LDS, added in wave order
         double s0 = 0.0, s1 = 0.0;
         for (int w = 0; w < 4; ++w) { s0 += wsum[(w * C + tid) * 2]; s1 += wsum[(w * C + tid) * 2 + 1]; }
-        __hip_atomic_store(mine + tid * 2, s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + tid * 2 + 1, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double pr[2] = {s0, s1};
+        i32x4 pv;
+        __builtin_memcpy(&pv, pr, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(pv, res, (s * 48 + tid) * 16, 0, ENC_AUX_SC1);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -506,8 +519,8 @@ __device__ __forceinline__ void enc_stats(const EncArgs& a, int layer, int g, in
         unsigned spins = 0;
         int ok = 1;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.S) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > 400000u || ((spins & 1023u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 800000u || ((spins & 1023u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(a.err, (0x7eu << 24) | 0x800000u | (blockIdx.x & 0xffffu), __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_AGENT);
                 ok = 0;
@@ -517,22 +530,43 @@ __device__ __forceinline__ void enc_stats(const EncArgs& a, int layer, int g, in
         *flag = ok;
     }
     __syncthreads();
+    {
+        const int r = tid / C, c = tid - r * C;
+        if (r < R) {
+            double p0 = 0.0, p1 = 0.0;
+            for (int s2 = r; s2 < a.S; s2 += 4 * R) {
+                i32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sx = s2 + u * R;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(res, sx < a.S ? (sx * 48 + c) * 16 : ENC_OOB, 0, ENC_AUX_SC1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double pr[2];
+                    __builtin_memcpy(pr, &v[u], 16);
+                    p0 += pr[0];
+                    p1 += pr[1];
+                }
+            }
+            wsum[(r * C + c) * 2] = p0;
+            wsum[(r * C + c) * 2 + 1] = p1;
+        }
+    }
+    __syncthreads();
     if (tid < C) {
         double s0 = 0.0, s1 = 0.0;
-        const double* base = a.part + (((long)layer * a.G + g) * a.S * 48) * 2;
-        for (int s2 = 0; s2 < a.S; ++s2) {
-            s0 += __hip_atomic_load(base + ((long)s2 * 48 + tid) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s1 += __hip_atomic_load(base + ((long)s2 * 48 + tid) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) { s0 += wsum[(r * C + tid) * 2]; s1 += wsum[(r * C + tid) * 2 + 1]; }
         const double mu = s0 / n_per_group;
         double var = s1 / n_per_group - mu * mu;
         if (var < 0.0) var = 0.0;
-        const float m = (float)mu, r = (float)(1.0 / sqrt(var + 1e-3));
+        const float m = (float)mu, rs = (float)(1.0 / sqrt(var + 1e-3));
         mean_l[tid] = m;
-        rstd_l[tid] = r;
+        rstd_l[tid] = rs;
         if (s == 0) {
             a.mean[layer][g * C + tid] = m;
-            a.rstd[layer][g * C + tid] = r;
+            a.rstd[layer][g * C + tid] = rs;
             a.var[layer][g * C + tid] = (float)var;
         }
     }
@@ -578,13 +612,14 @@ karel_encoder_fwd_kernel(EncArgs a) {
     float* img2 = stage1 + 4 * 2 * S1::BUF;                       // nfr16 x 16 px x PSF2 (+ zero slot)
     float* img3 = img2 + (size_t)nfr16 * 16 * S2::PSF + 4;        // nfr16 x 4 px x PSF3 (+ zero slot)
     float* a3s = img3 + (size_t)nfr16 * 4 * S3::PSF + 4;          // nfr16 x 48
-    double* wsum = reinterpret_cast<double*>(a3s + (size_t)nfr16 * 48);      // [4][48][2]
-    float* mean_l = reinterpret_cast<float*>(wsum + 4 * 48 * 2);  // [48]
+    double* wsum = reinterpret_cast<double*>(a3s + (size_t)nfr16 * 48);      // [4][48][2], then [R][C][2] (<= 512)
+    float* mean_l = reinterpret_cast<float*>(wsum + 512);         // [48]
     float* rstd_l = mean_l + 48;                                  // [48]
     int* flag = reinterpret_cast<int*>(rstd_l + 48);
     const int n1 = a.B * T * 16, n2 = a.B * T * 4, n3 = a.B * T;  // values per (index, channel) of each layer
     auto frame_of = [&](int lf) { return ((long)(b0 + lf / T) * a.G + g) * T + (lf % T); };
 
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 0] = wall_clock64();
     // ================= layer 1: 8x8x16 -> 4x4x16, one frame per tile =================
     {
         float wr[S1::NCH][4][S1::NB];
@@ -600,42 +635,58 @@ karel_encoder_fwd_kernel(EncArgs a) {
         }
 #pragma unroll
         for (int ch = 0; ch < S1::NCH; ++ch) if (toff[ch] < 0) toff[ch] = S1::NPIX * S1::PSF;
-        Stager<XT, S1> st;
-        st.init(lane);
+        // frame i of this wave: lf = wid + 4 i.  D frames ahead in registers (the HBM latency of a 1-KB frame is several
+        // frames' products), the next frame's image written to the other LDS buffer before this frame's products
+        constexpr int D = sizeof(XT) == 1 ? 4 : 2;
+        Stager<XT, S1> st[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) st[j].init(lane);
         const long total = (long)a.B * a.G * T * S1::CHUNK;
         double sa[1][4] = {{0.0, 0.0, 0.0, 0.0}}, sb[1][4] = {{0.0, 0.0, 0.0, 0.0}};
-        int lf = wid;
-        if (lf < nfr) {
-            st.load(reinterpret_cast<const XT*>(a.x), (int)frame_of(lf), total, lane);
-            st.store(im0);
+        const int nmine = nfr > wid ? (nfr - wid + 3) / 4 : 0;
+        const XT* xin = reinterpret_cast<const XT*>(a.x);
+        auto frame_i = [&](int i) { return (int)frame_of(wid + 4 * (i < nmine ? i : nmine - 1)); };
+        if (nmine > 0) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) st[j].load(xin, frame_i(j), total, lane);
+            st[0].store(im0);
+            st[0].load(xin, frame_i(D), total, lane);
         }
-        int par = 0;
-        while (lf < nfr) {
-            const float* rimg = par ? im1 : im0;
-            float* wimg = par ? im0 : im1;
-            const int nlf = lf + 4;
-            st.load(reinterpret_cast<const XT*>(a.x), (int)frame_of(nlf < nfr ? nlf : lf), total, lane);
-            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+        for (int base = 0; base < nmine; base += D) {
 #pragma unroll
-            for (int ch = 0; ch < S1::NCH; ++ch) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(rimg + toff[ch]);
+            for (int jj = 0; jj < D; ++jj) {
+                const int i = base + jj;                   // slot (i + 1) % D == (jj + 1) % D holds frame i + 1
+                if (i < nmine) {
+                    const int par = i & 1;
+                    const float* rimg = par ? im1 : im0;
+                    float* wimg = par ? im0 : im1;
+                    st[(jj + 1) % D].store(wimg);
+                    st[(jj + 1) % D].load(xin, frame_i(i + 1 + D), total, lane);
+                    const int lf = wid + 4 * i;
+                    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j & 1] = D2P_MFMA16(wr[ch][j][0], bb[j], acc[j & 1]);
+                    for (int ch = 0; ch < S1::NCH; ++ch) {
+                        const f32x4 bb = *reinterpret_cast<const f32x4*>(rimg + toff[ch]);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[j & 1] = D2P_MFMA16(wr[ch][j][0], bb[j], acc[j & 1]);
+                    }
+                    f32x4 o = (acc[0] + acc[1]) + bv;
+                    o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w);
+                    *reinterpret_cast<f32x4*>(a.a[0] + (frame_of(lf) * 16 + p) * 16 + 4 * q) = o;
+                    *reinterpret_cast<f32x4*>(img2 + ((size_t)lf * 16 + p) * S2::PSF + 4 * q) = o;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sa[0][r] += (double)o[r]; sb[0][r] += (double)o[r] * (double)o[r]; }
+                }
             }
-            f32x4 o = (acc[0] + acc[1]) + bv;
-            o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w);
-            *reinterpret_cast<f32x4*>(a.a[0] + (frame_of(lf) * 16 + p) * 16 + 4 * q) = o;
-            *reinterpret_cast<f32x4*>(img2 + ((size_t)lf * 16 + p) * S2::PSF + 4 * q) = o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { sa[0][r] += (double)o[r]; sb[0][r] += (double)o[r] * (double)o[r]; }
-            st.store(wimg);
-            lf = nlf;
-            par ^= 1;
         }
         enc_fold_sums<1>(sa, sb, 16, wid, p, q, wsum);
     }
     __syncthreads();
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 1] = wall_clock64();
+    float wr2[S2::NCH][4][S2::NB];                                // (the next layer's filter loads fly during the exchange)
+    enc_filter<S2>(a.w[1], p, q, wr2);
     enc_stats<16>(a, 0, g, s, n1, wsum, mean_l, rstd_l, flag);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 2] = wall_clock64();
     // normalise IMG2 in place (-> y1, also to memory)
     for (int i = tid; i < nfr * 16 * 4; i += 256) {
         const int px = i >> 2, c4 = (i & 3) * 4, lf = px >> 4;
@@ -649,10 +700,10 @@ karel_encoder_fwd_kernel(EncArgs a) {
     if (tid == 0) *reinterpret_cast<f32x4*>(img2 + (size_t)nfr16 * 16 * S2::PSF) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 3] = wall_clock64();
     // ================= layer 2: 4x4x16 -> 2x2x32, four frames per tile =================
     {
-        float wr[S2::NCH][4][S2::NB];
-        enc_filter<S2>(a.w[1], p, q, wr);
+        auto& wr = wr2;
         int toff[S2::NCH];
         enc_toff<S2>(p, q, 4, 4, toff);
         f32x4 bv[2];
@@ -694,7 +745,11 @@ karel_encoder_fwd_kernel(EncArgs a) {
         enc_fold_sums<2>(sa, sb, 32, wid, p, q, wsum);
     }
     __syncthreads();
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 4] = wall_clock64();
+    float wr3[S3::NCH][4][S3::NB];
+    enc_filter<S3>(a.w[2], p, q, wr3);
     enc_stats<32>(a, 1, g, s, n2, wsum, mean_l, rstd_l, flag);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 5] = wall_clock64();
     for (int i = tid; i < nfr * 4 * 8; i += 256) {
         const int px = i >> 3, c4 = (i & 7) * 4, lf = px >> 2;
         float* v = img3 + (size_t)px * S3::PSF + c4;
@@ -707,10 +762,10 @@ karel_encoder_fwd_kernel(EncArgs a) {
     if (tid == 0) *reinterpret_cast<f32x4*>(img3 + (size_t)nfr16 * 4 * S3::PSF) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 6] = wall_clock64();
     // ================= layer 3: 2x2x32 -> 1x1x48, sixteen frames per tile =================
     {
-        float wr[S3::NCH][4][S3::NB];
-        enc_filter<S3>(a.w[2], p, q, wr);
+        auto& wr = wr3;
         int toff[S3::NCH];
         enc_toff<S3>(p, q, 2, 2, toff);
         f32x4 bv[3];
@@ -752,7 +807,9 @@ karel_encoder_fwd_kernel(EncArgs a) {
         enc_fold_sums<3>(sa, sb, 48, wid, p, q, wsum);
     }
     __syncthreads();
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 7] = wall_clock64();
     enc_stats<48>(a, 2, g, s, n3, wsum, mean_l, rstd_l, flag);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 8] = wall_clock64();
     // y3, time-major: feats_tm[t][m = b*G + g][48]
     const long M = (long)a.B * a.G;
     for (int i = tid; i < nfr * 12; i += 256) {
@@ -764,6 +821,7 @@ karel_encoder_fwd_kernel(EncArgs a) {
         const long m = (long)(b0 + lf / T) * a.G + g;
         *reinterpret_cast<f32x4*>(a.feats_tm + ((long)(lf % T) * M + m) * 48 + c4) = o;
     }
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 9] = wall_clock64();
     // the counters of the slot ENC_SLOTS / 2 launches ahead are zeroed by this launch (one thread): a slot is reused
     // ENC_SLOTS launches later, long after; a launch that gave up leaves garbage only in its own slot
     if (blockIdx.x == 0 && tid < 3 * ENC_MAXG) {
@@ -777,7 +835,7 @@ static size_t enc_lds_bytes(int nb, int T) {
     using S2 = FrameShape<16, 32, 4, 4>;
     using S3 = FrameShape<32, 48, 2, 2>;
     const size_t nfr16 = (size_t)(nb * T + 15) / 16 * 16;
-    return (4 * 2 * S1::BUF + nfr16 * 16 * S2::PSF + 4 + nfr16 * 4 * S3::PSF + 4 + nfr16 * 48 + 4 * 48 * 2 * 2 + 96 + 4) * sizeof(float);
+    return (4 * 2 * S1::BUF + nfr16 * 16 * S2::PSF + 4 + nfr16 * 4 * S3::PSF + 4 + nfr16 * 48 + 512 * 2 + 96 + 4) * sizeof(float);
 }
 static bool enc_plan(int B, int G, int T, int& S, int& nb) {
     int dev = 0, cus = 0;
@@ -791,7 +849,15 @@ static bool enc_plan(int B, int G, int T, int& S, int& nb) {
     return true;
 }
 
+unsigned long long* g_enc_trace = nullptr;
+
 }   // namespace
+
+// diagnostic (tools/karel_encoder_time.py): 10 wall-clock stamps (100 MHz) per workgroup of the following launches
+extern "C" int d2p_karel_encoder_set_trace(void* buf) {
+    g_enc_trace = (unsigned long long*)buf;
+    return D2P_OK;
+}
 
 extern "C" size_t d2p_karel_encoder_ws_bytes(int B, int G, int T) {
     int S = 0, nb = 0;
@@ -830,6 +896,7 @@ extern "C" int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_i
     e.counters = counters;
     e.err = d2p_persist_err_ptr();
     e.B = B; e.G = G; e.T = T; e.S = S; e.nb = nb;
+    e.trace = g_enc_trace;
     static unsigned seq = 0;
     e.slot = (int)(seq++ % ENC_SLOTS);
     const size_t lds = enc_lds_bytes(nb, T);

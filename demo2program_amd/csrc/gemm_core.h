@@ -1090,11 +1090,14 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
     // long K loop alone (measured 19 us for 320x512x512 on 40 workgroups).  32x32 tiles give 4x
     // the workgroups, the four waves of each split K between them and combine through LDS.
     const long wgs = (long)ceil_div(M, p.bm) * ceil_div(N, p.bn) * p.splits;
-    if (wgs >= 128 || K < 128) return p;
+    // (a tall output of <= 64 columns with a long K -- the first encoder's input gradient, 4480 x 48 over K = 2048 --
+    //  is 35 tiles of 128x64 x 4 slices = 140 workgroups: 34 us; 280 tiles of 32x32 x 4 slices: 23 us)
+    const bool tall_skinny = N <= 64 && K >= 1024 && wgs < 256 && allow_split;
+    if ((wgs >= 128 && !tall_skinny) || K < 128) return p;
     const long t32 = (long)ceil_div(M, 32) * ceil_div(N, 32);
     long s = 1;
-    if (allow_split && K >= 1024 && t32 < 256) {
-        s = (512 + t32 - 1) / t32;                       // ~2 workgroups per CU
+    if (allow_split && K >= 1024 && (t32 < 256 || (tall_skinny && t32 < 512))) {
+        s = ((t32 < 256 ? 512 : 1024) + t32 - 1) / t32;  // ~2 (4) workgroups per CU
         const long maxs = K / 256;                       // >= 64 of K per wave
         if (s > maxs) s = maxs;
         if (s < 1) s = 1;

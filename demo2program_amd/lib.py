@@ -42,6 +42,7 @@ SIGNATURES = {
     'd2p_conv2d_nhwc_s2_same_dgrad': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, S]),
     'd2p_conv2d_nhwc_s2_same_wgrad': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_size_t, S]),
     'd2p_karel_encoder_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'd2p_karel_encoder_set_trace': (c_int, [P]),
     'd2p_karel_encoder_fwd': (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
     'd2p_bn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'd2p_bn_batched_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -201,6 +201,9 @@ int d2p_bn_group_bwd_batched(int nb, long xs, long ys, long ps, int R, int C, in
  * (T % 4 != 0, G > 32, more frames per workgroup than LDS holds) -- callers fall back to the separate launches.
  * A workgroup that waits too long for its group sets the status word of d2p_lstm_persist_error (code 0x7e). */
 size_t d2p_karel_encoder_ws_bytes(int B, int G, int T);   /* 0: geometry not supported */
+/* diagnostic: buf [workgroups][10] uint64 in device memory receives wall-clock stamps (100 MHz) of the following launches
+ * (start, after each layer's products / statistics exchange / normalisation, end); null: off */
+int d2p_karel_encoder_set_trace(void* buf);
 int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_is_u8, const float* const* w,
                           const float* const* bias, const float* const* gamma, const float* const* beta,
                           float* const* a, float* const* y, float* feats_tm, float* const* mean,

@@ -56,6 +56,23 @@ def main():
     print('separate launches: %.1f us' % timed(chain))
     if K.karel_encoder_ok(B, G, T):
         print('one launch:        %.1f us' % timed(fused))
+        nwg = 256
+        tr = torch.zeros(nwg, 10, dtype=torch.int64, device='cuda')
+        from demo2program_amd.lib import call
+        call.d2p_karel_encoder_set_trace(tr.data_ptr())
+        fused()
+        torch.cuda.synchronize()
+        call.d2p_karel_encoder_set_trace(None)
+        t = tr.cpu().double()
+        t = t[t[:, 0] > 0]
+        t0 = t[:, 0].min()
+        names = ['start', 'layer 1 products', 'statistics 1', 'normalise 1', 'layer 2 products', 'statistics 2',
+                 'normalise 2', 'layer 3 products', 'statistics 3', 'normalise 3 + transpose']
+        print('%d workgroups; stamps in us from the first workgroup\'s start (mean / max over workgroups):' % t.shape[0])
+        for i in range(10):
+            d = (t[:, i] - (t[:, i - 1] if i else t0)) / 100.0
+            print('   %-26s +%6.2f / %6.2f   (at %6.2f / %6.2f)' % (names[i], d.mean(), d.max(), ((t[:, i] - t0) / 100).mean(),
+                                                                  ((t[:, i] - t0) / 100).max()))
     print('error word: 0x%x' % K.lstm_persist_error())
 
 
