@@ -16,11 +16,193 @@ static int check_gemm_args(int M, int N, int K, const float* A, const float* B, 
     return D2P_OK;
 }
 
+
+// ---- A^T B straight from memory into the MFMA operand registers (round 4) -------------------------------------------
+// C[M, N] (+)= sum_k A[rowsA[k], :M]^T B[rowsB[k], :N] (the weight gradients dWx = X^T dZ, dWh = H^T dZ over the rows
+// inside their sequences).  Both operands are stored with the OUTPUT index contiguous, and that is the layout a
+// 16x16x4 MFMA wants its operands in: lane (c = l & 15, kq = l >> 4) supplies A[k + kq][m] and B[k + kq][n].  So a lane
+// loads 16 bytes -- four consecutive m (n) of row k + kq -- straight from memory and uses element i (j) as the operand of
+// the MFMA that owns output rows {m0 + 4 c' + i} (columns {n0 + 4 c'' + j}): two 16-byte loads per lane feed sixteen
+// MFMAs of a 64 x 64 wave tile, with no LDS staging, no barrier and no fragment read in the loop (the staged kernel
+// spends 8 ds_read_b32 per 4 MFMAs on these layouts and meets at a barrier every 32 rows of K).  The KW waves of a
+// workgroup own the SAME output tile and an eighth of K each (a ring of D row groups in flight per wave, a lane's row
+// index of a group fetched one ring round before the group's data); they meet once, at the end, in a fixed-order
+// tree through LDS.  Deterministic; not bit-identical to the staged kernel (another order of the K sum).
+typedef float tnd_f32x4 __attribute__((ext_vector_type(4)));
+#define TND_D 4           // row groups (of four K rows) in flight per wave
+
+template <int KW, bool GATHER>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn_direct_kernel(const float* __restrict__ A, int lda, const int* __restrict__ rowsA, const float* __restrict__ B,
+                      int ldb, const int* __restrict__ rowsB, float* __restrict__ C, long ldc, int M, int N, int K, int kps,
+                      int accumulate) {
+    extern __shared__ __attribute__((aligned(16))) float tnd_red[];      // [KW / 2][64 values][64 lanes]
+    const int lane = threadIdx.x & 63, c = lane & 15, kq = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbn = (N + 63) / 64;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int m0 = bm * 64, n0 = bn * 64;
+    const int kbeg = w * kps;
+    const int kend = kbeg + kps < K ? kbeg + kps : K;
+    const int ng = kend > kbeg ? (kend - kbeg) >> 2 : 0;                  // groups of four rows; a multiple of TND_D
+    // columns past the matrix: loaded from its last four (never stored)
+    const float* pa = A + (m0 + 4 * c < M - 4 ? m0 + 4 * c : M - 4);
+    const float* pb = B + (n0 + 4 * c < N - 4 ? n0 + 4 * c : N - 4);
+
+    tnd_f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = tnd_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (ng > 0) {
+        // The loads and their waits are written out (inline asm): left to itself hipcc sinks the ring's refills to half
+        // a round in front of their use and waits for fresh loads at the loop head.  Volatile asm statements keep their
+        // order, so the counts are exact.  Per slot and round, in this order: the two data loads of the group D ahead,
+        // then (row lists) the two index loads of the group 2 D ahead -- each lane its own K quarter's row, one dword --
+        // so when a slot is consumed the oldest NL of the NL D operations in flight are its own: vmcnt(NL (D - 1)).
+        constexpr int NL = GATHER ? 4 : 2;
+        tnd_f32x4 av[TND_D], bv[TND_D];
+        int ia[TND_D], ib[TND_D];                    // this lane's rows for the slot's NEXT data loads
+        const int* qia = rowsA + kbeg + kq;          // (GATHER) this lane's entry of group 0
+        const int* qib = rowsB + kbeg + kq;
+        auto load_idx = [&](int d, int g) {          // rows of group g (clamped to the wave's last group) into slot d
+            const int gc = g < ng ? g : ng - 1;
+            if constexpr (GATHER) {
+                asm volatile("global_load_dword %0, %1, off" : "=v"(ia[d]) : "v"(qia + 4 * gc) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(ib[d]) : "v"(qib + 4 * gc) : "memory");
+            } else {
+                ia[d] = ib[d] = kbeg + 4 * gc + kq;
+            }
+        };
+        auto load_data = [&](int d) {
+            const float* qa = pa + (long)ia[d] * lda;
+            const float* qb = pb + (long)ib[d] * ldb;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(av[d]) : "v"(qa) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[d]) : "v"(qb) : "memory");
+        };
+#pragma unroll
+        for (int d = 0; d < TND_D; ++d) load_idx(d, d);
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int d = 0; d < TND_D; ++d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ia[d]), "+v"(ib[d]) :: "memory");
+        }
+#pragma unroll
+        for (int d = 0; d < TND_D; ++d) {
+            load_data(d);
+            load_idx(d, TND_D + d);
+        }
+        for (int g0 = 0; g0 < ng; g0 += TND_D) {
+#pragma unroll
+            for (int d = 0; d < TND_D; ++d) {
+                if constexpr (GATHER)
+                    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(av[d]), "+v"(bv[d]), "+v"(ia[d]), "+v"(ib[d])
+                                 : "n"(NL * (TND_D - 1)) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(av[d]), "+v"(bv[d]) : "n"(NL * (TND_D - 1)) : "memory");
+                const tnd_f32x4 a4 = av[d], b4 = bv[d];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i], b4[j], acc[i][j], 0, 0, 0);
+                load_data(d);                        // group g0 + d + D into the slot just consumed
+                load_idx(d, g0 + d + 2 * TND_D);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (the clamped refills of the last round)
+    }
+
+    // the KW partial tiles: fixed-order tree through LDS (value e of lane l at [slot][e][l]: conflict-free)
+#pragma unroll
+    for (int step = KW / 2; step >= 1; step >>= 1) {
+        if (w >= step && w < 2 * step) {
+            float* dst = tnd_red + (size_t)(w - step) * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((i * 4 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (w < step) {
+            const float* src = tnd_red + (size_t)w * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * 4 + j) * 4 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (w != 0) return;
+    // lane (c, kq) holds, for MFMA (i, j) and register r: output row m0 + 4 (4 kq + r) + i, column n0 + 4 c + j
+    const int col = n0 + 4 * c;
+    if (col >= N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + 16 * kq + 4 * r + i;
+            if (row < M) {
+                float* dst = C + (long)row * ldc + col;
+                tnd_f32x4 o = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                if (accumulate) o += *reinterpret_cast<const tnd_f32x4*>(dst);
+                *reinterpret_cast<tnd_f32x4*>(dst) = o;
+            }
+        }
+}
+
+static int g_gemm_tn_direct = 1;          // d2p_gemm_set_option bit 6 switches it off (A/B)
+
+// true: launched.  Shapes it takes: whole 16-byte pieces everywhere, K in whole ring rounds, enough tiles to fill the chip
+template <int KW, bool GATHER>
+static bool tn_direct_launch_kw(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
+                                const int* rowsB, float* C, long ldc, int accumulate, hipStream_t st) {
+    if (!g_gemm_tn_direct || M < 4 || N < 4 || (M | N) % 4 != 0 || K % (4 * TND_D) != 0 || K < 1024) return false;
+    if (!vec_ok(A, lda) || !vec_ok(B, ldb) || !vec_ok(C, ldc)) return false;
+    const long tiles = (long)ceil_div(M, 64) * ceil_div(N, 64);
+    if (tiles < 128 || tiles > 65535 || lda > 0x7fffffffL || ldb > 0x7fffffffL) return false;
+    const int kps = (ceil_div(K, KW) + 4 * TND_D - 1) / (4 * TND_D) * (4 * TND_D);
+    // LDS: the tree's (KW / 2) x 16 KB -- and never less than 100 KB: with 64 KB these eight-wave workgroups become
+    // resident BESIDE a persistent recurrence of the other stream (64.5 / 81 KB of the CU's 160) and slow it down by
+    // more than they gain (two-stream profile: backward recurrence 343 us on average instead of 235, the step
+    // unchanged although the product itself is 15 % faster); at 100 KB they wait for the recurrence's workgroup to
+    // leave the CU, as the four-wave staged kernel does for want of a free SIMD (tools/corun_probe.py)
+    constexpr int lds_tree = (KW / 2) * 4096 * (int)sizeof(float);
+    static int lds_env = -1;
+    if (lds_env < 0) { const char* e = getenv("D2P_TND_LDS_KB"); lds_env = e ? atoi(e) * 1024 : 100 * 1024; }
+    const int lds = lds_tree > lds_env ? lds_tree : lds_env;
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)gemm_tn_direct_kernel<KW, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return false;
+        attr = true;
+    }
+    D2pProfScope prof(st, D2P_PROF_GEMM, 2.0 * M * N * K);
+    hipLaunchKernelGGL((gemm_tn_direct_kernel<KW, GATHER>), dim3((unsigned)tiles), dim3(64 * KW), lds, st, A, (int)lda, rowsA, B,
+                       (int)ldb, rowsB, C, ldc, M, N, K, kps, accumulate);
+    return true;
+}
+
+template <bool GATHER>
+static bool tn_direct_launch(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
+                             const int* rowsB, float* C, long ldc, int accumulate, hipStream_t st) {
+    static int env_on = -1;                  // D2P_GEMM_TN_DIRECT=0: the staged kernel for every product (same-box A/B of the step)
+    if (env_on < 0) { const char* e = getenv("D2P_GEMM_TN_DIRECT"); env_on = (e && e[0] == '0') ? 0 : 1; }
+    if (!env_on) return false;
+    return tn_direct_launch_kw<8, GATHER>(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate, st);
+}
+
 extern "C" int d2p_gemm_set_option(int bk32) {
     g_gemm_bk32 = (bk32 & 1) ? 1 : 0;
     g_gemm_small_ksr = (bk32 & 2) ? 0 : 1;     // bit 1: switch the small-problem 32x32 tile off
     g_gemm_nosel = (bk32 & 4) ? 0 : 1;         // bit 2: keep the select-at-store loaders for every K
     g_gemm_no_bk32 = (bk32 & 16) ? 1 : 0;      // bit 4 (experiment): never the 32-deep slabs
+    g_gemm_tn_direct = (bk32 & 64) ? 0 : 1;    // bit 6: the A^T B products on the staged kernel (no register-direct form)
     g_gemm_fold = (bk32 & 32) ? 0 : 1;         // bit 5: split-K combine as a separate launch (round 2's form)
     g_gemm_dma_big = (bk32 & 8) ? 1 : 0;       // bit 3 (experiment): large dense GEMMs on the persistent LDS-DMA kernel
     g_gemm_dma_grid = bk32 >> 8;               // bits 8..: persistent grid of the LDS-DMA kernel (0 = automatic)
@@ -119,6 +301,11 @@ extern "C" int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, co
                                int accumulate, void* ws, size_t ws_bytes, d2p_stream_t stream) {
     int rc = check_gemm_args(M, N, K, A, B, C, act);
     if (rc) return rc;
+    if (!bias && act == 0 && M > 0 && N > 0 &&
+        tn_direct_launch<false>(M, N, K, A, lda, nullptr, B, ldb, nullptr, C, ldc, accumulate, as_stream(stream))) {
+        D2P_LAUNCH_CHECK("gemm_tn_direct");
+        return D2P_OK;
+    }
     DenseXC al{A, lda, M, vec_ok(A, lda)};   // A is [K,M]: M contiguous
     DenseXC bl{B, ldb, N, vec_ok(B, ldb)};
     EpiDense ep{C, ldc, bias, act, accumulate};
@@ -137,6 +324,10 @@ extern "C" int d2p_gemm_f32_tn_rows(int M, int N, int K, const float* A, long ld
     if (rc) return rc;
     if (M == 0 || N == 0) return D2P_OK;
     D2P_REQUIRE(K == 0 || (rowsA && rowsB), D2P_EINVAL, "gemm_tn_rows: null row list");
+    if (tn_direct_launch<true>(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate, as_stream(stream))) {
+        D2P_LAUNCH_CHECK("gemm_tn_direct");
+        return D2P_OK;
+    }
     GatherXC al{A, lda, M, vec_ok(A, lda), rowsA};
     GatherXC bl{B, ldb, N, vec_ok(B, ldb), rowsB};
     EpiDense ep{C, ldc, nullptr, 0, accumulate};
