@@ -75,8 +75,9 @@ int d2p_gemm_f32_batched(int kind, int nb1, int nb0, int M, int N, int K, const 
  * use 32-deep K slabs; bit 1 switches OFF the small-problem path (32x32 tiles whose four waves split
  * K and combine through LDS, picked when the ordinary plan would fill fewer than 128 workgroups);
  * bit 2 keeps the select between global load and LDS store even when K is a multiple of the slab
- * depth (the dense loaders then need none); bits 8 and up: persistent grid size of the LDS-DMA kernel
- * (0 = CUs x resident workgroups per CU). */
+ * depth (the dense loaders then need none); bit 6: the A^T B products stay on the staged kernel (no
+ * gemm_tn_direct_kernel); bits 8 and up: persistent grid size of the LDS-DMA kernel (0 = CUs x resident workgroups
+ * per CU). */
 int d2p_gemm_set_option(int bk32);
 /* Tuning experiments only: force the tile (0 64x64, 1 128x128, 2 128x32, 3 256x32, 4 128x64, 5-7 the K-split
  * forms; 8-12 the LDS-DMA pipeline: 64x64 with a 4- / 3-deep ring, 128x64 3-deep, 128x128 2- / 3-deep, which
@@ -110,7 +111,12 @@ int d2p_gemm_f32_rows(int kind, int M, int N, int K, const float* A, long lda, c
  * with BOTH operands read through lists of K row indices.  For the weight gradients X^T dZ / h[t-1]^T dz[t] of a
  * padded time-major batch over the rows inside their sequences only (rows past a sequence's length are zeros in
  * dZ; the reference multiplies them in, tf.gradients of models/model_full.py:243-277).  K % 32 == 0 takes the
- * select-free loaders: pad the lists with a row that is zero in B and finite in A. */
+ * select-free loaders: pad the lists with a row that is zero in B and finite in A.
+ * Round 4: with M, N multiples of 4, K a multiple of 16 and >= 1024, 16-byte aligned operands and at least 128 output
+ * tiles of 64 x 64 these products (and the dense d2p_gemm_f32_tn without bias / activation) run on
+ * gemm_tn_direct_kernel: operands straight from memory into the MFMA registers, no LDS staging;
+ * deterministic, another order of the K sum than the staged kernel.  d2p_gemm_set_option bit 6 or
+ * D2P_GEMM_TN_DIRECT=0 keeps the staged kernel. */
 int d2p_gemm_f32_tn_rows(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
                          const int* rowsB, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes,
                          d2p_stream_t stream);
