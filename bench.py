@@ -114,7 +114,10 @@ def roofline_leg(trainer, feeds, steps=2):
     lib.d2p_prof_enable(1)
     lib._d2p_prof_on = True          # Trainer.train_step takes the eager (un-graphed) path
     side = trainer.model.use_side_stream
-    trainer.model.use_side_stream = False
+    # (D2P_PROF_KEEP_SIDE=1, diagnostic: the two-stream schedule under the brackets -- a family's time is then what its
+    #  launches take BESIDE the other stream's work; the reported roofline always uses one stream)
+    if os.environ.get('D2P_PROF_KEEP_SIDE', '0') != '1':
+        trainer.model.use_side_stream = False
     for i in range(steps):
         trainer.train_step(feeds[i % len(feeds)])
     torch.cuda.synchronize()
