@@ -53,7 +53,7 @@ PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r04_pmc_traffic.json',
 
 # profiling key (include/d2p.h) -> (name, roofline that bounds it, reporting group)
 PROF_FAMILIES = {
-    1: ('gemm_mfma_kernel (dense fp32 MFMA GEMM, all instantiations)', 'mfma', 'gemm'),
+    1: ('gemm_mfma_kernel + gemm_tn_direct_kernel (dense fp32 MFMA GEMM, all instantiations)', 'mfma', 'gemm'),
     2: ('conv kernels (whole-frame / direct 16x16x4 MFMA / row-strip, implicit-GEMM fallback)', 'mfma', 'conv'),
     3: ('lstm_gate_fwd_kernel', 'hbm', 'gate'),
     4: ('lstm_gate_bwd_kernel', 'hbm', 'gate'),
@@ -62,7 +62,7 @@ PROF_FAMILIES = {
     8: ('recurrent backward (lstm_persist_bwd_kernel / lstm_step_bwd_kernel)', 'mfma', 'recurrent'),
 }
 GROUP_NAMES = {
-    'gemm': 'gemm_mfma_kernel (dense fp32 MFMA GEMM, all instantiations)',
+    'gemm': 'gemm_mfma_kernel + gemm_tn_direct_kernel (dense fp32 MFMA GEMM, all instantiations)',
     'conv': 'conv kernels (forward + dgrad + wgrad of every encoder layer)',
     'recurrent': 'recurrent LSTM kernels, forward + backward (lstm_persist_fwdw_kernel + lstm_persist_bwd_kernel: '
                  'h.Wh / dz.Wh^T fp32 MFMA + gate math for all time steps of a sequence in one launch)',

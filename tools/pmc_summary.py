@@ -14,6 +14,7 @@ def family(name):
     if 'lstm_persist_bwd' in name: return 'lstm_persist_bwd_kernel'
     if 'lstm_step_fwd' in name: return 'lstm_step_fwd_kernel'
     if 'lstm_step_bwd' in name: return 'lstm_step_bwd_kernel'
+    if 'gemm_tn_direct_kernel' in name: return 'gemm_mfma_kernel'      # (the GEMM family's register-direct A^T B form)
     if 'gemm_mfma_kernel' in name:
         if 'Im2col' in name or 'Dgrad' in name: return 'gemm_mfma_kernel<conv>'
         if 'OneHot' in name: return 'gemm_mfma_kernel<onehot>'
