@@ -1426,7 +1426,8 @@ class Model(object):
             p = self.params.p
             if rows > 0:
                 S = self._buf(name + '/dz_by_token', (tok + 2, 4 * U))
-                K.embedding_scatter_add(e['token_ids'], dz_n, S, n=rows)
+                if not self._abl('scatter'):              # (timing experiment: tools/step_ablation.sh)
+                    K.embedding_scatter_add(e['token_ids'], dz_n, S, n=rows)
                 K.matmul_tn(p[scope + '/embedding'], S[:tok + 1], out=gk[:I])
                 K.matmul_nt(S[:tok + 1], p[name + '/kernel'][:I], out=g[scope + '/embedding'])
             else:
