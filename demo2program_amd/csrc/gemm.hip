@@ -453,9 +453,74 @@ struct OneHotXC {   // A operand, A^T·B form: x = table row v, k = id position 
     }
 };
 
+// ---- rows summed by key: out[v] = sum of the rows r of X with ids[r] == v (the embedding gradient) ------------------------
+// The one-hot GEMM above spends a matrix-pipe launch on what is a read of X (52 MB for the action decoder's dz: 57 us at
+// 7-8 table rows, one tile row of workgroups walking all of K).  Here a workgroup streams a slice of rows of 64 columns:
+// thread (cl, rl) reads 16 bytes of the rows rl, rl + 16, ... (four in flight) and adds each into ITS OWN cell
+// [rl][ids[row]][cl] of an LDS table -- no two threads share a cell, so the order of every sum is the row order;
+// the sixteen row lanes are then added in order and the slices by the deterministic combine kernel.
+// 256 threads (16 row lanes x 16 column lanes of 16 bytes): with fewer waves the workgroups become resident beside a
+// persistent recurrence of the other stream (tools/corun_probe.py) and their stream of HBM reads slows it down -- the first
+// version (128 threads) was 23 us faster than the one-hot GEMM alone and gained 5 us in the step.  So the table must
+// fit 16 row lanes: up to 32 keys (the action decoder's 8; the program decoder's 52 stay on the one-hot GEMM, which is
+// as fast there).
+#define RBK_RL 16
+
+__global__ void __launch_bounds__(256)
+rows_by_key_kernel(int n, int nkeys, int E, int rows_per_slice, const int* __restrict__ ids, const float* __restrict__ X,
+                   float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float rbk_tab[];      // [RBK_RL][nkeys][64]
+    const int tid = threadIdx.x, cl = tid & 15, rl = tid >> 4;
+    const int c0 = blockIdx.x * 64 + 4 * cl;
+    const int cc = c0 < E - 4 ? c0 : E - 4;                               // (E % 4 == 0; columns past E: loaded, never stored)
+    const int r0 = blockIdx.y * rows_per_slice;
+    const int r1 = r0 + rows_per_slice < n ? r0 + rows_per_slice : n;
+    for (int i = tid; i < RBK_RL * nkeys * 16; i += 256) reinterpret_cast<tnd_f32x4*>(rbk_tab)[i] = tnd_f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    float* mine = rbk_tab + (size_t)rl * nkeys * 64 + 4 * cl;
+    for (int r = r0 + rl; r < r1; r += 4 * RBK_RL) {
+        tnd_f32x4 v[4];
+        int key[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * RBK_RL < r1 ? r + u * RBK_RL : r;
+            key[u] = r + u * RBK_RL < r1 ? ids[rr] : -1;
+            v[u] = *reinterpret_cast<const tnd_f32x4*>(X + (long)rr * E + cc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (key[u] >= 0 && key[u] < nkeys) {                          // (ids outside the table: dropped, as the gather reads zeros)
+                tnd_f32x4* cell = reinterpret_cast<tnd_f32x4*>(mine + (size_t)key[u] * 64);
+                *cell = *cell + v[u];
+            }
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.y * nkeys * E;
+    for (int i = tid; i < nkeys * 16; i += 256) {
+        const int key = i >> 4, c4 = i & 15;
+        tnd_f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < RBK_RL; ++q) sum += *reinterpret_cast<const tnd_f32x4*>(rbk_tab + ((size_t)q * nkeys + key) * 64 + 4 * c4);
+        const int col = blockIdx.x * 64 + 4 * c4;
+        if (col < E) *reinterpret_cast<tnd_f32x4*>(out + (size_t)key * E + col) = sum;
+    }
+}
+
+static int rbk_slices(int n) {
+    int s = (n + 199) / 200;              // ~200 rows per workgroup
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : s;
+}
+static bool rbk_ok(int n, int rows, int E, const float* dout, const float* dtable) {
+    static int env_on = -1;               // D2P_ROWS_BY_KEY=0: the one-hot GEMM (same-box A/B)
+    if (env_on < 0) { const char* e = getenv("D2P_ROWS_BY_KEY"); env_on = (e && e[0] == '0') ? 0 : 1; }
+    return env_on && n >= 256 && rows <= 32 && E % 4 == 0 && E >= 64 && (((uintptr_t)dout | (uintptr_t)dtable) & 15) == 0;
+}
+
 extern "C" size_t d2p_embedding_scatter_ws_bytes(int n, int rows, int E) {
     if (n <= 0 || rows <= 0 || E <= 0) return 0;
-    return d2p_plan_ws_bytes(rows, E, n);
+    const size_t a = d2p_plan_ws_bytes(rows, E, n), b = (size_t)rbk_slices(n) * rows * E * sizeof(float);
+    return a > b ? a : b;
 }
 
 extern "C" int d2p_embedding_scatter_add_oob0(int n, int rows, int E, const int* ids,
@@ -463,6 +528,33 @@ extern "C" int d2p_embedding_scatter_add_oob0(int n, int rows, int E, const int*
                                               size_t ws_bytes, d2p_stream_t stream) {
     D2P_REQUIRE(n >= 0 && rows > 0 && E > 0, D2P_EINVAL, "embedding scatter: bad sizes");
     D2P_REQUIRE(dtable && (n == 0 || (ids && dout)), D2P_EINVAL, "embedding scatter: null pointer");
+    const int slices = rbk_slices(n);
+    if (rbk_ok(n, rows, E, dout, dtable) && ws && ws_bytes >= (size_t)slices * rows * E * sizeof(float)) {
+        hipStream_t st = as_stream(stream);
+        const int lds = RBK_RL * rows * 64 * (int)sizeof(float);
+        static bool attr = false;
+        if (!attr) {
+            D2P_HIP(hipFuncSetAttribute((const void*)rows_by_key_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            attr = true;
+        }
+        const int rps = (n + slices - 1) / slices;
+        hipLaunchKernelGGL(rows_by_key_kernel, dim3((E + 63) / 64, slices), dim3(256), lds, st, n, rows, E, rps, ids, dout,
+                           (float*)ws);
+        D2P_LAUNCH_CHECK("rows_by_key");
+        EpiDense ep{dtable, E, nullptr, 0, 0};
+        const long total = (long)rows * E;
+        if (slices <= 16) {
+            int blocks = (int)((total + 255) / 256);
+            hipLaunchKernelGGL((gemm_splitk_reduce_flat_kernel<EpiDense>), dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, st, ep,
+                               (const float*)ws, rows, E, slices);
+        } else {
+            int blocks = (int)((total * 16 + 255) / 256);
+            hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EpiDense>), dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, st, ep,
+                               (const float*)ws, rows, E, slices);
+        }
+        D2P_LAUNCH_CHECK("rows_by_key_combine");
+        return D2P_OK;
+    }
     OneHotXC al{ids, rows};
     DenseXC bl{dout, E, E, vec_ok(dout, E)};
     EpiDense ep{dtable, E, nullptr, 0, 0};

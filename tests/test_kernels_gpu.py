@@ -1428,3 +1428,22 @@ def test_karel_encoder_one_launch_matches_the_separate_launches(K, B, G, T, u8):
             got = y[l].view(B, G, T * hw * hw, c) if l < 2 else feats_tm.transpose(0, 1).reshape(B, G, T, c)
             torch.testing.assert_close(got.double(), yl, rtol=1e-5, atol=1e-5)
         feats_tm.fill_(nan)
+
+
+@pytest.mark.parametrize('n,rows,E', [(6400, 9, 2048), (1568, 53, 2048), (6400, 32, 512), (1000, 31, 68), (257, 3, 64)])
+def test_rows_summed_by_key_equal_index_add(K, n, rows, E):
+    """d2p_embedding_scatter_add_oob0 on rows_by_key_kernel (n >= 256): out[v] = sum of the rows whose id is v, ids
+    outside the table dropped (the gather reads zeros there: models/model_full.py:294) -- against
+    index_add_ in fp64; two runs bit-identical (every sum has a fixed order)."""
+    g = torch.Generator().manual_seed(n + rows + E)
+    ids = torch.randint(0, rows + 2, (n,), generator=g, dtype=torch.int32)      # rows, rows + 1: outside the table
+    ids[::7] = -1
+    x = torch.randn(n, E, generator=g)
+    out = torch.full((rows, E), float('nan'), device='cuda')
+    K.embedding_scatter_add(ids.cuda(), x.cuda(), out)
+    ok = (ids >= 0) & (ids < rows)
+    ref = torch.zeros(rows, E, dtype=torch.float64).index_add_(0, ids[ok].long(), x[ok].double())
+    torch.testing.assert_close(out.double().cpu(), ref, rtol=1e-5, atol=2e-4)
+    out2 = torch.full((rows, E), float('nan'), device='cuda')
+    K.embedding_scatter_add(ids.cuda(), x.cuda(), out2)
+    assert torch.equal(out, out2)
