@@ -814,7 +814,7 @@ class Model(object):
         if self.track_moving:
             # the k moving-average updates of each layer (one per reference BN call, in group order): nothing in the
             # step reads them -- beside the recurrences
-            st = side if self.use_side_stream else main
+            st = side if self.use_side_stream and not torch.cuda.is_current_stream_capturing() else main
             if st is not main:
                 st.wait_stream(main)
             with torch.cuda.stream(st):
