@@ -137,6 +137,7 @@ struct XbProb {
     float* dlogits; const float* proj; float* dhout;
     int blk0;             // first workgroup of this problem
     const float* hout; float* logits_out;     // optional (round 4): the logits themselves, hout . proj, in front
+    float* loss_part;     // optional (round 4): [workgroup of this problem][G] sums of the rows' loss values
 };
 struct XbArgs { int n; XbProb p[3]; };
 
@@ -210,32 +211,56 @@ xent_bwd_dhout_kernel(XbArgs a) {
         extern __shared__ __attribute__((aligned(16))) float xb_dyn[];      // [16][U] staged hout rows + [256 / VP][16][VP] partial sums
         xb_logits16(q, row0, nrows, xb_dyn, xb_dyn + XB_ROWS * q.U, dl);     // dl holds the 16 rows' logits
     }
+    __shared__ float rowloss[XB_ROWS];
+    __shared__ int rowgrp[XB_ROWS];
+    const bool want_loss = q.loss_part != nullptr;
     for (int i = 0; i < 4; ++i) {
         const int lr = wave * 4 + i;
         const long row = row0 + lr;
-        float out = 0.f;
+        float out = 0.f, rl = 0.f;
+        int grp = -1;
         if (row < nrows) {
             const int t = (int)(row / q.R), r = (int)(row - (long)t * q.R);
             float xl = 0.f;                                        // this lane's logit of the row
             if (lane < V) xl = own_logits ? dl[lr][lane] : q.logits[row * V + lane];
             if (t < q.lens[r]) {
-                const float w = q.scale / ((float)q.G * q.den[r % q.G]);
+                grp = r % q.G;
+                const float w = q.scale / ((float)q.G * q.den[grp]);
+                const float lb = lane < V ? q.lab.at(r, t, lane) : 0.f;
                 if (q.mode == 0) {
                     float mx = lane < V ? xl : -INFINITY;
                     mx = wave_reduce_max(mx);
                     const float ex = lane < V ? expf(xl - mx) : 0.f;
                     const float se = wave_reduce_sum(ex);
                     // [TF-1.3] SoftmaxCrossEntropyWithLogits backprop = softmax - labels
-                    if (lane < V) out = w * (ex * (1.f / se) - q.lab.at(r, t, lane));
-                } else if (lane < V) {
-                    out = (w / (float)V) * (d2p_sigmoid(xl) - q.lab.at(r, t, lane));
+                    if (lane < V) out = w * (ex * (1.f / se) - lb);
+                    if (want_loss) {                               // the row's loss value, as row_loss<0> computes it
+                        const float sl = wave_reduce_sum(lb), slx = wave_reduce_sum(lb * xl);
+                        rl = (mx + logf(se)) * sl - slx;
+                    }
+                } else {
+                    if (lane < V) out = (w / (float)V) * (d2p_sigmoid(xl) - lb);
+                    if (want_loss) {
+                        // [TF-1.3] max(x,0) - x*z + log(1 + exp(-|x|))
+                        const float e = lane < V ? fmaxf(xl, 0.f) - xl * lb + log1pf(expf(-fabsf(xl))) : 0.f;
+                        rl = wave_reduce_sum(e) / (float)V;
+                    }
                 }
             }
             if (lane < V) q.dlogits[row * V + lane] = out;
         }
         dl[lr][lane] = lane < V ? out : 0.f;
+        if (want_loss && lane == 0) { rowloss[lr] = rl; rowgrp[lr] = grp; }
     }
     __syncthreads();
+    if (want_loss && (int)threadIdx.x < q.G) {
+        // this workgroup's 16 rows by loss group (row order): the sums of all workgroups are added by
+        // d2p_loss_from_partials in workgroup order
+        float sum = 0.f;
+        for (int lr = 0; lr < XB_ROWS; ++lr)
+            if (rowgrp[lr] == (int)threadIdx.x) sum += rowloss[lr];
+        q.loss_part[((long)blockIdx.x - q.blk0) * q.G + threadIdx.x] = sum;
+    }
     const int U = q.U;
     for (int u = threadIdx.x; u < U; u += 256) {
         float acc[XB_ROWS];
@@ -271,7 +296,7 @@ extern "C" int d2p_xent_bwd_dhout_multi(int nprob, const d2p_xent_bwd_desc* d, d
         o.mode = q.sigmoid ? 1 : 0; o.R = q.R; o.V = q.V; o.G = q.G; o.n_steps = q.n_steps; o.U = q.U;
         o.logits = q.logits; o.lab = LabelView{q.labels, q.label_rs, q.label_ts, q.label_vs}; o.lens = q.lens;
         o.den = q.den; o.scale = q.scale; o.dlogits = q.dlogits; o.proj = q.proj; o.dhout = q.dhout;
-        o.hout = q.hout; o.logits_out = q.logits_out;
+        o.hout = q.hout; o.logits_out = q.logits_out; o.loss_part = q.loss_part;
         o.blk0 = blocks;
         blocks += (int)(((long)q.n_steps * q.R + XB_ROWS - 1) / XB_ROWS);
     }
@@ -398,6 +423,78 @@ extern "C" int d2p_loss_assemble(int n_terms, const int* groups, const float* nu
     hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(64), 0, as_stream(stream), tg, nums, dens,
                        loss, term_losses);
     D2P_LAUNCH_CHECK("loss_assemble");
+    return D2P_OK;
+}
+
+// The loss value from the per-workgroup sums d2p_xent_bwd_dhout_multi leaves behind (desc.loss_part): term j has G_j
+// groups and nb_j workgroups; group sums in workgroup order (SUB strided partial sums per group, then those in order),
+// then the assembly of loss_assemble_kernel.  One launch instead of three partial + three final + one assemble.
+#define LFP_SUB 4
+struct LfpArgs { int n; int g[3]; int nb[3]; const float* part[3]; };
+
+__global__ void __launch_bounds__(256)
+loss_from_partials_kernel(LfpArgs a, const float* dens, float* nums, float* loss, float* term_losses) {
+    __shared__ float sub[64][LFP_SUB];
+    __shared__ float num_s[64];
+    const int tid = threadIdx.x, grp = tid / LFP_SUB, sb = tid % LFP_SUB;
+    int j = 0, off = 0;
+    while (j < a.n && grp >= off + a.g[j]) { off += a.g[j]; ++j; }
+    if (j < a.n) {
+        const int g = grp - off, G = a.g[j], nb = a.nb[j];
+        const float* p = a.part[j] + g;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int b = sb;
+        for (; b + 3 * LFP_SUB < nb; b += 4 * LFP_SUB) {
+            s0 += p[(long)b * G]; s1 += p[(long)(b + LFP_SUB) * G]; s2 += p[(long)(b + 2 * LFP_SUB) * G];
+            s3 += p[(long)(b + 3 * LFP_SUB) * G];
+        }
+        for (; b < nb; b += LFP_SUB) s0 += p[(long)b * G];
+        sub[grp][sb] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (j < a.n && sb == 0) {
+        float s = 0.f;
+        for (int q = 0; q < LFP_SUB; ++q) s += sub[grp][q];
+        num_s[grp] = s;
+        if (nums) nums[grp] = s;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float total = 0.f;
+        int o = 0;
+        for (int t = 0; t < a.n; ++t) {
+            float s = 0.f;
+            for (int g = 0; g < a.g[t]; ++g) s += num_s[o + g] / dens[o + g];
+            s /= (float)a.g[t];
+            if (term_losses) term_losses[t] = s;
+            total += s;
+            o += a.g[t];
+        }
+        loss[0] = total;
+    }
+}
+
+extern "C" int d2p_loss_from_partials(int n_terms, const int* groups, const int* nblocks, const float* const* parts,
+                                      const float* dens, float* nums, float* loss, float* term_losses,
+                                      d2p_stream_t stream) {
+    D2P_REQUIRE(n_terms > 0 && n_terms <= 3 && groups && nblocks && parts && dens && loss, D2P_EINVAL,
+                "loss_from_partials: bad arguments (n_terms=%d)", n_terms);
+    LfpArgs a;
+    a.n = n_terms;
+    int total = 0;
+    for (int i = 0; i < 3; ++i) {
+        a.g[i] = i < n_terms ? groups[i] : 0;
+        a.nb[i] = i < n_terms ? nblocks[i] : 0;
+        a.part[i] = i < n_terms ? parts[i] : nullptr;
+        if (i < n_terms) {
+            D2P_REQUIRE(groups[i] > 0 && nblocks[i] >= 0 && (parts[i] || nblocks[i] == 0), D2P_EINVAL,
+                        "loss_from_partials: term %d", i);
+            total += groups[i];
+        }
+    }
+    D2P_REQUIRE(total <= 64, D2P_EINVAL, "loss_from_partials: %d groups (at most 64)", total);
+    hipLaunchKernelGGL(loss_from_partials_kernel, dim3(1), dim3(256), 0, as_stream(stream), a, dens, nums, loss, term_losses);
+    D2P_LAUNCH_CHECK("loss_from_partials");
     return D2P_OK;
 }
 

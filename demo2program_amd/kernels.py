@@ -601,7 +601,26 @@ def xent_bwd_dhout_multi(probs):
         d.dlogits, d.proj, d.dhout = ptr(q['dlogits']), ptr(q['proj']), ptr(q['dhout'])
         if q.get('hout') is not None:       # the launch computes the logits itself: logits <- hout . proj, then as above
             d.hout, d.logits_out = ptr(q['hout']), ptr(q['logits'])
+        if q.get('loss_part') is not None:  # per-workgroup sums of the rows' loss values (loss_from_partials)
+            assert q['loss_part'].numel() >= xent_blocks(q['n_steps'], q['R']) * q['G']
+            d.loss_part = ptr(q['loss_part'])
     call.d2p_xent_bwd_dhout_multi(len(probs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
+
+
+def xent_blocks(n_steps, R):
+    """workgroups (of 16 rows) xent_bwd_dhout_multi gives a problem = rows of its loss_part"""
+    return (n_steps * R + 15) // 16
+
+
+def loss_from_partials(groups, nblocks, parts, dens, nums, loss, term_losses):
+    """The loss value from the loss_part arrays of xent_bwd_dhout_multi (d2p_loss_from_partials)."""
+    import ctypes
+    n = len(groups)
+    ga, na = (ctypes.c_int * n)(*groups), (ctypes.c_int * n)(*nblocks)
+    pa = (ctypes.c_void_p * n)(*[ptr(t) for t in parts])
+    call.d2p_loss_from_partials(n, ctypes.cast(ga, ctypes.c_void_p), ctypes.cast(na, ctypes.c_void_p),
+                                ctypes.cast(pa, ctypes.c_void_p), ptr(dens), ptr(nums), ptr(loss), ptr(term_losses),
+                                current_stream())
 
 
 def loss_assemble(groups, nums, dens, loss, term_losses):

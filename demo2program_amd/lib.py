@@ -100,6 +100,7 @@ SIGNATURES = {
     'd2p_sigmoid_xent_masked_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, c_float, P, S]),
     'd2p_xent_bwd_dhout_multi': (c_int, [c_int, P, S]),
     'd2p_loss_assemble': (c_int, [c_int, P, P, P, P, P, S]),
+    'd2p_loss_from_partials': (c_int, [c_int, P, P, P, P, P, P, P, S]),
     'd2p_group_mean': (c_int, [c_int, c_int, c_int, P, P, P, S]),
     'd2p_group_mean_bwd': (c_int, [c_int, c_int, c_int, P, P, P, c_int, S]),
     'd2p_group_max': (c_int, [c_int, c_int, c_int, P, P, P, S]),
@@ -153,7 +154,7 @@ class XentBwdDesc(ctypes.Structure):
                 ('logits', c_void_p), ('labels', c_void_p), ('label_rs', c_long), ('label_ts', c_long),
                 ('label_vs', c_long), ('lens', c_void_p), ('den', c_void_p), ('scale', c_float),
                 ('dlogits', c_void_p), ('proj', c_void_p), ('dhout', c_void_p), ('hout', c_void_p),
-                ('logits_out', c_void_p)]
+                ('logits_out', c_void_p), ('loss_part', c_void_p)]
 
 
 _lib = None

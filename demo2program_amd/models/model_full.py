@@ -1156,9 +1156,14 @@ class Model(object):
                        dict(mode='sigmoid', logits=ctx['dq']['logits'], labels=feed['per'], lab_kind='rtv', lens=lens_d,
                             T=T, R=M, V=P, G=k, n_steps=n_d, den=dens[1 + k:], scale=loss_scale, dlogits=dl_q,
                             proj=p['per/proj'], dhout=self._buf('per/dhout', (T * M, U)), U=U)]
+                fused_loss = (bool(ctx.get('logits_deferred')) and os.environ.get('D2P_FUSED_LOSS', '1') == '1'
+                              and 1 + 2 * k <= 64)
                 if ctx.get('logits_deferred'):
                     for q_, e_ in zip(xb, (ctx['dp'], ctx['da'], ctx['dq'])):
                         q_['hout'] = e_['hout']                # logits <- hout . proj inside the launch
+                        if fused_loss:                         # ... and the rows' loss values by loss group
+                            q_['loss_part'] = self._buf(e_['scope'] + '/loss_part',
+                                                        (K.xent_blocks(q_['n_steps'], q_['R']) * q_['G'],))
                 K.xent_bwd_dhout_multi(xb)
                 if ctx.get('logits_deferred'):
                     for e_ in (ctx['dp'], ctx['da'], ctx['dq']):
@@ -1167,13 +1172,20 @@ class Model(object):
                     nums, dens_v, loss_, terms_ = ctx['loss_bufs']
                     side.wait_stream(main)
                     with torch.cuda.stream(side):              # the loss VALUE (joined where backward joins the streams)
-                        K.xent_fwd('softmax', ctx['dp']['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
-                                   nums[0:1], dens_v[0:1])
-                        K.xent_fwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
-                                   nums[1:1 + k], dens_v[1:1 + k])
-                        K.xent_fwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
-                                   nums[1 + k:], dens_v[1 + k:])
-                        K.loss_assemble([1, k, k], nums, dens_v, loss_, terms_)
+                        if fused_loss:
+                            # (round 4: the loss-backward launch left the rows' loss values summed per workgroup: one
+                            #  small launch instead of three partial-sum, three final and one assembly launch -- 50 us
+                            #  of side-stream time; the counts are the feed's)
+                            K.loss_from_partials([1, k, k], [K.xent_blocks(q_['n_steps'], q_['R']) for q_ in xb],
+                                                 [q_['loss_part'] for q_ in xb], dens, nums, loss_, terms_)
+                        else:
+                            K.xent_fwd('softmax', ctx['dp']['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1,
+                                       n_p, nums[0:1], dens_v[0:1])
+                            K.xent_fwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
+                                       nums[1:1 + k], dens_v[1:1 + k])
+                            K.xent_fwd('sigmoid', ctx['dq']['logits'], feed['per'], 'rtv', lens_d, T, M, P, k, n_d,
+                                       nums[1 + k:], dens_v[1 + k:])
+                            K.loss_assemble([1, k, k], nums, dens_v, loss_, terms_)
             else:
                 K.xent_bwd('softmax', ctx['da']['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
                            dens[1:1 + k], loss_scale, dl_a)

@@ -496,8 +496,18 @@ typedef struct {
      * GEMM launches between the decoders' forward and backward recurrences otherwise), and differentiates those;
      * `logits` is then not read. */
     const float* hout; float* logits_out;
+    /* optional (round 4): loss_part [ceil(n_steps*R / 16)][G] != NULL receives, per workgroup of 16 rows, the sums of the
+     * rows' loss VALUES by loss group (exactly the terms d2p_*_xent_masked_fwd adds up): d2p_loss_from_partials turns
+     * them into the loss -- a training step then needs no forward loss launches at all. */
+    float* loss_part;
 } d2p_xent_bwd_desc;
 int d2p_xent_bwd_dhout_multi(int nprob, const d2p_xent_bwd_desc* descs, d2p_stream_t stream);
+/* loss / term_losses / nums as d2p_loss_assemble writes them, from the loss_part arrays of d2p_xent_bwd_dhout_multi:
+ * term j has groups[j] loss groups and nblocks[j] = ceil(n_steps_j * R_j / 16) partial rows at parts[j]; groups, nblocks,
+ * parts: HOST arrays of n_terms (<= 3) entries, at most 64 groups in all; dens as for d2p_loss_assemble; nums may be NULL.
+ * Sums in workgroup order (fixed): equal to the forward kernels' value up to the order of an fp32 sum. */
+int d2p_loss_from_partials(int n_terms, const int* groups, const int* nblocks, const float* const* parts,
+                           const float* dens, float* nums, float* loss, float* term_losses, d2p_stream_t stream);
 
 /* loss[0] = sum_terms (1/G_j) * sum_g num_j[g]/den_j[g]   (models/model_full.py:932,1035-1038,
  * 1078-1079).  nums/dens: concatenated [G_0 + G_1 + ...]; groups: HOST array of n_terms ints. */

@@ -1309,3 +1309,25 @@ def test_one_launch_state_encoder_equals_the_separate_launches(monkeypatch):
     scale = float(res[0][1].abs().max())
     assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * scale
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-6, atol=1e-7)
+
+
+def test_loss_value_from_the_loss_backward_launch(monkeypatch):
+    """D2P_FUSED_LOSS: a training step's loss value comes from the per-workgroup sums the loss-backward launch leaves
+    behind (d2p_xent_bwd_desc.loss_part + d2p_loss_from_partials), not from forward loss launches: the same value up to
+    the order of an fp32 sum, the same gradients bit for bit."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.synthetic import make_batch
+    from demo2program_amd.trainer import Trainer
+    cfg = make_config('karel', batch_size=8, k=4, num_lstm_cell_units=128)
+    batch = make_batch(cfg, seed=77)
+    res = []
+    for fused in ('0', '1'):
+        monkeypatch.setenv('D2P_FUSED_LOSS', fused)
+        tr = Trainer(cfg, make_train_dir=False)
+        feed = tr.model.get_feed_dict(batch)
+        loss = tr.train_step(feed)
+        tr.settle()
+        res.append((float(loss.item()), tr.model.params.grad.clone(), tr.model._buf('loss_terms', (3,)).clone()))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0]), (res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=2e-6, atol=1e-7)
