@@ -535,7 +535,7 @@ class Model(object):
                                           pe_mean, pe_rstd, self._buf('per/H', (self.per_cols, U)))
                     HWx = K.matmul_nn(H, p['per/lstm/kernel'][:U], out=self._buf('per/HWx', (self.per_cols, 4 * U)))
                     z_q = self._buf('per/lstm/z', (T * M, 4 * U))
-                    if n_d > 0:
+                    if n_d > 0 and not self._abl('zq'):          # (timing experiment: tools/step_ablation.sh)
                         K.gemm_raw('nn', n_d * M, 4 * U, self.per_cols, feed['per_rows'], self.per_cols, HWx, 4 * U,
                                    z_q, 4 * U, bias=p['per/lstm/bias'])
                     pe = None
