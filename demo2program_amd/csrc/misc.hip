@@ -420,6 +420,44 @@ extern "C" int d2p_per_affine_rows(int G, int P, int U, int NCp, const float* W,
     return D2P_OK;
 }
 
+// Forward statistics of fc + batch norm from the Gram matrix alone (round 4): u = per . W + b over the rows of index g has
+//   mean_g = (p_g . W) / n + b,   E[(u - b)^2] = (W^T C_g W) / n      (p_g = colsum(per_g), C_g = per_g^T per_g:
+// the blocks of gram = A^T A that d2p_per_fc_bn_bwd reads), so the batch statistics the perception encoder's batch norm
+// needs -- all the factored decoder input uses of it -- cost G x U x 30 multiply-adds in fp64 instead of a K = 5 GEMM over
+// 6 400 rows and three batch-norm launches over its 13 MB result (41 us of the forward side stream).
+__global__ void __launch_bounds__(256)
+per_fc_bn_stats_kernel(int G, int P, int U, int NCp, float n, const float* __restrict__ W, const float* __restrict__ b,
+                       const float* __restrict__ gram, float* __restrict__ mean, float* __restrict__ rstd,
+                       float* __restrict__ var) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= G * U) return;
+    const int g = idx / U, u = idx - g * U;
+    const int o = g * (P + 1);
+    double m = 0.0, q = 0.0;
+    for (int j = 0; j < P; ++j) {
+        const double wj = (double)W[(long)j * U + u];
+        m += (double)gram[(long)(o + j) * NCp + o + P] * wj;
+        double r = 0.0;
+        for (int i = 0; i < P; ++i) r += (double)gram[(long)(o + j) * NCp + o + i] * (double)W[(long)i * U + u];
+        q += wj * r;
+    }
+    m /= (double)n;
+    double v = q / (double)n - m * m;
+    if (v < 0.0) v = 0.0;
+    mean[idx] = (float)(m + (double)b[u]);
+    rstd[idx] = (float)(1.0 / sqrt(v + 1e-3));
+    if (var) var[idx] = (float)v;
+}
+extern "C" int d2p_per_fc_bn_stats(int G, int P, int U, int NCp, int rows_per_group, const float* W, const float* b,
+                                   const float* gram, float* mean, float* rstd, float* var, d2p_stream_t stream) {
+    D2P_REQUIRE(G > 0 && P > 0 && U > 0 && NCp >= G * (P + 1) && rows_per_group > 0, D2P_EINVAL, "per_fc_bn_stats: bad sizes");
+    D2P_REQUIRE(W && b && gram && mean && rstd, D2P_EINVAL, "per_fc_bn_stats: null pointer");
+    hipLaunchKernelGGL(per_fc_bn_stats_kernel, dim3((G * U + 255) / 256), dim3(256), 0, as_stream(stream), G, P, U, NCp,
+                       (float)rows_per_group, W, b, gram, mean, rstd, var);
+    D2P_LAUNCH_CHECK("per_fc_bn_stats");
+    return D2P_OK;
+}
+
 // Backward of fc + batch norm from the column sums alone.  Q [NCp, U] = (A^T dZ) . Wx^T: row g*(P+1)+j = sum over
 // the group's rows of per[r, j] * dpe[r, :], row g*(P+1)+P = sum of dpe[r, :] (dpe = dZ . Wx^T is never formed;
 // rows past the decoded steps contribute nothing to Q).  gram [NCp, NCp] = A^T A over ALL rows: per_g^T per_g and

@@ -297,6 +297,13 @@ def per_affine_rows(G, P, W, b, gamma, beta, mean, rstd, H):
     return H
 
 
+def per_fc_bn_stats(G, P, rows_per_group, W, b, gram, mean, rstd, var=None):
+    """mean / rstd / var [G, U] of per . W + b per demonstration index, from gram alone (d2p_per_fc_bn_stats)."""
+    U = W.shape[1]
+    call.d2p_per_fc_bn_stats(G, P, U, gram.shape[0], rows_per_group, ptr(W), ptr(b), ptr(gram), ptr(mean), ptr(rstd),
+                             ptr(var), current_stream())
+
+
 def per_fc_bn_bwd(G, P, rows_per_group, W, b, gamma, mean, rstd, Q, gram, dW, db, dgamma, dbeta):
     NCp, U = Q.shape
     call.d2p_per_fc_bn_bwd(G, P, U, NCp, rows_per_group, ptr(W), ptr(b), ptr(gamma), ptr(mean), ptr(rstd), ptr(Q),

@@ -523,9 +523,22 @@ class Model(object):
                                                n=n_d * M)
                 # Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
                 per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
-                pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
-                                   bias=p['per/fc/b'], act=0)
-                pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
+                if (self.per_factored and self.is_train and feed.get('per_gram') is not None
+                        and os.environ.get('D2P_PER_STATS_CLOSED', '1') == '1'):
+                    # (round 4) the factored form below needs this batch norm's STATISTICS only, and those follow
+                    # from the Gram matrix that comes with the feed: no K = 5 product over 6 400 rows, no batch-norm
+                    # launches over its result (d2p_per_fc_bn_stats; 41 us of forward side-stream time)
+                    pe_a = pe = None
+                    pe_mean = self._buf('per/fc/bn_mean', (k, U))
+                    pe_rstd = self._buf('per/fc/bn_rstd', (k, U))
+                    pe_var = self._buf('per/fc/bn_var', (k, U))
+                    K.per_fc_bn_stats(k, P, T * B, p['per/fc/W'], p['per/fc/b'], feed['per_gram'], pe_mean, pe_rstd, pe_var)
+                    if self.track_moving:
+                        K.bn_update_moving(pe_mean, pe_var, *self.moving['per/fc'])
+                else:
+                    pe_a = K.matmul_nn(per_tm.view(T * M, P), p['per/fc/W'], out=self._buf('pe_a', (T * M, U)),
+                                       bias=p['per/fc/b'], act=0)
+                    pe, pe_mean, pe_rstd = self._bn_fwd('per/fc', pe_a, p['per/fc/gamma'], p['per/fc/beta'], k, 1)
                 z_a = (self._token_xproj('act', ids_a, A, M, T, n_d) if tokproj
                        else self._lstm_xproj('act/lstm', emb_a, U, M, T, n_d))
                 if self.per_factored and self.is_train:

@@ -563,6 +563,11 @@ int d2p_zero_past_group_steps(int T, int R, int V, int G, const int* lens, float
  * [NCp, NCp] -- no [rows, U] matrix is multiplied by Wx in either direction.  P <= 8. */
 int d2p_per_affine_rows(int G, int P, int U, int NCp, const float* W, const float* b, const float* gamma,
                         const float* beta, const float* mean, const float* rstd, float* H, d2p_stream_t stream);
+/* Batch statistics of u = per . W + b per demonstration index (the Per_Encoder's fc + batch norm, models/model_full.py:
+ * 383-398) from gram = A^T A alone (A as for d2p_per_affine_rows; its blocks hold per_g^T per_g and colsum(per_g)):
+ * mean / rstd / var [G, U] (var biased, may be NULL), fp64 inside.  rows_per_group = rows of A per index. */
+int d2p_per_fc_bn_stats(int G, int P, int U, int NCp, int rows_per_group, const float* W, const float* b,
+                        const float* gram, float* mean, float* rstd, float* var, d2p_stream_t stream);
 int d2p_per_fc_bn_bwd(int G, int P, int U, int NCp, int rows_per_group, const float* W, const float* b,
                       const float* gamma, const float* mean, const float* rstd, const float* Q, const float* gram,
                       float* dW, float* db, float* dgamma, float* dbeta, d2p_stream_t stream);

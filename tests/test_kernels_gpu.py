@@ -1447,3 +1447,27 @@ def test_rows_summed_by_key_equal_index_add(K, n, rows, E):
     out2 = torch.full((rows, E), float('nan'), device='cuda')
     K.embedding_scatter_add(ids.cuda(), x.cuda(), out2)
     assert torch.equal(out, out2)
+
+
+def test_per_fc_bn_statistics_from_the_gram_matrix(K):
+    """d2p_per_fc_bn_stats: mean / rstd / var per demonstration index of u = per . W + b (the Per_Encoder's fc in front of
+    its batch norm, models/model_full.py:383-398) from gram = A^T A alone, against the statistics of the rows themselves
+    in fp64."""
+    G, P, U, T, B = 10, 5, 512, 20, 32
+    g = torch.Generator().manual_seed(11)
+    per = torch.rand(T, B, G, P, generator=g)                       # rows t*M + b*k + i
+    W, b = torch.randn(P, U, generator=g) * 0.5, torch.randn(U, generator=g) * 0.1
+    NCp = 64
+    A = torch.zeros(T * B * G, NCp)
+    A4 = A.view(T, B, G, NCp)
+    for i in range(G):
+        A4[:, :, i, i * (P + 1):i * (P + 1) + P] = per[:, :, i]
+        A4[:, :, i, i * (P + 1) + P] = 1.0
+    gram = (A.double().t() @ A.double()).float().cuda()
+    mean, rstd, var = (torch.empty(G, U, device='cuda') for _ in range(3))
+    K.per_fc_bn_stats(G, P, T * B, W.cuda(), b.cuda(), gram, mean, rstd, var)
+    u = per.double() @ W.double() + b.double()                      # [T, B, G, U]
+    rows = u.permute(2, 0, 1, 3).reshape(G, T * B, U)
+    torch.testing.assert_close(mean.double().cpu(), rows.mean(1), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(var.double().cpu(), rows.var(1, unbiased=False), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(rstd.double().cpu(), 1.0 / torch.sqrt(rows.var(1, unbiased=False) + 1e-3), rtol=1e-4, atol=0)
