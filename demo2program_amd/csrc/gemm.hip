@@ -506,6 +506,100 @@ rows_by_key_kernel(int n, int nkeys, int E, int rows_per_slice, const int* __res
     }
 }
 
+// ---- S = A^T dz for the perception decoder's factored input, from the structure of A ---------------------------------
+// A (d2p_per_affine_rows) has P + 1 non-zeros per row: per[r, 0..P) in the columns of the row's demonstration index
+// g = r % G and a 1 behind them -- so S [NCp, E] is, per index, P + 1 weighted sums of the index's dz rows: a read of dz
+// (52 MB) instead of a 60 x 2048 x 6400 matrix-pipe launch (34 us).  Row lane = index: thread (column lane, g) walks the
+// rows r = g, g + G, ... of its slice (four in flight) with P + 1 accumulators of four columns in registers; slices are
+// added by the deterministic combine kernel.  G <= 16, P <= 8, rows a multiple of G.
+#define PRT_MAXP 8
+__global__ void __launch_bounds__(256)
+per_rows_tn_kernel(int rows, int G, int P, int E, int NCp, int rows_per_slice, const float* __restrict__ per,
+                   const float* __restrict__ dz, float* __restrict__ partial) {
+    const int tid = threadIdx.x, cl = tid & 15, g = tid >> 4;
+    float* out = partial + (size_t)blockIdx.y * NCp * E;
+    const int c0 = blockIdx.x * 64 + 4 * cl;
+    if (g >= G) {
+        // the spare row lanes write the pad rows of S (NC .. NCp) as zeros
+        for (int i = (g - G) * 16 + cl; i < (NCp - G * (P + 1)) * 16; i += (16 - G) * 16) {
+            const int row = G * (P + 1) + i / 16, c = blockIdx.x * 64 + 4 * (i % 16);
+            if (c < E) *reinterpret_cast<tnd_f32x4*>(out + (size_t)row * E + c) = tnd_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        return;
+    }
+    const int cc = c0 < E - 4 ? c0 : E - 4;
+    const int r0 = blockIdx.y * rows_per_slice;                      // (a multiple of G)
+    const int r1 = r0 + rows_per_slice < rows ? r0 + rows_per_slice : rows;
+    tnd_f32x4 acc[PRT_MAXP + 1];
+#pragma unroll
+    for (int j = 0; j <= PRT_MAXP; ++j) acc[j] = tnd_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = r0 + g; r < r1; r += 4 * G) {
+        tnd_f32x4 v[4];
+        float w[4][PRT_MAXP];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = r + u * G < r1;
+            const int rr = ok ? r + u * G : r;
+            v[u] = *reinterpret_cast<const tnd_f32x4*>(dz + (long)rr * E + cc);
+            if (!ok) v[u] = tnd_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < PRT_MAXP; ++j) w[u][j] = j < P ? per[(long)rr * P + j] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int j = 0; j < PRT_MAXP; ++j)
+                if (j < P) acc[j] += w[u][j] * v[u];
+            acc[PRT_MAXP] += v[u];
+        }
+    }
+    if (c0 < E) {
+#pragma unroll
+        for (int j = 0; j < PRT_MAXP; ++j)
+            if (j < P) *reinterpret_cast<tnd_f32x4*>(out + (size_t)(g * (P + 1) + j) * E + c0) = acc[j];
+        *reinterpret_cast<tnd_f32x4*>(out + (size_t)(g * (P + 1) + P) * E + c0) = acc[PRT_MAXP];
+    }
+}
+
+static int prt_slices(int rows, int G) {
+    int s = rows / (G * 24);                // ~24 rows per thread
+    if (s > 32) s = 32;
+    return s < 1 ? 1 : s;
+}
+extern "C" size_t d2p_per_rows_tn_ws_bytes(int rows, int G, int NCp, int E) {
+    if (rows <= 0 || G <= 0 || NCp <= 0 || E <= 0) return 0;
+    return (size_t)prt_slices(rows, G) * NCp * E * sizeof(float);
+}
+// (declared in include/d2p.h)
+extern "C" int d2p_per_rows_tn(int rows, int G, int P, int NCp, int E, const float* per, const float* dz, float* S,
+                               void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    D2P_REQUIRE(rows > 0 && G > 0 && G <= 15 && P > 0 && P <= PRT_MAXP && NCp >= G * (P + 1) && E >= 64 && E % 4 == 0 &&
+                rows % G == 0, D2P_EINVAL, "per_rows_tn: rows=%d G=%d P=%d NCp=%d E=%d", rows, G, P, NCp, E);
+    D2P_REQUIRE(per && dz && S && ws && ws_bytes >= d2p_per_rows_tn_ws_bytes(rows, G, NCp, E), D2P_EWS,
+                "per_rows_tn: null pointer or workspace too small");
+    D2P_REQUIRE((((uintptr_t)dz | (uintptr_t)S | (uintptr_t)ws) & 15) == 0, D2P_EALIGN, "per_rows_tn: 16-byte alignment");
+    hipStream_t st = as_stream(stream);
+    const int slices = prt_slices(rows, G);
+    int rps = (rows + slices - 1) / slices;
+    rps = (rps + G - 1) / G * G;
+    hipLaunchKernelGGL(per_rows_tn_kernel, dim3((E + 63) / 64, slices), dim3(256), 0, st, rows, G, P, E, NCp, rps, per, dz,
+                       (float*)ws);
+    D2P_LAUNCH_CHECK("per_rows_tn");
+    EpiDense ep{S, E, nullptr, 0, 0};
+    const long total = (long)NCp * E;
+    if (slices <= 16) {
+        int blocks = (int)((total + 255) / 256);
+        hipLaunchKernelGGL((gemm_splitk_reduce_flat_kernel<EpiDense>), dim3(blocks > 2048 ? 2048 : blocks), dim3(256), 0, st, ep,
+                           (const float*)ws, NCp, E, slices);
+    } else {
+        int blocks = (int)((total * 16 + 255) / 256);
+        hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EpiDense>), dim3(blocks > 4096 ? 4096 : blocks), dim3(256), 0, st, ep,
+                           (const float*)ws, NCp, E, slices);
+    }
+    D2P_LAUNCH_CHECK("per_rows_tn_combine");
+    return D2P_OK;
+}
+
 static int rbk_slices(int n) {
     int s = (n + 199) / 200;              // ~200 rows per workgroup
     if (s > 64) s = 64;

@@ -297,6 +297,18 @@ def per_affine_rows(G, P, W, b, gamma, beta, mean, rstd, H):
     return H
 
 
+def per_rows_tn_ok(rows, G, P, E):
+    return 0 < G <= 15 and 0 < P <= 8 and rows > 0 and rows % G == 0 and E >= 64 and E % 4 == 0
+
+
+def per_rows_tn(G, per_tm2d, dz, S, rows):
+    """S [NCp, E] = A^T dz[:rows] from per_tm2d [rows.., P] (d2p_per_rows_tn: the structure of A, no GEMM)."""
+    P_, (NCp, E) = per_tm2d.shape[1], S.shape
+    ws, wsb = SCRATCH.get(call.d2p_per_rows_tn_ws_bytes(rows, G, NCp, E))
+    call.d2p_per_rows_tn(rows, G, P_, NCp, E, ptr(per_tm2d), ptr(dz), ptr(S), ws, wsb, current_stream())
+    return S
+
+
 def per_fc_bn_stats(G, P, rows_per_group, W, b, gram, mean, rstd, var=None):
     """mean / rstd / var [G, U] of per . W + b per demonstration index, from gram alone (d2p_per_fc_bn_stats)."""
     U = W.shape[1]

@@ -1400,7 +1400,13 @@ class Model(object):
         gk = g[name + '/kernel']
         NCp = self.per_cols
         if rows > 0:
-            S = K.matmul_tn(feed['per_rows'][:rows], dz[:rows], out=self._buf('per/S', (NCp, 4 * U)))
+            per_tm = self._ctx.get('per_tm')
+            if (per_tm is not None and K.per_rows_tn_ok(rows, k, P, 4 * U)
+                    and os.environ.get('D2P_PER_ROWS_TN', '1') == '1'):
+                # (round 4) rows^T dZ from the structure of `rows` (P + 1 non-zeros per row): a read of dz
+                S = K.per_rows_tn(k, per_tm.view(-1, P), dz, self._buf('per/S', (NCp, 4 * U)), rows)
+            else:
+                S = K.matmul_tn(feed['per_rows'][:rows], dz[:rows], out=self._buf('per/S', (NCp, 4 * U)))
             K.matmul_tn(self._bufs['per/H'], S, out=gk[:U])                       # dWx = H^T (rows^T dZ)
             Q = K.matmul_nt(S, p[name + '/kernel'][:U], out=self._buf('per/Q', (NCp, U)))
             K.per_fc_bn_bwd(k, P, c.batch_size * c.max_demo_len, p['per/fc/W'], p['per/fc/b'], p['per/fc/gamma'],

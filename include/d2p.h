@@ -563,6 +563,13 @@ int d2p_zero_past_group_steps(int T, int R, int V, int G, const int* lens, float
  * [NCp, NCp] -- no [rows, U] matrix is multiplied by Wx in either direction.  P <= 8. */
 int d2p_per_affine_rows(int G, int P, int U, int NCp, const float* W, const float* b, const float* gamma,
                         const float* beta, const float* mean, const float* rstd, float* H, d2p_stream_t stream);
+/* S [NCp, E] = A^T dz over the first `rows` rows, from the structure of A (d2p_per_affine_rows: row r holds
+ * per[r, 0..P) in the columns g*(P+1) .. of its demonstration index g = r % G and a 1 at g*(P+1)+P): what
+ * d2p_gemm_f32_tn(A, dz) computes, as a read of dz.  per [rows, P] (time-major rows, as dz), G <= 15, P <= 8,
+ * rows % G == 0, E % 4 == 0; rows NC .. NCp of S are written as zeros.  Fixed summation order. */
+size_t d2p_per_rows_tn_ws_bytes(int rows, int G, int NCp, int E);
+int d2p_per_rows_tn(int rows, int G, int P, int NCp, int E, const float* per, const float* dz, float* S, void* ws,
+                    size_t ws_bytes, d2p_stream_t stream);
 /* Batch statistics of u = per . W + b per demonstration index (the Per_Encoder's fc + batch norm, models/model_full.py:
  * 383-398) from gram = A^T A alone (A as for d2p_per_affine_rows; its blocks hold per_g^T per_g and colsum(per_g)):
  * mean / rstd / var [G, U] (var biased, may be NULL), fp64 inside.  rows_per_group = rows of A per index. */

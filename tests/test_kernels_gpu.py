@@ -1471,3 +1471,28 @@ def test_per_fc_bn_statistics_from_the_gram_matrix(K):
     torch.testing.assert_close(mean.double().cpu(), rows.mean(1), rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(var.double().cpu(), rows.var(1, unbiased=False), rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(rstd.double().cpu(), 1.0 / torch.sqrt(rows.var(1, unbiased=False) + 1e-3), rtol=1e-4, atol=0)
+
+
+@pytest.mark.parametrize('G,P,T,B,E', [(10, 5, 20, 32, 2048), (3, 2, 7, 4, 256), (15, 8, 4, 2, 64)])
+def test_per_rows_transposed_product_from_the_structure_of_the_rows(K, G, P, T, B, E):
+    """d2p_per_rows_tn: S = A^T dz with A built as derive_per_rows builds it (per values in the columns of the row's
+    demonstration index, a 1 behind them) against the fp64 product; pad rows of S zero; two runs bit-identical."""
+    g = torch.Generator().manual_seed(G * 100 + P)
+    M = B * G
+    per = torch.rand(T, M, P, generator=g)
+    dz = torch.randn(T * M, E, generator=g)
+    NCp = (G * (P + 1) + 3) // 4 * 4 + 4
+    A = torch.zeros(T * M, NCp, dtype=torch.float64)
+    for i in range(G):
+        rows = torch.arange(T * M)[torch.arange(T * M) % G == i]
+        A[rows, i * (P + 1):i * (P + 1) + P] = per.view(T * M, P)[rows].double()
+        A[rows, i * (P + 1) + P] = 1.0
+    n = (T - 1) * M if T > 4 else T * M                      # (the decoded steps only)
+    ref = A[:n].t() @ dz[:n].double()
+    S = torch.full((NCp, E), float('nan'), device='cuda')
+    K.per_rows_tn(G, per.view(T * M, P).cuda(), dz.cuda(), S, n)
+    torch.testing.assert_close(S.double().cpu(), ref, rtol=1e-5, atol=1e-4)
+    assert float(S[G * (P + 1):].abs().max()) == 0.0
+    S2 = torch.full((NCp, E), float('nan'), device='cuda')
+    K.per_rows_tn(G, per.view(T * M, P).cuda(), dz.cuda(), S2, n)
+    assert torch.equal(S, S2)
