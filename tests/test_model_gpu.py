@@ -1331,3 +1331,32 @@ def test_loss_value_from_the_loss_backward_launch(monkeypatch):
     assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0]), (res[0][0], res[1][0])
     assert torch.equal(res[0][1], res[1][1])
     torch.testing.assert_close(res[0][2], res[1][2], rtol=2e-6, atol=1e-7)
+
+
+def test_rows_past_a_sequence_are_selected_around_not_multiplied():
+    """The encoders' input projections are computed over the rows inside their sequences only (d2p_gemm_f32_rows): the
+    other rows of z keep whatever an earlier batch left there.  Poisoned with NaN, loss and every gradient must come out
+    bit-identical -- the recurrences select around those rows, they do not multiply them by a mask."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.synthetic import make_batch
+    cfg = make_config('karel', batch_size=8, k=4, num_lstm_cell_units=128)
+    m = Model(cfg, seed=21)
+    feed = m.get_feed_dict(make_batch(cfg, seed=22))
+    assert feed.get('n_active') is not None and 0 < feed['n_active'] < cfg.max_demo_len * cfg.batch_size * cfg.k
+    loss0 = float(m.forward(feed).item())
+    m.backward()
+    torch.cuda.synchronize()
+    g0 = m.params.grad.clone()
+    poisoned = 0
+    for name in ('demo_lstm/z', 'second_lstm/z', 'second_lstm/dx', 'demo_lstm/dx'):
+        if name in m._bufs:
+            m._bufs[name].fill_(float('nan'))
+            poisoned += 1
+    assert poisoned >= 2
+    loss1 = float(m.forward(feed).item())
+    m.backward()
+    torch.cuda.synchronize()
+    assert loss1 == loss0
+    assert not torch.isnan(m.params.grad).any()
+    assert torch.equal(m.params.grad, g0)
