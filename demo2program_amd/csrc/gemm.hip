@@ -561,6 +561,47 @@ per_rows_tn_kernel(int rows, int G, int P, int E, int NCp, int rows_per_slice, c
     }
 }
 
+// The forward counterpart: z [rows, E] = A . HWx + bias from the structure of A (P + 1 non-zeros per row): a write of z
+// (52 MB) with the six HWx rows of the row's index in registers, instead of a K = 60 matrix-pipe launch (34 us).
+// Workgroup = (256 columns, index g, 32 rows of that index); thread (column lane, row lane).
+__global__ void __launch_bounds__(256)
+per_rows_nn_kernel(int rows, int G, int P, int E, const float* __restrict__ per, const float* __restrict__ HWx,
+                   const float* __restrict__ bias, float* __restrict__ z) {
+    const int tid = threadIdx.x, cl = tid & 63, rl = tid >> 6;
+    const int c0 = blockIdx.x * 256 + 4 * cl;
+    const int g = blockIdx.y, i0 = blockIdx.z * 32;
+    if (c0 >= E) return;
+    tnd_f32x4 hw[PRT_MAXP + 1];
+#pragma unroll
+    for (int j = 0; j < PRT_MAXP; ++j)
+        hw[j] = j < P ? *reinterpret_cast<const tnd_f32x4*>(HWx + (size_t)(g * (P + 1) + j) * E + c0) : tnd_f32x4{0.f, 0.f, 0.f, 0.f};
+    hw[PRT_MAXP] = *reinterpret_cast<const tnd_f32x4*>(HWx + (size_t)(g * (P + 1) + P) * E + c0);
+    if (bias) hw[PRT_MAXP] += *reinterpret_cast<const tnd_f32x4*>(bias + c0);
+#pragma unroll 2
+    for (int i = i0 + rl; i < i0 + 32; i += 4) {
+        const long r = (long)i * G + g;
+        if (r >= rows) break;
+        tnd_f32x4 o = hw[PRT_MAXP];
+#pragma unroll
+        for (int j = 0; j < PRT_MAXP; ++j)
+            if (j < P) o += per[r * P + j] * hw[j];
+        *reinterpret_cast<tnd_f32x4*>(z + r * E + c0) = o;
+    }
+}
+// (declared in include/d2p.h)
+extern "C" int d2p_per_rows_nn(int rows, int G, int P, int NCp, int E, const float* per, const float* HWx, const float* bias,
+                               float* z, d2p_stream_t stream) {
+    D2P_REQUIRE(rows > 0 && G > 0 && G <= 65535 && P > 0 && P <= PRT_MAXP && NCp >= G * (P + 1) && E >= 4 && E % 4 == 0 &&
+                rows % G == 0, D2P_EINVAL, "per_rows_nn: rows=%d G=%d P=%d NCp=%d E=%d", rows, G, P, NCp, E);
+    D2P_REQUIRE(per && HWx && z, D2P_EINVAL, "per_rows_nn: null pointer");
+    D2P_REQUIRE((((uintptr_t)HWx | (uintptr_t)z | (uintptr_t)bias) & 15) == 0, D2P_EALIGN, "per_rows_nn: 16-byte alignment");
+    const int per_group = rows / G;
+    hipLaunchKernelGGL(per_rows_nn_kernel, dim3((E + 255) / 256, G, (per_group + 31) / 32), dim3(256), 0, as_stream(stream), rows,
+                       G, P, E, per, HWx, bias, z);
+    D2P_LAUNCH_CHECK("per_rows_nn");
+    return D2P_OK;
+}
+
 static int prt_slices(int rows, int G) {
     int s = rows / (G * 24);                // ~24 rows per thread
     if (s > 32) s = 32;

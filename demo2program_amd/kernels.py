@@ -297,6 +297,13 @@ def per_affine_rows(G, P, W, b, gamma, beta, mean, rstd, H):
     return H
 
 
+def per_rows_nn(G, per_tm2d, HWx, bias, z, rows):
+    """z[:rows] = A . HWx + bias from per_tm2d [.., P] (d2p_per_rows_nn: the structure of A, no GEMM)."""
+    call.d2p_per_rows_nn(rows, G, per_tm2d.shape[1], HWx.shape[0], HWx.shape[1], ptr(per_tm2d), ptr(HWx), ptr(bias), ptr(z),
+                         current_stream())
+    return z
+
+
 def per_rows_tn_ok(rows, G, P, E):
     return 0 < G <= 15 and 0 < P <= 8 and rows > 0 and rows % G == 0 and E >= 64 and E % 4 == 0
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     'd2p_bn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'd2p_bn_batched_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'd2p_per_affine_rows': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, S]),
+    'd2p_per_rows_nn': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, S]),
     'd2p_per_rows_tn_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'd2p_per_rows_tn': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, c_size_t, S]),
     'd2p_per_fc_bn_stats': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, S]),

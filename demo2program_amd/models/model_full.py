@@ -549,8 +549,12 @@ class Model(object):
                     HWx = K.matmul_nn(H, p['per/lstm/kernel'][:U], out=self._buf('per/HWx', (self.per_cols, 4 * U)))
                     z_q = self._buf('per/lstm/z', (T * M, 4 * U))
                     if n_d > 0 and not self._abl('zq'):          # (timing experiment: tools/step_ablation.sh)
-                        K.gemm_raw('nn', n_d * M, 4 * U, self.per_cols, feed['per_rows'], self.per_cols, HWx, 4 * U,
-                                   z_q, 4 * U, bias=p['per/lstm/bias'])
+                        if K.per_rows_tn_ok(n_d * M, k, P, 4 * U) and os.environ.get('D2P_PER_ROWS_NN', '1') == '1':
+                            # (round 4) from the structure of `rows` (P + 1 non-zeros per row): a write of z
+                            K.per_rows_nn(k, per_tm.view(T * M, P), HWx, p['per/lstm/bias'], z_q, n_d * M)
+                        else:
+                            K.gemm_raw('nn', n_d * M, 4 * U, self.per_cols, feed['per_rows'], self.per_cols, HWx, 4 * U,
+                                       z_q, 4 * U, bias=p['per/lstm/bias'])
                     pe = None
                 else:
                     z_q = self._lstm_xproj('per/lstm', pe, U, M, T, n_d)

@@ -570,6 +570,11 @@ int d2p_per_affine_rows(int G, int P, int U, int NCp, const float* W, const floa
 size_t d2p_per_rows_tn_ws_bytes(int rows, int G, int NCp, int E);
 int d2p_per_rows_tn(int rows, int G, int P, int NCp, int E, const float* per, const float* dz, float* S, void* ws,
                     size_t ws_bytes, d2p_stream_t stream);
+/* z [rows, E] = A . HWx + bias over the first `rows` rows from the structure of A (as d2p_per_rows_tn): what
+ * d2p_gemm_f32_nn(A, HWx, bias) computes -- the factored perception decoder's input projection -- as a write of z.
+ * HWx [NCp, E], bias [E] or NULL, per [rows, P]; P <= 8, rows % G == 0, E % 4 == 0. */
+int d2p_per_rows_nn(int rows, int G, int P, int NCp, int E, const float* per, const float* HWx, const float* bias,
+                    float* z, d2p_stream_t stream);
 /* Batch statistics of u = per . W + b per demonstration index (the Per_Encoder's fc + batch norm, models/model_full.py:
  * 383-398) from gram = A^T A alone (A as for d2p_per_affine_rows; its blocks hold per_g^T per_g and colsum(per_g)):
  * mean / rstd / var [G, U] (var biased, may be NULL), fp64 inside.  rows_per_group = rows of A per index. */

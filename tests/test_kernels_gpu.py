@@ -1496,3 +1496,25 @@ def test_per_rows_transposed_product_from_the_structure_of_the_rows(K, G, P, T, 
     S2 = torch.full((NCp, E), float('nan'), device='cuda')
     K.per_rows_tn(G, per.view(T * M, P).cuda(), dz.cuda(), S2, n)
     assert torch.equal(S, S2)
+
+
+@pytest.mark.parametrize('G,P,T,B,E', [(10, 5, 20, 32, 2048), (3, 2, 7, 4, 260), (25, 8, 4, 2, 64)])
+def test_per_rows_product_from_the_structure_of_the_rows(K, G, P, T, B, E):
+    """d2p_per_rows_nn: z = A . HWx + bias with A as derive_per_rows builds it, against the fp64 product; rows past the
+    decoded steps untouched."""
+    g = torch.Generator().manual_seed(G * 10 + P)
+    M = B * G
+    per = torch.rand(T, M, P, generator=g)
+    NCp = (G * (P + 1) + 3) // 4 * 4 + 4
+    HWx, bias = torch.randn(NCp, E, generator=g), torch.randn(E, generator=g)
+    A = torch.zeros(T * M, NCp, dtype=torch.float64)
+    for i in range(G):
+        rows = torch.arange(T * M)[torch.arange(T * M) % G == i]
+        A[rows, i * (P + 1):i * (P + 1) + P] = per.view(T * M, P)[rows].double()
+        A[rows, i * (P + 1) + P] = 1.0
+    n = (T - 1) * M
+    z = torch.full((T * M, E), 7.0, device='cuda')
+    K.per_rows_nn(G, per.view(T * M, P).cuda(), HWx.cuda(), bias.cuda(), z, n)
+    ref = A[:n] @ HWx.double() + bias.double()
+    torch.testing.assert_close(z[:n].double().cpu(), ref, rtol=1e-5, atol=1e-5)
+    assert bool((z[n:] == 7.0).all())
