@@ -458,8 +458,11 @@ class Model(object):
         x = feed['s_h']
         ctx['conv'] = []
         feats_tm = None
-        if self._fused_encoder(B, k, T) and not self._abl('conv_fwd'):
+        if self._abl('conv_fwd') and 'conv_fused' in self._abl_cache:        # (timing experiment: the previous step's)
+            ctx['conv'], feats_tm = self._abl_cache['conv_fused']
+        elif self._fused_encoder(B, k, T) and not self._abl('conv_fwd'):
             feats_tm = self._encoder_fwd_fused(x, ctx, main, side)
+            self._abl_cache['conv_fused'] = (ctx['conv'], feats_tm)
         for l, (h, w, cin, cout, ho, wo) in enumerate(self._conv, start=1):
             if feats_tm is not None:
                 break
