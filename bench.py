@@ -48,7 +48,7 @@ EMPTY_LAUNCH_US = 2.7          # a dependent empty launch on one stream (DESIGN.
 # kernel family -> key in profiles/*_pmc_traffic.json (tools/pmc_summary.py)
 PMC_KEYS = {1: 'gemm_mfma_kernel', 2: 'gemm_mfma_kernel<conv>', 7: 'lstm_persist_fwd_kernel',
             8: 'lstm_persist_bwd_kernel', 3: 'lstm_gate_fwd_kernel', 4: 'lstm_gate_bwd_kernel'}
-PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json',
+PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json',
                                                          'r01_pmc_traffic.json')]
 
 # profiling key (include/d2p.h) -> (name, roofline that bounds it, reporting group)
@@ -102,7 +102,7 @@ def _rate(work, ms, bound):
     return work / (ms / 1e3) / (1e12 if bound == 'mfma' else 1e9)
 
 
-def roofline_leg(trainer, feeds, steps=2):
+def roofline_leg(trainer, feeds, steps=2, keep_side=False):
     """Re-runs `steps` training steps with per-launch HIP events enabled inside the library (events on
     the launch stream, eager launches on ONE stream so a bracket times that kernel alone).  Families
     are grouped before ranking: all GEMM instantiations are one family, and so are the forward and
@@ -114,9 +114,9 @@ def roofline_leg(trainer, feeds, steps=2):
     lib.d2p_prof_enable(1)
     lib._d2p_prof_on = True          # Trainer.train_step takes the eager (un-graphed) path
     side = trainer.model.use_side_stream
-    # (D2P_PROF_KEEP_SIDE=1, diagnostic: the two-stream schedule under the brackets -- a family's time is then what its
+    # (--prof-keep-side, diagnostic: the two-stream schedule under the brackets -- a family's time is then what its
     #  launches take BESIDE the other stream's work; the reported roofline always uses one stream)
-    if os.environ.get('D2P_PROF_KEEP_SIDE', '0') != '1':
+    if not keep_side:
         trainer.model.use_side_stream = False
     for i in range(steps):
         trainer.train_step(feeds[i % len(feeds)])
@@ -484,6 +484,11 @@ def main():
                     'no prefetch); the prefetched PCIe-inclusive rate is always reported')
     ap.add_argument('--no-h2d', action='store_true', help='skip the PCIe-inclusive leg')
     ap.add_argument('--no-config4', action='store_true', help='skip the ViZDoom (BASELINE config 4) leg')
+    ap.add_argument('--prof-keep-side', action='store_true',
+                    help='diagnostic: the instrumented pass keeps the two-stream schedule (family times BESIDE the other queue)')
+    ap.add_argument('--ablate', default='',
+                    help='MEASUREMENT ONLY (tools/step_ablation.sh): comma-separated pieces of the step to leave out '
+                         '(Model.set_ablation); the line is then marked invalid -- it is not a throughput of the model')
     ap.add_argument('--self-spawn', action='store_true',
                     help='start the N ranks from this process even for N = 1 (the path `python bench.py --gpus N` takes '
                          'for N > 1 when it was not launched by torch.distributed.run)')
@@ -514,6 +519,8 @@ def main():
     config = make_config(args.preset)
     log('building trainer')
     trainer = Trainer(config, make_train_dir=False, dp=dp)
+    if args.ablate:
+        trainer.model.set_ablation(args.ablate.split(','))
     log('trainer ready; making batches')
     # distinct per-rank synthetic batches, made resident in HBM before the timed region
     host_batches = [make_batch(config, seed=123 + 7919 * dp.rank + i) for i in range(4)]
@@ -531,7 +538,7 @@ def main():
     log('warmup done; timing %d steps' % args.steps)
     dp.barrier()
     torch.cuda.synchronize()
-    waited0 = trainer.guard.waited if trainer.guard is not None else 0.0
+    waited0 = trainer.guard.waited
     t0 = time.perf_counter()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     marks[0].record()
@@ -539,10 +546,9 @@ def main():
         loss = trainer.train_step(feeds[i % len(feeds)])
         marks[i + 1].record()             # device-side step boundaries (no host sync inside the region)
     host_enqueue = time.perf_counter() - t0   # host time to ENQUEUE the K steps (device may still be running)
-    if trainer.guard is not None:
-        # the step guard lets the host run at most StepGuard.DEPTH steps ahead: time it spent WAITING for the device
-        # is not enqueue work
-        host_enqueue -= trainer.guard.waited - waited0
+    # the step guard lets the host run at most StepGuard.DEPTH steps ahead: time it spent WAITING for the device is not
+    # enqueue work
+    host_enqueue -= trainer.guard.waited - waited0
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -628,7 +634,7 @@ def main():
 
     if not args.no_roofline:
         log('roofline leg')
-        roof, furthest, table, every = roofline_leg(trainer, feeds)
+        roof, furthest, table, every = roofline_leg(trainer, feeds, keep_side=args.prof_keep_side)
         out['roofline'] = roof
         out['roofline_every_group'] = every
         out['furthest_below_roofline'] = furthest
@@ -642,6 +648,9 @@ def main():
         from demo2program_amd.params import init_params
         log('cpu baseline leg (%d host cores)' % (os.cpu_count() or 1))
         out['cpu_baseline'] = cpu_baseline_leg(config, host_batches[0], init_params(config, 123))
+    if args.ablate:
+        out['invalid'] = 'timing-only ablation: the step leaves out %s -- not a throughput of the model' % args.ablate
+        out['value'] = None
     if dp.rank == 0:
         print(json.dumps(out))
     dp.shutdown()

@@ -438,7 +438,7 @@ struct WgradLaunch {
 //
 // A workgroup owns the frames of ONE demonstration index g for a few programs b (frames (b*G + g)*T .. +T-1): the
 // batch-norm statistics of a layer mix all frames of an index, so the S workgroups of an index meet at a barrier per
-// layer -- partial sums as write-through stores, an arrival counter per (launch slot, layer, index), every workgroup
+// layer -- partial sums as write-through stores, an arrival counter per (slice count S, layer, index), every workgroup
 // adds the S partial sums in slice order (fp64: the same statistics as the bn_partial / finalize launches up to the
 // order of an fp64 sum).  A layer's activations never leave the CU on the way to the next layer: the epilogue writes
 // them into the next layer's LDS image (the padded pixel-major form conv_frames_fwd_kernel stages from memory), the
@@ -447,9 +447,16 @@ struct WgradLaunch {
 // Needs the G*S workgroups co-resident (grid <= CUs, checked on the host); every spin is bounded and reports through the
 // persistent kernels' status word (the guarded optimizer step then skips the step and the trainer re-runs it on the
 // separate launches).
-#define ENC_SLOTS 64
+// The arrival counters are MONOTONIC 64-bit tickets, never reset and not chosen by the host: a workgroup's ticket t =
+// fetch_add(counter, 1) belongs to generation t / S and waits for the counter to reach (t / S + 1) * S.  Launches that
+// share a counter are ordered (one stream, or graph replays of one stream's capture) and every workgroup of a launch
+// counts itself in exactly once per layer even when it gives up, so a launch always leaves a multiple of S behind --
+// which makes the barrier safe under hipGraph replay (round 4 picked a counter slot on the HOST per launch: baked into
+// a captured node, every replay after the first fell through).  One counter set per slice count S,
+// so that launches of different geometry never share one.
 #define ENC_MAXG 32
-__device__ unsigned g_enc_counters[ENC_SLOTS][3][ENC_MAXG];
+#define ENC_MAXS 256
+__device__ unsigned long long g_enc_counters[ENC_MAXS + 1][3][ENC_MAXG];
 
 struct EncArgs {
     const void* x;
@@ -458,9 +465,9 @@ struct EncArgs {
     float* feats_tm;                 // [T, B*G, 48]
     float *mean[3], *rstd[3], *var[3];   // [G, C_l]
     double* part;                    // [3][G][S][48][2]
-    unsigned* counters;              // g_enc_counters
+    unsigned long long* counters;    // g_enc_counters[S]
     unsigned* err;
-    int B, G, T, S, nb, slot;
+    int B, G, T, S, nb;
     unsigned long long* trace;       // diagnostic (d2p_karel_encoder_set_trace): [workgroup][10] wall-clock stamps, or null
 };
 
@@ -514,11 +521,12 @@ __device__ __forceinline__ void enc_stats(const EncArgs& a, int layer, int g, in
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        unsigned* cnt = a.counters + ((long)a.slot * 3 + layer) * ENC_MAXG + g;
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* cnt = a.counters + (long)layer * ENC_MAXG + g;
+        const unsigned long long ticket = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (ticket / (unsigned)a.S + 1ull) * (unsigned)a.S;
         unsigned spins = 0;
         int ok = 1;
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.S) {
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > 800000u || ((spins & 1023u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                 __hip_atomic_store(a.err, (0x7eu << 24) | 0x800000u | (blockIdx.x & 0xffffu), __ATOMIC_RELAXED,
@@ -822,12 +830,6 @@ karel_encoder_fwd_kernel(EncArgs a) {
         *reinterpret_cast<f32x4*>(a.feats_tm + ((long)(lf % T) * M + m) * 48 + c4) = o;
     }
     if (a.trace && tid == 0) a.trace[blockIdx.x * 10 + 9] = wall_clock64();
-    // the counters of the slot ENC_SLOTS / 2 launches ahead are zeroed by this launch (one thread): a slot is reused
-    // ENC_SLOTS launches later, long after; a launch that gave up leaves garbage only in its own slot
-    if (blockIdx.x == 0 && tid < 3 * ENC_MAXG) {
-        unsigned* c = a.counters + (long)((a.slot + ENC_SLOTS / 2) % ENC_SLOTS) * 3 * ENC_MAXG;
-        __hip_atomic_store(c + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
 
 static size_t enc_lds_bytes(int nb, int T) {
@@ -841,7 +843,7 @@ static bool enc_plan(int B, int G, int T, int& S, int& nb) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
-    if (B < 1 || G < 1 || G > ENC_MAXG || T < 4 || T % 4 != 0 || G > cus) return false;
+    if (B < 1 || G < 1 || G > ENC_MAXG || T < 4 || T % 4 != 0 || G > cus || cus / G > ENC_MAXS) return false;
     S = cus / G < B ? cus / G : B;
     nb = (B + S - 1) / S;
     S = (B + nb - 1) / nb;                       // no empty slices
@@ -891,14 +893,12 @@ extern "C" int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_i
     D2P_REQUIRE((((uintptr_t)x | (uintptr_t)feats_tm) & 15) == 0, D2P_EALIGN, "karel encoder: 16-byte alignment");
     e.feats_tm = feats_tm;
     e.part = (double*)ws;
-    static unsigned* counters = nullptr;
+    static unsigned long long* counters = nullptr;
     if (!counters) D2P_HIP(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_enc_counters)));
-    e.counters = counters;
+    e.counters = counters + (size_t)S * 3 * ENC_MAXG;
     e.err = d2p_persist_err_ptr();
     e.B = B; e.G = G; e.T = T; e.S = S; e.nb = nb;
     e.trace = g_enc_trace;
-    static unsigned seq = 0;
-    e.slot = (int)(seq++ % ENC_SLOTS);
     const size_t lds = enc_lds_bytes(nb, T);
     hipStream_t st = as_stream(stream);
     // conv flops of the three layers (as the separate launches count them)

@@ -1,5 +1,4 @@
 // K5: dense fp32 MFMA GEMM entry points + column sum (include/d2p.h).
-#define D2P_GEMM_CORUN_TILES
 #include "gemm_core.h"
 
 static inline int vec_ok(const float* p, long ld) {
@@ -156,6 +155,7 @@ gemm_tn_direct_kernel(const float* __restrict__ A, int lda, const int* __restric
 }
 
 static int g_gemm_tn_direct = 1;          // d2p_gemm_set_option bit 6 switches it off (A/B)
+static int g_rows_by_key = 1;             // d2p_gemm_set_option bit 7 switches it off (A/B, tests)
 
 // true: launched.  Shapes it takes: whole 16-byte pieces everywhere, K in whole ring rounds, enough tiles to fill the chip
 template <int KW, bool GATHER>
@@ -172,9 +172,9 @@ static bool tn_direct_launch_kw(int M, int N, int K, const float* A, long lda, c
     // unchanged although the product itself is 15 % faster); at 100 KB they wait for the recurrence's workgroup to
     // leave the CU, as the four-wave staged kernel does for want of a free SIMD (tools/corun_probe.py)
     constexpr int lds_tree = (KW / 2) * 4096 * (int)sizeof(float);
-    static int lds_env = -1;
-    if (lds_env < 0) { const char* e = getenv("D2P_TND_LDS_KB"); lds_env = e ? atoi(e) * 1024 : 100 * 1024; }
-    const int lds = lds_tree > lds_env ? lds_tree : lds_env;
+    // (100 KB: the optimum of a sweep of the request in the step, profiles/r04_tnd_lds_request_sweep.log)
+    constexpr int lds_req = 100 * 1024;
+    const int lds = lds_tree > lds_req ? lds_tree : lds_req;
     static bool attr = false;
     if (!attr) {
         if (hipFuncSetAttribute((const void*)gemm_tn_direct_kernel<KW, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -191,9 +191,6 @@ static bool tn_direct_launch_kw(int M, int N, int K, const float* A, long lda, c
 template <bool GATHER>
 static bool tn_direct_launch(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
                              const int* rowsB, float* C, long ldc, int accumulate, hipStream_t st) {
-    static int env_on = -1;                  // D2P_GEMM_TN_DIRECT=0: the staged kernel for every product (same-box A/B of the step)
-    if (env_on < 0) { const char* e = getenv("D2P_GEMM_TN_DIRECT"); env_on = (e && e[0] == '0') ? 0 : 1; }
-    if (!env_on) return false;
     return tn_direct_launch_kw<8, GATHER>(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate, st);
 }
 
@@ -203,13 +200,10 @@ extern "C" int d2p_gemm_set_option(int bk32) {
     g_gemm_nosel = (bk32 & 4) ? 0 : 1;         // bit 2: keep the select-at-store loaders for every K
     g_gemm_no_bk32 = (bk32 & 16) ? 1 : 0;      // bit 4 (experiment): never the 32-deep slabs
     g_gemm_tn_direct = (bk32 & 64) ? 0 : 1;    // bit 6: the A^T B products on the staged kernel (no register-direct form)
+    g_rows_by_key = (bk32 & 128) ? 0 : 1;      // bit 7: the embedding gradient as a one-hot GEMM (no rows_by_key_kernel)
     g_gemm_fold = (bk32 & 32) ? 0 : 1;         // bit 5: split-K combine as a separate launch (round 2's form)
     g_gemm_dma_big = (bk32 & 8) ? 1 : 0;       // bit 3 (experiment): large dense GEMMs on the persistent LDS-DMA kernel
-    g_gemm_dma_grid = bk32 >> 8;               // bits 8..: persistent grid of the LDS-DMA kernel (0 = automatic)
-    return D2P_OK;
-}
-extern "C" int d2p_gemm_set_corun(int on) {
-    g_gemm_corun = on ? 1 : 0;
+    g_gemm_dma_grid = bk32 >> 16;              // bits 16..: persistent grid of the LDS-DMA kernel (0 = automatic)
     return D2P_OK;
 }
 extern "C" int d2p_gemm_force_plan(int tile, int splits) {
@@ -647,9 +641,7 @@ static int rbk_slices(int n) {
     return s < 1 ? 1 : s;
 }
 static bool rbk_ok(int n, int rows, int E, const float* dout, const float* dtable) {
-    static int env_on = -1;               // D2P_ROWS_BY_KEY=0: the one-hot GEMM (same-box A/B)
-    if (env_on < 0) { const char* e = getenv("D2P_ROWS_BY_KEY"); env_on = (e && e[0] == '0') ? 0 : 1; }
-    return env_on && n >= 256 && rows <= 32 && E % 4 == 0 && E >= 64 && (((uintptr_t)dout | (uintptr_t)dtable) & 15) == 0;
+    return g_rows_by_key && n >= 256 && rows <= 32 && E % 4 == 0 && E >= 64 && (((uintptr_t)dout | (uintptr_t)dtable) & 15) == 0;
 }
 
 extern "C" size_t d2p_embedding_scatter_ws_bytes(int n, int rows, int E) {

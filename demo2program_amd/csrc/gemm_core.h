@@ -292,11 +292,8 @@ template <int BM, int BN, int WM, int WN, int BK, bool FAST, bool KS, class AL, 
 __global__ void __launch_bounds__(256)
 gemm_mfma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, float* partial, unsigned* tickets) {
     static_assert(!NOSEL || FAST, "NOSEL is a refinement of the fast loaders");
-    static_assert(KS || WM * WN == 4 || WM * WN == 2, "4 waves per workgroup, or 2 (the co-run tiles)");
-    // threads: one wave per wave tile.  Two-wave workgroups exist for launches that run BESIDE a persistent recurrent
-    // kernel (round 4, tools/corun_probe.py): such a kernel holds five 256-register waves per CU, i.e. one SIMD
-    // completely, and the dispatcher then places no FOUR-wave workgroup on that CU whatever its size (it starts when
-    // the recurrence ends), while two-wave workgroups start at once on the other three SIMDs.
+    static_assert(KS || WM * WN == 4, "4 waves per workgroup");
+    // threads: one wave per wave tile
     constexpr int NT = KS ? 256 : 64 * WM * WN;
     static_assert(!KS || (WM == 1 && WN == 1 && BK == 32), "KS: one tile for all waves, 4 chunks per slab");
     static_assert(BK % 8 == 0, "K slab is consumed in chunks of 8");
@@ -950,7 +947,6 @@ gemm_dma_kernel(AL al, BL bl, EP ep, int M, int N, int K, int k_per_split, int s
 // ------------------------------------------------------------------------------------
 static int g_gemm_bk32 = 0;   // per translation unit; toggled through d2p_gemm_set_option
 static int g_gemm_nosel = 1;  // 0: always keep the select between global load and LDS store
-static int g_gemm_corun = 0;         // 1: the launches that follow run beside a persistent recurrent kernel -- two-wave workgroups (d2p_gemm_set_corun)
 static int g_gemm_force_tile = -1;   // -1: automatic; else a GemmTile value (tuning experiments)
 static int g_gemm_force_split = 0;   // 0: automatic
 static int g_gemm_dma_grid = 0;      // 0: CUs x resident workgroups per CU; else the persistent grid (tuning)
@@ -1007,9 +1003,6 @@ static inline GemmPlan d2p_plan_gemm_base(int M, int N, int K, bool allow_split)
         (long)ceil_div(M, 64) * ceil_div(N, N <= 32 ? 32 : 64) <= 8) {
         if (N <= 32) { p.tile = TILE_64x32_KS; p.bm = 64; p.bn = 32; }
         else { p.tile = TILE_64x64_KS; p.bm = 64; p.bn = 64; }
-    }
-    if (g_gemm_corun && (p.tile == TILE_128x64 || p.tile == TILE_128x128)) {    // (the two-wave co-run form is a 64x64 tile)
-        p.tile = TILE_64x64; p.bm = 64; p.bn = 64;
     }
     if (g_gemm_force_tile >= 0) {
         p.tile = g_gemm_force_tile;
@@ -1092,9 +1085,11 @@ static inline GemmPlan d2p_plan_gemm(int M, int N, int K, bool allow_split) {
     const long wgs = (long)ceil_div(M, p.bm) * ceil_div(N, p.bn) * p.splits;
     // (a tall output of <= 64 columns with a long K -- the first encoder's input gradient, 4480 x 48 over K = 2048 --
     //  is 35 tiles of 128x64 x 4 slices = 140 workgroups: 34 us; 280 tiles of 32x32 x 4 slices: 23 us)
-    const bool tall_skinny = N <= 64 && K >= 1024 && wgs < 256 && allow_split;
-    if ((wgs >= 128 && !tall_skinny) || K < 128) return p;
     const long t32 = (long)ceil_div(M, 32) * ceil_div(N, 32);
+    // (only while the 32x32 tiles still get a K split, t32 < 512: past that each of ~1000 small workgroups would walk
+    //  the whole K alone -- the one measured shape is 4480x48x2048)
+    const bool tall_skinny = N <= 64 && K >= 1024 && wgs < 256 && allow_split && t32 < 512;
+    if ((wgs >= 128 && !tall_skinny) || K < 128) return p;
     long s = 1;
     if (allow_split && K >= 1024 && (t32 < 256 || (tall_skinny && t32 < 512))) {
         s = ((t32 < 256 ? 512 : 1024) + t32 - 1) / t32;  // ~2 (4) workgroups per CU
@@ -1221,14 +1216,6 @@ static int d2p_launch_gemm(const AL& al, const BL& bl, const EP& ep, int M, int 
         case TILE_64x64_KS: d2p_launch_tile<64, 64, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch); break;
         case TILE_32x32_KSR: d2p_launch_tile<32, 32, 1, 1, 32, true>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets); break;
         default:
-#ifdef D2P_GEMM_CORUN_TILES           // (gemm.hip only: the conv translation units never launch beside a recurrence)
-            if (g_gemm_corun) {
-                // 64x64 tile on TWO waves (32x64 each, 16-deep slabs: ~100 registers, 16 KB of LDS): the form that
-                // becomes resident beside a persistent recurrent kernel
-                d2p_launch_tile<64, 64, 2, 1, 16>(al, bl, ep, M, N, K, p, fast, partial, st, batch, tickets);
-                break;
-            }
-#endif
             // 32-deep slabs (half the barriers, 128-byte runs): +3-5 % on the large grids, a loss when
             // the workgroups are few (each then walks its K loop with less overlap)
             if (!g_gemm_no_bk32 && (g_gemm_bk32 || (long)ceil_div(M, 64) * ceil_div(N, 64) * p.splits >= 1024) && K >= 256 && fast)

@@ -100,6 +100,9 @@ class Evaler(object):
         _start_time = time.time()
         batch_chunk = batch.next()
         m = self.model
+        if getattr(m, '_ablate', None):
+            raise RuntimeError('this model carries a timing-only ablation (%s): its results are invalid -- Evaler refuses'
+                               % ','.join(sorted(m._ablate)))
         feed = m.get_feed_dict(batch_chunk, is_training=False)
         m.forward(feed)
         loss, acc = m.report(with_greedy=True)

@@ -104,25 +104,6 @@ def gemm_batched(kind, nb1, nb0, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, bi
                               act, 1 if accumulate else 0, current_stream())
 
 
-class gemm_corun(object):
-    """`with gemm_corun():` -- the GEMMs issued inside run beside a persistent recurrent launch of the other stream:
-    two-wave workgroups (d2p_gemm_set_corun; D2P_GEMM_CORUN=0 switches the hint off)."""
-    enabled = None
-
-    def __enter__(self):
-        import os
-        if gemm_corun.enabled is None:
-            gemm_corun.enabled = os.environ.get('D2P_GEMM_CORUN', '0') == '1'
-        if gemm_corun.enabled:
-            call.d2p_gemm_set_corun(1)
-        return self
-
-    def __exit__(self, *exc):
-        if gemm_corun.enabled:
-            call.d2p_gemm_set_corun(0)
-        return False
-
-
 def _p(x):
     if x is None or isinstance(x, int):
         return x

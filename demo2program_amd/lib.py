@@ -29,7 +29,6 @@ SIGNATURES = {
     'd2p_gemm_f32_batched': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_long, c_long, c_long, P, c_long, c_long,
                                      c_long, P, c_long, c_long, c_long, P, c_long, c_long, c_int, c_int, S]),
     'd2p_gemm_force_plan': (c_int, [c_int, c_int]),
-    'd2p_gemm_set_corun': (c_int, [c_int]),
     'd2p_gemm_f32_nn': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
     'd2p_gemm_f32_nt': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
     'd2p_gemm_f32_tn': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
@@ -207,18 +206,7 @@ class _Caller(object):
         lib = load()
         fn = getattr(lib, name)
         res = SIGNATURES[name][0]
-        delay = float(os.environ.get('D2P_HOST_DELAY_US', '0')) * 1e-6
-        if res is c_int and name != 'd2p_version' and delay > 0:
-            # measurement hook: every entry point costs the host `delay` more -- if the step time follows, the host's
-            # enqueue rate is on the critical path somewhere (tools/ab_env.sh D2P_HOST_DELAY_US 0 3)
-            import time
-
-            def wrapped(*args):
-                t_end = time.perf_counter() + delay
-                while time.perf_counter() < t_end:
-                    pass
-                _check(name, fn(*args))
-        elif res is c_int and name != 'd2p_version':
+        if res is c_int and name != 'd2p_version':
             def wrapped(*args):
                 _check(name, fn(*args))
         else:

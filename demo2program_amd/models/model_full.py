@@ -18,7 +18,6 @@ What is batched differently from the reference (results are identical, see DESIG
     [B*k*k, 2U] pair matrix (:335-341) is never materialised.
 Row order everywhere: sequences m = b*k + i; recurrent tensors are time-major [T, M, *].
 """
-import os
 import sys
 
 import numpy as np
@@ -26,6 +25,7 @@ import torch
 
 from .. import kernels as K
 from ..config import conv_shapes, feature_dim, n_conv
+from ..options import flag
 from ..params import FlatParams
 
 
@@ -164,51 +164,38 @@ class Model(object):
         self._ss_rng = torch.tensor([seed * 2654435761 + 12345, 0], dtype=torch.int64, device='cuda')
         if self.scheduled_sampling:
             self.set_sampling_step(int(global_step) if not callable(global_step) else 0)
-        self.fuse_decoders = os.environ.get('D2P_FUSE_DECODERS', '0') == '1'
-        # Second stream for the batch-only work (forward) and the decoders' weight gradients
-        # (backward).  OFF by default: it paid off (~4 %) while the step took 7 ms, but once the small
-        # GEMMs and the K loop were fixed the fork/join edges of the captured two-queue graph cost
-        # more than the remaining overlap buys (6.19 vs 6.29 ms/step Karel, 11.00 vs 11.09 ViZDoom).
-        # a second stream for the work that does not depend on the recurrences (decoder input projections in
-        # forward, the decoders' nine weight / input-gradient GEMMs in backward).  Round 1 measured it as a
-        # loss next to the per-step LSTM kernels; next to the persistent ones (round 2) the GEMMs fill the
-        # matrix pipe while a recurrence waits for its hand-offs: 4.82 vs 5.10 ms per step with eager
-        # launches.  D2P_NO_SIDE_STREAM=1 / D2P_SIDE_STREAM=0 switch it off.
-        # two decoders per persistent launch (d2p_lstm_seq_*_multi with two sequences)
-        self.pair_decoders = os.environ.get('D2P_PAIR_DECODERS', '1') == '1'
+        # all three decoders advanced by ONE per-step launch (d2p_lstm_seq_*_multi on the per-step kernels): an
+        # attribute, not a switch -- tests/test_model_gpu.py sets it to check that path against the default
+        self.fuse_decoders = False
         # the second encoder's input projection and dX run over the rows inside their sequences only (the rows past
-        # a demonstration's length are zeros in its input and in dz); off under hipGraph capture, where the row
-        # count would have to be part of the graph key
-        self.compact_rows = os.environ.get('D2P_COMPACT_ROWS', '1') == '1'
+        # a demonstration's length are zeros in its input and in dz), and the weight gradients over K lists of those
+        # rows; a graph-static feed carries no row lists (their lengths would join the graph key), so a captured step
+        # multiplies the zero rows in
+        self.compact_rows = True
+        self.k_rows = True
         # perception decoder: its batch-normed fc features are never multiplied by Wx row by row (forward _per_xproj)
-        self.per_factored = os.environ.get('D2P_PER_FACTORED', '1') == '1' and config.per_dim <= 8
+        self.per_factored = flag('D2P_PER_FACTORED') and config.per_dim <= 8
         self.per_cols = (config.k * (config.per_dim + 1) + 3) // 4 * 4
         # token-input decoders: project the embedding TABLE and gather, instead of projecting gathered rows
-        self.token_projection = os.environ.get('D2P_TOKEN_PROJECTION', '1') == '1'
-        self.use_side_stream = (os.environ.get('D2P_SIDE_STREAM', '1') == '1' and
-                                os.environ.get('D2P_NO_SIDE_STREAM', '0') != '1')
-        if os.environ.get('D2P_GEMM_OPTION') is not None:          # experiments (d2p_gemm_set_option bits)
-            from ..lib import call
-            call.d2p_gemm_set_option(int(os.environ['D2P_GEMM_OPTION']))
-        if os.environ.get('D2P_LSTM_DIRECT') is not None:           # A/B: 0 = a preparation launch in front of every recurrence
-            from ..lib import call
-            call.d2p_lstm_persist_set_direct(int(os.environ['D2P_LSTM_DIRECT']))
-        if os.environ.get('D2P_LSTM_POLL') is not None:             # A/B: 0 = read / sleep / read flag polls
-            from ..lib import call
-            call.d2p_lstm_persist_set_poll(int(os.environ['D2P_LSTM_POLL']))
-        if os.environ.get('D2P_BWD_DEFER_FROM') is not None:       # experiment: d2p_lstm_persist_set_bwd_defer
-            from ..lib import call
-            call.d2p_lstm_persist_set_bwd_defer(int(os.environ['D2P_BWD_DEFER_FROM']))
-        if os.environ.get('D2P_LSTM_XCD_LOCAL') is not None:       # A/B: 0 = write-through hand-offs in the wide forward kernel too
-            from ..lib import call
-            call.d2p_lstm_persist_set_fwd_wide(1, 0, 0, int(os.environ['D2P_LSTM_XCD_LOCAL']) & 1)
-        K.bn_set_fold(int(os.environ.get('D2P_BN_FOLD', '0')))   # bit 0: ticket fold (no gain), bit 1: round-2 finalize
-        # measurement hook (tools/step_ablation.py): D2P_ABLATE=conv_fwd,rn_bwd,... leaves pieces of the step out from the
-        # second forward pass on (their outputs go stale: timing only, results invalid) -- what a piece is worth in
-        # the real two-queue schedule is the step time without it
-        self._ablate = set(filter(None, os.environ.get('D2P_ABLATE', '').split(',')))
+        self.token_projection = flag('D2P_TOKEN_PROJECTION')
+        # a second stream for the work that does not depend on the recurrences (decoder input projections in
+        # forward, the weight-gradient products in backward): beside the persistent recurrences the GEMMs fill the
+        # matrix pipe while a recurrence waits for its hand-offs
+        self.use_side_stream = flag('D2P_SIDE_STREAM')
+        self.fused_encoder = flag('D2P_FUSED_ENCODER')
+        self.fused_loss = flag('D2P_FUSED_LOSS')
+        # timing-only ablation (tools/step_ablation.py -> set_ablation): NEVER from the environment; Trainer.train and
+        # Evaler refuse a model that carries one
+        self._ablate = frozenset()
         self._abl_cache = {}
         self._reserve_scratch()
+
+    def set_ablation(self, names):
+        """MEASUREMENT HOOK (tools/step_ablation.py, bench.py --ablate): leaves the named pieces of the step out from the
+        second forward pass on -- their outputs go stale, the results of such a step are INVALID; what a piece is
+        worth in the two-queue schedule is the step time without it.  Trainer.train / Evaler raise on such a model."""
+        self._ablate = frozenset(n for n in names if n)
+        self._abl_cache = {}
 
     def _abl(self, name):
         return name in self._ablate and self._abl_cache.get('ready', False)
@@ -442,9 +429,9 @@ class Model(object):
         # the demonstrations by decreasing length (with the feed): the encoders' forward and every backward recurrence
         # group rows of similar length into their row domains and stop each domain at its longest row
         order = None
-        if feed.get('demo_slab_steps') is not None and os.environ.get('D2P_LSTM_SORTED', '1') == '1':
+        if feed.get('demo_slab_steps') is not None:
             order = (feed['demo_order'], feed['demo_slab_steps'])
-        fwd_order = order if os.environ.get('D2P_LSTM_SORTED_FWD', '1') == '1' else None
+        fwd_order = order
 
         # ---- side stream: everything that depends only on the batch -- decoder input ids,
         #      embeddings, the perception encoder and the three hoisted decoder projections
@@ -452,7 +439,6 @@ class Model(object):
         #      whose step kernels leave most of the matrix pipe idle.
         main = torch.cuda.current_stream()
         side = self._side_stream()
-        self._pack_lstm_weights(main, side)
 
         # ---- State_Encoder: conv -> +bias -> lrelu -> BN(train), per demo-index statistics
         x = feed['s_h']
@@ -491,10 +477,9 @@ class Model(object):
             feats_tm = K.transpose_rt(feats, M, T, F, out=self._buf('feats_tm', (T, M, F)))
 
         # (rows past their sequence: neither their projection nor, in backward, their input gradient is computed --
-        #  the recurrence selects around what it reads there, D2P_ACTIVE_XPROJ=0: all rows)
+        #  the recurrence selects around what it reads there)
         act_rows = None
-        if (self.compact_rows and feed.get('n_active') is not None and 0 < feed['n_active'] < T * M
-                and os.environ.get('D2P_ACTIVE_XPROJ', '1') == '1'):
+        if self.compact_rows and feed.get('n_active') is not None and 0 < feed['n_active'] < T * M:
             act_rows = (feed['active_rows'], feed['n_active'])
         ctx['rows_e1'] = act_rows
         if act_rows is not None:
@@ -507,9 +492,7 @@ class Model(object):
         #  these GEMMs only took the CUs the chain was waiting for -- 320 us instead of 100 for the chain;
         #  beside the first recurrence they fill matrix-pipe time its hand-offs leave)
         side.wait_stream(main)
-        if self._wpack_ev is not None:
-            main.wait_event(self._wpack_ev)
-        with torch.cuda.stream(side), self._corun(side != main):
+        with torch.cuda.stream(side):
             # Token-input decoders: x = embedding[id], so x.Wx + b takes one of tok+2 values per row -- the
             # projected TABLE (a [tok+1, U] x [U, 4U] GEMM: 7 or 51 rows) is gathered instead of projecting
             # 6400 gathered rows (13.4 GFLOP per decoder and direction; backward: _lstm_bwd_weights).  The
@@ -526,8 +509,7 @@ class Model(object):
                                                n=n_d * M)
                 # Perception decoders: Per_Encoder = fc (no activation) + BN per demo index
                 per_tm = K.transpose_rt(feed['per'].view(M, T, P), M, T, P, out=self._buf('per_tm', (T, M, P)))
-                if (self.per_factored and self.is_train and feed.get('per_gram') is not None
-                        and os.environ.get('D2P_PER_STATS_CLOSED', '1') == '1'):
+                if self.per_factored and self.is_train and feed.get('per_gram') is not None:
                     # (round 4) the factored form below needs this batch norm's STATISTICS only, and those follow
                     # from the Gram matrix that comes with the feed: no K = 5 product over 6 400 rows, no batch-norm
                     # launches over its result (d2p_per_fc_bn_stats; 41 us of forward side-stream time)
@@ -552,7 +534,7 @@ class Model(object):
                     HWx = K.matmul_nn(H, p['per/lstm/kernel'][:U], out=self._buf('per/HWx', (self.per_cols, 4 * U)))
                     z_q = self._buf('per/lstm/z', (T * M, 4 * U))
                     if n_d > 0 and not self._abl('zq'):          # (timing experiment: tools/step_ablation.sh)
-                        if K.per_rows_tn_ok(n_d * M, k, P, 4 * U) and os.environ.get('D2P_PER_ROWS_NN', '1') == '1':
+                        if K.per_rows_tn_ok(n_d * M, k, P, 4 * U):
                             # (round 4) from the structure of `rows` (P + 1 non-zeros per row): a write of z
                             K.per_rows_nn(k, per_tm.view(T * M, P), HWx, p['per/lstm/bias'], z_q, n_d * M)
                         else:
@@ -641,18 +623,16 @@ class Model(object):
                 ids_a = da['fed_ids']
         elif self.fuse_decoders and self.multitask:
             dp, da, dq = self._decoders_fwd(specs)
-        elif self.multitask and self.pair_decoders and os.environ.get('D2P_TRIPLE_FWD', '1') == '1':
+        elif self.multitask:
             # all three decoders in ONE launch of the wide-tile persistent kernel (3 + 3 + 2 row domains, as their
-            # backward recurrences; round 3: action + program as a pair, then the perception decoder -- 295 + 195 us)
-            side_loss = (self.use_side_stream and os.environ.get('D2P_SIDE_LOSS', '1') == '1' and defer_loss
-                         and feed.get('loss_dens') is not None)
+            # backward recurrences)
+            side_loss = self.use_side_stream and defer_loss and feed.get('loss_dens') is not None
             dp, da, dq = self._decoders_fwd(specs, logits=False)
             # a training step (a backward pass follows at once): the logits themselves are left to backward's first
             # launch -- d2p_xent_bwd_dhout_multi computes hout . proj in front of the loss backward -- and the loss
             # value follows it on the side stream: three skinny GEMM launches (17 us each, K = 512 walked by 50
             # workgroups) leave the critical path between the forward and the backward recurrences
-            defer_logits = (side_loss and os.environ.get('D2P_FUSED_LOGITS', '1') == '1' and max(V, A, P) <= 64
-                            and os.environ.get('D2P_FUSED_XENT_BWD', '1') == '1' and U % 128 == 0 and U <= 512 and self.is_train)
+            defer_logits = (side_loss and max(V, A, P) <= 64 and U % 128 == 0 and U <= 512 and self.is_train)
             ctx['logits_deferred'] = defer_logits
             for e_ in (dp, da, dq):
                 if self._abl('logits'):
@@ -670,29 +650,8 @@ class Model(object):
                                nums[0:1], dens[0:1])
                     K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
                                nums[1:1 + k], dens[1:1 + k])
-        elif self.multitask and self.pair_decoders:
-            # the program decoder (32 rows: a latency-bound chain on a quarter of the CUs) shares ONE persistent
-            # launch with the action decoder, on disjoint workgroups; the perception decoder follows alone
-            side_loss = self.use_side_stream and os.environ.get('D2P_SIDE_LOSS', '1') == '1'
-            dp, da = self._decoders_fwd(specs[:2], logits=not side_loss)
-            if side_loss:
-                # their logits and cross-entropy sums go to the side stream, beside the perception decoder's
-                # recurrence (small launches: they finish well inside it)
-                nums, dens = self._buf('loss_nums', (1 + 2 * k,)), self._buf('loss_dens', (1 + 2 * k,))
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self._decoder_logits(dp)
-                    self._decoder_logits(da)
-                    K.xent_fwd('softmax', dp['logits'], feed['program'], 'bvl', lens_p, L, B, V, 1, n_p,
-                               nums[0:1], dens[0:1])
-                    K.xent_fwd('softmax', da['logits'], feed['a_h'], 'rtv', lens_d, T, M, A, k, n_d,
-                               nums[1:1 + k], dens[1:1 + k])
-            dq = self._decoders_fwd([specs[2]])[0]
         else:
-            outs = [self._decoders_fwd([sp])[0] for sp in specs]
-            dp = outs[0]
-            if self.multitask:
-                da, dq = outs[1], outs[2]
+            dp = self._decoders_fwd([specs[0]])[0]
 
         # ---- losses: program + mean_k action + mean_k perception, each mask-count normalised
         #      (the baselines: the program term alone)
@@ -729,7 +688,6 @@ class Model(object):
             K.loss_assemble([1], nums, dens, loss, terms)
 
         # K lists of the weight-gradient GEMMs (rows inside their sequences only); absent from the graph-static feed
-        self.k_rows = os.environ.get('D2P_K_ROWS', '1') == '1'
         ctx['klists'] = {}
         if self.k_rows and feed.get('n_active_pad') is not None:
             if feed['n_active_pad'] and feed['n_t1_pad']:
@@ -750,51 +708,6 @@ class Model(object):
         self._abl_cache['ready'] = True
         return loss
 
-    def _pack_lstm_weights(self, main, side):
-        """The persistent kernels' packed weight images (forward, and in training backward) of every recurrent cell in
-        ONE launch on the side stream, beside the conv / batch-norm chain: the recurrences' prologues then read
-        contiguous 16-byte fragments instead of gathering them from the row-major kernel (d2p_lstm_pack_weights).
-        Off by default (D2P_LSTM_WPACK=1 turns it on): measured on one box, 3 alternating runs each -- 3.104 / 3.155 /
-        3.139 ms per step gathering, 3.124 / 3.146 / 3.102 with the images; the kernels' averages 205.4 / 294.0 us against
-        205.1 / 289.9 (profiles/r03_wpack_ab.txt): the prologue is not what the launches wait for."""
-        self._wpack, self._wpack_ev = {}, None
-        U = self.num_lstm_cell_units
-        if (os.environ.get('D2P_LSTM_WPACK', '0') != '1' or side == main or U not in (64, 128, 256, 512)
-                or not K.lstm_is_persistent() or torch.cuda.is_current_stream_capturing()):
-            return
-        names = ['demo_lstm', 'prog/lstm']
-        if self.variant != 'synthesis_baseline':
-            names.append('second_lstm')
-        if self.multitask:
-            names += ['act/lstm', 'per/lstm']
-        p = self.params.p
-        cells = []
-        for name in names:
-            kernel = p[name + '/kernel']
-            Wh = kernel[kernel.shape[0] - U:]
-            wf = self._buf(name + '/wpack_f', (4 * U * U,))
-            wb = self._buf(name + '/wpack_b', (4 * U * U,)) if self.is_train else None
-            cells.append((Wh, wf, wb))
-            self._wpack[name] = (wf, wb)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            K.lstm_pack_weights(cells)
-            self._wpack_ev = torch.cuda.Event()
-            self._wpack_ev.record(side)
-
-    def _wp(self, name, which):
-        w = getattr(self, '_wpack', {}).get(name)
-        return None if w is None else w[which]
-
-    def _corun(self, on_side=True):
-        """Context for the GEMMs of a side-stream block that runs beside persistent recurrent launches of the main
-        stream: two-wave workgroups (kernels.gemm_corun) -- four-wave ones are not placed on a CU while a recurrence
-        holds one of its SIMDs completely (tools/corun_probe.py)."""
-        import contextlib
-        if on_side and self.use_side_stream and K.lstm_is_persistent() and not torch.cuda.is_current_stream_capturing():
-            return K.gemm_corun()
-        return contextlib.nullcontext()
-
     def _side_stream(self):
         if not self.use_side_stream:
             return torch.cuda.current_stream()
@@ -807,7 +720,12 @@ class Model(object):
     def _fused_encoder(self, B, k, T):
         """the State_Encoder's forward pass as ONE launch (d2p_karel_encoder_fwd): training mode, Karel's 8x8x16
         frames, a batch whose workgroups are co-resident (D2P_FUSED_ENCODER=0: the 13 separate launches)"""
-        if not self.is_train or os.environ.get('D2P_FUSED_ENCODER', '1') != '1':
+        if not self.is_train or not self.fused_encoder:
+            return False
+        # its bounded spin reports through the persistent kernels' status word; a step that is re-run after a time-out
+        # (Trainer._recover, run_test's redo: both switch the recurrences to the per-step kernels first) must not meet
+        # the same barrier again
+        if not K.lstm_is_persistent():
             return False
         if [tuple(c) for c in self._conv] != self._KAREL_CONV:
             return False
@@ -932,7 +850,7 @@ class Model(object):
             cf = self._buf(name + '/c_final', (M, U)) if want_final else None
         if n_steps > 0:
             K.lstm_seq_fwd_multi([dict(M=M, U=U, n_steps=n_steps, z=z, Wh=Wh, h0=h0, c0=c0, lens=lens, hout=hout, cs=cs,
-                                       h_final=hf, c_final=cf, wpack=self._wp(name, 0),
+                                       h_final=hf, c_final=cf,
                                        row_order=row_order if n_steps == T else None)])
         else:
             K.lstm_seq_fwd(z, 4 * U, M * 4 * U, M, U, n_steps, Wh, h0, c0, lens, hout, cs, hf, cf)
@@ -958,8 +876,7 @@ class Model(object):
                 e['token_ids'] = self._bufs['ids_p' if scope == 'prog' else 'ids_a']
             es.append(e)
             if n_steps > 0:
-                seqs.append(dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs,
-                                 wpack=self._wp(name, 0)))
+                seqs.append(dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs))
         if seqs:
             K.lstm_seq_fwd_multi(seqs)
         if logits:
@@ -1097,7 +1014,7 @@ class Model(object):
         launch set (own statistics, own parameters at stride ps, own moving statistics); returns per scope
         (y, mean, rstd) like _bn_fwd."""
         p = self.params.p
-        if not self.is_train or os.environ.get('D2P_RN_BN_BATCHED', '1') != '1':
+        if not self.is_train:
             return [self._bn_fwd(sc + '/' + leaf, x[i], p[sc + '/' + leaf + '/gamma'], p[sc + '/' + leaf + '/beta'],
                                  1, 1, y=y[i]) for i, sc in enumerate(self.RN_SCOPES)]
         U = x.shape[2]
@@ -1154,7 +1071,7 @@ class Model(object):
         dl_p = self._buf('prog/dlogits', (L * B, V))
         # one launch for the loss backward of all decoders AND their dhout = dlogits . proj^T (D2P_FUSED_XENT_BWD=0:
         # one launch per loss + one K = V GEMM per decoder, round 2's form)
-        fused_xb = os.environ.get('D2P_FUSED_XENT_BWD', '1') == '1' and max(V, A, P) <= 64
+        fused_xb = max(V, A, P) <= 64
         ctx['fused_xb'] = fused_xb
         xb = [dict(mode='softmax', logits=ctx['dp']['logits'], labels=feed['program'], lab_kind='bvl', lens=lens_p, T=L,
                    R=B, V=V, G=1, n_steps=n_p, den=dens[0:1], scale=loss_scale, dlogits=dl_p, proj=p['prog/proj'],
@@ -1176,8 +1093,7 @@ class Model(object):
                        dict(mode='sigmoid', logits=ctx['dq']['logits'], labels=feed['per'], lab_kind='rtv', lens=lens_d,
                             T=T, R=M, V=P, G=k, n_steps=n_d, den=dens[1 + k:], scale=loss_scale, dlogits=dl_q,
                             proj=p['per/proj'], dhout=self._buf('per/dhout', (T * M, U)), U=U)]
-                fused_loss = (bool(ctx.get('logits_deferred')) and os.environ.get('D2P_FUSED_LOSS', '1') == '1'
-                              and 1 + 2 * k <= 64)
+                fused_loss = bool(ctx.get('logits_deferred')) and self.fused_loss and 1 + 2 * k <= 64
                 if ctx.get('logits_deferred'):
                     for q_, e_ in zip(xb, (ctx['dp'], ctx['da'], ctx['dq'])):
                         q_['hout'] = e_['hout']                # logits <- hout . proj inside the launch
@@ -1244,37 +1160,13 @@ class Model(object):
                                   dbias=g['per/fc/b'])
                 K.matmul_tn(ctx['per_tm'].view(T * M, P), d_pe_a, out=g['per/fc/W'])
             grads = (prog_grads, act_grads, per_grads)
-            if self.fuse_decoders:
-                dzs = self._decoders_bwd_rec(bspecs)
-                side.wait_stream(main)
-                with torch.cuda.stream(side), self._corun(side != main):
-                    for fn, dz in zip(grads, dzs):
-                        fn(dz)
-            elif self.pair_decoders:
-                # perception first, then action + program as one launch (as in forward); each group's gradient
-                # GEMMs are forked right behind its recurrence
-                # (all three backward recurrences as ONE launch -- 3 + 3 + 2 row domains -- take 444 us against
-                #  218 + 334 in isolation, tools/lstm_persist_pair.py.  Round 2 measured no gain in the step: the
-                #  perception decoder's gradient GEMMs then no longer ran beside the other two recurrences.  With the
-                #  lighter side stream of round 3 -- no column-sum passes, weight gradients over the active rows only
-                #  -- the triple wins: 3.27 -> 3.20 ms per step; D2P_TRIPLE_BWD=0 restores one + pair)
-                groups = ((2, 1, 0),) if os.environ.get('D2P_TRIPLE_BWD', '1') == '1' else ((2,), (1, 0))
-                # (the projections' small weight-gradient GEMMs stay in front of the recurrences: on the side
-                #  stream they cost 0.06 ms per step -- measured twice)
-                for grp in groups:
-                    dzs = self._decoders_bwd_rec([bspecs[i] for i in grp])
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side), self._corun(side != main):
-                        for i, dz in zip(grp, dzs):
-                            grads[i](dz)
-            else:
-                # action, perception, then program: measured 4.49 ms per step against 4.70 for one fork
-                # after all three recurrences and 4.73 for program first (profiles/r02x_decoder_order.txt)
-                for i in (1, 2, 0):
-                    dz = self._decoders_bwd_rec([bspecs[i]])[0]
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side), self._corun(side != main):
-                        grads[i](dz)
+            # all three backward recurrences as ONE launch (3 + 3 + 2 row domains; with fuse_decoders on the per-step
+            # kernels: one launch per step for all three), the three decoders' gradient products forked behind it
+            dzs = self._decoders_bwd_rec(bspecs if self.fuse_decoders else [bspecs[i] for i in (2, 1, 0)])
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for i, dz in zip((0, 1, 2) if self.fuse_decoders else (2, 1, 0), dzs):
+                    grads[i](dz)
             K.axpy(1.0, tmp_hc, d_demo)
             if split_cb is not None:
                 self._call_split(split_cb, main, side)
@@ -1284,7 +1176,7 @@ class Model(object):
                 K.xent_bwd_dhout_multi(xb)
             dz_p = self._decoders_bwd_rec([(ctx['dp'], dl_p, d_init_h, d_init_c)])[0]
             side.wait_stream(main)
-            with torch.cuda.stream(side), self._corun(side != main):
+            with torch.cuda.stream(side):
                 self._token_decoder_grads(ctx['dp'], dz_p, ctx['ids_p'], n_p * B)
             if split_cb is not None:
                 self._call_split(split_cb, main, side)
@@ -1323,7 +1215,7 @@ class Model(object):
             else:
                 d_hout1 = self._lstm_bwd_dx(e2, dz2)
             side.wait_stream(main)
-            with torch.cuda.stream(side), self._corun(side != main):
+            with torch.cuda.stream(side):
                 self._lstm_bwd_weights(e2, dz2)
             # summary = mean_k(step-1 final states), broadcast to every demo of the program
             K.group_mean_bwd(None, dhc0_2, d_hc1f, 2 * B, k, U, False)
@@ -1338,7 +1230,7 @@ class Model(object):
         else:
             d_feats_tm = self._lstm_bwd_dx(ctx['e1'], dz1)
         side.wait_stream(main)
-        with torch.cuda.stream(side), self._corun(side != main):
+        with torch.cuda.stream(side):
             self._lstm_bwd_weights(ctx['e1'], dz1)
         d_feats = K.transpose_rt(d_feats_tm.view(T, M, F), T, M, F, out=self._buf('d_feats', (M, T, F)))
 
@@ -1383,7 +1275,7 @@ class Model(object):
             # (the bias gradient -- the column sums of dz -- comes out of the same launch)
             K.lstm_seq_bwd_multi([dict(M=M, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], lens=e['lens'],
                                        cs=e['cs'], dhout=dhout, dh_final=dh_final, dc_final=dc_final, dz=dz,
-                                       dh0=dh0, dc0=dc0, db=gb, wpack=self._wp(name, 1),
+                                       dh0=dh0, dc0=dc0, db=gb,
                                        row_order=e.get('row_order'))])
         else:
             K.lstm_seq_bwd(e['z'], 4 * U, M * 4 * U, M, U, n, e['Wh'], e['c0'], e['lens'], e['cs'],
@@ -1408,8 +1300,7 @@ class Model(object):
         NCp = self.per_cols
         if rows > 0:
             per_tm = self._ctx.get('per_tm')
-            if (per_tm is not None and K.per_rows_tn_ok(rows, k, P, 4 * U)
-                    and os.environ.get('D2P_PER_ROWS_TN', '1') == '1'):
+            if per_tm is not None and K.per_rows_tn_ok(rows, k, P, 4 * U):
                 # (round 4) rows^T dZ from the structure of `rows` (P + 1 non-zeros per row): a read of dz
                 S = K.per_rows_tn(k, per_tm.view(-1, P), dz, self._buf('per/S', (NCp, 4 * U)), rows)
             else:
@@ -1532,7 +1423,7 @@ class Model(object):
                     K.gemm_raw('nt', rows, U, V, dlogits, V, p[scope + '/proj'], V, dhout, U)
                 seqs.append(dict(M=R, U=U, n_steps=n, z=e['z'], Wh=e['Wh'], c0=e['c0'], cs=e['cs'],
                                  dhout=dhout, dz=dz, dh0=dh0, dc0=dc0, db=g[e['name'] + '/bias'],
-                                 wpack=self._wp(e['name'], 1), row_order=e.get('row_order')))
+                                 row_order=e.get('row_order')))
             else:
                 g[scope + '/proj'].zero_()
                 g[e['name'] + '/bias'].zero_()
@@ -1543,10 +1434,10 @@ class Model(object):
         # backward: on the side stream, beside the recurrences (D2P_WPROJ_SIDE=0: in front of them, round 2's place)
         main = torch.cuda.current_stream()
         side = self._side_stream()
-        on_side = side != main and os.environ.get('D2P_WPROJ_SIDE', '1') == '1'
+        on_side = side != main
         if on_side and wproj:
             side.wait_stream(main)
-        with torch.cuda.stream(side if on_side else main), self._corun(on_side):
+        with torch.cuda.stream(side if on_side else main):
             for (U_, V, rows, hout2d, dlogits, gproj) in wproj:
                 K.gemm_raw('tn', U_, V, rows, hout2d, U_, dlogits, V, gproj, V)
         if seqs:
@@ -1580,7 +1471,7 @@ class Model(object):
         dy2 = self._buf('rn/dy2', (2, R, U))
         K.pair_mean_bwd(d_out, dy2, 2 * B, k * k, U)
         dy2a, dy1, dy1a = self._buf('rn/dy2a', (2, R, U)), self._buf('rn/dy1', (2, R, U)), self._buf('rn/dy1a', (2, R, U))
-        batched = os.environ.get('D2P_RN_BN_BATCHED', '1') == '1'
+        batched = True
         if batched:
             # st[i] = (y, mean, rstd) with mean / rstd views of one [2, 1, U] buffer each
             K.bn_bwd_batched(r['y2a'], dy2, p['rn_h/fc2/gamma'], ps, r['st2'][0][1], r['st2'][0][2], 1, 1, True,
@@ -1612,7 +1503,7 @@ class Model(object):
         main = torch.cuda.current_stream()
         side = self._side_stream()
         side.wait_stream(main)
-        with torch.cuda.stream(side), self._corun(side != main):
+        with torch.cuda.stream(side):
             for i, sc in enumerate(self.RN_SCOPES):
                 K.matmul_tn(r['y1'][i], dy2a[i], out=g[sc + '/fc2/W'])   # K = B*k*k: split-K, one call each
             # gW1[:U] = feat^T dP, gW1[U:] = feat^T dQ for both scopes: four problems, one launch

@@ -19,6 +19,7 @@ import torch
 from . import kernels as K
 from .config import config_from_dataset, dataset_module, has_dataset, input_ops_module, make_config
 from .dist import DataParallel
+from .options import flag
 from .synthetic import make_batch
 
 CLIP_GRADIENTS = 20.0        # trainer.py:107
@@ -239,13 +240,13 @@ class Trainer(object):
             # launch per sequence), the host keeps ahead of the device, and the two-stream schedule runs
             # faster eagerly (4.82 ms) than as a captured two-queue graph (4.94) or one stream (5.02).
             # D2P_GRAPH=1 captures forward + backward per (n_prog, n_demo) as before (frees the host).
-            use_graph = os.environ.get('D2P_GRAPH', '0') == '1' and os.environ.get('D2P_NO_GRAPH', '0') != '1'
+            use_graph = flag('D2P_GRAPH')
         self.use_graph = bool(use_graph)
         # overlap of the decoders' all-reduce with the encoder backward: built and tested, OFF by default --
         # the persistent LSTM kernels of that part of backward need every CU, so a collective kernel running
         # beside them only delays their start (one rank, forced RCCL group: 5.20 vs 5.02 ms/step); no
         # multi-GPU box was available to show a gain at N > 1
-        self.dp_overlap = os.environ.get('D2P_DP_OVERLAP', '0') == '1'
+        self.dp_overlap = flag('D2P_DP_OVERLAP')
         self._graphs = {}
         self._static_feed = None
         hyper_parameter_str = 'bs_{}_lr_{}_{}_cell_{}'.format(
@@ -277,10 +278,9 @@ class Trainer(object):
         dev = self.model.params.flat.device
         self._sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self._lr_dev = torch.zeros(1, dtype=torch.float32, device=dev)
-        # guarded optimizer step (StepGuard); D2P_STEP_GUARD=0 restores the unguarded kernel + check_device_status
-        self.guard = None
-        if os.environ.get('D2P_STEP_GUARD', '1') == '1':
-            self.guard = StepGuard(self.model.params.flat.device, getattr(self.model, 'moving_flat', None))
+        # guarded optimizer step (StepGuard): always on -- the unguarded form applied invalid gradients until a host-side
+        # status check noticed
+        self.guard = StepGuard(self.model.params.flat.device, getattr(self.model, 'moving_flat', None))
         self._recovering = False
 
         if config.checkpoint is not None:
@@ -314,12 +314,11 @@ class Trainer(object):
         Adam rate changes per step and is read from device memory)."""
         m = self.model
         g = self.guard
-        if g is not None and not self._recovering and g.poll(self.dp.active):
+        if not self._recovering and g.poll(self.dp.active):
             self._recover()
         if m.scheduled_sampling:
             m.set_sampling_step(self.global_step)     # sampling probability + noise counter of this step
-        if g is not None:
-            g.snapshot()
+        g.snapshot()
         P = m.params
         # data parallelism: the decoders' gradients (the tail of the flat buffer) are all-reduced while
         # the rest of backward runs; one message for everything when that is switched off
@@ -327,11 +326,11 @@ class Trainer(object):
         dec = m.decoder_grad_offset() if overlap else 0
         start = None
         persist_was = K.lstm_is_persistent()
-        # EXPERIMENTAL (never run on more than one GPU), behind its own switch: the encoder recurrences that follow the
-        # split run beside the collective's kernels; the persistent kernels need every workgroup resident at once, which
-        # a collective waiting for a late peer can prevent -- per-step launches need no co-residency.  (A captured
-        # graph holds the launches it was captured with: the toggle acts on eager launches and at capture time.)
-        per_step_after_split = overlap and persist_was and os.environ.get('D2P_DP_OVERLAP_PER_STEP', '1') == '1'
+        # the encoder recurrences that follow the split run beside the collective's kernels; the persistent kernels need
+        # every workgroup resident at once, which a collective waiting for a late peer can prevent -- per-step launches
+        # need no co-residency.  (A captured graph holds the launches it was captured with: the toggle acts on eager
+        # launches and at capture time.)
+        per_step_after_split = overlap and persist_was
         if overlap:
             def start():
                 self.dp.all_reduce_start(P.grad[dec:])
@@ -341,15 +340,15 @@ class Trainer(object):
             if self.use_graph and not self._profiling():
                 loss = self._graphed_forward_backward(feed, start)
             else:
-                loss = m.forward(feed, defer_loss=os.environ.get('D2P_DEFER_LOSS', '1') == '1')
-                if g is not None and getattr(m, 'use_side_stream', False) and not self._recovering:
+                loss = m.forward(feed, defer_loss=True)
+                if getattr(m, 'use_side_stream', False) and not self._recovering:
                     g.snapshot_ahead(m._side_stream())          # the next step's moving-statistics snapshot, off the critical path
                 m.backward(split_cb=start)
         finally:
             if per_step_after_split:
                 K.lstm_set_persistent(True)       # (also when backward or the collective raised)
         slot = None
-        if g is not None and self.dp.active:
+        if self.dp.active:
             # this rank's status word joins the exchange: after the SUM every rank skips the step together
             slot = P.status_slot
             K.step_status_publish(slot)
@@ -372,13 +371,9 @@ class Trainer(object):
         t = self.adam_step + 1
         lr = learning_rate_at(self.config, self.global_step)
         lr_t = lr * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
-        if g is None:
-            K.adam_clip_flat(P.flat, P.grad, P.m, P.v, self._sumsq, pre, CLIP_GRADIENTS, lr_t,
-                             ADAM_B1, ADAM_B2, ADAM_EPS)
-        else:
-            K.adam_clip_flat(P.flat, P.grad, P.m, P.v, self._sumsq, pre, CLIP_GRADIENTS, lr_t,
-                             ADAM_B1, ADAM_B2, ADAM_EPS, counters=g.counters, fail_slot=slot, mirror=g.mirror())
-            g.launched((feed, self.global_step, self.adam_step))
+        K.adam_clip_flat(P.flat, P.grad, P.m, P.v, self._sumsq, pre, CLIP_GRADIENTS, lr_t,
+                         ADAM_B1, ADAM_B2, ADAM_EPS, counters=g.counters, fail_slot=slot, mirror=g.mirror())
+        g.launched((feed, self.global_step, self.adam_step))
         self.adam_step = t
         self.global_step += 1
         return loss
@@ -427,16 +422,24 @@ class Trainer(object):
         if g.failures < self.MAX_PERSIST_FAILURES:
             K.lstm_set_persistent(True)
             self._graphs.clear()
-        g.handled = int(g.counters[1].item())       # (nothing is skipped on the per-step kernels)
+        # nothing can be skipped on the re-run: the per-step recurrent kernels and the separate conv / batch-norm
+        # launches (Model._fused_encoder) have no bounded waits.  If the device still counted a skip, an optimizer step
+        # would be lost silently while global_step / adam_step advance -- refuse
+        skipped_after = int(g.counters[1].item())
+        if skipped_after != skipped:
+            raise RuntimeError('%d step(s) were skipped again while re-running skipped steps on the per-step kernels '
+                               '(status 0x%08x): refusing to drop optimizer steps'
+                               % (skipped_after - skipped, K.lstm_persist_error(reset=False) & 0xffffffff))
+        g.handled = skipped_after
         return loss
 
     def settle(self):
         """Synchronising: waits for every launched step and re-runs skipped ones.  Returns the number of
         hand-off failures recovered so far."""
         g = self.guard
-        if g is not None and not self._recovering and g.poll(self.dp.active, wait_all=True):
+        if not self._recovering and g.poll(self.dp.active, wait_all=True):
             self._recover()
-        return 0 if g is None else g.failures
+        return g.failures
 
     @staticmethod
     def _profiling():
@@ -531,7 +534,7 @@ class Trainer(object):
             feed = self.model.get_feed_dict(batch_chunk, step=step, is_training=is_train)
             loss = self.train_step(feed)
         loss_value = float(loss.item())             # the reference fetches the loss every step
-        if self.guard is not None and not self.dp.active and self.guard.poll(False, wait_all=True):
+        if not self.dp.active and self.guard.poll(False, wait_all=True):
             # this step was skipped on the device (single rank: detected right here; several ranks detect it
             # together StepGuard.DEPTH steps later): re-run it, report the re-run's loss
             redo = self._recover()
@@ -549,16 +552,15 @@ class Trainer(object):
         batch_chunk = batch.next()
         feed = self.model.get_feed_dict(batch_chunk, is_training=False)
         guard = self.guard
-        if guard is not None:
-            self.settle()                       # (a pending failure belongs to a training step, not to this batch)
-            guard.ahead = -1                    # (this forward pass moves the statistics: the next step snapshots afresh)
-            guard.snapshot()                    # (slot of the NEXT training step: rewritten before it is used)
+        self.settle()                           # (a pending failure belongs to a training step, not to this batch)
+        guard.ahead = -1                        # (this forward pass moves the statistics: the next step snapshots afresh)
+        guard.snapshot()                        # (slot of the NEXT training step: rewritten before it is used)
         loss = self.model.forward(feed)
         loss_value = float(loss.item())
         # the 'test' summaries of the reference: greedy decoders + accuracies, and for Karel the
         # syntax / exact-program / execution metrics (models/model_full.py:1102-1177)
         self.last_test_report = self.model.report(with_greedy=True)
-        if guard is not None and K.lstm_persist_error(reset=True):
+        if K.lstm_persist_error(reset=True):
             # a hand-off failure inside this forward pass: garbage must not reach the log / the event file -- the batch
             # again on the per-step kernels, from the moving statistics this pass started with (as evaler.py does)
             import sys
@@ -576,11 +578,15 @@ class Trainer(object):
         return self.global_step, self.last_test_report, loss_value, None, (_end_time - _start_time)
 
     def train(self, max_steps=1000000, prefetch=True):
+        if getattr(self.model, '_ablate', None):
+            raise RuntimeError('this model carries a timing-only ablation (%s): its steps leave work out and their '
+                               'results are invalid -- Trainer.train refuses (tools/step_ablation.py times single '
+                               'steps through Trainer.train_step)' % ','.join(sorted(self.model._ablate)))
         ckpt_save_step = 1000
         source = FeedPrefetcher(self.model, self.batch_train) if prefetch else self.batch_train
         # scalar summaries as TensorBoard event files in train_dir (trainer.py:116,170-178), rank 0 only
         writer = None
-        if self.dp.rank == 0 and os.path.isdir(self.train_dir) and os.environ.get('D2P_SUMMARIES', '1') == '1':
+        if self.dp.rank == 0 and os.path.isdir(self.train_dir):
             from .summary import SummaryWriter
             writer = SummaryWriter(self.train_dir)
         for s in range(max_steps):
@@ -602,8 +608,6 @@ class Trainer(object):
                                             **{'test_loss/' + n: v for n, v in list(tl.items()) + list(ta.items())
                                                if isinstance(v, float)}), step)
                     writer.flush()
-            if self.guard is None and s % self.log_step == 0:
-                self.check_device_status()     # unguarded: invalid gradients must not be applied for long unnoticed
             if s % ckpt_save_step == 0:
                 # every rank settles (re-runs steps the device skipped) before rank 0 writes the parameters
                 self.check_device_status()
@@ -614,17 +618,10 @@ class Trainer(object):
             writer.close()
 
     def check_device_status(self):
-        """The persistent LSTM kernels give up a hand-off after a bounded wait instead of hanging (a
-        workgroup that was not resident, e.g. a shared device) and record it; their results are then
-        invalid.  Synchronising.  With the step guard (default) skipped steps are re-run here and nothing is
-        raised; without it (D2P_STEP_GUARD=0) a set status word raises."""
-        if self.guard is not None:
-            self.settle()
-            return
-        err = K.lstm_persist_error(reset=True)
-        if err:
-            raise RuntimeError('persistent LSTM kernel gave up a hand-off (status 0x%08x): the device was shared or '
-                               'a workgroup was not resident; rerun, or set d2p_lstm_set_persistent(0)' % (err & 0xffffffff))
+        """The persistent LSTM kernels give up a hand-off after a bounded wait instead of hanging (a workgroup that was
+        not resident, e.g. a shared device) and record it; the guarded optimizer step skipped those steps on the device.
+        Synchronising: skipped steps are re-run here."""
+        self.settle()
 
     def log_step_message(self, step, loss, step_time, is_train=True):
         """The reference's log line, verbatim (trainer.py:227-240)."""

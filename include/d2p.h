@@ -76,21 +76,14 @@ int d2p_gemm_f32_batched(int kind, int nb1, int nb0, int M, int N, int K, const 
  * K and combine through LDS, picked when the ordinary plan would fill fewer than 128 workgroups);
  * bit 2 keeps the select between global load and LDS store even when K is a multiple of the slab
  * depth (the dense loaders then need none); bit 6: the A^T B products stay on the staged kernel (no
- * gemm_tn_direct_kernel); bits 8 and up: persistent grid size of the LDS-DMA kernel (0 = CUs x resident workgroups
- * per CU). */
+ * gemm_tn_direct_kernel); bit 7: the embedding gradient stays a one-hot GEMM (no rows_by_key_kernel); bits 16 and up:
+ * persistent grid size of the LDS-DMA kernel (0 = CUs x resident workgroups per CU). */
 int d2p_gemm_set_option(int bk32);
 /* Tuning experiments only: force the tile (0 64x64, 1 128x128, 2 128x32, 3 256x32, 4 128x64, 5-7 the K-split
  * forms; 8-12 the LDS-DMA pipeline: 64x64 with a 4- / 3-deep ring, 128x64 3-deep, 128x128 2- / 3-deep, which
  * falls back to the staged kernel of the same tile when the operands are not 16-byte aligned or K is not a
  * multiple of 32; -1 auto) and the split-K factor (0 auto) of the dense entry points. */
 int d2p_gemm_force_plan(int tile, int splits);
-/* Process-global hint (default 0), set by a caller around the GEMMs it issues on a second stream BESIDE a persistent
- * recurrent launch (d2p_lstm_seq_*_multi): 1 = those products run as two-wave workgroups (64x64 tile, 32x64 per wave).
- * A persistent recurrent kernel holds five 256-register waves per CU -- one SIMD completely -- and the dispatcher then
- * places no four-wave workgroup on that CU until the recurrence ends, whereas two-wave workgroups become resident at
- * once on the other three SIMDs (tools/corun_probe.py).  Results are identical up to the summation order of a split K.
- * The workspace query d2p_gemm_ws_bytes follows the hint: query and launch under the same setting. */
-int d2p_gemm_set_corun(int on);
 int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                     float* C, long ldc, const float* bias, int act, int accumulate,
                     void* ws, size_t ws_bytes, d2p_stream_t stream);

@@ -164,3 +164,53 @@ def test_scalar_summaries_are_tensorboard_event_files(tmp_path):
     with open(w.path, 'rb') as f:
         head = f.read(64)
     assert b'brain.Event:2' in head
+
+
+def test_every_environment_switch_is_declared():
+    """demo2program_amd/options.py: the product reads no D2P_* environment name that is not in its table, every A/B
+    switch names a test that exists, and no switch leaves work out of a step."""
+    import os
+    import re
+    from demo2program_amd import options
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = set()
+    for dirpath, _, files in os.walk(os.path.join(root, 'demo2program_amd')):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                text = open(os.path.join(dirpath, f), errors='replace').read()
+                if f.endswith('.py'):
+                    seen |= set(re.findall(r"environ[^\n]*?['\"](D2P_[A-Z0-9_]+)['\"]", text))
+                    seen |= set(re.findall(r"flag\(['\"](D2P_[A-Z0-9_]+)['\"]\)", text))
+                else:
+                    seen |= set(re.findall(r'getenv\("(D2P_[A-Z0-9_]+)"\)', text))
+    assert seen <= set(options.SWITCHES), sorted(seen - set(options.SWITCHES))
+    assert 'D2P_ABLATE' not in seen
+    for name, (default, _, test) in options.SWITCHES.items():
+        if default is None:
+            continue
+        path, _, fn = test.partition('::')
+        text = open(os.path.join(root, path)).read()
+        assert ('def %s(' % fn) in text, (name, test)
+        assert name in text or fn in ('test_bench_starts_its_own_ranks',), (name, test)
+
+
+def test_trainer_and_evaler_refuse_an_ablated_model():
+    """Model.set_ablation is a timing hook of tools/step_ablation.sh: Trainer.train and Evaler must refuse such a model."""
+    from demo2program_amd.evaler import Evaler
+    from demo2program_amd.trainer import Trainer
+
+    class M(object):
+        _ablate = frozenset(['conv_fwd'])
+
+    tr = Trainer.__new__(Trainer)
+    tr.model = M()
+    with pytest.raises(RuntimeError, match='ablation'):
+        tr.train(max_steps=1)
+    ev = Evaler.__new__(Evaler)
+    ev.model = M()
+
+    class B(object):
+        def next(self):
+            return {}
+    with pytest.raises(RuntimeError, match='ablation'):
+        ev.run_single_step(B())

@@ -1298,7 +1298,7 @@ def test_one_launch_state_encoder_equals_the_separate_launches(monkeypatch):
     m = Model(cfg, seed=5)
     mov0 = m.moving_flat.clone()
     for fused in ('0', '1'):
-        monkeypatch.setenv('D2P_FUSED_ENCODER', fused)
+        m.fused_encoder = fused == '1'          # (what D2P_FUSED_ENCODER sets at construction)
         m.moving_flat.copy_(mov0)
         loss = float(m.forward(m.get_feed_dict(batch)).item())
         m.backward()
@@ -1309,6 +1309,38 @@ def test_one_launch_state_encoder_equals_the_separate_launches(monkeypatch):
     scale = float(res[0][1].abs().max())
     assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * scale
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-6, atol=1e-7)
+
+
+def test_one_launch_state_encoder_under_graph_replay():
+    """the one-launch encoder's cross-workgroup barrier under hipGraph replay.  Its arrival counters were
+    chosen per launch on the HOST (baked into the captured node: every replay after the first fell through the barrier
+    and normalised with stale partial sums); they are monotonic device-side tickets now.  S = 16 slices per
+    demonstration index, five replays of one graph against five eager steps: same losses, same moving statistics."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.config import make_config
+    from demo2program_amd.synthetic import make_batch
+    from demo2program_amd.trainer import Trainer
+    cfg = make_config('karel', batch_size=32, k=10, num_lstm_cell_units=128)
+    if not K.karel_encoder_ok(32, 10, cfg.max_demo_len):
+        pytest.skip('geometry not taken by the one-launch kernel on this device')
+    batches = [make_batch(cfg, seed=3), make_batch(cfg, seed=4)]
+    res = []
+    for use_graph in (False, True):
+        tr = Trainer(cfg, make_train_dir=False, use_graph=use_graph)
+        assert tr.model._fused_encoder(32, 10, cfg.max_demo_len)
+        feeds = [tr.model.get_feed_dict(b) for b in batches]
+        # (the same (n_prog, n_demo) key for both batches would be luck: replay ONE graph, feeding batch 0 throughout,
+        #  after one step on batch 1 so that stale partial sums of another batch sit in the workspace)
+        losses = [float(tr.train_step(feeds[1]).item())]
+        for _ in range(5):
+            losses.append(float(tr.train_step(feeds[0]).item()))
+        assert tr.settle() == 0 and K.lstm_persist_error() == 0
+        res.append((losses, tr.model.moving_flat.clone(), tr.model._bufs['conv1/bn_mean'].clone(),
+                    tr.model._bufs['conv3/bn_rstd'].clone()))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert abs(a - b) <= 1e-4 * abs(a), res
+    for q in (1, 2, 3):
+        torch.testing.assert_close(res[0][q], res[1][q], rtol=2e-4, atol=1e-6)
 
 
 def test_loss_value_from_the_loss_backward_launch(monkeypatch):

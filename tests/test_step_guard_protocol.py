@@ -160,7 +160,7 @@ def _run(rank, dp, fail):
 
 def _worker(rank, world, port, outdir):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
-                      MASTER_PORT=str(port), D2P_STEP_GUARD='1', D2P_DP_OVERLAP='0', D2P_GRAPH='0')
+                      MASTER_PORT=str(port), D2P_DP_OVERLAP='0', D2P_GRAPH='0')
     torch.set_num_threads(1)
     from demo2program_amd.dist import DataParallel
     dp = DataParallel.from_env(backend='gloo')
@@ -206,7 +206,7 @@ def test_single_rank_recovery_restores_the_moving_statistics():
     """One rank, no process group: the failure is detected by the next step's poll of an arrived slot; the re-run starts
     from the moving statistics of the skipped step."""
     from demo2program_amd.dist import DataParallel
-    os.environ.update(D2P_STEP_GUARD='1', D2P_GRAPH='0')
+    os.environ.update(D2P_GRAPH='0')
     clean = _run(0, DataParallel(), fail=False)
     FakeModel.fail_at = None
     saved_rank = FAIL_RANK

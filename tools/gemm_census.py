@@ -9,7 +9,7 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ['D2P_NO_SIDE_STREAM'] = '1'
+os.environ['D2P_SIDE_STREAM'] = '0'
 from demo2program_amd import kernels as K  # noqa: E402
 from demo2program_amd.config import make_config  # noqa: E402
 from demo2program_amd.synthetic import make_batch  # noqa: E402

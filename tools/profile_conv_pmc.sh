@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box: instruction mix of the implicit-GEMM conv kernels inside the ViZDoom bench.
 export TMPDIR=/tmp
-export D2P_NO_GRAPH=1
+export D2P_GRAPH=0
 REPO=$PWD
 OUT=$REPO/gpurun_out/conv_pmc
 mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Run on the GPU box: instruction-mix / stall counters of the recurrent step kernels inside the
 # default bench (eager, one stream).  -> gpurun_out/lstm_pmc.txt
 export TMPDIR=/tmp
-export D2P_NO_GRAPH=1
+export D2P_GRAPH=0
 REPO=$PWD
 OUT=$REPO/gpurun_out/lstm_pmc
 mkdir -p $OUT

@@ -7,7 +7,7 @@ TAG=${1:-r01}
 OUT=$PWD/gpurun_out/pmc_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-export D2P_NO_GRAPH=1 D2P_NO_SIDE_STREAM=1
+export D2P_GRAPH=0 D2P_SIDE_STREAM=0
 REPO=$PWD
 cd /tmp
 for C in FETCH_SIZE WRITE_SIZE; do

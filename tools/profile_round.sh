@@ -7,7 +7,7 @@ for P in vizdoom vizdoom_k25; do
   python bench.py --preset $P --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/${TAG}_bench_$P.json 2>> gpurun_out/${TAG}_bench.err
 done
 # kernel trace: eager one-stream launches (per-kernel durations), then the default two-stream schedule
-D2P_NO_SIDE_STREAM=1 bash tools/profile_bench.sh ${TAG}s > /dev/null 2>&1
+D2P_SIDE_STREAM=0 bash tools/profile_bench.sh ${TAG}s > /dev/null 2>&1
 DB=$(find gpurun_out/prof_${TAG}s -name "*.db" | head -1)
 python tools/rocpd_summary.py $DB 13 > gpurun_out/${TAG}_kernel_stats_serial.md
 bash tools/profile_bench.sh ${TAG}g > /dev/null 2>&1

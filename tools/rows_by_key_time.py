@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Microseconds of d2p_embedding_scatter_add_oob0 at the decoders' shapes: rows_by_key_kernel (+ combine) against the one-hot
-GEMM (D2P_ROWS_BY_KEY=0, a second process).   python tools/rows_by_key_time.py"""
+GEMM (d2p_gemm_set_option bit 7).   python tools/rows_by_key_time.py"""
 import os
 import sys
 
@@ -24,7 +24,10 @@ def timed(fn, reps=50):
 
 
 build.build_library()
-print('D2P_ROWS_BY_KEY=%s' % os.environ.get('D2P_ROWS_BY_KEY', '1'))
+from demo2program_amd.lib import call  # noqa: E402
+OFF = len(sys.argv) > 1 and sys.argv[1] == 'onehot'
+call.d2p_gemm_set_option(128 if OFF else 0)
+print('rows_by_key_kernel %s' % ('off (one-hot GEMM)' if OFF else 'on'))
 g = torch.Generator().manual_seed(1)
 for n, rows, E in ((6400, 9, 2048), (1568, 53, 2048), (6400, 52, 512)):
     ids = torch.randint(0, rows, (n,), generator=g, dtype=torch.int32).cuda()
