@@ -18,7 +18,10 @@ the one exchange step the sharded path needs:
   * batch-norm statistics and the loss denominators stay per rank (no sync-BN): N ranks x
     B/N programs == N independent reference steps with averaged gradients.
 
-``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used for the CPU tests.
+``torch.distributed`` backend "nccl" is RCCL on ROCm; "gloo" is used for the CPU tests -- and for the one multi-rank run
+of the REAL HIP step that a one-GPU box allows: two processes sharing the device (RCCL refuses two ranks on one device),
+their device buffers exchanged through host memory (`_reduce`: device -> host copy, gloo all-reduce, copy back; stream
+ordered with the step like the RCCL call it stands in for).  tests/test_dp_two_ranks_gpu.py.
 """
 import os
 import sys
@@ -90,12 +93,24 @@ class DataParallel(object):
     def prescale(self):
         return 1.0 / self.world_size
 
+    def _reduce(self, t, op, async_op=False):
+        """dist.all_reduce of `t` in place.  RCCL takes the device buffer; a gloo group given a device buffer (two ranks
+        sharing one GPU) stages it through host memory, synchronously: the copy out waits for the stream's work so far,
+        the copy back is stream-ordered in front of whatever follows."""
+        import torch.distributed as dist
+        if t.is_cuda and dist.get_backend() != 'nccl':
+            host = t.detach().cpu()              # (synchronises with the current stream)
+            dist.all_reduce(host, op=op)
+            t.copy_(host)
+            return None
+        return dist.all_reduce(t, op=op, async_op=async_op)
+
     def all_reduce_grads(self, flat_grad):
         """SUM the flat gradient buffer across ranks, in place (no-op for one rank without a
         process group)."""
         if self.world_size > 1 or self.initialized:
             import torch.distributed as dist
-            dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
+            self._reduce(flat_grad, dist.ReduceOp.SUM)
         return flat_grad
 
     @property
@@ -112,7 +127,9 @@ class DataParallel(object):
         import torch.distributed as dist
         if not hasattr(self, '_pending'):
             self._pending = []
-        self._pending.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+        w = self._reduce(piece, dist.ReduceOp.SUM, async_op=True)
+        if w is not None:
+            self._pending.append(w)
 
     def all_reduce_finish(self, rest=None):
         """All-reduces `rest` (the part of the buffer not started earlier) and makes the current stream
@@ -121,7 +138,7 @@ class DataParallel(object):
             return
         import torch.distributed as dist
         if rest is not None and rest.numel():
-            dist.all_reduce(rest, op=dist.ReduceOp.SUM)
+            self._reduce(rest, dist.ReduceOp.SUM)
         for w in getattr(self, '_pending', []):
             w.wait()
         self._pending = []
@@ -129,7 +146,12 @@ class DataParallel(object):
     def broadcast_params(self, flat_params, src=0):
         if self.world_size > 1 or self.initialized:
             import torch.distributed as dist
-            dist.broadcast(flat_params, src=src)
+            if flat_params.is_cuda and dist.get_backend() != 'nccl':
+                host = flat_params.detach().cpu()
+                dist.broadcast(host, src=src)
+                flat_params.copy_(host)
+            else:
+                dist.broadcast(flat_params, src=src)
         return flat_params
 
     def shard(self, ids):

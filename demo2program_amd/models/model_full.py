@@ -1069,8 +1069,8 @@ class Model(object):
 
         # ---- losses -> dlogits (time-major, first n_steps*R rows)
         dl_p = self._buf('prog/dlogits', (L * B, V))
-        # one launch for the loss backward of all decoders AND their dhout = dlogits . proj^T (D2P_FUSED_XENT_BWD=0:
-        # one launch per loss + one K = V GEMM per decoder, round 2's form)
+        # one launch for the loss backward of all decoders AND their dhout = dlogits . proj^T (vocabularies
+        # of more than 64 tokens: one launch per loss + one K = V GEMM per decoder)
         fused_xb = max(V, A, P) <= 64
         ctx['fused_xb'] = fused_xb
         xb = [dict(mode='softmax', logits=ctx['dp']['logits'], labels=feed['program'], lab_kind='bvl', lens=lens_p, T=L,
@@ -1431,7 +1431,7 @@ class Model(object):
                 dc0.zero_()
             e['db_done'] = True
         # the projections' weight gradients (K = all rows: split-K launches + their combine passes) feed nothing in
-        # backward: on the side stream, beside the recurrences (D2P_WPROJ_SIDE=0: in front of them, round 2's place)
+        # backward: on the side stream, beside the recurrences
         main = torch.cuda.current_stream()
         side = self._side_stream()
         on_side = side != main
