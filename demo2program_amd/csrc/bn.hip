@@ -728,6 +728,76 @@ static int bn_fwd_impl(int nb, long xs, long ys, long ps, long ms, int R, int C,
     return D2P_OK;
 }
 
+// ---- statistics from a producer's partial sums; the apply pass alone (round 5) --------------------------------------
+// One wavefront per (group, channel): mean / rstd / var from partial[((g*S + s)*C + c)*2 + {0,1}] (what a folding conv
+// launch leaves, d2p_conv2d_nhwc_s2_same_fwd_bn), and the folded affine of the NEXT consumer: scale = gamma * rstd,
+// shift = beta - mean * scale.
+__global__ void __launch_bounds__(256)
+bn_stats_from_partials_kernel(int n, int C, int G, int S, const double* partial, const float* gamma, const float* beta,
+                              float* mean, float* rstd, float* var_out, float* scale, float* shift) {
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (idx >= G * C) return;
+    const int g = idx / C, c = idx - g * C;
+    double a = 0.0, b = 0.0;
+    for (int s = lane; s < S; s += 64) {
+        const double* p = partial + (((long)g * S + s) * C + c) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    a = wave_reduce_sum(a);
+    b = wave_reduce_sum(b);
+    const double mu = a / n;
+    double var = b / n - mu * mu;   // biased variance
+    if (var < 0.0) var = 0.0;
+    if (lane == 0) {
+        const float m = (float)mu, rs = (float)(1.0 / sqrt(var + BN_EPS));
+        mean[idx] = m;
+        rstd[idx] = rs;
+        if (var_out) var_out[idx] = (float)var;
+        if (scale) {
+            const float sc = gamma[c] * rs;
+            scale[idx] = sc;
+            shift[idx] = beta[c] - m * sc;
+        }
+    }
+}
+extern "C" int d2p_bn_stats_from_partials(int n_per_group, int C, int G, int S, const double* partial, const float* gamma,
+                                          const float* beta, float* mean, float* rstd, float* var, float* scale,
+                                          float* shift, d2p_stream_t stream) {
+    D2P_REQUIRE(n_per_group > 0 && C > 0 && G > 0 && S > 0, D2P_EINVAL, "bn stats: bad sizes n=%d C=%d G=%d S=%d", n_per_group, C, G, S);
+    D2P_REQUIRE(partial && mean && rstd, D2P_EINVAL, "bn stats: null pointer");
+    D2P_REQUIRE((scale == nullptr) == (shift == nullptr) && (!scale || (gamma && beta)), D2P_EINVAL,
+                "bn stats: scale / shift go together and need gamma / beta");
+    hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, as_stream(stream), n_per_group, C,
+                       G, S, partial, gamma, beta, mean, rstd, var, scale, shift);
+    D2P_LAUNCH_CHECK("bn_stats_from_partials");
+    return D2P_OK;
+}
+// the apply pass of d2p_bn_group_fwd alone, with statistics the caller already has
+extern "C" int d2p_bn_apply_fwd(int R, int C, int G, int inner, const float* x, const float* gamma, const float* beta,
+                                const float* mean, const float* rstd, float* y, d2p_stream_t stream) {
+    int rc = bn_check(R, C, G, inner);
+    if (rc) return rc;
+    if (R == 0) return D2P_OK;
+    D2P_REQUIRE(x && gamma && beta && mean && rstd && y, D2P_EINVAL, "bn apply: null pointer");
+    const BnBatch bb{0, 0, 0, 0, 0, 0};
+    BnMoving mo{nullptr, nullptr, nullptr, 0.f, (const unsigned*)d2p_persist_err_ptr(), 0};
+    const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean |
+                                        (uintptr_t)rstd) & 15) == 0);
+    if (vec) {
+        mo.nblk = ew_blocks((long)R * C / 4);
+        hipLaunchKernelGGL(bn_apply_fwd_vec4_kernel, dim3(mo.nblk, 1, 1), dim3(256), 0, as_stream(stream), (long)R, C, G, inner,
+                           x, gamma, beta, mean, rstd, y, bb, mo);
+    } else {
+        mo.nblk = ew_blocks((long)R * C);
+        hipLaunchKernelGGL(bn_apply_fwd_kernel, dim3(mo.nblk, 1, 1), dim3(256), 0, as_stream(stream), (long)R, C, G, inner, x,
+                           gamma, beta, mean, rstd, y, bb, mo);
+    }
+    D2P_LAUNCH_CHECK("bn_apply_fwd");
+    return D2P_OK;
+}
+
 extern "C" int d2p_bn_group_fwd(int R, int C, int G, int inner, const float* x, const float* gamma,
                                 const float* beta, float* y, float* mean, float* rstd,
                                 float* var_out, float* moving_mean, float* moving_var, float decay,

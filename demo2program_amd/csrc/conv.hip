@@ -230,6 +230,54 @@ extern "C" int d2p_conv2d_nhwc_s2_same_fwd(int N, int H, int W, int Cin, int Cou
     return d2p_launch_gemm(al, bl, ep, M, Cout, K, nullptr, 0, as_stream(stream), "conv_fwd", D2P_PROF_CONV);
 }
 
+// ---- batch norm folded into the conv launches (round 5; ConvBnFold in conv_geom.h) ------------------------------------
+// slices per demonstration index the folding forward launch of this geometry writes statistics for; 0: not taken
+extern "C" int d2p_conv_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq) {
+    if (N <= 0 || G <= 0 || seq <= 0 || N % (G * seq) != 0) return 0;
+    ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    long units;                                  // work units of one index: strips (first layer) or 16-pixel tiles
+    if (Cin == 4 && Cout == 16 && W == 80) units = (long)N / G * g.Ho;
+    else if (Cin == 16 && Cout == 32 && H * W >= 400 && (seq * g.Ho * g.Wo) % 16 == 0) units = (long)N / G * g.Ho * g.Wo / 16;
+    else return 0;
+    // ~2048 workgroups (8 per CU) of >= 16 units each, as the plain launches of these kernels
+    long S = 2048 / G;
+    if (S * 16 > units) S = units / 16;
+    return (int)(S < 1 ? 1 : S);
+}
+extern "C" int d2p_conv2d_nhwc_s2_same_fwd_bn(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8,
+                                              const float* w, const float* bias, int act, float* y, int G, int seq,
+                                              const float* in_scale, const float* in_shift, double* stats, int S,
+                                              d2p_stream_t stream) {
+    int rc = check_conv(N, H, W, Cin, Cout);
+    if (rc) return rc;
+    D2P_REQUIRE(x && w && y && stats, D2P_EINVAL, "conv fwd (bn): null pointer");
+    D2P_REQUIRE(act == 0 || act == 1, D2P_EINVAL, "conv fwd (bn): unknown act %d", act);
+    D2P_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), D2P_EINVAL, "conv fwd (bn): in_scale and in_shift go together");
+    D2P_REQUIRE(S >= 1 && S == d2p_conv_bn_slices(N, H, W, Cin, Cout, G, seq), D2P_EINVAL,
+                "conv fwd (bn): geometry not taken, or S = %d is not d2p_conv_bn_slices()", S);
+    ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    ConvBnFold bn{G, seq, S, in_scale, in_shift, stats};
+    rc = d2p_conv_direct_fwd(g, x, x_is_u8, w, bias, act, y, as_stream(stream), &bn);
+    if (rc < 0) return rc;
+    D2P_REQUIRE(rc == 1, D2P_EINVAL, "conv fwd (bn): this combination (Cin=%d, affine input %d, u8 %d) has no folding kernel",
+                Cin, in_scale != nullptr, x_is_u8);
+    return D2P_OK;
+}
+extern "C" int d2p_conv2d_nhwc_s2_same_wgrad_bn(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8,
+                                                const float* dy, float* dw, int G, int seq, const float* in_scale,
+                                                const float* in_shift, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    int rc = check_conv(N, H, W, Cin, Cout);
+    if (rc) return rc;
+    D2P_REQUIRE(dw && x && dy && in_scale && in_shift, D2P_EINVAL, "conv wgrad (bn): null pointer");
+    D2P_REQUIRE(G >= 1 && seq >= 1 && N % (G * seq) == 0, D2P_EINVAL, "conv wgrad (bn): N=%d is not a multiple of G*seq", N);
+    ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    ConvBnFold bn{G, seq, 0, in_scale, in_shift, nullptr};
+    rc = d2p_conv_direct_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, as_stream(stream), &bn);
+    if (rc < 0) return rc;
+    D2P_REQUIRE(rc == 1, D2P_EINVAL, "conv wgrad (bn): no folding kernel for Cin=%d Cout=%d W=%d", Cin, Cout, W);
+    return D2P_OK;
+}
+
 extern "C" int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int Cout, const void* x,
                                              int x_is_u8, const float* dy, float* dw, void* ws,
                                              size_t ws_bytes, d2p_stream_t stream) {

@@ -160,14 +160,48 @@ __device__ __forceinline__ void fwd_gather(const DirectGeom& g, const T* __restr
     }
 }
 
-template <int CIN, int COUT, int MASK, typename T>
+// BN (round 5, the ViZDoom-size layers; ConvBnFold in conv_geom.h): the work is dealt out by demonstration index --
+// workgroup (g, s) = blockIdx.x takes slice s of the 16-pixel tiles of index g's frames (tile j of the index ->
+// global tile ((j / tps) * G + g) * tps + j % tps, tps = tiles of one (program, index) sequence) -- so that
+//   STATS:  the launch leaves stats[((g*S + s)*COUT + c)*2 + {0,1}] = (sum, sum of squares) of its outputs (fp64; lanes,
+//           then waves in a fixed order) -- no separate partial-sum pass over the output;
+//   AFFINE: its input is x * in_scale[g] + in_shift[g], the previous layer's batch-norm apply (x = that layer's
+//           pre-norm activation; the normalised tensor is never written).  Out-of-image taps stay zero.
+struct DirectBn {
+    int G, S, tps, per_slice, per_idx;      // per_idx: tiles of one index, per_slice: tiles of a slice
+    const float* in_scale; const float* in_shift;
+    double* stats;
+};
+template <int CIN, int COUT, int MASK, typename T, bool STATS = false, bool AFFINE = false>
 __global__ void __launch_bounds__(256)
 conv_direct_fwd_kernel(DirectGeom g, const T* __restrict__ x, const float* __restrict__ w,
                        const float* __restrict__ bias, int act, float* __restrict__ y, int ntiles,
-                       int keep) {
+                       int keep, DirectBn bn) {
     constexpr int CB = FwdShape<CIN, MASK>::CB, NCH = FwdShape<CIN, MASK>::NCH, NB = COUT / 16;
+    constexpr bool BN = STATS || AFFINE;
     const int lane = threadIdx.x & 63, p = lane & 15, q = lane >> 4;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), NW = gridDim.x * 4;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), NW = BN ? 4 : gridDim.x * 4;
+    const int sg = BN ? (int)blockIdx.x / bn.S : 0, ss = BN ? (int)blockIdx.x - sg * bn.S : 0;
+    // BN: `tile` below counts the tiles of this workgroup's index; gtile() maps it to the tile of the tensor
+    const int tlo = BN ? ss * bn.per_slice : 0, thi = BN ? min(tlo + bn.per_slice, bn.per_idx) : ntiles;
+    auto gtile = [&](int j) {
+        if (!BN) return j;
+        const int b_ = j / bn.tps;
+        return (b_ * bn.G + sg) * bn.tps + (j - b_ * bn.tps);
+    };
+    f32x4 asc[CB], ash[CB];
+    if (AFFINE) {
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            asc[cb] = ldg4(bn.in_scale + sg * CIN + cb * 16 + 4 * q);
+            ash[cb] = ldg4(bn.in_shift + sg * CIN + cb * 16 + 4 * q);
+        }
+    }
+    double sa[NB][4], sb[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sa[b][r] = sb[b][r] = 0.0;
 
     // filter -> registers (A operand): wr[ch][j][blk] = W[k = chunk ch, 4q + j][co = 16 blk + p]
     float wr[NCH][4][NB];
@@ -198,7 +232,7 @@ conv_direct_fwd_kernel(DirectGeom g, const T* __restrict__ x, const float* __res
                     float (&okn)[NCH]) {
         // prefetch the wave's next tile (unconditional: past the end it re-reads a clamped pixel)
         const int nt = tile + NW;
-        fwd_gather<CIN, MASK, T>(g, x, nt < ntiles ? nt * 16 + p : g.P, q, nxt, okn);
+        fwd_gather<CIN, MASK, T>(g, x, nt < thi ? gtile(nt) * 16 + p : g.P, q, nxt, okn);
         __builtin_amdgcn_sched_barrier(0);
         // two accumulator sets (even / odd chunks) so consecutive MFMAs are independent
         f32x4 acc[2][NB];
@@ -206,33 +240,68 @@ conv_direct_fwd_kernel(DirectGeom g, const T* __restrict__ x, const float* __res
         for (int b = 0; b < NB; ++b) acc[0][b] = acc[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
-            const f32x4 bb = cur[ch] * okc[ch];   // out-of-image taps -> 0 (clamped loads are finite)
+            f32x4 bb;                             // out-of-image taps -> 0 (clamped loads are finite)
+            if (AFFINE) bb = (cur[ch] * asc[ch % CB] + ash[ch % CB]) * okc[ch];
+            else bb = cur[ch] * okc[ch];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) acc[j & 1][b] = D2P_MFMA16(wr[ch][j][b], bb[j], acc[j & 1][b]);
         }
-        const int pix = tile * 16 + p;
+        const int pix = gtile(tile) * 16 + p;
         if (pix < g.P) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
                 f32x4 o = (acc[0][b] + acc[1][b]) + bv[b];
                 if (act) { o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w); }
                 *reinterpret_cast<f32x4*>(y + (long)pix * COUT + b * 16 + 4 * q) = o;
+                if (STATS) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sa[b][r] += (double)o[r]; sb[b][r] += (double)o[r] * (double)o[r]; }
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
     f32x4 r0[NCH], r1[NCH];
     float ok0[NCH], ok1[NCH];
-    int tile = wave;
-    fwd_gather<CIN, MASK, T>(g, x, tile < ntiles ? tile * 16 + p : g.P, q, r0, ok0);
-    while (tile < ntiles) {
+    int tile = BN ? tlo + (int)(threadIdx.x >> 6) : wave;
+    fwd_gather<CIN, MASK, T>(g, x, tile < thi ? gtile(tile) * 16 + p : g.P, q, r0, ok0);
+    while (tile < thi) {
         step(tile, r0, ok0, r1, ok1);
         tile += NW;
-        if (tile >= ntiles) break;
+        if (tile >= thi) break;
         step(tile, r1, ok1, r0, ok0);
         tile += NW;
+    }
+    if (STATS) {
+        // lanes (p, q) hold channels 16b + 4q + r of pixel lane p: the 16 pixel lanes by xor-shuffles, the 4 waves
+        // through LDS in wave order
+        __shared__ double wsum[4 * COUT * 2];
+        const int wid = threadIdx.x >> 6;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double u = sa[b][r], v = sb[b][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    u += __shfl_xor(u, off, 64);
+                    v += __shfl_xor(v, off, 64);
+                }
+                if (p == 0) {
+                    wsum[(wid * COUT + b * 16 + 4 * q + r) * 2] = u;
+                    wsum[(wid * COUT + b * 16 + 4 * q + r) * 2 + 1] = v;
+                }
+            }
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < 2 * COUT) {
+            const int c = tid >> 1, k = tid & 1;
+            bn.stats[((long)blockIdx.x * COUT + c) * 2 + k] =
+                ((wsum[(0 * COUT + c) * 2 + k] + wsum[(1 * COUT + c) * 2 + k]) + wsum[(2 * COUT + c) * 2 + k]) +
+                wsum[(3 * COUT + c) * 2 + k];
+        }
     }
     // `keep` is always 0.  The prefetched sets stay live on the exit path, so the compiler cannot
     // sink a step's prefetch below the loop-exit test into the next step (which would serialise
@@ -560,13 +629,50 @@ static int launch_fwd(const ConvGeom& g, const T* x, const float* w, const float
     const int blocks = ceil_div(direct_waves(ntiles, g_direct_fwd_tpw), 4);
     D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * COUT);
     hipLaunchKernelGGL((conv_direct_fwd_kernel<CIN, COUT, MASK, T>), dim3(blocks), dim3(256), 0, st, d, x, w,
-                       bias, act, y, ntiles, 0);
+                       bias, act, y, ntiles, 0, DirectBn{});
     D2P_LAUNCH_CHECK("conv_direct_fwd");
     return 1;
 }
 
+// the batch-norm-folding forms (ConvBnFold): tiles dealt out by demonstration index; needs whole tiles per sequence
+static bool direct_bn_ok(const ConvGeom& g, const ConvBnFold& bn) {
+    return bn.G >= 1 && bn.seq >= 1 && bn.S >= 1 && g.N % (bn.G * bn.seq) == 0 && (bn.seq * g.Ho * g.Wo) % 16 == 0 &&
+           (!bn.in_scale || ((((uintptr_t)bn.in_scale | (uintptr_t)bn.in_shift) & 15) == 0 && bn.in_shift));
+}
+template <int CIN, int COUT, int MASK>
+static int launch_fwd_bn(const ConvGeom& g, const float* x, const float* w, const float* bias, int act, float* y,
+                         hipStream_t st, const ConvBnFold& bn) {
+    if (!direct_bn_ok(g, bn) || !bn.stats) return 0;
+    DirectGeom d = make_direct(g);
+    DirectBn b;
+    b.G = bn.G; b.S = bn.S;
+    b.tps = bn.seq * g.Ho * g.Wo / 16;
+    b.per_idx = g.N / (bn.G * bn.seq) * b.tps;
+    b.per_slice = ceil_div(b.per_idx, bn.S);
+    b.in_scale = bn.in_scale; b.in_shift = bn.in_shift; b.stats = bn.stats;
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * COUT);
+    if (bn.in_scale)
+        hipLaunchKernelGGL((conv_direct_fwd_kernel<CIN, COUT, MASK, float, true, true>), dim3(bn.G * bn.S), dim3(256), 0, st, d,
+                           x, w, bias, act, y, 0, 0, b);
+    else
+        hipLaunchKernelGGL((conv_direct_fwd_kernel<CIN, COUT, MASK, float, true, false>), dim3(bn.G * bn.S), dim3(256), 0, st, d,
+                           x, w, bias, act, y, 0, 0, b);
+    D2P_LAUNCH_CHECK("conv_direct_fwd_bn");
+    return 1;
+}
+
 int d2p_conv_direct_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias,
-                        int act, float* y, hipStream_t st) {
+                        int act, float* y, hipStream_t st, const ConvBnFold* bn) {
+    if (bn) {
+        // the batch-norm-folding forms: first layer (frames in, statistics out) on the row-strip kernel, the 16 -> 32
+        // layer (affine in, statistics out) on the gather kernel; anything else: 0 = not taken (the caller runs the
+        // separate launches)
+        int rc = d2p_conv_rows_fwd(g, x, x_is_u8, w, bias, act, y, st, bn);
+        if (rc != 0) return rc;
+        if (x_is_u8 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
+        if (g.Cin == 16 && g.Cout == 32 && g.H * g.W >= 400) return launch_fwd_bn<16, 32, 0x1FF>(g, (const float*)x, w, bias, act, y, st, *bn);
+        return 0;
+    }
     if (!g_direct_fwd) return 0;
     if (g_direct_fwd >= 2) {
         int rc = d2p_conv_frames_fwd(g, x, x_is_u8, w, bias, act, y, st);
@@ -677,7 +783,8 @@ static int launch_wgrad(const ConvGeom& g, const T* x, const float* dy, float* d
 }
 
 int d2p_conv_direct_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,
-                          size_t ws_bytes, hipStream_t st) {
+                          size_t ws_bytes, hipStream_t st, const ConvBnFold* bn) {
+    if (bn) return d2p_conv_rows_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st, bn);    // (input affine: the row-strip kernel only)
     if (!g_direct_wgrad) return 0;
     if (g_direct_wgrad >= 2) {
         int rc = d2p_conv_frames_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st);

@@ -24,14 +24,27 @@ static inline ConvGeom make_geom(int N, int H, int W, int Cin, int Cout) {
     return g;
 }
 
+// Batch-norm pieces folded into a conv launch (round 5; the ViZDoom-size layers, models/ops.py:14-33: conv -> lrelu ->
+// batch norm with statistics per demonstration index g = (frame / seq) % G):
+//   in_scale / in_shift [G, Cin] (or null): the launch's input is x * scale[g] + shift[g] -- x is the PREVIOUS layer's
+//       pre-norm activation and the affine its batch-norm apply (gamma * rstd, beta - mean * gamma * rstd), so the
+//       normalised tensor is never written; zero padding applies to the normalised values;
+//   stats (or null): the launch leaves [G][S][Cout][2] fp64 partial sums (sum, sum of squares) of ITS outputs behind --
+//       the layout d2p_bn_stats_from_partials reads; S slices per index, chosen by d2p_conv_bn_slices.
+struct ConvBnFold {
+    int G, seq, S;
+    const float* in_scale; const float* in_shift;
+    double* stats;
+};
+
 // Direct back end (conv_direct.hip).  Each returns 1 when it handled the call, 0 when the
 // geometry is not one it is instantiated for (caller falls through to the GEMM back end), or a
 // negative D2P_E* / hipError code.
 int d2p_conv_direct_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w,
-                        const float* bias, int act, float* y, hipStream_t st);
+                        const float* bias, int act, float* y, hipStream_t st, const ConvBnFold* bn = nullptr);
 int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
 int d2p_conv_direct_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw,
-                          void* ws, size_t ws_bytes, hipStream_t st);
+                          void* ws, size_t ws_bytes, hipStream_t st, const ConvBnFold* bn = nullptr);
 size_t d2p_conv_direct_wgrad_ws(const ConvGeom& g);
 void d2p_conv_direct_enable(int fwd, int dgrad, int wgrad);
 
@@ -46,10 +59,10 @@ void d2p_conv_frames_tune(int tiles_per_wave);
 
 // Row-strip back end (conv_rows.hip): weight gradients of the narrow layers of large frames.
 int d2p_conv_rows_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,
-                        size_t ws_bytes, hipStream_t st);
+                        size_t ws_bytes, hipStream_t st, const ConvBnFold* bn = nullptr);
 size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g);
 int d2p_conv_rows_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act,
-                      float* y, hipStream_t st);
+                      float* y, hipStream_t st, const ConvBnFold* bn = nullptr);
 void d2p_conv_rows_fwd_tune(int workgroups);
 int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
 void d2p_conv_rows_dgrad_tune(int workgroups);

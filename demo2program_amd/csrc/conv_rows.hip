@@ -63,6 +63,23 @@ struct RowStager<float, S, CIN, W> {
             r[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
+    // the previous layer's batch-norm apply on the way in (ConvBnFold::in_scale / in_shift): this lane's pieces all
+    // hold channel quad lane % (CIN / 4) (64 and the row's piece count are multiples of CIN / 4); rows outside the
+    // image stay zero -- the zero padding is of the NORMALISED tensor
+    __device__ __forceinline__ void load_affine(const float* __restrict__ x, long frame_off, int iy0, int H, int lane,
+                                                f32x4 sc, f32x4 sh) {
+        static_assert(S::RP4 % (CIN / 4) == 0 && 64 % (CIN / 4) == 0, "a lane keeps one channel quad");
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int j = i * 64 + lane;
+            const int row = j / S::RP4, wi = j - row * S::RP4;
+            const int iy = iy0 + row;
+            const bool ok = (row < 3) & (iy >= 0) & (iy < H);
+            const int iyc = min(max(iy, 0), H - 1);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + frame_off + ((long)iyc * W) * CIN + (row < 3 ? wi : 0) * 4);
+            r[i] = ok ? v * sc + sh : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     __device__ __forceinline__ void store(float* img, int lane) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -109,10 +126,11 @@ struct RowStager<uint8_t, S, CIN, W> {
     }
 };
 
-template <int CIN, int COUT, int W, typename T>
+template <int CIN, int COUT, int W, typename T, bool AFFINE = false>
 __global__ void __launch_bounds__(256)
 conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs, int nframes,
-                       int H, int Ho, int pt) {
+                       int H, int Ho, int pt, int bnG, int bnseq, const float* __restrict__ in_scale,
+                       const float* __restrict__ in_shift) {
     using S = RowShape<CIN, COUT, W>;
     constexpr int AB = S::AB, NBO = S::NBO, KS = S::KS, PSF = S::PSF, Wo = S::Wo;
     constexpr int ACC = AB * NBO * 4, KK = 9 * CIN;
@@ -155,7 +173,14 @@ conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, fl
     for (int s = 0; s < KS; ++s) colmask[s] = (4 * s + kq < Wo) ? 1.f : 0.f;
     for (int strip = wave; strip < nstrips; strip += NW) {
         const int n = strip / Ho, oy = strip - n * Ho;
-        st.load(x, (long)n * frame_elems, 2 * oy - pt, H, lane);
+        if constexpr (AFFINE) {
+            // (x is the previous layer's PRE-norm activation: its batch-norm apply, per demonstration index, on the way in)
+            const int ao = ((n / bnseq) % bnG) * CIN + 4 * (lane & (CIN / 4 - 1));
+            st.load_affine(x, (long)n * frame_elems, 2 * oy - pt, H, lane, *reinterpret_cast<const f32x4*>(in_scale + ao),
+                           *reinterpret_cast<const f32x4*>(in_shift + ao));
+        } else {
+            st.load(x, (long)n * frame_elems, 2 * oy - pt, H, lane);
+        }
         float bv[KS][NBO];
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -222,6 +247,36 @@ conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, fl
     }
 }
 
+// per-lane fp64 channel sums of a wave's epilogue values -> out[c*2 + {0,1}] for the workgroup: lanes (p, q) hold
+// channels 16b + 4q + r of pixel lane p; the 16 pixel lanes by xor-shuffles, the 4 waves through LDS in wave order
+template <int NB>
+__device__ __forceinline__ void rows_fold_stats(const double (&sa)[NB][4], const double (&sb)[NB][4], int C, int wid, int p,
+                                                int q, double* wsum, double* out) {
+    __syncthreads();                      // (the staging area is free: every wave is behind its last strip)
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double u = sa[b][r], v = sb[b][r];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                u += __shfl_xor(u, off, 64);
+                v += __shfl_xor(v, off, 64);
+            }
+            if (p == 0) {
+                wsum[(wid * C + b * 16 + 4 * q + r) * 2] = u;
+                wsum[(wid * C + b * 16 + 4 * q + r) * 2 + 1] = v;
+            }
+        }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    if (tid < 2 * C) {
+        const int c = tid >> 1, k = tid & 1;
+        out[c * 2 + k] = ((wsum[(0 * C + c) * 2 + k] + wsum[(1 * C + c) * 2 + k]) + wsum[(2 * C + c) * 2 + k]) +
+                         wsum[(3 * C + c) * 2 + k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // forward for the 3(4)-channel first layer: same staging, one output row per strip, 16-pixel MFMA
 // tiles along the row (the last tile of a 40-pixel row is half empty: 17 % padding, the price of
@@ -241,10 +296,20 @@ struct FwdRowShape {
     static_assert(W + 2 <= ROWPIX, "staged row must hold the image row and its halo");
 };
 
-template <int CIN, int COUT, int W, typename T>
+// STATS (round 5, the ViZDoom-size layers): the launch also leaves the batch-norm statistics' partial sums behind
+// (models/ops.py:14-33: conv -> lrelu -> batch norm; the separate partial-sum pass re-read the 655 MB of conv1's
+// output).  Statistics are per demonstration index g = (frame / seq) % G, so the work is dealt out by index: workgroup
+// (g, s) = blockIdx.x takes slice s of the strips of index g's frames -- strips j of the index, frame-major, j ->
+// global strip ((j / (seq*Ho)) * G + g) * seq*Ho + j % (seq*Ho) -- and writes stats[((g*S + s)*COUT + c)*2 + {0,1}] =
+// (sum, sum of squares) of its outputs in fp64: lanes, then waves in a fixed order (the layout bn_finalize reads).
+struct RowsBn {
+    int G, seq, S, per_slice;          // per_slice: strips of a slice
+    double* stats;
+};
+template <int CIN, int COUT, int W, typename T, bool STATS = false>
 __global__ void __launch_bounds__(256)
 conv_rows_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, int act,
-                     float* __restrict__ y, int nframes, int H, int Ho, int pt) {
+                     float* __restrict__ y, int nframes, int H, int Ho, int pt, RowsBn bn) {
     using S = FwdRowShape<CIN, COUT, W>;
     constexpr int NCH = S::NCH, NB = S::NB, PSF = S::PSF, Wo = S::Wo, KK = 9 * CIN;
     extern __shared__ float lds[];
@@ -281,7 +346,22 @@ conv_rows_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const
     const int nstrips = nframes * Ho;
     const long frame_elems = (long)H * W * CIN;
     RowStager<T, S, CIN, W> st;
-    for (int strip = wave; strip < nstrips; strip += NW) {
+    double sa[NB][4], sb[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sa[b][r] = sb[b][r] = 0.0;
+    // plain launch: strips interleaved over all waves; STATS: the strips of this workgroup's (index, slice)
+    const int sg = STATS ? (int)blockIdx.x / bn.S : 0, ss = STATS ? (int)blockIdx.x - sg * bn.S : 0;
+    const int seqs = bn.seq * Ho;                                   // strips of one (program, index) sequence
+    const int per_idx = STATS ? (nframes / (bn.G * bn.seq)) * seqs : 0;
+    const int j0 = STATS ? ss * bn.per_slice : wave, j1 = STATS ? min(j0 + bn.per_slice, per_idx) : nstrips;
+    for (int jj = STATS ? j0 + wid : j0; jj < j1; jj += STATS ? 4 : NW) {
+        int strip = jj;
+        if (STATS) {
+            const int b_ = jj / seqs;
+            strip = (b_ * bn.G + sg) * seqs + (jj - b_ * seqs);
+        }
         const int n = strip / Ho, oy = strip - n * Ho;
         st.load(x, (long)n * frame_elems, 2 * oy - pt, H, lane);
         st.store(img, lane);
@@ -306,30 +386,47 @@ conv_rows_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const
                     f32x4 o = (acc[0][b] + acc[1][b]) + bv[b];
                     if (act) { o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w); }
                     *reinterpret_cast<f32x4*>(y + ((long)strip * Wo + ox) * COUT + b * 16 + 4 * q) = o;
+                    if (STATS) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { sa[b][r] += (double)o[r]; sb[b][r] += (double)o[r] * (double)o[r]; }
+                    }
                 }
             }
         }
     }
+    if (STATS) rows_fold_stats<NB>(sa, sb, COUT, wid, p, q, reinterpret_cast<double*>(lds), bn.stats + (long)blockIdx.x * COUT * 2);
 }
 
 int g_rows_fwd_wgs = 2048;
 
 template <int CIN, int COUT, int W, typename T>
-int launch_rows_fwd(const ConvGeom& g, const T* x, const float* w, const float* bias, int act, float* y, hipStream_t st) {
+int launch_rows_fwd(const ConvGeom& g, const T* x, const float* w, const float* bias, int act, float* y, hipStream_t st,
+                    const ConvBnFold* bn = nullptr) {
     using S = FwdRowShape<CIN, COUT, W>;
     constexpr size_t lds_bytes = (size_t)4 * S::IMG * sizeof(float);
+    static_assert(lds_bytes >= (size_t)4 * COUT * 2 * sizeof(double), "the statistics' fold reuses the staging area");
     static bool attr_set = false;
     if (!attr_set) {
-        D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_fwd_kernel<CIN, COUT, W, T>,
+        D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_fwd_kernel<CIN, COUT, W, T, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_fwd_kernel<CIN, COUT, W, T, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
+    }
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * 9 * CIN * COUT);
+    if (bn && bn->stats) {
+        const int per_idx = g.N / bn->G * g.Ho;           // strips of one demonstration index
+        RowsBn rb{bn->G, bn->seq, bn->S, ceil_div(per_idx, bn->S), bn->stats};
+        hipLaunchKernelGGL((conv_rows_fwd_kernel<CIN, COUT, W, T, true>), dim3(bn->G * bn->S), dim3(256), lds_bytes, st, x, w,
+                           bias, act, y, g.N, g.H, g.Ho, g.pt, rb);
+        D2P_LAUNCH_CHECK("conv_rows_fwd_stats");
+        return 1;
     }
     int nb = ceil_div(g.N * g.Ho, 4 * 4);                 // >= 4 strips per wave
     if (nb > g_rows_fwd_wgs) nb = g_rows_fwd_wgs;
     if (nb < 1) nb = 1;
-    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * 9 * CIN * COUT);
-    hipLaunchKernelGGL((conv_rows_fwd_kernel<CIN, COUT, W, T>), dim3(nb), dim3(256), lds_bytes, st, x, w, bias, act, y,
-                       g.N, g.H, g.Ho, g.pt);
+    hipLaunchKernelGGL((conv_rows_fwd_kernel<CIN, COUT, W, T, false>), dim3(nb), dim3(256), lds_bytes, st, x, w, bias, act, y,
+                       g.N, g.H, g.Ho, g.pt, RowsBn{});
     D2P_LAUNCH_CHECK("conv_rows_fwd");
     return 1;
 }
@@ -508,20 +605,33 @@ struct RowsWgrad {
         if (b > cap) b = cap;                                              // workgroups, the combine pass does not
         return b < 1 ? 1 : b;
     }
-    static int run(const ConvGeom& g, const T* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st) {
+    static int run(const ConvGeom& g, const T* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st,
+                   const ConvBnFold* bn = nullptr) {
+        constexpr bool CAN_AFFINE = std::is_same<T, float>::value && CIN >= 16;
         static bool attr_set = false;
         if (!attr_set) {
-            D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_wgrad_kernel<CIN, COUT, W, T>,
+            D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_wgrad_kernel<CIN, COUT, W, T, false>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            if constexpr (CAN_AFFINE)
+                D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_wgrad_kernel<CIN, COUT, W, T, true>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
             attr_set = true;
         }
+        const bool affine = bn && bn->in_scale;
+        if (affine && !CAN_AFFINE) return 0;
         const int KK = 9 * CIN, nb = blocks(g);
         D2P_REQUIRE(ws && ws_bytes >= (size_t)nb * KK * COUT * sizeof(float), D2P_EWS,
                     "conv wgrad: workspace too small (%zu bytes)", ws_bytes);
         float* slabs = (float*)ws;
         D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * KK * COUT);
-        hipLaunchKernelGGL((conv_rows_wgrad_kernel<CIN, COUT, W, T>), dim3(nb), dim3(256), lds_bytes, st, x, dy, slabs,
-                           g.N, g.H, g.Ho, g.pt);
+        if constexpr (CAN_AFFINE) {
+            if (affine)
+                hipLaunchKernelGGL((conv_rows_wgrad_kernel<CIN, COUT, W, T, true>), dim3(nb), dim3(256), lds_bytes, st, x, dy,
+                                   slabs, g.N, g.H, g.Ho, g.pt, bn->G, bn->seq, bn->in_scale, bn->in_shift);
+        }
+        if (!affine)
+            hipLaunchKernelGGL((conv_rows_wgrad_kernel<CIN, COUT, W, T, false>), dim3(nb), dim3(256), lds_bytes, st, x, dy,
+                               slabs, g.N, g.H, g.Ho, g.pt, 1, 1, (const float*)nullptr, (const float*)nullptr);
         D2P_LAUNCH_CHECK("conv_rows_wgrad");
         EpiDense ep{dw, COUT, nullptr, 0, 0};
         const long total = (long)KK * COUT;
@@ -544,11 +654,12 @@ static int rows_key(const ConvGeom& g) {
 }
 
 int d2p_conv_rows_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act,
-                      float* y, hipStream_t st) {
+                      float* y, hipStream_t st, const ConvBnFold* bn) {
     if (!(g.Cin == 4 && g.Cout == 16 && g.W == 80) || g.N < 1) return 0;
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
-    if (x_is_u8) return launch_rows_fwd<4, 16, 80, uint8_t>(g, (const uint8_t*)x, w, bias, act, y, st);
-    return launch_rows_fwd<4, 16, 80, float>(g, (const float*)x, w, bias, act, y, st);
+    if (bn && (bn->in_scale || !bn->stats)) return 0;       // (the first layer's input is the frames: no affine to fold)
+    if (x_is_u8) return launch_rows_fwd<4, 16, 80, uint8_t>(g, (const uint8_t*)x, w, bias, act, y, st, bn);
+    return launch_rows_fwd<4, 16, 80, float>(g, (const float*)x, w, bias, act, y, st, bn);
 }
 
 int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
@@ -564,10 +675,14 @@ size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g) {
 }
 
 int d2p_conv_rows_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,
-                        size_t ws_bytes, hipStream_t st) {
+                        size_t ws_bytes, hipStream_t st, const ConvBnFold* bn) {
     const int key = rows_key(g);
     if (!key || g.N < 1) return 0;
     if (((uintptr_t)x & 15) || ((uintptr_t)dy & 3)) return 0;
+    if (bn && bn->in_scale) {
+        if (key != 2 || x_is_u8 || (((uintptr_t)bn->in_scale | (uintptr_t)bn->in_shift) & 15)) return 0;
+        return RowsWgrad<16, 32, 40, float, 512>::run(g, (const float*)x, dy, dw, ws, ws_bytes, st, bn);
+    }
     if (key == 1) {
         if (x_is_u8) return RowsWgrad<4, 16, 80, uint8_t, 1024>::run(g, (const uint8_t*)x, dy, dw, ws, ws_bytes, st);
         return RowsWgrad<4, 16, 80, float, 1024>::run(g, (const float*)x, dy, dw, ws, ws_bytes, st);

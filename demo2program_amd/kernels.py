@@ -176,6 +176,57 @@ def conv_fwd(x, w, bias, act=1, out=None):
     return out
 
 
+def conv_bn_slices(x_shape, Cout, G, seq):
+    """slices per demonstration index the batch-norm-folding forward conv of this geometry writes statistics for (0: no
+    such kernel -- the separate conv / batch-norm launches run)"""
+    N, H, W, Cin = x_shape
+    return int(_load_lib().d2p_conv_bn_slices(N, H, W, Cin, Cout, G, seq))
+
+
+def conv_fwd_bn(x, w, bias, G, seq, S, stats, act=1, out=None, in_affine=None):
+    """conv_fwd that also leaves the batch-norm partial sums of its output in stats [G, S, Cout, 2] (fp64) and, with
+    in_affine = (scale, shift) [G, Cin], reads its input as x * scale[g] + shift[g] (d2p_conv2d_nhwc_s2_same_fwd_bn)."""
+    _require_gpu(x, w, stats)
+    N, H, W, Cin = x.shape
+    Cout = w.shape[3]
+    Ho, Wo = conv_out_hw(H, W)
+    if out is None:
+        out = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    assert stats.dtype == torch.float64 and stats.numel() >= G * S * Cout * 2
+    sc, sh = in_affine if in_affine is not None else (None, None)
+    call.d2p_conv2d_nhwc_s2_same_fwd_bn(N, H, W, Cin, Cout, ptr(x), 1 if x.dtype == torch.uint8 else 0, ptr(w), ptr(bias), act,
+                                        ptr(out), G, seq, ptr(sc), ptr(sh), ptr(stats), S, current_stream())
+    return out
+
+
+def conv_wgrad_bn(x, dy, dw, G, seq, in_affine):
+    """conv_wgrad whose input is x * scale[g] + shift[g] (the previous layer's batch-norm apply, never materialised)"""
+    _require_gpu(x, dy, dw)
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    ws, wsb = SCRATCH.get(call.d2p_conv_ws_bytes(N, H, W, Cin, Cout))
+    call.d2p_conv2d_nhwc_s2_same_wgrad_bn(N, H, W, Cin, Cout, ptr(x), 1 if x.dtype == torch.uint8 else 0, ptr(dy), ptr(dw),
+                                          G, seq, ptr(in_affine[0]), ptr(in_affine[1]), ws, wsb, current_stream())
+    return dw
+
+
+def bn_stats_from_partials(stats, n_per_group, C, G, S, gamma, beta, mean, rstd, var=None, affine=None):
+    """mean / rstd / var [G, C] from a folding conv launch's partial sums; affine = (scale, shift) [G, C] buffers to
+    receive gamma * rstd and beta - mean * gamma * rstd"""
+    sc, sh = affine if affine is not None else (None, None)
+    call.d2p_bn_stats_from_partials(n_per_group, C, G, S, ptr(stats), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(var),
+                                    ptr(sc), ptr(sh), current_stream())
+
+
+def bn_apply_fwd(x2d, gamma, beta, mean, rstd, G, inner, y=None):
+    _require_gpu(x2d)
+    R, C = x2d.shape
+    if y is None:
+        y = torch.empty_like(x2d)
+    call.d2p_bn_apply_fwd(R, C, G, inner, ptr(x2d), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(y), current_stream())
+    return y
+
+
 def karel_encoder_ok(B, G, T):
     """whether the one-launch State_Encoder forward (d2p_karel_encoder_fwd) takes this batch geometry"""
     return _load_lib().d2p_karel_encoder_ws_bytes(B, G, T) > 0

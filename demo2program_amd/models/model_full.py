@@ -183,6 +183,9 @@ class Model(object):
         # matrix pipe while a recurrence waits for its hand-offs
         self.use_side_stream = flag('D2P_SIDE_STREAM')
         self.fused_encoder = flag('D2P_FUSED_ENCODER')
+        # batch norm folded into the conv launches where the geometry has folding kernels (the ViZDoom-size layers): an
+        # attribute, not a switch -- tests set it to compare with the separate launches
+        self.fold_bn = True
         self.fused_loss = flag('D2P_FUSED_LOSS')
         # timing-only ablation (tools/step_ablation.py -> set_ablation): NEVER from the environment; Trainer.train and
         # Evaler refuse a model that carries one
@@ -444,6 +447,7 @@ class Model(object):
         x = feed['s_h']
         ctx['conv'] = []
         feats_tm = None
+        in_aff = None                  # (scale, shift) [k, C] when x is a pre-norm activation read through its batch-norm apply
         if self._abl('conv_fwd') and 'conv_fused' in self._abl_cache:        # (timing experiment: the previous step's)
             ctx['conv'], feats_tm = self._abl_cache['conv_fused']
         elif self._fused_encoder(B, k, T) and not self._abl('conv_fwd'):
@@ -465,11 +469,43 @@ class Model(object):
                     x = K.pad_axis(x, NF * h * w, cin, cp, 1,
                                    self._buf('conv1/xpad', (NF, h, w, cp), x.dtype))
                 Wl = K.pad_axis(Wl, 9, cin, cp, cout, self._buf('conv1/Wpad', (3, 3, cp, cout)))
-            a = K.conv_fwd(x, Wl, p['conv%d/b' % l], act=1,
-                           out=self._buf('conv%d/a' % l, (NF, ho, wo, cout)))
-            y, mean, rstd = self._bn_fwd('conv%d' % l, a.view(NF * ho * wo, cout),
-                                         p['conv%d/gamma' % l], p['conv%d/beta' % l], k, T * ho * wo)
-            ctx['conv'].append((x, a, mean, rstd))
+            name = 'conv%d' % l
+            a = self._buf(name + '/a', (NF, ho, wo, cout))
+            S = K.conv_bn_slices(x.shape, cout, k, T) if (self.is_train and self.fold_bn) else 0
+            if S > 0:
+                # (round 5, the ViZDoom-size layers) batch norm folded into the conv launches: this layer's statistics
+                # come out of its own conv launch (no partial-sum pass over `a`), and where the NEXT layer's kernels
+                # can take it, the apply pass is folded into their input staging -- they read `a` through the affine
+                # (gamma * rstd, beta - mean * gamma * rstd) and the normalised tensor is never written
+                stats = self._buf(name + '/bn_partial', (k * S * cout * 2,), torch.float64)
+                K.conv_fwd_bn(x, Wl, p[name + '/b'], k, T, S, stats, act=1, out=a, in_affine=in_aff)
+                mean, rstd = self._buf(name + '/bn_mean', (k, cout)), self._buf(name + '/bn_rstd', (k, cout))
+                var = self._buf(name + '/bn_var', (k, cout))
+                nxt = self._conv[l] if l < len(self._conv) else None
+                fold_next = (nxt is not None and nxt[2] == 16 and
+                             K.conv_bn_slices((NF, ho, wo, cout), nxt[3], k, T) > 0)
+                aff = (self._buf(name + '/bn_scale', (k, cout)), self._buf(name + '/bn_shift', (k, cout))) if fold_next else None
+                K.bn_stats_from_partials(stats, B * T * ho * wo, cout, k, S, p[name + '/gamma'], p[name + '/beta'], mean, rstd,
+                                         var, affine=aff)
+                if self.track_moving:
+                    st = side if self.use_side_stream and not torch.cuda.is_current_stream_capturing() else main
+                    if st is not main:
+                        st.wait_stream(main)
+                    with torch.cuda.stream(st):
+                        K.bn_update_moving(mean, var, *self.moving[name])
+                ctx['conv'].append((x, a, mean, rstd, in_aff))
+                if fold_next:
+                    x, in_aff = a, aff                      # (the next layer reads a through the affine)
+                else:
+                    y = K.bn_apply_fwd(a.view(NF * ho * wo, cout), p[name + '/gamma'], p[name + '/beta'], mean, rstd, k,
+                                       T * ho * wo, y=self._buf(name + '/bn_y', (NF * ho * wo, cout)))
+                    x, in_aff = y.view(NF, ho, wo, cout), None
+                continue
+            assert in_aff is None
+            K.conv_fwd(x, Wl, p[name + '/b'], act=1, out=a)
+            y, mean, rstd = self._bn_fwd(name, a.view(NF * ho * wo, cout),
+                                         p[name + '/gamma'], p[name + '/beta'], k, T * ho * wo)
+            ctx['conv'].append((x, a, mean, rstd, None))
             x = y.view(NF, ho, wo, cout)
         if feats_tm is None:
             self._abl_cache['conv'] = (ctx['conv'], x)
@@ -759,7 +795,7 @@ class Model(object):
                 for n, m_, v_ in zip(names, mean, var):
                     K.bn_update_moving(m_, v_, *self.moving[n])
         xin = [x, y[0].view(NF, 4, 4, 16), y[1].view(NF, 2, 2, 32)]
-        ctx['conv'] = [(xin[l], a[l], mean[l], rstd[l]) for l in range(3)]
+        ctx['conv'] = [(xin[l], a[l], mean[l], rstd[l], None) for l in range(3)]
         return feats_tm
 
     def _bn_fwd(self, name, x2d, gamma, beta, G, inner, y=None):
@@ -1240,7 +1276,7 @@ class Model(object):
             if self._abl('conv_bwd'):
                 break
             (h, w, cin, cout, ho, wo) = self._conv[l - 1]
-            x_in, a, mean, rstd = ctx['conv'][l - 1]
+            x_in, a, mean, rstd, x_aff = ctx['conv'][l - 1]
             da_ = K.bn_bwd(a.view(NF * ho * wo, cout), dy.view(NF * ho * wo, cout), p['conv%d/gamma' % l],
                            mean, rstd, k, T * ho * wo, True, g['conv%d/gamma' % l], g['conv%d/beta' % l],
                            dx=self._buf('conv%d/da' % l, (NF * ho * wo, cout)), dbias=g['conv%d/b' % l])
@@ -1252,7 +1288,9 @@ class Model(object):
             if wg_side:
                 side.wait_stream(main)
             with torch.cuda.stream(side if wg_side else main):
-                if x_in.shape[3] != cin:            # channel-padded conv1 input: unpad the gradient
+                if x_aff is not None:               # x_in is the previous layer's pre-norm activation + its batch-norm apply
+                    K.conv_wgrad_bn(x_in, da_.view(NF, ho, wo, cout), g['conv%d/W' % l], k, T, x_aff)
+                elif x_in.shape[3] != cin:          # channel-padded conv1 input: unpad the gradient
                     cp = x_in.shape[3]
                     gpad = K.conv_wgrad(x_in, da_.view(NF, ho, wo, cout),
                                         self._buf('conv1/gWpad', (3, 3, cp, cout)))

@@ -207,6 +207,33 @@ int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_is_u8, const
                           const float* const* bias, const float* const* gamma, const float* const* beta,
                           float* const* a, float* const* y, float* feats_tm, float* const* mean,
                           float* const* rstd, float* const* var, void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* Batch norm folded into the conv launches (round 5; the ViZDoom-size layers of models/model_full.py:216-231, whose
+ * conv -> lrelu -> batch-norm chain of models/ops.py:14-33 otherwise writes and re-reads each activation three times).
+ * Frames are ordered (program, demonstration index, step): the statistics of frame n belong to index g = (n / seq) % G.
+ *   d2p_conv_bn_slices: slices S per index the folding forward launch of this geometry writes partial sums for
+ *       (0: no folding kernel for it -- run d2p_conv2d_nhwc_s2_same_fwd + d2p_bn_group_fwd);
+ *   d2p_conv2d_nhwc_s2_same_fwd_bn: the forward conv (+bias, act) that also leaves stats [G][S][Cout][2] fp64 = (sum, sum
+ *       of squares) of its outputs per (index, slice), and -- in_scale / in_shift [G, Cin] non-null -- reads its input as
+ *       x * in_scale[g] + in_shift[g]: x is the PREVIOUS layer's pre-norm activation and the affine that layer's
+ *       batch-norm apply, so the normalised tensor is never written (zero padding applies to the normalised values);
+ *   d2p_conv2d_nhwc_s2_same_wgrad_bn: the weight gradient with the same input affine;
+ *   d2p_bn_stats_from_partials: mean / rstd / var [G, C] (biased variance; feed d2p_bn_update_moving) from such partial
+ *       sums over n_per_group values per (index, channel), and (scale, shift non-null) the folded affine scale = gamma *
+ *       rstd, shift = beta - mean * scale;
+ *   d2p_bn_apply_fwd: the apply pass of d2p_bn_group_fwd alone, y = gamma * (x - mean[g]) * rstd[g] + beta.
+ * Same values as the separate launches up to the order of the fp64 sums / one fp32 rounding of the affine. */
+int d2p_conv_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq);
+int d2p_conv2d_nhwc_s2_same_fwd_bn(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8, const float* w,
+                                   const float* bias, int act, float* y, int G, int seq, const float* in_scale,
+                                   const float* in_shift, double* stats, int S, d2p_stream_t stream);
+int d2p_conv2d_nhwc_s2_same_wgrad_bn(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8, const float* dy,
+                                     float* dw, int G, int seq, const float* in_scale, const float* in_shift, void* ws,
+                                     size_t ws_bytes, d2p_stream_t stream);
+int d2p_bn_stats_from_partials(int n_per_group, int C, int G, int S, const double* partial, const float* gamma,
+                               const float* beta, float* mean, float* rstd, float* var, float* scale, float* shift,
+                               d2p_stream_t stream);
+int d2p_bn_apply_fwd(int R, int C, int G, int inner, const float* x, const float* gamma, const float* beta,
+                     const float* mean, const float* rstd, float* y, d2p_stream_t stream);
 /* d2p_bn_group_fwd's moving_mean / moving_var ([C], nullable together): the G moving-average
  * updates of this call (one per group = one per reference BN call, in group order) are applied
  * by the statistics kernel itself; d2p_bn_update_moving below is the same update stand-alone. */

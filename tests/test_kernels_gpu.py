@@ -309,6 +309,74 @@ def test_conv_uint8_frames_equal_float_frames(K, N, H, W, Cin, Cout):
     close(dw, dwf, atol=1e-3, rtol=1e-5)
 
 
+@pytest.mark.parametrize('B,G,T', [(3, 2, 2), (2, 5, 4)])
+def test_batch_norm_folded_into_the_conv_launches(K, B, G, T):
+    """Round 5, the ViZDoom-size layers (models/ops.py:14-33 behind models/model_full.py:216-231): the forward conv launch
+    leaves the batch-norm partial sums of its output per demonstration index (d2p_conv2d_nhwc_s2_same_fwd_bn), the next
+    layer's forward conv and weight gradient read the PRE-norm activation through the folded affine instead of a
+    materialised normalised tensor.  Against the separate launches and an fp64 reference of the statistics."""
+    N = B * G * T
+    g = torch.Generator().manual_seed(11)
+    xu = torch.randint(0, 256, (N, 80, 80, 4), generator=g, dtype=torch.uint8)
+    xu[..., 3] = 0
+    w1, b1 = rnd(3, 3, 4, 16, seed=2, scale=0.02), rnd(16, seed=3)
+    grp = (torch.arange(N) // T) % G
+    # ---- layer 1: frames in, statistics out
+    S1 = K.conv_bn_slices((N, 80, 80, 4), 16, G, T)
+    assert S1 > 0
+    st1 = torch.zeros(G * S1 * 16 * 2, dtype=torch.float64, device='cuda')
+    a1 = K.conv_fwd_bn(xu.cuda(), dev(w1), dev(b1), G, T, S1, st1, act=1)
+    ref1 = K.conv_fwd(xu.cuda(), dev(w1), dev(b1), act=1)
+    assert torch.equal(a1, ref1)                                   # the same products in the same order
+    gam, bet = rnd(16, seed=5) + 1.0, rnd(16, seed=6)
+    mean, rstd, var = (torch.empty(G, 16, device='cuda') for _ in range(3))
+    sc, sh = torch.empty(G, 16, device='cuda'), torch.empty(G, 16, device='cuda')
+    n1 = B * T * 40 * 40
+    K.bn_stats_from_partials(st1, n1, 16, G, S1, dev(gam), dev(bet), mean, rstd, var, affine=(sc, sh))
+    a1d = a1.double().cpu()
+    for gi in range(G):
+        v = a1d[grp == gi].reshape(-1, 16)
+        mu, vv = v.mean(0), v.var(0, unbiased=False)
+        close(mean[gi], mu, atol=1e-6 * float(mu.abs().max()) + 1e-7)
+        close(var[gi], vv, rtol=1e-5, atol=1e-7)
+        close(rstd[gi], 1.0 / torch.sqrt(vv + 1e-3), rtol=1e-5)
+        close(sc[gi], gam.double() / torch.sqrt(vv + 1e-3), rtol=1e-5)
+        close(sh[gi], bet.double() - mu * gam.double() / torch.sqrt(vv + 1e-3), rtol=1e-4, atol=1e-5)
+    # the separate launches' statistics
+    _, m_ref, r_ref, _ = K.bn_fwd(a1.view(N * 1600, 16), dev(gam), dev(bet), G, T * 1600)
+    close(mean, m_ref.double().cpu(), rtol=1e-6, atol=1e-6)
+    close(rstd, r_ref.double().cpu(), rtol=1e-5)
+    # ---- layer 2: the affine on the way in, statistics out; weight gradient with the same affine
+    y1 = K.bn_apply_fwd(a1.view(N * 1600, 16), dev(gam), dev(bet), mean, rstd, G, T * 1600).view(N, 40, 40, 16)
+    w2, b2 = rnd(3, 3, 16, 32, seed=7, scale=0.1), rnd(32, seed=8)
+    S2 = K.conv_bn_slices((N, 40, 40, 16), 32, G, T)
+    assert S2 > 0
+    st2 = torch.zeros(G * S2 * 32 * 2, dtype=torch.float64, device='cuda')
+    a2 = K.conv_fwd_bn(a1, dev(w2), dev(b2), G, T, S2, st2, act=1, in_affine=(sc, sh))
+    ref2 = K.conv_fwd(y1, dev(w2), dev(b2), act=1)
+    close(a2, ref2.double().cpu(), atol=2e-5 * float(ref2.abs().max()))     # (one fp32 rounding of the affine apart)
+    mean2, rstd2 = torch.empty(G, 32, device='cuda'), torch.empty(G, 32, device='cuda')
+    K.bn_stats_from_partials(st2, B * T * 400, 32, G, S2, None, None, mean2, rstd2)
+    a2d = a2.double().cpu()
+    for gi in range(G):
+        v = a2d[grp == gi].reshape(-1, 32)
+        close(mean2[gi], v.mean(0), atol=1e-6 * float(v.abs().max()) + 1e-7)
+        close(rstd2[gi], 1.0 / torch.sqrt(v.var(0, unbiased=False) + 1e-3), rtol=1e-5)
+    # statistics without the affine input (layer 1 not folded)
+    st2b = torch.zeros_like(st2)
+    a2b = K.conv_fwd_bn(y1, dev(w2), dev(b2), G, T, S2, st2b, act=1)
+    assert torch.equal(a2b, ref2)
+    dy2 = dev(rnd(N, 20, 20, 32, seed=9))
+    dw, dw_ref = torch.empty(3, 3, 16, 32, device='cuda'), torch.empty(3, 3, 16, 32, device='cuda')
+    K.conv_wgrad_bn(a1, dy2, dw, G, T, (sc, sh))
+    K.conv_wgrad(y1, dy2, dw_ref)
+    close(dw, dw_ref.double().cpu(), atol=2e-5 * float(dw_ref.abs().max()))
+    # geometries without folding kernels are refused, not silently run
+    assert K.conv_bn_slices((N, 8, 8, 16), 16, G, T) == 0
+    with pytest.raises(Exception):
+        K.conv_fwd_bn(dev(rnd(N, 8, 8, 16)), dev(rnd(3, 3, 16, 16)), dev(rnd(16)), G, T, 1, st1, act=1)
+
+
 # ------------------------------------------------------------------ scheduled sampling
 def test_sched_sample_statistics(K):
     """d2p_sched_sample: p = 0 keeps the ground truth, p = 1 always draws, the draw frequencies

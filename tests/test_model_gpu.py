@@ -813,6 +813,28 @@ def test_vizdoom_80x80_frames_match_oracle():
     _check_against_oracle(cfg, params, batch, out, grads)
 
 
+def test_batch_norm_folded_into_the_conv_launches_equals_the_separate_launches():
+    """Model.fold_bn (round 5): conv1 / conv2 of the 80x80 geometry with their batch-norm statistics out of the conv
+    launch and conv1's normalised output never written (conv2's forward and weight gradient read it through the affine)
+    -- same loss, gradients and moving statistics as the separate conv / batch-norm launches."""
+    from demo2program_amd.models.model_full import Model
+    cfg, params, batch = small_case('vizdoom', seed=61, h=80, w=80, batch_size=2, k=3, max_demo_len=4, max_program_len=6)
+    res = []
+    for fold in (False, True):
+        m = Model(cfg, params=params)
+        m.fold_bn = fold
+        loss = float(m.forward(m.get_feed_dict(batch)).item())
+        m.backward()
+        torch.cuda.synchronize()
+        assert ('conv1/bn_partial' in m._bufs) == fold and ('conv1/bn_scale' in m._bufs) == fold
+        res.append((loss, {n: t.clone() for n, t in m.params.g.items()}, m.moving_flat.clone()))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0]), (res[0][0], res[1][0])
+    for n in res[0][1]:
+        scale = float(res[0][1][n].abs().max()) + 1e-12
+        assert float((res[0][1][n] - res[1][1][n]).abs().max()) <= 5e-5 * scale, n
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-5, atol=1e-6)
+
+
 def test_k25_demonstrations_match_oracle():
     """BASELINE config 5's k = 25: 25 batch-norm groups per layer, 625 relation-network pairs per
     program, 25 action / perception decoders -- against the oracle's per-demonstration loops."""
