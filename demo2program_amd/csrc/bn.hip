@@ -731,10 +731,12 @@ static int bn_fwd_impl(int nb, long xs, long ys, long ps, long ms, int R, int C,
 // ---- statistics from a producer's partial sums; the apply pass alone (round 5) --------------------------------------
 // One wavefront per (group, channel): mean / rstd / var from partial[((g*S + s)*C + c)*2 + {0,1}] (what a folding conv
 // launch leaves, d2p_conv2d_nhwc_s2_same_fwd_bn), and the folded affine of the NEXT consumer: scale = gamma * rstd,
-// shift = beta - mean * scale.
+// shift = beta - mean * scale, and its PAD PIXEL -shift / scale -- the input value the affine maps to zero, which a
+// folding conv kernel loads for its out-of-image taps instead of masking them.  |scale| is kept >= 1e-20 so that the pad
+// pixel exists (an fp32 gamma never trains that close to zero; every consumer of the affine sees the same scale).
 __global__ void __launch_bounds__(256)
 bn_stats_from_partials_kernel(int n, int C, int G, int S, const double* partial, const float* gamma, const float* beta,
-                              float* mean, float* rstd, float* var_out, float* scale, float* shift) {
+                              float* mean, float* rstd, float* var_out, float* scale, float* shift, float* pad) {
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (idx >= G * C) return;
@@ -756,21 +758,24 @@ bn_stats_from_partials_kernel(int n, int C, int G, int S, const double* partial,
         rstd[idx] = rs;
         if (var_out) var_out[idx] = (float)var;
         if (scale) {
-            const float sc = gamma[c] * rs;
+            float sc = gamma[c] * rs;
+            if (!(fabsf(sc) >= 1e-20f)) sc = sc < 0.f ? -1e-20f : 1e-20f;
+            const float sf = beta[c] - m * sc;
             scale[idx] = sc;
-            shift[idx] = beta[c] - m * sc;
+            shift[idx] = sf;
+            if (pad) pad[idx] = -sf / sc;
         }
     }
 }
 extern "C" int d2p_bn_stats_from_partials(int n_per_group, int C, int G, int S, const double* partial, const float* gamma,
                                           const float* beta, float* mean, float* rstd, float* var, float* scale,
-                                          float* shift, d2p_stream_t stream) {
+                                          float* shift, float* pad, d2p_stream_t stream) {
     D2P_REQUIRE(n_per_group > 0 && C > 0 && G > 0 && S > 0, D2P_EINVAL, "bn stats: bad sizes n=%d C=%d G=%d S=%d", n_per_group, C, G, S);
     D2P_REQUIRE(partial && mean && rstd, D2P_EINVAL, "bn stats: null pointer");
-    D2P_REQUIRE((scale == nullptr) == (shift == nullptr) && (!scale || (gamma && beta)), D2P_EINVAL,
-                "bn stats: scale / shift go together and need gamma / beta");
+    D2P_REQUIRE((scale == nullptr) == (shift == nullptr) && (!scale || (gamma && beta)) && (!pad || scale), D2P_EINVAL,
+                "bn stats: scale / shift go together (pad with them) and need gamma / beta");
     hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, as_stream(stream), n_per_group, C,
-                       G, S, partial, gamma, beta, mean, rstd, var, scale, shift);
+                       G, S, partial, gamma, beta, mean, rstd, var, scale, shift, pad);
     D2P_LAUNCH_CHECK("bn_stats_from_partials");
     return D2P_OK;
 }

@@ -112,10 +112,13 @@ struct FwdShape {
 
 // B-operand gather for one 16-pixel tile: v[ch] = 4 consecutive k of chunk ch for this lane's
 // pixel; ok bit ch says whether the tap was inside the image (select deferred to use).
-template <int CIN, int MASK, typename T>
+// PADROW (the batch-norm-folding form with an input affine): an out-of-image tap reads the "pad pixel" of the
+// workgroup's demonstration index instead -- padoff = its offset in x -- whose value the affine maps to zero, so
+// nothing is masked afterwards (okf is not written).
+template <int CIN, int MASK, typename T, bool PADROW = false>
 __device__ __forceinline__ void fwd_gather(const DirectGeom& g, const T* __restrict__ x, int pix, int q,
                                            f32x4 (&v)[FwdShape<CIN, MASK>::NCH],
-                                           float (&okf)[FwdShape<CIN, MASK>::NCH]) {
+                                           float (&okf)[FwdShape<CIN, MASK>::NCH], unsigned padoff = 0u) {
     constexpr int CB = FwdShape<CIN, MASK>::CB, NCH = FwdShape<CIN, MASK>::NCH;
     const bool valid = pix < g.P;
     const int pc = valid ? pix : 0;
@@ -141,9 +144,10 @@ __device__ __forceinline__ void fwd_gather(const DirectGeom& g, const T* __restr
             const int tap = nth_tap(MASK, ch / CB);
             const int ky = tap / 3, kx = tap % 3;
             unsigned off = (unsigned)(rowoff[ky] + coloff[kx] + (ch % CB) * 16);
+            if (PADROW) off = (rok[ky] & cok[kx]) ? off : padoff + (unsigned)((ch % CB) * 16 + 4 * q);   // (a select of the offset, not of the load)
             D2P_OPAQUE(off);
             v[ch] = ldg4(x + off);
-            okf[ch] = (rok[ky] & cok[kx]) ? 1.f : 0.f;
+            if (!PADROW) okf[ch] = (rok[ky] & cok[kx]) ? 1.f : 0.f;
         }
     } else {   // CIN == 4: a chunk is 4 taps x 4 channels, this lane's tap is 4*ch + q
 #pragma unroll
@@ -166,11 +170,17 @@ __device__ __forceinline__ void fwd_gather(const DirectGeom& g, const T* __restr
 //   STATS:  the launch leaves stats[((g*S + s)*COUT + c)*2 + {0,1}] = (sum, sum of squares) of its outputs (fp64; lanes,
 //           then waves in a fixed order) -- no separate partial-sum pass over the output;
 //   AFFINE: its input is x * in_scale[g] + in_shift[g], the previous layer's batch-norm apply (x = that layer's
-//           pre-norm activation; the normalised tensor is never written).  Out-of-image taps stay zero.
+//           pre-norm activation; the normalised tensor is never written).  Costs the loop NOTHING over the plain kernel
+//           (an fp32 VALU instruction beside an fp32 MFMA chain is paid in full, profiles/r05_mfma_gate_corun.txt): the
+//           workgroup's index is fixed, so the scale goes into its filter registers once (W' = W * scale[c]), the
+//           loop adds shift / scale to what it loads, and an out-of-image tap loads the index's PAD PIXEL --
+//           -shift / scale, G*CIN floats behind x's last element, written with the statistics
+//           (d2p_bn_stats_from_partials) -- so that tap contributes W' * 0: no mask multiply either.
 struct DirectBn {
     int G, S, tps, per_slice, per_idx;      // per_idx: tiles of one index, per_slice: tiles of a slice
-    const float* in_scale; const float* in_shift;
+    const float* in_scale; const float* in_nshift;    // (in_nshift: shift / scale, what the loop adds)
     double* stats;
+    unsigned pad0;                          // AFFINE: float offset of index 0's pad pixel in x
 };
 template <int CIN, int COUT, int MASK, typename T, bool STATS = false, bool AFFINE = false>
 __global__ void __launch_bounds__(256)
@@ -190,18 +200,35 @@ conv_direct_fwd_kernel(DirectGeom g, const T* __restrict__ x, const float* __res
         return (b_ * bn.G + sg) * bn.tps + (j - b_ * bn.tps);
     };
     f32x4 asc[CB], ash[CB];
+    const unsigned padoff = AFFINE ? bn.pad0 + (unsigned)(sg * CIN) : 0u;
     if (AFFINE) {
 #pragma unroll
         for (int cb = 0; cb < CB; ++cb) {
             asc[cb] = ldg4(bn.in_scale + sg * CIN + cb * 16 + 4 * q);
-            ash[cb] = ldg4(bn.in_shift + sg * CIN + cb * 16 + 4 * q);
+            // the pad pixel holds -shift / scale: what the loop adds is its negative
+            ash[cb] = -ldg4(x + padoff + cb * 16 + 4 * q);
         }
     }
+    // statistics: per-lane fp32 sums over the wave's tiles (packed adds: 8 instructions per tile; a lane sees one pixel
+    // per tile, a few dozen values per sum), moved into fp64 ONCE behind the loop.  fp64 adds per tile cost 25 % of this
+    // kernel (a VALU instruction beside an fp32 MFMA chain is paid in full), a flush every few tiles nearly as much --
+    // a branch in the loop makes hipcc wait for the prefetch at the join.
     double sa[NB][4], sb[NB][4];
+    f32x4 fs[NB], fq[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b) {
+        fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) sa[b][r] = sb[b][r] = 0.0;
+    }
+    auto flush = [&]() {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sa[b][r] += (double)fs[b][r]; sb[b][r] += (double)fq[b][r]; }
+            fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
 
     // filter -> registers (A operand): wr[ch][j][blk] = W[k = chunk ch, 4q + j][co = 16 blk + p]
     float wr[NCH][4][NB];
@@ -219,6 +246,14 @@ conv_direct_fwd_kernel(DirectGeom g, const T* __restrict__ x, const float* __res
                 wr[ch][j][b] = ok ? t : 0.f;
             }
         }
+    if (AFFINE) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < NB; ++b) wr[ch][j][b] *= asc[ch % CB][j];
+    }
     f32x4 bv[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
@@ -228,11 +263,11 @@ conv_direct_fwd_kernel(DirectGeom g, const T* __restrict__ x, const float* __res
 
     // Two register sets in ping-pong (no copies: a "cur = nxt" rotation makes the compiler wait
     // for the prefetch at the bottom of every iteration).
-    auto step = [&](int tile, const f32x4 (&cur)[NCH], const float (&okc)[NCH], f32x4 (&nxt)[NCH],
+    // (gt: the tile of the tensor; gtn: the wave's next one, < 0 past its last)
+    auto step = [&](int gt, int gtn, const f32x4 (&cur)[NCH], const float (&okc)[NCH], f32x4 (&nxt)[NCH],
                     float (&okn)[NCH]) {
         // prefetch the wave's next tile (unconditional: past the end it re-reads a clamped pixel)
-        const int nt = tile + NW;
-        fwd_gather<CIN, MASK, T>(g, x, nt < thi ? gtile(nt) * 16 + p : g.P, q, nxt, okn);
+        fwd_gather<CIN, MASK, T, AFFINE>(g, x, gtn >= 0 ? gtn * 16 + p : g.P, q, nxt, okn, padoff);
         __builtin_amdgcn_sched_barrier(0);
         // two accumulator sets (even / odd chunks) so consecutive MFMAs are independent
         f32x4 acc[2][NB];
@@ -241,14 +276,14 @@ conv_direct_fwd_kernel(DirectGeom g, const T* __restrict__ x, const float* __res
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             f32x4 bb;                             // out-of-image taps -> 0 (clamped loads are finite)
-            if (AFFINE) bb = (cur[ch] * asc[ch % CB] + ash[ch % CB]) * okc[ch];
+            if (AFFINE) bb = cur[ch] + ash[ch % CB];        // (x + shift / scale; a pad pixel gives exactly 0)
             else bb = cur[ch] * okc[ch];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int b = 0; b < NB; ++b) acc[j & 1][b] = D2P_MFMA16(wr[ch][j][b], bb[j], acc[j & 1][b]);
         }
-        const int pix = gtile(tile) * 16 + p;
+        const int pix = gt * 16 + p;
         if (pix < g.P) {
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
@@ -256,25 +291,40 @@ conv_direct_fwd_kernel(DirectGeom g, const T* __restrict__ x, const float* __res
                 if (act) { o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w); }
                 *reinterpret_cast<f32x4*>(y + (long)pix * COUT + b * 16 + 4 * q) = o;
                 if (STATS) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { sa[b][r] += (double)o[r]; sb[b][r] += (double)o[r] * (double)o[r]; }
+                    fs[b] += o;
+                    fq[b] += o * o;
                 }
             }
         }
+
         __builtin_amdgcn_sched_barrier(0);
     };
     f32x4 r0[NCH], r1[NCH];
     float ok0[NCH], ok1[NCH];
-    int tile = BN ? tlo + (int)(threadIdx.x >> 6) : wave;
-    fwd_gather<CIN, MASK, T>(g, x, tile < thi ? gtile(tile) * 16 + p : g.P, q, r0, ok0);
-    while (tile < thi) {
-        step(tile, r0, ok0, r1, ok1);
+    int tile = BN ? tlo + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : wave;      // (BN: scalar index arithmetic)
+    // the tile of the tensor, advanced without divisions: (sequence tb, tile tr inside it) of this workgroup's index
+    int tb = BN ? tile / bn.tps : 0, tr = BN ? tile - tb * bn.tps : 0;
+    auto advance = [&]() {           // -> the tensor's tile for `tile` after tile += NW (< 0 past the end)
         tile += NW;
-        if (tile >= thi) break;
-        step(tile, r1, ok1, r0, ok0);
-        tile += NW;
+        if (BN) {
+            tr += NW;
+            if (tr >= bn.tps) { tr -= bn.tps; ++tb; }
+        }
+        return tile < thi ? (BN ? (tb * bn.G + sg) * bn.tps + tr : tile) : -1;
+    };
+    int gt = tile < thi ? gtile(tile) : -1;
+    fwd_gather<CIN, MASK, T, AFFINE>(g, x, gt >= 0 ? gt * 16 + p : g.P, q, r0, ok0, padoff);
+    while (gt >= 0) {
+        int gtn = advance();
+        step(gt, gtn, r0, ok0, r1, ok1);
+        gt = gtn;
+        if (gt < 0) break;
+        gtn = advance();
+        step(gt, gtn, r1, ok1, r0, ok0);
+        gt = gtn;
     }
     if (STATS) {
+        flush();
         // lanes (p, q) hold channels 16b + 4q + r of pixel lane p: the 16 pixel lanes by xor-shuffles, the 4 waves
         // through LDS in wave order
         __shared__ double wsum[4 * COUT * 2];
@@ -637,6 +687,7 @@ static int launch_fwd(const ConvGeom& g, const T* x, const float* w, const float
 // the batch-norm-folding forms (ConvBnFold): tiles dealt out by demonstration index; needs whole tiles per sequence
 static bool direct_bn_ok(const ConvGeom& g, const ConvBnFold& bn) {
     return bn.G >= 1 && bn.seq >= 1 && bn.S >= 1 && g.N % (bn.G * bn.seq) == 0 && (bn.seq * g.Ho * g.Wo) % 16 == 0 &&
+           bn.seq * g.Ho * g.Wo / 16 >= 4 && (size_t)g.N * g.H * g.W * g.Cin + (size_t)bn.G * g.Cin < (1ull << 32) &&
            (!bn.in_scale || ((((uintptr_t)bn.in_scale | (uintptr_t)bn.in_shift) & 15) == 0 && bn.in_shift));
 }
 template <int CIN, int COUT, int MASK>
@@ -649,7 +700,8 @@ static int launch_fwd_bn(const ConvGeom& g, const float* x, const float* w, cons
     b.tps = bn.seq * g.Ho * g.Wo / 16;
     b.per_idx = g.N / (bn.G * bn.seq) * b.tps;
     b.per_slice = ceil_div(b.per_idx, bn.S);
-    b.in_scale = bn.in_scale; b.in_shift = bn.in_shift; b.stats = bn.stats;
+    b.in_scale = bn.in_scale; b.in_nshift = nullptr; b.stats = bn.stats;
+    b.pad0 = (unsigned)((size_t)g.N * g.H * g.W * g.Cin);
     D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * COUT);
     if (bn.in_scale)
         hipLaunchKernelGGL((conv_direct_fwd_kernel<CIN, COUT, MASK, float, true, true>), dim3(bn.G * bn.S), dim3(256), 0, st, d,

@@ -77,7 +77,10 @@ struct RowStager<float, S, CIN, W> {
             const bool ok = (row < 3) & (iy >= 0) & (iy < H);
             const int iyc = min(max(iy, 0), H - 1);
             const f32x4 v = *reinterpret_cast<const f32x4*>(x + frame_off + ((long)iyc * W) * CIN + (row < 3 ? wi : 0) * 4);
-            r[i] = ok ? v * sc + sh : f32x4{0.f, 0.f, 0.f, 0.f};
+            // (a 0/1 multiply, not a select: hipcc turns `ok ? v * sc + sh : 0` into a branch around the load and waits
+            //  vmcnt(0) at every join -- measured +100 us on the 16 -> 32 layer)
+            const float okf = ok ? 1.f : 0.f;
+            r[i] = (v * sc + sh) * okf;
         }
     }
     __device__ __forceinline__ void store(float* img, int lane) const {
@@ -346,21 +349,39 @@ conv_rows_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const
     const int nstrips = nframes * Ho;
     const long frame_elems = (long)H * W * CIN;
     RowStager<T, S, CIN, W> st;
+    // statistics: per-lane fp32 sums over the wave's strips (packed adds; a lane sees <= NTILE pixels per strip, ~100
+    // values per sum), moved into fp64 ONCE behind the loop -- fp64 adds per value cost this MFMA-light kernel 13 % (a
+    // VALU instruction beside an fp32 MFMA chain is paid in full), a flush branch in the loop as much
     double sa[NB][4], sb[NB][4];
+    f32x4 fs[NB], fq[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b)
+    for (int b = 0; b < NB; ++b) {
+        fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) sa[b][r] = sb[b][r] = 0.0;
-    // plain launch: strips interleaved over all waves; STATS: the strips of this workgroup's (index, slice)
+    }
+    auto flush = [&]() {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { sa[b][r] += (double)fs[b][r]; sb[b][r] += (double)fq[b][r]; }
+            fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // plain launch: strips interleaved over all waves; STATS: the strips of this workgroup's (index, slice), the
+    // tensor's strip advanced without divisions: (sequence sq, strip sr inside it) of the index
     const int sg = STATS ? (int)blockIdx.x / bn.S : 0, ss = STATS ? (int)blockIdx.x - sg * bn.S : 0;
     const int seqs = bn.seq * Ho;                                   // strips of one (program, index) sequence
     const int per_idx = STATS ? (nframes / (bn.G * bn.seq)) * seqs : 0;
     const int j0 = STATS ? ss * bn.per_slice : wave, j1 = STATS ? min(j0 + bn.per_slice, per_idx) : nstrips;
-    for (int jj = STATS ? j0 + wid : j0; jj < j1; jj += STATS ? 4 : NW) {
+    const int swid = __builtin_amdgcn_readfirstlane(wid);          // (scalar index arithmetic)
+    int sq = STATS ? (j0 + swid) / seqs : 0, sr = STATS ? (j0 + swid) - sq * seqs : 0;
+    for (int jj = STATS ? j0 + swid : j0; jj < j1; jj += STATS ? 4 : NW) {
         int strip = jj;
         if (STATS) {
-            const int b_ = jj / seqs;
-            strip = (b_ * bn.G + sg) * seqs + (jj - b_ * seqs);
+            strip = (sq * bn.G + sg) * seqs + sr;
+            sr += 4;
+            if (sr >= seqs) { sr -= seqs; ++sq; }
         }
         const int n = strip / Ho, oy = strip - n * Ho;
         st.load(x, (long)n * frame_elems, 2 * oy - pt, H, lane);
@@ -387,13 +408,14 @@ conv_rows_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, const
                     if (act) { o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w); }
                     *reinterpret_cast<f32x4*>(y + ((long)strip * Wo + ox) * COUT + b * 16 + 4 * q) = o;
                     if (STATS) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) { sa[b][r] += (double)o[r]; sb[b][r] += (double)o[r] * (double)o[r]; }
+                        fs[b] += o;
+                        fq[b] += o * o;
                     }
                 }
             }
         }
     }
+    if (STATS) flush();
     if (STATS) rows_fold_stats<NB>(sa, sb, COUT, wid, p, q, reinterpret_cast<double*>(lds), bn.stats + (long)blockIdx.x * COUT * 2);
 }
 

@@ -193,7 +193,10 @@ def conv_fwd_bn(x, w, bias, G, seq, S, stats, act=1, out=None, in_affine=None):
     if out is None:
         out = torch.empty(N, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
     assert stats.dtype == torch.float64 and stats.numel() >= G * S * Cout * 2
-    sc, sh = in_affine if in_affine is not None else (None, None)
+    sc, sh = in_affine[:2] if in_affine is not None else (None, None)
+    if in_affine is not None:
+        # the pad pixels (-shift / scale per index) right behind x's last element
+        assert len(in_affine) == 3 and in_affine[2].data_ptr() == x.data_ptr() + x.numel() * 4, 'pad pixels must follow x'
     call.d2p_conv2d_nhwc_s2_same_fwd_bn(N, H, W, Cin, Cout, ptr(x), 1 if x.dtype == torch.uint8 else 0, ptr(w), ptr(bias), act,
                                         ptr(out), G, seq, ptr(sc), ptr(sh), ptr(stats), S, current_stream())
     return out
@@ -211,11 +214,12 @@ def conv_wgrad_bn(x, dy, dw, G, seq, in_affine):
 
 
 def bn_stats_from_partials(stats, n_per_group, C, G, S, gamma, beta, mean, rstd, var=None, affine=None):
-    """mean / rstd / var [G, C] from a folding conv launch's partial sums; affine = (scale, shift) [G, C] buffers to
-    receive gamma * rstd and beta - mean * gamma * rstd"""
-    sc, sh = affine if affine is not None else (None, None)
+    """mean / rstd / var [G, C] from a folding conv launch's partial sums; affine = (scale, shift[, pad]) [G, C] buffers
+    to receive gamma * rstd, beta - mean * gamma * rstd and the pad pixels -shift / scale (which must sit right behind
+    the activation the affine belongs to when a folding forward conv reads it: conv_fwd_bn)"""
+    sc, sh, pad = (tuple(affine) + (None,))[:3] if affine is not None else (None, None, None)
     call.d2p_bn_stats_from_partials(n_per_group, C, G, S, ptr(stats), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd), ptr(var),
-                                    ptr(sc), ptr(sh), current_stream())
+                                    ptr(sc), ptr(sh), ptr(pad), current_stream())
 
 
 def bn_apply_fwd(x2d, gamma, beta, mean, rstd, G, inner, y=None):

@@ -470,8 +470,13 @@ class Model(object):
                                    self._buf('conv1/xpad', (NF, h, w, cp), x.dtype))
                 Wl = K.pad_axis(Wl, 9, cin, cp, cout, self._buf('conv1/Wpad', (3, 3, cp, cout)))
             name = 'conv%d' % l
-            a = self._buf(name + '/a', (NF, ho, wo, cout))
             S = K.conv_bn_slices(x.shape, cout, k, T) if (self.is_train and self.fold_bn) else 0
+            nxt = self._conv[l] if l < len(self._conv) else None
+            fold_next = (S > 0 and nxt is not None and nxt[2] == 16 and
+                         K.conv_bn_slices((NF, ho, wo, cout), nxt[3], k, T) > 0)
+            # (read through the affine by the next layer: the k pad pixels sit right behind the activation)
+            a_ext = self._buf(name + '/a', (NF * ho * wo * cout + (k * cout if fold_next else 0),))
+            a = a_ext[:NF * ho * wo * cout].view(NF, ho, wo, cout)
             if S > 0:
                 # (round 5, the ViZDoom-size layers) batch norm folded into the conv launches: this layer's statistics
                 # come out of its own conv launch (no partial-sum pass over `a`), and where the NEXT layer's kernels
@@ -481,10 +486,8 @@ class Model(object):
                 K.conv_fwd_bn(x, Wl, p[name + '/b'], k, T, S, stats, act=1, out=a, in_affine=in_aff)
                 mean, rstd = self._buf(name + '/bn_mean', (k, cout)), self._buf(name + '/bn_rstd', (k, cout))
                 var = self._buf(name + '/bn_var', (k, cout))
-                nxt = self._conv[l] if l < len(self._conv) else None
-                fold_next = (nxt is not None and nxt[2] == 16 and
-                             K.conv_bn_slices((NF, ho, wo, cout), nxt[3], k, T) > 0)
-                aff = (self._buf(name + '/bn_scale', (k, cout)), self._buf(name + '/bn_shift', (k, cout))) if fold_next else None
+                aff = (self._buf(name + '/bn_scale', (k, cout)), self._buf(name + '/bn_shift', (k, cout)),
+                       a_ext[NF * ho * wo * cout:].view(k, cout)) if fold_next else None
                 K.bn_stats_from_partials(stats, B * T * ho * wo, cout, k, S, p[name + '/gamma'], p[name + '/beta'], mean, rstd,
                                          var, affine=aff)
                 if self.track_moving:
@@ -1289,7 +1292,7 @@ class Model(object):
                 side.wait_stream(main)
             with torch.cuda.stream(side if wg_side else main):
                 if x_aff is not None:               # x_in is the previous layer's pre-norm activation + its batch-norm apply
-                    K.conv_wgrad_bn(x_in, da_.view(NF, ho, wo, cout), g['conv%d/W' % l], k, T, x_aff)
+                    K.conv_wgrad_bn(x_in, da_.view(NF, ho, wo, cout), g['conv%d/W' % l], k, T, x_aff[:2])
                 elif x_in.shape[3] != cin:          # channel-padded conv1 input: unpad the gradient
                     cp = x_in.shape[3]
                     gpad = K.conv_wgrad(x_in, da_.view(NF, ho, wo, cout),

@@ -215,11 +215,13 @@ int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_is_u8, const
  *   d2p_conv2d_nhwc_s2_same_fwd_bn: the forward conv (+bias, act) that also leaves stats [G][S][Cout][2] fp64 = (sum, sum
  *       of squares) of its outputs per (index, slice), and -- in_scale / in_shift [G, Cin] non-null -- reads its input as
  *       x * in_scale[g] + in_shift[g]: x is the PREVIOUS layer's pre-norm activation and the affine that layer's
- *       batch-norm apply, so the normalised tensor is never written (zero padding applies to the normalised values);
+ *       batch-norm apply, so the normalised tensor is never written (zero padding applies to the normalised values).
+ *       With the affine, x's N*H*W*Cin elements must be FOLLOWED by G*Cin floats, index g's "pad pixel" -in_shift[g] /
+ *       in_scale[g] (d2p_bn_stats_from_partials writes them): out-of-image taps load it instead of being masked;
  *   d2p_conv2d_nhwc_s2_same_wgrad_bn: the weight gradient with the same input affine;
  *   d2p_bn_stats_from_partials: mean / rstd / var [G, C] (biased variance; feed d2p_bn_update_moving) from such partial
  *       sums over n_per_group values per (index, channel), and (scale, shift non-null) the folded affine scale = gamma *
- *       rstd, shift = beta - mean * scale;
+ *       rstd (kept >= 1e-20 in magnitude), shift = beta - mean * scale, pad (nullable) = -shift / scale [G, C];
  *   d2p_bn_apply_fwd: the apply pass of d2p_bn_group_fwd alone, y = gamma * (x - mean[g]) * rstd[g] + beta.
  * Same values as the separate launches up to the order of the fp64 sums / one fp32 rounding of the affine. */
 int d2p_conv_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq);
@@ -231,7 +233,7 @@ int d2p_conv2d_nhwc_s2_same_wgrad_bn(int N, int H, int W, int Cin, int Cout, con
                                      size_t ws_bytes, d2p_stream_t stream);
 int d2p_bn_stats_from_partials(int n_per_group, int C, int G, int S, const double* partial, const float* gamma,
                                const float* beta, float* mean, float* rstd, float* var, float* scale, float* shift,
-                               d2p_stream_t stream);
+                               float* pad, d2p_stream_t stream);
 int d2p_bn_apply_fwd(int R, int C, int G, int inner, const float* x, const float* gamma, const float* beta,
                      const float* mean, const float* rstd, float* y, d2p_stream_t stream);
 /* d2p_bn_group_fwd's moving_mean / moving_var ([C], nullable together): the G moving-average

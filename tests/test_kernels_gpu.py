@@ -325,14 +325,17 @@ def test_batch_norm_folded_into_the_conv_launches(K, B, G, T):
     S1 = K.conv_bn_slices((N, 80, 80, 4), 16, G, T)
     assert S1 > 0
     st1 = torch.zeros(G * S1 * 16 * 2, dtype=torch.float64, device='cuda')
-    a1 = K.conv_fwd_bn(xu.cuda(), dev(w1), dev(b1), G, T, S1, st1, act=1)
+    # (the activation the next layer reads through the affine carries its G pad pixels right behind its last element)
+    a1_ext = torch.empty(N * 1600 * 16 + G * 16, device='cuda')
+    a1, pad = a1_ext[:N * 1600 * 16].view(N, 40, 40, 16), a1_ext[N * 1600 * 16:].view(G, 16)
+    K.conv_fwd_bn(xu.cuda(), dev(w1), dev(b1), G, T, S1, st1, act=1, out=a1)
     ref1 = K.conv_fwd(xu.cuda(), dev(w1), dev(b1), act=1)
     assert torch.equal(a1, ref1)                                   # the same products in the same order
     gam, bet = rnd(16, seed=5) + 1.0, rnd(16, seed=6)
     mean, rstd, var = (torch.empty(G, 16, device='cuda') for _ in range(3))
     sc, sh = torch.empty(G, 16, device='cuda'), torch.empty(G, 16, device='cuda')
     n1 = B * T * 40 * 40
-    K.bn_stats_from_partials(st1, n1, 16, G, S1, dev(gam), dev(bet), mean, rstd, var, affine=(sc, sh))
+    K.bn_stats_from_partials(st1, n1, 16, G, S1, dev(gam), dev(bet), mean, rstd, var, affine=(sc, sh, pad))
     a1d = a1.double().cpu()
     for gi in range(G):
         v = a1d[grp == gi].reshape(-1, 16)
@@ -342,6 +345,7 @@ def test_batch_norm_folded_into_the_conv_launches(K, B, G, T):
         close(rstd[gi], 1.0 / torch.sqrt(vv + 1e-3), rtol=1e-5)
         close(sc[gi], gam.double() / torch.sqrt(vv + 1e-3), rtol=1e-5)
         close(sh[gi], bet.double() - mu * gam.double() / torch.sqrt(vv + 1e-3), rtol=1e-4, atol=1e-5)
+        close(pad[gi], -sh[gi].double().cpu() / sc[gi].double().cpu(), rtol=1e-6, atol=1e-7)
     # the separate launches' statistics
     _, m_ref, r_ref, _ = K.bn_fwd(a1.view(N * 1600, 16), dev(gam), dev(bet), G, T * 1600)
     close(mean, m_ref.double().cpu(), rtol=1e-6, atol=1e-6)
@@ -352,7 +356,7 @@ def test_batch_norm_folded_into_the_conv_launches(K, B, G, T):
     S2 = K.conv_bn_slices((N, 40, 40, 16), 32, G, T)
     assert S2 > 0
     st2 = torch.zeros(G * S2 * 32 * 2, dtype=torch.float64, device='cuda')
-    a2 = K.conv_fwd_bn(a1, dev(w2), dev(b2), G, T, S2, st2, act=1, in_affine=(sc, sh))
+    a2 = K.conv_fwd_bn(a1, dev(w2), dev(b2), G, T, S2, st2, act=1, in_affine=(sc, sh, pad))
     ref2 = K.conv_fwd(y1, dev(w2), dev(b2), act=1)
     close(a2, ref2.double().cpu(), atol=2e-5 * float(ref2.abs().max()))     # (one fp32 rounding of the affine apart)
     mean2, rstd2 = torch.empty(G, 32, device='cuda'), torch.empty(G, 32, device='cuda')
