@@ -905,6 +905,63 @@ static int bn_bwd_impl(int nb, long xs, long ys, long ps, int R, int C, int G, i
     return D2P_OK;
 }
 
+// ---- batch-norm backward as per-(group, channel) COEFFICIENTS (round 5) -----------------------------------------------
+// dx = gamma * rstd * (dy - m1 - xhat * m2) [* lrelu'(x)] is affine in (dy, x) per (group, channel):
+//   dx = (k1 * dy + k2 * x + k3) [* lrelu'(x)],  k1 = gamma * rstd,  k2 = -k1 * rstd * m2,  k3 = -k1 * m1 - k2 * mean,
+// so a CONSUMER of dx (the first conv layer's weight gradient, d2p_conv2d_nhwc_s2_same_wgrad_bnbwd) can form it on load
+// from x and dy instead of reading a materialised dx: the apply pass (a read of x and dy and a write of dx) disappears.
+// This entry runs the two-stage sums of d2p_bn_group_bwd (same kernels, same order) and leaves coef [G, C, 4] =
+// (k1, k2, k3, 0) plus dgamma / dbeta; the bias gradient (column sums of dx) comes from the consumer.
+__global__ void __launch_bounds__(256)
+bn_bwd_coef_kernel(int C, int G, const float* gamma, const float* mean, const float* rstd, const float* m12,
+                   const double* gs, float* coef, float* dgamma, float* dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double sb = 0.0, sg = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const int idx = g * C + c;
+        const float rs = rstd[idx], k1 = gamma[c] * rs, k2 = -k1 * rs * m12[(long)idx * 2 + 1];
+        const float k3 = -k1 * m12[(long)idx * 2] - k2 * mean[idx];
+        *reinterpret_cast<float4*>(coef + (long)idx * 4) = make_float4(k1, k2, k3, 0.f);
+        sb += gs[(long)idx * 2 + 0];
+        sg += gs[(long)idx * 2 + 1];
+    }
+    if (dgamma) dgamma[c] = (float)sg;
+    if (dbeta) dbeta[c] = (float)sb;
+}
+extern "C" int d2p_bn_group_bwd_coef(int R, int C, int G, int inner, const float* x, const float* dy, const float* gamma,
+                                     const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta,
+                                     void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    int rc = bn_check(R, C, G, inner);
+    if (rc) return rc;
+    D2P_REQUIRE(R > 0 && x && dy && gamma && mean && rstd && coef, D2P_EINVAL, "bn bwd coef: null pointer or no rows");
+    D2P_REQUIRE(((uintptr_t)coef & 15) == 0, D2P_EALIGN, "bn bwd coef: coef must be 16-byte aligned");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_bn_ws_bytes(R, C, G), D2P_EWS, "bn bwd coef: workspace too small");
+    hipStream_t st = as_stream(stream);
+    BnPlan p = bn_plan(R, C, G);
+    const int n = R / G;
+    const BnBatch bb{0, 0, 0, 0, 0, 0};
+    double* partial = (double*)ws;
+    double* gsum = partial + (size_t)G * p.S * C * 2;
+    float* m12 = (float*)(gsum + (size_t)G * C * 2);
+    const bool vec4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
+    BnFold fo{};
+    if (vec4)
+        hipLaunchKernelGGL((bn_partial_kernel<1, 4>), dim3(G, p.S, 1), dim3(256), 0, st, n, C, G, inner, p.lanes_c, p.row_lanes,
+                           x, dy, mean, rstd, partial, bb, fo);
+    else
+        hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(G, p.S, 1), dim3(256), 0, st, n, C, G, inner, (C < 256 ? C : 256),
+                           256 / (C < 256 ? C : 256), x, dy, mean, rstd, partial, bb, fo);
+    D2P_LAUNCH_CHECK("bn_partial_bwd");
+    hipLaunchKernelGGL(bn_finalize_bwd_gc_kernel, dim3(ceil_div(G * C, 4), 1, 1), dim3(256), 0, st, n, C, G, p.S, partial, m12,
+                       gsum, bb);
+    D2P_LAUNCH_CHECK("bn_finalize_bwd");
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, G, gamma, mean, rstd, m12, gsum, coef,
+                       dgamma, dbeta);
+    D2P_LAUNCH_CHECK("bn_bwd_coef");
+    return D2P_OK;
+}
+
 extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float* dy,
                                 const float* gamma, const float* mean, const float* rstd,
                                 int act_bwd, float* dx, float* dgamma, float* dbeta, float* dx_colsum,

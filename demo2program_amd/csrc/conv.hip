@@ -278,6 +278,26 @@ extern "C" int d2p_conv2d_nhwc_s2_same_wgrad_bn(int N, int H, int W, int Cin, in
     return D2P_OK;
 }
 
+// the weight gradient of a layer whose batch-norm backward is folded in: dy = gradient w.r.t. the layer's batch-norm
+// output, act = its pre-norm activation, coef from d2p_bn_group_bwd_coef; also the bias gradient.  D2P_EINVAL when the
+// geometry has no such kernel (d2p_conv_bnbwd_ok).
+extern "C" int d2p_conv_bnbwd_ok(int N, int H, int W, int Cin, int Cout) {
+    return N > 0 && Cin == 4 && Cout == 16 && W == 80 && H > 0;
+}
+extern "C" int d2p_conv2d_nhwc_s2_same_wgrad_bnbwd(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8,
+                                                   const float* act, const float* dy, const float* coef, int G, int seq,
+                                                   float* dw, float* dbias, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    int rc = check_conv(N, H, W, Cin, Cout);
+    if (rc) return rc;
+    D2P_REQUIRE(x && act && dy && coef && dw, D2P_EINVAL, "conv wgrad (bn backward): null pointer");
+    D2P_REQUIRE(G >= 1 && seq >= 1 && N % (G * seq) == 0, D2P_EINVAL, "conv wgrad (bn backward): N=%d is not a multiple of G*seq", N);
+    ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    rc = d2p_conv_rows_wgrad_bnbwd(g, x, x_is_u8, act, dy, coef, G, seq, dw, dbias, ws, ws_bytes, as_stream(stream));
+    if (rc < 0) return rc;
+    D2P_REQUIRE(rc == 1, D2P_EINVAL, "conv wgrad (bn backward): no folding kernel for Cin=%d Cout=%d W=%d", Cin, Cout, W);
+    return D2P_OK;
+}
+
 extern "C" int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int Cout, const void* x,
                                              int x_is_u8, const float* dy, float* dw, void* ws,
                                              size_t ws_bytes, d2p_stream_t stream) {

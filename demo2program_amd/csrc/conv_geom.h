@@ -61,6 +61,9 @@ void d2p_conv_frames_tune(int tiles_per_wave);
 int d2p_conv_rows_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,
                         size_t ws_bytes, hipStream_t st, const ConvBnFold* bn = nullptr);
 size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g);
+int d2p_conv_rows_wgrad_bnbwd(const ConvGeom& g, const void* x, int x_is_u8, const float* act, const float* dy,
+                              const float* coef, int G, int seq, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                              hipStream_t st);
 int d2p_conv_rows_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act,
                       float* y, hipStream_t st, const ConvBnFold* bn = nullptr);
 void d2p_conv_rows_fwd_tune(int workgroups);

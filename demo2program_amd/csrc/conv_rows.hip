@@ -129,11 +129,20 @@ struct RowStager<uint8_t, S, CIN, W> {
     }
 };
 
-template <int CIN, int COUT, int W, typename T, bool AFFINE = false>
+// BNBWD (round 5): `dy` is the gradient w.r.t. the batch-norm OUTPUT of this layer and `act` the layer's pre-norm
+// activation; the conv's own output gradient da = (k1 * dy + k2 * act + k3) * lrelu'(act) -- coef [G, COUT, 4] from
+// d2p_bn_group_bwd_coef -- is formed as the dY fragments are loaded (the batch-norm apply pass that used to write it,
+// a read of act and dy and a write of da, is gone), and the bias gradient, its column sums, comes out with the slab:
+// bsum [workgroups][COUT].
+struct RowsBnBwd {
+    const float* act; const float* coef; float* bsum;
+    int G; unsigned seq_m; int seq_s; unsigned g_m; int g_s;      // (n / seq) % G by multiply-high (d2p_make_div)
+};
+template <int CIN, int COUT, int W, typename T, bool AFFINE = false, bool BNBWD = false>
 __global__ void __launch_bounds__(256)
 conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs, int nframes,
                        int H, int Ho, int pt, int bnG, int bnseq, const float* __restrict__ in_scale,
-                       const float* __restrict__ in_shift) {
+                       const float* __restrict__ in_shift, RowsBnBwd bw) {
     using S = RowShape<CIN, COUT, W>;
     constexpr int AB = S::AB, NBO = S::NBO, KS = S::KS, PSF = S::PSF, Wo = S::Wo;
     constexpr int ACC = AB * NBO * 4, KK = 9 * CIN;
@@ -174,6 +183,9 @@ conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, fl
     float colmask[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) colmask[s] = (4 * s + kq < Wo) ? 1.f : 0.f;
+    float bsum[NBO];            // BNBWD: this lane's sum of da (channel 16b + c, pixels of quarter kq)
+#pragma unroll
+    for (int b = 0; b < NBO; ++b) bsum[b] = 0.f;
     for (int strip = wave; strip < nstrips; strip += NW) {
         const int n = strip / Ho, oy = strip - n * Ho;
         if constexpr (AFFINE) {
@@ -185,19 +197,47 @@ conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, fl
             st.load(x, (long)n * frame_elems, 2 * oy - pt, H, lane);
         }
         float bv[KS][NBO];
+        if constexpr (BNBWD) {
+            float av[KS][NBO];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int ox = 4 * s + kq;
-            const int oxc = ox < Wo ? ox : Wo - 1;
+            for (int s = 0; s < KS; ++s) {
+                const int ox = 4 * s + kq;
+                const int oxc = ox < Wo ? ox : Wo - 1;
 #pragma unroll
-            for (int b = 0; b < NBO; ++b) bv[s][b] = dy[((long)strip * Wo + oxc) * COUT + b * 16 + c];
+                for (int b = 0; b < NBO; ++b) {
+                    bv[s][b] = dy[((long)strip * Wo + oxc) * COUT + b * 16 + c];
+                    av[s][b] = bw.act[((long)strip * Wo + oxc) * COUT + b * 16 + c];
+                }
+            }
+            const int sq_ = d2p_div(n, D2pDiv{bw.seq_m, bw.seq_s});
+            const int g_ = sq_ - d2p_div(sq_, D2pDiv{bw.g_m, bw.g_s}) * bw.G;
+#pragma unroll
+            for (int b = 0; b < NBO; ++b) {
+                const f32x4 k = *reinterpret_cast<const f32x4*>(bw.coef + ((long)g_ * COUT + b * 16 + c) * 4);
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const float a_ = av[s][b];
+                    float d = (k.x * bv[s][b] + k.y * a_ + k.z) * d2p_lrelu_grad_from_out(a_);
+                    if (!(4 * (KS - 1) + 3 < Wo)) d *= colmask[s];
+                    bv[s][b] = d;
+                    bsum[b] += d;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int ox = 4 * s + kq;
+                const int oxc = ox < Wo ? ox : Wo - 1;
+#pragma unroll
+                for (int b = 0; b < NBO; ++b) bv[s][b] = dy[((long)strip * Wo + oxc) * COUT + b * 16 + c];
+            }
         }
         st.store(img, lane);
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             float bc[NBO];
 #pragma unroll
-            for (int b = 0; b < NBO; ++b) bc[b] = (4 * (KS - 1) + 3 < Wo) ? bv[s][b] : bv[s][b] * colmask[s];
+            for (int b = 0; b < NBO; ++b) bc[b] = (BNBWD || 4 * (KS - 1) + 3 < Wo) ? bv[s][b] : bv[s][b] * colmask[s];
 #pragma unroll
             for (int a = 0; a < AB; ++a) {
                 float av = img[aoff[a] + s * 8 * PSF];
@@ -210,6 +250,23 @@ conv_rows_wgrad_kernel(const T* __restrict__ x, const float* __restrict__ dy, fl
 
     // fixed-order tree over the 4 waves (scratch reuses the strip area)
     __syncthreads();
+    if constexpr (BNBWD) {
+        // the bias gradient's share of this workgroup: the four pixel quarters of a wave by two shuffles, the waves
+        // through LDS in wave order
+        float* const bred = lds;
+#pragma unroll
+        for (int b = 0; b < NBO; ++b) {
+            float v = bsum[b];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) bred[wid * COUT + b * 16 + lane] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < COUT)
+            bw.bsum[(long)blockIdx.x * COUT + threadIdx.x] = ((bred[threadIdx.x] + bred[COUT + threadIdx.x]) +
+                                                              bred[2 * COUT + threadIdx.x]) + bred[3 * COUT + threadIdx.x];
+        __syncthreads();
+    }
     float* const red = lds;
 #pragma unroll
     for (int step = 1; step < 4; step *= 2) {
@@ -614,6 +671,17 @@ int launch_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float*
 
 int g_rows_wgrad_wgs = 0;      // 0: per-layer default (template CAP)
 
+// out[c] = sum over workgroups of bsum[workgroup][c] (fp64, lanes stride the workgroups: deterministic)
+__global__ void __launch_bounds__(256)
+rows_bias_reduce_kernel(int C, int nblocks, const float* __restrict__ bsum, float* __restrict__ out) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= C) return;
+    double acc = 0.0;
+    for (int b = lane; b < nblocks; b += 64) acc += (double)bsum[(long)b * C + c];
+    acc = wave_reduce_sum(acc);
+    if (lane == 0) out[c] = (float)acc;
+}
+
 template <int CIN, int COUT, int W, typename T, int CAP>
 struct RowsWgrad {
     using S = RowShape<CIN, COUT, W>;
@@ -626,6 +694,39 @@ struct RowsWgrad {
         const int cap = g_rows_wgrad_wgs > 0 ? g_rows_wgrad_wgs : CAP;   // measured: kernel keeps scaling to 2048
         if (b > cap) b = cap;                                              // workgroups, the combine pass does not
         return b < 1 ? 1 : b;
+    }
+    // the weight gradient with the layer's batch-norm backward folded in (conv_rows_wgrad_kernel, BNBWD): ws holds the
+    // slabs and, behind them, the workgroups' bias-gradient shares
+    static int run_bnbwd(const ConvGeom& g, const T* x, const float* act, const float* dy, const float* coef, int G, int seq,
+                         float* dw, float* dbias, void* ws, size_t ws_bytes, hipStream_t st) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_wgrad_kernel<CIN, COUT, W, T, false, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+            attr_set = true;
+        }
+        const int KK = 9 * CIN, nb = blocks(g);
+        const size_t slab_bytes = (size_t)nb * KK * COUT * sizeof(float);
+        D2P_REQUIRE(ws && ws_bytes >= slab_bytes + (size_t)nb * COUT * sizeof(float), D2P_EWS,
+                    "conv wgrad (bn backward): workspace too small (%zu bytes)", ws_bytes);
+        float* slabs = (float*)ws;
+        float* bsum = (float*)((char*)ws + slab_bytes);
+        const D2pDiv ds = d2p_make_div(seq), dg = d2p_make_div(G);
+        RowsBnBwd bw{act, coef, bsum, G, ds.m, ds.s, dg.m, dg.s};
+        D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * KK * COUT);
+        hipLaunchKernelGGL((conv_rows_wgrad_kernel<CIN, COUT, W, T, false, true>), dim3(nb), dim3(256), lds_bytes, st, x, dy,
+                           slabs, g.N, g.H, g.Ho, g.pt, 1, 1, (const float*)nullptr, (const float*)nullptr, bw);
+        D2P_LAUNCH_CHECK("conv_rows_wgrad_bnbwd");
+        EpiDense ep{dw, COUT, nullptr, 0, 0};
+        const long total = (long)KK * COUT;
+        hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EpiDense>), dim3((int)((total * 16 + 255) / 256)), dim3(256), 0,
+                           st, ep, slabs, KK, COUT, nb);
+        D2P_LAUNCH_CHECK("conv_rows_wgrad_combine");
+        if (dbias) {
+            hipLaunchKernelGGL(rows_bias_reduce_kernel, dim3(ceil_div(COUT, 4)), dim3(256), 0, st, COUT, nb, bsum, dbias);
+            D2P_LAUNCH_CHECK("rows_bias_reduce");
+        }
+        return 1;
     }
     static int run(const ConvGeom& g, const T* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st,
                    const ConvBnFold* bn = nullptr) {
@@ -649,11 +750,11 @@ struct RowsWgrad {
         if constexpr (CAN_AFFINE) {
             if (affine)
                 hipLaunchKernelGGL((conv_rows_wgrad_kernel<CIN, COUT, W, T, true>), dim3(nb), dim3(256), lds_bytes, st, x, dy,
-                                   slabs, g.N, g.H, g.Ho, g.pt, bn->G, bn->seq, bn->in_scale, bn->in_shift);
+                                   slabs, g.N, g.H, g.Ho, g.pt, bn->G, bn->seq, bn->in_scale, bn->in_shift, RowsBnBwd{});
         }
         if (!affine)
             hipLaunchKernelGGL((conv_rows_wgrad_kernel<CIN, COUT, W, T, false>), dim3(nb), dim3(256), lds_bytes, st, x, dy,
-                               slabs, g.N, g.H, g.Ho, g.pt, 1, 1, (const float*)nullptr, (const float*)nullptr);
+                               slabs, g.N, g.H, g.Ho, g.pt, 1, 1, (const float*)nullptr, (const float*)nullptr, RowsBnBwd{});
         D2P_LAUNCH_CHECK("conv_rows_wgrad");
         EpiDense ep{dw, COUT, nullptr, 0, 0};
         const long total = (long)KK * COUT;
@@ -693,7 +794,18 @@ void d2p_conv_rows_dgrad_tune(int wgs) { if (wgs > 0) g_rows_dgrad_wgs = wgs; }
 
 size_t d2p_conv_rows_wgrad_ws(const ConvGeom& g) {
     if (!rows_key(g)) return 0;
-    return (size_t)(g_rows_wgrad_wgs > 2048 ? g_rows_wgrad_wgs : 2048) * 9 * g.Cin * g.Cout * sizeof(float);
+    // (slabs, and the bias-gradient shares of the batch-norm-backward form behind them)
+    return (size_t)(g_rows_wgrad_wgs > 2048 ? g_rows_wgrad_wgs : 2048) * (9 * g.Cin + 1) * g.Cout * sizeof(float);
+}
+
+// the first layer's weight gradient with its batch-norm backward folded in (RowsBnBwd): 1 = taken, 0 = no such kernel
+int d2p_conv_rows_wgrad_bnbwd(const ConvGeom& g, const void* x, int x_is_u8, const float* act, const float* dy,
+                              const float* coef, int G, int seq, float* dw, float* dbias, void* ws, size_t ws_bytes,
+                              hipStream_t st) {
+    if (rows_key(g) != 1 || g.N < 1 || G < 1 || seq < 1) return 0;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 3) || ((uintptr_t)act & 3) || ((uintptr_t)coef & 15)) return 0;
+    if (x_is_u8) return RowsWgrad<4, 16, 80, uint8_t, 1024>::run_bnbwd(g, (const uint8_t*)x, act, dy, coef, G, seq, dw, dbias, ws, ws_bytes, st);
+    return RowsWgrad<4, 16, 80, float, 1024>::run_bnbwd(g, (const float*)x, act, dy, coef, G, seq, dw, dbias, ws, ws_bytes, st);
 }
 
 int d2p_conv_rows_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,

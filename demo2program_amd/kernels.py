@@ -222,6 +222,33 @@ def bn_stats_from_partials(stats, n_per_group, C, G, S, gamma, beta, mean, rstd,
                                     ptr(sc), ptr(sh), ptr(pad), current_stream())
 
 
+def conv_bnbwd_ok(x_shape, Cout):
+    N, H, W, Cin = x_shape
+    return bool(_load_lib().d2p_conv_bnbwd_ok(N, H, W, Cin, Cout))
+
+
+def bn_bwd_coef(x2d, dy, gamma, mean, rstd, G, inner, coef, dgamma, dbeta):
+    """the sums of bn_bwd, leaving coef [G, C, 4] of dx = (k1 dy + k2 x + k3) lrelu'(x) instead of dx (d2p_bn_group_bwd_coef)"""
+    _require_gpu(x2d, dy, coef)
+    R, C = x2d.shape
+    ws, wsb = SCRATCH.get(call.d2p_bn_ws_bytes(R, C, G))
+    call.d2p_bn_group_bwd_coef(R, C, G, inner, ptr(x2d), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(coef), ptr(dgamma),
+                               ptr(dbeta), ws, wsb, current_stream())
+    return coef
+
+
+def conv_wgrad_bnbwd(x, act, dy, coef, G, seq, dw, dbias):
+    """weight (and bias) gradient of a conv layer from the gradient w.r.t. its batch-norm OUTPUT: the batch-norm backward's
+    apply pass is formed on load from act and dy (d2p_conv2d_nhwc_s2_same_wgrad_bnbwd)"""
+    _require_gpu(x, act, dy, dw)
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    ws, wsb = SCRATCH.get(call.d2p_conv_ws_bytes(N, H, W, Cin, Cout))
+    call.d2p_conv2d_nhwc_s2_same_wgrad_bnbwd(N, H, W, Cin, Cout, ptr(x), 1 if x.dtype == torch.uint8 else 0, ptr(act), ptr(dy),
+                                             ptr(coef), G, seq, ptr(dw), ptr(dbias), ws, wsb, current_stream())
+    return dw
+
+
 def bn_apply_fwd(x2d, gamma, beta, mean, rstd, G, inner, y=None):
     _require_gpu(x2d)
     R, C = x2d.shape

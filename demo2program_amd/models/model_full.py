@@ -1280,6 +1280,23 @@ class Model(object):
                 break
             (h, w, cin, cout, ho, wo) = self._conv[l - 1]
             x_in, a, mean, rstd, x_aff = ctx['conv'][l - 1]
+            if l == 1 and self.fold_bn and K.conv_bnbwd_ok(x_in.shape, cout):
+                # (round 5) the first layer needs no input gradient, so its batch-norm backward never materialises the
+                # conv's output gradient: the sums leave coefficients, the weight-gradient kernel forms da from (a, dy)
+                # as it loads them and returns the bias gradient too (the apply pass -- a read of a and dy and a 655 MB
+                # write at 80x80 frames -- is gone)
+                coef = self._buf('conv1/bn_coef', (k, cout, 4))
+                K.bn_bwd_coef(a.view(NF * ho * wo, cout), dy.view(NF * ho * wo, cout), p['conv1/gamma'], mean, rstd, k,
+                              T * ho * wo, coef, g['conv1/gamma'], g['conv1/beta'])
+                dyv = dy.view(NF, ho, wo, cout)
+                if x_in.shape[3] != cin:            # channel-padded conv1 input: unpad the gradient
+                    cp = x_in.shape[3]
+                    gpad = self._buf('conv1/gWpad', (3, 3, cp, cout))
+                    K.conv_wgrad_bnbwd(x_in, a, dyv, coef, k, T, gpad, g['conv1/b'])
+                    K.pad_axis(gpad, 9, cin, cp, cout, g['conv1/W'], unpad=True)
+                else:
+                    K.conv_wgrad_bnbwd(x_in, a, dyv, coef, k, T, g['conv1/W'], g['conv1/b'])
+                continue
             da_ = K.bn_bwd(a.view(NF * ho * wo, cout), dy.view(NF * ho * wo, cout), p['conv%d/gamma' % l],
                            mean, rstd, k, T * ho * wo, True, g['conv%d/gamma' % l], g['conv%d/beta' % l],
                            dx=self._buf('conv%d/da' % l, (NF * ho * wo, cout)), dbias=g['conv%d/b' % l])

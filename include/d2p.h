@@ -236,6 +236,19 @@ int d2p_bn_stats_from_partials(int n_per_group, int C, int G, int S, const doubl
                                float* pad, d2p_stream_t stream);
 int d2p_bn_apply_fwd(int R, int C, int G, int inner, const float* x, const float* gamma, const float* beta,
                      const float* mean, const float* rstd, float* y, d2p_stream_t stream);
+/* The FIRST conv layer's batch-norm backward folded into its weight gradient (nothing needs that layer's input
+ * gradient): d2p_bn_group_bwd_coef runs the sums of d2p_bn_group_bwd and leaves, instead of dx, the coefficients
+ * coef [G, C, 4] = (k1, k2, k3, 0) of dx = (k1 * dy + k2 * x + k3) * lrelu'(x) (+ dgamma, dbeta [C]; ws as
+ * d2p_bn_group_bwd); d2p_conv2d_nhwc_s2_same_wgrad_bnbwd forms that dx from act (= x, the pre-norm activation) and dy as
+ * it loads them -- the apply pass and the materialised dx are gone -- and also returns dbias [Cout] = column sums of dx.
+ * d2p_conv_bnbwd_ok: 1 when the geometry has the folding kernel (80-wide 4 -> 16 layers; ws: d2p_conv_ws_bytes). */
+int d2p_bn_group_bwd_coef(int R, int C, int G, int inner, const float* x, const float* dy, const float* gamma,
+                          const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta, void* ws,
+                          size_t ws_bytes, d2p_stream_t stream);
+int d2p_conv_bnbwd_ok(int N, int H, int W, int Cin, int Cout);
+int d2p_conv2d_nhwc_s2_same_wgrad_bnbwd(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8,
+                                        const float* act, const float* dy, const float* coef, int G, int seq, float* dw,
+                                        float* dbias, void* ws, size_t ws_bytes, d2p_stream_t stream);
 /* d2p_bn_group_fwd's moving_mean / moving_var ([C], nullable together): the G moving-average
  * updates of this call (one per group = one per reference BN call, in group order) are applied
  * by the statistics kernel itself; d2p_bn_update_moving below is the same update stand-alone. */

@@ -375,7 +375,39 @@ def test_batch_norm_folded_into_the_conv_launches(K, B, G, T):
     K.conv_wgrad_bn(a1, dy2, dw, G, T, (sc, sh))
     K.conv_wgrad(y1, dy2, dw_ref)
     close(dw, dw_ref.double().cpu(), atol=2e-5 * float(dw_ref.abs().max()))
+    # ---- layer 1 backward: the batch-norm backward's apply pass folded into the weight gradient
+    dy1 = dev(rnd(N, 40, 40, 16, seed=12))
+    a1f = a1.reshape(N * 1600, 16)
+    dg_ref, db_ref, dbias_ref = (torch.empty(16, device='cuda') for _ in range(3))
+    da_ref = K.bn_bwd(a1f, dy1.view(N * 1600, 16), dev(gam), mean, rstd, G, T * 1600, True, dg_ref, db_ref, dbias=dbias_ref)
+    dw1_ref = torch.empty(3, 3, 4, 16, device='cuda')
+    K.conv_wgrad(xu.cuda(), da_ref.view(N, 40, 40, 16), dw1_ref)
+    assert K.conv_bnbwd_ok((N, 80, 80, 4), 16)
+    coef = torch.empty(G, 16, 4, device='cuda')
+    dg, db, dbias, dw1 = tuple(torch.empty(16, device='cuda') for _ in range(3)) + (torch.empty(3, 3, 4, 16, device='cuda'),)
+    K.bn_bwd_coef(a1f, dy1.view(N * 1600, 16), dev(gam), mean, rstd, G, T * 1600, coef, dg, db)
+    K.conv_wgrad_bnbwd(xu.cuda(), a1, dy1, coef, G, T, dw1, dbias)
+    assert torch.equal(dg, dg_ref) and torch.equal(db, db_ref)          # the same sums by the same kernels
+    close(dw1, dw1_ref.double().cpu(), atol=3e-5 * float(dw1_ref.abs().max()))
+    close(dbias, dbias_ref.double().cpu(), atol=3e-5 * float(dbias_ref.abs().max()) + 1e-4 * float(da_ref.abs().max()))
+    # ... against an fp64 reference of the whole chain (batch-norm backward, then the weight gradient)
+    a64, dy64 = a1.double().cpu().reshape(N, 1600, 16), dy1.double().cpu().reshape(N, 1600, 16)
+    da64 = torch.zeros_like(a64)
+    for gi in range(G):
+        sel = grp == gi
+        v, d = a64[sel].reshape(-1, 16), dy64[sel].reshape(-1, 16)
+        mu, rs = v.mean(0), 1.0 / torch.sqrt(v.var(0, unbiased=False) + 1e-3)
+        xh = (v - mu) * rs
+        dxx = gam.double() * rs * (d - d.mean(0) - xh * (d * xh).mean(0))
+        dxx = dxx * torch.where(v > 0, torch.ones_like(v), torch.full_like(v, 0.2))
+        da64[sel] = dxx.reshape(-1, 1600, 16)
+    close(dbias, da64.sum((0, 1)), atol=1e-4 * float(da64.abs().max()) * 40)
+    xr = xu.double().requires_grad_(False)
+    wref = torch.zeros(3, 3, 4, 16, dtype=torch.float64, requires_grad=True)
+    _conv_ref(xr, wref, torch.zeros(16, dtype=torch.float64)).backward(da64.reshape(N, 40, 40, 16))
+    close(dw1, wref.grad, atol=1e-4 * float(wref.grad.abs().max()))
     # geometries without folding kernels are refused, not silently run
+    assert not K.conv_bnbwd_ok((N, 8, 8, 16), 16)
     assert K.conv_bn_slices((N, 8, 8, 16), 16, G, T) == 0
     with pytest.raises(Exception):
         K.conv_fwd_bn(dev(rnd(N, 8, 8, 16)), dev(rnd(3, 3, 16, 16)), dev(rnd(16)), G, T, 1, st1, act=1)
