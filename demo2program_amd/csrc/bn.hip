@@ -931,10 +931,11 @@ bn_bwd_coef_kernel(int C, int G, const float* gamma, const float* mean, const fl
 }
 extern "C" int d2p_bn_group_bwd_coef(int R, int C, int G, int inner, const float* x, const float* dy, const float* gamma,
                                      const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta,
-                                     void* ws, size_t ws_bytes, d2p_stream_t stream) {
+                                     const double* sums, int S_sums, void* ws, size_t ws_bytes, d2p_stream_t stream) {
     int rc = bn_check(R, C, G, inner);
     if (rc) return rc;
-    D2P_REQUIRE(R > 0 && x && dy && gamma && mean && rstd && coef, D2P_EINVAL, "bn bwd coef: null pointer or no rows");
+    D2P_REQUIRE(R > 0 && (sums || (x && dy)) && gamma && mean && rstd && coef, D2P_EINVAL, "bn bwd coef: null pointer or no rows");
+    D2P_REQUIRE(!sums || S_sums >= 1, D2P_EINVAL, "bn bwd coef: S_sums = %d", S_sums);
     D2P_REQUIRE(((uintptr_t)coef & 15) == 0, D2P_EALIGN, "bn bwd coef: coef must be 16-byte aligned");
     D2P_REQUIRE(ws && ws_bytes >= d2p_bn_ws_bytes(R, C, G), D2P_EWS, "bn bwd coef: workspace too small");
     hipStream_t st = as_stream(stream);
@@ -946,15 +947,17 @@ extern "C" int d2p_bn_group_bwd_coef(int R, int C, int G, int inner, const float
     float* m12 = (float*)(gsum + (size_t)G * C * 2);
     const bool vec4 = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
     BnFold fo{};
-    if (vec4)
+    if (sums) {
+        // (the producer of dy already left the partial sums: d2p_conv2d_nhwc_s2_same_dgrad_bn)
+    } else if (vec4)
         hipLaunchKernelGGL((bn_partial_kernel<1, 4>), dim3(G, p.S, 1), dim3(256), 0, st, n, C, G, inner, p.lanes_c, p.row_lanes,
                            x, dy, mean, rstd, partial, bb, fo);
     else
         hipLaunchKernelGGL((bn_partial_kernel<1, 1>), dim3(G, p.S, 1), dim3(256), 0, st, n, C, G, inner, (C < 256 ? C : 256),
                            256 / (C < 256 ? C : 256), x, dy, mean, rstd, partial, bb, fo);
     D2P_LAUNCH_CHECK("bn_partial_bwd");
-    hipLaunchKernelGGL(bn_finalize_bwd_gc_kernel, dim3(ceil_div(G * C, 4), 1, 1), dim3(256), 0, st, n, C, G, p.S, partial, m12,
-                       gsum, bb);
+    hipLaunchKernelGGL(bn_finalize_bwd_gc_kernel, dim3(ceil_div(G * C, 4), 1, 1), dim3(256), 0, st, n, C, G,
+                       sums ? S_sums : p.S, sums ? sums : (const double*)partial, m12, gsum, bb);
     D2P_LAUNCH_CHECK("bn_finalize_bwd");
     hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, st, C, G, gamma, mean, rstd, m12, gsum, coef,
                        dgamma, dbeta);

@@ -278,6 +278,28 @@ extern "C" int d2p_conv2d_nhwc_s2_same_wgrad_bn(int N, int H, int W, int Cin, in
     return D2P_OK;
 }
 
+// the input gradient of layer l+1 that also leaves layer l's batch-norm-backward partial sums (ConvDgradBn)
+extern "C" int d2p_conv_dgrad_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq) {
+    if (N <= 0 || H <= 0 || W <= 0) return 0;
+    ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    return d2p_conv_rows_dgrad_slices(g, G, seq);
+}
+extern "C" int d2p_conv2d_nhwc_s2_same_dgrad_bn(int N, int H, int W, int Cin, int Cout, const float* dy, const float* w,
+                                                float* dx, const float* act, const float* mean, const float* rstd, int G,
+                                                int seq, double* stats, int S, d2p_stream_t stream) {
+    int rc = check_conv(N, H, W, Cin, Cout);
+    if (rc) return rc;
+    D2P_REQUIRE(dy && w && dx && act && mean && rstd && stats, D2P_EINVAL, "conv dgrad (bn): null pointer");
+    D2P_REQUIRE(S >= 1 && S == d2p_conv_dgrad_bn_slices(N, H, W, Cin, Cout, G, seq), D2P_EINVAL,
+                "conv dgrad (bn): geometry not taken, or S = %d is not d2p_conv_dgrad_bn_slices()", S);
+    ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    ConvDgradBn bn{G, seq, S, act, mean, rstd, stats};
+    rc = d2p_conv_direct_dgrad(g, dy, w, dx, as_stream(stream), &bn);
+    if (rc < 0) return rc;
+    D2P_REQUIRE(rc == 1, D2P_EINVAL, "conv dgrad (bn): no folding kernel (alignment?) for Cin=%d Cout=%d W=%d", Cin, Cout, W);
+    return D2P_OK;
+}
+
 // the weight gradient of a layer whose batch-norm backward is folded in: dy = gradient w.r.t. the layer's batch-norm
 // output, act = its pre-norm activation, coef from d2p_bn_group_bwd_coef; also the bias gradient.  D2P_EINVAL when the
 // geometry has no such kernel (d2p_conv_bnbwd_ok).

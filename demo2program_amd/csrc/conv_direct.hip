@@ -775,7 +775,9 @@ static int launch_dgrad(const ConvGeom& g, const float* dy, const float* w, floa
     return 1;
 }
 
-int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st,
+                          const ConvDgradBn* bn) {
+    if (bn) return d2p_conv_rows_dgrad(g, dy, w, dx, st, bn);      // (statistics out: the row-strip kernel only)
     if (!g_direct_dgrad) return 0;
     if (g_direct_dgrad >= 2) {
         const int rc = d2p_conv_rows_dgrad(g, dy, w, dx, st);

@@ -37,12 +37,22 @@ struct ConvBnFold {
     double* stats;
 };
 
+// The input-gradient launch of layer l+1 leaving the batch-norm BACKWARD partial sums of layer l: dx is the gradient w.r.t.
+// layer l's batch-norm output, act its pre-norm activation, mean / rstd [G, Cin] its statistics; stats [G][S][Cin][2]
+// fp64 = (sum dx, sum dx * xhat) per (index, slice) -- the layout bn_finalize_bwd reads.
+struct ConvDgradBn {
+    int G, seq, S;
+    const float* act; const float* mean; const float* rstd;
+    double* stats;
+};
+
 // Direct back end (conv_direct.hip).  Each returns 1 when it handled the call, 0 when the
 // geometry is not one it is instantiated for (caller falls through to the GEMM back end), or a
 // negative D2P_E* / hipError code.
 int d2p_conv_direct_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w,
                         const float* bias, int act, float* y, hipStream_t st, const ConvBnFold* bn = nullptr);
-int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
+int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st,
+                          const ConvDgradBn* bn = nullptr);
 int d2p_conv_direct_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw,
                           void* ws, size_t ws_bytes, hipStream_t st, const ConvBnFold* bn = nullptr);
 size_t d2p_conv_direct_wgrad_ws(const ConvGeom& g);
@@ -67,7 +77,9 @@ int d2p_conv_rows_wgrad_bnbwd(const ConvGeom& g, const void* x, int x_is_u8, con
 int d2p_conv_rows_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act,
                       float* y, hipStream_t st, const ConvBnFold* bn = nullptr);
 void d2p_conv_rows_fwd_tune(int workgroups);
-int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
+int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st,
+                        const ConvDgradBn* bn = nullptr);
+int d2p_conv_rows_dgrad_slices(const ConvGeom& g, int G, int seq);
 void d2p_conv_rows_dgrad_tune(int workgroups);
 void d2p_conv_rows_tune(int wgrad_workgroups);
 void d2p_conv_frames_wgrad_cap(int cap);

@@ -535,10 +535,21 @@ struct DgradRowShape {
     static_assert(CIN == 16, "one 16-channel block of dX per MFMA row tile");
 };
 
-template <int CIN, int COUT, int W>
+// STATS (round 5): dx is the gradient w.r.t. the PREVIOUS layer's batch-norm output; the launch also leaves that batch
+// norm's backward partial sums -- (sum dx, sum dx * xhat) per (demonstration index, channel), xhat = (act - mean) *
+// rstd with `act` the previous layer's pre-norm activation, read at the positions this launch writes -- so the separate
+// partial-sum pass (a read of act and dx, 1.3 GB at 80x80 frames) is gone.  Work dealt out by index as in the folding
+// forward kernels: workgroup (g, s) = blockIdx.x takes slice s of the strips of index g's frames and writes
+// stats[((g*S + s)*CIN + c)*2 + {0,1}] (fp64; lanes, then waves in a fixed order) -- what bn_finalize_bwd reads.
+struct RowsDgradBn {
+    int G, seq, S, per_slice;
+    const float* act; const float* mean; const float* rstd;
+    double* stats;
+};
+template <int CIN, int COUT, int W, bool STATS = false>
 __global__ void __launch_bounds__(256)
 conv_rows_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx, int nframes,
-                       int H, int Ho, int pt) {
+                       int H, int Ho, int pt, RowsDgradBn bn) {
     using S = DgradRowShape<CIN, COUT, W>;
     constexpr int CC = S::CC, PSF = S::PSF, Wo = S::Wo, PL = S::PL, NL = S::NL;
     extern __shared__ float lds[];
@@ -580,7 +591,26 @@ conv_rows_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w
     const int n0 = (H - e0 + 1) / 2, n1 = (H - (1 - e0) + 1) / 2;
     const int s0 = (n0 + 1) / 2, s1 = (n1 + 1) / 2, per_frame = s0 + s1;
     const long nstrips = (long)nframes * per_frame;
-    for (long strip = wave; strip < nstrips; strip += NW) {
+    // STATS: the strips of this workgroup's (index, slice); the tensor's strip advanced without divisions
+    const int sg = STATS ? (int)blockIdx.x / bn.S : 0, ss = STATS ? (int)blockIdx.x - sg * bn.S : 0;
+    const int sps = bn.seq * per_frame;                                 // strips of one (program, index) sequence
+    const int per_idx = STATS ? (nframes / (bn.G * bn.seq)) * sps : 0;
+    const int swid = __builtin_amdgcn_readfirstlane(wid);
+    const long j0 = STATS ? (long)ss * bn.per_slice + swid : wave;
+    const long j1 = STATS ? min((long)(ss + 1) * bn.per_slice, (long)per_idx) : nstrips;
+    int sq = STATS ? (int)(j0 / sps) : 0, sr = STATS ? (int)(j0 - (long)sq * sps) : 0;
+    f32x4 mu4 = {0.f, 0.f, 0.f, 0.f}, rs4 = mu4, fs = mu4, fq = mu4;
+    if (STATS) {
+        mu4 = *reinterpret_cast<const f32x4*>(bn.mean + sg * CIN + 4 * q);
+        rs4 = *reinterpret_cast<const f32x4*>(bn.rstd + sg * CIN + 4 * q);
+    }
+    for (long jj = j0; jj < j1; jj += STATS ? 4 : NW) {
+        long strip = jj;
+        if (STATS) {
+            strip = (long)(sq * bn.G + sg) * sps + sr;
+            sr += 4;
+            if (sr >= sps) { sr -= sps; ++sq; }
+        }
         const int n = (int)(strip / per_frame);
         int sidx = (int)(strip - (long)n * per_frame);
         const int ey = sidx >= s0 ? 1 : 0;
@@ -636,35 +666,87 @@ conv_rows_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w
                         }
                     const int xo = xoff[ex][t];
                     // second row of the strip may be past the image (odd row count)
-                    if (xo >= 0 && (row1 || xo < W * CIN))
-                        *reinterpret_cast<f32x4*>(out + xo) = acc[0] + acc[1];
+                    if (xo >= 0 && (row1 || xo < W * CIN)) {
+                        const f32x4 o = acc[0] + acc[1];
+                        *reinterpret_cast<f32x4*>(out + xo) = o;
+                        if (STATS) {
+                            const f32x4 av = *reinterpret_cast<const f32x4*>(bn.act + (out - dx) + xo);
+                            fs += o;
+                            fq += o * ((av - mu4) * rs4);
+                        }
+                    }
                 }
             }
         };
         if (ey) run(std::integral_constant<int, 1>{});
         else run(std::integral_constant<int, 0>{});
     }
+    if (STATS) {
+        // lanes (p, q) hold channels 4q + r of their pixels: fp32 sums of a lane's few hundred values -> fp64, the 16
+        // pixel lanes by xor-shuffles, the 4 waves through LDS in wave order
+        __syncthreads();
+        double* wsum = reinterpret_cast<double*>(lds);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double u = (double)fs[r], v = (double)fq[r];
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+                u += __shfl_xor(u, off, 64);
+                v += __shfl_xor(v, off, 64);
+            }
+            if (p == 0) {
+                wsum[(wid * CIN + 4 * q + r) * 2] = u;
+                wsum[(wid * CIN + 4 * q + r) * 2 + 1] = v;
+            }
+        }
+        __syncthreads();
+        const int tid = threadIdx.x;
+        if (tid < 2 * CIN) {
+            const int c = tid >> 1, k = tid & 1;
+            bn.stats[((long)blockIdx.x * CIN + c) * 2 + k] =
+                ((wsum[(0 * CIN + c) * 2 + k] + wsum[(1 * CIN + c) * 2 + k]) + wsum[(2 * CIN + c) * 2 + k]) +
+                wsum[(3 * CIN + c) * 2 + k];
+        }
+    }
 }
 
 int g_rows_dgrad_wgs = 512;     // measured best (occupancy-limited: 160 VGPRs, 38 KB LDS per workgroup)
 
+// strips of one frame in conv_rows_dgrad_kernel's enumeration (two rows of equal parity per strip)
+static int rows_dgrad_per_frame(const ConvGeom& g) {
+    const int e0 = g.pt & 1;
+    const int n0 = (g.H - e0 + 1) / 2, n1 = (g.H - (1 - e0) + 1) / 2;
+    return (n0 + 1) / 2 + (n1 + 1) / 2;
+}
 template <int CIN, int COUT, int W>
-int launch_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+int launch_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st,
+                      const ConvDgradBn* bn = nullptr) {
     using S = DgradRowShape<CIN, COUT, W>;
     constexpr size_t lds_bytes = (size_t)4 * S::IMG * sizeof(float);
+    static_assert(lds_bytes >= (size_t)4 * CIN * 2 * sizeof(double), "the statistics' fold reuses the staging area");
     static bool attr_set = false;
     if (!attr_set) {
-        D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_dgrad_kernel<CIN, COUT, W>,
+        D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_dgrad_kernel<CIN, COUT, W, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        D2P_HIP(hipFuncSetAttribute((const void*)conv_rows_dgrad_kernel<CIN, COUT, W, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
+    }
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * 9 * CIN * COUT);
+    if (bn) {
+        const int per_idx = g.N / bn->G * rows_dgrad_per_frame(g);
+        RowsDgradBn rb{bn->G, bn->seq, bn->S, ceil_div(per_idx, bn->S), bn->act, bn->mean, bn->rstd, bn->stats};
+        hipLaunchKernelGGL((conv_rows_dgrad_kernel<CIN, COUT, W, true>), dim3(bn->G * bn->S), dim3(256), lds_bytes, st, dy, w,
+                           dx, g.N, g.H, g.Ho, g.pt, rb);
+        D2P_LAUNCH_CHECK("conv_rows_dgrad_stats");
+        return 1;
     }
     long strips = (long)g.N * ((g.H + 3) / 4 * 2 + 2);
     int nb = (int)((strips + 15) / 16);
     if (nb > g_rows_dgrad_wgs) nb = g_rows_dgrad_wgs;
     if (nb < 1) nb = 1;
-    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * g.N * g.Ho * g.Wo * 9 * CIN * COUT);
-    hipLaunchKernelGGL((conv_rows_dgrad_kernel<CIN, COUT, W>), dim3(nb), dim3(256), lds_bytes, st, dy, w, dx, g.N, g.H,
-                       g.Ho, g.pt);
+    hipLaunchKernelGGL((conv_rows_dgrad_kernel<CIN, COUT, W, false>), dim3(nb), dim3(256), lds_bytes, st, dy, w, dx, g.N, g.H,
+                       g.Ho, g.pt, RowsDgradBn{});
     D2P_LAUNCH_CHECK("conv_rows_dgrad");
     return 1;
 }
@@ -785,10 +867,22 @@ int d2p_conv_rows_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float
     return launch_rows_fwd<4, 16, 80, float>(g, (const float*)x, w, bias, act, y, st, bn);
 }
 
-int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st,
+                        const ConvDgradBn* bn) {
     if (!(g.Cin == 16 && g.Cout == 32 && g.W == 40) || g.N < 1) return 0;
     if (((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return 0;
-    return launch_rows_dgrad<16, 32, 40>(g, dy, w, dx, st);
+    if (bn && (bn->G < 1 || bn->seq < 1 || bn->S < 1 || g.N % (bn->G * bn->seq) != 0 || !bn->act || !bn->stats ||
+               (((uintptr_t)bn->act | (uintptr_t)bn->mean | (uintptr_t)bn->rstd) & 15)))
+        return 0;
+    return launch_rows_dgrad<16, 32, 40>(g, dy, w, dx, st, bn);
+}
+// slices per demonstration index of the statistics-folding input-gradient launch (0: no such kernel)
+int d2p_conv_rows_dgrad_slices(const ConvGeom& g, int G, int seq) {
+    if (!(g.Cin == 16 && g.Cout == 32 && g.W == 40) || g.N < 1 || G < 1 || seq < 1 || g.N % (G * seq) != 0) return 0;
+    const long units = (long)g.N / G * rows_dgrad_per_frame(g);
+    long S = 2048 / G;
+    if (S * 16 > units) S = units / 16;
+    return (int)(S < 1 ? 1 : S);
 }
 void d2p_conv_rows_dgrad_tune(int wgs) { if (wgs > 0) g_rows_dgrad_wgs = wgs; }
 

@@ -227,14 +227,35 @@ def conv_bnbwd_ok(x_shape, Cout):
     return bool(_load_lib().d2p_conv_bnbwd_ok(N, H, W, Cin, Cout))
 
 
-def bn_bwd_coef(x2d, dy, gamma, mean, rstd, G, inner, coef, dgamma, dbeta):
-    """the sums of bn_bwd, leaving coef [G, C, 4] of dx = (k1 dy + k2 x + k3) lrelu'(x) instead of dx (d2p_bn_group_bwd_coef)"""
+def bn_bwd_coef(x2d, dy, gamma, mean, rstd, G, inner, coef, dgamma, dbeta, sums=None):
+    """the sums of bn_bwd, leaving coef [G, C, 4] of dx = (k1 dy + k2 x + k3) lrelu'(x) instead of dx (d2p_bn_group_bwd_coef);
+    sums = (stats, S): the partial sums the producer of dy left (conv_dgrad_bn) -- no pass over x and dy at all"""
     _require_gpu(x2d, dy, coef)
     R, C = x2d.shape
     ws, wsb = SCRATCH.get(call.d2p_bn_ws_bytes(R, C, G))
+    st, S = sums if sums is not None else (None, 0)
     call.d2p_bn_group_bwd_coef(R, C, G, inner, ptr(x2d), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), ptr(coef), ptr(dgamma),
-                               ptr(dbeta), ws, wsb, current_stream())
+                               ptr(dbeta), ptr(st), S, ws, wsb, current_stream())
     return coef
+
+
+def conv_dgrad_bn_slices(x_shape, Cout, G, seq):
+    N, H, W, Cin = x_shape
+    return int(_load_lib().d2p_conv_dgrad_bn_slices(N, H, W, Cin, Cout, G, seq))
+
+
+def conv_dgrad_bn(dy, w, x_shape, act, mean, rstd, G, seq, stats, S, dx=None):
+    """conv_dgrad that also leaves the batch-norm-backward partial sums of the layer whose output gradient it writes
+    (act: that layer's pre-norm activation, mean / rstd [G, Cin]) in stats [G, S, Cin, 2] fp64"""
+    _require_gpu(dy, w, act, stats)
+    N, H, W, Cin = x_shape
+    Cout = w.shape[3]
+    if dx is None:
+        dx = torch.empty(N, H, W, Cin, dtype=torch.float32, device=dy.device)
+    assert stats.dtype == torch.float64 and stats.numel() >= G * S * Cin * 2
+    call.d2p_conv2d_nhwc_s2_same_dgrad_bn(N, H, W, Cin, Cout, ptr(dy), ptr(w), ptr(dx), ptr(act), ptr(mean), ptr(rstd), G, seq,
+                                          ptr(stats), S, current_stream())
+    return dx
 
 
 def conv_wgrad_bnbwd(x, act, dy, coef, G, seq, dw, dbias):

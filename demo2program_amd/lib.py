@@ -47,7 +47,9 @@ SIGNATURES = {
                                                  c_size_t, S]),
     'd2p_bn_stats_from_partials': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, S]),
     'd2p_bn_apply_fwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, S]),
-    'd2p_bn_group_bwd_coef': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_size_t, S]),
+    'd2p_bn_group_bwd_coef': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_int, P, c_size_t, S]),
+    'd2p_conv_dgrad_bn_slices': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'd2p_conv2d_nhwc_s2_same_dgrad_bn': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, P, c_int, S]),
     'd2p_conv_bnbwd_ok': (c_int, [c_int, c_int, c_int, c_int, c_int]),
     'd2p_conv2d_nhwc_s2_same_wgrad_bnbwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_int, c_int, P, P,
                                                     P, c_size_t, S]),

@@ -1275,6 +1275,7 @@ class Model(object):
 
         # ---- State_Encoder backward
         dy = d_feats
+        dy_sums = None                 # (stats, S): batch-norm-backward partial sums the producer of dy left behind
         for l in range(len(self._conv), 0, -1):
             if self._abl('conv_bwd'):
                 break
@@ -1287,7 +1288,7 @@ class Model(object):
                 # write at 80x80 frames -- is gone)
                 coef = self._buf('conv1/bn_coef', (k, cout, 4))
                 K.bn_bwd_coef(a.view(NF * ho * wo, cout), dy.view(NF * ho * wo, cout), p['conv1/gamma'], mean, rstd, k,
-                              T * ho * wo, coef, g['conv1/gamma'], g['conv1/beta'])
+                              T * ho * wo, coef, g['conv1/gamma'], g['conv1/beta'], sums=dy_sums)
                 dyv = dy.view(NF, ho, wo, cout)
                 if x_in.shape[3] != cin:            # channel-padded conv1 input: unpad the gradient
                     cp = x_in.shape[3]
@@ -1318,8 +1319,20 @@ class Model(object):
                 else:
                     K.conv_wgrad(x_in, da_.view(NF, ho, wo, cout), g['conv%d/W' % l])
             if l > 1:
-                dy = K.conv_dgrad(da_.view(NF, ho, wo, cout), p['conv%d/W' % l], (NF, h, w, cin),
-                                  dx=self._buf('conv%d/dx' % l, (NF, h, w, cin)))
+                dxb = self._buf('conv%d/dx' % l, (NF, h, w, cin))
+                Sd = 0
+                if l == 2 and self.fold_bn and K.conv_bnbwd_ok(ctx['conv'][0][0].shape, cin):
+                    Sd = K.conv_dgrad_bn_slices((NF, h, w, cin), cout, k, T)
+                if Sd > 0:
+                    # the first layer's batch-norm-backward partial sums come out of this launch (it writes the gradient
+                    # they are sums of): no separate pass over (a1, dy1)
+                    _, a_prev, mean_prev, rstd_prev, _ = ctx['conv'][0]
+                    st_ = self._buf('conv1/bn_bwd_partial', (k * Sd * cin * 2,), torch.float64)
+                    dy = K.conv_dgrad_bn(da_.view(NF, ho, wo, cout), p['conv%d/W' % l], (NF, h, w, cin), a_prev, mean_prev,
+                                         rstd_prev, k, T, st_, Sd, dx=dxb)
+                    dy_sums = (st_, Sd)
+                else:
+                    dy = K.conv_dgrad(da_.view(NF, ho, wo, cout), p['conv%d/W' % l], (NF, h, w, cin), dx=dxb)
         main.wait_stream(side)
         return self.params.grad
 

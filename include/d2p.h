@@ -243,8 +243,17 @@ int d2p_bn_apply_fwd(int R, int C, int G, int inner, const float* x, const float
  * it loads them -- the apply pass and the materialised dx are gone -- and also returns dbias [Cout] = column sums of dx.
  * d2p_conv_bnbwd_ok: 1 when the geometry has the folding kernel (80-wide 4 -> 16 layers; ws: d2p_conv_ws_bytes). */
 int d2p_bn_group_bwd_coef(int R, int C, int G, int inner, const float* x, const float* dy, const float* gamma,
-                          const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta, void* ws,
-                          size_t ws_bytes, d2p_stream_t stream);
+                          const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta,
+                          const double* sums, int S_sums, void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* ... and its partial sums from the PRODUCER of dy: the input-gradient launch of the next conv layer leaves stats
+ * [G][S][Cin][2] fp64 = (sum dx, sum dx * xhat) per (index, slice) of what it writes (xhat from act, the pre-norm
+ * activation dx belongs to, and that layer's mean / rstd [G, Cin]); pass them as `sums`, S as `S_sums` to
+ * d2p_bn_group_bwd_coef (x, dy may then be null: no pass over them at all).  d2p_conv_dgrad_bn_slices: S, 0 when the
+ * geometry has no such kernel. */
+int d2p_conv_dgrad_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq);
+int d2p_conv2d_nhwc_s2_same_dgrad_bn(int N, int H, int W, int Cin, int Cout, const float* dy, const float* w, float* dx,
+                                     const float* act, const float* mean, const float* rstd, int G, int seq,
+                                     double* stats, int S, d2p_stream_t stream);
 int d2p_conv_bnbwd_ok(int N, int H, int W, int Cin, int Cout);
 int d2p_conv2d_nhwc_s2_same_wgrad_bnbwd(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8,
                                         const float* act, const float* dy, const float* coef, int G, int seq, float* dw,

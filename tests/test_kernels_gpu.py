@@ -406,7 +406,24 @@ def test_batch_norm_folded_into_the_conv_launches(K, B, G, T):
     wref = torch.zeros(3, 3, 4, 16, dtype=torch.float64, requires_grad=True)
     _conv_ref(xr, wref, torch.zeros(16, dtype=torch.float64)).backward(da64.reshape(N, 40, 40, 16))
     close(dw1, wref.grad, atol=1e-4 * float(wref.grad.abs().max()))
+    # ---- conv2's input gradient leaves layer 1's batch-norm-backward partial sums: the same coefficients without a pass
+    # over (a1, dy1)
+    Sd = K.conv_dgrad_bn_slices((N, 40, 40, 16), 32, G, T)
+    assert Sd > 0
+    std = torch.zeros(G * Sd * 16 * 2, dtype=torch.float64, device='cuda')
+    dx_ref = K.conv_dgrad(dy2, dev(w2), (N, 40, 40, 16))
+    dx_bn = K.conv_dgrad_bn(dy2, dev(w2), (N, 40, 40, 16), a1, mean, rstd, G, T, std, Sd)
+    assert torch.equal(dx_bn, dx_ref)
+    coef_a, coef_b = torch.empty(G, 16, 4, device='cuda'), torch.empty(G, 16, 4, device='cuda')
+    dga, dba, dgb, dbb = (torch.empty(16, device='cuda') for _ in range(4))
+    K.bn_bwd_coef(a1f, dx_ref.view(N * 1600, 16), dev(gam), mean, rstd, G, T * 1600, coef_a, dga, dba)
+    K.bn_bwd_coef(a1f, dx_ref.view(N * 1600, 16), dev(gam), mean, rstd, G, T * 1600, coef_b, dgb, dbb, sums=(std, Sd))
+    sc_ = float(coef_a.abs().max())
+    close(coef_b, coef_a.double().cpu(), atol=2e-5 * sc_)
+    close(dgb, dga.double().cpu(), atol=2e-5 * float(dga.abs().max()) + 1e-6)
+    close(dbb, dba.double().cpu(), atol=2e-5 * float(dba.abs().max()) + 1e-6)
     # geometries without folding kernels are refused, not silently run
+    assert K.conv_dgrad_bn_slices((N, 8, 8, 16), 32, G, T) == 0
     assert not K.conv_bnbwd_ok((N, 8, 8, 16), 16)
     assert K.conv_bn_slices((N, 8, 8, 16), 16, G, T) == 0
     with pytest.raises(Exception):
