@@ -16,6 +16,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define D2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define D2P_OPAQUE_I(v) asm volatile("" : "+v"(v))
 
 namespace {
 
@@ -639,6 +640,21 @@ conv_rows_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w
         }
         float* const out = dx + ((long)n * H + iy0) * W * CIN;
         const bool row1 = iy0 + 2 < H;
+        // STATS: the activation at the positions this strip writes, requested NOW (a load issued in the epilogue, where
+        // its value is needed, exposed a full memory latency per tile: + 240 us); lanes that store nothing re-read 0
+        f32x4 apre[2][NTMAX];
+        if (STATS) {
+            const float* const abase = bn.act + (out - dx);
+#pragma unroll
+            for (int ex = 0; ex < 2; ++ex)
+#pragma unroll
+                for (int t = 0; t < NTMAX; ++t) {
+                    const int xo = xoff[ex][t];
+                    int ao = (xo >= 0 && (row1 || xo < W * CIN)) ? xo : 0;
+                    D2P_OPAQUE_I(ao);
+                    apre[ex][t] = *reinterpret_cast<const f32x4*>(abase + ao);
+                }
+        }
         auto run = [&](auto EYc) {
             constexpr int EY = decltype(EYc)::value;
 #pragma unroll
@@ -670,9 +686,8 @@ conv_rows_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w
                         const f32x4 o = acc[0] + acc[1];
                         *reinterpret_cast<f32x4*>(out + xo) = o;
                         if (STATS) {
-                            const f32x4 av = *reinterpret_cast<const f32x4*>(bn.act + (out - dx) + xo);
                             fs += o;
-                            fq += o * ((av - mu4) * rs4);
+                            fq += o * ((apre[ex][t] - mu4) * rs4);
                         }
                     }
                 }
@@ -880,7 +895,8 @@ int d2p_conv_rows_dgrad(const ConvGeom& g, const float* dy, const float* w, floa
 int d2p_conv_rows_dgrad_slices(const ConvGeom& g, int G, int seq) {
     if (!(g.Cin == 16 && g.Cout == 32 && g.W == 40) || g.N < 1 || G < 1 || seq < 1 || g.N % (G * seq) != 0) return 0;
     const long units = (long)g.N / G * rows_dgrad_per_frame(g);
-    long S = 2048 / G;
+    long S = g_rows_dgrad_wgs / G;           // (as many workgroups as the plain launch: occupancy-limited, 512 measured best)
+    if (S < 1) S = 1;
     if (S * 16 > units) S = units / 16;
     return (int)(S < 1 ? 1 : S);
 }

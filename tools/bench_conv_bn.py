@@ -58,3 +58,21 @@ gam, bet = torch.ones(16, device='cuda'), torch.zeros(16, device='cuda')
 print('batch norm of conv1 (separate launches): statistics + apply %.1f us; apply alone %.1f us' % (
     timed(lambda: K.bn_fwd(a1.view(N * 1600, 16), gam, bet, G, T * 1600, y=y)),
     timed(lambda: K.bn_apply_fwd(a1.view(N * 1600, 16), gam, bet, mean, rstd, G, T * 1600, y=y))))
+Sd = K.conv_dgrad_bn_slices((N, 40, 40, 16), 32, G, T)
+std = torch.zeros(G * Sd * 16 * 2, dtype=torch.float64, device='cuda')
+dx1 = torch.empty(N, 40, 40, 16, device='cuda')
+print('conv2 dgrad plain %.1f us | + conv1 batch-norm-backward sums %.1f us (slices %d); the separate sums pass: see below' % (
+    timed(lambda: K.conv_dgrad(dy2, w2, (N, 40, 40, 16), dx=dx1)),
+    timed(lambda: K.conv_dgrad_bn(dy2, w2, (N, 40, 40, 16), a1, mean, rstd, G, T, std, Sd, dx=dx1)), Sd))
+coef = torch.empty(G, 16, 4, device='cuda')
+dg, db = torch.empty(16, device='cuda'), torch.empty(16, device='cuda')
+da1 = torch.empty(N * 1600, 16, device='cuda')
+dw1, dbias = torch.empty(3, 3, 4, 16, device='cuda'), torch.empty(16, device='cuda')
+a1f, dx1f = a1.view(N * 1600, 16), dx1.view(N * 1600, 16)
+print('conv1 backward: batch-norm backward (sums + apply) %.1f us + weight gradient %.1f us | sums + coefficients %.1f us '
+      '(coefficients from the producer\'s sums %.1f us) + folded weight gradient %.1f us' % (
+          timed(lambda: K.bn_bwd(a1f, dx1f, gam, mean, rstd, G, T * 1600, True, dg, db, dx=da1, dbias=dbias)),
+          timed(lambda: K.conv_wgrad(xu, da1.view(N, 40, 40, 16), dw1)),
+          timed(lambda: K.bn_bwd_coef(a1f, dx1f, gam, mean, rstd, G, T * 1600, coef, dg, db)),
+          timed(lambda: K.bn_bwd_coef(a1f, dx1f, gam, mean, rstd, G, T * 1600, coef, dg, db, sums=(std, Sd))),
+          timed(lambda: K.conv_wgrad_bnbwd(xu, a1, dx1, coef, G, T, dw1, dbias))))
