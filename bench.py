@@ -57,6 +57,7 @@ PROF_FAMILIES = {
     2: ('conv kernels (whole-frame / direct 16x16x4 MFMA / row-strip, implicit-GEMM fallback)', 'mfma', 'conv'),
     3: ('lstm_gate_fwd_kernel', 'hbm', 'gate'),
     4: ('lstm_gate_bwd_kernel', 'hbm', 'gate'),
+    5: ('batch-norm launches (bn_partial / finalize / apply, statistics from partial sums, backward coefficients)', 'hbm', 'bn'),
     7: ('recurrent forward (lstm_persist_fwdw_kernel: one launch for up to three sequences; lstm_step_fwd_kernel per step '
         'for shapes it does not take)', 'mfma', 'recurrent'),
     8: ('recurrent backward (lstm_persist_bwd_kernel / lstm_step_bwd_kernel)', 'mfma', 'recurrent'),
@@ -67,6 +68,7 @@ GROUP_NAMES = {
     'recurrent': 'recurrent LSTM kernels, forward + backward (lstm_persist_fwdw_kernel + lstm_persist_bwd_kernel: '
                  'h.Wh / dz.Wh^T fp32 MFMA + gate math for all time steps of a sequence in one launch)',
     'gate': 'standalone LSTM gate kernels',
+    'bn': 'batch-norm launches of every layer (work = the bytes the separate passes read and write)',
 }
 
 
@@ -81,6 +83,23 @@ def pmc_traffic(family):
         except (OSError, KeyError, ValueError):
             continue
     return None
+
+
+def pmc_family_traffic(patterns, tag):
+    """HBM MB per STEP of the kernels whose name holds one of `patterns`, from the committed PMC passes of `bench.py
+    --preset <tag>` (profiles/r05_pmc_traffic_<tag>.json, tools/profile_vizdoom.sh); None if not collected."""
+    path = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic_%s.json' % tag)
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    steps = d.get('_meta', {}).get('steps')
+    if not steps:
+        return None
+    tot = sum(v['total_mb'] for k, v in d.items() if k != '_meta' and any(p_ in k for p_ in patterns))
+    return {'MB_per_step': round(tot / steps, 1), 'file': os.path.relpath(path, ROOT),
+            'source_commit': d['_meta'].get('source_commit', 'unknown'),
+            'note': 'forward + backward, every conv / batch-norm kernel; counters from separate rocprofv3 --pmc passes'}
 
 
 def pmc_traffic_source():
@@ -381,11 +400,24 @@ def config4_leg(steps=10, warmup=3):
     _, _, table, _ = roofline_leg(tr, feeds)
     conv = [r for r in table if r['group'] == 'conv']
     if conv:
-        res['conv_encoder'] = {'achieved': conv[0]['rate'], 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(conv[0]['rate'] / PEAK_F32_MFMA_TFLOPS, 4),
+        br = conv_binding_roofline(cfg, conv[0]['ms_per_step'], conv[0]['launches_per_step'])
+        # on ALGORITHMIC flops (3 input channels; the kernels multiply the zero-padded 4th channel of conv1 as well)
+        alg = br['flops_per_step'] / (conv[0]['ms_per_step'] * 1e-3) / 1e12
+        res['conv_encoder'] = {'achieved': round(alg, 2), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                               'frac': round(alg / PEAK_F32_MFMA_TFLOPS, 4),
+                               'frac_counting_the_padded_channel': round(conv[0]['rate'] / PEAK_F32_MFMA_TFLOPS, 4),
                                'ms_per_step': conv[0]['ms_per_step'], 'launches_per_step': conv[0]['launches_per_step'],
-                               'binding_roofline': conv_binding_roofline(cfg, conv[0]['ms_per_step'],
-                                                                         conv[0]['launches_per_step'])}
+                               'binding_roofline': br}
+        # the State_Encoder as ONE family: conv launches + batch-norm launches (round 5: conv1 / conv2 carry their
+        # batch-norm statistics, conv1's apply pass and its whole batch-norm backward inside the conv launches)
+        bn = [r for r in table if r['group'] == 'bn']
+        ms = conv[0]['ms_per_step'] + (bn[0]['ms_per_step'] if bn else 0.0)
+        res['conv_bn_encoder'] = {
+            'ms_per_step': round(ms, 4), 'conv_ms': conv[0]['ms_per_step'], 'bn_ms': bn[0]['ms_per_step'] if bn else 0.0,
+            'launches_per_step': conv[0]['launches_per_step'] + (bn[0]['launches_per_step'] if bn else 0),
+            'note': 'bn_ms includes the relation networks\' and the perception encoder\'s batch norms (small)',
+            'algorithmic_fwd_MB': 2776, 'algorithmic_fwd_MB_source': 'SURVEY.md 8(d): conv stack with two-pass batch norm',
+            'hbm_traffic': pmc_family_traffic(('conv_', 'bn_', 'Im2col', 'Dgrad'), 'vizdoom')}
     res['kernel_table'] = table
     del tr
     torch.cuda.empty_cache()

@@ -8,6 +8,7 @@
 // a finalize kernel folds them in a fixed order.  fp64 accumulation makes
 // E[x^2] - E[x]^2 safe for the un-normalised 0..255 ViZDoom activations.
 #include "common.h"
+#include "prof.h"
 
 #define BN_EPS 1e-3   // [TF-1.3] contrib.layers.batch_norm default epsilon
 
@@ -674,6 +675,7 @@ static int bn_fwd_impl(int nb, long xs, long ys, long ps, long ms, int R, int C,
     D2P_REQUIRE(ws && ws_bytes >= (nb > 1 ? ws1 * nb : d2p_bn_ws_bytes(R, C, G)), D2P_EWS,
                 "bn fwd: workspace too small (%zu < %zu)", ws_bytes, ws1 * nb);
     hipStream_t st = as_stream(stream);
+    D2pProfScope prof(st, D2P_PROF_BN, 3.0 * nb * R * C * sizeof(float));       // two reads, one write
     BnPlan p = bn_plan(R, C, G);
     const int n = R / G;
     const BnBatch bb{xs, ys, ps, ms, nb > 1 ? (long)G * C : 0L, nb > 1 ? (long)ws1 : 0L};
@@ -774,6 +776,7 @@ extern "C" int d2p_bn_stats_from_partials(int n_per_group, int C, int G, int S, 
     D2P_REQUIRE(partial && mean && rstd, D2P_EINVAL, "bn stats: null pointer");
     D2P_REQUIRE((scale == nullptr) == (shift == nullptr) && (!scale || (gamma && beta)) && (!pad || scale), D2P_EINVAL,
                 "bn stats: scale / shift go together (pad with them) and need gamma / beta");
+    D2pProfScope prof(as_stream(stream), D2P_PROF_BN, (double)G * S * C * 2 * sizeof(double));
     hipLaunchKernelGGL(bn_stats_from_partials_kernel, dim3(ceil_div(G * C, 4)), dim3(256), 0, as_stream(stream), n_per_group, C,
                        G, S, partial, gamma, beta, mean, rstd, var, scale, shift, pad);
     D2P_LAUNCH_CHECK("bn_stats_from_partials");
@@ -787,6 +790,7 @@ extern "C" int d2p_bn_apply_fwd(int R, int C, int G, int inner, const float* x, 
     if (R == 0) return D2P_OK;
     D2P_REQUIRE(x && gamma && beta && mean && rstd && y, D2P_EINVAL, "bn apply: null pointer");
     const BnBatch bb{0, 0, 0, 0, 0, 0};
+    D2pProfScope prof(as_stream(stream), D2P_PROF_BN, 2.0 * R * C * sizeof(float));
     BnMoving mo{nullptr, nullptr, nullptr, 0.f, (const unsigned*)d2p_persist_err_ptr(), 0};
     const bool vec = (C % 4 == 0) && ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean |
                                         (uintptr_t)rstd) & 15) == 0);
@@ -836,6 +840,7 @@ static int bn_bwd_impl(int nb, long xs, long ys, long ps, int R, int C, int G, i
     hipStream_t st = as_stream(stream);
     BnPlan p = bn_plan(R, C, G);
     const int n = R / G;
+    D2pProfScope prof(st, D2P_PROF_BN, 5.0 * nb * R * C * sizeof(float));       // (x, dy) twice, dx once
     const BnBatch bb{xs, ys, ps, 0L, nb > 1 ? (long)G * C : 0L, nb > 1 ? (long)ws1 : 0L};
     double* partial = (double*)ws;
     double* gsum = partial + (size_t)G * p.S * C * 2;
@@ -939,6 +944,7 @@ extern "C" int d2p_bn_group_bwd_coef(int R, int C, int G, int inner, const float
     D2P_REQUIRE(((uintptr_t)coef & 15) == 0, D2P_EALIGN, "bn bwd coef: coef must be 16-byte aligned");
     D2P_REQUIRE(ws && ws_bytes >= d2p_bn_ws_bytes(R, C, G), D2P_EWS, "bn bwd coef: workspace too small");
     hipStream_t st = as_stream(stream);
+    D2pProfScope prof(st, D2P_PROF_BN, sums ? (double)G * S_sums * C * 2 * sizeof(double) : 2.0 * R * C * sizeof(float));
     BnPlan p = bn_plan(R, C, G);
     const int n = R / G;
     const BnBatch bb{0, 0, 0, 0, 0, 0};

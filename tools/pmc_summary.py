@@ -10,6 +10,7 @@ import sys
 
 
 def family(name):
+    name = name.replace('(anonymous namespace)::', '')
     if 'lstm_persist_fwd' in name: return 'lstm_persist_fwd_kernel'
     if 'lstm_persist_bwd' in name: return 'lstm_persist_bwd_kernel'
     if 'lstm_step_fwd' in name: return 'lstm_step_fwd_kernel'
@@ -60,6 +61,8 @@ def main():
         out['_meta'] = {'collected_by': 'tools/profile_pmc.sh (rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE, '
                                         'one counter per pass, eager one-stream launches)',
                         'source_commit': os.environ.get('D2P_COMMIT', 'unknown'),
+                        # optimizer steps the passes ran (warm-up + timed; the adam_clip launches count them)
+                        'steps': max((r['launches'] for r in rows if r['kernel'].startswith('adam_clip')), default=0),
                         'correction': 'HBM bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE counts half '
                                       'of wide coalesced reads; WRITE_SIZE uncalibrated)'}
         json.dump(out, open(sys.argv[2], 'w'), indent=1)
