@@ -417,7 +417,7 @@ def config4_leg(steps=10, warmup=3):
             'launches_per_step': conv[0]['launches_per_step'] + (bn[0]['launches_per_step'] if bn else 0),
             'note': 'bn_ms includes the relation networks\' and the perception encoder\'s batch norms (small)',
             'algorithmic_fwd_MB': 2776, 'algorithmic_fwd_MB_source': 'SURVEY.md 8(d): conv stack with two-pass batch norm',
-            'hbm_traffic': pmc_family_traffic(('conv_', 'bn_', 'Im2col', 'Dgrad'), 'vizdoom')}
+            'hbm_traffic': pmc_family_traffic(('conv_', 'bn_', '<conv>'), 'vizdoom')}
     res['kernel_table'] = table
     del tr
     torch.cuda.empty_cache()
