@@ -918,7 +918,623 @@ extern "C" int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_i
 
 namespace {
 
+// ------------------------------------------------------------------------------------------
+// The whole Karel State_Encoder BACKWARD in one launch + one combine launch (round 5).
+// The chain it replaces is 21 launches of 5-15 us each at the END of a step, where nothing runs beside them: the
+// transpose of the feature gradient, and per layer batch-norm backward (partial sums, finalize, apply, column sums), the
+// weight gradient + its combine, the input gradient (models/model_full.py:216-231, models/ops.py:14-33 in reverse).
+//
+// Same decomposition as the forward launch: workgroup (index g, slice s) owns the frames of a few programs of ONE
+// demonstration index through all three layers; what the layers hand to each other stays in LDS:
+//   D3 [frame][48]   gradient of layer 3's batch-norm output (read time-major: no transpose pass), turned in place into
+//                    the gradient of its conv output (batch-norm backward + lrelu'),
+//   D2 [frame][2x2][32], D1 [frame][4x4][16]   the same for layers 2 and 1; the input gradients of layers 3 and 2 are
+//                    written straight into them (layer 3's taps map 1:1 onto layer 2's four pixels; layer 2's nine taps
+//                    are scattered from 16-row output tiles, a frame's tile belonging to one wave, in a fixed order),
+//   A3, A2, A1       the saved pre-norm activations a_l (batch-norm backward needs x-hat and the sign; the layer
+//                    above needs y_l = batch norm(a_l) as its conv input: formed on load, one multiply-add).
+// The batch-norm backward of a layer needs sum(dy) and sum(dy * x-hat) over ALL frames of the index: the S workgroups
+// of an index meet once per layer exactly as in the forward launch (fp64 partial sums, monotonic arrival tickets).
+// Products on the matrix pipe (16x16x4 fp32), operands from LDS:
+//   input gradient   C[ci][pixel] = sum_co W[tap][ci][co] dpre[pixel][co]   (A = filter in registers, B = 16-byte LDS reads),
+//   weight gradient  C[ci][co] = sum_pixel y[pixel@tap][ci] dpre[pixel][co]  (A, B = 4-byte LDS reads; layers 3 / 2: the
+//                    taps dealt out to the waves, no cross-wave sum; layer 1: frames dealt out, x staged per wave as in
+//                    the forward launch, the four waves' sums added in a fixed tree).
+// Every parameter gradient (filters, biases, gamma, beta) is a sum over the workgroups: each writes ONE slab of
+// ENC_SLAB floats, karel_encoder_bwd_fold_kernel adds the slabs in workgroup order (deterministic) into the gradient
+// tensors -- the second launch.
+#define ENC_SLAB_W1 0
+#define ENC_SLAB_W2 2304                     // 9 * 16 * 16
+#define ENC_SLAB_W3 6912                     // + 9 * 16 * 32; layer 3: the 4 taps that touch a 2x2 frame, [4][32][48]
+#define ENC_SLAB_DB 13056                    // + 4 * 32 * 48; bias gradients 16 | 32 | 48
+#define ENC_SLAB_GB 13152                    // (dgamma, dbeta) of layer 1 (16 | 16), layer 2 (32 | 32), layer 3 (48 | 48)
+#define ENC_SLAB 13376                      // 13344 used, padded to whole 64-element blocks
+__device__ unsigned long long g_enc_bwd_counters[ENC_MAXS + 1][3][ENC_MAXG];
+
+struct EncBwdArgs {
+    const void* x;                   // frames [B, G, T, 8, 8, 16]
+    const float* dfeat_tm;           // [T, B*G, 48]: gradient of the time-major features
+    const float *w[3], *gamma[3], *beta[3];
+    const float* a[3];               // saved pre-norm activations
+    const float *mean[3], *rstd[3];  // [G, C_l]
+    double* part;                    // [3][G][S][48][2]
+    float* slabs;                    // [G*S][ENC_SLAB]
+    unsigned long long* counters;    // g_enc_bwd_counters[S]
+    unsigned* err;
+    int B, G, T, S, nb;
+    unsigned long long* trace;       // diagnostic (d2p_karel_encoder_set_trace): [workgroup][16] wall-clock stamps, or null
+};
+
+// this workgroup's sums over its npx pixels: wsum[r][c] = (sum dy, sum dy * x-hat) of thread row r (R = 256 / C rows)
+template <int C>
+__device__ __forceinline__ void enc_bwd_sums(const float* A, int psa, const float* D, int psd, int npx, const float* mean,
+                                             const float* rstd, double* wsum) {
+    constexpr int R = 256 / C;
+    const int r = threadIdx.x / C, c = threadIdx.x - r * C;
+    if (r < R) {
+        const float mu = mean[c], rs = rstd[c];
+        double s1 = 0.0, s2 = 0.0;
+        for (int px = r; px < npx; px += R) {
+            const float dy = D[px * psd + c], xh = (A[px * psa + c] - mu) * rs;
+            s1 += (double)dy;
+            s2 += (double)dy * (double)xh;
+        }
+        wsum[(r * C + c) * 2] = s1;
+        wsum[(r * C + c) * 2 + 1] = s2;
+    }
+    __syncthreads();
+}
+
+// the exchange of layer `layer` among the S workgroups of index g (as enc_stats), in two halves so that work that does
+// not depend on it runs while the other workgroups arrive.  publish: own sums -> slab (dbeta, dgamma are sums over every
+// workgroup) and -> part, then this workgroup's arrival ticket (its target count stays in LDS).
+template <int C>
+__device__ __forceinline__ void enc_bwd_publish(const EncBwdArgs& a, int layer, int g, int s, double* wsum, int* flag,
+                                                float* slab_gb) {
+    constexpr int R = 256 / C;
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
+        a.part + ((long)layer * a.G + g) * a.S * 96, 0, a.S * 96 * (int)sizeof(double), 0x00020000);
+    if (tid < C) {
+        double s0 = 0.0, s1 = 0.0;
+        for (int w = 0; w < R; ++w) { s0 += wsum[(w * C + tid) * 2]; s1 += wsum[(w * C + tid) * 2 + 1]; }
+        const double pr[2] = {s0, s1};
+        i32x4 pv;
+        __builtin_memcpy(&pv, pr, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(pv, res, (s * 48 + tid) * 16, 0, ENC_AUX_SC1);
+        slab_gb[tid] = (float)s1;            // dgamma
+        slab_gb[C + tid] = (float)s0;        // dbeta
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        unsigned long long* cnt = a.counters + (long)layer * ENC_MAXG + g;
+        const unsigned long long ticket = __hip_atomic_fetch_add(cnt, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long target = (ticket / (unsigned)a.S + 1ull) * (unsigned)a.S;
+        __builtin_memcpy(flag + 2, &target, 8);
+    }
+}
+// collect: wait for the S arrivals, add the S partial sums in slice order -> cst[5][48] = gamma*rstd, m1, m2, mean, rstd of (g, c)
+template <int C>
+__device__ __forceinline__ void enc_bwd_collect(const EncBwdArgs& a, int layer, int g, int n_per_group, double* wsum,
+                                                float* cst, int* flag) {
+    constexpr int R = 256 / C;
+    const int tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
+        a.part + ((long)layer * a.G + g) * a.S * 96, 0, a.S * 96 * (int)sizeof(double), 0x00020000);
+    if (tid == 0) {
+        unsigned long long* cnt = a.counters + (long)layer * ENC_MAXG + g;
+        unsigned long long target;
+        __builtin_memcpy(&target, flag + 2, 8);
+        unsigned spins = 0;
+        int ok = 1;
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > 800000u || ((spins & 1023u) == 0u && __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(a.err, (0x7du << 24) | 0x800000u | (blockIdx.x & 0xffffu), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        *flag = ok;
+    }
+    __syncthreads();
+    {
+        const int r = tid / C, c = tid - r * C;
+        if (r < R) {
+            double p0 = 0.0, p1 = 0.0;
+            for (int s2 = r; s2 < a.S; s2 += 4 * R) {
+                i32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int sx = s2 + u * R;
+                    v[u] = __builtin_amdgcn_raw_buffer_load_b128(res, sx < a.S ? (sx * 48 + c) * 16 : ENC_OOB, 0, ENC_AUX_SC1);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    double pr[2];
+                    __builtin_memcpy(pr, &v[u], 16);
+                    p0 += pr[0];
+                    p1 += pr[1];
+                }
+            }
+            wsum[(r * C + c) * 2] = p0;
+            wsum[(r * C + c) * 2 + 1] = p1;
+        }
+    }
+    __syncthreads();
+    if (tid < C) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) { s0 += wsum[(r * C + tid) * 2]; s1 += wsum[(r * C + tid) * 2 + 1]; }
+        const float rs = a.rstd[layer][g * C + tid];
+        cst[tid] = a.gamma[layer][tid] * rs;
+        cst[48 + tid] = (float)(s0 / n_per_group);
+        cst[96 + tid] = (float)(s1 / n_per_group);
+        cst[144 + tid] = a.mean[layer][g * C + tid];
+        cst[192 + tid] = rs;
+    }
+    __syncthreads();
+}
+
+// D <- gamma rstd (dy - m1 - x-hat m2) lrelu'(a) in place (the formula of bn_apply_bwd_kernel); the column sums of the
+// result (this workgroup's share of the bias gradient) -> slab_db
+template <int C>
+__device__ __forceinline__ void enc_bwd_apply(const float* A, int psa, float* D, int psd, int npx, const float* cst,
+                                              double* wsum, float* slab_db) {
+    constexpr int R = 256 / C;
+    const int r = threadIdx.x / C, c = threadIdx.x - r * C;
+    if (r < R) {
+        const float k1 = cst[c], m1 = cst[48 + c], m2 = cst[96 + c], mu = cst[144 + c], rs = cst[192 + c];
+        float sum = 0.f;
+        for (int px = r; px < npx; px += R) {
+            const float av = A[px * psa + c];
+            const float xh = (av - mu) * rs;
+            float d = k1 * (D[px * psd + c] - m1 - xh * m2);
+            d *= d2p_lrelu_grad_from_out(av);
+            D[px * psd + c] = d;
+            sum += d;
+        }
+        wsum[r * C + c] = (double)sum;
+    }
+    __syncthreads();
+    if (threadIdx.x < C) {
+        double t = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < R; ++rr) t += wsum[rr * C + threadIdx.x];
+        slab_db[threadIdx.x] = (float)t;
+    }
+    __syncthreads();
+}
+
+struct EncBwdLds {      // offsets in floats
+    int r0, r1, r2, wsum, cst, flag, zero, total;
+};
+__host__ __device__ inline EncBwdLds enc_bwd_lds(int nfr) {
+    const int nfr16 = (nfr + 15) / 16 * 16;
+    EncBwdLds L;
+    const int s0 = 288 * nfr16 > 10272 ? 288 * nfr16 : 10272;       // A2 | D2 (36 floats per pixel); later conv1's staging images
+    const int s1 = 256 * nfr > 4608 ? 256 * nfr : 4608;              // A1 (16 per pixel); later the weight-gradient tree
+    const int s2 = 320 * nfr > 104 * nfr16 ? 320 * nfr : 104 * nfr16;   // D1 (20 per pixel); before that A3 | D3 (52 per frame)
+    L.r0 = 0; L.r1 = s0; L.r2 = s0 + s1;
+    L.wsum = s0 + s1 + s2;                      // 512 doubles
+    L.cst = L.wsum + 1024;
+    L.flag = L.cst + 240;                      // ok flag, -, the arrival target (64 bits)
+    L.zero = L.flag + 8;                        // 36 zeros: the pixel outside a 2x2 gradient frame
+    L.total = L.zero + 36;
+    return L;
+}
+
+template <typename XT>
+__global__ void __launch_bounds__(256)
+karel_encoder_bwd_kernel(EncBwdArgs a) {
+    using S1 = FrameShape<16, 16, 8, 8>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, q = lane >> 4, wid = tid >> 6;
+    const int g = blockIdx.x / a.S, s = blockIdx.x % a.S;
+    const int b0 = s * a.nb, nbl = min(a.nb, a.B - b0);
+    const int T = a.T, nfr = nbl > 0 ? nbl * T : 0;              // (no empty slices: enc_plan)
+    const int nfr16 = (nfr + 15) / 16 * 16;
+    const EncBwdLds L = enc_bwd_lds(a.nb * T);
+    float* const A2 = lds + L.r0;                                 // [nfr16 * 4][36]
+    float* const D2 = A2 + (size_t)((a.nb * T + 15) / 16 * 16) * 144;
+    float* const A1 = lds + L.r1;                                 // [nfr * 16][16]
+    float* const D1 = lds + L.r2;                                 // [nfr * 16][20]
+    float* const A3 = D1;                                         // [nfr16][52]  (dead before layer 2's input gradient lands in D1)
+    float* const D3 = A3 + (size_t)((a.nb * T + 15) / 16 * 16) * 52;
+    double* const wsum = reinterpret_cast<double*>(lds + L.wsum);
+    float* const cst = lds + L.cst;
+    int* const flag = reinterpret_cast<int*>(lds + L.flag);
+    float* const slab = a.slabs + (size_t)blockIdx.x * ENC_SLAB;
+    const long M = (long)a.B * a.G;
+    const int n1 = a.B * T * 16, n2 = a.B * T * 4, n3 = a.B * T;
+    auto frame_of = [&](int lf) { return ((long)(b0 + lf / T) * a.G + g) * T + (lf % T); };
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 0] = wall_clock64();
+
+    // ---------------- layer 3's activations and the incoming gradient -> LDS ----------------
+    for (int i = tid; i < nfr16 * 12; i += 256) {
+        const int lf = i / 12, c4 = (i - lf * 12) * 4;
+        f32x4 av = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+        if (lf < nfr) {
+            av = *reinterpret_cast<const f32x4*>(a.a[2] + frame_of(lf) * 48 + c4);
+            const long m = (long)(b0 + lf / T) * a.G + g;
+            dv = *reinterpret_cast<const f32x4*>(a.dfeat_tm + ((long)(lf % T) * M + m) * 48 + c4);
+        }
+        *reinterpret_cast<f32x4*>(A3 + lf * 52 + c4) = av;
+        *reinterpret_cast<f32x4*>(D3 + lf * 52 + c4) = dv;
+    }
+    if (tid < 9) *reinterpret_cast<f32x4*>(lds + L.zero + tid * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 1] = wall_clock64();
+
+    // ================= layer 3: 2x2x32 -> 1x1x48 =================
+    enc_bwd_sums<48>(A3, 52, D3, 52, nfr, a.mean[2] + g * 48, a.rstd[2] + g * 48, wsum);
+    enc_bwd_publish<48>(a, 2, g, s, wsum, flag, slab + ENC_SLAB_GB + 96);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 2] = wall_clock64();
+    // while the index's other workgroups arrive: the activations of layers 2 and 1 -> LDS
+    for (int i = tid; i < nfr16 * 32; i += 256) {
+        const int lf = i >> 5, rem = i & 31;
+        f32x4 av = {0.f, 0.f, 0.f, 0.f};
+        if (lf < nfr) av = *reinterpret_cast<const f32x4*>(a.a[1] + frame_of(lf) * 128 + rem * 4);
+        *reinterpret_cast<f32x4*>(A2 + (lf * 4 + (rem >> 3)) * 36 + (rem & 7) * 4) = av;
+    }
+    for (int i = tid; i < nfr * 64; i += 256) {
+        const int lf = i >> 6, rem = i & 63;
+        *reinterpret_cast<f32x4*>(A1 + (size_t)i * 4) = *reinterpret_cast<const f32x4*>(a.a[0] + frame_of(lf) * 256 + rem * 4);
+    }
+    enc_bwd_collect<48>(a, 2, g, n3, wsum, cst, flag);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 3] = wall_clock64();
+    enc_bwd_apply<48>(A3, 52, D3, 52, nfr, cst, wsum, slab + ENC_SLAB_DB + 48);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 4] = wall_clock64();
+    {
+        // input gradient: D2[frame][pixel w][ci] = sum_co W3[tap][ci][co] dpre3[frame][co]; wave w: tap (ky, kx) =
+        // (w / 2, w % 2), the tap that reads pixel w of the 2x2 frame (pad_before(2) = 0)
+        const int tapid = (wid >> 1) * 3 + (wid & 1);
+        float wr[2][3][4];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ob = 0; ob < 3; ++ob)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wr[cb][ob][j] = a.w[2][((tapid * 32 + cb * 16 + p) * 48) + ob * 16 + 4 * q + j];
+        for (int ft = 0; ft < nfr16 / 16; ++ft) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int ob = 0; ob < 3; ++ob) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(D3 + (ft * 16 + p) * 52 + ob * 16 + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) acc[cb] = D2P_MFMA16(wr[cb][ob][j], bb[j], acc[cb]);
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                *reinterpret_cast<f32x4*>(D2 + ((ft * 16 + p) * 4 + wid) * 36 + cb * 16 + 4 * q) = acc[cb];
+        }
+    }
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 5] = wall_clock64();
+
+    // ================= layer 2: 4x4x16 -> 2x2x32 =================
+    enc_bwd_sums<32>(A2, 36, D2, 36, nfr * 4, a.mean[1] + g * 32, a.rstd[1] + g * 32, wsum);
+    enc_bwd_publish<32>(a, 1, g, s, wsum, flag, slab + ENC_SLAB_GB + 32);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 6] = wall_clock64();
+    {
+        // while the others arrive -- layer 3's weight gradient (nothing downstream reads it):
+        // dW3[tap][ci][co] = sum_frame y2[frame][pixel w][ci] dpre3[frame][co], wave w: tap w
+        float sc[2], sh[2];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            const int ci = cb * 16 + p;
+            sc[cb] = a.gamma[1][ci] * a.rstd[1][g * 32 + ci];
+            sh[cb] = a.beta[1][ci] - a.mean[1][g * 32 + ci] * sc[cb];
+        }
+        f32x4 acc[2][3];
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ob = 0; ob < 3; ++ob) acc[cb][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ks = 0; ks < nfr16 / 4; ++ks) {
+            const int f = 4 * ks + q;
+            float av[2], bv[3];
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) av[cb] = A2[(f * 4 + wid) * 36 + cb * 16 + p] * sc[cb] + sh[cb];
+#pragma unroll
+            for (int ob = 0; ob < 3; ++ob) bv[ob] = D3[f * 52 + ob * 16 + p];      // (rows past nfr: zeros)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                for (int ob = 0; ob < 3; ++ob) acc[cb][ob] = D2P_MFMA16(av[cb], bv[ob], acc[cb][ob]);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int ob = 0; ob < 3; ++ob)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    slab[ENC_SLAB_W3 + (wid * 32 + cb * 16 + 4 * q + r) * 48 + ob * 16 + p] = acc[cb][ob][r];
+    }
+    enc_bwd_collect<32>(a, 1, g, n2, wsum, cst, flag);           // (its first barrier: A3 / D3 are dead from here)
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 7] = wall_clock64();
+    enc_bwd_apply<32>(A2, 36, D2, 36, nfr * 4, cst, wsum, slab + ENC_SLAB_DB + 16);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 8] = wall_clock64();
+    {
+        // input gradient, gathered by the parity class (ey, ex) of the input pixel: pixel (2 cy + ey, 2 cx + ex) of a 4x4
+        // frame receives the taps ky in {0, 2} (ey = 0) or {1} (ey = 1) from output row oy = cy - (ky == 2) (pad_before(4) =
+        // 0), likewise in x -- 4 + 2 + 2 + 1 tap instances, each C[ci][pixel] (K = 32 co) on a tile of 4 frames x the
+        // class's 2x2 pixels; a row outside the 2x2 gradient frame reads the zero pixel.  Every D1 element is written once.
+        float wr[9][2][4];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wr[tap][ob][j] = a.w[1][(tap * 16 + p) * 32 + ob * 16 + 4 * q + j];
+        const int fl = p >> 2, cy = (p >> 1) & 1, cx = p & 1;
+        const int zoff = (int)(lds + L.zero - D2);
+        for (int tile = wid; tile < nfr / 4; tile += 4) {
+            const int fbase = (tile * 4 + fl) * 4;
+#pragma unroll
+            for (int ey = 0; ey < 2; ++ey)
+#pragma unroll
+                for (int ex = 0; ex < 2; ++ex) {
+                    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int ky = ey; ky < 3; ky += 2)
+#pragma unroll
+                        for (int kx = ex; kx < 3; kx += 2) {
+                            const int oy = cy - (ky == 2 ? 1 : 0), ox = cx - (kx == 2 ? 1 : 0);
+                            const int off = (oy >= 0 && ox >= 0) ? (fbase + oy * 2 + ox) * 36 : zoff;
+#pragma unroll
+                            for (int ob = 0; ob < 2; ++ob) {
+                                const f32x4 bb = *reinterpret_cast<const f32x4*>(D2 + off + ob * 16 + 4 * q);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    if (j & 1) acc1 = D2P_MFMA16(wr[ky * 3 + kx][ob][j], bb[j], acc1);
+                                    else acc0 = D2P_MFMA16(wr[ky * 3 + kx][ob][j], bb[j], acc0);
+                                }
+                            }
+                        }
+                    *reinterpret_cast<f32x4*>(D1 + ((tile * 4 + fl) * 16 + (2 * cy + ey) * 4 + 2 * cx + ex) * 20 + 4 * q) = acc0 + acc1;
+                }
+        }
+    }
+    __syncthreads();
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 9] = wall_clock64();
+
+    // ================= layer 1: 8x8x16 -> 4x4x16 (no input gradient) =================
+    enc_bwd_sums<16>(A1, 16, D1, 20, nfr * 16, a.mean[0] + g * 16, a.rstd[0] + g * 16, wsum);
+    enc_bwd_publish<16>(a, 0, g, s, wsum, flag, slab + ENC_SLAB_GB);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 10] = wall_clock64();
+    {
+        // while the others arrive -- layer 2's weight gradient: (tap, 16-column block) pairs dealt out to the waves; the
+        // reduction index of a matrix instruction is (frame, output pixel q)
+        const float sc = a.gamma[0][p] * a.rstd[0][g * 16 + p], sh = a.beta[0][p] - a.mean[0][g * 16 + p] * sc;
+#pragma unroll 1
+        for (int pr = wid; pr < 18; pr += 4) {
+            const int tap = pr >> 1, ob = pr & 1, ky = tap / 3, kx = tap - 3 * ky;
+            const int iy = 2 * (q >> 1) + ky, ix = 2 * (q & 1) + kx;
+            const bool ok = iy < 4 && ix < 4;
+            const int aoff = ok ? (iy * 4 + ix) * 16 + p : 0;
+            const float scv = ok ? sc : 0.f, shv = ok ? sh : 0.f;      // (outside the frame: the zero padding, not beta)
+            const int boff = q * 36 + ob * 16 + p;
+            f32x4 acc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int f = 0; f < nfr; f += 4) {                        // (nfr % 4 == 0)
+                float av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { av[u] = A1[(f + u) * 256 + aoff]; bv[u] = D2[(f + u) * 144 + boff]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] = D2P_MFMA16(av[u] * scv + shv, bv[u], acc[u]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[ENC_SLAB_W2 + (tap * 16 + 4 * q + r) * 32 + ob * 16 + p] = (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]);
+        }
+    }
+    enc_bwd_collect<16>(a, 0, g, n1, wsum, cst, flag);           // (its first barrier: A2 / D2 are dead from here)
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 11] = wall_clock64();
+    enc_bwd_apply<16>(A1, 16, D1, 20, nfr * 16, cst, wsum, slab + ENC_SLAB_DB);
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 12] = wall_clock64();
+    {
+        // weight gradient: frames dealt out to the waves (lf = wid + 4 i), x staged through wave-private images in the
+        // dead A2 | D2 region as in the forward launch
+        float* const im0 = lds + L.r0 + (size_t)wid * 2 * S1::BUF;
+        float* const im1 = im0 + S1::BUF;
+        if (lane == 0) {
+            *reinterpret_cast<f32x4*>(im0 + S1::NPIX * S1::PSF) = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(im1 + S1::NPIX * S1::PSF) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        int toff[9][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int opx = 4 * m + q, oy = opx >> 2, ox = opx & 3;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = 2 * oy + tap / 3, ix = 2 * ox + tap % 3;
+                toff[tap][m] = (iy < 8 && ix < 8) ? (iy * 8 + ix) * S1::PSF + p : S1::NPIX * S1::PSF;
+            }
+        }
+        f32x4 acc[9];
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) acc[tap] = f32x4{0.f, 0.f, 0.f, 0.f};
+        Stager<XT, S1> st;
+        st.init(lane);
+        const long total = (long)a.B * a.G * T * S1::CHUNK;
+        const XT* xin = reinterpret_cast<const XT*>(a.x);
+        const int nmine = nfr > wid ? (nfr - wid + 3) / 4 : 0;
+        if (nmine > 0) st.load(xin, (int)frame_of(wid), total, lane);
+        for (int i = 0; i < nmine; ++i) {
+            float* const img = (i & 1) ? im1 : im0;
+            st.store(img);
+            const int nx = i + 1 < nmine ? i + 1 : i;
+            st.load(xin, (int)frame_of(wid + 4 * nx), total, lane);
+            const int lf = wid + 4 * i;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float bv = D1[(lf * 16 + 4 * m + q) * 20 + p];
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) acc[tap] = D2P_MFMA16(img[toff[tap][m]], bv, acc[tap]);
+            }
+        }
+        // the four waves' sums in a fixed tree through the dead A1 region
+        __syncthreads();
+        if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 13] = wall_clock64();
+        float* const red = lds + L.r1;
+#pragma unroll
+        for (int step = 1; step < 4; step *= 2) {
+            if ((wid & (2 * step - 1)) == step) {
+                float* dst = red + (size_t)(wid / (2 * step)) * 36 * 64;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[(tap * 4 + r) * 64 + lane] = acc[tap][r];
+            }
+            __syncthreads();
+            if ((wid & (2 * step - 1)) == 0) {
+                const float* src = red + (size_t)(wid / (2 * step)) * 36 * 64;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[tap][r] += src[(tap * 4 + r) * 64 + lane];
+            }
+            __syncthreads();
+        }
+        if (wid == 0) {
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[ENC_SLAB_W1 + (tap * 16 + 4 * q + r) * 16 + p] = acc[tap][r];
+        }
+    }
+    if (a.trace && tid == 0) a.trace[blockIdx.x * 16 + 14] = wall_clock64();
+}
+
+// the slabs of all workgroups added in workgroup order -> the twelve gradient tensors (layer 3's five taps that never
+// touch a 2x2 frame get their exact zeros)
+struct EncFoldArgs {
+    const float* slabs;
+    int nslab;
+    float *dw[3], *db[3], *dgamma[3], *dbeta[3];
+};
+// 256 threads = 4 waves x 64 consecutive elements (coalesced 256-byte rows of a slab); wave w adds the slabs
+// [w * nslab / 4, (w + 1) * nslab / 4) in order, eight loads in flight, then the four partial sums meet in LDS in wave order
+__global__ void __launch_bounds__(256) karel_encoder_bwd_fold_kernel(EncFoldArgs a) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + lane;
+    if (blockIdx.x * 64 >= ENC_SLAB) {                           // (ENC_SLAB is a multiple of 64: whole blocks of zeros)
+        const int i = e - ENC_SLAB;
+        if (wv == 0 && i < 5 * 1536) {
+            const int t5 = i / 1536;
+            a.dw[2][(t5 == 0 ? 2 : t5 + 4) * 1536 + (i - t5 * 1536)] = 0.f;      // taps 2, 5, 6, 7, 8
+        }
+        return;
+    }
+    const int n0 = (int)((long)a.nslab * wv / 4), n1 = (int)((long)a.nslab * (wv + 1) / 4);
+    const float* sp = a.slabs + e;
+    float sum = 0.f;
+    int n = n0;
+    for (; n + 8 <= n1; n += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sp[(size_t)(n + u) * ENC_SLAB];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; n < n1; ++n) sum += sp[(size_t)n * ENC_SLAB];
+    part[wv][lane] = sum;
+    __syncthreads();
+    if (wv != 0) return;
+    sum = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+    if (e < ENC_SLAB_W2) a.dw[0][e] = sum;
+    else if (e < ENC_SLAB_W3) a.dw[1][e - ENC_SLAB_W2] = sum;
+    else if (e < ENC_SLAB_DB) {
+        const int i = e - ENC_SLAB_W3, t4 = i / 1536;
+        a.dw[2][((t4 >> 1) * 3 + (t4 & 1)) * 1536 + (i - t4 * 1536)] = sum;
+    } else if (e < ENC_SLAB_GB) {
+        const int i = e - ENC_SLAB_DB;
+        if (i < 16) a.db[0][i] = sum;
+        else if (i < 48) a.db[1][i - 16] = sum;
+        else a.db[2][i - 48] = sum;
+    } else {
+        const int i = e - ENC_SLAB_GB;
+        if (i < 16) a.dgamma[0][i] = sum;
+        else if (i < 32) a.dbeta[0][i - 16] = sum;
+        else if (i < 64) a.dgamma[1][i - 32] = sum;
+        else if (i < 96) a.dbeta[1][i - 64] = sum;
+        else if (i < 144) a.dgamma[2][i - 96] = sum;
+        else if (i < 192) a.dbeta[2][i - 144] = sum;
+    }
+}
+
+static bool enc_bwd_plan(int B, int G, int T, int& S, int& nb) {
+    if (!enc_plan(B, G, T, S, nb)) return false;
+    return (size_t)enc_bwd_lds(nb * T).total * sizeof(float) <= 160 * 1024;
+}
+
 }   // namespace
+
+extern "C" size_t d2p_karel_encoder_bwd_ws_bytes(int B, int G, int T) {
+    int S = 0, nb = 0;
+    if (!enc_bwd_plan(B, G, T, S, nb)) return 0;
+    return (size_t)3 * G * S * 48 * 2 * sizeof(double) + (size_t)G * S * ENC_SLAB * sizeof(float);
+}
+
+// (declared in include/d2p.h)
+extern "C" int d2p_karel_encoder_bwd(int B, int G, int T, const void* x, int x_is_u8, const float* dfeat_tm,
+                                     const float* const* w, const float* const* gamma, const float* const* beta,
+                                     const float* const* a, const float* const* mean, const float* const* rstd,
+                                     float* const* dw, float* const* db, float* const* dgamma, float* const* dbeta, void* ws,
+                                     size_t ws_bytes, d2p_stream_t stream) {
+    int S = 0, nb = 0;
+    D2P_REQUIRE(enc_bwd_plan(B, G, T, S, nb), D2P_EINVAL,
+                "karel encoder backward: B=%d G=%d T=%d does not fit one launch", B, G, T);
+    D2P_REQUIRE(x && dfeat_tm && w && gamma && beta && a && mean && rstd && dw && db && dgamma && dbeta, D2P_EINVAL,
+                "karel encoder backward: null pointer");
+    D2P_REQUIRE(ws && ws_bytes >= d2p_karel_encoder_bwd_ws_bytes(B, G, T), D2P_EWS, "karel encoder backward: workspace too small");
+    EncBwdArgs e;
+    EncFoldArgs f;
+    e.x = x; e.dfeat_tm = dfeat_tm;
+    for (int l = 0; l < 3; ++l) {
+        D2P_REQUIRE(w[l] && gamma[l] && beta[l] && a[l] && mean[l] && rstd[l] && dw[l] && db[l] && dgamma[l] && dbeta[l],
+                    D2P_EINVAL, "karel encoder backward: null pointer (layer %d)", l + 1);
+        D2P_REQUIRE(((uintptr_t)a[l] & 15) == 0, D2P_EALIGN, "karel encoder backward: 16-byte alignment (layer %d)", l + 1);
+        e.w[l] = w[l]; e.gamma[l] = gamma[l]; e.beta[l] = beta[l]; e.a[l] = a[l]; e.mean[l] = mean[l]; e.rstd[l] = rstd[l];
+        f.dw[l] = dw[l]; f.db[l] = db[l]; f.dgamma[l] = dgamma[l]; f.dbeta[l] = dbeta[l];
+    }
+    D2P_REQUIRE((((uintptr_t)x | (uintptr_t)dfeat_tm | (uintptr_t)ws) & 15) == 0, D2P_EALIGN,
+                "karel encoder backward: 16-byte alignment");
+    e.part = (double*)ws;
+    e.slabs = (float*)((char*)ws + (size_t)3 * G * S * 48 * 2 * sizeof(double));
+    static unsigned long long* counters = nullptr;
+    if (!counters) D2P_HIP(hipGetSymbolAddress((void**)&counters, HIP_SYMBOL(g_enc_bwd_counters)));
+    e.counters = counters + (size_t)S * 3 * ENC_MAXG;
+    e.err = d2p_persist_err_ptr();
+    e.B = B; e.G = G; e.T = T; e.S = S; e.nb = nb;
+    e.trace = g_enc_trace;
+    f.slabs = e.slabs; f.nslab = G * S;
+    const size_t lds = (size_t)enc_bwd_lds(nb * T).total * sizeof(float);
+    hipStream_t st = as_stream(stream);
+    // conv flops as the separate launches count them: three weight gradients, two input gradients
+    const double nf = (double)B * G * T;
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * nf * (16 * 144 * 16 + 2 * 4 * 144 * 32 + 2 * 1 * 288 * 48));
+    static bool attr = false;
+    if (!attr) {
+        D2P_HIP(hipFuncSetAttribute((const void*)karel_encoder_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        D2P_HIP(hipFuncSetAttribute((const void*)karel_encoder_bwd_kernel<uint8_t>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr = true;
+    }
+    if (x_is_u8) hipLaunchKernelGGL(karel_encoder_bwd_kernel<uint8_t>, dim3(G * S), dim3(256), lds, st, e);
+    else hipLaunchKernelGGL(karel_encoder_bwd_kernel<float>, dim3(G * S), dim3(256), lds, st, e);
+    D2P_LAUNCH_CHECK("karel_encoder_bwd");
+    static_assert(ENC_SLAB % 64 == 0, "the combine launch works on whole 64-element blocks");
+    hipLaunchKernelGGL(karel_encoder_bwd_fold_kernel, dim3((ENC_SLAB + 5 * 1536) / 64), dim3(256), 0, st, f);
+    D2P_LAUNCH_CHECK("karel_encoder_bwd_fold");
+    return D2P_OK;
+}
 
 void d2p_conv_frames_tune(int tpw) { g_frames_tpw = tpw > 0 ? tpw : 0; }
 void d2p_conv_frames_wgrad_cap(int cap) { g_frames_wgrad_cap = cap; }

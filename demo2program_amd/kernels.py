@@ -295,6 +295,23 @@ def karel_encoder_fwd(x, B, G, T, w, bias, gamma, beta, a, y, feats_tm, mean, rs
                                ws.numel() * ws.element_size(), current_stream())
 
 
+def karel_encoder_bwd_ok(B, G, T):
+    """whether the one-launch State_Encoder backward (d2p_karel_encoder_bwd) takes this batch geometry"""
+    return _load_lib().d2p_karel_encoder_bwd_ws_bytes(B, G, T) > 0
+
+
+def karel_encoder_bwd(x, dfeat_tm, B, G, T, w, gamma, beta, a, mean, rstd, dw, db, dgamma, dbeta, ws):
+    """the backward of karel_encoder_fwd from dfeat_tm [T, B*G, 48]: dw, db, dgamma, dbeta (three tensors each) are
+    written; ws: a uint8 buffer of d2p_karel_encoder_bwd_ws_bytes(B, G, T)."""
+    _require_gpu(x, dfeat_tm, ws)
+    import ctypes
+    arr = lambda ts: (ctypes.c_void_p * len(ts))(*[ptr(t) for t in ts])        # noqa: E731
+    assert dfeat_tm.is_contiguous() and all(t.is_contiguous() for t in list(dw) + list(db) + list(dgamma) + list(dbeta))
+    call.d2p_karel_encoder_bwd(B, G, T, ptr(x), 1 if x.dtype == torch.uint8 else 0, ptr(dfeat_tm), arr(w), arr(gamma),
+                               arr(beta), arr(a), arr(mean), arr(rstd), arr(dw), arr(db), arr(dgamma), arr(dbeta), ptr(ws),
+                               ws.numel() * ws.element_size(), current_stream())
+
+
 def conv_wgrad(x, dy, dw):
     _require_gpu(x, dy, dw)
     N, H, W, Cin = x.shape

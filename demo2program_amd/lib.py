@@ -56,6 +56,8 @@ SIGNATURES = {
     'd2p_karel_encoder_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'd2p_karel_encoder_set_trace': (c_int, [P]),
     'd2p_karel_encoder_fwd': (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
+    'd2p_karel_encoder_bwd_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'd2p_karel_encoder_bwd': (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
     'd2p_bn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'd2p_bn_batched_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),
     'd2p_per_affine_rows': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, S]),

@@ -146,6 +146,7 @@ class Model(object):
         self._ctx = None
         self._conv = conv_shapes(config)
         self._fused_enc_ok = {}
+        self._fused_enc_bwd_ok = {}
         self.feature_dim = feature_dim(config)
         # non-trainable BN moving statistics (updated inline, once per reference call): views of ONE buffer
         # (`moving_flat`), so that the trainer's step guard snapshots / restores all of them with a single device copy
@@ -799,7 +800,27 @@ class Model(object):
                     K.bn_update_moving(m_, v_, *self.moving[n])
         xin = [x, y[0].view(NF, 4, 4, 16), y[1].view(NF, 2, 2, 32)]
         ctx['conv'] = [(xin[l], a[l], mean[l], rstd[l], None) for l in range(3)]
+        ctx['enc_fused'] = True            # backward may take the one-launch form too (_encoder_bwd_fused)
         return feats_tm
+
+    def _encoder_bwd_fused(self, ctx, d_feats_tm):
+        """the State_Encoder's backward pass as one launch + one combine launch (d2p_karel_encoder_bwd), from the
+        time-major feature gradient; False when this batch geometry does not fit (the separate launches run)"""
+        c, p, g = self.config, self.params.p, self.params.g
+        B, k, T = c.batch_size, c.k, c.max_demo_len
+        key = (B, k, T)
+        if key not in self._fused_enc_bwd_ok:
+            self._fused_enc_bwd_ok[key] = K.karel_encoder_bwd_ok(B, k, T)
+        if not self._fused_enc_bwd_ok[key] or not K.lstm_is_persistent():
+            return False
+        names = ['conv%d' % l for l in (1, 2, 3)]
+        ws = self._buf('enc/ws_bwd', (K._load_lib().d2p_karel_encoder_bwd_ws_bytes(B, k, T),), torch.uint8)
+        conv = ctx['conv']
+        K.karel_encoder_bwd(conv[0][0], d_feats_tm, B, k, T, [p[n + '/W'] for n in names], [p[n + '/gamma'] for n in names],
+                            [p[n + '/beta'] for n in names], [cv[1] for cv in conv], [cv[2] for cv in conv],
+                            [cv[3] for cv in conv], [g[n + '/W'] for n in names], [g[n + '/b'] for n in names],
+                            [g[n + '/gamma'] for n in names], [g[n + '/beta'] for n in names], ws)
+        return True
 
     def _bn_fwd(self, name, x2d, gamma, beta, G, inner, y=None):
         R, C = x2d.shape
@@ -1271,9 +1292,11 @@ class Model(object):
         side.wait_stream(main)
         with torch.cuda.stream(side):
             self._lstm_bwd_weights(ctx['e1'], dz1)
-        d_feats = K.transpose_rt(d_feats_tm.view(T, M, F), T, M, F, out=self._buf('d_feats', (M, T, F)))
-
         # ---- State_Encoder backward
+        if ctx.get('enc_fused') and not self._abl('conv_bwd') and self._encoder_bwd_fused(ctx, d_feats_tm):
+            main.wait_stream(side)
+            return self.params.grad
+        d_feats = K.transpose_rt(d_feats_tm.view(T, M, F), T, M, F, out=self._buf('d_feats', (M, T, F)))
         dy = d_feats
         dy_sums = None                 # (stats, S): batch-norm-backward partial sums the producer of dy left behind
         for l in range(len(self._conv), 0, -1):

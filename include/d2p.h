@@ -207,6 +207,23 @@ int d2p_karel_encoder_fwd(int B, int G, int T, const void* x, int x_is_u8, const
                           const float* const* bias, const float* const* gamma, const float* const* beta,
                           float* const* a, float* const* y, float* feats_tm, float* const* mean,
                           float* const* rstd, float* const* var, void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* The Karel State_Encoder's BACKWARD pass in one launch + one combine launch (round 5; the reverse of
+ * models/model_full.py:216-231 / models/ops.py:14-33 as tf.gradients runs it: per layer batch-norm backward with the
+ * statistics of one demonstration index, lrelu', the conv's weight / bias gradient, and the input gradient of layers 3
+ * and 2).  dfeat_tm [T, B*G, 48] is the gradient of d2p_karel_encoder_fwd's feats_tm (time-major: no transpose pass);
+ * x, w, gamma, beta, a, mean, rstd are that launch's inputs and outputs (a = the activations before normalisation);
+ * dw[l] [3,3,Cin,Cout], db / dgamma / dbeta [l] [Cout] receive the gradients (written, not accumulated).  All array
+ * arguments are HOST arrays of three device pointers.  Same workgroup decomposition and co-residency requirement as
+ * the forward launch (the S workgroups of an index meet once per layer for the batch-norm sums; 0x7d in the status
+ * word of d2p_lstm_persist_error when one waits too long); every gradient is a sum over the workgroups' slabs in ws,
+ * added in workgroup order by the second launch (deterministic).  D2P_EINVAL for geometries it does not take
+ * (d2p_karel_encoder_bwd_ws_bytes == 0): callers run the separate launches. */
+size_t d2p_karel_encoder_bwd_ws_bytes(int B, int G, int T);   /* 0: geometry not supported */
+int d2p_karel_encoder_bwd(int B, int G, int T, const void* x, int x_is_u8, const float* dfeat_tm,
+                          const float* const* w, const float* const* gamma, const float* const* beta,
+                          const float* const* a, const float* const* mean, const float* const* rstd,
+                          float* const* dw, float* const* db, float* const* dgamma, float* const* dbeta, void* ws,
+                          size_t ws_bytes, d2p_stream_t stream);
 /* Batch norm folded into the conv launches (round 5; the ViZDoom-size layers of models/model_full.py:216-231, whose
  * conv -> lrelu -> batch-norm chain of models/ops.py:14-33 otherwise writes and re-reads each activation three times).
  * Frames are ordered (program, demonstration index, step): the statistics of frame n belong to index g = (n / seq) % G.

@@ -1551,6 +1551,99 @@ def test_karel_encoder_one_launch_matches_the_separate_launches(K, B, G, T, u8):
         feats_tm.fill_(nan)
 
 
+@pytest.mark.parametrize('B,G,T,u8', [(32, 10, 20, True), (32, 10, 20, False), (5, 3, 8, True), (1, 1, 4, False),
+                                     (40, 10, 20, True), (7, 32, 12, True), (64, 10, 8, False)])
+def test_karel_encoder_backward_one_launch_matches_the_separate_launches(K, B, G, T, u8):
+    """d2p_karel_encoder_bwd against the chain it replaces (transpose, then per layer d2p_bn_group_bwd, the conv's weight
+    gradient and input gradient: models/model_full.py:216-231 / models/ops.py:14-33 under tf.gradients), on the
+    activations and statistics the one-launch forward wrote; and against torch autograd in fp64 on the host for the
+    full-size case.  Two runs bit-identical (every sum has a fixed order)."""
+    if not (K.karel_encoder_ok(B, G, T) and K.karel_encoder_bwd_ok(B, G, T)):
+        pytest.skip('geometry not taken by the one-launch kernels on this device')
+    g = torch.Generator().manual_seed(B * 1000 + G * 10 + T + 7)
+    NF = B * G * T
+    if u8:
+        x = (torch.rand(NF, 8, 8, 16, generator=g) < 0.15).to(torch.uint8).cuda()
+    else:
+        x = torch.randn(NF, 8, 8, 16, generator=g).cuda()
+    prm = dict(w=[], b=[], gamma=[], beta=[])
+    for cin, cout in ((16, 16), (16, 32), (32, 48)):
+        prm['w'].append((torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5).cuda())
+        prm['b'].append((torch.randn(cout, generator=g) * 0.1).cuda())
+        prm['gamma'].append((1 + 0.2 * torch.randn(cout, generator=g)).cuda())
+        prm['beta'].append((0.1 * torch.randn(cout, generator=g)).cuda())
+    a = [torch.empty(NF, 4, 4, 16, device='cuda'), torch.empty(NF, 2, 2, 32, device='cuda'), torch.empty(NF, 1, 1, 48, device='cuda')]
+    y = [torch.empty(NF * 16, 16, device='cuda'), torch.empty(NF * 4, 32, device='cuda')]
+    stat = lambda: [torch.empty(G, c, device='cuda') for c in (16, 32, 48)]       # noqa: E731
+    mean, rstd, var = stat(), stat(), stat()
+    feats_tm = torch.empty(T, B * G, 48, device='cuda')
+    ws = torch.empty(K._load_lib().d2p_karel_encoder_ws_bytes(B, G, T), dtype=torch.uint8, device='cuda')
+    K.karel_encoder_fwd(x, B, G, T, prm['w'], prm['b'], prm['gamma'], prm['beta'], a, y, feats_tm, mean, rstd, var, ws)
+    dfeat_tm = torch.randn(T, B * G, 48, generator=g).cuda()
+    dfeat_tm[T - 1, ::3] = 0                                  # (rows past a demonstration's length carry no gradient)
+
+    # the separate launches
+    ref = dict(dw=[None] * 3, db=[None] * 3, dgamma=[None] * 3, dbeta=[None] * 3)
+    dy = dfeat_tm.transpose(0, 1).contiguous().view(NF, 48)
+    xin = [x, y[0].view(NF, 4, 4, 16), y[1].view(NF, 2, 2, 32)]
+    for l, (cin, cout, hw, hin) in reversed(list(enumerate(((16, 16, 4, 8), (16, 32, 2, 4), (32, 48, 1, 2))))):
+        ref['dgamma'][l], ref['dbeta'][l], ref['db'][l] = (torch.empty(cout, device='cuda') for _ in range(3))
+        da = K.bn_bwd(a[l].view(NF * hw * hw, cout), dy.view(NF * hw * hw, cout), prm['gamma'][l], mean[l], rstd[l], G,
+                      T * hw * hw, True, ref['dgamma'][l], ref['dbeta'][l], dbias=ref['db'][l])
+        ref['dw'][l] = K.conv_wgrad(xin[l], da.view(NF, hw, hw, cout), torch.empty(3, 3, cin, cout, device='cuda'))
+        if l > 0:
+            dy = K.conv_dgrad(da.view(NF, hw, hw, cout), prm['w'][l], (NF, hin, hin, cin))
+
+    nan = float('nan')
+    out = {k: [torch.full_like(t, nan) for t in ref[k]] for k in ref}
+    wsb = torch.empty(K._load_lib().d2p_karel_encoder_bwd_ws_bytes(B, G, T), dtype=torch.uint8, device='cuda')
+    first = None
+    for rep in range(3):
+        K.karel_encoder_bwd(x, dfeat_tm, B, G, T, prm['w'], prm['gamma'], prm['beta'], a, mean, rstd, out['dw'], out['db'],
+                            out['dgamma'], out['dbeta'], wsb)
+        torch.cuda.synchronize()
+        assert K.lstm_persist_error() == 0
+        for k in ref:
+            for l in range(3):
+                scale = float(ref[k][l].abs().max()) + 1e-6
+                err = float((out[k][l] - ref[k][l]).abs().max())
+                assert err <= 2e-5 * scale + 1e-6, (k, l, err, scale)
+        snap = [t.clone() for k in sorted(out) for t in out[k]]
+        if first is None:
+            first = snap
+        else:
+            assert all(torch.equal(u, v) for u, v in zip(first, snap))
+        for k in out:
+            for t in out[k]:
+                t.fill_(nan)
+
+    if (B, G, T) == (32, 10, 20):
+        # second opinion: torch autograd in fp64 on the host, through conv -> +bias -> lrelu -> batch norm per index
+        import torch.nn.functional as F
+        P = {k: [t.double().cpu().requires_grad_(True) for t in prm[k]] for k in prm}
+        cur = x.double().cpu().permute(0, 3, 1, 2)
+        for l, hin in enumerate((8, 4, 2)):
+            wt = P['w'][l].permute(3, 2, 0, 1)
+            cur = F.conv2d(F.pad(cur, (0, 1, 0, 1)), wt, P['b'][l], stride=2)
+            cur = 0.6 * cur + 0.4 * cur.abs()
+            c, hw = cur.shape[1], cur.shape[2]
+            v = cur.view(B, G, T, c, hw, hw)
+            mu = v.mean(dim=(0, 2, 4, 5), keepdim=True)
+            va = v.var(dim=(0, 2, 4, 5), unbiased=False, keepdim=True)
+            v = (v - mu) / torch.sqrt(va + 1e-3) * P['gamma'][l].view(1, 1, 1, c, 1, 1) + P['beta'][l].view(1, 1, 1, c, 1, 1)
+            cur = v.view(NF, c, hw, hw)
+        feats = cur.view(B * G, T, 48).transpose(0, 1)
+        feats.backward(dfeat_tm.double().cpu())
+        K.karel_encoder_bwd(x, dfeat_tm, B, G, T, prm['w'], prm['gamma'], prm['beta'], a, mean, rstd, out['dw'], out['db'],
+                            out['dgamma'], out['dbeta'], wsb)
+        torch.cuda.synchronize()
+        for k, pk in (('dw', 'w'), ('db', 'b'), ('dgamma', 'gamma'), ('dbeta', 'beta')):
+            for l in range(3):
+                r = P[pk][l].grad
+                err = float((out[k][l].double().cpu() - r).abs().max())
+                assert err <= 2e-4 * float(r.abs().max()) + 1e-6, (k, l, err)
+
+
 @pytest.mark.parametrize('n,rows,E', [(6400, 9, 2048), (1568, 53, 2048), (6400, 32, 512), (1000, 31, 68), (257, 3, 64)])
 def test_rows_summed_by_key_equal_index_add(K, n, rows, E):
     """d2p_embedding_scatter_add_oob0 on rows_by_key_kernel (n >= 256): out[v] = sum of the rows whose id is v, ids

@@ -73,6 +73,48 @@ def main():
             d = (t[:, i] - (t[:, i - 1] if i else t0)) / 100.0
             print('   %-26s +%6.2f / %6.2f   (at %6.2f / %6.2f)' % (names[i], d.mean(), d.max(), ((t[:, i] - t0) / 100).mean(),
                                                                   ((t[:, i] - t0) / 100).max()))
+    # ---- backward: the chain of the separate launches against d2p_karel_encoder_bwd (+ its combine launch)
+    fused()
+    dfeat_tm = torch.randn(T, B * G, 48, generator=g).cuda()
+    dfeat = torch.empty(B * G, T, 48, device='cuda')
+    dw = [torch.empty_like(t) for t in w]
+    db, dgam, dbet = ([torch.empty(c, device='cuda') for c in (16, 32, 48)] for _ in range(3))
+    da = [torch.empty(NF * hw * hw, c, device='cuda') for c, hw in ((16, 4), (32, 2), (48, 1))]
+    dx = [None, torch.empty(NF, 4, 4, 16, device='cuda'), torch.empty(NF, 2, 2, 32, device='cuda')]
+    xin = [x, y[0].view(NF, 4, 4, 16), y[1].view(NF, 2, 2, 32)]
+
+    def chain_bwd():
+        dy = K.transpose_rt(dfeat_tm, T, B * G, 48, out=dfeat).view(NF, 48)
+        for l, (cin, cout, hw, hin) in reversed(list(enumerate(((16, 16, 4, 8), (16, 32, 2, 4), (32, 48, 1, 2))))):
+            K.bn_bwd(a[l].view(NF * hw * hw, cout), dy.view(NF * hw * hw, cout), gam[l], mean[l], rstd[l], G, T * hw * hw, True,
+                     dgam[l], dbet[l], dx=da[l], dbias=db[l])
+            K.conv_wgrad(xin[l], da[l].view(NF, hw, hw, cout), dw[l])
+            if l > 0:
+                dy = K.conv_dgrad(da[l].view(NF, hw, hw, cout), w[l], (NF, hin, hin, cin), dx=dx[l])
+    print('backward, separate launches: %.1f us' % timed(chain_bwd))
+    if K.karel_encoder_bwd_ok(B, G, T):
+        wsb = torch.empty(K._load_lib().d2p_karel_encoder_bwd_ws_bytes(B, G, T), dtype=torch.uint8, device='cuda')
+
+        def fused_bwd():
+            K.karel_encoder_bwd(x, dfeat_tm, B, G, T, w, gam, bet, a, mean, rstd, dw, db, dgam, dbet, wsb)
+        print('backward, one launch + combine: %.1f us' % timed(fused_bwd))
+        tr = torch.zeros(256, 16, dtype=torch.int64, device='cuda')
+        from demo2program_amd.lib import call
+        call.d2p_karel_encoder_set_trace(tr.data_ptr())
+        fused_bwd()
+        torch.cuda.synchronize()
+        call.d2p_karel_encoder_set_trace(None)
+        t = tr.cpu().double()
+        t = t[t[:, 0] > 0]
+        t0 = t[:, 0].min()
+        names = ['start', 'loads -> LDS', 'sums 3', 'exchange 3', 'apply 3', 'dgrad 3 + wgrad 3', 'sums 2 + zero fill',
+                 'exchange 2', 'apply 2', 'dgrad 2 + wgrad 2', 'sums 1', 'exchange 1', 'apply 1', 'wgrad 1 products',
+                 'tree + slab']
+        print('%d workgroups; stamps in us from the first workgroup\'s start (mean / max over workgroups):' % t.shape[0])
+        for i in range(15):
+            d = (t[:, i] - (t[:, i - 1] if i else t0)) / 100.0
+            print('   %-26s +%6.2f / %6.2f   (at %6.2f / %6.2f)' % (names[i], d.mean(), d.max(), ((t[:, i] - t0) / 100).mean(),
+                                                                  ((t[:, i] - t0) / 100).max()))
     print('error word: 0x%x' % K.lstm_persist_error())
 
 
