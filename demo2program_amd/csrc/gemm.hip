@@ -34,14 +34,16 @@ template <int KW, bool GATHER>
 __global__ void __launch_bounds__(64 * KW)
 gemm_tn_direct_kernel(const float* __restrict__ A, int lda, const int* __restrict__ rowsA, const float* __restrict__ B,
                       int ldb, const int* __restrict__ rowsB, float* __restrict__ C, long ldc, int M, int N, int K, int kps,
-                      int accumulate) {
+                      int accumulate, float* __restrict__ partial, unsigned* __restrict__ tickets) {
     extern __shared__ __attribute__((aligned(16))) float tnd_red[];      // [KW / 2][64 values][64 lanes]
     const int lane = threadIdx.x & 63, c = lane & 15, kq = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nbn = (N + 63) / 64;
     const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
     const int m0 = bm * 64, n0 = bn * 64;
-    const int kbeg = w * kps;
+    // (round 5) gridDim.y workgroups share an output tile and split K between them (outputs with fewer than 128 tiles:
+    // 48 x 2048, 512 x 512): wave w of slice blockIdx.y walks rows [(y KW + w) kps, + kps)
+    const int kbeg = ((int)blockIdx.y * KW + w) * kps;
     const int kend = kbeg + kps < K ? kbeg + kps : K;
     const int ng = kend > kbeg ? (kend - kbeg) >> 2 : 0;                  // groups of four rows; a multiple of TND_D
     // columns past the matrix: loaded from its last four (never stored)
@@ -136,6 +138,44 @@ gemm_tn_direct_kernel(const float* __restrict__ A, int lda, const int* __restric
         }
         __syncthreads();
     }
+    if (gridDim.y > 1) {
+        // K split between workgroups: each leaves its 64 x 64 partial tile ([value][lane], write-through), takes a ticket of
+        // the tile, and the LAST one adds all slices in slice order (sc1 loads; its own included: the same order whoever is
+        // last) -- wave w the sixteen-byte pieces (i = w / 2, r in {2 (w % 2), + 1}) -- and stores C
+        const unsigned tile_floats = 4096u, nt = gridDim.x;
+        const __amdgpu_buffer_rsrc_t pres = d2p_wt_rsrc(partial, gridDim.y * nt * tile_floats * 4u);
+        if (w == 0) {
+            const int base = (int)((blockIdx.y * nt + blockIdx.x) * tile_floats) + lane;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d2p_st_wt(pres, base + ((i * 4 + j) * 4 + r) * 64, acc[i][j][r]);
+        }
+        if (!d2p_last_slice(tickets + blockIdx.x, gridDim.y, reinterpret_cast<int*>(tnd_red))) return;
+        const int col = n0 + 4 * c;
+        if (KW == 8) {
+            const int i = w >> 1;
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * (w & 1) + rr;
+                tnd_f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                for (unsigned y = 0; y < gridDim.y; ++y) {
+                    const int base = (int)((y * nt + blockIdx.x) * tile_floats) + lane;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] += d2p_ld_wt(pres, base + ((i * 4 + j) * 4 + r) * 64);
+                }
+                const int row = m0 + 16 * kq + 4 * r + i;
+                if (row < M && col < N) {
+                    float* dst = C + (long)row * ldc + col;
+                    if (accumulate) o += *reinterpret_cast<const tnd_f32x4*>(dst);
+                    *reinterpret_cast<tnd_f32x4*>(dst) = o;
+                }
+            }
+        }
+        return;
+    }
     if (w != 0) return;
     // lane (c, kq) holds, for MFMA (i, j) and register r: output row m0 + 4 (4 kq + r) + i, column n0 + 4 c + j
     const int col = n0 + 4 * c;
@@ -157,15 +197,37 @@ gemm_tn_direct_kernel(const float* __restrict__ A, int lda, const int* __restric
 static int g_gemm_tn_direct = 1;          // d2p_gemm_set_option bit 6 switches it off (A/B)
 static int g_rows_by_key = 1;             // d2p_gemm_set_option bit 7 switches it off (A/B, tests)
 
-// true: launched.  Shapes it takes: whole 16-byte pieces everywhere, K in whole ring rounds, enough tiles to fill the chip
+// K slices between workgroups for outputs of fewer than 128 tiles (1: none): enough slices to fill the chip, at least 512
+// rows of K per workgroup
+static int tn_direct_slices(long tiles, int K) {
+    if (tiles >= 128) return 1;
+    int ks = (int)(256 / tiles);
+    while (ks > 1 && K / ks < 512) --ks;
+    return ks > 16 ? 16 : ks;
+}
+static size_t tn_direct_ws_bytes(int M, int N, int K) {
+    const long tiles = (long)ceil_div(M, 64) * ceil_div(N, 64);
+    const int ks = tn_direct_slices(tiles, K);
+    return ks > 1 ? (size_t)ks * tiles * 4096 * sizeof(float) : 0;
+}
+// true: launched.  Shapes it takes: whole 16-byte pieces everywhere, K in whole ring rounds, enough tiles (x K slices) to
+// fill the chip
 template <int KW, bool GATHER>
 static bool tn_direct_launch_kw(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
-                                const int* rowsB, float* C, long ldc, int accumulate, hipStream_t st) {
-    if (!g_gemm_tn_direct || M < 4 || N < 4 || (M | N) % 4 != 0 || K % (4 * TND_D) != 0 || K < 1024) return false;
+                                const int* rowsB, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!g_gemm_tn_direct || M < 4 || N < 4 || (M | N) % 4 != 0 || K % (4 * TND_D) != 0 || K < 768) return false;
     if (!vec_ok(A, lda) || !vec_ok(B, ldb) || !vec_ok(C, ldc)) return false;
     const long tiles = (long)ceil_div(M, 64) * ceil_div(N, 64);
-    if (tiles < 128 || tiles > 65535 || lda > 0x7fffffffL || ldb > 0x7fffffffL) return false;
-    const int kps = (ceil_div(K, KW) + 4 * TND_D - 1) / (4 * TND_D) * (4 * TND_D);
+    if (tiles < 16 || tiles > 65535 || lda > 0x7fffffffL || ldb > 0x7fffffffL) return false;
+    const int ks = tn_direct_slices(tiles, K);
+    if (tiles * ks < 128) return false;
+    unsigned* tickets = nullptr;
+    if (ks > 1) {
+        if (!ws || ws_bytes < tn_direct_ws_bytes(M, N, K) || ((uintptr_t)ws & 15)) return false;
+        tickets = d2p_gemm_take_tickets((unsigned)tiles);
+        if (!tickets) return false;
+    }
+    const int kps = (ceil_div(K, KW * ks) + 4 * TND_D - 1) / (4 * TND_D) * (4 * TND_D);
     // LDS: the tree's (KW / 2) x 16 KB -- and never less than 100 KB: with 64 KB these eight-wave workgroups become
     // resident BESIDE a persistent recurrence of the other stream (64.5 / 81 KB of the CU's 160) and slow it down by
     // more than they gain (two-stream profile: backward recurrence 343 us on average instead of 235, the step
@@ -183,15 +245,15 @@ static bool tn_direct_launch_kw(int M, int N, int K, const float* A, long lda, c
         attr = true;
     }
     D2pProfScope prof(st, D2P_PROF_GEMM, 2.0 * M * N * K);
-    hipLaunchKernelGGL((gemm_tn_direct_kernel<KW, GATHER>), dim3((unsigned)tiles), dim3(64 * KW), lds, st, A, (int)lda, rowsA, B,
-                       (int)ldb, rowsB, C, ldc, M, N, K, kps, accumulate);
+    hipLaunchKernelGGL((gemm_tn_direct_kernel<KW, GATHER>), dim3((unsigned)tiles, (unsigned)ks), dim3(64 * KW), lds, st, A, (int)lda,
+                       rowsA, B, (int)ldb, rowsB, C, ldc, M, N, K, kps, accumulate, (float*)ws, tickets);
     return true;
 }
 
 template <bool GATHER>
 static bool tn_direct_launch(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
-                             const int* rowsB, float* C, long ldc, int accumulate, hipStream_t st) {
-    return tn_direct_launch_kw<8, GATHER>(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate, st);
+                             const int* rowsB, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st) {
+    return tn_direct_launch_kw<8, GATHER>(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate, ws, ws_bytes, st);
 }
 
 extern "C" int d2p_gemm_set_option(int bk32) {
@@ -214,7 +276,8 @@ extern "C" int d2p_gemm_force_plan(int tile, int splits) {
 
 extern "C" size_t d2p_gemm_ws_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    return d2p_plan_ws_bytes(M, N, K);
+    const size_t a = d2p_plan_ws_bytes(M, N, K), b = tn_direct_ws_bytes(M, N, K);     // (whichever kernel takes the product)
+    return a > b ? a : b;
 }
 
 extern "C" int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, const float* B,
@@ -296,7 +359,7 @@ extern "C" int d2p_gemm_f32_tn(int M, int N, int K, const float* A, long lda, co
     int rc = check_gemm_args(M, N, K, A, B, C, act);
     if (rc) return rc;
     if (!bias && act == 0 && M > 0 && N > 0 &&
-        tn_direct_launch<false>(M, N, K, A, lda, nullptr, B, ldb, nullptr, C, ldc, accumulate, as_stream(stream))) {
+        tn_direct_launch<false>(M, N, K, A, lda, nullptr, B, ldb, nullptr, C, ldc, accumulate, ws, ws_bytes, as_stream(stream))) {
         D2P_LAUNCH_CHECK("gemm_tn_direct");
         return D2P_OK;
     }
@@ -318,7 +381,7 @@ extern "C" int d2p_gemm_f32_tn_rows(int M, int N, int K, const float* A, long ld
     if (rc) return rc;
     if (M == 0 || N == 0) return D2P_OK;
     D2P_REQUIRE(K == 0 || (rowsA && rowsB), D2P_EINVAL, "gemm_tn_rows: null row list");
-    if (tn_direct_launch<true>(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate, as_stream(stream))) {
+    if (tn_direct_launch<true>(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate, ws, ws_bytes, as_stream(stream))) {
         D2P_LAUNCH_CHECK("gemm_tn_direct");
         return D2P_OK;
     }

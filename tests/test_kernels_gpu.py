@@ -1259,7 +1259,7 @@ def test_lstm_backward_over_rows_sorted_by_length(K, specs):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('M,N,R,Kn', [(512, 2048, 6400, 4480), (48, 2048, 6400, 4512), (512, 2048, 1600, 864),
-                                     (60, 256, 700, 333), (512, 512, 300, 64), (20, 36, 90, 50)])
+                                     (512, 512, 3296, 3200), (60, 256, 700, 333), (512, 512, 300, 64), (20, 36, 90, 50)])
 def test_gemm_tn_over_lists_of_k_rows(K, M, N, R, Kn):
     """d2p_gemm_f32_tn_rows: C = A[rowsA]^T B[rowsB] (+ C) with both operands read through lists of K row indices
     (weight gradients over the rows inside their sequences; rowsA = rowsB - shift for dWh).  Against fp64, incl. a
