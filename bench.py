@@ -273,7 +273,17 @@ def north_star_targets(config, table):
                                'ms_per_step': conv[0]['ms_per_step'],
                                'launches_per_step': conv[0]['launches_per_step'],
                                'binding_roofline': conv_binding_roofline(config, conv[0]['ms_per_step'],
-                                                                         conv[0]['launches_per_step'])}
+                                                                         conv[0]['launches_per_step']),
+                               'note': 'launches_per_step counts the instrumented entry points (Karel: d2p_karel_encoder_fwd and '
+                                       'd2p_karel_encoder_bwd = one forward launch, one backward launch + its combine launch). '
+                                       'north_star asks for 0.30 of the fp32 MFMA peak: 46 us for the 2.18 GFLOP of the three '
+                                       'layers forward + backward.  What bounds the family at this size: the batch-norm '
+                                       'statistics of a demonstration index mix every frame of the index, so each direction has '
+                                       'three index-wide exchanges between its workgroups (about 5 us each by the kernels\' own '
+                                       'clock stamps, profiles/r05_karel_encoder_bwd_time.log: 30 us of the family by themselves), '
+                                       'and the products are chains of 16x16x4 MFMAs on one wave per SIMD of 160 of the 256 CUs '
+                                       '(40 frames per workgroup).  The fused launches changed the step by less than the box-to-box '
+                                       'spread: the backward chain they replace ran beside the side stream\'s weight-gradient GEMMs'}
     U = config.num_lstm_cell_units
     M = config.batch_size * config.k
     gate = {'note': 'standalone micro-benchmark of d2p_lstm_gate_fwd/_bwd; the training step never launches them '
