@@ -146,6 +146,7 @@ class Model(object):
         self._ctx = None
         self._conv = conv_shapes(config)
         self._fused_enc_ok = {}
+        self.decoder_skip_past_len = True     # (tests switch it off on a Model object: the A side of their A/B)
         self._fused_enc_bwd_ok = {}
         self.feature_dim = feature_dim(config)
         # non-trainable BN moving statistics (updated inline, once per reference call): views of ONE buffer
@@ -667,13 +668,21 @@ class Model(object):
             # all three decoders in ONE launch of the wide-tile persistent kernel (3 + 3 + 2 row domains, as their
             # backward recurrences)
             side_loss = self.use_side_stream and defer_loss and feed.get('loss_dens') is not None
-            dp, da, dq = self._decoders_fwd(specs, logits=False)
             # a training step (a backward pass follows at once): the logits themselves are left to backward's first
             # launch -- d2p_xent_bwd_dhout_multi computes hout . proj in front of the loss backward -- and the loss
             # value follows it on the side stream: three skinny GEMM launches (17 us each, K = 512 walked by 50
             # workgroups) leave the critical path between the forward and the backward recurrences
             defer_logits = (side_loss and max(V, A, P) <= 64 and U % 128 == 0 and U <= 512 and self.is_train)
             ctx['logits_deferred'] = defer_logits
+            # (round 5) in that step nothing reads a decoder's output past a row's own length -- the loss and its
+            # gradient mask those steps, the weight-gradient products run over the rows inside their sequences -- so the
+            # action / perception recurrences skip them like the encoders' (length-sorted row domains that run only
+            # their longest row's steps; hout is zero there, as TF's impute_finished would leave it).  forward() outside
+            # a training step, evaluation and the baselines keep the reference's free-running outputs past a row's
+            # length (BasicDecoder without impute_finished, models/model_full.py:465-471).
+            skip = ({'act': (lens_d, fwd_order), 'per': (lens_d, fwd_order)}
+                    if (defer_logits and fwd_order is not None and self.decoder_skip_past_len) else None)
+            dp, da, dq = self._decoders_fwd(specs, logits=False, skip_past=skip)
             for e_ in (dp, da, dq):
                 if self._abl('logits'):
                     e_['logits'] = self._bufs[e_['scope'] + '/logits']
@@ -917,10 +926,11 @@ class Model(object):
         return dict(name=name, x=x2d, I=I, M=M, T=T, n=n_steps, h0=h0, c0=c0, lens=lens, z=z,
                     hout=hout, hbuf=hbuf, cs=cs, h_final=hf, c_final=cf, Wx=Wx, Wh=Wh)
 
-    def _decoders_fwd(self, specs, logits=True):
+    def _decoders_fwd(self, specs, logits=True, skip_past=None):
         """BasicDecoder + TrainingHelper + Dense(no bias) (models/model_full.py:440-490) for
         several independent decoders at once.  logits=False: the recurrences only (the caller projects with
-        _decoder_logits, e.g. on the other stream)."""
+        _decoder_logits, e.g. on the other stream).  skip_past: {scope: (lens, row_order)} -- the recurrence of that
+        decoder does not run a row past its length (training step only: see forward())."""
         p = self.params.p
         U = self.num_lstm_cell_units
         es, seqs = [], []
@@ -936,7 +946,10 @@ class Model(object):
                 e['token_ids'] = self._bufs['ids_p' if scope == 'prog' else 'ids_a']
             es.append(e)
             if n_steps > 0:
-                seqs.append(dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs))
+                q = dict(M=R, U=U, n_steps=n_steps, z=z, Wh=e['Wh'], h0=h0, c0=c0, hout=hout, cs=cs)
+                if skip_past and scope in skip_past:
+                    q['lens'], q['row_order'] = skip_past[scope]
+                seqs.append(q)
         if seqs:
             K.lstm_seq_fwd_multi(seqs)
         if logits:

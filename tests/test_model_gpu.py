@@ -1333,6 +1333,50 @@ def test_one_launch_state_encoder_equals_the_separate_launches(monkeypatch):
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-6, atol=1e-7)
 
 
+def test_training_step_decoders_skip_the_steps_past_a_rows_length():
+    """Round 5: in a training step (deferred logits) the action / perception decoders' forward recurrences run
+    length-sorted and do not compute a row past its own length -- nothing reads those outputs there (the loss and its
+    gradient mask them: models/model_full.py:1018-1079; the weight gradients run over the rows inside their sequences).
+    Same loss and gradients as the free-running recurrences up to fp32 summation order, hout zero past a row's length;
+    forward() outside a training step keeps the reference's free-running outputs (BasicDecoder without
+    impute_finished, models/model_full.py:465-471)."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.config import make_config
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.synthetic import make_batch
+    cfg = make_config('karel', batch_size=32, k=10, num_lstm_cell_units=128)
+    batch = make_batch(cfg, seed=11)
+    m = Model(cfg, seed=5)
+    feed = m.get_feed_dict(batch)
+    if feed.get('demo_slab_steps') is None or feed.get('loss_dens') is None:
+        pytest.skip('this feed carries no row order / mask counts')
+    res = []
+    for skip in (False, True):
+        m.decoder_skip_past_len = skip
+        loss = m.forward(feed, defer_loss=True)
+        m.backward()
+        torch.cuda.synchronize()
+        assert K.lstm_persist_error() == 0
+        assert m._ctx.get('logits_deferred'), 'the deferred-logits path of a training step did not run'
+        res.append((float(loss.item()), m.params.grad.clone(), m._ctx['da']['hout'].clone(), m._ctx['dq']['hout'].clone()))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0]), (res[0][0], res[1][0])
+    scale = float(res[0][1].abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * scale
+    T, M = cfg.max_demo_len, cfg.batch_size * cfg.k
+    lens = feed['demo_len'].view(-1).cpu()
+    past = (torch.arange(T).view(T, 1) >= lens.view(1, M)).cuda()          # [T, M]: step t is past row m's length
+    inside = ~past
+    for i in (2, 3):
+        free, skipped = res[0][i], res[1][i]
+        assert float(skipped[past].abs().max()) == 0.0                         # zeros, as impute_finished would leave
+        assert float(free[past].abs().max()) > 0.0                             # (the free-running cell keeps going)
+        assert float((free[inside] - skipped[inside]).abs().max()) <= 1e-6
+    # outside a training step: the free-running outputs, whatever the switch says
+    m.decoder_skip_past_len = True
+    m.forward(feed)
+    assert float(m._ctx['da']['hout'][past].abs().max()) > 0.0
+
+
 def test_one_launch_state_encoder_under_graph_replay():
     """the one-launch encoder's cross-workgroup barrier under hipGraph replay.  Its arrival counters were
     chosen per launch on the HOST (baked into the captured node: every replay after the first fell through the barrier
