@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--rounds', type=int, default=4)
     ap.add_argument('--steps', type=int, default=200)
     ap.add_argument('--preset', default='karel')
+    ap.add_argument('--extra', type=int, nargs='*', default=[], help='further constant arguments of the setter')
     args = ap.parse_args()
     from demo2program_amd import build
     from demo2program_amd.config import make_config
@@ -53,7 +54,7 @@ def main():
     res = {args.a: [], args.b: []}
     for r in range(args.rounds):
         for v in (args.a, args.b):
-            setter(v)
+            setter(v, *args.extra)
             block(10)
             ms = block(args.steps)
             res[v].append(ms)
