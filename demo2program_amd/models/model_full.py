@@ -1282,8 +1282,10 @@ class Model(object):
             dz2 = self._lstm_bwd_rec(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2)
             if ctx.get('rows') is not None:
                 rows_idx, n_act = ctx['rows']
+                # (no zero fill: the only reader is the first encoder's backward recurrence, which SELECTS dhout by the row's
+                #  length -- rows past their sequence keep whatever an earlier batch left there;
+                #  test_rows_past_a_sequence_are_selected_around_not_multiplied poisons them)
                 d_hout1 = self._buf(e2['name'] + '/dx', (T * M, U))
-                d_hout1.zero_()                       # rows past their sequence: no gradient
                 K.gemm_rows('nt', n_act, U, 4 * U, dz2, 4 * U, e2['Wx'], 4 * U, d_hout1, U, rows_idx)
             else:
                 d_hout1 = self._lstm_bwd_dx(e2, dz2)
