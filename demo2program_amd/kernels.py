@@ -295,6 +295,40 @@ def karel_encoder_fwd(x, B, G, T, w, bias, gamma, beta, a, y, feats_tm, mean, rs
                                ws.numel() * ws.element_size(), current_stream())
 
 
+def rn_ok(B, k, U):
+    """whether the four-launch form of the relation networks' pointwise chains (d2p_rn_*) takes this geometry"""
+    return _load_lib().d2p_rn_ws_bytes(B, k, U) > 0
+
+
+def rn_fc1_fwd(P, Q, bias, gamma, beta, pstride, B, k, U, y1a, y1, mean, rstd, var, moving, decay, ws):
+    """y1a = lrelu(P[b,c] + Q[b,a] + bias), y1 = its batch norm, both summaries (d2p_rn_fc1_fwd); moving = (mm, mv) [2, U] or None"""
+    _require_gpu(P, y1a, ws)
+    mm, mv = moving if moving is not None else (None, None)
+    call.d2p_rn_fc1_fwd(B, k, U, ptr(P), ptr(Q), ptr(bias), ptr(gamma), ptr(beta), pstride, ptr(y1a), ptr(y1), ptr(mean),
+                        ptr(rstd), ptr(var), ptr(mm), ptr(mv), decay, ptr(ws), ws.numel() * ws.element_size(), current_stream())
+
+
+def rn_fc2_fwd(y2a, gamma, beta, pstride, feat, B, k, U, out, psum, mean, rstd, var, moving, decay, ws):
+    """out = mean over a program's pairs of batch norm(y2a) (+ mean over k of feat), from one read of y2a (d2p_rn_fc2_fwd)"""
+    _require_gpu(y2a, out, ws)
+    mm, mv = moving if moving is not None else (None, None)
+    call.d2p_rn_fc2_fwd(B, k, U, ptr(y2a), ptr(gamma), ptr(beta), pstride, ptr(feat), ptr(out), ptr(psum), ptr(mean), ptr(rstd),
+                        ptr(var), ptr(mm), ptr(mv), decay, ptr(ws), ws.numel() * ws.element_size(), current_stream())
+
+
+def rn_fc2_bwd(y2a, dout, psum, gamma, pstride, mean, rstd, B, k, U, dpre, dgamma, dbeta, ws):
+    _require_gpu(y2a, dout, dpre, ws)
+    assert dout.is_contiguous() and psum.is_contiguous()
+    call.d2p_rn_fc2_bwd(B, k, U, ptr(y2a), ptr(dout), ptr(psum), ptr(gamma), pstride, ptr(mean), ptr(rstd), ptr(dpre),
+                        ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel() * ws.element_size(), current_stream())
+
+
+def rn_fc1_bwd(y1a, dy1, gamma, pstride, mean, rstd, B, k, U, dP, dQ, dgamma, dbeta, dbias, dbias2, ws):
+    _require_gpu(y1a, dy1, dP, ws)
+    call.d2p_rn_fc1_bwd(B, k, U, ptr(y1a), ptr(dy1), ptr(gamma), pstride, ptr(mean), ptr(rstd), ptr(dP), ptr(dQ), ptr(dgamma),
+                        ptr(dbeta), ptr(dbias), ptr(dbias2), ptr(ws), ws.numel() * ws.element_size(), current_stream())
+
+
 def karel_encoder_bwd_ok(B, G, T):
     """whether the one-launch State_Encoder backward (d2p_karel_encoder_bwd) takes this batch geometry"""
     return _load_lib().d2p_karel_encoder_bwd_ws_bytes(B, G, T) > 0

@@ -57,6 +57,11 @@ SIGNATURES = {
     'd2p_karel_encoder_set_trace': (c_int, [P]),
     'd2p_karel_encoder_fwd': (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
     'd2p_karel_encoder_bwd_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'd2p_rn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
+    'd2p_rn_fc1_fwd': (c_int, [c_int, c_int, c_int, P, P, P, P, P, c_long, P, P, P, P, P, P, P, c_float, P, c_size_t, S]),
+    'd2p_rn_fc2_fwd': (c_int, [c_int, c_int, c_int, P, P, P, c_long, P, P, P, P, P, P, P, P, c_float, P, c_size_t, S]),
+    'd2p_rn_fc2_bwd': (c_int, [c_int, c_int, c_int, P, P, P, P, c_long, P, P, P, P, P, P, c_size_t, S]),
+    'd2p_rn_fc1_bwd': (c_int, [c_int, c_int, c_int, P, P, P, c_long, P, P, P, P, P, P, P, P, P, c_size_t, S]),
     'd2p_karel_encoder_bwd': (c_int, [c_int, c_int, c_int, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, c_size_t, S]),
     'd2p_bn_ws_bytes': (c_size_t, [c_int, c_int, c_int]),
     'd2p_bn_batched_ws_bytes': (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -146,6 +146,8 @@ class Model(object):
         self._ctx = None
         self._conv = conv_shapes(config)
         self._fused_enc_ok = {}
+        self._fused_rn_ok = {}
+        self.fused_rn = True                  # (tests switch it off on a Model object: the nine + eleven separate launches)
         self.decoder_skip_past_len = True     # (tests switch it off on a Model object: the A side of their A/B)
         self._fused_enc_bwd_ok = {}
         self.feature_dim = feature_dim(config)
@@ -1068,6 +1070,27 @@ class Model(object):
         PQ = self._buf('rn/PQ', (2, 2, M, U))
         K.gemm_batched('nn', 2, 2, M, U, U, feat, U, (M * U, 0), W1, U, (ps, U * U), PQ, U, (M * U, 2 * M * U))
         y1a = self._buf('rn/y1a', (2, R, U))
+        if self._rn_fused(B, k, U):
+            # (round 5) the pointwise chains around the two GEMMs in two launches (d2p_rn_fc1_fwd / d2p_rn_fc2_fwd) instead of nine
+            y1, y2a = self._buf('rn/y1', (2, R, U)), self._buf('rn/y2a', (2, R, U))
+            ws = self._buf('rn/ws', (K._load_lib().d2p_rn_ws_bytes(B, k, U),), torch.uint8)
+            st = {}
+            for leaf in ('fc1', 'fc2'):
+                st[leaf] = [self._buf('rn/%s/bn_%s' % (leaf, q), (2, 1, U)) for q in ('mean', 'rstd', 'var')]
+                assert self.moving['rn_c/' + leaf][0].data_ptr() - self.moving['rn_h/' + leaf][0].data_ptr() == 4 * U
+                for q in ('gamma', 'beta'):
+                    assert (p['rn_c/%s/%s' % (leaf, q)].data_ptr() - p['rn_h/%s/%s' % (leaf, q)].data_ptr()) // 4 == ps
+            mov = (lambda leaf: self.moving['rn_h/' + leaf] if self.track_moving else None)
+            K.rn_fc1_fwd(PQ[0], PQ[1], p['rn_h/fc1/b'], p['rn_h/fc1/gamma'], p['rn_h/fc1/beta'], ps, B, k, U, y1a, y1,
+                         st['fc1'][0], st['fc1'][1], st['fc1'][2], mov('fc1'), 0.9, ws)
+            K.gemm_batched('nn', 2, 1, R, U, U, y1, U, (R * U, 0), W2, U, (ps, 0), y2a, U, (R * U, 0),
+                           bias=p['rn_h/fc2/b'], sbias=(ps, 0), act=1)
+            out, psum = self._buf('rn/out', (2, B, U)), self._buf('rn/psum', (2, B, U))
+            K.rn_fc2_fwd(y2a, p['rn_h/fc2/gamma'], p['rn_h/fc2/beta'], ps, feat if add_mean else None, B, k, U, out, psum,
+                         st['fc2'][0], st['fc2'][1], st['fc2'][2], mov('fc2'), 0.9, ws)
+            return dict(feat=feat, y1a=y1a, y1=y1, y2a=y2a, out=out, add_mean=add_mean, ps=ps, psum=psum, ws=ws, fused=True,
+                        st1=[(y1[i], st['fc1'][0][i], st['fc1'][1][i]) for i in range(2)],
+                        st2=[(None, st['fc2'][0][i], st['fc2'][1][i]) for i in range(2)])
         K.rn_pair_fwd(PQ[0], PQ[1], p['rn_h/fc1/b'], y1a, 2 * B, k, U, scopes=2, bias_stride=ps)
         y1, y2a, y2 = self._buf('rn/y1', (2, R, U)), self._buf('rn/y2a', (2, R, U)), self._buf('rn/y2', (2, R, U))
         st1 = self._rn_bn_fwd('fc1', y1a, y1, ps)
@@ -1081,6 +1104,15 @@ class Model(object):
         out = self._buf('rn/out', (2, B, U))
         K.pair_mean_fwd(y2, base, out, 2 * B, k * k, U)
         return dict(feat=feat, y1a=y1a, y1=y1, y2a=y2a, st1=st1, st2=st2, out=out, add_mean=add_mean, ps=ps)
+
+    def _rn_fused(self, B, k, U):
+        """training mode, a geometry d2p_rn_* takes, and the switch the tests flip on a Model object"""
+        if not (self.is_train and self.fused_rn):
+            return False
+        key = (B, k, U)
+        if key not in self._fused_rn_ok:
+            self._fused_rn_ok[key] = K.rn_ok(B, k, U)
+        return self._fused_rn_ok[key]
 
     def _rn_bn_fwd(self, leaf, x, y, ps):
         """Batch norm of layer `leaf` of BOTH relation networks: x, y [2, R, U].  Training: one two-problem
@@ -1577,6 +1609,19 @@ class Model(object):
         feat = r['feat']
         if r['add_mean']:
             K.group_mean_bwd(d_out, None, d_feat, 2 * B, k, U, True)         # the avg-pool branch
+        if r.get('fused'):
+            # (round 5) d2p_rn_fc2_bwd / d2p_rn_fc1_bwd around the input-gradient GEMM of fc2 instead of eleven launches
+            dy2a, dy1 = self._buf('rn/dy2a', (2, R, U)), self._buf('rn/dy1', (2, R, U))
+            dPQ = self._buf('rn/dPQ', (2, 2, M, U))                          # [half][scope], as PQ
+            mean2, rstd2 = self._bufs['rn/fc2/bn_mean'], self._bufs['rn/fc2/bn_rstd']
+            mean1, rstd1 = self._bufs['rn/fc1/bn_mean'], self._bufs['rn/fc1/bn_rstd']
+            K.rn_fc2_bwd(r['y2a'], d_out, r['psum'], p['rn_h/fc2/gamma'], ps, mean2, rstd2, B, k, U, dy2a,
+                         g['rn_h/fc2/gamma'], g['rn_h/fc2/beta'], r['ws'])
+            K.gemm_batched('nt', 2, 1, R, U, U, dy2a, U, (R * U, 0), W2, U, (ps, 0), dy1, U, (R * U, 0))
+            K.rn_fc1_bwd(r['y1a'], dy1, p['rn_h/fc1/gamma'], ps, mean1, rstd1, B, k, U, dPQ[0], dPQ[1],
+                         g['rn_h/fc1/gamma'], g['rn_h/fc1/beta'], g['rn_h/fc1/b'], g['rn_h/fc2/b'], r['ws'])
+            self._rn_bwd_tail(r, d_feat, dPQ, dy2a, B, k, U)
+            return
         dy2 = self._buf('rn/dy2', (2, R, U))
         K.pair_mean_bwd(d_out, dy2, 2 * B, k * k, U)
         dy2a, dy1, dy1a = self._buf('rn/dy2a', (2, R, U)), self._buf('rn/dy1', (2, R, U)), self._buf('rn/dy1a', (2, R, U))
@@ -1601,6 +1646,14 @@ class Model(object):
                          g[sc + '/fc1/gamma'], g[sc + '/fc1/beta'], dx=dy1a[i], dbias=g[sc + '/fc1/b'])
         dPQ = self._buf('rn/dPQ', (2, 2, M, U))                          # [half][scope], as PQ
         K.rn_pair_bwd(dy1a, dPQ[0], dPQ[1], 2 * B, k, U)
+        self._rn_bwd_tail(r, d_feat, dPQ, dy2a, B, k, U)
+
+    def _rn_bwd_tail(self, r, d_feat, dPQ, dy2a, B, k, U):
+        """what follows the pair backward: the feature gradient through fc1's two half-projections, and the weight gradients"""
+        p, g = self.params.p, self.params.g
+        M, ps = B * k, r['ps']
+        W1 = p['rn_h/fc1/W']
+        feat = r['feat']
         # d_feat += dP . W1[:U]^T, then += dQ . W1[U:]^T (two launches: both write d_feat)
         K.gemm_batched('nt', 2, 1, M, U, U, dPQ[0], U, (M * U, 0), W1, U, (ps, 0), d_feat, U, (M * U, 0),
                        accumulate=True)

@@ -224,6 +224,36 @@ int d2p_karel_encoder_bwd(int B, int G, int T, const void* x, int x_is_u8, const
                           const float* const* a, const float* const* mean, const float* const* rstd,
                           float* const* dw, float* const* db, float* const* dgamma, float* const* dbeta, void* ws,
                           size_t ws_bytes, d2p_stream_t stream);
+/* The relation networks' pointwise chains around their two GEMMs in four launches (round 5; rn_pool of
+ * models/model_full.py:333-349 for BOTH summaries: leading dimension 2 everywhere, parameters of the second summary
+ * pstride floats behind the first's).  B programs, k demonstrations, U units; rows of a summary ordered (b, a, c).
+ *   d2p_rn_fc1_fwd: y1a[b,a,c] = lrelu(P[b,c] + Q[b,a] + bias) (P, Q [2, B*k, U]: the two half-projections of fc1) and y1 =
+ *       its batch norm over all B*k*k rows (training mode, one group): the sums come from recomputed values, y1a and y1 are
+ *       written once; mean / rstd / var [2, U]; moving statistics [2, U] updated in the launch when non-null.
+ *   d2p_rn_fc2_fwd: out[b] = mean over the pairs of batch norm(y2a)[b] (+ mean over k of feat [2, B*k, U] when non-null:
+ *       the avg-pool branch) from ONE read of y2a [2, B*k*k, U] (batch norm is affine per column: it commutes with the
+ *       mean); psum [2, B, U] = the per-program sums of y2a, for the backward.
+ *   d2p_rn_fc2_bwd: dpre [2, B*k*k, U] = gradient of fc2's pre-activation from dout [2, B, U] (the batch-norm backward's
+ *       sums are closed forms of dout and psum), dgamma / dbeta [U] (+ pstride); fc2's bias gradient is finished by
+ *   d2p_rn_fc1_bwd: batch-norm backward of fc1 (+ lrelu') from dy1, summed over a into dP [2, B*k, U] and over c into dQ
+ *       (the pre-activation gradient itself is never written); dgamma, dbeta, dbias of fc1 and dbias2 of fc2.
+ * The B workgroups of a (summary, 128-column slice) exchange fp64 partial sums through ws (d2p_rn_ws_bytes; one ws for the
+ * four calls of a step) and must be co-resident: D2P_EINVAL / d2p_rn_ws_bytes == 0 for geometries that are not taken
+ * (U % 128, k > 32, more workgroups than two per CU) -- callers run the separate launches.  Same values as those up to the
+ * order of the fp64 sums.  A workgroup that waits too long sets the status word of d2p_lstm_persist_error (code 0x7c). */
+size_t d2p_rn_ws_bytes(int B, int k, int U);   /* 0: geometry not supported */
+int d2p_rn_fc1_fwd(int B, int k, int U, const float* P, const float* Q, const float* bias, const float* gamma,
+                   const float* beta, long pstride, float* y1a, float* y1, float* mean, float* rstd, float* var,
+                   float* moving_mean, float* moving_var, float decay, void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_rn_fc2_fwd(int B, int k, int U, const float* y2a, const float* gamma, const float* beta, long pstride,
+                   const float* feat, float* out, float* psum, float* mean, float* rstd, float* var, float* moving_mean,
+                   float* moving_var, float decay, void* ws, size_t ws_bytes, d2p_stream_t stream);
+int d2p_rn_fc2_bwd(int B, int k, int U, const float* y2a, const float* dout, const float* psum, const float* gamma,
+                   long pstride, const float* mean, const float* rstd, float* dpre, float* dgamma, float* dbeta, void* ws,
+                   size_t ws_bytes, d2p_stream_t stream);
+int d2p_rn_fc1_bwd(int B, int k, int U, const float* y1a, const float* dy1, const float* gamma, long pstride,
+                   const float* mean, const float* rstd, float* dP, float* dQ, float* dgamma, float* dbeta, float* dbias,
+                   float* dbias2, void* ws, size_t ws_bytes, d2p_stream_t stream);
 /* Batch norm folded into the conv launches (round 5; the ViZDoom-size layers of models/model_full.py:216-231, whose
  * conv -> lrelu -> batch-norm chain of models/ops.py:14-33 otherwise writes and re-reads each activation three times).
  * Frames are ordered (program, demonstration index, step): the statistics of frame n belong to index g = (n / seq) % G.

@@ -1333,6 +1333,52 @@ def test_one_launch_state_encoder_equals_the_separate_launches(monkeypatch):
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize('model_kind', ['full', 'summarizer'])
+def test_relation_networks_in_four_launches_equal_the_separate_launches(model_kind):
+    """Round 5: the relation networks' pointwise chains around their two GEMMs as d2p_rn_fc1_fwd / _fc2_fwd / _fc2_bwd /
+    _fc1_bwd (batch-norm sums from recomputed pair values, batch norm commuted with the mean over a program's pairs,
+    closed-form sums in fc2's batch-norm backward, the pair backward from registers) against the 9 + 11 separate
+    launches (rn_pool of models/model_full.py:333-349 under tf.gradients): same summaries, loss, gradients and moving
+    statistics to fp32 rounding of the batch statistics; the summarizer baseline runs it without the avg-pool branch."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.config import make_config
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.synthetic import make_batch
+    kw = dict(batch_size=32, k=10, num_lstm_cell_units=128)
+    if model_kind == 'summarizer':
+        kw['model'] = 'summarizer'
+    cfg = make_config('karel', **kw)
+    if not K.rn_ok(32, 10, 128):
+        pytest.skip('geometry not taken by the four-launch form on this device')
+    batch = make_batch(cfg, seed=13)
+    m = Model(cfg, seed=7)
+    mov0 = m.moving_flat.clone()
+    feed = m.get_feed_dict(batch)
+    res = []
+    for fused in (False, True):
+        m.fused_rn = fused
+        m.moving_flat.copy_(mov0)
+        for rep in range(2):                                   # (twice: the arrival tickets of a second generation)
+            loss = float(m.forward(feed).item())
+            m.backward()
+        torch.cuda.synchronize()
+        assert K.lstm_persist_error() == 0
+        assert bool(m._ctx['rn_h'].get('fused')) == fused
+        res.append((loss, m.params.grad.clone(), m.moving_flat.clone(), m._ctx['rn_h']['out'].clone()))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[0][0])
+    torch.testing.assert_close(res[0][3], res[1][3], rtol=1e-5, atol=1e-6)
+    scale = float(res[0][1].abs().max())
+    assert float((res[0][1] - res[1][1]).abs().max()) <= 2e-5 * scale
+    # every relation-network gradient tensor on its own scale (the bound of the oracle parity tests)
+    m.params.grad.copy_(res[0][1]); g_sep = m.params.to_numpy('g')
+    m.params.grad.copy_(res[1][1]); g_fus = m.params.to_numpy('g')
+    for n in g_sep:
+        if n.startswith('rn_'):
+            s_ = np.abs(g_sep[n]).max()
+            assert np.abs(g_sep[n] - g_fus[n]).max() <= 2e-4 * s_ + 1e-6, n
+    torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-5, atol=1e-7)
+
+
 def test_training_step_decoders_skip_the_steps_past_a_rows_length():
     """Round 5: in a training step (deferred logits) the action / perception decoders' forward recurrences run
     length-sorted and do not compute a row past its own length -- nothing reads those outputs there (the loss and its
