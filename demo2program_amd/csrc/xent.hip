@@ -145,51 +145,53 @@ struct XbArgs { int n; XbProb p[3]; };
 // models/model_full.py:463-464 in FRONT of the loss backward, in the same launch).  The 5- / 6- / 50-column products
 // were three skinny GEMM launches of 17 us each on the critical path between the decoders' forward and backward
 // recurrences -- 50 workgroups each walking K = 512 alone; here ~900 workgroups do 16 rows each.
-// The 16 hout rows are staged in LDS (coalesced 16-byte loads); thread = (column v, K slice): VP = V rounded up to a
-// power of two (>= 8), 256 / VP slices of U; a thread multiplies its slice for ALL 16 rows (one coalesced proj load
-// feeds 16 multiply-adds, the hout values are LDS broadcasts), the slices meet in LDS and are added in slice order.
-__device__ __forceinline__ void xb_logits16(const XbProb& q, long row0, long nrows, float* hs, float* part,
-                                            float (*lg)[XB_MAXV]) {
-    const int V = q.V, U = q.U, tid = threadIdx.x;
-    // stage hout[row0 .. row0+15][0 .. U): rows past the end as zeros
-    for (int i = tid; i < XB_ROWS * U / 4; i += 256) {
-        const int r = i / (U / 4), c = i - r * (U / 4);
-        float4 v4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < nrows) v4 = *reinterpret_cast<const float4*>(q.hout + (row0 + r) * U + c * 4);
-        *reinterpret_cast<float4*>(hs + r * U + c * 4) = v4;
-    }
-    __syncthreads();
-    int VP = 8;
-    while (VP < V) VP <<= 1;
-    const int KS = 256 / VP, v = tid & (VP - 1), ks = tid / VP;
-    const int ulen = U / KS, u0 = ks * ulen;           // (U % 32 == 0 and KS <= 32: whole multiples of 4... checked on the host)
-    float acc[XB_ROWS];
+// Round 5: on the matrix pipe.  [16 rows x U] . [U x V] is a 16 x 16 x 4 MFMA shape: lane (row m, k quarter kq) loads
+// 16 bytes of its hout row straight from memory (four consecutive k: the A operands of four MFMAs, no LDS staging of
+// the 32 KB of rows), the B operands are proj[k][n] for the tile's 16 columns (zeros past V); the four waves take a
+// quarter of U each and meet in LDS in wave order.  (Round 4's form staged the rows in LDS and multiplied on the vector
+// ALUs: 20 us of the launch's 42.)
+typedef float xb_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void xb_logits16(const XbProb& q, long row0, long nrows, float* part, float (*lg)[XB_MAXV]) {
+    const int V = q.V, U = q.U, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, m = lane & 15, kq = lane >> 4;
+    const int NT = (V + 15) >> 4;
+    const long row = row0 + m < nrows ? row0 + m : nrows - 1;            // (rows past the end: repeated, never stored)
+    const int kw = U >> 2;                                               // this wave's share of K
+    const float* hp = q.hout + row * U + w * kw + 4 * kq;
+    xb_f32x4 acc[4];
 #pragma unroll
-    for (int r = 0; r < XB_ROWS; ++r) acc[r] = 0.f;
-    if (v < V) {
-        const float* pr = q.proj + (long)u0 * V + v;
-#pragma unroll 2
-        for (int u = 0; u < ulen; u += 4) {
-            const float p0 = pr[(long)(u + 0) * V], p1 = pr[(long)(u + 1) * V], p2 = pr[(long)(u + 2) * V],
-                        p3 = pr[(long)(u + 3) * V];
+    for (int nt = 0; nt < 4; ++nt) acc[nt] = xb_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < kw; c += 16) {
+        const float4 a4 = *reinterpret_cast<const float4*>(hp + c);
+        const float* pk = q.proj + (long)(w * kw + c + 4 * kq) * V + m;
 #pragma unroll
-            for (int r = 0; r < XB_ROWS; ++r) {
-                const float4 h = *reinterpret_cast<const float4*>(hs + r * U + u0 + u);
-                acc[r] = fmaf(h.w, p3, fmaf(h.z, p2, fmaf(h.y, p1, fmaf(h.x, p0, acc[r]))));
+        for (int nt = 0; nt < 4; ++nt) {
+            if (nt < NT) {
+                const bool ok = nt * 16 + m < V;
+                const float* pp = pk + nt * 16;
+                const float b0 = ok ? pp[0] : 0.f, b1 = ok ? pp[V] : 0.f, b2 = ok ? pp[2 * V] : 0.f, b3 = ok ? pp[3 * V] : 0.f;
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b0, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b1, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b2, acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b3, acc[nt], 0, 0, 0);
             }
         }
     }
-    // part[ks][r][VP]
+    // part[wave][tile][r][lane]: lane (n = lane & 15, q = lane >> 4) holds rows 4 q + r of column 16 tile + n
 #pragma unroll
-    for (int r = 0; r < XB_ROWS; ++r) part[(ks * XB_ROWS + r) * VP + v] = acc[r];
+    for (int nt = 0; nt < 4; ++nt)
+        if (nt < NT)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part[((w * 4 + nt) * 4 + r) * 64 + lane] = acc[nt][r];
     __syncthreads();
-    for (int i = tid; i < XB_ROWS * VP; i += 256) {
-        const int r = i / VP, vv = i - r * VP;
+    for (int i = tid; i < XB_ROWS * NT * 16; i += 256) {
+        const int r16 = i / (NT * 16), vv = i - r16 * (NT * 16);
+        const int nt = vv >> 4, n = vv & 15, l2 = (r16 >> 2) * 16 + n, r = r16 & 3;
         float sum = 0.f;
-        for (int k2 = 0; k2 < KS; ++k2) sum += part[(k2 * XB_ROWS + r) * VP + vv];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) sum += part[((w2 * 4 + nt) * 4 + r) * 64 + l2];
         if (vv < V) {
-            lg[r][vv] = sum;
-            if (row0 + r < nrows) q.logits_out[(row0 + r) * V + vv] = sum;
+            lg[r16][vv] = sum;
+            if (row0 + r16 < nrows) q.logits_out[(row0 + r16) * V + vv] = sum;
         }
     }
     __syncthreads();
@@ -208,8 +210,8 @@ xent_bwd_dhout_kernel(XbArgs a) {
     const int V = q.V;
     const bool own_logits = q.hout != nullptr;
     if (own_logits) {
-        extern __shared__ __attribute__((aligned(16))) float xb_dyn[];      // [16][U] staged hout rows + [256 / VP][16][VP] partial sums
-        xb_logits16(q, row0, nrows, xb_dyn, xb_dyn + XB_ROWS * q.U, dl);     // dl holds the 16 rows' logits
+        extern __shared__ __attribute__((aligned(16))) float xb_dyn[];      // [4 waves][4 tiles][4][64] partial logits tiles
+        xb_logits16(q, row0, nrows, xb_dyn, dl);     // dl holds the 16 rows' logits
     }
     __shared__ float rowloss[XB_ROWS];
     __shared__ int rowgrp[XB_ROWS];
@@ -305,7 +307,7 @@ extern "C" int d2p_xent_bwd_dhout_multi(int nprob, const d2p_xent_bwd_desc* d, d
     size_t dyn = 0;
     for (int i = 0; i < a.n; ++i)
         if (a.p[i].hout) {
-            const size_t need = ((size_t)XB_ROWS * a.p[i].U + (size_t)XB_ROWS * 256) * sizeof(float);
+            const size_t need = (size_t)4 * 4 * 4 * 64 * sizeof(float);
             dyn = need > dyn ? need : dyn;
         }
     hipLaunchKernelGGL(xent_bwd_dhout_kernel, dim3(blocks), dim3(256), dyn, as_stream(stream), a);

@@ -1207,12 +1207,13 @@ class Model(object):
                                                         (K.xent_blocks(q_['n_steps'], q_['R']) * q_['G'],))
                 K.xent_bwd_dhout_multi(xb)
                 if ctx.get('logits_deferred'):
-                    for e_ in (ctx['dp'], ctx['da'], ctx['dq']):
-                        if e_['n'] < e_['T']:
-                            e_['logits'][e_['n']:].zero_()      # dynamic zero padding (:476-484)
                     nums, dens_v, loss_, terms_ = ctx['loss_bufs']
                     side.wait_stream(main)
                     with torch.cuda.stream(side):              # the loss VALUE (joined where backward joins the streams)
+                        # (nothing in backward reads the logits: their zero padding leaves the critical path too)
+                        for e_ in (ctx['dp'], ctx['da'], ctx['dq']):
+                            if e_['n'] < e_['T']:
+                                e_['logits'][e_['n']:].zero_()      # dynamic zero padding (:476-484)
                         if fused_loss:
                             # (round 4: the loss-backward launch left the rows' loss values summed per workgroup: one
                             #  small launch instead of three partial-sum, three final and one assembly launch -- 50 us
