@@ -676,14 +676,15 @@ class Model(object):
             # workgroups) leave the critical path between the forward and the backward recurrences
             defer_logits = (side_loss and max(V, A, P) <= 64 and U % 128 == 0 and U <= 512 and self.is_train)
             ctx['logits_deferred'] = defer_logits
-            # (round 5) in that step nothing reads a decoder's output past a row's own length -- the loss and its
+            # (round 5) in a training step (defer_loss: Trainer.train_step) nothing reads a decoder's output past a row's own length -- the loss and its
             # gradient mask those steps, the weight-gradient products run over the rows inside their sequences -- so the
             # action / perception recurrences skip them like the encoders' (length-sorted row domains that run only
             # their longest row's steps; hout is zero there, as TF's impute_finished would leave it).  forward() outside
             # a training step, evaluation and the baselines keep the reference's free-running outputs past a row's
             # length (BasicDecoder without impute_finished, models/model_full.py:465-471).
+            # (whatever the stream schedule: the one-stream instrumented pass and a captured step take it too)
             skip = ({'act': (lens_d, fwd_order), 'per': (lens_d, fwd_order)}
-                    if (defer_logits and fwd_order is not None and self.decoder_skip_past_len) else None)
+                    if (defer_loss and self.is_train and fwd_order is not None and self.decoder_skip_past_len) else None)
             dp, da, dq = self._decoders_fwd(specs, logits=False, skip_past=skip)
             for e_ in (dp, da, dq):
                 if self._abl('logits'):
