@@ -56,7 +56,7 @@ struct RnGeom {
 // The exchange of a (summary, slice): threads ch < 128 hold this workgroup's (s0, s1); every thread ch < 128 leaves
 // with the sums over the B workgroups in program order.  part: [group][B][128][2] doubles.
 __device__ __forceinline__ void rn_exchange(double* part, unsigned long long* counters, unsigned* err, int group, int B, int b,
-                                            double& s0, double& s1, int* flag) {
+                                            double& s0, double& s1, int* flag, double* xred /* [2][128][2] doubles of LDS */) {
     const int tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
         part + (long)group * B * RN_CS * 2, 0, B * RN_CS * 2 * (int)sizeof(double), 0x00020000);
@@ -86,23 +86,33 @@ __device__ __forceinline__ void rn_exchange(double* part, unsigned long long* co
         *flag = ok;
     }
     __syncthreads();
-    if (tid < RN_CS) {
+    {
+        // both thread halves read: half h the programs [h ceil(B/2), ...) of its column, sixteen 16-byte loads in flight
+        // (four at a time by half the threads was eight memory round trips at B = 32); the two halves' sums meet in
+        // LDS -- lower programs first: the same order in every workgroup
+        const int ch = tid & (RN_CS - 1), half = tid >> 7, hb = (B + 1) >> 1;
+        const int p0 = half * hb, p1 = p0 + hb < B ? p0 + hb : B;
         double t0 = 0.0, t1 = 0.0;
-        for (int s = 0; s < B; s += 4) {
-            rn_i32x4 v[4];
+        for (int s = p0; s < p1; s += 16) {
+            rn_i32x4 v[16];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                v[u] = __builtin_amdgcn_raw_buffer_load_b128(res, s + u < B ? ((s + u) * RN_CS + tid) * 16 : 0x7fffff00, 0, RN_AUX_SC1);
+            for (int u = 0; u < 16; ++u)
+                v[u] = __builtin_amdgcn_raw_buffer_load_b128(res, s + u < p1 ? ((s + u) * RN_CS + ch) * 16 : 0x7fffff00, 0, RN_AUX_SC1);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 double pr[2];
                 __builtin_memcpy(pr, &v[u], 16);
                 t0 += pr[0];
                 t1 += pr[1];
             }
         }
-        s0 = t0;
-        s1 = t1;
+        xred[(half * RN_CS + ch) * 2] = t0;
+        xred[(half * RN_CS + ch) * 2 + 1] = t1;
+    }
+    __syncthreads();
+    if (tid < RN_CS) {
+        s0 = xred[tid * 2] + xred[(RN_CS + tid) * 2];
+        s1 = xred[tid * 2 + 1] + xred[(RN_CS + tid) * 2 + 1];
     }
 }
 
@@ -150,8 +160,8 @@ __global__ void __launch_bounds__(256) rn_fc1_fwd_kernel(RnFc1FwdArgs a) {
     const int u = g.cs * RN_CS + ch;
     float* Ps = lds;                           // [k][128]
     float* Qs = Ps + k * RN_CS;                // [k][128]
-    double* red = reinterpret_cast<double*>(Qs + k * RN_CS);      // [128][2]
-    float* lmean = reinterpret_cast<float*>(red + 2 * RN_CS);
+    double* red = reinterpret_cast<double*>(Qs + k * RN_CS);      // [2][128][2]
+    float* lmean = reinterpret_cast<float*>(red + 4 * RN_CS);
     float* lrstd = lmean + RN_CS;
     int* flag = reinterpret_cast<int*>(lrstd + RN_CS);
     const long M = (long)a.B * k;
@@ -176,7 +186,7 @@ __global__ void __launch_bounds__(256) rn_fc1_fwd_kernel(RnFc1FwdArgs a) {
     if (half) { red[ch * 2] = s0; red[ch * 2 + 1] = s1; }
     __syncthreads();
     if (!half) { s0 += red[ch * 2]; s1 += red[ch * 2 + 1]; }
-    rn_exchange(a.part, a.counters, a.err, g.group(), a.B, g.b, s0, s1, flag);
+    rn_exchange(a.part, a.counters, a.err, g.group(), a.B, g.b, s0, s1, flag, red);
     rn_stats(g, a.B * k * k, s0, s1, lmean, lrstd, a.mean, a.rstd, a.var, a.mm, a.mv, a.decay, a.err);
     const float mu = lmean[ch], rs = lrstd[ch];
     const float ga = a.gamma[g.sc * a.pstride + u], be = a.beta[g.sc * a.pstride + u];
@@ -203,7 +213,7 @@ struct RnFc2FwdArgs {
 };
 
 __global__ void __launch_bounds__(256) rn_fc2_fwd_kernel(RnFc2FwdArgs a) {
-    __shared__ double red[RN_CS * 2];
+    __shared__ double red[RN_CS * 4];
     __shared__ float lmean[RN_CS], lrstd[RN_CS];
     __shared__ int flag;
     RnGeom g;
@@ -215,19 +225,26 @@ __global__ void __launch_bounds__(256) rn_fc2_fwd_kernel(RnFc2FwdArgs a) {
     const int j0 = half ? (kk + 1) / 2 : 0, j1 = half ? kk : (kk + 1) / 2;
     double s0 = 0.0, s1 = 0.0;
     int j = j0;
-    for (; j + 4 <= j1; j += 4) {
-        float v[4];
+    for (; j + 25 <= j1; j += 25) {           // (25 loads in flight: at one wave per SIMD a batch is a memory round trip)
+        float v[25];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = src[(long)(j + q) * a.U];
+        for (int q = 0; q < 25; ++q) v[q] = src[(long)(j + q) * a.U];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { s0 += (double)v[q]; s1 += (double)v[q] * (double)v[q]; }
+        for (int q = 0; q < 25; ++q) { s0 += (double)v[q]; s1 += (double)v[q] * (double)v[q]; }
+    }
+    for (; j + 5 <= j1; j += 5) {
+        float v[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) v[q] = src[(long)(j + q) * a.U];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) { s0 += (double)v[q]; s1 += (double)v[q] * (double)v[q]; }
     }
     for (; j < j1; ++j) { const float v = src[(long)j * a.U]; s0 += (double)v; s1 += (double)v * (double)v; }
     if (half) { red[ch * 2] = s0; red[ch * 2 + 1] = s1; }
     __syncthreads();
     double own = 0.0;
     if (!half) { s0 += red[ch * 2]; s1 += red[ch * 2 + 1]; own = s0; }
-    rn_exchange(a.part, a.counters, a.err, g.group(), a.B, g.b, s0, s1, &flag);
+    rn_exchange(a.part, a.counters, a.err, g.group(), a.B, g.b, s0, s1, &flag, red);
     rn_stats(g, a.B * kk, s0, s1, lmean, lrstd, a.mean, a.rstd, a.var, a.mm, a.mv, a.decay, a.err);
     if (!half) {
         const long o = ((long)g.sc * a.B + g.b) * a.U + u;
@@ -266,11 +283,22 @@ __global__ void __launch_bounds__(256) rn_fc2_bwd_kernel(RnFc2BwdArgs a) {
         // dy is d_out[b] / kk on every pair of program b: sum dy = sum_b d_out[b], sum dy x-hat = sum_b d_out[b] / kk *
         // (psum[b] - kk mean) rstd -- in program order, the same in every workgroup of the (summary, slice)
         double t1 = 0.0, t2 = 0.0;
-        for (int bb = 0; bb < a.B; ++bb) {
-            const long o = ((long)g.sc * a.B + bb) * a.U + u;
-            const double d = (double)a.dout[o];
-            t1 += d;
-            t2 += d / kk * ((double)a.psum[o] - (double)kk * (double)mu) * (double)rs;
+        for (int b0 = 0; b0 < a.B; b0 += 8) {
+            float dv[8], pv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const long o = ((long)g.sc * a.B + (b0 + q < a.B ? b0 + q : a.B - 1)) * a.U + u;
+                dv[q] = a.dout[o];
+                pv[q] = a.psum[o];
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (b0 + q < a.B) {
+                    const double d = (double)dv[q];
+                    t1 += d;
+                    t2 += d / kk * ((double)pv[q] - (double)kk * (double)mu) * (double)rs;
+                }
+            }
         }
         cst[0][ch] = (float)(t1 / (double)R);
         cst[1][ch] = (float)(t2 / (double)R);
@@ -287,12 +315,12 @@ __global__ void __launch_bounds__(256) rn_fc2_bwd_kernel(RnFc2BwdArgs a) {
     const int j0 = half ? (kk + 1) / 2 : 0, j1 = half ? kk : (kk + 1) / 2;
     float sum = 0.f;
     int j = j0;
-    for (; j + 4 <= j1; j += 4) {
-        float v[4];
+    for (; j + 25 <= j1; j += 25) {
+        float v[25];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = a.y2a[base + (long)(j + q) * a.U];
+        for (int q = 0; q < 25; ++q) v[q] = a.y2a[base + (long)(j + q) * a.U];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 25; ++q) {
             const float xh = (v[q] - mu) * rs;
             float d = k1 * (dy - m1 - xh * m2);
             d *= d2p_lrelu_grad_from_out(v[q]);
@@ -325,14 +353,20 @@ struct RnFc1BwdArgs {
     double* part; unsigned long long* counters; unsigned long long* tickets; unsigned* err;
 };
 
+// KT: k at compile time (0: run-time k <= 32).  With k known and small the thread's whole share of a pass -- ceil(k/2) rows of k
+// pairs, two arrays: 100 loads at k = 10 -- is in flight at once; at one workgroup per CU (a wave per SIMD) every batch of
+// loads is a full memory round trip, and the run-time form pays one per row of pairs.
+template <int KT>
 __global__ void __launch_bounds__(256) rn_fc1_bwd_kernel(RnFc1BwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     RnGeom g;
     g.init(a.B, a.k, a.U);
-    const int tid = threadIdx.x, ch = tid & (RN_CS - 1), half = tid >> 7, k = a.k, kk = k * k;
+    constexpr int KC = KT > 0 ? KT : 32;                    // pairs per row held in registers
+    constexpr int NA = (KT > 0 && KT <= 12) ? (KT + 1) / 2 : 1;      // rows of pairs per batch
+    const int tid = threadIdx.x, ch = tid & (RN_CS - 1), half = tid >> 7, k = KT > 0 ? KT : a.k, kk = k * k;
     const int u = g.cs * RN_CS + ch;
-    double* red = reinterpret_cast<double*>(lds);                 // [128][2]
-    float* cst = reinterpret_cast<float*>(red + 2 * RN_CS);       // [2][128]
+    double* red = reinterpret_cast<double*>(lds);                 // [2][128][2]
+    float* cst = reinterpret_cast<float*>(red + 4 * RN_CS);       // [2][128]
     float* dPs = cst + 2 * RN_CS;                                 // [k][128]: the second half's share of dP
     int* flag = reinterpret_cast<int*>(dPs + k * RN_CS);
     const long R = (long)a.B * kk;
@@ -341,15 +375,34 @@ __global__ void __launch_bounds__(256) rn_fc1_bwd_kernel(RnFc1BwdArgs a) {
     const int a0 = half ? (k + 1) / 2 : 0, a1 = half ? k : (k + 1) / 2;
     // pass 1: sum dy, sum dy x-hat over this program's pairs
     double s0 = 0.0, s1 = 0.0;
-    for (int j = a0 * k; j < a1 * k; ++j) {
-        const float d = a.dy1[base + (long)j * a.U], xh = (a.y1a[base + (long)j * a.U] - mu) * rs;
-        s0 += (double)d;
-        s1 += (double)d * (double)xh;
+    for (int ab = a0; ab < a1; ab += NA) {
+        float dv[NA][KC], yv[NA][KC];
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c < k) {
+                    const int aa = ab + i < a1 ? ab + i : a1 - 1;            // (past the half's rows: repeated, not added)
+                    const long o = base + (long)(aa * k + c) * a.U;
+                    dv[i][c] = a.dy1[o];
+                    yv[i][c] = a.y1a[o];
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c < k && ab + i < a1) {
+                    const float xh = (yv[i][c] - mu) * rs;
+                    s0 += (double)dv[i][c];
+                    s1 += (double)dv[i][c] * (double)xh;
+                }
+            }
     }
     if (half) { red[ch * 2] = s0; red[ch * 2 + 1] = s1; }
     __syncthreads();
     if (!half) { s0 += red[ch * 2]; s1 += red[ch * 2 + 1]; }
-    rn_exchange(a.part, a.counters, a.err, g.group(), a.B, g.b, s0, s1, flag);
+    rn_exchange(a.part, a.counters, a.err, g.group(), a.B, g.b, s0, s1, flag, red);
     if (tid < RN_CS) {
         cst[ch] = (float)(s0 / (double)R);
         cst[RN_CS + ch] = (float)(s1 / (double)R);
@@ -358,7 +411,13 @@ __global__ void __launch_bounds__(256) rn_fc1_bwd_kernel(RnFc1BwdArgs a) {
             a.dbeta[g.sc * a.pstride + u] = (float)s0;
             // fc2's bias gradient: the per-program column sums rn_fc2_bwd_kernel left, in program order
             float t = 0.f;
-            for (int bb = 0; bb < a.B; ++bb) t += a.dbpart2[((long)g.sc * a.B + bb) * a.U + u];
+            for (int b0 = 0; b0 < a.B; b0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) v[q] = b0 + q < a.B ? a.dbpart2[((long)g.sc * a.B + b0 + q) * a.U + u] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) t += v[q];
+            }
             a.dbias2[g.sc * a.pstride + u] = t;
         }
     }
@@ -370,36 +429,52 @@ __global__ void __launch_bounds__(256) rn_fc1_bwd_kernel(RnFc1BwdArgs a) {
     float tot = 0.f;
     // (dP accumulators over this half's a: in LDS columns of this thread -- k is a run-time value)
     float* myP = dPs + ch;                 // second half: its sums; first half adds them at the end
-    float dpacc[32];
+    float dpacc[KC];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) dpacc[c] = 0.f;
-    for (int aa = a0; aa < a1; ++aa) {
-        float dq = 0.f;
+    for (int c = 0; c < KC; ++c) dpacc[c] = 0.f;
+    for (int ab = a0; ab < a1; ab += NA) {
+        float dv[NA][KC], yv[NA][KC];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) {
-            if (c < k) {
-                const long o = base + (long)(aa * k + c) * a.U;
-                const float v = a.y1a[o];
-                const float xh = (v - mu) * rs;
-                float d = k1 * (a.dy1[o] - m1 - xh * m2);
-                d *= d2p_lrelu_grad_from_out(v);
-                dq += d;
-                dpacc[c] += d;
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int c = 0; c < KC; ++c) {
+                if (c < k) {
+                    const int aa = ab + i < a1 ? ab + i : a1 - 1;
+                    const long o = base + (long)(aa * k + c) * a.U;
+                    dv[i][c] = a.dy1[o];
+                    yv[i][c] = a.y1a[o];
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if (ab + i < a1) {
+                float dq = 0.f;
+#pragma unroll
+                for (int c = 0; c < KC; ++c) {
+                    if (c < k) {
+                        const float v = yv[i][c];
+                        const float xh = (v - mu) * rs;
+                        float d = k1 * (dv[i][c] - m1 - xh * m2);
+                        d *= d2p_lrelu_grad_from_out(v);
+                        dq += d;
+                        dpacc[c] += d;
+                    }
+                }
+                a.dQ[((long)g.sc * M + (long)g.b * k + ab + i) * a.U + u] = dq;
+                tot += dq;
             }
         }
-        a.dQ[((long)g.sc * M + (long)g.b * k + aa) * a.U + u] = dq;
-        tot += dq;
     }
     if (half) {
 #pragma unroll
-        for (int c = 0; c < 32; ++c)
+        for (int c = 0; c < KC; ++c)
             if (c < k) myP[c * RN_CS] = dpacc[c];
         reinterpret_cast<float*>(red)[ch] = tot;
     }
     __syncthreads();
     if (!half) {
 #pragma unroll
-        for (int c = 0; c < 32; ++c)
+        for (int c = 0; c < KC; ++c)
             if (c < k) a.dP[((long)g.sc * M + (long)g.b * k + c) * a.U + u] = dpacc[c] + myP[c * RN_CS];
         // fc1's bias gradient = sum over all rows: per-program column sums (write-through, as the exchange's partial sums:
         // no fence -- a release fence writes back the XCD's whole L2), the LAST program to arrive adds them in order
@@ -419,8 +494,15 @@ __global__ void __launch_bounds__(256) rn_fc1_bwd_kernel(RnFc1BwdArgs a) {
         const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
             a.dbpart + (long)g.sc * a.B * a.U, 0, a.B * a.U * (int)sizeof(float), 0x00020000);
         float t = 0.f;
-        for (int bb = 0; bb < a.B; ++bb)
-            t += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res, (bb * a.U + u) * 4, 0, RN_AUX_SC1));
+        for (int b0 = 0; b0 < a.B; b0 += 16) {        // sixteen loads in flight (one at a time: a memory round trip each)
+            float v[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+                v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                     res, b0 + q < a.B ? ((b0 + q) * a.U + u) * 4 : 0x7fffff00, 0, RN_AUX_SC1));
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += v[q];
+        }
         a.dbias[g.sc * a.pstride + u] = t;
     }
 }
@@ -458,7 +540,7 @@ extern "C" int d2p_rn_fc1_fwd(int B, int k, int U, const float* P, const float* 
     RnFc1FwdArgs a{B, k, U, P, Q, bias, gamma, beta, pstride, y1a, y1, mean, rstd, var, moving_mean, moving_var, decay,
                    (double*)ws, rn_counters(0, B), d2p_persist_err_ptr()};
     D2P_REQUIRE(a.counters, D2P_EINVAL, "rn: counters");
-    const size_t lds = (size_t)(2 * k * RN_CS) * sizeof(float) + 2 * RN_CS * sizeof(double) + 2 * RN_CS * sizeof(float) + 16;
+    const size_t lds = (size_t)(2 * k * RN_CS) * sizeof(float) + 4 * RN_CS * sizeof(double) + 2 * RN_CS * sizeof(float) + 16;
     hipStream_t st = as_stream(stream);
     D2pProfScope prof(st, D2P_PROF_BN, 2.0 * 2.0 * B * k * k * U * sizeof(float));
     hipLaunchKernelGGL(rn_fc1_fwd_kernel, dim3(2 * (U / RN_CS) * B), dim3(256), lds, st, a);
@@ -510,10 +592,11 @@ extern "C" int d2p_rn_fc1_bwd(int B, int k, int U, const float* y1a, const float
     RnFc1BwdArgs a{B, k, U, y1a, dy1, gamma, pstride, mean, rstd, dP, dQ, dgamma, dbeta, dbias, dbpart2, dbias2, dbpart,
                    (double*)((char*)ws + 2 * rn_part_bytes(B, U)), rn_counters(2, B), rn_counters(3, B), d2p_persist_err_ptr()};
     D2P_REQUIRE(a.counters && a.tickets, D2P_EINVAL, "rn: counters");
-    const size_t lds = 2 * RN_CS * sizeof(double) + (size_t)(2 * RN_CS + k * RN_CS) * sizeof(float) + 16;
+    const size_t lds = 4 * RN_CS * sizeof(double) + (size_t)(2 * RN_CS + k * RN_CS) * sizeof(float) + 16;
     hipStream_t st = as_stream(stream);
     D2pProfScope prof(st, D2P_PROF_BN, 2.0 * 2.0 * B * k * k * U * sizeof(float));
-    hipLaunchKernelGGL(rn_fc1_bwd_kernel, dim3(2 * (U / RN_CS) * B), dim3(256), lds, st, a);
+    if (k == 10) hipLaunchKernelGGL(rn_fc1_bwd_kernel<10>, dim3(2 * (U / RN_CS) * B), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(rn_fc1_bwd_kernel<0>, dim3(2 * (U / RN_CS) * B), dim3(256), lds, st, a);
     D2P_LAUNCH_CHECK("rn_fc1_bwd");
     return D2P_OK;
 }

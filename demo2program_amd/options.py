@@ -8,6 +8,12 @@ OBJECT by that tool (`Model.set_ablation`), and `Trainer.train` / `Evaler` refus
 
 tests/test_host_logic.py::test_every_environment_switch_is_declared checks that no other D2P_* name is read
 anywhere in the package.
+
+Not process switches: three attributes of a Model OBJECT that exist for the A side of a test's A/B and are never read
+from the environment -- `fused_encoder` (set from D2P_FUSED_ENCODER at construction), `fused_rn` (the relation networks'
+four-launch form; tests/test_model_gpu.py::test_relation_networks_in_four_launches_equal_the_separate_launches) and
+`decoder_skip_past_len` (a training step's decoders stop at a row's length;
+::test_training_step_decoders_skip_the_steps_past_a_rows_length).
 """
 import os
 
