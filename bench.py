@@ -184,7 +184,10 @@ def roofline_leg(trainer, feeds, steps=2, keep_side=False):
             # longest row, so the row-steps past a sequence's length are mostly not multiplied any more.  Rounds 1-2
             # multiplied (and counted) every row at every step -- the same count for this round's launches:
             dense = sum(recurrent_dense_flops(cfgm, feeds[i % len(feeds)]) for i in range(steps))
-            d['work_counts'] = 'executed row-steps (a row domain of a length-sorted backward launch runs only its longest row\'s steps)'
+            d['work_counts'] = ('executed row-steps (a row domain of a length-sorted launch runs only its longest row\'s steps: '
+                                'both encoders and every backward recurrence; round 5: in a training step also the action / '
+                                'perception decoders\' FORWARD recurrences -- 30 % fewer row-steps there in 14 % less time, so '
+                                'this fraction fell from 0.434 to ~0.42 while the family went from 1.36 to 1.33 ms per step)')
             d['frac_dense_rows'] = round(_rate(dense, g['total_ms'], 'mfma') / PEAK_F32_MFMA_TFLOPS, 4)
             d['frac_dense_rows_note'] = ('every row at every decoded step, the count of rounds 1-2 '
                                          '(2*M*4U*U per time step): comparable with their roofline.frac')
