@@ -1110,6 +1110,10 @@ class Model(object):
         """training mode, a geometry d2p_rn_* takes, and the switch the tests flip on a Model object"""
         if not (self.is_train and self.fused_rn):
             return False
+        # its exchange's bounded spin reports through the persistent kernels' status word: a step that is re-run after a
+        # time-out (the recurrences on the per-step kernels by then) must not meet the same barrier again -- as _fused_encoder
+        if not K.lstm_is_persistent():
+            return False
         key = (B, k, U)
         if key not in self._fused_rn_ok:
             self._fused_rn_ok[key] = K.rn_ok(B, k, U)
