@@ -12,7 +12,7 @@ void d2p_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int d2p_version(void) { return 1; }
+extern "C" int d2p_version(void) { return 2; }
 
 extern "C" const char* d2p_last_error(void) { return g_err; }
 

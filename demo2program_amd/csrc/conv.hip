@@ -239,6 +239,11 @@ extern "C" int d2p_conv_bn_slices(int N, int H, int W, int Cin, int Cout, int G,
     if (Cin == 4 && Cout == 16 && W == 80) units = (long)N / G * g.Ho;
     else if (Cin == 16 && Cout == 32 && H * W >= 400 && (seq * g.Ho * g.Wo) % 16 == 0) units = (long)N / G * g.Ho * g.Wo / 16;
     else return 0;
+    // what the folding launches themselves require of the geometry (conv_direct.hip direct_bn_ok: whole 16-pixel tiles per
+    // sequence, four at least; 32-bit element offsets incl. the pad pixels behind the tensor) -- answered HERE, so that a
+    // caller that asks first never meets D2P_EINVAL from the launch
+    if ((seq * g.Ho * g.Wo) % 16 != 0 || seq * g.Ho * g.Wo / 16 < 4) return 0;
+    if ((size_t)N * H * W * Cin + (size_t)G * Cin >= (1ull << 32)) return 0;
     // ~2048 workgroups (8 per CU) of >= 16 units each, as the plain launches of these kernels
     long S = 2048 / G;
     if (S * 16 > units) S = units / 16;

@@ -512,8 +512,16 @@ bool rn_geom_ok(int B, int k, int U) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
         return false;
-    // 256-thread workgroups with < 32 KB of LDS: four fit a CU beside each other; the exchange needs them all resident
-    return 2L * (U / RN_CS) * B <= 2L * cus;
+    // the exchange needs every workgroup resident: at most two per CU are counted on, and only where two of the LARGEST
+    // dynamic-LDS request of the four kernels (rn_fc1_fwd: 2 k 512 + 5136 bytes -- 37.9 KB at k = 32) fit a CU's LDS
+    // beside each other (gfx950: 160 KB; a 64 KB part holds one such workgroup for k >= 27) -- ADVICE round 5
+    int lds_cu = 0;
+    if (hipDeviceGetAttribute(&lds_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess || lds_cu <= 0)
+        lds_cu = 64 * 1024;
+    const long lds_wg = (long)(2 * k * RN_CS) * (long)sizeof(float) + 4 * RN_CS * (long)sizeof(double) +
+                        2 * RN_CS * (long)sizeof(float) + 16;
+    const long per_cu = lds_cu / lds_wg >= 2 ? 2 : (lds_cu / lds_wg >= 1 ? 1 : 0);
+    return 2L * (U / RN_CS) * B <= per_cu * cus;
 }
 size_t rn_part_bytes(int B, int U) { return (size_t)2 * (U / RN_CS) * B * RN_CS * 2 * sizeof(double); }
 unsigned long long* rn_counters(int kind, int B) {

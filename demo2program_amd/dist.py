@@ -93,15 +93,29 @@ class DataParallel(object):
     def prescale(self):
         return 1.0 / self.world_size
 
+    @staticmethod
+    def _through_host(t, collective):
+        """TEST-ONLY path: a gloo group handed a DEVICE buffer (two ranks sharing the one GPU of the test box,
+        tests/test_dp_two_ranks_gpu.py) stages it through pageable host memory.  SYNCHRONOUS: the copy out waits for
+        everything on the current stream, the host blocks in the collective, the copy back is stream-ordered in front of
+        what follows -- there is no work handle and nothing overlaps.  Production ranks run RCCL (backend 'nccl') on the
+        device buffer and never come here."""
+        host = t.detach().cpu()
+        collective(host)
+        t.copy_(host)
+
     def _reduce(self, t, op, async_op=False):
-        """dist.all_reduce of `t` in place.  RCCL takes the device buffer; a gloo group given a device buffer (two ranks
-        sharing one GPU) stages it through host memory, synchronously: the copy out waits for the stream's work so far,
-        the copy back is stream-ordered in front of whatever follows."""
+        """dist.all_reduce of `t` in place; returns the work handle of an asynchronous RCCL reduce, else None.
+        async_op is IGNORED on the gloo device path (_through_host: synchronous, test-only) -- D2P_DP_OVERLAP=1 on such a
+        group is correct but serialises the host in the middle of backward; a warning says so once."""
         import torch.distributed as dist
         if t.is_cuda and dist.get_backend() != 'nccl':
-            host = t.detach().cpu()              # (synchronises with the current stream)
-            dist.all_reduce(host, op=op)
-            t.copy_(host)
+            if async_op and not getattr(self, '_warned_sync', False):
+                self._warned_sync = True
+                print('[demo2program_amd] all_reduce_start on a %s group with a device buffer is synchronous (staged '
+                      'through host memory): nothing overlaps -- the overlap schedule needs RCCL' % dist.get_backend(),
+                      file=sys.stderr)
+            self._through_host(t, lambda host: dist.all_reduce(host, op=op))
             return None
         return dist.all_reduce(t, op=op, async_op=async_op)
 
@@ -147,9 +161,7 @@ class DataParallel(object):
         if self.world_size > 1 or self.initialized:
             import torch.distributed as dist
             if flat_params.is_cuda and dist.get_backend() != 'nccl':
-                host = flat_params.detach().cpu()
-                dist.broadcast(host, src=src)
-                flat_params.copy_(host)
+                self._through_host(flat_params, lambda host: dist.broadcast(host, src=src))
             else:
                 dist.broadcast(flat_params, src=src)
         return flat_params

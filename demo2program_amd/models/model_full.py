@@ -144,6 +144,7 @@ class Model(object):
         self._bufs = {}
         self._feed = None
         self._ctx = None
+        self.forward_count = 0                # forward passes so far (trainer.StepOutput: is a step's output still there?)
         self._conv = conv_shapes(config)
         self._fused_enc_ok = {}
         self._fused_rn_ok = {}
@@ -431,6 +432,7 @@ class Model(object):
             feed['per_gram'] = self._buf('feed/per_gram', (self.per_cols, self.per_cols))
             self.derive_per_rows(feed)
         ctx = {'feed': feed}
+        self.forward_count += 1
         lens_d, lens_p = feed['demo_len'], feed['program_len']
         n_p, n_d = feed['n_prog'], feed['n_demo']
         # the demonstrations by decreasing length (with the feed): the encoders' forward and every backward recurrence
@@ -682,7 +684,11 @@ class Model(object):
             # their longest row's steps; hout is zero there, as TF's impute_finished would leave it).  forward() outside
             # a training step, evaluation and the baselines keep the reference's free-running outputs past a row's
             # length (BasicDecoder without impute_finished, models/model_full.py:465-471).
-            # (whatever the stream schedule: the one-stream instrumented pass and a captured step take it too)
+            # (whatever the STREAM schedule -- the one-stream instrumented pass takes it too.  EAGER launches only: a
+            #  graph-static feed carries no demo_slab_steps, fwd_order is None and a captured step (D2P_GRAPH=1) runs every
+            #  row to the last decoded step.  So ctx['da' | 'dq']['hout'] past a row's length is schedule-dependent -- zeros
+            #  here, the free-running output there -- and nothing may consume it: loss, gradients and the weight-gradient
+            #  products all mask it)
             skip = ({'act': (lens_d, fwd_order), 'per': (lens_d, fwd_order)}
                     if (defer_loss and self.is_train and fwd_order is not None and self.decoder_skip_past_len) else None)
             dp, da, dq = self._decoders_fwd(specs, logits=False, skip_past=skip)
@@ -1953,6 +1959,8 @@ class Model(object):
         c = self.config
         B, k, T = c.batch_size, c.k, c.max_demo_len
         out = [f['program'], self.pred_program]
+        if not self.multitask:                # the baselines: the program pair alone (model_synthesis.py / model_summarizer.py)
+            return out
         pa, pq = self.pred_action, self.pred_per
         gt_a = f['a_h'].view(B, k, T, self.action_space)
         gt_q = f['per'].view(B, k, T, self.per_dim)

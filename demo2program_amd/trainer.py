@@ -114,6 +114,39 @@ def _device_sync():
     torch.cuda.synchronize()
 
 
+class StepOutput(object):
+    """The `output` slot of run_single_step / run_test (trainer.py:191-192,217-219 fetch `self.model.output`: the
+    [ground truth, prediction] pairs of the program, the k action and the k perception decoders,
+    models/model_full.py:919-933,1034,1077) as a LAZY list of numpy arrays: nothing is computed or copied until an
+    element is read -- the reference's own train loop never reads it (trainer.py:163-166) -- and it must be read before
+    the next forward pass of the model (afterwards the buffers hold another batch: RuntimeError).
+
+    After a TRAINING step the action / perception predictions are zero past a row's own length where the reference's
+    decoders are free-running up to the call's max(len) (BasicDecoder without impute_finished,
+    models/model_full.py:465-471): Trainer.train_step does not run those steps (nothing in the step reads them).
+    `model.decoder_skip_past_len = False` before the step, or `model.forward(feed)` outside a step -- what run_test
+    does -- gives the free-running values."""
+
+    def __init__(self, model):
+        self._model, self._pass, self._items = model, model.forward_count, None
+
+    def _get(self):
+        if self._items is None:
+            if self._model.forward_count != self._pass:
+                raise RuntimeError('this step\'s output was not read before the next forward pass of the model')
+            self._items = [t.detach().cpu().numpy() for t in self._model.output]
+        return self._items
+
+    def __len__(self):
+        return 2 * (1 + 2 * self._model.k) if self._model.multitask else 2
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
+
+
 class StepGuard(object):
     """Host side of the guarded optimizer step (include/d2p.h: d2p_adam_clip_flat_guarded).
 
@@ -541,7 +574,8 @@ class Trainer(object):
             if redo is not None:
                 loss_value = float(redo.item())
         _end_time = time.time()
-        return self.global_step, None, loss_value, None, (_end_time - _start_time)
+        # (summary: the reference's serialized 'train' collection; here Model.report() builds it on write steps only)
+        return self.global_step, None, loss_value, StepOutput(self.model), (_end_time - _start_time)
 
     def run_test(self, batch):
         """trainer.py:207-225: the training-mode graph on a test batch, no parameter update
@@ -575,7 +609,7 @@ class Trainer(object):
             finally:
                 K.lstm_set_persistent(was)
         _end_time = time.time()
-        return self.global_step, self.last_test_report, loss_value, None, (_end_time - _start_time)
+        return self.global_step, self.last_test_report, loss_value, StepOutput(self.model), (_end_time - _start_time)
 
     def train(self, max_steps=1000000, prefetch=True):
         if getattr(self.model, '_ablate', None):

@@ -48,7 +48,10 @@ extern "C" {
 typedef void* d2p_stream_t; /* hipStream_t */
 
 /* ---- library ------------------------------------------------------------------ */
-int d2p_version(void);                 /* ABI version, currently 1 */
+/* ABI version, currently 2.  History -- 1: rounds 1-4.  2 (round 5/6): d2p_gemm_set_corun removed; the bit layout of
+ * d2p_gemm_set_option changed (the LDS-DMA grid moved from bits 8.. to bits 16.., bit 7 = the embedding gradient stays a
+ * one-hot GEMM): a caller written against version 1 that passes a grid in bits 8.. must be updated. */
+int d2p_version(void);
 const char* d2p_last_error(void);      /* thread-local, never NULL */
 /* Fills: name (<=255 chars), number of CUs, wavefront size, HBM bytes.  HOST pointers. */
 int d2p_device_info(int device, char* name, int name_len, int* cus, int* wave, size_t* hbm_bytes);

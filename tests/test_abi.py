@@ -31,7 +31,7 @@ def test_header_matches_ctypes_table():
 def test_library_loads_and_exports_everything(d2p_lib):
     for name in _header_prototypes():
         assert hasattr(d2p_lib, name), name
-    assert d2p_lib.d2p_version() == 1
+    assert d2p_lib.d2p_version() == 2        # (2: d2p_gemm_set_option bit layout, include/d2p.h)
     assert d2p_lib.d2p_last_error() is not None
 
 

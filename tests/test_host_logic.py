@@ -192,6 +192,10 @@ def test_every_environment_switch_is_declared():
         text = open(os.path.join(root, path)).read()
         assert ('def %s(' % fn) in text, (name, test)
         assert name in text or fn in ('test_bench_starts_its_own_ranks',), (name, test)
+    # INTEGRATION.md names exactly the declared switches (it listed six deleted ones)
+    doc = set(re.findall(r'D2P_[A-Z][A-Z0-9_]+', open(os.path.join(root, 'INTEGRATION.md')).read()))
+    doc -= {n for n in doc if n.startswith('D2P_E')}            # the C ABI's error codes (D2P_EINVAL, ...)
+    assert doc == set(options.SWITCHES), (sorted(doc - set(options.SWITCHES)), sorted(set(options.SWITCHES) - doc))
 
 
 def test_trainer_and_evaler_refuse_an_ablated_model():

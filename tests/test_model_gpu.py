@@ -334,6 +334,55 @@ def test_output_list_and_dynamic_padding():
     assert _maxerr(model.pred_action, out2['pred_action'].permute(0, 1, 3, 2)) <= 1e-4
 
 
+def test_run_single_step_and_run_test_return_the_output_pairs():
+    """trainer.py:186-225: both return (step, summary, loss, output, step_time) with output = the fetched
+    `model.output`.  Here the slot is a lazy list (StepOutput): read after a TRAINING step it holds the step's own
+    (pre-update) predictions -- the oracle's inside every row's length, zeros past it for the action / perception
+    decoders (documented deviation: the step does not run a row past its length) --, after run_test the reference's
+    free-running values everywhere; reading it after a later forward pass raises."""
+    from demo2program_amd.trainer import Trainer, StepOutput
+    cfg, params, batch = small_case('karel', seed=5, num_lstm_cell_units=128)
+    batch['demo_len'][0, 0] = 2                               # (some row shorter than its demonstration index's longest)
+
+    class One(object):
+        def next(self):
+            return batch
+
+    k, T = cfg.k, cfg.max_demo_len
+    ref, _ = run_oracle(cfg, params, batch, dtype=torch.float64)
+    tr = Trainer(cfg, dataset=One(), dataset_test=One(), make_train_dir=False)
+    tr.model.params.load(params)
+    step, summary, loss, output, dt = tr.run_single_step(One())
+    assert isinstance(output, StepOutput) and len(output) == 2 + 4 * k and step == 1
+    got = list(output)
+    assert all(isinstance(a, np.ndarray) for a in got)
+    assert np.abs(got[1] - ref['pred_program'].numpy()).max() <= 1e-4
+    dlen = np.asarray(batch['demo_len']).reshape(cfg.batch_size, k).astype(int)
+    inside = np.arange(T)[None, None, :] < dlen[:, :, None]                      # [B, k, T]
+    for i in range(k):
+        assert np.array_equal(got[2 + 2 * i], np.asarray(batch['a_h'])[:, i].transpose(0, 2, 1))
+        for j, name in ((2 + 2 * i + 1, 'pred_action'), (2 + 2 * k + 2 * i + 1, 'pred_per')):
+            want = ref[name][:, i].numpy()                                        # [B, A, T]
+            m_in = inside[:, i][:, None, :]
+            assert np.abs(np.where(m_in, got[j] - want, 0)).max() <= 1e-4, name
+            assert np.abs(np.where(m_in, 0, got[j])).max() == 0, name             # zeros past a row's own length
+    # run_test: the training-mode graph without the skip -> the reference's values everywhere (parameters have moved
+    # by one step: against a fresh oracle pass on them)
+    after = tr.model.params.to_numpy('p')
+    ref2, _ = run_oracle(cfg, after, batch, dtype=torch.float64)
+    _, report, _, out_t, _ = tr.run_test(One())
+    got_t = list(out_t)
+    for i in range(k):
+        assert np.abs(got_t[2 + 2 * i + 1] - ref2['pred_action'][:, i].numpy()).max() <= 1e-4
+        assert np.abs(got_t[2 + 2 * k + 2 * i + 1] - ref2['pred_per'][:, i].numpy()).max() <= 1e-4
+    assert dlen[:, 0].max() > 2 and np.abs(got_t[3][0, :, 2:dlen[:, 0].max()]).max() > 0     # free-running past row 0's length
+    # stale: an output not read before the next forward pass
+    _, _, _, stale, _ = tr.run_single_step(One())
+    tr.run_single_step(One())
+    with pytest.raises(RuntimeError):
+        stale[0]
+
+
 def test_trainer_steps_match_oracle_adam():
     """Three optimizer steps (clip 20 + Adam) against the oracle's optimizer, and the loss
     goes down on a repeated batch."""
@@ -745,6 +794,74 @@ def test_headline_config_matches_oracle_at_full_size():
     for n in grads:
         ref = grads[n].numpy()
         assert np.abs(got[n] - ref).max() <= 2e-4 * np.abs(ref).max() + 5e-7, (n, float(np.abs(ref).max()))
+
+
+def _one_training_step_against_oracle(cfg, params, batch):
+    """ONE Trainer.train_step -- the schedule bench.py times: two streams, logits deferred into the loss-backward launch,
+    the loss value out of that launch, action / perception decoders stopped at a row's own length, one-launch
+    State_Encoder / relation networks where the geometry has them -- from given parameters on a given batch; its loss
+    and every gradient tensor it leaves in params.grad against the fp64 oracle, then the parameters after the step
+    against the oracle's clip(20) + Adam."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.trainer import Trainer
+    tr = Trainer(cfg, make_train_dir=False, use_graph=False)
+    m = tr.model
+    m.params.load(params)
+    feed = m.get_feed_dict(batch)
+    loss = float(tr.train_step(feed).item())
+    torch.cuda.synchronize()
+    assert tr.settle() == 0 and K.lstm_persist_error() == 0           # nothing fell back to the per-step kernels
+    # the step really took the timed schedule
+    ctx = m._ctx
+    assert m.use_side_stream and m._side_stream() != torch.cuda.current_stream()
+    assert ctx['logits_deferred'] and m.fused_loss and m.decoder_skip_past_len and K.lstm_is_persistent()
+    assert ctx['da']['row_order'] is not None
+    if feed['n_active_pad'] and feed['n_t1_pad']:
+        assert ctx['klists'].get('demo') is not None
+    assert int(tr.guard.counters[0].item()) == 1 and int(tr.guard.counters[1].item()) == 0
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    out, grads = run_oracle(cfg, params, batch, dtype=torch.float64)
+    ref = float(out['loss'])
+    assert abs(loss - ref) <= 1e-5 * abs(ref) + 1e-6, (loss, ref)
+    got = m.params.to_numpy('g')
+    assert set(got) == set(grads)
+    for n in grads:
+        r = grads[n].double().numpy()
+        assert np.abs(got[n] - r).max() <= 2e-4 * np.abs(r).max() + 5e-7, (n, float(np.abs(r).max()))
+    # ... and the optimizer step it applied: the oracle's clip + Adam from the oracle's gradients.  Adam's first update
+    # is lr * g / (|g| + eps) -- sign-like -- so an element whose gradient is at fp32-noise level may move by up to lr
+    # either way: the bulk within 2e-5, every element within 2 lr
+    p64 = {n: torch.from_numpy(v).double() for n, v in params.items()}
+    mom = {n: torch.zeros_like(v) for n, v in p64.items()}
+    var = {n: torch.zeros_like(v) for n, v in p64.items()}
+    oracle.adam_clip_step(p64, grads, mom, var, 1, cfg.learning_rate)
+    after = m.params.to_numpy('p')
+    for n in p64:
+        diff = np.abs(after[n] - p64[n].numpy())
+        assert diff.max() <= 2.02 * cfg.learning_rate, n
+        assert (diff > 2e-5).sum() <= max(2, 0.02 * diff.size), (n, int((diff > 2e-5).sum()), diff.size)
+    return tr
+
+
+def test_one_training_step_matches_oracle_at_full_size():
+    """BASELINE config 2 at its FULL size through Trainer.train_step (what bench.py times), not Model.forward +
+    backward: loss 1e-5 rel, every gradient 2e-4 max|g| + 5e-7 -- the bounds of
+    test_headline_config_matches_oracle_at_full_size."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.karel_env.generator import sample_batch
+    from demo2program_amd.params import init_params
+    cfg = make_config('karel')
+    tr = _one_training_step_against_oracle(cfg, init_params(cfg, 123), sample_batch(cfg, seed=11))
+    assert tr.model._ctx.get('enc_fused') and tr.model._ctx['rn_h'].get('fused')     # the one-launch forms ran
+
+
+def test_one_training_step_matches_oracle_at_the_vizdoom_geometry():
+    """The same at BASELINE config 4's frame geometry (80x80x3, five conv layers with the batch norm folded into the
+    conv launches), at a batch the fp64 oracle finishes in seconds."""
+    cfg, params, batch = small_case('vizdoom', seed=53, h=80, w=80, batch_size=2, k=3, max_demo_len=4, max_program_len=6,
+                                    num_lstm_cell_units=128)
+    tr = _one_training_step_against_oracle(cfg, params, batch)
+    assert 'conv1/bn_partial' in tr.model._bufs
 
 
 def test_headline_config_properties():
@@ -1333,7 +1450,7 @@ def test_one_launch_state_encoder_equals_the_separate_launches(monkeypatch):
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize('model_kind', ['full', 'summarizer', 'full_k25', 'full_k3'])
+@pytest.mark.parametrize('model_kind', ['full', 'summarizer', 'full_k25', 'full_k3', 'full_k28'])
 def test_relation_networks_in_four_launches_equal_the_separate_launches(model_kind):
     """Round 5: the relation networks' pointwise chains around their two GEMMs as d2p_rn_fc1_fwd / _fc2_fwd / _fc2_bwd /
     _fc1_bwd (batch-norm sums from recomputed pair values, batch norm commuted with the mean over a program's pairs,
@@ -1351,6 +1468,8 @@ def test_relation_networks_in_four_launches_equal_the_separate_launches(model_ki
         kw.update(batch_size=8, k=25)
     if model_kind == 'full_k3':
         kw.update(batch_size=5, k=3)
+    if model_kind == 'full_k28':          # (rn_fc1_fwd asks for > 32 KB of LDS from k = 27 on: the residency bound of
+        kw.update(batch_size=6, k=28)     #  rn_geom_ok counts workgroups per CU from the real request -- ADVICE round 5)
     cfg = make_config('karel', **kw)
     if not K.rn_ok(kw['batch_size'], kw['k'], 128):
         pytest.skip('geometry not taken by the four-launch form on this device')
