@@ -48,7 +48,7 @@ EMPTY_LAUNCH_US = 2.7          # a dependent empty launch on one stream (DESIGN.
 # kernel family -> key in profiles/*_pmc_traffic.json (tools/pmc_summary.py)
 PMC_KEYS = {1: 'gemm_mfma_kernel', 2: 'gemm_mfma_kernel<conv>', 7: 'lstm_persist_fwd_kernel',
             8: 'lstm_persist_bwd_kernel', 3: 'lstm_gate_fwd_kernel', 4: 'lstm_gate_bwd_kernel'}
-PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json',
+PMC_FILES = [os.path.join(ROOT, 'profiles', n) for n in ('r06_pmc_traffic.json', 'r05_pmc_traffic.json', 'r04_pmc_traffic.json', 'r03_pmc_traffic.json', 'r02_pmc_traffic.json',
                                                          'r01_pmc_traffic.json')]
 
 # profiling key (include/d2p.h) -> (name, roofline that bounds it, reporting group)
@@ -87,11 +87,16 @@ def pmc_traffic(family):
 
 def pmc_family_traffic(patterns, tag):
     """HBM MB per STEP of the kernels whose name holds one of `patterns`, from the committed PMC passes of `bench.py
-    --preset <tag>` (profiles/r05_pmc_traffic_<tag>.json, tools/profile_vizdoom.sh); None if not collected."""
-    path = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic_%s.json' % tag)
-    try:
-        d = json.load(open(path))
-    except (OSError, ValueError):
+    --preset <tag>` (profiles/r06_pmc_traffic_<tag>.json, else round 5's; tools/profile_vizdoom.sh); None if not collected."""
+    d = path = None
+    for rnd in ('r06', 'r05'):
+        path = os.path.join(ROOT, 'profiles', '%s_pmc_traffic_%s.json' % (rnd, tag))
+        try:
+            d = json.load(open(path))
+            break
+        except (OSError, ValueError):
+            continue
+    if d is None:
         return None
     steps = d.get('_meta', {}).get('steps')
     if not steps:
@@ -385,14 +390,14 @@ def recurrent_step_microbench(M, U, T):
     return res
 
 
-def config4_leg(steps=10, warmup=3):
-    """BASELINE config 4 (ViZDoom full model, k=10, 80x80x3 frames, B=32) in the same run: ms/step of the
-    same optimizer step, inputs resident in HBM, and the conv encoder's fraction of the fp32 MFMA peak
-    from an instrumented pass."""
+def config4_leg(steps=10, warmup=3, preset='vizdoom'):
+    """BASELINE config 4 (ViZDoom full model, k=10, 80x80x3 frames, B=32; preset 'vizdoom_k25': config 5's per-rank
+    shape, k=25, B=16) in the same run: ms/step of the same optimizer step, inputs resident in HBM, and the conv
+    encoder's fraction of the fp32 MFMA peak from an instrumented pass."""
     from demo2program_amd.config import make_config
     from demo2program_amd.synthetic import make_batch
     from demo2program_amd.trainer import Trainer
-    cfg = make_config('vizdoom')
+    cfg = make_config(preset)
     tr = Trainer(cfg, make_train_dir=False)
     batches = [make_batch(cfg, seed=321 + i) for i in range(2)]
     for b in batches:
@@ -430,7 +435,7 @@ def config4_leg(steps=10, warmup=3):
             'launches_per_step': conv[0]['launches_per_step'] + (bn[0]['launches_per_step'] if bn else 0),
             'note': 'bn_ms includes the relation networks\' and the perception encoder\'s batch norms (small)',
             'algorithmic_fwd_MB': 2776, 'algorithmic_fwd_MB_source': 'SURVEY.md 8(d): conv stack with two-pass batch norm',
-            'hbm_traffic': pmc_family_traffic(('conv_', 'bn_', '<conv>'), 'vizdoom')}
+            'hbm_traffic': pmc_family_traffic(('conv_', 'bn_', '<conv>'), preset)}
     res['kernel_table'] = table
     del tr
     torch.cuda.empty_cache()
@@ -688,7 +693,26 @@ def main():
             out['north_star_targets'] = north_star_targets(config, table)
     if dp.rank == 0 and dp.world_size == 1 and args.preset == 'karel' and not args.no_config4:
         log('config 4 (ViZDoom 80x80x3) leg')
-        out['config4_vizdoom'] = config4_leg()
+        c4 = out['config4_vizdoom'] = config4_leg()
+        # the numbers of that leg that matter, at the TOP level of the line ...
+        out['config4_ms_per_step'], out['config4_value'] = c4['ms_per_step'], c4['value']
+        if 'conv_encoder' in c4:
+            out['config4_conv_frac'] = c4['conv_encoder']['frac']
+            out['config4_conv_bn_ms'] = c4['conv_bn_encoder']['ms_per_step']
+            out['config4_bn_launches'] = next((r['launches_per_step'] for r in c4['kernel_table'] if r['group'] == 'bn'), 0)
+            tr_ = c4['conv_bn_encoder'].get('hbm_traffic')
+            # measured conv + batch-norm HBM bytes per step / the algorithmic bytes (2 776 MB forward with a
+            # two-pass batch norm; backward reads / writes each tensor about twice more -> x3)
+            out['config4_traffic_ratio'] = round(tr_['MB_per_step'] / (3 * 2776.0), 3) if tr_ else None
+        log('config 5 per-rank shape (ViZDoom k=25, B=16) leg')
+        c5 = config4_leg(steps=5, warmup=2, preset='vizdoom_k25')
+        c5.pop('kernel_table', None)
+        out['config5_per_rank_vizdoom_k25'] = c5
+        out['config5_rank_ms_per_step'], out['config5_rank_value'] = c5['ms_per_step'], c5['value']
+        # ... and inside `config`, which the driver's record keeps whole
+        out['config']['also_measured_in_this_run'] = {n: out.get(n) for n in (
+            'config4_ms_per_step', 'config4_value', 'config4_conv_frac', 'config4_conv_bn_ms', 'config4_traffic_ratio',
+            'config5_rank_ms_per_step', 'config5_rank_value')}
     if dp.rank == 0 and dp.world_size == 1 and not args.no_cpu_baseline:
         from demo2program_amd.params import init_params
         log('cpu baseline leg (%d host cores)' % (os.cpu_count() or 1))
@@ -697,7 +721,13 @@ def main():
         out['invalid'] = 'timing-only ablation: the step leaves out %s -- not a throughput of the model' % args.ablate
         out['value'] = None
     if dp.rank == 0:
-        print(json.dumps(out))
+        # the long tables first, the contract fields and the summary numbers LAST: a reader who keeps only the tail of
+        # the line still sees them
+        bulky = ('kernel_table', 'north_star_targets', 'config4_vizdoom', 'config5_per_rank_vizdoom_k25',
+                 'roofline_every_group', 'furthest_below_roofline')
+        ordered = {n: out[n] for n in bulky if n in out}
+        ordered.update({n: v for n, v in out.items() if n not in bulky})
+        print(json.dumps(ordered))
     dp.shutdown()
 
 
