@@ -235,6 +235,7 @@ extern "C" int d2p_conv2d_nhwc_s2_same_fwd(int N, int H, int W, int Cin, int Cou
 extern "C" int d2p_conv_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq) {
     if (N <= 0 || G <= 0 || seq <= 0 || N % (G * seq) != 0) return 0;
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
+    if (Cout == 48) return d2p_conv_wide_bn_slices(g, G, seq);      // (the 48-channel layers: conv_wide.hip)
     long units;                                  // work units of one index: strips (first layer) or 16-pixel tiles
     if (Cin == 4 && Cout == 16 && W == 80) units = (long)N / G * g.Ho;
     else if (Cin == 16 && Cout == 32 && H * W >= 400 && (seq * g.Ho * g.Wo) % 16 == 0) units = (long)N / G * g.Ho * g.Wo / 16;

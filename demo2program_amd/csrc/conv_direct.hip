@@ -721,6 +721,8 @@ int d2p_conv_direct_fwd(const ConvGeom& g, const void* x, int x_is_u8, const flo
         // separate launches)
         int rc = d2p_conv_rows_fwd(g, x, x_is_u8, w, bias, act, y, st, bn);
         if (rc != 0) return rc;
+        rc = d2p_conv_wide_fwd(g, x, x_is_u8, w, bias, act, y, st, bn);        // (the 48-channel layers, round 6)
+        if (rc != 0) return rc;
         if (x_is_u8 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
         if (g.Cin == 16 && g.Cout == 32 && g.H * g.W >= 400) return launch_fwd_bn<16, 32, 0x1FF>(g, (const float*)x, w, bias, act, y, st, *bn);
         return 0;
@@ -730,6 +732,8 @@ int d2p_conv_direct_fwd(const ConvGeom& g, const void* x, int x_is_u8, const flo
         int rc = d2p_conv_frames_fwd(g, x, x_is_u8, w, bias, act, y, st);
         if (rc != 0) return rc;
         rc = d2p_conv_rows_fwd(g, x, x_is_u8, w, bias, act, y, st);
+        if (rc != 0) return rc;
+        rc = d2p_conv_wide_fwd(g, x, x_is_u8, w, bias, act, y, st);
         if (rc != 0) return rc;
     }
     if (((uintptr_t)x & (x_is_u8 ? 3 : 15)) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
@@ -780,7 +784,9 @@ int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, fl
     if (bn) return d2p_conv_rows_dgrad(g, dy, w, dx, st, bn);      // (statistics out: the row-strip kernel only)
     if (!g_direct_dgrad) return 0;
     if (g_direct_dgrad >= 2) {
-        const int rc = d2p_conv_rows_dgrad(g, dy, w, dx, st);
+        int rc = d2p_conv_rows_dgrad(g, dy, w, dx, st);
+        if (rc != 0) return rc;
+        rc = d2p_conv_wide_dgrad(g, dy, w, dx, st);            // (the 48-channel layers, round 6)
         if (rc != 0) return rc;
     }
     if (((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return 0;

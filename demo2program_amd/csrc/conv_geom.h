@@ -84,6 +84,13 @@ void d2p_conv_rows_dgrad_tune(int workgroups);
 void d2p_conv_rows_tune(int wgrad_workgroups);
 void d2p_conv_frames_wgrad_cap(int cap);
 
+// Wide back end (conv_wide.hip, round 6): the 48-output-channel layers (32 -> 48, 48 -> 48), filter in LDS; same return
+// convention.  bn (optional): statistics out and / or the input read through the previous layer's batch-norm apply.
+int d2p_conv_wide_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act, float* y,
+                      hipStream_t st, const ConvBnFold* bn = nullptr);
+int d2p_conv_wide_bn_slices(const ConvGeom& g, int G, int seq);
+int d2p_conv_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
+
 // floor(n / d) for 0 <= n < 2^31 and d >= 1 by multiply-high + shift (exact: m = ceil(2^(31+s) / d),
 // s = ceil(log2 d)).  An integer division costs ~25 VALU instructions on gfx950; the implicit-GEMM
 // loaders decompose a row / column index several times per 16-byte load (VALU : MFMA was 10-38 : 1).

@@ -1,0 +1,464 @@
+// K1 (wide back end, round 6): the 48-channel layers of the ViZDoom State_Encoder -- conv3 32 -> 48 on 20x20,
+// conv4 / conv5 48 -> 48 on 10x10 / 5x5 frames (models/ops.py:27-33 called from models/model_full.py:216-231),
+// 3x3 stride 2 TF-"SAME".  640 k x 288 x 48, 160 k x 432 x 48 and 57.6 k x 432 x 48 as GEMMs: on the generic
+// implicit-GEMM kernel a quarter of every 64-wide tile multiplies zeros (N = 48) and its im2col loaders decompose an
+// index per 16-byte load -- 0.34-0.38 of the fp32 MFMA peak at conv3 (profiles/r05h_kernel_stats_vizdoom.md).  The
+// register-resident-filter kernels of conv_direct.hip stop at 16 -> 32: a 32 -> 48 filter is 216 registers per lane.
+//
+// Here the FILTER LIVES IN LDS, in MFMA fragment order, shared by the workgroup's eight waves:
+//   * v_mfma_f32_16x16x4_f32 with the filter as the A operand and 16 output pixels as B, N = 48 as three 16-channel
+//     blocks: D = [channel][pixel], a lane ends with 4 consecutive channels of one pixel = one 16-byte NHWC store;
+//   * a wave owns whole 16-pixel tiles (all K, all 48 channels): no partial sums, no barrier in the loop; its B operand
+//     is gathered HBM/L2 -> VGPR with one 16-byte load per (pixel, tap, 4 channels) as in conv_direct.hip, the A
+//     fragments are lane-linear ds_read_b128 (one per 4 MFMAs, conflict-free);
+//   * two to four waves per SIMD: one wave's gather latency and epilogue sit under the others' MFMA chains (a wave
+//     keeps ONE tile's operands in registers: 72 / 108 of them);
+//   * the batch-norm folding of round 5 (ConvBnFold, conv_geom.h) carries over: tiles are dealt out by demonstration
+//     index, STATS leaves the fp64 (sum, sum of squares) partials of the launch's own outputs, AFFINE reads the input
+//     through the previous layer's batch-norm apply at no cost in the loop (scale folded into the LDS filter copy,
+//     shift / scale added to what is loaded, out-of-image taps load the index's pad pixel).  Sequences whose pixel count
+//     is not a multiple of 16 (10x10 -> 5x5: 500 pixels per sequence of 20 frames) end in a ragged, masked tile.
+#include "conv_geom.h"
+#include "gemm_core.h"
+#include "prof.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define D2P_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define D2P_OPAQUE_U(v) asm volatile("" : "+v"(v))
+
+namespace {
+
+constexpr int WCO = 48;          // output channels of every layer here
+constexpr int WNB = 3;           // 16-channel blocks
+// waves per workgroup: three per SIMD at 32 input channels (153 registers), two at 48 (211)
+constexpr int wide_waves(int cin) { return cin == 32 ? 12 : 8; }
+
+struct WDiv {
+    uint32_t m;
+    int s;
+};
+WDiv make_wdiv(int d) {
+    WDiv f;
+    f.s = 0;
+    while ((1L << f.s) < d) ++f.s;
+    const uint64_t num = 1ULL << (31 + f.s);
+    f.m = (uint32_t)((num + d - 1) / d);
+    return f;
+}
+__device__ __forceinline__ int wdiv(int n, WDiv f) { return (int)((uint32_t)(((uint64_t)(uint32_t)n * f.m) >> 31) >> f.s); }
+
+struct WideGeom {
+    int N, H, W, Ho, Wo, pt, pl, P;
+    WDiv d_howo, d_wo;
+};
+WideGeom make_wide(const ConvGeom& g) {
+    WideGeom d;
+    d.N = g.N; d.H = g.H; d.W = g.W; d.Ho = g.Ho; d.Wo = g.Wo; d.pt = g.pt; d.pl = g.pl;
+    d.P = g.N * g.Ho * g.Wo;
+    d.d_howo = make_wdiv(g.Ho * g.Wo);
+    d.d_wo = make_wdiv(g.Wo);
+    return d;
+}
+
+// how the launch's 16-pixel tiles are dealt out: workgroup (g, s) = blockIdx.x takes slice s of the tiles of
+// demonstration index g; tile j of an index = tile j % tps of its sequence j / tps (a sequence = the seq frames of one
+// (program, index) pair, frames ordered (program, index, t)); a plain launch is G = 1 with the whole batch as one sequence
+struct WideDeal {
+    int G, S;
+    int seqpix;              // output pixels of one sequence
+    int tps;                 // tiles of one sequence (the last one ragged when seqpix % 16 != 0)
+    int per_idx, per_slice;  // tiles of one index / of one slice
+    const float* in_scale;   // [G, CIN] or null (AFFINE)
+    double* stats;           // [G][S][48][2] or null (STATS)
+    unsigned pad0;           // AFFINE: float offset of index 0's pad pixel in x
+};
+
+__device__ __forceinline__ f32x4 wldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ int wclamp(int v, int hi) { return min(max(v, 0), hi); }
+
+template <int CIN, bool STATS, bool AFFINE>
+__global__ void __launch_bounds__(wide_waves(CIN) * 64)
+conv_wide_fwd_kernel(WideGeom g, const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                     int act, float* __restrict__ y, WideDeal dl) {
+    constexpr int CB = CIN / 16, NCH = 9 * CB, WWAVES = wide_waves(CIN);
+    extern __shared__ __attribute__((aligned(16))) float wide_lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(wide_lds);                 // [NCH][3][64]: A fragments of (chunk, block)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
+    const int sg = (int)blockIdx.x / dl.S, ss = (int)blockIdx.x - sg * dl.S;
+
+    // ---- filter -> LDS in fragment order: wl[(ch*3 + b)*64 + l][j] = W[k = chunk ch, 4q + j][co = 16 b + p]
+    //      (AFFINE: times the input scale of k's channel -- the index is fixed for the workgroup)
+    for (int i = tid; i < NCH * WNB * 64; i += WWAVES * 64) {
+        const int l = i & 63, cb3 = i >> 6;
+        const int ch = cb3 / WNB, b = cb3 - ch * WNB;
+        const int pp = l & 15, qq = l >> 4;
+        const int cin0 = (ch % CB) * 16 + 4 * qq;
+        const int kbase = (ch / CB) * CIN + cin0;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = w[(kbase + j) * WCO + b * 16 + pp];
+        if (AFFINE) v *= wldg4(dl.in_scale + sg * CIN + cin0);
+        wl[i] = v;
+    }
+    const unsigned padoff = AFFINE ? dl.pad0 + (unsigned)(sg * CIN) : 0u;
+    f32x4 ash[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        // the pad pixel holds -shift / scale: what the loop adds is its negative
+        if (AFFINE) ash[cb] = -wldg4(x + padoff + cb * 16 + 4 * q);
+        else ash[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 bv[WNB];
+#pragma unroll
+    for (int b = 0; b < WNB; ++b) {
+        if (bias) bv[b] = wldg4(bias + b * 16 + 4 * q);
+        else bv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4 fs[WNB], fq[WNB];
+#pragma unroll
+    for (int b = 0; b < WNB; ++b) fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int tlo = ss * dl.per_slice, thi = min(tlo + dl.per_slice, dl.per_idx);
+    int tile = tlo + __builtin_amdgcn_readfirstlane(wave);
+    int tb = tile / dl.tps, tr = tile - tb * dl.tps;           // (sequence, tile inside it) of this index
+    const int HoWo = g.Ho * g.Wo;
+    for (; tile < thi; tile += WWAVES) {
+        const int local = tr * 16 + p;
+        const bool valid = local < dl.seqpix;
+        const int pix = (tb * dl.G + sg) * dl.seqpix + (valid ? local : 0);
+        // ---- gather: v[ch] = 4 consecutive k of chunk ch (tap ch / CB, channels 16 (ch % CB) + 4q ..) of this lane's pixel
+        const int n = wdiv(pix, g.d_howo);
+        const int rem = pix - n * HoWo;
+        const int oy = wdiv(rem, g.d_wo), ox = rem - oy * g.Wo;
+        const int iy0 = 2 * oy - g.pt, ix0 = 2 * ox - g.pl;
+        int rowoff[3], coloff[3];
+        unsigned okbits = 0u;
+        bool rok[3], cok[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int iy = iy0 + k, ix = ix0 + k;
+            rok[k] = valid & ((unsigned)iy < (unsigned)g.H);
+            cok[k] = (unsigned)ix < (unsigned)g.W;
+            rowoff[k] = (n * g.H + wclamp(iy, g.H - 1)) * g.W * CIN;
+            coloff[k] = wclamp(ix, g.W - 1) * CIN + 4 * q;
+        }
+        f32x4 v[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int tap = ch / CB, ky = tap / 3, kx = tap % 3;
+            unsigned off = (unsigned)(rowoff[ky] + coloff[kx] + (ch % CB) * 16);
+            const bool ok = rok[ky] & cok[kx];
+            if (AFFINE) off = ok ? off : padoff + (unsigned)((ch % CB) * 16 + 4 * q);     // (a select of the offset, not of the load)
+            else if (ch % CB == 0) okbits |= ok ? (1u << tap) : 0u;
+            D2P_OPAQUE_U(off);
+            v[ch] = wldg4(x + off);
+        }
+        // ---- 4 * 3 MFMAs per chunk, A fragments from LDS
+        f32x4 acc[2][WNB];
+#pragma unroll
+        for (int b = 0; b < WNB; ++b) acc[0][b] = acc[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            f32x4 bb;
+            if (AFFINE) bb = v[ch] + ash[ch % CB];                 // (x + shift / scale; a pad pixel gives exactly 0)
+            else bb = v[ch] * (((okbits >> (ch / CB)) & 1u) ? 1.f : 0.f);
+#pragma unroll
+            for (int b = 0; b < WNB; ++b) {
+                const f32x4 a4 = wl[(ch * WNB + b) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j & 1][b] = D2P_MFMA16(a4[j], bb[j], acc[j & 1][b]);
+            }
+        }
+        // ---- epilogue: bias, leaky ReLU, store, statistics
+        const float vf = valid ? 1.f : 0.f;
+#pragma unroll
+        for (int b = 0; b < WNB; ++b) {
+            f32x4 o = (acc[0][b] + acc[1][b]) + bv[b];
+            if (act) { o.x = d2p_lrelu(o.x); o.y = d2p_lrelu(o.y); o.z = d2p_lrelu(o.z); o.w = d2p_lrelu(o.w); }
+            if (valid) *reinterpret_cast<f32x4*>(y + (long)pix * WCO + b * 16 + 4 * q) = o;
+            if (STATS) {
+                o *= vf;
+                fs[b] += o;
+                fq[b] += o * o;
+            }
+        }
+        tr += WWAVES;
+        while (tr >= dl.tps) { tr -= dl.tps; ++tb; }
+    }
+    if (STATS) {
+        // lanes (p, q) hold channels 16b + 4q + r of pixel lane p: the 16 pixel lanes by xor-shuffles (fp64 from here
+        // on), the eight waves through LDS in wave order
+        __shared__ double wsum[WWAVES * WCO * 2];
+#pragma unroll
+        for (int b = 0; b < WNB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double u = (double)fs[b][r], s2 = (double)fq[b][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    u += __shfl_xor(u, off, 64);
+                    s2 += __shfl_xor(s2, off, 64);
+                }
+                if (p == 0) {
+                    wsum[(wave * WCO + b * 16 + 4 * q + r) * 2] = u;
+                    wsum[(wave * WCO + b * 16 + 4 * q + r) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * WCO) {
+            const int c = tid >> 1, k = tid & 1;
+            double t = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < WWAVES; ++wv) t += wsum[(wv * WCO + c) * 2 + k];
+            dl.stats[((long)blockIdx.x * WCO + c) * 2 + k] = t;
+        }
+    }
+}
+
+bool wide_geom_ok(const ConvGeom& g) {
+    if (g.Cout != WCO || (g.Cin != 32 && g.Cin != 48)) return false;
+    if (g.H < 3 || g.W < 3) return false;                  // every tap touches the image somewhere
+    return (size_t)g.N * g.H * g.W * g.Cin + (size_t)4096 * g.Cin < (1ull << 32) && (size_t)g.N * g.Ho * g.Wo < (1ull << 31) / 16;
+}
+
+// slices per index: ONE round of workgroups over the chip (a workgroup fills its CU: 12 waves of 153 registers / 8 waves of
+// 211 and 54 / 81 KB of LDS) -- G * S <= CUs, a tile per wave at least.  (Two workgroups per CU's worth of slices ran as a
+// second, partly filled round: 410 workgroups at conv3 = 0.8 of the chip on average; 60 at conv5 left 196 CUs idle.)
+int wide_cus() {
+    static int n = 0;
+    if (n <= 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+            n = v;
+        else
+            (void)hipGetLastError();
+    }
+    return n > 0 ? n : 256;
+}
+int wide_slices(long per_idx, int G, int cin) {
+    long S = wide_cus() / G;
+    const long cap = per_idx / wide_waves(cin);
+    if (S > cap) S = cap;
+    return (int)(S < 1 ? 1 : S);
+}
+
+template <int CIN>
+int launch_wide_fwd(const ConvGeom& g, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st,
+                    const ConvBnFold* bn) {
+    WideGeom d = make_wide(g);
+    WideDeal dl;
+    const int G = bn ? bn->G : 1, seq = bn ? bn->seq : g.N;
+    dl.G = G;
+    dl.seqpix = seq * g.Ho * g.Wo;
+    dl.tps = ceil_div(dl.seqpix, 16);
+    dl.per_idx = g.N / (G * seq) * dl.tps;
+    dl.S = bn && bn->S > 0 ? bn->S : wide_slices(dl.per_idx, G, CIN);
+    dl.per_slice = ceil_div(dl.per_idx, dl.S);
+    dl.in_scale = bn ? bn->in_scale : nullptr;
+    dl.stats = bn ? bn->stats : nullptr;
+    dl.pad0 = (unsigned)((size_t)g.N * g.H * g.W * g.Cin);
+    constexpr size_t lds = (size_t)9 * (CIN / 16) * WNB * 64 * sizeof(f32x4);
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * WCO);
+    const dim3 grid(G * dl.S), block(wide_waves(CIN) * 64);
+#define D2P_WIDE_LAUNCH(ST, AF)                                                                                     \
+    do {                                                                                                            \
+        auto kern = conv_wide_fwd_kernel<CIN, ST, AF>;                                                              \
+        static bool attr = false;                                                                                   \
+        if (!attr) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            D2P_REQUIRE(e == hipSuccess, (int)e, "conv wide fwd: %s", hipGetErrorString(e));                        \
+            attr = true;                                                                                            \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, d, x, w, bias, act, y, dl);                                  \
+    } while (0)
+    if (dl.stats && dl.in_scale) D2P_WIDE_LAUNCH(true, true);
+    else if (dl.stats) D2P_WIDE_LAUNCH(true, false);
+    else if (dl.in_scale) D2P_WIDE_LAUNCH(false, true);
+    else D2P_WIDE_LAUNCH(false, false);
+#undef D2P_WIDE_LAUNCH
+    D2P_LAUNCH_CHECK("conv_wide_fwd");
+    return 1;
+}
+
+
+// ==========================================================================================
+// input gradient: dX[pix, ci] = sum_(tap, co) dY[(pix + pad - tap) / 2, co] * W[tap, ci, co], one parity class of input
+// pixels per workgroup (even coordinate: taps {0, 2}, odd: tap {1} -- 4 / 2 / 2 / 1 taps per class).  Same skeleton as the
+// forward kernel: the class's W^T fragments in LDS (A operand: [ci][co], 16-byte loads -- co is contiguous in W), dY
+// gathered with one 16-byte load per (pixel, tap, 4 channels), a wave owns whole 16-pixel tiles of its class.
+// ==========================================================================================
+struct WDgCls {
+    int iy0, ix0, Hc, Wc, P, blk0, nblk, ntiles;
+    WDiv d_hw, d_w;
+};
+struct WDgArgs {
+    WDgCls c[4];             // indexed by e = 2 EY + EX, EY = (iy + pt) & 1
+};
+constexpr int WDG_WAVES = 8;
+
+template <int E>             // E = 0: taps {0, 2};  E = 1: tap {1}
+struct WClsTaps {
+    static constexpr int n = E ? 1 : 2;
+    static constexpr int k(int i) { return E ? 1 : 2 * i; }
+};
+
+template <int CIN, int EY, int EX>
+__device__ __forceinline__ void wide_dgrad_class(const WideGeom& g, const WDgCls& c, const float* __restrict__ dy,
+                                                 const float* __restrict__ w, float* __restrict__ dx, f32x4* wl) {
+    constexpr int CC = WCO / 16, NBI = CIN / 16;
+    constexpr int NTY = WClsTaps<EY>::n, NTX = WClsTaps<EX>::n, NT = NTY * NTX;
+    const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, q = lane >> 4;
+    // ---- W^T -> LDS: wl[((t * CC + cc) * NBI + b) * 64 + l][j] = W[tap t][ci = 16 b + p][co = 16 cc + 4q + j]
+    for (int i = tid; i < NT * CC * NBI * 64; i += WDG_WAVES * 64) {
+        const int l = i & 63;
+        int r = i >> 6;
+        const int b = r % NBI;
+        r /= NBI;
+        const int cc = r % CC, t = r / CC;
+        const int ty = t / NTX, tx = t - ty * NTX;
+        const int tap = (EY ? 1 : 2 * ty) * 3 + (EX ? 1 : 2 * tx);
+        wl[i] = wldg4(w + (tap * CIN + b * 16 + (l & 15)) * WCO + cc * 16 + 4 * (l >> 4));
+    }
+    __syncthreads();
+    const int NW = c.nblk * WDG_WAVES;
+    for (int tile = ((int)blockIdx.x - c.blk0) * WDG_WAVES + __builtin_amdgcn_readfirstlane(tid >> 6); tile < c.ntiles;
+         tile += NW) {
+        const int j = tile * 16 + p;
+        const bool valid = j < c.P;
+        const int jc = valid ? j : 0;
+        const int n = wdiv(jc, c.d_hw);
+        const int rem = jc - n * c.Hc * c.Wc;
+        const int a = wdiv(rem, c.d_w), bcol = rem - a * c.Wc;
+        const int iy = c.iy0 + 2 * a, ix = c.ix0 + 2 * bcol;
+        f32x4 v[NT][CC];
+        unsigned okmask = 0u;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int ky = WClsTaps<EY>::k(t / NTX), kx = WClsTaps<EX>::k(t % NTX);
+            const int oy = (iy + g.pt - ky) >> 1, ox = (ix + g.pl - kx) >> 1;
+            const bool ok = valid & (oy >= 0) & (oy < g.Ho) & (ox >= 0) & (ox < g.Wo);
+            unsigned off = (unsigned)(((n * g.Ho + wclamp(oy, g.Ho - 1)) * g.Wo + wclamp(ox, g.Wo - 1)) * WCO + 4 * q);
+            D2P_OPAQUE_U(off);
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) v[t][cc] = wldg4(dy + off + cc * 16);
+            okmask |= ok ? (1u << t) : 0u;
+        }
+        f32x4 acc[2][NBI];
+#pragma unroll
+        for (int b = 0; b < NBI; ++b) acc[0][b] = acc[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float okf = ((okmask >> t) & 1u) ? 1.f : 0.f;
+#pragma unroll
+            for (int cc = 0; cc < CC; ++cc) {
+                const f32x4 bb = v[t][cc] * okf;
+#pragma unroll
+                for (int b = 0; b < NBI; ++b) {
+                    const f32x4 a4 = wl[((t * CC + cc) * NBI + b) * 64 + lane];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) acc[jj & 1][b] = D2P_MFMA16(a4[jj], bb[jj], acc[jj & 1][b]);
+                }
+            }
+        }
+        if (valid) {
+            const long xoff = ((long)(n * g.H + iy) * g.W + ix) * CIN;
+#pragma unroll
+            for (int b = 0; b < NBI; ++b) *reinterpret_cast<f32x4*>(dx + xoff + b * 16 + 4 * q) = acc[0][b] + acc[1][b];
+        }
+    }
+}
+
+template <int CIN>
+__global__ void __launch_bounds__(WDG_WAVES * 64)
+conv_wide_dgrad_kernel(WideGeom g, WDgArgs a, const float* __restrict__ dy, const float* __restrict__ w,
+                       float* __restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) float wide_lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(wide_lds);
+    const int b = blockIdx.x;
+    if (b < a.c[1].blk0) wide_dgrad_class<CIN, 0, 0>(g, a.c[0], dy, w, dx, wl);
+    else if (b < a.c[2].blk0) wide_dgrad_class<CIN, 0, 1>(g, a.c[1], dy, w, dx, wl);
+    else if (b < a.c[3].blk0) wide_dgrad_class<CIN, 1, 0>(g, a.c[2], dy, w, dx, wl);
+    else wide_dgrad_class<CIN, 1, 1>(g, a.c[3], dy, w, dx, wl);
+}
+
+template <int CIN>
+int launch_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+    WideGeom d = make_wide(g);
+    WDgArgs a;
+    long work[4], total = 0;
+    for (int e = 0; e < 4; ++e) {
+        const int ey = e >> 1, ex = e & 1;
+        WDgCls& c = a.c[e];
+        c.iy0 = ey ^ (g.pt & 1);            // (iy + pt) & 1 == ey
+        c.ix0 = ex ^ (g.pl & 1);
+        c.Hc = c.iy0 < g.H ? (g.H - c.iy0 + 1) / 2 : 0;
+        c.Wc = c.ix0 < g.W ? (g.W - c.ix0 + 1) / 2 : 0;
+        c.P = g.N * c.Hc * c.Wc;
+        c.ntiles = ceil_div(c.P, 16);
+        c.d_hw = make_wdiv(c.Hc * c.Wc > 0 ? c.Hc * c.Wc : 1);
+        c.d_w = make_wdiv(c.Wc > 0 ? c.Wc : 1);
+        work[e] = (long)c.ntiles * (ey ? 1 : 2) * (ex ? 1 : 2);
+        total += work[e];
+    }
+    if (total == 0) return 1;
+    // two workgroups per CU (<= 36 KB of LDS, 8 waves each), dealt out by the classes' MFMA counts; a tile per wave at least
+    const int budget = 2 * wide_cus();
+    int blk = 0;
+    for (int e = 0; e < 4; ++e) {
+        WDgCls& c = a.c[e];
+        long nb = c.ntiles > 0 ? (work[e] * budget + total - 1) / total : 0;
+        const long cap = ceil_div(c.ntiles, WDG_WAVES);
+        if (nb > cap) nb = cap;
+        if (c.ntiles > 0 && nb < 1) nb = 1;
+        c.nblk = (int)nb;
+        c.blk0 = blk;
+        blk += c.nblk;
+    }
+    constexpr size_t lds = (size_t)4 * 3 * (CIN / 16) * 64 * sizeof(f32x4);
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * WCO);
+    auto kern = conv_wide_dgrad_kernel<CIN>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        D2P_REQUIRE(e == hipSuccess, (int)e, "conv wide dgrad: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(blk), dim3(WDG_WAVES * 64), lds, st, d, a, dy, w, dx);
+    D2P_LAUNCH_CHECK("conv_wide_dgrad");
+    return 1;
+}
+
+}   // namespace
+
+// slices per demonstration index the folding forward launch writes statistics for; 0: geometry not taken
+int d2p_conv_wide_bn_slices(const ConvGeom& g, int G, int seq) {
+    if (!wide_geom_ok(g) || G < 1 || seq < 1 || g.N % (G * seq) != 0 || G > 4096) return 0;
+    const long tps = ((long)seq * g.Ho * g.Wo + 15) / 16;
+    return wide_slices((long)g.N / (G * seq) * tps, G, g.Cin);
+}
+
+// 1: handled, 0: not a geometry of this back end, < 0: error (the convention of conv_geom.h)
+int d2p_conv_wide_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act, float* y,
+                      hipStream_t st, const ConvBnFold* bn) {
+    if (x_is_u8 || !wide_geom_ok(g)) return 0;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
+    if (bn) {
+        if (bn->G < 1 || bn->seq < 1 || g.N % (bn->G * bn->seq) != 0 || bn->G > 4096) return 0;
+        if (bn->stats && bn->S != d2p_conv_wide_bn_slices(g, bn->G, bn->seq)) return 0;
+        if (bn->in_scale && (((uintptr_t)bn->in_scale) & 15)) return 0;
+        if (!bn->stats && !bn->in_scale) bn = nullptr;
+    }
+    if (g.N == 0) return 1;
+    if (g.Cin == 32) return launch_wide_fwd<32>(g, (const float*)x, w, bias, act, y, st, bn);
+    return launch_wide_fwd<48>(g, (const float*)x, w, bias, act, y, st, bn);
+}
+
+int d2p_conv_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+    if (!wide_geom_ok(g)) return 0;
+    if (((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)w & 15)) return 0;
+    if ((size_t)g.N * g.Ho * g.Wo * WCO >= (1ull << 32)) return 0;
+    if (g.N == 0) return 1;
+    if (g.Cin == 32) return launch_wide_dgrad<32>(g, dy, w, dx, st);
+    return launch_wide_dgrad<48>(g, dy, w, dx, st);
+}

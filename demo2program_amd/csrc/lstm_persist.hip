@@ -1769,6 +1769,14 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
 // =============================================================================================
 // Host side
 // =============================================================================================
+// CUs the planners may fill (d2p_lstm_persist_set_cu_budget; 0 = every CU): a launch planned for fewer leaves whole CUs to
+// the other queue -- a four-wave workgroup never becomes resident on a CU that holds a recurrence's five 256-register waves
+// (DESIGN_APPENDIX: corun_probe), so beside a launch that fills the chip the side queue only WAITS
+static int g_ps_cu_budget = 0;
+extern "C" int d2p_lstm_persist_set_cu_budget(int cus) {
+    g_ps_cu_budget = cus > 0 ? cus : 0;
+    return D2P_OK;
+}
 static int ps_num_cus() {
     // hipDeviceGetAttribute is legal under stream capture (hipGetDeviceProperties is not: a first call from
     // inside a captured training step would silently disable the persistent path); retried until it works
@@ -1781,7 +1789,8 @@ static int ps_num_cus() {
         else
             (void)hipGetLastError();
     }
-    return n > 0 ? n : 1;
+    const int have = n > 0 ? n : 1;
+    return g_ps_cu_budget > 0 && g_ps_cu_budget < have ? g_ps_cu_budget : have;
 }
 
 // row domains for `ncol` column tiles: as many as fit the chip, at most one per 16-row sub-tile

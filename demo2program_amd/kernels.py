@@ -591,6 +591,11 @@ def lstm_set_sorted(on):
     call.d2p_lstm_persist_set_sorted(1 if on else 0)
 
 
+def lstm_set_cu_budget(cus):
+    """CUs the persistent recurrences are planned for (0: all); fewer leaves whole CUs to the other queue."""
+    call.d2p_lstm_persist_set_cu_budget(int(cus))
+
+
 def lstm_pack_weights(cells):
     """cells: list (<= 8) of (Wh [U, 4U], Wf image or None, Wb image or None): the packed weight images of the persistent
     kernels in one launch."""

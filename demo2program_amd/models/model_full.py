@@ -536,7 +536,20 @@ class Model(object):
         # (forked here, not at the start of the step: beside the chain of small conv / batch-norm launches
         #  these GEMMs only took the CUs the chain was waiting for -- 320 us instead of 100 for the chain;
         #  beside the first recurrence they fill matrix-pipe time its hand-offs leave)
-        side.wait_stream(main)
+        # (round 6) the fork is an EVENT and the first recurrence is enqueued BEFORE the side stream's dozen small launches:
+        # the host needs ~8 us per launch, and with the side work enqueued first the main queue sat idle for 77 us in
+        # front of the recurrence (profiles/r05g_streams_timeline_two_queues.txt @ 79-156 us)
+        fork = None
+        if side != main:
+            fork = torch.cuda.Event()
+            fork.record(main)
+        # ---- Demo_Encoder LSTM (zero initial state, length-masked)
+        e1_hc = self._buf('demo_lstm/hc_final', (2, M, U))
+        e1 = self._lstm_fwd('demo_lstm', feats_tm.view(T * M, F), F, M, T, T, None, None, lens_d,
+                            want_final=True, z=z_e1, final_out=(e1_hc[0], e1_hc[1]), row_order=fwd_order)
+        e1['hc_final'] = e1_hc
+        if fork is not None:
+            side.wait_event(fork)
         with torch.cuda.stream(side):
             # Token-input decoders: x = embedding[id], so x.Wx + b takes one of tok+2 values per row -- the
             # projected TABLE (a [tok+1, U] x [U, 4U] GEMM: 7 or 51 rows) is gathered instead of projecting
@@ -591,11 +604,6 @@ class Model(object):
             z_p = (self._token_xproj('prog', ids_p, V, B, L, n_p) if tokproj
                    else self._lstm_xproj('prog/lstm', emb_p, U, B, L, n_p))
 
-        # ---- Demo_Encoder LSTM (zero initial state, length-masked)
-        e1_hc = self._buf('demo_lstm/hc_final', (2, M, U))
-        e1 = self._lstm_fwd('demo_lstm', feats_tm.view(T * M, F), F, M, T, T, None, None, lens_d,
-                            want_final=True, z=z_e1, final_out=(e1_hc[0], e1_hc[1]), row_order=fwd_order)
-        e1['hc_final'] = e1_hc
         if self.variant == 'synthesis_baseline':
             # model_synthesis.py:324-358: no second pass; the program decoder starts from the
             # demonstrations' final states pooled over k

@@ -411,6 +411,10 @@ int d2p_lstm_persist_set_direct(int on);
  * sized for (0 keeps the current value; default 1).  2 cuts the rows into twice as many domains so
  * that two workgroups share a CU and overlap each other's MFMA and epilogue phases. */
 int d2p_lstm_persist_set_wgs_per_cu(int fwd, int bwd);
+/* CUs the persistent launches are planned for (process-global; 0 = all of them, the default).  A smaller budget -- 224 of
+ * 256: seven row domains of 32 column tiles instead of eight -- leaves whole CUs to other queues: four-wave workgroups
+ * (GEMMs, a collective's kernels) cannot become resident on a CU that holds a recurrence's workgroup. */
+int d2p_lstm_persist_set_cu_budget(int cus);
 /* The wide-tile forward kernel (round 4: 16 units per column tile -- 8 row domains at U = 512 --, one to three
  * sequences per launch, length-sorted where a descriptor brings rowmap / slab_steps, row domains that find all their
  * workgroups on one XCD exchange through its L2).  on: 1 (default) / 0 = every forward launch goes to the 8-unit-tile

@@ -239,7 +239,7 @@ def _conv_ref(x, w, b):
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout', [(40, 8, 8, 16, 16), (40, 4, 4, 16, 32), (40, 2, 2, 32, 48),
                                             (6, 80, 80, 3, 16), (7, 5, 5, 48, 48), (9, 3, 3, 48, 48),
-                                            (3, 10, 10, 48, 48), (5, 7, 9, 4, 8),
+                                            (3, 10, 10, 48, 48), (5, 7, 9, 4, 8), (5, 20, 20, 32, 48), (33, 20, 20, 32, 48), (64, 10, 10, 48, 48), (2, 9, 6, 32, 48),
                                             (41, 4, 4, 16, 32), (37, 2, 2, 32, 48), (33, 8, 8, 16, 16),
                                             (3, 20, 20, 16, 32), (2, 21, 19, 16, 16), (5, 11, 14, 4, 16),
                                             (1, 1, 1, 16, 16), (700, 8, 8, 16, 16),
@@ -307,6 +307,52 @@ def test_conv_uint8_frames_equal_float_frames(K, N, H, W, Cin, Cout):
     dwf = torch.empty(3, 3, Cin, Cout, device='cuda')
     K.conv_wgrad(dev(xu.double()), dev(dy), dwf)
     close(dw, dwf, atol=1e-3, rtol=1e-5)
+
+
+@pytest.mark.parametrize('B,G,T,H,Cin', [(2, 3, 4, 20, 32), (3, 2, 5, 10, 48), (2, 5, 4, 5, 48), (9, 10, 20, 10, 48)])
+def test_wide_layers_forward_with_statistics_and_input_affine(K, B, G, T, H, Cin):
+    """Round 6, conv_wide.hip: the 48-channel layers' forward pass (filter in LDS; conv3 32 -> 48 on 20x20, conv4 / conv5
+    48 -> 48 on 10x10 / 5x5; models/ops.py:27-33) with the batch-norm folding of ConvBnFold -- statistics of its own
+    output per demonstration index out of the launch (sequences whose pixel count is no multiple of 16 end in a masked
+    tile: 10x10 -> 5x5 frames), and the input read through the previous layer's batch-norm apply -- against an fp64
+    reference and against the plain launch."""
+    N = B * G * T
+    Ho = (H + 1) // 2
+    x = rnd(N, H, H, Cin, seed=21)
+    w, b = rnd(3, 3, Cin, 48, seed=22, scale=0.1), rnd(48, seed=23)
+    grp = (torch.arange(N) // T) % G
+    S = K.conv_bn_slices((N, H, H, Cin), 48, G, T)
+    assert S > 0
+    ref = oracle.lrelu(_conv_ref(x, w, b))
+    st = torch.zeros(G * S * 48 * 2, dtype=torch.float64, device='cuda')
+    a = K.conv_fwd_bn(dev(x), dev(w), dev(b), G, T, S, st, act=1)
+    close(a, ref, atol=1e-4)
+    assert torch.equal(a, K.conv_fwd(dev(x), dev(w), dev(b), act=1))        # the same products in the same order
+    mean, rstd, var = (torch.empty(G, 48, device='cuda') for _ in range(3))
+    K.bn_stats_from_partials(st, B * T * Ho * Ho, 48, G, S, None, None, mean, rstd, var)
+    ad = a.double().cpu()
+    for gi in range(G):
+        v = ad[grp == gi].reshape(-1, 48)
+        close(mean[gi], v.mean(0), atol=1e-6 * float(v.abs().max()) + 1e-7)
+        close(var[gi], v.var(0, unbiased=False), rtol=1e-5, atol=1e-7)
+    # the input through an affine per (index, channel): x * sc + sh, zero padding of the NORMALISED tensor
+    sc = (rnd(G, Cin, seed=24).abs() + 0.5)
+    sh = rnd(G, Cin, seed=25)
+    xn = x * sc[grp].view(N, 1, 1, Cin) + sh[grp].view(N, 1, 1, Cin)
+    ref2 = oracle.lrelu(_conv_ref(xn, w, b))
+    x_ext = torch.empty(N * H * H * Cin + G * Cin, device='cuda')
+    xd, pad = x_ext[:N * H * H * Cin].view(N, H, H, Cin), x_ext[N * H * H * Cin:].view(G, Cin)
+    xd.copy_(dev(x))
+    pad.copy_(dev(-sh / sc))
+    st2 = torch.zeros_like(st)
+    a2 = K.conv_fwd_bn(xd, dev(w), dev(b), G, T, S, st2, act=1, in_affine=(dev(sc), dev(sh), pad))
+    close(a2, ref2, atol=2e-5 * float(ref2.abs().max()) + 1e-4)
+    K.bn_stats_from_partials(st2, B * T * Ho * Ho, 48, G, S, None, None, mean, rstd, var)
+    a2d = a2.double().cpu()
+    for gi in range(G):
+        v = a2d[grp == gi].reshape(-1, 48)
+        close(mean[gi], v.mean(0), atol=1e-6 * float(v.abs().max()) + 1e-7)
+        close(rstd[gi], 1.0 / torch.sqrt(v.var(0, unbiased=False) + 1e-3), rtol=1e-5)
 
 
 @pytest.mark.parametrize('B,G,T', [(3, 2, 2), (2, 5, 4)])
