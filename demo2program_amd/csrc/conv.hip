@@ -250,6 +250,19 @@ extern "C" int d2p_conv_bn_slices(int N, int H, int W, int Cin, int Cout, int G,
     if (S * 16 > units) S = units / 16;
     return (int)(S < 1 ? 1 : S);
 }
+// 1 when this layer's forward AND weight-gradient launches take their input through the previous layer's batch-norm apply
+// (ConvBnFold::in_scale / in_shift: x = that layer's pre-norm activation with its G pad pixels behind it), so that the
+// normalised tensor need not be written: the 16 -> 32 layer of the large frames (row-strip / gather kernels) and the
+// 48-channel layers (conv_wide.hip)
+extern "C" int d2p_conv_bn_affine_ok(int N, int H, int W, int Cin, int Cout, int G, int seq) {
+    if (d2p_conv_bn_slices(N, H, W, Cin, Cout, G, seq) <= 0) return 0;
+    if (Cin == 16 && Cout == 32) return 1;
+    if (Cout == 48) {
+        ConvGeom g = make_geom(N, H, W, Cin, Cout);
+        return d2p_conv_wide_wgrad_ws(g) > 0 ? 1 : 0;
+    }
+    return 0;
+}
 extern "C" int d2p_conv2d_nhwc_s2_same_fwd_bn(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8,
                                               const float* w, const float* bias, int act, float* y, int G, int seq,
                                               const float* in_scale, const float* in_shift, double* stats, int S,

@@ -814,6 +814,8 @@ size_t d2p_conv_direct_wgrad_ws(const ConvGeom& g) {
     size_t fr = d2p_conv_frames_wgrad_ws(g);
     const size_t rw = d2p_conv_rows_wgrad_ws(g);
     if (rw > fr) fr = rw;
+    const size_t ww = d2p_conv_wide_wgrad_ws(g);
+    if (ww > fr) fr = ww;
     if (!wgrad_supported(g)) return fr;
     const size_t di = (size_t)wgrad_blocks(g) * 9 * g.Cin * g.Cout * sizeof(float);
     return fr > di ? fr : di;
@@ -844,12 +846,17 @@ static int launch_wgrad(const ConvGeom& g, const T* x, const float* dy, float* d
 
 int d2p_conv_direct_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws,
                           size_t ws_bytes, hipStream_t st, const ConvBnFold* bn) {
-    if (bn) return d2p_conv_rows_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st, bn);    // (input affine: the row-strip kernel only)
+    if (bn) {       // (input affine: the row-strip kernel of the 16 -> 32 layer, the wide kernel of the 48-channel layers)
+        const int rc = d2p_conv_rows_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st, bn);
+        return rc != 0 ? rc : d2p_conv_wide_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st, bn);
+    }
     if (!g_direct_wgrad) return 0;
     if (g_direct_wgrad >= 2) {
         int rc = d2p_conv_frames_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st);
         if (rc != 0) return rc;
         rc = d2p_conv_rows_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st);
+        if (rc != 0) return rc;
+        rc = d2p_conv_wide_wgrad(g, x, x_is_u8, dy, dw, ws, ws_bytes, st);          // (the 48-channel layers, round 6)
         if (rc != 0) return rc;
     }
     if (!wgrad_supported(g)) return 0;

@@ -90,6 +90,9 @@ int d2p_conv_wide_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float
                       hipStream_t st, const ConvBnFold* bn = nullptr);
 int d2p_conv_wide_bn_slices(const ConvGeom& g, int G, int seq);
 int d2p_conv_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st);
+int d2p_conv_wide_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                        hipStream_t st, const ConvBnFold* bn = nullptr);
+size_t d2p_conv_wide_wgrad_ws(const ConvGeom& g);
 
 // floor(n / d) for 0 <= n < 2^31 and d >= 1 by multiply-high + shift (exact: m = ceil(2^(31+s) / d),
 // s = ceil(log2 d)).  An integer division costs ~25 VALU instructions on gfx950; the implicit-GEMM

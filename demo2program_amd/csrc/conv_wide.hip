@@ -429,6 +429,238 @@ int launch_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float*
     return 1;
 }
 
+
+// ==========================================================================================
+// weight gradient: dW[tap, ci, co] = sum_pix x[pix @ tap, ci] * dY[pix, co] -- the reduction index is the PIXEL (4 per
+// MFMA), A = x [ci][pixel], B = dY [pixel][co], the whole dW in accumulators: 18 / 27 row blocks x 3 column blocks, split
+// over the three waves of a pixel stream by the tap's row ky (6 / 9 row blocks = 72 / 108 accumulator registers each).
+// A workgroup = 4 pixel streams x 3 waves; nothing goes through LDS in the loop: both operands are 4-byte buffer loads
+// (16 consecutive channels of a pixel per quarter wave) whose per-lane offset comes from a TABLE in LDS, built once per
+// workgroup over the pixels of one block of frames (a sequence of one demonstration index, or 16 frames of a plain
+// launch): entry [ky][pixel] = the byte offsets of x at (ky, kx = 0..2) and of the dY pixel, an out-of-image tap or a
+// pixel past the block = an offset past the buffer (a buffer load returns 0 there) -- no index arithmetic and no masks
+// in the loop, one ds_read_b128 per four pixels' worth of loads.
+// AFFINE (the input read through the previous layer's batch-norm apply, x' = sc x + sh inside the image, 0 outside):
+// the index is fixed per workgroup, so the scale multiplies the finished rows of dW, the loop adds sh / sc to what it
+// loads, and an out-of-image tap loads the index's pad pixel (-sh / sc) -- one add per load.
+// Each workgroup leaves one [9 CIN, 48] slab (streams added in a fixed order through LDS); gemm_splitk_reduce_kernel
+// adds the slabs in order.
+// ==========================================================================================
+constexpr int WWG_STREAMS = 4, WWG_WAVES = 3 * WWG_STREAMS;
+constexpr unsigned WWG_SENT = 0x7fff0000u;         // a byte offset past every buffer (sizes are checked < 2^31 - 2^17)
+constexpr int WWG_MAX_TPS = 170;                   // tiles of one block of frames: 3 x 16 x 170 table entries = 127.5 KB
+
+struct WideWg {
+    int G, S, seq, fb, nsub;     // frames per sequence, per block, blocks per sequence
+    int blkpix, tps;             // output pixels / tiles of one block
+    int per_idx, per_slice;      // tiles of one index / of one slice
+    const float* in_scale;       // [G, CIN] or null
+    unsigned pad0;               // AFFINE: float offset of index 0's pad pixel in x
+    unsigned x_bytes, dy_bytes;  // buffer sizes (x: incl. the pad pixels when AFFINE)
+};
+
+template <int CIN, bool AFFINE>
+__global__ void __launch_bounds__(WWG_WAVES * 64)
+conv_wide_wgrad_kernel(WideGeom g, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
+                       WideWg dl) {
+    constexpr int CB = CIN / 16, NA = 3 * CB;           // row blocks of one wave: (kx, cb)
+    extern __shared__ __attribute__((aligned(16))) float wide_lds[];
+    uint4* tab = reinterpret_cast<uint4*>(wide_lds);                // [3][tps * 16]
+    f32x4* red = reinterpret_cast<f32x4*>(wide_lds);                // (after the loop) [3][NA][3][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), p = lane & 15, q = lane >> 4;
+    const int ks = wave % 3, ps = wave / 3;
+    const int sg = (int)blockIdx.x / dl.S, ss = (int)blockIdx.x - sg * dl.S;
+    const int HoWo = g.Ho * g.Wo, npix = dl.tps * 16;
+    // ---- the offset table of one block of frames
+    for (int i = tid; i < 3 * npix; i += WWG_WAVES * 64) {
+        const int ky = i / npix, local = i - ky * npix;
+        uint4 e{WWG_SENT, WWG_SENT, WWG_SENT, WWG_SENT};
+        if (local < dl.blkpix) {
+            const int t = wdiv(local, g.d_howo);
+            const int rem = local - t * HoWo;
+            const int oy = wdiv(rem, g.d_wo), ox = rem - oy * g.Wo;
+            const int iy = 2 * oy - g.pt + ky, ix0 = 2 * ox - g.pl;
+            if ((unsigned)iy < (unsigned)g.H) {
+                const unsigned row = (unsigned)((t * g.H + iy) * g.W);
+                if ((unsigned)ix0 < (unsigned)g.W) e.x = (row + ix0) * CIN * 4u;
+                if ((unsigned)(ix0 + 1) < (unsigned)g.W) e.y = (row + ix0 + 1) * CIN * 4u;
+                if ((unsigned)(ix0 + 2) < (unsigned)g.W) e.z = (row + ix0 + 2) * CIN * 4u;
+            }
+            e.w = (unsigned)local * (WCO * 4u);
+        }
+        tab[i] = e;
+    }
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)dl.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (int)dl.dy_bytes, 0x00020000);
+    float tsh[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) tsh[cb] = AFFINE ? -x[dl.pad0 + sg * CIN + cb * 16 + p] : 0.f;
+    const unsigned pad_abs = AFFINE ? (dl.pad0 + (unsigned)(sg * CIN)) * 4u : 0u;
+    f32x4 acc[NA][WNB];
+#pragma unroll
+    for (int a = 0; a < NA; ++a)
+#pragma unroll
+        for (int b = 0; b < WNB; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    const int tlo = ss * dl.per_slice, thi = min(tlo + dl.per_slice, dl.per_idx);
+    int tile = tlo + ps;
+    int tb = tile / dl.tps, tr = tile - tb * dl.tps;            // (block of this index, tile inside it)
+    const unsigned frame_bytes = (unsigned)(g.H * g.W * CIN) * 4u;
+    for (; tile < thi; tile += WWG_STREAMS) {
+        const int sb = tb / dl.nsub, sub = tb - sb * dl.nsub;
+        const int frame0 = (sb * dl.G + sg) * dl.seq + sub * dl.fb;
+        const unsigned xs = (unsigned)frame0 * frame_bytes;                     // (wave-uniform: scalar offsets)
+        const unsigned ys = (unsigned)frame0 * (unsigned)(HoWo * WCO * 4);
+        const unsigned padrel = pad_abs - xs;
+        float A[4][NA], B[4][WNB];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const uint4 e = tab[ks * npix + tr * 16 + 4 * q + kk];
+            unsigned off[3] = {e.x, e.y, e.z};
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                if (AFFINE) off[kx] = off[kx] == WWG_SENT ? padrel : off[kx];
+                off[kx] += (unsigned)(p * 4);
+            }
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+                A[kk][a] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, (int)(off[a / CB] + (a % CB) * 64), (int)xs, 0));
+            const unsigned ob = e.w + (unsigned)(p * 4);
+#pragma unroll
+            for (int b = 0; b < WNB; ++b)
+                B[kk][b] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rdy, (int)(ob + b * 64), (int)ys, 0));
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int a = 0; a < NA; ++a) {
+                const float av = AFFINE ? A[kk][a] + tsh[a % CB] : A[kk][a];
+#pragma unroll
+                for (int b = 0; b < WNB; ++b) acc[a][b] = D2P_MFMA16(av, B[kk][b], acc[a][b]);
+            }
+        tr += WWG_STREAMS;
+        while (tr >= dl.tps) { tr -= dl.tps; ++tb; }
+    }
+    if (AFFINE) {
+        // rows ci = 16 cb + 4q + r of every block times the input scale of ci
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const f32x4 sc = wldg4(dl.in_scale + sg * CIN + cb * 16 + 4 * q);
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int b = 0; b < WNB; ++b) acc[kx * CB + cb][b] *= sc;
+        }
+    }
+    // ---- the four pixel streams added in a fixed order (3 + 2, then + 1, then + 0) through LDS
+    __syncthreads();                                  // (every wave is done with the table)
+#pragma unroll 1
+    for (int s_ = WWG_STREAMS - 1; s_ >= 1; --s_) {
+        if (ps == s_) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < WNB; ++b) red[((ks * NA + a) * WNB + b) * 64 + lane] = acc[a][b];
+        }
+        __syncthreads();
+        if (ps == s_ - 1) {
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
+#pragma unroll
+                for (int b = 0; b < WNB; ++b) acc[a][b] += red[((ks * NA + a) * WNB + b) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (ps == 0) {
+        float* slab = slabs + (long)blockIdx.x * (9 * CIN * WCO);
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+            const int kx = a / CB, cb = a % CB;
+            const int row0 = (ks * 3 + kx) * CIN + cb * 16 + 4 * q;
+#pragma unroll
+            for (int b = 0; b < WNB; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(row0 + r) * WCO + b * 16 + p] = acc[a][b][r];
+        }
+    }
+}
+
+// frames per block of the offset table: a whole sequence when its tiles fit the table, else its largest divisor that does
+int wide_wg_fb(const ConvGeom& g, int seq) {
+    const int howo = g.Ho * g.Wo;
+    for (int fb = seq; fb >= 1; --fb)
+        if (seq % fb == 0 && ceil_div(fb * howo, 16) <= WWG_MAX_TPS) return fb;
+    return 0;
+}
+bool wide_wgrad_ok(const ConvGeom& g) {
+    return wide_geom_ok(g) && (size_t)g.N * g.H * g.W * g.Cin * 4 + (size_t)4096 * g.Cin * 4 < (1ull << 31) - (1u << 17) &&
+           (size_t)g.N * g.Ho * g.Wo * WCO * 4 < (1ull << 31) - (1u << 17) && g.Ho * g.Wo <= 16 * WWG_MAX_TPS;
+}
+int wide_wgrad_blocks(const ConvGeom& g, int G, int seq, WideWg* out) {
+    WideWg dl{};
+    const bool plain = G <= 0;
+    dl.G = plain ? 1 : G;
+    dl.seq = plain ? wide_wg_fb(g, 16) : seq;
+    dl.fb = plain ? dl.seq : wide_wg_fb(g, seq);
+    if (dl.fb < 1) return 0;
+    dl.nsub = dl.seq / dl.fb;
+    dl.blkpix = dl.fb * g.Ho * g.Wo;
+    dl.tps = ceil_div(dl.blkpix, 16);
+    const long nseq = plain ? ceil_div(g.N, dl.seq) : g.N / (dl.G * dl.seq);
+    dl.per_idx = (int)(nseq * dl.nsub * dl.tps);
+    long S = wide_cus() / dl.G;
+    const long cap = dl.per_idx / WWG_STREAMS;
+    if (S > cap) S = cap;
+    dl.S = (int)(S < 1 ? 1 : S);
+    dl.per_slice = ceil_div(dl.per_idx, dl.S);
+    if (out) *out = dl;
+    return dl.G * dl.S;
+}
+
+template <int CIN>
+int launch_wide_wgrad(const ConvGeom& g, const float* x, const float* dy, float* dw, void* ws, size_t ws_bytes, hipStream_t st,
+                      const ConvBnFold* bn) {
+    WideGeom d = make_wide(g);
+    WideWg dl;
+    const int blocks = wide_wgrad_blocks(g, bn ? bn->G : 0, bn ? bn->seq : 0, &dl);
+    if (blocks < 1) return 0;
+    const int KK = 9 * CIN;
+    D2P_REQUIRE(ws && ws_bytes >= (size_t)blocks * KK * WCO * sizeof(float), D2P_EWS, "conv wide wgrad: workspace too small (%zu bytes)",
+                ws_bytes);
+    dl.in_scale = bn ? bn->in_scale : nullptr;
+    dl.pad0 = (unsigned)((size_t)g.N * g.H * g.W * g.Cin);
+    dl.x_bytes = (unsigned)(((size_t)g.N * g.H * g.W * g.Cin + (bn ? (size_t)dl.G * g.Cin : 0)) * 4);
+    dl.dy_bytes = (unsigned)((size_t)g.N * g.Ho * g.Wo * WCO * 4);
+    const size_t tab_bytes = (size_t)3 * dl.tps * 16 * sizeof(uint4), red_bytes = (size_t)3 * 3 * (CIN / 16) * WNB * 64 * sizeof(f32x4);
+    const size_t lds = tab_bytes > red_bytes ? tab_bytes : red_bytes;
+    float* slabs = (float*)ws;
+    {
+        D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * KK * WCO);
+#define D2P_WIDE_WG(AF)                                                                                                  \
+    do {                                                                                                                 \
+        auto kern = conv_wide_wgrad_kernel<CIN, AF>;                                                                     \
+        static size_t have = 0;                                                                                          \
+        if (lds > have) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            D2P_REQUIRE(e == hipSuccess, (int)e, "conv wide wgrad: %s", hipGetErrorString(e));                           \
+            have = lds;                                                                                                  \
+        }                                                                                                                \
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(WWG_WAVES * 64), lds, st, d, x, dy, slabs, dl);                      \
+    } while (0)
+        if (dl.in_scale) D2P_WIDE_WG(true);
+        else D2P_WIDE_WG(false);
+#undef D2P_WIDE_WG
+        D2P_LAUNCH_CHECK("conv_wide_wgrad");
+        EpiDense ep{dw, WCO, nullptr, 0, 0};
+        const long total = (long)KK * WCO;
+        const int rb = (int)((total * 16 + 255) / 256);
+        hipLaunchKernelGGL((gemm_splitk_reduce_kernel<EpiDense>), dim3(rb), dim3(256), 0, st, ep, slabs, KK, WCO, blocks);
+        D2P_LAUNCH_CHECK("conv_wide_wgrad_combine");
+    }
+    return 1;
+}
+
 }   // namespace
 
 // slices per demonstration index the folding forward launch writes statistics for; 0: geometry not taken
@@ -461,4 +693,24 @@ int d2p_conv_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, floa
     if (g.N == 0) return 1;
     if (g.Cin == 32) return launch_wide_dgrad<32>(g, dy, w, dx, st);
     return launch_wide_dgrad<48>(g, dy, w, dx, st);
+}
+
+size_t d2p_conv_wide_wgrad_ws(const ConvGeom& g) {
+    if (!wide_wgrad_ok(g)) return 0;
+    // (the most workgroups any dealing of this geometry uses: one per CU)
+    return (size_t)wide_cus() * 9 * g.Cin * WCO * sizeof(float);
+}
+
+// bn (optional): in_scale / in_shift = the input read through the previous layer's batch-norm apply (the pad pixels behind x)
+int d2p_conv_wide_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws, size_t ws_bytes,
+                        hipStream_t st, const ConvBnFold* bn) {
+    if (x_is_u8 || !wide_wgrad_ok(g)) return 0;
+    if (((uintptr_t)x & 15) || ((uintptr_t)dy & 15)) return 0;
+    if (bn) {
+        if (bn->G < 1 || bn->seq < 1 || g.N % (bn->G * bn->seq) != 0 || bn->G > 4096 || !bn->in_scale) return 0;
+        if (((uintptr_t)bn->in_scale) & 15) return 0;
+    }
+    if (g.N == 0) return 0;
+    if (g.Cin == 32) return launch_wide_wgrad<32>(g, (const float*)x, dy, dw, ws, ws_bytes, st, bn);
+    return launch_wide_wgrad<48>(g, (const float*)x, dy, dw, ws, ws_bytes, st, bn);
 }

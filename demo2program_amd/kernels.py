@@ -183,6 +183,12 @@ def conv_bn_slices(x_shape, Cout, G, seq):
     return int(_load_lib().d2p_conv_bn_slices(N, H, W, Cin, Cout, G, seq))
 
 
+def conv_bn_affine_ok(x_shape, Cout, G, seq):
+    """this layer's folding forward / weight-gradient launches read their input through the previous layer's batch-norm apply"""
+    N, H, W, Cin = x_shape
+    return bool(_load_lib().d2p_conv_bn_affine_ok(N, H, W, Cin, Cout, G, seq))
+
+
 def conv_fwd_bn(x, w, bias, G, seq, S, stats, act=1, out=None, in_affine=None):
     """conv_fwd that also leaves the batch-norm partial sums of its output in stats [G, S, Cout, 2] (fp64) and, with
     in_affine = (scale, shift) [G, Cin], reads its input as x * scale[g] + shift[g] (d2p_conv2d_nhwc_s2_same_fwd_bn)."""

@@ -41,6 +41,7 @@ SIGNATURES = {
     'd2p_conv2d_nhwc_s2_same_dgrad': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, P, S]),
     'd2p_conv2d_nhwc_s2_same_wgrad': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, P, c_size_t, S]),
     'd2p_conv_bn_slices': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
+    'd2p_conv_bn_affine_ok': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     'd2p_conv2d_nhwc_s2_same_fwd_bn': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, P, c_int, c_int, P, P,
                                                P, c_int, S]),
     'd2p_conv2d_nhwc_s2_same_wgrad_bn': (c_int, [c_int, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int, P, P, P,

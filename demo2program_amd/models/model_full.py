@@ -478,8 +478,8 @@ class Model(object):
             name = 'conv%d' % l
             S = K.conv_bn_slices(x.shape, cout, k, T) if (self.is_train and self.fold_bn) else 0
             nxt = self._conv[l] if l < len(self._conv) else None
-            fold_next = (S > 0 and nxt is not None and nxt[2] == 16 and
-                         K.conv_bn_slices((NF, ho, wo, cout), nxt[3], k, T) > 0)
+            # (round 6: every layer behind the first -- the 48-channel layers' kernels of conv_wide.hip take the affine too)
+            fold_next = (S > 0 and nxt is not None and K.conv_bn_affine_ok((NF, ho, wo, cout), nxt[3], k, T))
             # (read through the affine by the next layer: the k pad pixels sit right behind the activation)
             a_ext = self._buf(name + '/a', (NF * ho * wo * cout + (k * cout if fold_next else 0),))
             a = a_ext[:NF * ho * wo * cout].view(NF, ho, wo, cout)

@@ -275,6 +275,9 @@ int d2p_rn_fc1_bwd(int B, int k, int U, const float* y1a, const float* dy1, cons
  *   d2p_bn_apply_fwd: the apply pass of d2p_bn_group_fwd alone, y = gamma * (x - mean[g]) * rstd[g] + beta.
  * Same values as the separate launches up to the order of the fp64 sums / one fp32 rounding of the affine. */
 int d2p_conv_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq);
+/* 1 when this layer's folding forward and weight-gradient launches read their input through the previous layer's batch-norm
+ * apply (in_scale / in_shift + the G pad pixels behind x): the caller then never writes the normalised tensor. */
+int d2p_conv_bn_affine_ok(int N, int H, int W, int Cin, int Cout, int G, int seq);
 int d2p_conv2d_nhwc_s2_same_fwd_bn(int N, int H, int W, int Cin, int Cout, const void* x, int x_is_u8, const float* w,
                                    const float* bias, int act, float* y, int G, int seq, const float* in_scale,
                                    const float* in_shift, double* stats, int S, d2p_stream_t stream);

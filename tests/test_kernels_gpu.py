@@ -353,6 +353,20 @@ def test_wide_layers_forward_with_statistics_and_input_affine(K, B, G, T, H, Cin
         v = a2d[grp == gi].reshape(-1, 48)
         close(mean[gi], v.mean(0), atol=1e-6 * float(v.abs().max()) + 1e-7)
         close(rstd[gi], 1.0 / torch.sqrt(v.var(0, unbiased=False) + 1e-3), rtol=1e-5)
+    # the weight gradient with the same affine on its input (conv_wide_wgrad_kernel<.., true>: scale on the finished rows,
+    # shift / scale added to what is loaded, out-of-image taps on the pad pixel), and the plain one, against fp64
+    dy = rnd(N, Ho, Ho, 48, seed=26)
+    xr = xn.double().requires_grad_(True)
+    wr_ = w.double().requires_grad_(True)
+    _conv_ref(xr, wr_, b.double()).backward(dy.double())
+    dw = torch.empty(3, 3, Cin, 48, device='cuda')
+    K.conv_wgrad_bn(xd, dev(dy), dw, G, T, (dev(sc), dev(sh)))
+    close(dw, wr_.grad, atol=2e-5 * float(wr_.grad.abs().max()) + 1e-4, rtol=1e-5)
+    dwp = torch.empty(3, 3, Cin, 48, device='cuda')
+    K.conv_wgrad(dev(xn), dev(dy), dwp)
+    close(dwp, wr_.grad, atol=2e-5 * float(wr_.grad.abs().max()) + 1e-4, rtol=1e-5)
+    K.conv_wgrad(dev(xn), dev(dy), dw)
+    assert torch.equal(dw, dwp)                                  # deterministic combine
 
 
 @pytest.mark.parametrize('B,G,T', [(3, 2, 2), (2, 5, 4)])

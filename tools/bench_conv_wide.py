@@ -52,6 +52,7 @@ def main():
         st = torch.zeros(max(1, G * S * 48 * 2), dtype=torch.float64, device='cuda')
         fns = [('fwd', lambda: K.conv_fwd(x, w, b, act=1, out=y)),
                ('wgrad', lambda: K.conv_wgrad(x, dy, dw)),
+               ('wgrad+affine', lambda: K.conv_wgrad_bn(x, dy, dw, G, T, (sc, sh))),
                ('dgrad', lambda: K.conv_dgrad(dy, w, (N, H, H, Cin), dx=dx))]
         if S > 0:
             fns.insert(1, ('fwd+stats', lambda: K.conv_fwd_bn(x, w, b, G, T, S, st, act=1, out=y)))
@@ -60,7 +61,7 @@ def main():
         for name, fn in fns:
             out = []
             for label, sel in (('gemm', 0), ('default', 2)):
-                if label == 'gemm' and 'stats' in name:
+                if label == 'gemm' and ('stats' in name or 'affine' in name):
                     continue
                 lib.d2p_conv_set_direct(sel, sel, sel)
                 t = min(timed(fn), timed(fn))
