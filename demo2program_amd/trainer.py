@@ -280,6 +280,13 @@ class Trainer(object):
         # beside them only delays their start (one rank, forced RCCL group: 5.20 vs 5.02 ms/step); no
         # multi-GPU box was available to show a gain at N > 1
         self.dp_overlap = flag('D2P_DP_OVERLAP')
+        # CUs the recurrences behind the split point are planned for while a collective runs beside them (round 6): a
+        # four-wave workgroup -- a collective's kernel -- never becomes resident on a CU that holds a persistent
+        # recurrence's workgroup, so a launch over all 256 CUs and the collective only take turns; 7 row domains of 32
+        # column tiles instead of 8 cost the step 0.2 % (profiles/r06b_cu_budget_karel.log) and leave 32 CUs free.
+        # 0: the round-3 form (the recurrences behind the split run on the per-step kernels, which need no co-residency)
+        self.dp_overlap_cus = max(0, torch.cuda.get_device_properties(0).multi_processor_count - 32) \
+            if torch.cuda.is_available() else 0
         self._graphs = {}
         self._static_feed = None
         hyper_parameter_str = 'bs_{}_lr_{}_{}_cell_{}'.format(
@@ -359,16 +366,18 @@ class Trainer(object):
         dec = m.decoder_grad_offset() if overlap else 0
         start = None
         persist_was = K.lstm_is_persistent()
-        # the encoder recurrences that follow the split run beside the collective's kernels; the persistent kernels need
-        # every workgroup resident at once, which a collective waiting for a late peer can prevent -- per-step launches
-        # need no co-residency.  (A captured graph holds the launches it was captured with: the toggle acts on eager
-        # launches and at capture time.)
-        per_step_after_split = overlap and persist_was
+        # the encoder recurrences that follow the split run beside the collective's kernels.  The persistent kernels need
+        # every workgroup resident at once: they are planned for dp_overlap_cus CUs there, so that the collective's
+        # workgroups find CUs of their own (should it take more than that leaves -- a hand-off then times out -- the
+        # guarded step is skipped on every rank and re-run on the per-step kernels like any other hand-off failure).
+        # dp_overlap_cus = 0: per-step launches, which need no co-residency.  (A captured graph holds the launches it
+        # was captured with: both toggles act on eager launches and at capture time.)
+        budget_after_split = overlap and persist_was and self.dp_overlap_cus > 0
+        per_step_after_split = overlap and persist_was and not budget_after_split
         if overlap:
             def start():
                 self.dp.all_reduce_start(P.grad[dec:])
-                if per_step_after_split:
-                    K.lstm_set_persistent(False)
+                self._after_split(per_step_after_split, budget_after_split)
         try:
             if self.use_graph and not self._profiling():
                 loss = self._graphed_forward_backward(feed, start)
@@ -380,6 +389,8 @@ class Trainer(object):
         finally:
             if per_step_after_split:
                 K.lstm_set_persistent(True)       # (also when backward or the collective raised)
+            if budget_after_split:
+                K.lstm_set_cu_budget(0)
         slot = None
         if self.dp.active:
             # this rank's status word joins the exchange: after the SUM every rank skips the step together
@@ -410,6 +421,13 @@ class Trainer(object):
         self.adam_step = t
         self.global_step += 1
         return loss
+
+    def _after_split(self, per_step, budget):
+        """what changes for the recurrences behind backward's split point while the decoders' all-reduce is in flight"""
+        if per_step:
+            K.lstm_set_persistent(False)
+        if budget:
+            K.lstm_set_cu_budget(self.dp_overlap_cus)
 
     MAX_PERSIST_FAILURES = 2      # after that many the run stays on the per-step recurrent kernels
 
@@ -533,11 +551,19 @@ class Trainer(object):
                 with torch.cuda.stream(cap):
                     g1.capture_begin()
 
+                    persist = K.lstm_is_persistent()
+                    budget = persist and self.dp_overlap_cus > 0
+
                     def cut():
                         g1.capture_end()
                         g2.capture_begin(pool=g1.pool())
+                        self._after_split(persist and not budget, budget)   # (the launches behind the split, as eager steps plan them)
                     m.forward(static)
-                    m.backward(split_cb=cut)
+                    try:
+                        m.backward(split_cb=cut)
+                    finally:
+                        K.lstm_set_persistent(persist)
+                        K.lstm_set_cu_budget(0)
                     g2.capture_end()
                 torch.cuda.current_stream().wait_stream(cap)
                 g = (g1, g2)

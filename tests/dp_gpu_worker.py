@@ -9,6 +9,8 @@ case: per_step   -- recurrences on the per-step kernels (two processes' persiste
       persistent -- the persistent kernels left ON: whether a hand-off times out depends on how the two processes'
                     launches meet on the device; whatever happens, the guarded step / all-reduced status slot /
                     restore / re-run protocol must end at the same parameters
+      overlap_persistent -- D2P_DP_OVERLAP=1 with the persistent kernels ON: the recurrences behind backward's split point are
+                    planned for Trainer.dp_overlap_cus CUs (round 6) -- the same protocol guarantees as `persistent`
       inject     -- persistent kernels on, and rank 1's status word is set before its step 1 (as a timed-out hand-off
                     sets it): BOTH ranks must skip that step on the device and re-run it
 """
@@ -38,7 +40,7 @@ def rank_batches(cfg, rank):
 def main():
     rank, world, port, outdir, case = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4], sys.argv[5]
     os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=port,
-                      D2P_GRAPH='0', D2P_DP_OVERLAP='1' if case == 'overlap' else '0')
+                      D2P_GRAPH='0', D2P_DP_OVERLAP='1' if case in ('overlap', 'overlap_persistent') else '0')
     import numpy as np
     import torch
     from demo2program_amd import kernels as K
@@ -50,6 +52,8 @@ def main():
     if case in ('per_step', 'overlap'):
         K.lstm_set_persistent(False)
     tr = Trainer(cfg, make_train_dir=False, dp=dp)
+    if case == 'overlap_persistent':
+        assert tr.dp_overlap and tr.dp_overlap_cus > 0
     if rank == 0:
         tr.model.params.load(params)           # rank 1 keeps its own initialiser: the broadcast must overwrite it
     dp.broadcast_params(tr.model.params.flat)

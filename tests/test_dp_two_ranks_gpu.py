@@ -80,7 +80,7 @@ def _run_case(case, tmp_path):
     return [np.load(os.path.join(str(tmp_path), 'rank%d.npz' % r)) for r in range(2)], outs
 
 
-@pytest.mark.parametrize('case', ['per_step', 'overlap', 'persistent', 'inject'])
+@pytest.mark.parametrize('case', ['per_step', 'overlap', 'persistent', 'overlap_persistent', 'inject'])
 def test_two_ranks_on_one_gpu_equal_averaged_independent_steps(case, tmp_path, reference):
     from dp_gpu_worker import N_STEPS
     r, outs = _run_case(case, tmp_path)

@@ -1044,8 +1044,9 @@ def test_rccl_single_rank_self_test(monkeypatch):
         dp.barrier()
     finally:
         dp.shutdown()
-    # the one-message form runs the very same kernels; the overlap forms run the encoder recurrences on the per-step
-    # kernels (beside a collective the persistent ones are not used) and the graph form multiplies the padded rows in
+    # the one-message form runs the very same kernels; the overlap forms plan the encoder recurrences behind the split for
+    # Trainer.dp_overlap_cus CUs (seven row domains instead of eight: another summation order of the bias gradients) and
+    # the graph form multiplies the padded rows in
     # its weight gradients (no row lists in a captured step): equal to fp32 round-off, not bit for bit
     assert one_message == plain
     for other in (with_group, eager, two_streams):
