@@ -825,10 +825,12 @@ extern "C" int d2p_bn_group_fwd_batched(int nb, long xs, long ys, long ps, long 
                        moving_var, decay, ws, ws_bytes, stream);
 }
 
+// sums / S_sums (optional, nb == 1): the partial sums [G][S_sums][C][2] fp64 = (sum dy, sum dy * xhat) the PRODUCER of dy left
+// behind (an input-gradient conv launch: ConvDgradBn) -- the partial-sum pass over (x, dy) is then not run
 static int bn_bwd_impl(int nb, long xs, long ys, long ps, int R, int C, int G, int inner, const float* x,
                        const float* dy, const float* gamma, const float* mean, const float* rstd, int act_bwd,
                        float* dx, float* dgamma, float* dbeta, float* dx_colsum, void* ws, size_t ws_bytes,
-                       d2p_stream_t stream) {
+                       d2p_stream_t stream, const double* sums = nullptr, int S_sums = 0) {
     int rc = bn_check(R, C, G, inner);
     if (rc) return rc;
     if (R == 0) return D2P_OK;
@@ -849,11 +851,15 @@ static int bn_bwd_impl(int nb, long xs, long ys, long ps, int R, int C, int G, i
     const bool vec4 = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)dy) & 15) == 0);
     BnFold fo{};
     unsigned* tickets = nullptr;
-    if (bn_fold_ok(nb, G, p.S, C)) {
+    D2P_REQUIRE(!sums || (nb == 1 && S_sums >= 1), D2P_EINVAL, "bn bwd: sums need one problem and S_sums >= 1");
+    const int S_use = sums ? S_sums : p.S;
+    if (!sums && bn_fold_ok(nb, G, p.S, C)) {
         tickets = fo.tickets = bn_ticket_slot();
         fo.m12 = m12; fo.dgamma = dgamma; fo.dbeta = dbeta; fo.gsum = gsum;
     }
-    if (vec4)
+    if (sums) {
+        partial = const_cast<double*>(sums);
+    } else if (vec4)
         hipLaunchKernelGGL((bn_partial_kernel<1, 4>), dim3(G, p.S, nb), dim3(256), 0, st, n, C, G, inner,
                            p.lanes_c, p.row_lanes, x, dy, mean, rstd, partial, bb, fo);
     else
@@ -864,12 +870,12 @@ static int bn_bwd_impl(int nb, long xs, long ys, long ps, int R, int C, int G, i
     // group sums, m12 by one wavefront per (group, channel)
     const bool gc = !fo.tickets && g_bn_gc && dx_colsum != nullptr;
     if (gc) {
-        hipLaunchKernelGGL(bn_finalize_bwd_gc_kernel, dim3(ceil_div(G * C, 4), 1, nb), dim3(256), 0, st, n, C, G, p.S,
+        hipLaunchKernelGGL(bn_finalize_bwd_gc_kernel, dim3(ceil_div(G * C, 4), 1, nb), dim3(256), 0, st, n, C, G, S_use,
                            partial, m12, gsum, bb);
         D2P_LAUNCH_CHECK("bn_finalize_bwd");
     } else if (!fo.tickets) {
         hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(ceil_div(C, 4), 1, nb), dim3(256), 0, st, n, C, G,
-                           p.S, partial, m12, dgamma, dbeta, bb);
+                           S_use, partial, m12, dgamma, dbeta, bb);
         D2P_LAUNCH_CHECK("bn_finalize_bwd");
     }
     const bool v4 = (C % 4 == 0) && al && ((((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0);
@@ -977,6 +983,14 @@ extern "C" int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, 
                                 void* ws, size_t ws_bytes, d2p_stream_t stream) {
     return bn_bwd_impl(1, 0, 0, 0, R, C, G, inner, x, dy, gamma, mean, rstd, act_bwd, dx, dgamma, dbeta, dx_colsum, ws,
                        ws_bytes, stream);
+}
+extern "C" int d2p_bn_group_bwd_sums(int R, int C, int G, int inner, const float* x, const float* dy,
+                                     const float* gamma, const float* mean, const float* rstd,
+                                     int act_bwd, float* dx, float* dgamma, float* dbeta, float* dx_colsum,
+                                     const double* sums, int S_sums, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    D2P_REQUIRE(sums && S_sums >= 1, D2P_EINVAL, "bn bwd (sums): null sums or S_sums = %d", S_sums);
+    return bn_bwd_impl(1, 0, 0, 0, R, C, G, inner, x, dy, gamma, mean, rstd, act_bwd, dx, dgamma, dbeta, dx_colsum, ws,
+                       ws_bytes, stream, sums, S_sums);
 }
 extern "C" int d2p_bn_group_bwd_batched(int nb, long xs, long ys, long ps, int R, int C, int G, int inner,
                                         const float* x, const float* dy, const float* gamma, const float* mean,

@@ -301,7 +301,8 @@ extern "C" int d2p_conv2d_nhwc_s2_same_wgrad_bn(int N, int H, int W, int Cin, in
 extern "C" int d2p_conv_dgrad_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
-    return d2p_conv_rows_dgrad_slices(g, G, seq);
+    const int S = d2p_conv_rows_dgrad_slices(g, G, seq);
+    return S > 0 ? S : d2p_conv_wide_dgrad_bn_slices(g, G, seq);
 }
 extern "C" int d2p_conv2d_nhwc_s2_same_dgrad_bn(int N, int H, int W, int Cin, int Cout, const float* dy, const float* w,
                                                 float* dx, const float* act, const float* mean, const float* rstd, int G,

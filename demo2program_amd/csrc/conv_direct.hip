@@ -781,7 +781,10 @@ static int launch_dgrad(const ConvGeom& g, const float* dy, const float* w, floa
 
 int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st,
                           const ConvDgradBn* bn) {
-    if (bn) return d2p_conv_rows_dgrad(g, dy, w, dx, st, bn);      // (statistics out: the row-strip kernel only)
+    if (bn) {       // (statistics out: the row-strip kernel of the 16 -> 32 layer, the wide kernel of the 48-channel layers)
+        const int rc = d2p_conv_rows_dgrad(g, dy, w, dx, st, bn);
+        return rc != 0 ? rc : d2p_conv_wide_dgrad(g, dy, w, dx, st, bn);
+    }
     if (!g_direct_dgrad) return 0;
     if (g_direct_dgrad >= 2) {
         int rc = d2p_conv_rows_dgrad(g, dy, w, dx, st);

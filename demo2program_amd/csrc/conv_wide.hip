@@ -283,152 +283,237 @@ int launch_wide_fwd(const ConvGeom& g, const float* x, const float* w, const flo
 
 
 // ==========================================================================================
-// input gradient: dX[pix, ci] = sum_(tap, co) dY[(pix + pad - tap) / 2, co] * W[tap, ci, co], one parity class of input
-// pixels per workgroup (even coordinate: taps {0, 2}, odd: tap {1} -- 4 / 2 / 2 / 1 taps per class).  Same skeleton as the
-// forward kernel: the class's W^T fragments in LDS (A operand: [ci][co], 16-byte loads -- co is contiguous in W), dY
-// gathered with one 16-byte load per (pixel, tap, 4 channels), a wave owns whole 16-pixel tiles of its class.
+// input gradient: dX[pix, ci] = sum_(tap, co) dY[(pix + pad - tap) / 2, co] * W[tap, ci, co].  An input pixel sees the taps
+// of its parity class only (even coordinate: taps {0, 2}, odd: tap {1} -- 4 / 2 / 2 / 1 taps), and the four pixels of a
+// 2x2 BLOCK of the input (one of each class) read the same 2x2 neighbourhood of dY.  So the unit of work is the block:
+// a lane's 16-pixel tile is 16 blocks, the neighbourhood is gathered once (12 16-byte loads serve all nine taps), one
+// index decomposition per four output pixels, and a wave runs 9 x 3 x 4 x CIN/16 MFMAs per tile like the forward kernel
+// -- W^T fragments of all nine taps in LDS (A operand [ci][co]: 16-byte loads, co is contiguous in W).  (The first form,
+// one parity class per workgroup, gathered per class: 0.42 of the fp32 MFMA peak at conv3 -- the single-tap class spent
+// more on its index arithmetic than on its 24 MFMAs per tile.)
+// BNSTATS (ConvDgradBn): dX is the gradient w.r.t. the previous layer's batch-norm OUTPUT; the launch also leaves that
+// batch norm's backward partial sums per demonstration index -- (sum dX, sum dX * xhat) from the previous layer's
+// pre-norm activation read at the pixels it writes -- so no pass over (activation, dX) is needed for them.
 // ==========================================================================================
-struct WDgCls {
-    int iy0, ix0, Hc, Wc, P, blk0, nblk, ntiles;
-    WDiv d_hw, d_w;
-};
-struct WDgArgs {
-    WDgCls c[4];             // indexed by e = 2 EY + EX, EY = (iy + pt) & 1
-};
 constexpr int WDG_WAVES = 8;
-
-template <int E>             // E = 0: taps {0, 2};  E = 1: tap {1}
-struct WClsTaps {
-    static constexpr int n = E ? 1 : 2;
-    static constexpr int k(int i) { return E ? 1 : 2 * i; }
+struct WDgBlk {
+    int Hb, Wb;               // blocks per frame
+    int iy0[2], ix0[2];       // first row / column of parity class e: (iy + pt) & 1 == e
+    int Hc[2], Wc[2];         // rows / columns of the class
+    WDiv d_hw, d_w;           // / (Hb * Wb), / Wb
+    const float* act; const float* mean; const float* rstd;     // BNSTATS: [pixels, CIN], [G, CIN], [G, CIN]
 };
 
-template <int CIN, int EY, int EX>
-__device__ __forceinline__ void wide_dgrad_class(const WideGeom& g, const WDgCls& c, const float* __restrict__ dy,
-                                                 const float* __restrict__ w, float* __restrict__ dx, f32x4* wl) {
+template <int CIN, int PT, int PL, bool BNSTATS>
+__global__ void __launch_bounds__(WDG_WAVES * 64)
+conv_wide_dgrad_kernel(WideGeom g, WDgBlk c, const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
+                       WideDeal dl) {
     constexpr int CC = WCO / 16, NBI = CIN / 16;
-    constexpr int NTY = WClsTaps<EY>::n, NTX = WClsTaps<EX>::n, NT = NTY * NTX;
-    const int tid = threadIdx.x, lane = tid & 63, p = lane & 15, q = lane >> 4;
-    // ---- W^T -> LDS: wl[((t * CC + cc) * NBI + b) * 64 + l][j] = W[tap t][ci = 16 b + p][co = 16 cc + 4q + j]
-    for (int i = tid; i < NT * CC * NBI * 64; i += WDG_WAVES * 64) {
+    extern __shared__ __attribute__((aligned(16))) float wide_lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(wide_lds);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
+    const int sg = (int)blockIdx.x / dl.S, ss = (int)blockIdx.x - sg * dl.S;
+    // ---- W^T -> LDS: wl[((tap * CC + cc) * NBI + b) * 64 + l][j] = W[tap][ci = 16 b + p][co = 16 cc + 4q + j]
+    for (int i = tid; i < 9 * CC * NBI * 64; i += WDG_WAVES * 64) {
         const int l = i & 63;
         int r = i >> 6;
         const int b = r % NBI;
         r /= NBI;
-        const int cc = r % CC, t = r / CC;
-        const int ty = t / NTX, tx = t - ty * NTX;
-        const int tap = (EY ? 1 : 2 * ty) * 3 + (EX ? 1 : 2 * tx);
+        const int cc = r % CC, tap = r / CC;
         wl[i] = wldg4(w + (tap * CIN + b * 16 + (l & 15)) * WCO + cc * 16 + 4 * (l >> 4));
     }
+    f32x4 fs[NBI], fq[NBI];                 // BNSTATS: per-lane sums of dX and of dX * activation
+#pragma unroll
+    for (int b = 0; b < NBI; ++b) fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    const int NW = c.nblk * WDG_WAVES;
-    for (int tile = ((int)blockIdx.x - c.blk0) * WDG_WAVES + __builtin_amdgcn_readfirstlane(tid >> 6); tile < c.ntiles;
-         tile += NW) {
-        const int j = tile * 16 + p;
-        const bool valid = j < c.P;
-        const int jc = valid ? j : 0;
-        const int n = wdiv(jc, c.d_hw);
-        const int rem = jc - n * c.Hc * c.Wc;
-        const int a = wdiv(rem, c.d_w), bcol = rem - a * c.Wc;
-        const int iy = c.iy0 + 2 * a, ix = c.ix0 + 2 * bcol;
-        f32x4 v[NT][CC];
-        unsigned okmask = 0u;
+    const int tlo = ss * dl.per_slice, thi = min(tlo + dl.per_slice, dl.per_idx);
+    int tile = tlo + __builtin_amdgcn_readfirstlane(wave);
+    int tb = tile / dl.tps, tr = tile - tb * dl.tps;
+    const int HbWb = c.Hb * c.Wb;
+    for (; tile < thi; tile += WDG_WAVES) {
+        const int local = tr * 16 + p;                        // block of this lane inside its sequence
+        const bool valid = local < dl.seqpix;
+        const int lc = valid ? local : 0;
+        const int t = wdiv(lc, c.d_hw);
+        const int rem = lc - t * HbWb;
+        const int a = wdiv(rem, c.d_w), bcol = rem - a * c.Wb;
+        const int n = (tb * dl.G + sg) * (dl.seqpix / HbWb) + t;      // frame
+        // ---- the 2x2 neighbourhood of dY: rows a + PT - 1, a + PT; columns likewise
+        const int r_lo = a + PT - 1, c_lo = bcol + PL - 1;
+        bool rok[2], cok[2];
+        int roff[2], coff[2];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int ky = WClsTaps<EY>::k(t / NTX), kx = WClsTaps<EX>::k(t % NTX);
-            const int oy = (iy + g.pt - ky) >> 1, ox = (ix + g.pl - kx) >> 1;
-            const bool ok = valid & (oy >= 0) & (oy < g.Ho) & (ox >= 0) & (ox < g.Wo);
-            unsigned off = (unsigned)(((n * g.Ho + wclamp(oy, g.Ho - 1)) * g.Wo + wclamp(ox, g.Wo - 1)) * WCO + 4 * q);
-            D2P_OPAQUE_U(off);
-#pragma unroll
-            for (int cc = 0; cc < CC; ++cc) v[t][cc] = wldg4(dy + off + cc * 16);
-            okmask |= ok ? (1u << t) : 0u;
+        for (int k = 0; k < 2; ++k) {
+            rok[k] = valid & ((unsigned)(r_lo + k) < (unsigned)g.Ho);
+            cok[k] = (unsigned)(c_lo + k) < (unsigned)g.Wo;
+            roff[k] = (n * g.Ho + wclamp(r_lo + k, g.Ho - 1)) * g.Wo;
+            coff[k] = wclamp(c_lo + k, g.Wo - 1);
         }
-        f32x4 acc[2][NBI];
+        f32x4 v[2][2][CC];
+        float okf[2][2];
 #pragma unroll
-        for (int b = 0; b < NBI; ++b) acc[0][b] = acc[1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int ry = 0; ry < 2; ++ry)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float okf = ((okmask >> t) & 1u) ? 1.f : 0.f;
+            for (int rx = 0; rx < 2; ++rx) {
+                unsigned off = (unsigned)((roff[ry] + coff[rx]) * WCO + 4 * q);
+                D2P_OPAQUE_U(off);
+#pragma unroll
+                for (int cc = 0; cc < CC; ++cc) v[ry][rx][cc] = wldg4(dy + off + cc * 16);
+                okf[ry][rx] = (rok[ry] & cok[rx]) ? 1.f : 0.f;
+            }
+        // ---- nine taps: tap (ky, kx) belongs to class (ky odd, kx odd) and reads neighbour (row(ky), col(kx)):
+        //      ky = 0 -> the high row, ky = 2 -> the low row, ky = 1 -> row a (= high for PT = 0, low for PT = 1)
+        f32x4 acc[4][2][NBI];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int b = 0; b < NBI; ++b) acc[e][0][b] = acc[e][1][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            constexpr int dummy = 0;
+            (void)dummy;
+            const int ky = tap / 3, kx = tap % 3;
+            const int ey = ky & 1, ex = kx & 1;
+            const int ry = ky == 0 ? 1 : (ky == 2 ? 0 : (PT ? 0 : 1));
+            const int rx = kx == 0 ? 1 : (kx == 2 ? 0 : (PL ? 0 : 1));
+            const int e = 2 * ey + ex;
 #pragma unroll
             for (int cc = 0; cc < CC; ++cc) {
-                const f32x4 bb = v[t][cc] * okf;
+                const f32x4 bb = v[ry][rx][cc] * okf[ry][rx];
 #pragma unroll
                 for (int b = 0; b < NBI; ++b) {
-                    const f32x4 a4 = wl[((t * CC + cc) * NBI + b) * 64 + lane];
+                    const f32x4 a4 = wl[((tap * CC + cc) * NBI + b) * 64 + lane];
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) acc[jj & 1][b] = D2P_MFMA16(a4[jj], bb[jj], acc[jj & 1][b]);
+                    for (int jj = 0; jj < 4; ++jj) acc[e][jj & 1][b] = D2P_MFMA16(a4[jj], bb[jj], acc[e][jj & 1][b]);
                 }
             }
         }
-        if (valid) {
-            const long xoff = ((long)(n * g.H + iy) * g.W + ix) * CIN;
+        // ---- the block's four input pixels
 #pragma unroll
-            for (int b = 0; b < NBI; ++b) *reinterpret_cast<f32x4*>(dx + xoff + b * 16 + 4 * q) = acc[0][b] + acc[1][b];
+        for (int e = 0; e < 4; ++e) {
+            const int ey = e >> 1, ex = e & 1;
+            const bool in = valid & (a < c.Hc[ey]) & (bcol < c.Wc[ex]);
+            const int iy = c.iy0[ey] + 2 * a, ix = c.ix0[ex] + 2 * bcol;
+            const long xoff = ((long)(n * g.H + (in ? iy : 0)) * g.W + (in ? ix : 0)) * CIN;
+#pragma unroll
+            for (int b = 0; b < NBI; ++b) {
+                const f32x4 o = acc[e][0][b] + acc[e][1][b];
+                if (in) *reinterpret_cast<f32x4*>(dx + xoff + b * 16 + 4 * q) = o;
+                if (BNSTATS) {
+                    const f32x4 av = wldg4(c.act + xoff + b * 16 + 4 * q);
+                    const f32x4 om = o * (in ? 1.f : 0.f);
+                    fs[b] += om;
+                    fq[b] += om * av;
+                }
+            }
+        }
+        tr += WDG_WAVES;
+        while (tr >= dl.tps) { tr -= dl.tps; ++tb; }
+    }
+    if (BNSTATS) {
+        // (sum dX, sum dX * xhat) with xhat = (act - mean) rstd: rstd (sum dX act - mean sum dX), in fp64 from here on;
+        // the 16 pixel lanes by xor-shuffles, the waves through LDS in wave order
+        __shared__ double wsum[WDG_WAVES * 48 * 2];
+#pragma unroll
+        for (int b = 0; b < NBI; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double u = (double)fs[b][r], s2 = (double)fq[b][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    u += __shfl_xor(u, off, 64);
+                    s2 += __shfl_xor(s2, off, 64);
+                }
+                if (p == 0) {
+                    wsum[(wave * CIN + b * 16 + 4 * q + r) * 2] = u;
+                    wsum[(wave * CIN + b * 16 + 4 * q + r) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < CIN) {
+            double sd = 0.0, sda = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < WDG_WAVES; ++wv) {
+                sd += wsum[(wv * CIN + tid) * 2];
+                sda += wsum[(wv * CIN + tid) * 2 + 1];
+            }
+            const double mu = (double)c.mean[sg * CIN + tid], rs = (double)c.rstd[sg * CIN + tid];
+            dl.stats[((long)blockIdx.x * CIN + tid) * 2] = sd;
+            dl.stats[((long)blockIdx.x * CIN + tid) * 2 + 1] = rs * (sda - mu * sd);
         }
     }
 }
 
-template <int CIN>
-__global__ void __launch_bounds__(WDG_WAVES * 64)
-conv_wide_dgrad_kernel(WideGeom g, WDgArgs a, const float* __restrict__ dy, const float* __restrict__ w,
-                       float* __restrict__ dx) {
-    extern __shared__ __attribute__((aligned(16))) float wide_lds[];
-    f32x4* wl = reinterpret_cast<f32x4*>(wide_lds);
-    const int b = blockIdx.x;
-    if (b < a.c[1].blk0) wide_dgrad_class<CIN, 0, 0>(g, a.c[0], dy, w, dx, wl);
-    else if (b < a.c[2].blk0) wide_dgrad_class<CIN, 0, 1>(g, a.c[1], dy, w, dx, wl);
-    else if (b < a.c[3].blk0) wide_dgrad_class<CIN, 1, 0>(g, a.c[2], dy, w, dx, wl);
-    else wide_dgrad_class<CIN, 1, 1>(g, a.c[3], dy, w, dx, wl);
+// slices per index of the input-gradient launch (one round of workgroups; a tile per wave at least)
+void wide_dgrad_blocks(const ConvGeom& g, WDgBlk& c) {
+    for (int e = 0; e < 2; ++e) {
+        c.iy0[e] = e ^ (g.pt & 1);            // (iy + pt) & 1 == e
+        c.ix0[e] = e ^ (g.pl & 1);
+        c.Hc[e] = c.iy0[e] < g.H ? (g.H - c.iy0[e] + 1) / 2 : 0;
+        c.Wc[e] = c.ix0[e] < g.W ? (g.W - c.ix0[e] + 1) / 2 : 0;
+    }
+    c.Hb = c.Hc[0] > c.Hc[1] ? c.Hc[0] : c.Hc[1];
+    c.Wb = c.Wc[0] > c.Wc[1] ? c.Wc[0] : c.Wc[1];
+    c.d_hw = make_wdiv(c.Hb * c.Wb);
+    c.d_w = make_wdiv(c.Wb);
+}
+int wide_dgrad_slices(const ConvGeom& g, int G, int seq) {
+    WDgBlk cb{};
+    wide_dgrad_blocks(g, cb);
+    const int Hb = cb.Hb, Wb = cb.Wb;
+    const long tps = ((long)seq * Hb * Wb + 15) / 16;
+    const long per_idx = (long)g.N / (G * seq) * tps;
+    long S = wide_cus() / G;
+    const long cap = per_idx / WDG_WAVES;
+    if (S > cap) S = cap;
+    return (int)(S < 1 ? 1 : S);
 }
 
 template <int CIN>
-int launch_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+int launch_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st, const ConvDgradBn* bn) {
     WideGeom d = make_wide(g);
-    WDgArgs a;
-    long work[4], total = 0;
-    for (int e = 0; e < 4; ++e) {
-        const int ey = e >> 1, ex = e & 1;
-        WDgCls& c = a.c[e];
-        c.iy0 = ey ^ (g.pt & 1);            // (iy + pt) & 1 == ey
-        c.ix0 = ex ^ (g.pl & 1);
-        c.Hc = c.iy0 < g.H ? (g.H - c.iy0 + 1) / 2 : 0;
-        c.Wc = c.ix0 < g.W ? (g.W - c.ix0 + 1) / 2 : 0;
-        c.P = g.N * c.Hc * c.Wc;
-        c.ntiles = ceil_div(c.P, 16);
-        c.d_hw = make_wdiv(c.Hc * c.Wc > 0 ? c.Hc * c.Wc : 1);
-        c.d_w = make_wdiv(c.Wc > 0 ? c.Wc : 1);
-        work[e] = (long)c.ntiles * (ey ? 1 : 2) * (ex ? 1 : 2);
-        total += work[e];
-    }
-    if (total == 0) return 1;
-    // two workgroups per CU (<= 36 KB of LDS, 8 waves each), dealt out by the classes' MFMA counts; a tile per wave at least
-    const int budget = 2 * wide_cus();
-    int blk = 0;
-    for (int e = 0; e < 4; ++e) {
-        WDgCls& c = a.c[e];
-        long nb = c.ntiles > 0 ? (work[e] * budget + total - 1) / total : 0;
-        const long cap = ceil_div(c.ntiles, WDG_WAVES);
-        if (nb > cap) nb = cap;
-        if (c.ntiles > 0 && nb < 1) nb = 1;
-        c.nblk = (int)nb;
-        c.blk0 = blk;
-        blk += c.nblk;
-    }
-    constexpr size_t lds = (size_t)4 * 3 * (CIN / 16) * 64 * sizeof(f32x4);
+    WDgBlk c{};
+    wide_dgrad_blocks(g, c);
+    c.act = bn ? bn->act : nullptr; c.mean = bn ? bn->mean : nullptr; c.rstd = bn ? bn->rstd : nullptr;
+    WideDeal dl{};
+    const int G = bn ? bn->G : 1, seq = bn ? bn->seq : g.N;
+    dl.G = G;
+    dl.seqpix = seq * c.Hb * c.Wb;                 // (blocks of one sequence)
+    dl.tps = ceil_div(dl.seqpix, 16);
+    dl.per_idx = g.N / (G * seq) * dl.tps;
+    dl.S = bn ? bn->S : wide_dgrad_slices(g, 1, g.N);
+    dl.per_slice = ceil_div(dl.per_idx, dl.S);
+    dl.stats = bn ? bn->stats : nullptr;
+    constexpr size_t lds = (size_t)9 * 3 * (CIN / 16) * 64 * sizeof(f32x4);
     D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * WCO);
-    auto kern = conv_wide_dgrad_kernel<CIN>;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        D2P_REQUIRE(e == hipSuccess, (int)e, "conv wide dgrad: %s", hipGetErrorString(e));
-        attr = true;
+    const dim3 grid(G * dl.S), block(WDG_WAVES * 64);
+#define D2P_WIDE_DG(PT_, PL_, BN_)                                                                                  \
+    do {                                                                                                            \
+        auto kern = conv_wide_dgrad_kernel<CIN, PT_, PL_, BN_>;                                                     \
+        static bool attr = false;                                                                                   \
+        if (!attr) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            D2P_REQUIRE(e == hipSuccess, (int)e, "conv wide dgrad: %s", hipGetErrorString(e));                      \
+            attr = true;                                                                                            \
+        }                                                                                                           \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, d, c, dy, w, dx, dl);                                        \
+    } while (0)
+    const int pp = (g.pt ? 2 : 0) | (g.pl ? 1 : 0);
+    if (bn) {
+        if (pp == 0) D2P_WIDE_DG(0, 0, true);
+        else if (pp == 1) D2P_WIDE_DG(0, 1, true);
+        else if (pp == 2) D2P_WIDE_DG(1, 0, true);
+        else D2P_WIDE_DG(1, 1, true);
+    } else {
+        if (pp == 0) D2P_WIDE_DG(0, 0, false);
+        else if (pp == 1) D2P_WIDE_DG(0, 1, false);
+        else if (pp == 2) D2P_WIDE_DG(1, 0, false);
+        else D2P_WIDE_DG(1, 1, false);
     }
-    hipLaunchKernelGGL(kern, dim3(blk), dim3(WDG_WAVES * 64), lds, st, d, a, dy, w, dx);
+#undef D2P_WIDE_DG
     D2P_LAUNCH_CHECK("conv_wide_dgrad");
     return 1;
 }
-
 
 // ==========================================================================================
 // weight gradient: dW[tap, ci, co] = sum_pix x[pix @ tap, ci] * dY[pix, co] -- the reduction index is the PIXEL (4 per
@@ -686,13 +771,23 @@ int d2p_conv_wide_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float
     return launch_wide_fwd<48>(g, (const float*)x, w, bias, act, y, st, bn);
 }
 
-int d2p_conv_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st) {
+// slices per index of the input-gradient launch that also leaves the previous layer's batch-norm-backward sums; 0: not taken
+int d2p_conv_wide_dgrad_bn_slices(const ConvGeom& g, int G, int seq) {
+    if (!wide_geom_ok(g) || G < 1 || seq < 1 || g.N % (G * seq) != 0 || G > 4096) return 0;
+    return wide_dgrad_slices(g, G, seq);
+}
+
+int d2p_conv_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st, const ConvDgradBn* bn) {
     if (!wide_geom_ok(g)) return 0;
     if (((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)w & 15)) return 0;
     if ((size_t)g.N * g.Ho * g.Wo * WCO >= (1ull << 32)) return 0;
+    if (bn) {
+        if (!bn->act || !bn->mean || !bn->rstd || !bn->stats || ((uintptr_t)bn->act & 15)) return 0;
+        if (bn->S < 1 || bn->S != d2p_conv_wide_dgrad_bn_slices(g, bn->G, bn->seq)) return 0;
+    }
     if (g.N == 0) return 1;
-    if (g.Cin == 32) return launch_wide_dgrad<32>(g, dy, w, dx, st);
-    return launch_wide_dgrad<48>(g, dy, w, dx, st);
+    if (g.Cin == 32) return launch_wide_dgrad<32>(g, dy, w, dx, st, bn);
+    return launch_wide_dgrad<48>(g, dy, w, dx, st, bn);
 }
 
 size_t d2p_conv_wide_wgrad_ws(const ConvGeom& g) {

@@ -391,14 +391,20 @@ def bn_fwd(x2d, gamma, beta, G, inner, y=None, mean=None, rstd=None, var=None, m
     return y, mean, rstd, var
 
 
-def bn_bwd(x2d, dy, gamma, mean, rstd, G, inner, act_bwd, dgamma, dbeta, dx=None, dbias=None):
+def bn_bwd(x2d, dy, gamma, mean, rstd, G, inner, act_bwd, dgamma, dbeta, dx=None, dbias=None, sums=None):
     """Training-mode BN backward (+ lrelu' of the layer underneath when act_bwd).  dbias, if
-    given, receives colsum(dx): the gradient of the bias added before the activation."""
+    given, receives colsum(dx): the gradient of the bias added before the activation.
+    sums = (stats, S): the partial sums the producer of dy left (conv_dgrad_bn) -- no partial-sum pass over x and dy."""
     _require_gpu(x2d, dy)
     R, C = x2d.shape
     if dx is None:
         dx = torch.empty_like(x2d)
     ws, wsb = SCRATCH.get(call.d2p_bn_ws_bytes(R, C, G))
+    if sums is not None:
+        call.d2p_bn_group_bwd_sums(R, C, G, inner, ptr(x2d), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd),
+                                   1 if act_bwd else 0, ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dbias), ptr(sums[0]), sums[1],
+                                   ws, wsb, current_stream())
+        return dx
     call.d2p_bn_group_bwd(R, C, G, inner, ptr(x2d), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd),
                           1 if act_bwd else 0, ptr(dx), ptr(dgamma), ptr(dbeta), ptr(dbias), ws, wsb,
                           current_stream())

@@ -78,6 +78,7 @@ SIGNATURES = {
                                          P, P, P, P, P, c_size_t, S]),
     'd2p_bn_group_fwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, c_float, P, c_size_t, S]),
     'd2p_bn_group_bwd': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, c_size_t, S]),
+    'd2p_bn_group_bwd_sums': (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, c_int, P, c_size_t, S]),
     'd2p_bn_inference_fwd': (c_int, [c_int, c_int, P, P, P, P, P, P, S]),
     'd2p_bn_set_fold': (c_int, [c_int]),
     'd2p_bn_update_moving': (c_int, [c_int, c_int, c_float, P, P, P, P, S]),

@@ -144,6 +144,7 @@ class Model(object):
         self._bufs = {}
         self._feed = None
         self._ctx = None
+        self._marks = None                    # (tools/step_marks.py: list of (name, event) while measuring)
         self.forward_count = 0                # forward passes so far (trainer.StepOutput: is a step's output still there?)
         self._conv = conv_shapes(config)
         self._fused_enc_ok = {}
@@ -197,6 +198,15 @@ class Model(object):
         self._ablate = frozenset()
         self._abl_cache = {}
         self._reserve_scratch()
+
+    def mark(self, name):
+        """MEASUREMENT HOOK (tools/step_marks.py): when `self._marks` is a list, a timing event on the CURRENT stream is
+        appended under `name` -- the device time at which everything enqueued on that stream so far has finished.  Off
+        (None) in every product path: one attribute test per call."""
+        if self._marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((name, ev))
 
     def set_ablation(self, names):
         """MEASUREMENT HOOK (tools/step_ablation.py, bench.py --ablate): leaves the named pieces of the step out from the
@@ -450,6 +460,7 @@ class Model(object):
         side = self._side_stream()
 
         # ---- State_Encoder: conv -> +bias -> lrelu -> BN(train), per demo-index statistics
+        self.mark('fwd:start')
         x = feed['s_h']
         ctx['conv'] = []
         feats_tm = None
@@ -533,6 +544,7 @@ class Model(object):
                         z_e1, 4 * U, act_rows[0], bias=p['demo_lstm/bias'])
         else:
             z_e1 = self._lstm_xproj('demo_lstm', feats_tm.view(T * M, F), F, M, T, T)
+        self.mark('fwd:conv+xproj1')
         # (forked here, not at the start of the step: beside the chain of small conv / batch-norm launches
         #  these GEMMs only took the CUs the chain was waiting for -- 320 us instead of 100 for the chain;
         #  beside the first recurrence they fill matrix-pipe time its hand-offs leave)
@@ -548,6 +560,7 @@ class Model(object):
         e1 = self._lstm_fwd('demo_lstm', feats_tm.view(T * M, F), F, M, T, T, None, None, lens_d,
                             want_final=True, z=z_e1, final_out=(e1_hc[0], e1_hc[1]), row_order=fwd_order)
         e1['hc_final'] = e1_hc
+        self.mark('fwd:enc1')
         if fork is not None:
             side.wait_event(fork)
         with torch.cuda.stream(side):
@@ -634,8 +647,10 @@ class Model(object):
                 z_e2 = self._buf('second_lstm/z', (T * M, 4 * U))
                 K.gemm_rows('nn', feed['n_active'], 4 * U, U, e1['hout'], U, p['second_lstm/kernel'][:U], 4 * U,
                             z_e2, 4 * U, feed['active_rows'], bias=p['second_lstm/bias'])
+            self.mark('fwd:mean+xproj2')
             e2 = self._lstm_fwd('second_lstm', e1['hout'].view(T * M, U), U, M, T, T, h0_2, c0_2, lens_d,
                                 want_final=True, final_out=(demo_hc[0], demo_hc[1]), z=z_e2, row_order=fwd_order)
+            self.mark('fwd:enc2')
             demo_h, demo_c = demo_hc[0], demo_hc[1]
             # ---- SummarizeFeature('rn') = mean_k + rn_pool (the summarizer baseline: rn_pool alone)
             if self._abl('rn_fwd'):
@@ -644,6 +659,7 @@ class Model(object):
                 rn_h = rn_c = self._abl_cache['rn'] = self._rn_fwd(demo_hc, B, k, U, add_mean=self.multitask)
             init_h, init_c = rn_h['out'][0], rn_h['out'][1]
 
+        self.mark('fwd:rn')
         main.wait_stream(side)
         # the initial states in front of the saved outputs (hbuf[0]): second encoder, the three decoders
         stage = [('prog/lstm', L, B, init_h)]
@@ -719,6 +735,7 @@ class Model(object):
         else:
             dp = self._decoders_fwd([specs[0]])[0]
 
+        self.mark('fwd:decoders')
         # ---- losses: program + mean_k action + mean_k perception, each mask-count normalised
         #      (the baselines: the program term alone)
         nums = self._buf('loss_nums', (1 + 2 * k,))
@@ -1287,7 +1304,9 @@ class Model(object):
             grads = (prog_grads, act_grads, per_grads)
             # all three backward recurrences as ONE launch (3 + 3 + 2 row domains; with fuse_decoders on the per-step
             # kernels: one launch per step for all three), the three decoders' gradient products forked behind it
+            self.mark('bwd:loss')
             dzs = self._decoders_bwd_rec(bspecs if self.fuse_decoders else [bspecs[i] for i in (2, 1, 0)])
+            self.mark('bwd:decoders')
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 for i, dz in zip((0, 1, 2) if self.fuse_decoders else (2, 1, 0), dzs):
@@ -1331,7 +1350,9 @@ class Model(object):
             dhc0_2 = self._buf('dhc0_2', (2, M, U))
             dh0_2, dc0_2 = dhc0_2[0], dhc0_2[1]
             # (its weight gradients go to the side stream: two large GEMMs beside the next recurrence)
+            self.mark('bwd:rn')
             dz2 = self._lstm_bwd_rec(e2, None, d_demo_h, d_demo_c, dh0_2, dc0_2)
+            self.mark('bwd:enc2')
             if ctx.get('rows') is not None:
                 rows_idx, n_act = ctx['rows']
                 # (no zero fill: the only reader is the first encoder's backward recurrence, which SELECTS dhout by the row's
@@ -1347,7 +1368,9 @@ class Model(object):
             # summary = mean_k(step-1 final states), broadcast to every demo of the program
             K.group_mean_bwd(None, dhc0_2, d_hc1f, 2 * B, k, U, False)
         # ---- Demo_Encoder LSTM backward
+        self.mark('bwd:dx2+mean')
         dz1 = self._lstm_bwd_rec(ctx['e1'], d_hout1, d_h1f, d_c1f, None, None)
+        self.mark('bwd:enc1')
         if ctx.get('rows_e1') is not None:
             e1_ = ctx['e1']
             d_feats_tm = self._buf(e1_['name'] + '/dx', (T * M, e1_['I']))
@@ -1361,7 +1384,9 @@ class Model(object):
             self._lstm_bwd_weights(ctx['e1'], dz1)
         # ---- State_Encoder backward
         if ctx.get('enc_fused') and not self._abl('conv_bwd') and self._encoder_bwd_fused(ctx, d_feats_tm):
+            self.mark('bwd:dx1+conv')
             main.wait_stream(side)
+            self.mark('bwd:join')
             return self.params.grad
         d_feats = K.transpose_rt(d_feats_tm.view(T, M, F), T, M, F, out=self._buf('d_feats', (M, T, F)))
         dy = d_feats
@@ -1388,9 +1413,11 @@ class Model(object):
                 else:
                     K.conv_wgrad_bnbwd(x_in, a, dyv, coef, k, T, g['conv1/W'], g['conv1/b'])
                 continue
+            # (dy_sums: the input-gradient launch of layer l + 1 left this batch norm's backward partial sums behind)
             da_ = K.bn_bwd(a.view(NF * ho * wo, cout), dy.view(NF * ho * wo, cout), p['conv%d/gamma' % l],
                            mean, rstd, k, T * ho * wo, True, g['conv%d/gamma' % l], g['conv%d/beta' % l],
-                           dx=self._buf('conv%d/da' % l, (NF * ho * wo, cout)), dbias=g['conv%d/b' % l])
+                           dx=self._buf('conv%d/da' % l, (NF * ho * wo, cout)), dbias=g['conv%d/b' % l], sums=dy_sums)
+            dy_sums = None
             # the weight gradient feeds nothing inside backward: on the side stream, beside this layer's data
             # gradient and the next layer's batch-norm backward (ViZDoom frames: 40 % of the conv backward)
             # (only where the layer is large enough to matter: at Karel's 8x8 frames the three weight-gradient
@@ -1411,19 +1438,22 @@ class Model(object):
             if l > 1:
                 dxb = self._buf('conv%d/dx' % l, (NF, h, w, cin))
                 Sd = 0
-                if l == 2 and self.fold_bn and K.conv_bnbwd_ok(ctx['conv'][0][0].shape, cin):
+                if self.fold_bn and (l > 2 or K.conv_bnbwd_ok(ctx['conv'][0][0].shape, cin)):
                     Sd = K.conv_dgrad_bn_slices((NF, h, w, cin), cout, k, T)
                 if Sd > 0:
-                    # the first layer's batch-norm-backward partial sums come out of this launch (it writes the gradient
-                    # they are sums of): no separate pass over (a1, dy1)
-                    _, a_prev, mean_prev, rstd_prev, _ = ctx['conv'][0]
-                    st_ = self._buf('conv1/bn_bwd_partial', (k * Sd * cin * 2,), torch.float64)
+                    # the previous layer's batch-norm-backward partial sums come out of this launch (it writes the gradient
+                    # they are sums of): no separate pass over (a, dy) of that layer (round 5: the first layer's, out of
+                    # the 16 -> 32 layer's row-strip kernel; round 6: every 48-channel layer's launch leaves them)
+                    _, a_prev, mean_prev, rstd_prev, _ = ctx['conv'][l - 2]
+                    st_ = self._buf('conv%d/bn_bwd_partial' % (l - 1), (k * Sd * cin * 2,), torch.float64)
                     dy = K.conv_dgrad_bn(da_.view(NF, ho, wo, cout), p['conv%d/W' % l], (NF, h, w, cin), a_prev, mean_prev,
                                          rstd_prev, k, T, st_, Sd, dx=dxb)
                     dy_sums = (st_, Sd)
                 else:
                     dy = K.conv_dgrad(da_.view(NF, ho, wo, cout), p['conv%d/W' % l], (NF, h, w, cin), dx=dxb)
+        self.mark('bwd:dx1+conv')
         main.wait_stream(side)
+        self.mark('bwd:join')
         return self.params.grad
 
     def _lstm_bwd_rec(self, e, dhout, dh_final, dc_final, dh0, dc0):

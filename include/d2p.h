@@ -175,6 +175,12 @@ int d2p_bn_group_bwd(int R, int C, int G, int inner, const float* x, const float
                      const float* gamma, const float* mean, const float* rstd, int act_bwd,
                      float* dx, float* dgamma, float* dbeta, float* dx_colsum,
                      void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* The same with the partial sums [G][S_sums][C][2] (fp64: sum dy, sum dy * xhat per (group, slice)) left behind by the
+ * launch that produced dy (d2p_conv2d_nhwc_s2_same_dgrad_bn): the partial-sum pass over (x, dy) is not run. */
+int d2p_bn_group_bwd_sums(int R, int C, int G, int inner, const float* x, const float* dy,
+                          const float* gamma, const float* mean, const float* rstd,
+                          int act_bwd, float* dx, float* dgamma, float* dbeta, float* dx_colsum,
+                          const double* sums, int S_sums, void* ws, size_t ws_bytes, d2p_stream_t stream);
 /* nb independent, equally shaped batch-norm problems in ONE set of launches (grid.z = problem).  Problem b uses
  * every pointer of problem 0 plus b times a stride, in floats: xs for the [R, C] inputs (x, dy), ys for the
  * [R, C] outputs (y, dx), ps for per-channel parameters and their gradients (gamma, beta, dgamma, dbeta,

@@ -367,6 +367,30 @@ def test_wide_layers_forward_with_statistics_and_input_affine(K, B, G, T, H, Cin
     close(dwp, wr_.grad, atol=2e-5 * float(wr_.grad.abs().max()) + 1e-4, rtol=1e-5)
     K.conv_wgrad(dev(xn), dev(dy), dw)
     assert torch.equal(dw, dwp)                                  # deterministic combine
+    # the input gradient (2x2 blocks of input pixels sharing a 2x2 neighbourhood of dY), plain and with the batch-norm
+    # backward partial sums of the layer underneath per demonstration index: (sum dX, sum dX * xhat), xhat from that
+    # layer's pre-norm activation `act` and its statistics
+    xr2 = x.double().requires_grad_(True)
+    _conv_ref(xr2, w.double(), b.double()).backward(dy.double())
+    dxp = K.conv_dgrad(dev(dy), dev(w), (N, H, H, Cin))
+    close(dxp, xr2.grad, atol=1e-4)
+    act = rnd(N, H, H, Cin, seed=27)
+    mu, rs = rnd(G, Cin, seed=28), rnd(G, Cin, seed=29).abs() + 0.5
+    Sd = K.conv_dgrad_bn_slices((N, H, H, Cin), 48, G, T)
+    assert Sd > 0
+    std = torch.zeros(G * Sd * Cin * 2, dtype=torch.float64, device='cuda')
+    dxb = K.conv_dgrad_bn(dev(dy), dev(w), (N, H, H, Cin), dev(act), dev(mu), dev(rs), G, T, std, Sd)
+    assert torch.equal(dxb, dxp)
+    got = std.view(G, Sd, Cin, 2).sum(1).cpu()
+    gd = xr2.grad
+    for gi in range(G):
+        sel = grp == gi
+        xhat = (act[sel].double() - mu[gi].double()) * rs[gi].double()
+        want0 = gd[sel].reshape(-1, Cin).sum(0)
+        want1 = (gd[sel] * xhat).reshape(-1, Cin).sum(0)
+        scale = float(gd[sel].abs().sum(dim=(0, 1, 2)).max())
+        close(got[gi, :, 0], want0, atol=2e-6 * scale + 1e-5, rtol=1e-5)
+        close(got[gi, :, 1], want1, atol=1e-5 * scale + 1e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize('B,G,T', [(3, 2, 2), (2, 5, 4)])
