@@ -203,6 +203,8 @@ extern "C" size_t d2p_conv_ws_bytes(int N, int H, int W, int Cin, int Cout) {
 }
 
 extern "C" int d2p_conv_set_direct(int fwd, int dgrad, int wgrad) {
+    d2p_conv_wide_set_dgrad_1632(dgrad != 3);            // (dgrad = 3: as 2, with the 16 -> 32 layer on the row-strip kernel)
+    if (dgrad == 3) dgrad = 2;
     d2p_conv_direct_enable(fwd, dgrad, wgrad);
     return D2P_OK;
 }
@@ -301,8 +303,8 @@ extern "C" int d2p_conv2d_nhwc_s2_same_wgrad_bn(int N, int H, int W, int Cin, in
 extern "C" int d2p_conv_dgrad_bn_slices(int N, int H, int W, int Cin, int Cout, int G, int seq) {
     if (N <= 0 || H <= 0 || W <= 0) return 0;
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
-    const int S = d2p_conv_rows_dgrad_slices(g, G, seq);
-    return S > 0 ? S : d2p_conv_wide_dgrad_bn_slices(g, G, seq);
+    const int S = d2p_conv_wide_dgrad_bn_slices(g, G, seq);      // (the same order as d2p_conv_direct_dgrad tries the kernels)
+    return S > 0 ? S : d2p_conv_rows_dgrad_slices(g, G, seq);
 }
 extern "C" int d2p_conv2d_nhwc_s2_same_dgrad_bn(int N, int H, int W, int Cin, int Cout, const float* dy, const float* w,
                                                 float* dx, const float* act, const float* mean, const float* rstd, int G,

@@ -781,15 +781,15 @@ static int launch_dgrad(const ConvGeom& g, const float* dy, const float* w, floa
 
 int d2p_conv_direct_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st,
                           const ConvDgradBn* bn) {
-    if (bn) {       // (statistics out: the row-strip kernel of the 16 -> 32 layer, the wide kernel of the 48-channel layers)
-        const int rc = d2p_conv_rows_dgrad(g, dy, w, dx, st, bn);
-        return rc != 0 ? rc : d2p_conv_wide_dgrad(g, dy, w, dx, st, bn);
+    if (bn) {       // (statistics out: the block-form kernel of conv_wide.hip, else the row-strip kernel of the 16 -> 32 layer)
+        const int rc = d2p_conv_wide_dgrad(g, dy, w, dx, st, bn);
+        return rc != 0 ? rc : d2p_conv_rows_dgrad(g, dy, w, dx, st, bn);
     }
     if (!g_direct_dgrad) return 0;
     if (g_direct_dgrad >= 2) {
-        int rc = d2p_conv_rows_dgrad(g, dy, w, dx, st);
+        int rc = d2p_conv_wide_dgrad(g, dy, w, dx, st);            // (the 48-channel layers and the large 16 -> 32 layer, round 6)
         if (rc != 0) return rc;
-        rc = d2p_conv_wide_dgrad(g, dy, w, dx, st);            // (the 48-channel layers, round 6)
+        rc = d2p_conv_rows_dgrad(g, dy, w, dx, st);
         if (rc != 0) return rc;
     }
     if (((uintptr_t)dy & 15) || ((uintptr_t)dx & 15)) return 0;

@@ -304,11 +304,11 @@ struct WDgBlk {
     const float* act; const float* mean; const float* rstd;     // BNSTATS: [pixels, CIN], [G, CIN], [G, CIN]
 };
 
-template <int CIN, int PT, int PL, bool BNSTATS>
+template <int CIN, int COUT, int PT, int PL, bool BNSTATS>
 __global__ void __launch_bounds__(WDG_WAVES * 64)
 conv_wide_dgrad_kernel(WideGeom g, WDgBlk c, const float* __restrict__ dy, const float* __restrict__ w, float* __restrict__ dx,
                        WideDeal dl) {
-    constexpr int CC = WCO / 16, NBI = CIN / 16;
+    constexpr int CC = COUT / 16, NBI = CIN / 16;
     extern __shared__ __attribute__((aligned(16))) float wide_lds[];
     f32x4* wl = reinterpret_cast<f32x4*>(wide_lds);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
@@ -320,11 +320,14 @@ conv_wide_dgrad_kernel(WideGeom g, WDgBlk c, const float* __restrict__ dy, const
         const int b = r % NBI;
         r /= NBI;
         const int cc = r % CC, tap = r / CC;
-        wl[i] = wldg4(w + (tap * CIN + b * 16 + (l & 15)) * WCO + cc * 16 + 4 * (l >> 4));
+        wl[i] = wldg4(w + (tap * CIN + b * 16 + (l & 15)) * COUT + cc * 16 + 4 * (l >> 4));
     }
-    f32x4 fs[NBI], fq[NBI];                 // BNSTATS: per-lane sums of dX and of dX * activation
+    f32x4 fs[NBI], fq[NBI], mu4[NBI];       // BNSTATS: per-lane sums of dX and of dX * (activation - mean)
 #pragma unroll
-    for (int b = 0; b < NBI; ++b) fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NBI; ++b) {
+        fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mu4[b] = BNSTATS ? wldg4(c.mean + sg * CIN + b * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     __syncthreads();
     const int tlo = ss * dl.per_slice, thi = min(tlo + dl.per_slice, dl.per_idx);
     int tile = tlo + __builtin_amdgcn_readfirstlane(wave);
@@ -355,7 +358,7 @@ conv_wide_dgrad_kernel(WideGeom g, WDgBlk c, const float* __restrict__ dy, const
         for (int ry = 0; ry < 2; ++ry)
 #pragma unroll
             for (int rx = 0; rx < 2; ++rx) {
-                unsigned off = (unsigned)((roff[ry] + coff[rx]) * WCO + 4 * q);
+                unsigned off = (unsigned)((roff[ry] + coff[rx]) * COUT + 4 * q);
                 D2P_OPAQUE_U(off);
 #pragma unroll
                 for (int cc = 0; cc < CC; ++cc) v[ry][rx][cc] = wldg4(dy + off + cc * 16);
@@ -403,7 +406,7 @@ conv_wide_dgrad_kernel(WideGeom g, WDgBlk c, const float* __restrict__ dy, const
                     const f32x4 av = wldg4(c.act + xoff + b * 16 + 4 * q);
                     const f32x4 om = o * (in ? 1.f : 0.f);
                     fs[b] += om;
-                    fq[b] += om * av;
+                    fq[b] += om * (av - mu4[b]);       // (centred before the product: no cancellation at the end)
                 }
             }
         }
@@ -411,7 +414,7 @@ conv_wide_dgrad_kernel(WideGeom g, WDgBlk c, const float* __restrict__ dy, const
         while (tr >= dl.tps) { tr -= dl.tps; ++tb; }
     }
     if (BNSTATS) {
-        // (sum dX, sum dX * xhat) with xhat = (act - mean) rstd: rstd (sum dX act - mean sum dX), in fp64 from here on;
+        // (sum dX, sum dX * xhat) with xhat = (act - mean) rstd: rstd * sum dX (act - mean), in fp64 from here on;
         // the 16 pixel lanes by xor-shuffles, the waves through LDS in wave order
         __shared__ double wsum[WDG_WAVES * 48 * 2];
 #pragma unroll
@@ -437,9 +440,8 @@ conv_wide_dgrad_kernel(WideGeom g, WDgBlk c, const float* __restrict__ dy, const
                 sd += wsum[(wv * CIN + tid) * 2];
                 sda += wsum[(wv * CIN + tid) * 2 + 1];
             }
-            const double mu = (double)c.mean[sg * CIN + tid], rs = (double)c.rstd[sg * CIN + tid];
             dl.stats[((long)blockIdx.x * CIN + tid) * 2] = sd;
-            dl.stats[((long)blockIdx.x * CIN + tid) * 2 + 1] = rs * (sda - mu * sd);
+            dl.stats[((long)blockIdx.x * CIN + tid) * 2 + 1] = (double)c.rstd[sg * CIN + tid] * sda;
         }
     }
 }
@@ -463,13 +465,14 @@ int wide_dgrad_slices(const ConvGeom& g, int G, int seq) {
     const int Hb = cb.Hb, Wb = cb.Wb;
     const long tps = ((long)seq * Hb * Wb + 15) / 16;
     const long per_idx = (long)g.N / (G * seq) * tps;
-    long S = wide_cus() / G;
+    // (the 16 -> 32 layer: ~100 registers and 18 KB of LDS -- two workgroups per CU, four waves per SIMD, for an HBM-bound launch)
+    long S = (g.Cout == 32 ? 2 : 1) * wide_cus() / G;
     const long cap = per_idx / WDG_WAVES;
     if (S > cap) S = cap;
     return (int)(S < 1 ? 1 : S);
 }
 
-template <int CIN>
+template <int CIN, int COUT>
 int launch_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st, const ConvDgradBn* bn) {
     WideGeom d = make_wide(g);
     WDgBlk c{};
@@ -484,12 +487,12 @@ int launch_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float*
     dl.S = bn ? bn->S : wide_dgrad_slices(g, 1, g.N);
     dl.per_slice = ceil_div(dl.per_idx, dl.S);
     dl.stats = bn ? bn->stats : nullptr;
-    constexpr size_t lds = (size_t)9 * 3 * (CIN / 16) * 64 * sizeof(f32x4);
-    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * WCO);
+    constexpr size_t lds = (size_t)9 * (COUT / 16) * (CIN / 16) * 64 * sizeof(f32x4);
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * COUT);
     const dim3 grid(G * dl.S), block(WDG_WAVES * 64);
 #define D2P_WIDE_DG(PT_, PL_, BN_)                                                                                  \
     do {                                                                                                            \
-        auto kern = conv_wide_dgrad_kernel<CIN, PT_, PL_, BN_>;                                                     \
+        auto kern = conv_wide_dgrad_kernel<CIN, COUT, PT_, PL_, BN_>;                                                     \
         static bool attr = false;                                                                                   \
         if (!attr) {                                                                                                \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -771,23 +774,35 @@ int d2p_conv_wide_fwd(const ConvGeom& g, const void* x, int x_is_u8, const float
     return launch_wide_fwd<48>(g, (const float*)x, w, bias, act, y, st, bn);
 }
 
+// the input-gradient kernel also takes the 16 -> 32 layer of the large frames (40x40 -> 20x20): one 16-channel block out,
+// two in -- HBM-bound there (it writes 655 MB at config 4), which the block form serves with a quarter of the index
+// arithmetic and 8 instead of 18 gathers per four output pixels
+static int g_wide_dgrad_1632 = 1;            // (0: that layer stays on the row-strip kernel; d2p_conv_wide_set_dgrad_1632)
+void d2p_conv_wide_set_dgrad_1632(int on) { g_wide_dgrad_1632 = on ? 1 : 0; }
+static bool wide_dgrad_geom_ok(const ConvGeom& g) {
+    if (wide_geom_ok(g)) return true;
+    return g_wide_dgrad_1632 && g.Cin == 16 && g.Cout == 32 && g.H >= 3 && g.W >= 3 && g.H * g.W >= 400 &&
+           (size_t)g.N * g.H * g.W * g.Cin < (1ull << 31) && (size_t)g.N * g.Ho * g.Wo * g.Cout < (1ull << 32) / 2;
+}
+
 // slices per index of the input-gradient launch that also leaves the previous layer's batch-norm-backward sums; 0: not taken
 int d2p_conv_wide_dgrad_bn_slices(const ConvGeom& g, int G, int seq) {
-    if (!wide_geom_ok(g) || G < 1 || seq < 1 || g.N % (G * seq) != 0 || G > 4096) return 0;
+    if (!wide_dgrad_geom_ok(g) || G < 1 || seq < 1 || g.N % (G * seq) != 0 || G > 4096) return 0;
     return wide_dgrad_slices(g, G, seq);
 }
 
 int d2p_conv_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, float* dx, hipStream_t st, const ConvDgradBn* bn) {
-    if (!wide_geom_ok(g)) return 0;
+    if (!wide_dgrad_geom_ok(g)) return 0;
     if (((uintptr_t)dy & 15) || ((uintptr_t)dx & 15) || ((uintptr_t)w & 15)) return 0;
-    if ((size_t)g.N * g.Ho * g.Wo * WCO >= (1ull << 32)) return 0;
+    if ((size_t)g.N * g.Ho * g.Wo * g.Cout >= (1ull << 32)) return 0;
     if (bn) {
         if (!bn->act || !bn->mean || !bn->rstd || !bn->stats || ((uintptr_t)bn->act & 15)) return 0;
         if (bn->S < 1 || bn->S != d2p_conv_wide_dgrad_bn_slices(g, bn->G, bn->seq)) return 0;
     }
     if (g.N == 0) return 1;
-    if (g.Cin == 32) return launch_wide_dgrad<32>(g, dy, w, dx, st, bn);
-    return launch_wide_dgrad<48>(g, dy, w, dx, st, bn);
+    if (g.Cout == 32) return launch_wide_dgrad<16, 32>(g, dy, w, dx, st, bn);
+    if (g.Cin == 32) return launch_wide_dgrad<32, 48>(g, dy, w, dx, st, bn);
+    return launch_wide_dgrad<48, 48>(g, dy, w, dx, st, bn);
 }
 
 size_t d2p_conv_wide_wgrad_ws(const ConvGeom& g) {
