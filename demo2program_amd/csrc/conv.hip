@@ -205,6 +205,8 @@ extern "C" size_t d2p_conv_ws_bytes(int N, int H, int W, int Cin, int Cout) {
 extern "C" int d2p_conv_set_direct(int fwd, int dgrad, int wgrad) {
     d2p_conv_wide_set_dgrad_1632(dgrad != 3);            // (dgrad = 3: as 2, with the 16 -> 32 layer on the row-strip kernel)
     if (dgrad == 3) dgrad = 2;
+    d2p_conv_wide_set_fwd2(fwd != 3);                    // (fwd = 3: as 2, with the 16 -> 32 layer on the gather kernel)
+    if (fwd == 3) fwd = 2;
     d2p_conv_direct_enable(fwd, dgrad, wgrad);
     return D2P_OK;
 }
@@ -238,6 +240,10 @@ extern "C" int d2p_conv_bn_slices(int N, int H, int W, int Cin, int Cout, int G,
     if (N <= 0 || G <= 0 || seq <= 0 || N % (G * seq) != 0) return 0;
     ConvGeom g = make_geom(N, H, W, Cin, Cout);
     if (Cout == 48) return d2p_conv_wide_bn_slices(g, G, seq);      // (the 48-channel layers: conv_wide.hip)
+    {
+        const int S2 = d2p_conv_wide_fwd2_bn_slices(g, G, seq);     // (the large 16 -> 32 layer in block form)
+        if (S2 > 0) return S2;
+    }
     long units;                                  // work units of one index: strips (first layer) or 16-pixel tiles
     if (Cin == 4 && Cout == 16 && W == 80) units = (long)N / G * g.Ho;
     else if (Cin == 16 && Cout == 32 && H * W >= 400 && (seq * g.Ho * g.Wo) % 16 == 0) units = (long)N / G * g.Ho * g.Wo / 16;

@@ -723,6 +723,8 @@ int d2p_conv_direct_fwd(const ConvGeom& g, const void* x, int x_is_u8, const flo
         if (rc != 0) return rc;
         rc = d2p_conv_wide_fwd(g, x, x_is_u8, w, bias, act, y, st, bn);        // (the 48-channel layers, round 6)
         if (rc != 0) return rc;
+        rc = d2p_conv_wide_fwd2(g, x, x_is_u8, w, bias, act, y, st, bn);       // (the large 16 -> 32 layer in block form)
+        if (rc != 0) return rc;
         if (x_is_u8 || ((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
         if (g.Cin == 16 && g.Cout == 32 && g.H * g.W >= 400) return launch_fwd_bn<16, 32, 0x1FF>(g, (const float*)x, w, bias, act, y, st, *bn);
         return 0;
@@ -734,6 +736,8 @@ int d2p_conv_direct_fwd(const ConvGeom& g, const void* x, int x_is_u8, const flo
         rc = d2p_conv_rows_fwd(g, x, x_is_u8, w, bias, act, y, st);
         if (rc != 0) return rc;
         rc = d2p_conv_wide_fwd(g, x, x_is_u8, w, bias, act, y, st);
+        if (rc != 0) return rc;
+        rc = d2p_conv_wide_fwd2(g, x, x_is_u8, w, bias, act, y, st);
         if (rc != 0) return rc;
     }
     if (((uintptr_t)x & (x_is_u8 ? 3 : 15)) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;

@@ -93,6 +93,10 @@ int d2p_conv_wide_dgrad(const ConvGeom& g, const float* dy, const float* w, floa
                         const ConvDgradBn* bn = nullptr);
 int d2p_conv_wide_dgrad_bn_slices(const ConvGeom& g, int G, int seq);
 void d2p_conv_wide_set_dgrad_1632(int on);
+int d2p_conv_wide_fwd2(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act, float* y,
+                       hipStream_t st, const ConvBnFold* bn = nullptr);
+int d2p_conv_wide_fwd2_bn_slices(const ConvGeom& g, int G, int seq);
+void d2p_conv_wide_set_fwd2(int on);
 int d2p_conv_wide_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const float* dy, float* dw, void* ws, size_t ws_bytes,
                         hipStream_t st, const ConvBnFold* bn = nullptr);
 size_t d2p_conv_wide_wgrad_ws(const ConvGeom& g);

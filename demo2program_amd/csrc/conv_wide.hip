@@ -283,6 +283,199 @@ int launch_wide_fwd(const ConvGeom& g, const float* x, const float* w, const flo
 
 
 // ==========================================================================================
+// forward, block form (the 16 -> 32 layer of the large frames, 40x40 -> 20x20: 23.6 GFLOP per pass at config 4): a lane's
+// unit is a 2x2 BLOCK of output pixels, whose four 3x3 windows are one 5x5 window of the input -- 25 gathers and one
+// index decomposition for four output pixels instead of 36 and four, the input affine added once per loaded value, and
+// an A fragment read from LDS feeds 16 MFMAs.  (The register-filter gather kernel of conv_direct.hip spends as many
+// clocks on index arithmetic, masks and epilogue as on its 72 MFMAs per 16 pixels: 0.51 of the fp32 MFMA peak.)  Same
+// dealing by demonstration index, STATS and AFFINE as conv_wide_fwd_kernel; tiles are 16 blocks of one sequence.
+// ==========================================================================================
+constexpr int WF2_WAVES = 8;
+struct WF2Blk {
+    int Hb, Wb;               // blocks per frame: ceil(Ho / 2), ceil(Wo / 2)
+    WDiv d_hw, d_w;
+};
+
+template <int CIN, int COUT, bool STATS, bool AFFINE>
+__global__ void __launch_bounds__(WF2_WAVES * 64)
+conv_wide_fwd2_kernel(WideGeom g, WF2Blk c, const float* __restrict__ x, const float* __restrict__ w,
+                      const float* __restrict__ bias, int act, float* __restrict__ y, WideDeal dl) {
+    constexpr int CB = CIN / 16, NB = COUT / 16;
+    static_assert(CB == 1, "one 16-channel block of input per tap");
+    extern __shared__ __attribute__((aligned(16))) float wide_lds[];
+    f32x4* wl = reinterpret_cast<f32x4*>(wide_lds);                 // [9][NB][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, p = lane & 15, q = lane >> 4;
+    const int sg = (int)blockIdx.x / dl.S, ss = (int)blockIdx.x - sg * dl.S;
+    for (int i = tid; i < 9 * NB * 64; i += WF2_WAVES * 64) {
+        const int l = i & 63, tb_ = i >> 6;
+        const int tap = tb_ / NB, b = tb_ - tap * NB;
+        const int pp = l & 15, qq = l >> 4;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = w[(tap * CIN + 4 * qq + j) * COUT + b * 16 + pp];
+        if (AFFINE) v *= wldg4(dl.in_scale + sg * CIN + 4 * qq);
+        wl[i] = v;
+    }
+    const unsigned padoff = AFFINE ? dl.pad0 + (unsigned)(sg * CIN) : 0u;
+    const f32x4 ash = AFFINE ? -wldg4(x + padoff + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 bv[NB], fs[NB], fq[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        bv[b] = bias ? wldg4(bias + b * 16 + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+        fs[b] = fq[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    const int tlo = ss * dl.per_slice, thi = min(tlo + dl.per_slice, dl.per_idx);
+    int tile = tlo + __builtin_amdgcn_readfirstlane(wave);
+    int tb = tile / dl.tps, tr = tile - tb * dl.tps;
+    const int HbWb = c.Hb * c.Wb;
+    for (; tile < thi; tile += WF2_WAVES) {
+        const int local = tr * 16 + p;
+        const bool valid = local < dl.seqpix;
+        const int lc = valid ? local : 0;
+        const int t = wdiv(lc, c.d_hw);
+        const int rem = lc - t * HbWb;
+        const int a = wdiv(rem, c.d_w), bcol = rem - a * c.Wb;
+        const int n = (tb * dl.G + sg) * (dl.seqpix / HbWb) + t;
+        // ---- the 5x5 window: rows 4a - pt + r, columns 4 bcol - pl + r
+        const int iy0 = 4 * a - g.pt, ix0 = 4 * bcol - g.pl;
+        int rowoff[5], coloff[5];
+        bool rok[5], cok[5];
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            rok[r] = valid & ((unsigned)(iy0 + r) < (unsigned)g.H);
+            cok[r] = (unsigned)(ix0 + r) < (unsigned)g.W;
+            rowoff[r] = (n * g.H + wclamp(iy0 + r, g.H - 1)) * g.W * CIN;
+            coloff[r] = wclamp(ix0 + r, g.W - 1) * CIN + 4 * q;
+        }
+        f32x4 v[5][5];
+#pragma unroll
+        for (int ry = 0; ry < 5; ++ry)
+#pragma unroll
+            for (int rx = 0; rx < 5; ++rx) {
+                unsigned off = (unsigned)(rowoff[ry] + coloff[rx]);
+                const bool ok = rok[ry] & cok[rx];
+                if (AFFINE) off = ok ? off : padoff + (unsigned)(4 * q);
+                D2P_OPAQUE_U(off);
+                v[ry][rx] = wldg4(x + off);
+                if (AFFINE) v[ry][rx] += ash;                          // (x + shift / scale; a pad pixel gives exactly 0)
+                else v[ry][rx] *= ok ? 1.f : 0.f;
+            }
+        f32x4 acc[4][NB];
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) acc[o][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const f32x4 a4 = wl[(tap * NB + b) * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int o = 0; o < 4; ++o)
+                        acc[o][b] = D2P_MFMA16(a4[j], v[2 * (o >> 1) + ky][2 * (o & 1) + kx][j], acc[o][b]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int oy = 2 * a + (o >> 1), ox = 2 * bcol + (o & 1);
+            const bool in = valid & (oy < g.Ho) & (ox < g.Wo);
+            const long yoff = ((long)(n * g.Ho + (in ? oy : 0)) * g.Wo + (in ? ox : 0)) * COUT;
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                f32x4 r_ = acc[o][b] + bv[b];
+                if (act) { r_.x = d2p_lrelu(r_.x); r_.y = d2p_lrelu(r_.y); r_.z = d2p_lrelu(r_.z); r_.w = d2p_lrelu(r_.w); }
+                if (in) *reinterpret_cast<f32x4*>(y + yoff + b * 16 + 4 * q) = r_;
+                if (STATS) {
+                    r_ *= in ? 1.f : 0.f;
+                    fs[b] += r_;
+                    fq[b] += r_ * r_;
+                }
+            }
+        }
+        tr += WF2_WAVES;
+        while (tr >= dl.tps) { tr -= dl.tps; ++tb; }
+    }
+    if (STATS) {
+        __shared__ double wsum[WF2_WAVES * COUT * 2];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                double u = (double)fs[b][r], s2 = (double)fq[b][r];
+#pragma unroll
+                for (int off = 1; off < 16; off <<= 1) {
+                    u += __shfl_xor(u, off, 64);
+                    s2 += __shfl_xor(s2, off, 64);
+                }
+                if (p == 0) {
+                    wsum[(wave * COUT + b * 16 + 4 * q + r) * 2] = u;
+                    wsum[(wave * COUT + b * 16 + 4 * q + r) * 2 + 1] = s2;
+                }
+            }
+        __syncthreads();
+        if (tid < 2 * COUT) {
+            const int ch = tid >> 1, k = tid & 1;
+            double tsum = 0.0;
+#pragma unroll
+            for (int wv = 0; wv < WF2_WAVES; ++wv) tsum += wsum[(wv * COUT + ch) * 2 + k];
+            dl.stats[((long)blockIdx.x * COUT + ch) * 2 + k] = tsum;
+        }
+    }
+}
+
+bool wide_fwd2_geom_ok(const ConvGeom& g) {
+    return g.Cin == 16 && g.Cout == 32 && g.H >= 3 && g.W >= 3 && g.H * g.W >= 400 &&
+           (size_t)g.N * g.H * g.W * g.Cin + (size_t)4096 * g.Cin < (1ull << 32) && (size_t)g.N * g.Ho * g.Wo < (1ull << 31) / 32;
+}
+int wide_fwd2_slices(const ConvGeom& g, int G, int seq) {
+    const int Hb = (g.Ho + 1) / 2, Wb = (g.Wo + 1) / 2;
+    const long tps = ((long)seq * Hb * Wb + 15) / 16;
+    const long per_idx = (long)g.N / (G * seq) * tps;
+    long S = wide_cus() / G;                               // (one workgroup per CU: ~190 registers, two waves per SIMD)
+    const long cap = per_idx / WF2_WAVES;
+    if (S > cap) S = cap;
+    return (int)(S < 1 ? 1 : S);
+}
+
+template <int CIN, int COUT>
+int launch_wide_fwd2(const ConvGeom& g, const float* x, const float* w, const float* bias, int act, float* y, hipStream_t st,
+                     const ConvBnFold* bn) {
+    WideGeom d = make_wide(g);
+    WF2Blk c{};
+    c.Hb = (g.Ho + 1) / 2; c.Wb = (g.Wo + 1) / 2;
+    c.d_hw = make_wdiv(c.Hb * c.Wb);
+    c.d_w = make_wdiv(c.Wb);
+    WideDeal dl{};
+    const int G = bn ? bn->G : 1, seq = bn ? bn->seq : g.N;
+    dl.G = G;
+    dl.seqpix = seq * c.Hb * c.Wb;
+    dl.tps = ceil_div(dl.seqpix, 16);
+    dl.per_idx = g.N / (G * seq) * dl.tps;
+    dl.S = bn && bn->S > 0 ? bn->S : wide_fwd2_slices(g, G, seq);
+    dl.per_slice = ceil_div(dl.per_idx, dl.S);
+    dl.in_scale = bn ? bn->in_scale : nullptr;
+    dl.stats = bn ? bn->stats : nullptr;
+    dl.pad0 = (unsigned)((size_t)g.N * g.H * g.W * g.Cin);
+    constexpr size_t lds = (size_t)9 * (COUT / 16) * 64 * sizeof(f32x4);
+    D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * 9 * g.Cin * COUT);
+    const dim3 grid(G * dl.S), block(WF2_WAVES * 64);
+    if (dl.stats && dl.in_scale)
+        hipLaunchKernelGGL((conv_wide_fwd2_kernel<CIN, COUT, true, true>), grid, block, lds, st, d, c, x, w, bias, act, y, dl);
+    else if (dl.stats)
+        hipLaunchKernelGGL((conv_wide_fwd2_kernel<CIN, COUT, true, false>), grid, block, lds, st, d, c, x, w, bias, act, y, dl);
+    else if (dl.in_scale)
+        hipLaunchKernelGGL((conv_wide_fwd2_kernel<CIN, COUT, false, true>), grid, block, lds, st, d, c, x, w, bias, act, y, dl);
+    else
+        hipLaunchKernelGGL((conv_wide_fwd2_kernel<CIN, COUT, false, false>), grid, block, lds, st, d, c, x, w, bias, act, y, dl);
+    D2P_LAUNCH_CHECK("conv_wide_fwd2");
+    return 1;
+}
+
+// ==========================================================================================
 // input gradient: dX[pix, ci] = sum_(tap, co) dY[(pix + pad - tap) / 2, co] * W[tap, ci, co].  An input pixel sees the taps
 // of its parity class only (even coordinate: taps {0, 2}, odd: tap {1} -- 4 / 2 / 2 / 1 taps), and the four pixels of a
 // 2x2 BLOCK of the input (one of each class) read the same 2x2 neighbourhood of dY.  So the unit of work is the block:
@@ -823,4 +1016,25 @@ int d2p_conv_wide_wgrad(const ConvGeom& g, const void* x, int x_is_u8, const flo
     if (g.N == 0) return 0;
     if (g.Cin == 32) return launch_wide_wgrad<32>(g, (const float*)x, dy, dw, ws, ws_bytes, st, bn);
     return launch_wide_wgrad<48>(g, (const float*)x, dy, dw, ws, ws_bytes, st, bn);
+}
+
+// ---- the 16 -> 32 layer of the large frames in block form (conv_wide_fwd2_kernel)
+static int g_wide_fwd2 = 1;                  // (0: that layer stays on the gather kernel of conv_direct.hip)
+void d2p_conv_wide_set_fwd2(int on) { g_wide_fwd2 = on ? 1 : 0; }
+int d2p_conv_wide_fwd2_bn_slices(const ConvGeom& g, int G, int seq) {
+    if (!g_wide_fwd2 || !wide_fwd2_geom_ok(g) || G < 1 || seq < 1 || g.N % (G * seq) != 0 || G > 4096) return 0;
+    return wide_fwd2_slices(g, G, seq);
+}
+int d2p_conv_wide_fwd2(const ConvGeom& g, const void* x, int x_is_u8, const float* w, const float* bias, int act, float* y,
+                       hipStream_t st, const ConvBnFold* bn) {
+    if (!g_wide_fwd2 || x_is_u8 || !wide_fwd2_geom_ok(g)) return 0;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15) || (bias && ((uintptr_t)bias & 15))) return 0;
+    if (bn) {
+        if (bn->G < 1 || bn->seq < 1 || g.N % (bn->G * bn->seq) != 0 || bn->G > 4096) return 0;
+        if (bn->stats && bn->S != d2p_conv_wide_fwd2_bn_slices(g, bn->G, bn->seq)) return 0;
+        if (bn->in_scale && (((uintptr_t)bn->in_scale) & 15)) return 0;
+        if (!bn->stats && !bn->in_scale) bn = nullptr;
+    }
+    if (g.N == 0) return 1;
+    return launch_wide_fwd2<16, 32>(g, (const float*)x, w, bias, act, y, st, bn);
 }

@@ -144,7 +144,10 @@ int d2p_conv2d_nhwc_s2_same_wgrad(int N, int H, int W, int Cin, int Cout,
  * narrow layers (Cin,Cout) in {(4,16), (16,16), (16,32)} and the 2x2 -> 1x1 (32,48) layer
  * run on register-resident-filter direct kernels by default (selector 2: whole-frame LDS-staged
  * kernels for the Karel geometries, gather kernels otherwise; 1: gather kernels only); 0 routes
- * that direction through the implicit-im2col GEMM instead.  Results agree to fp32 rounding. */
+ * that direction through the implicit-im2col GEMM instead.  Results agree to fp32 rounding.
+ * Round 6: selector 2 also covers the LDS-filter kernels of conv_wide.hip (the 48-channel layers in every direction; the
+ * large 16 -> 32 layer's forward and input gradient in block form); fwd = 3 / dgrad = 3: as 2, with that 16 -> 32 layer
+ * back on the round-5 gather / row-strip kernels (A/B measurements: tools/bench_conv2.py). */
 int d2p_conv_set_direct(int fwd, int dgrad, int wgrad);
 /* > 0 sets a knob, 0 leaves it, < 0 (fwd, wgrad) returns it to the automatic per-layer choice */
 int d2p_conv_direct_tune(int fwd_tiles_per_wave, int dgrad_tiles_per_wave, int wgrad_workgroups);

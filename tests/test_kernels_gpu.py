@@ -244,7 +244,8 @@ def _conv_ref(x, w, b):
                                             (3, 20, 20, 16, 32), (2, 21, 19, 16, 16), (5, 11, 14, 4, 16),
                                             (1, 1, 1, 16, 16), (700, 8, 8, 16, 16),
                                             (3, 80, 80, 4, 16), (2, 37, 80, 4, 16), (3, 40, 40, 16, 32),
-                                            (2, 21, 40, 16, 32), (70, 6, 80, 4, 16), (5, 6, 40, 16, 32), (3, 3, 40, 16, 32)])
+                                            (2, 21, 40, 16, 32), (70, 6, 80, 4, 16), (5, 6, 40, 16, 32), (3, 3, 40, 16, 32),
+                                            (3, 23, 21, 16, 32), (2, 40, 38, 16, 32)])
 def test_conv_fwd_dgrad_wgrad(K, N, H, W, Cin, Cout):
     x = rnd(N, H, W, Cin, seed=1).requires_grad_(True)
     w = rnd(3, 3, Cin, Cout, seed=2, scale=0.3).requires_grad_(True)

@@ -38,6 +38,29 @@ def main():
         print('%-11s plain %.1f us (%.0f GB/s algorithmic, %.1f TF/s) | + batch-norm sums %.1f us (%.0f GB/s incl. the activation read)  S=%d'
               % (label, t0 * 1e6, by / t0 / 1e9, fl / t0 / 1e12, t1 * 1e6, (by + act.numel() * 4) / t1 / 1e9, S), flush=True)
     lib.d2p_conv_set_direct(2, 2, 2)
+    # ---- forward: statistics out, the input through the first layer's batch-norm apply
+    xe = torch.empty(N * H * H * Cin + G * Cin, device='cuda')
+    x = xe[:N * H * H * Cin].view(N, H, H, Cin)
+    x.copy_(act)
+    sc, sh = (torch.rand(G, Cin, generator=g) + 0.5).cuda(), (torch.rand(G, Cin, generator=g) - 0.5).cuda()
+    pad = xe[N * H * H * Cin:].view(G, Cin)
+    pad.copy_(-sh / sc)
+    bias = torch.zeros(Cout, device='cuda')
+    y = torch.empty(N, 20, 20, Cout, device='cuda')
+    outs = {}
+    for label, sel in (('gather kernel', 3), ('block form', 2)):
+        lib.d2p_conv_set_direct(sel, 2, 2)
+        S = K.conv_bn_slices((N, H, H, Cin), Cout, G, T)
+        st = torch.zeros(G * S * Cout * 2, dtype=torch.float64, device='cuda')
+        t0 = min(timed(lambda: K.conv_fwd(x, w, bias, act=1, out=y)) for _ in range(2))
+        t1 = min(timed(lambda: K.conv_fwd_bn(x, w, bias, G, T, S, st, act=1, out=y, in_affine=(sc, sh, pad))) for _ in range(2))
+        outs[label] = (y.clone(), st.view(G, S, Cout, 2).sum(1).clone())
+        print('forward %-13s plain %.1f us (%.1f TF/s, %.3f of peak) | + statistics + input affine %.1f us (%.3f of peak)  S=%d'
+              % (label, t0 * 1e6, fl / t0 / 1e12, fl / t0 / 1e12 / 157.3, t1 * 1e6, fl / t1 / 1e12 / 157.3, S), flush=True)
+    lib.d2p_conv_set_direct(2, 2, 2)
+    ya, yb = outs['gather kernel'], outs['block form']
+    print('forward: max |y difference| %.3e (scale %.3e); statistics: max rel difference %.3e' %
+          (float((ya[0] - yb[0]).abs().max()), float(ya[0].abs().max()), float(((ya[1] - yb[1]).abs() / (ya[1].abs() + 1e-3)).max())))
     a, b = res['row-strip'], res['block form']
     print('max |dx difference| %.3e (scale %.3e); sums: max rel difference %.3e' %
           (float((a[0] - b[0]).abs().max()), float(a[0].abs().max()), float(((a[1] - b[1]).abs() / (a[1].abs() + 1e-3)).max())))
