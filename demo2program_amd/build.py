@@ -9,7 +9,7 @@ from concurrent.futures import ThreadPoolExecutor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
 SOURCES = ['api.hip', 'gemm.hip', 'conv.hip', 'conv_direct.hip', 'conv_frames.hip', 'conv_rows.hip', 'conv_wide.hip', 'bn.hip',
-           'lstm.hip', 'lstm_step.hip', 'lstm_persist.hip', 'greedy.hip', 'xent.hip', 'misc.hip', 'adam.hip', 'rn.hip']
+           'lstm.hip', 'lstm_step.hip', 'lstm_persist.hip', 'greedy.hip', 'xent.hip', 'misc.hip', 'adam.hip', 'rn.hip', 'small_products.hip']
 HEADERS = ['common.h', 'conv_geom.h', 'gemm_core.h', 'prof.h', 'lstm_math.h', 'lstm_internal.h',
            os.path.join('..', '..', 'include', 'd2p.h')]
 OUT = os.path.join(CSRC, 'libd2p_hip.so')

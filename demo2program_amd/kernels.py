@@ -785,6 +785,23 @@ def xent_bwd_dhout_multi(probs):
     call.d2p_xent_bwd_dhout_multi(len(probs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
 
 
+def pair_products_ok(R, U):
+    return 1 <= R <= 256 and U >= 64 and U % 64 == 0
+
+
+def small_pair_products(probs):
+    """G1 = A^T S and G2 = S Wx^T for up to four decoders in one launch (d2p_small_pair_products).
+    probs: (R, U, S [>= R, 4U], A [R, U], Wx [U, 4U], G1 [U, 4U], G2 [R, U]) tuples."""
+    import ctypes
+    from .lib import PairProductsDesc
+    arr = (PairProductsDesc * len(probs))()
+    for d, (R, U, S_, A, Wx, G1, G2) in zip(arr, probs):
+        assert S_.stride(0) == 4 * U and A.stride(0) == U and Wx.stride(0) == 4 * U and G1.stride(0) == 4 * U and G2.stride(0) == U
+        d.R, d.U, d.N4 = R, U, 4 * U
+        d.S, d.A, d.Wx, d.G1, d.G2 = ptr(S_), ptr(A), ptr(Wx), ptr(G1), ptr(G2)
+    call.d2p_small_pair_products(len(probs), ctypes.cast(arr, ctypes.c_void_p), current_stream())
+
+
 def xent_blocks(n_steps, R):
     """workgroups (of 16 rows) xent_bwd_dhout_multi gives a problem = rows of its loss_part"""
     return (n_steps * R + 15) // 16

@@ -125,6 +125,7 @@ SIGNATURES = {
     'd2p_sigmoid_xent_masked_fwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, P, P, c_size_t, S]),
     'd2p_sigmoid_xent_masked_bwd': (c_int, [c_int, c_int, c_int, c_int, c_int, P, P, c_long, c_long, c_long, P, P, c_float, P, S]),
     'd2p_xent_bwd_dhout_multi': (c_int, [c_int, P, S]),
+    'd2p_small_pair_products': (c_int, [c_int, P, S]),
     'd2p_loss_assemble': (c_int, [c_int, P, P, P, P, P, S]),
     'd2p_loss_from_partials': (c_int, [c_int, P, P, P, P, P, P, P, S]),
     'd2p_group_mean': (c_int, [c_int, c_int, c_int, P, P, P, S]),
@@ -172,6 +173,12 @@ class LstmBwdDesc(ctypes.Structure):
                 ('dz', c_void_p), ('dh0', c_void_p), ('dc0', c_void_p),
                 ('ws', c_void_p), ('ws_bytes', c_size_t), ('db', c_void_p), ('flags', c_void_p),
                 ('epoch', ctypes.c_uint), ('wpack', c_void_p), ('rowmap', c_void_p), ('slab_steps', c_void_p)]
+
+
+class PairProductsDesc(ctypes.Structure):
+    """d2p_pair_products_desc (include/d2p.h)."""
+    _fields_ = [('R', c_int), ('U', c_int), ('N4', c_int), ('S', c_void_p), ('A', c_void_p), ('Wx', c_void_p),
+                ('G1', c_void_p), ('G2', c_void_p)]
 
 
 class XentBwdDesc(ctypes.Structure):

@@ -192,6 +192,8 @@ class Model(object):
         # batch norm folded into the conv launches where the geometry has folding kernels (the ViZDoom-size layers): an
         # attribute, not a switch -- tests set it to compare with the separate launches
         self.fold_bn = True
+        # the decoders' small gradient products grouped into one launch (an attribute, not a switch: tests compare)
+        self.grouped_decoder_grads = True
         self.fused_loss = flag('D2P_FUSED_LOSS')
         # timing-only ablation (tools/step_ablation.py -> set_ablation): NEVER from the environment; Trainer.train and
         # Evaler refuse a model that carries one
@@ -1309,8 +1311,10 @@ class Model(object):
             self.mark('bwd:decoders')
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                for i, dz in zip((0, 1, 2) if self.fuse_decoders else (2, 1, 0), dzs):
-                    grads[i](dz)
+                order_ = (0, 1, 2) if self.fuse_decoders else (2, 1, 0)
+                if not self._decoder_grads_grouped(dict(zip(order_, dzs)), feed, n_p * B, n_d * M):
+                    for i, dz in zip(order_, dzs):
+                        grads[i](dz)
             K.axpy(1.0, tmp_hc, d_demo)
             if split_cb is not None:
                 self._call_split(split_cb, main, side)
@@ -1507,6 +1511,46 @@ class Model(object):
             gk[:U].zero_()
         self._lstm_bwd_weights(e, dz)              # bias and recurrent-kernel gradients (e['factored_x'] skips dWx)
 
+    def _decoder_grads_grouped(self, dz_of, feed, rows_p, rows_d):
+        """(round 6) The three decoders' gradient products behind their backward recurrences with the SMALL ones grouped:
+        each decoder's dz rows summed by input token / perception column (S: three launches, one read of dz each), then
+        ONE launch for the six products G1 = A^T S (the input half of the kernel gradient) and G2 = S Wx^T (embedding
+        gradient / the perception encoder's Q) -- d2p_small_pair_products --, the perception encoder's fc / batch-norm
+        gradients, and the three large recurrent-kernel gradients.  False (nothing done) when a decoder is not on the
+        projected-table / factored path or the sizes are not taken: the per-decoder launches run."""
+        ctx, c, p, g = self._ctx, self.config, self.params.p, self.params.g
+        U, P, k = self.num_lstm_cell_units, c.per_dim, c.k
+        dp, da, dq = ctx['dp'], ctx['da'], ctx['dq']
+        if self.grouped_decoder_grads is False or self._abl('wgrad') or self._abl('scatter'):
+            return False
+        if dp.get('token_ids') is None or da.get('token_ids') is None or dq['x'] is not None or 'per/H' not in self._bufs:
+            return False
+        if rows_p <= 0 or rows_d <= 0 or not K.pair_products_ok(max(dp['token_dim'] + 1, da['token_dim'] + 1, self.per_cols), U):
+            return False
+        per_tm = ctx.get('per_tm')
+        if per_tm is None or not K.per_rows_tn_ok(rows_d, k, P, 4 * U):
+            return False
+        probs = []
+        for e, dz, rows in ((dq, dz_of[2], rows_d), (da, dz_of[1], rows_d), (dp, dz_of[0], rows_p)):
+            name, scope = e['name'], e['scope']
+            gk, Wx = g[name + '/kernel'], p[name + '/kernel'][:U]
+            if e is dq:
+                S = K.per_rows_tn(k, per_tm.view(-1, P), dz, self._buf('per/S', (self.per_cols, 4 * U)), rows)
+                R_, A_, G2 = self.per_cols, self._bufs['per/H'], self._buf('per/Q', (self.per_cols, U))
+            else:
+                tok = e['token_dim']
+                S = self._buf(name + '/dz_by_token', (tok + 2, 4 * U))
+                K.embedding_scatter_add(e['token_ids'], dz[:rows], S, n=rows)
+                R_, A_, G2 = tok + 1, p[scope + '/embedding'], g[scope + '/embedding']
+            probs.append((R_, U, S, A_, Wx, gk[:U], G2))
+        K.small_pair_products(probs)
+        K.per_fc_bn_bwd(k, P, c.batch_size * c.max_demo_len, p['per/fc/W'], p['per/fc/b'], p['per/fc/gamma'],
+                        ctx['pe_mean'], ctx['pe_rstd'], self._bufs['per/Q'], feed['per_gram'], g['per/fc/W'], g['per/fc/b'],
+                        g['per/fc/gamma'], g['per/fc/beta'])
+        for e, dz in ((dq, dz_of[2]), (da, dz_of[1]), (dp, dz_of[0])):
+            self._lstm_bwd_weights(e, dz, part='h')
+        return True
+
     def _token_decoder_grads(self, e, dz, ids, rows):
         """Kernel / bias / embedding gradients of a token-input decoder from its dz."""
         if e.get('token_ids') is not None:
@@ -1525,8 +1569,9 @@ class Model(object):
             K.gemm_raw('nt', rows, I, 4 * U, dz[:rows], 4 * U, e['Wx'], 4 * U, dx, I)
         return dx
 
-    def _lstm_bwd_weights(self, e, dz):
-        """Kernel / bias gradients from dz: nothing downstream reads them before the optimizer."""
+    def _lstm_bwd_weights(self, e, dz, part='all'):
+        """Kernel / bias gradients from dz: nothing downstream reads them before the optimizer.  part='h': the recurrent
+        half alone (the input half was written by _decoder_grads_grouped)."""
         if self._abl('wgrad') or self._abl('wgrad:' + e['name']):
             return
         g = self.params.g
@@ -1538,7 +1583,9 @@ class Model(object):
         # the rows inside their sequences, as K lists (d2p_gemm_f32_tn_rows): the others are zeros in dz
         kl = self._ctx.get('klists', {}).get(e.get('rowspace')) if rows > 0 else None
         # dWx = X^T dZ ; db = colsum(dZ)
-        if e.get('token_ids') is not None:
+        if part == 'h':
+            pass
+        elif e.get('token_ids') is not None:
             # x = embedding[id]: S[v] = sum of the dz rows whose input token was v (one-hot GEMM, tok+2 rows),
             # then dWx = embedding^T S and d embedding = S Wx^T -- three small products instead of two
             # 13.4 GFLOP GEMMs (dWx, dX) and the scatter of dX

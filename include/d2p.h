@@ -612,6 +612,16 @@ typedef struct {
     float* loss_part;
 } d2p_xent_bwd_desc;
 int d2p_xent_bwd_dhout_multi(int nprob, const d2p_xent_bwd_desc* descs, d2p_stream_t stream);
+/* Round 6: the decoders' small gradient products in one launch for up to four decoders (descs: HOST array).
+ * d2p_small_pair_products: with S [R <= 256, N4 = 4U] (the decoder's dz rows summed by input token / perception column),
+ *   G1 [U, N4] = A^T S (A [R, U]: the embedding table or the perception rows' matrix H) -- the input half of the LSTM
+ *   kernel's gradient -- and G2 [R, U] = S Wx^T (Wx [U, N4] row-major) -- the embedding gradient / the Q of
+ *   d2p_per_fc_bn_bwd.  Replaces a d2p_gemm_f32_tn and a d2p_gemm_f32_nt call per decoder. */
+typedef struct {
+    int R, U, N4;
+    const float* S; const float* A; const float* Wx; float* G1; float* G2;
+} d2p_pair_products_desc;
+int d2p_small_pair_products(int n, const d2p_pair_products_desc* descs, d2p_stream_t stream);
 /* loss / term_losses / nums as d2p_loss_assemble writes them, from the loss_part arrays of d2p_xent_bwd_dhout_multi:
  * term j has groups[j] loss groups and nblocks[j] = ceil(n_steps_j * R_j / 16) partial rows at parts[j]; groups, nblocks,
  * parts: HOST arrays of n_terms (<= 3) entries, at most 64 groups in all; dens as for d2p_loss_assemble; nums may be NULL.

@@ -1817,3 +1817,23 @@ def test_per_rows_product_from_the_structure_of_the_rows(K, G, P, T, B, E):
     ref = A[:n] @ HWx.double() + bias.double()
     torch.testing.assert_close(z[:n].double().cpu(), ref, rtol=1e-5, atol=1e-5)
     assert bool((z[n:] == 7.0).all())
+
+
+# ------------------------------------------------------------------ the decoders' small gradient products (round 6)
+@pytest.mark.parametrize('U', [128, 512])
+def test_small_pair_products_of_several_decoders_in_one_launch(K, U):
+    """d2p_small_pair_products: G1 = A^T S (the input half of the LSTM kernel's gradient from the dz rows summed by input
+    token / perception column) and G2 = S Wx^T (the embedding gradient, models/model_full.py:282-296; the perception
+    encoder's Q) for R = 7 / 51 / 60 / 176 rows -- against fp64; rows of S past R are never read into the result."""
+    probs, refs = [], []
+    for i, R in enumerate([7, 51, 60, 176]):
+        S, A, Wx = rnd(R + 3, 4 * U, seed=120 + i), rnd(R, U, seed=130 + i), rnd(U, 4 * U, seed=140 + i, scale=0.1)
+        S[R:] = float('nan')                                # (buffers carry spare rows: tok + 2, padded perception columns)
+        G1, G2 = torch.full((U, 4 * U), 3.0, device='cuda'), torch.full((R + 2, U), 5.0, device='cuda')
+        probs.append((R, U, dev(S), dev(A), dev(Wx), G1, G2))
+        refs.append((A.double().t() @ S[:R].double(), S[:R].double() @ Wx.double().t()))
+    K.small_pair_products(probs)
+    for (R, _, _, _, _, G1, G2), (r1, r2) in zip(probs, refs):
+        close(G1, r1, atol=2e-5 * float(r1.abs().max()) + 1e-5, rtol=1e-5)
+        close(G2[:R], r2, atol=2e-5 * float(r2.abs().max()) + 1e-5, rtol=1e-5)
+        assert (G2[R:] == 5.0).all()

@@ -1503,6 +1503,33 @@ def test_relation_networks_in_four_launches_equal_the_separate_launches(model_ki
     torch.testing.assert_close(res[0][2], res[1][2], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize('kind', ['karel', 'vizdoom'])
+def test_decoder_small_gradient_products_grouped_equal_the_separate_launches(kind):
+    """Round 6: the six products behind the decoders' dz rows summed by token / perception column in one launch
+    (d2p_small_pair_products), against the per-decoder GEMM launches: same gradients to fp32 summation order (the oracle
+    parity tests run with the grouped form)."""
+    from demo2program_amd import kernels as K
+    from demo2program_amd.models.model_full import Model
+    over = dict(num_lstm_cell_units=128)
+    if kind == 'vizdoom':
+        over.update(h=20, w=20)
+    cfg, params, batch = small_case(kind, seed=71, **over)
+    res = []
+    for grouped in (False, True):
+        m = Model(cfg, params=params)
+        m.grouped_decoder_grads = grouped
+        loss = float(m.forward(m.get_feed_dict(batch)).item())
+        m.backward()
+        torch.cuda.synchronize()
+        res.append((loss, m.params.to_numpy('g')))
+    assert res[0][0] == res[1][0]
+    for n in res[0][1]:
+        a, b = res[0][1][n], res[1][1][n]
+        assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max() + 1e-7, n
+    changed = [n for n in res[0][1] if not np.array_equal(res[0][1][n], res[1][1][n])]
+    assert any('embedding' in n or n.endswith('lstm/kernel') for n in changed), changed      # (the other path really ran)
+
+
 def test_training_step_decoders_skip_the_steps_past_a_rows_length():
     """Round 5: in a training step (deferred logits) the action / perception decoders' forward recurrences run
     length-sorted and do not compute a row past its own length -- nothing reads those outputs there (the loss and its
