@@ -13,7 +13,8 @@ Not process switches: three attributes of a Model OBJECT that exist for the A si
 from the environment -- `fused_encoder` (set from D2P_FUSED_ENCODER at construction), `fused_rn` (the relation networks'
 four-launch form; tests/test_model_gpu.py::test_relation_networks_in_four_launches_equal_the_separate_launches) and
 `decoder_skip_past_len` (a training step's decoders stop at a row's length;
-::test_training_step_decoders_skip_the_steps_past_a_rows_length).
+::test_training_step_decoders_skip_the_steps_past_a_rows_length); likewise `fold_bn` (batch norm folded into the conv launches)
+and `grouped_decoder_grads` (::test_decoder_small_gradient_products_grouped_equal_the_separate_launches).
 """
 import os
 
