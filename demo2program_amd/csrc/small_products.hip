@@ -91,13 +91,22 @@ __global__ void __launch_bounds__(256) small_pair_products_kernel(SpArgs a) {
     const float* wp = q.Wx + (long)(itile * 16 + p) * q.N4 + 4 * qq;
     const int kper = q.N4 / 4;                                  // this wave's share of K
     f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int k = wave * kper; k < (wave + 1) * kper; k += 32) {
-        const f32x4 s0 = sp_ldg4(sp + k), w0 = sp_ldg4(wp + k), s1 = sp_ldg4(sp + k + 16), w1 = sp_ldg4(wp + k + 16);
+    // (eight 16-deep chunks of both operands in flight at a time: a chunk-by-chunk loop waits out a memory round trip per
+    //  8 MFMAs -- 50 us for the whole launch)
+    for (int k = wave * kper; k < (wave + 1) * kper; k += 128) {
+        f32x4 sv[8], wv[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            acc0 = SP_MFMA16(s0[j], w0[j], acc0);
-            acc1 = SP_MFMA16(s1[j], w1[j], acc1);
+        for (int c = 0; c < 8; ++c) {
+            sv[c] = sp_ldg4(sp + k + 16 * c);
+            wv[c] = sp_ldg4(wp + k + 16 * c);
         }
+#pragma unroll
+        for (int c = 0; c < 8; c += 2)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc0 = SP_MFMA16(sv[c][j], wv[c][j], acc0);
+                acc1 = SP_MFMA16(sv[c + 1][j], wv[c + 1][j], acc1);
+            }
     }
     float* red = lds + 64 * 32;                                 // [4 waves][64 lanes][4]
     *reinterpret_cast<f32x4*>(red + (wave * 64 + lane) * 4) = acc0 + acc1;
@@ -124,8 +133,8 @@ extern "C" int d2p_small_pair_products(int n, const d2p_pair_products_desc* d, d
     int blk = 0;
     double fl = 0.0;
     for (int i = 0; i < n; ++i) {
-        D2P_REQUIRE(d[i].R >= 1 && d[i].R <= 256 && d[i].U >= 32 && d[i].U % 32 == 0 && d[i].N4 >= 256 && d[i].N4 % 256 == 0,
-                    D2P_EINVAL, "pair products: problem %d: R=%d U=%d N4=%d (R <= 256, U a multiple of 32, N4 of 256)", i, d[i].R,
+        D2P_REQUIRE(d[i].R >= 1 && d[i].R <= 256 && d[i].U >= 32 && d[i].U % 32 == 0 && d[i].N4 >= 512 && d[i].N4 % 512 == 0,
+                    D2P_EINVAL, "pair products: problem %d: R=%d U=%d N4=%d (R <= 256, U a multiple of 32, N4 of 512)", i, d[i].R,
                     d[i].U, d[i].N4);
         D2P_REQUIRE(d[i].S && d[i].A && d[i].Wx && d[i].G1 && d[i].G2, D2P_EINVAL, "pair products: null pointer");
         D2P_REQUIRE((((uintptr_t)d[i].S | (uintptr_t)d[i].Wx) & 15) == 0, D2P_EALIGN, "pair products: S, Wx must be 16-byte aligned");

@@ -786,7 +786,7 @@ def xent_bwd_dhout_multi(probs):
 
 
 def pair_products_ok(R, U):
-    return 1 <= R <= 256 and U >= 64 and U % 64 == 0
+    return 1 <= R <= 256 and U >= 128 and U % 128 == 0
 
 
 def small_pair_products(probs):
