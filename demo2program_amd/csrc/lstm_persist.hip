@@ -39,7 +39,6 @@
 //   * needs all workgroups co-resident: grid <= number of CUs, one workgroup per CU.
 #include "common.h"
 #include "lstm_internal.h"
-#include <type_traits>
 #include "lstm_math.h"
 #include "prof.h"
 
@@ -1287,7 +1286,6 @@ struct PsBwdArgs {
     float* db; float* dbpart; unsigned* dbtick;
     int defer_from;         // phases per domain from which the deferred form runs (a large value: never)
     int lds_nb;             // 1, or 2 when the launch may defer (double-buffered partial tiles / staged rows)
-    int skip_zero_pass;     // 1: the ticks of pass 0 leave out their MFMA chain (it multiplies zeros)
     // "direct" launches (no preparation launch, as PsFwdArgs): Wh^T fragments straight from the row-major Wh (one
     // 16-byte load each: the packed image is a permutation of its float4s), pass 0's all-zero operand from a
     // zero-length buffer descriptor, flags on epochs, bias-gradient tickets reset by their last arriver
@@ -1444,10 +1442,8 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
     pre_prev.q = LstmCellBwdPre{0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     pre_prev.dhx = 0.f; pre_prev.dcv = 0.f; pre_prev.cur_active = false; pre_prev.prow = 0;
     PsTick kprev = {0, 0};
-    // ZERO (round 6): the ticks of pass 0 multiply dz[T], which does not exist (zeros from the descriptor's bounds check):
-    // their MFMA chain -- 4 096 clocks of a phase's ~7 000 -- is left out; loads, flags, gate math and publication as ever
-    auto tick = [&](int n, auto ztag) __attribute__((always_inline)) {
-        constexpr bool ZERO = decltype(ztag)::value;
+#pragma unroll 1
+    for (int n = 0; n < nticks; ++n) {
         const int par = DEFER ? (n & 1) : 0;
         float* Pw = P + par * PS_BWD_P_FLOATS + wave * 16 * PS_PLD;
         const bool e1 = n + 1 >= nticks, e2 = n + 2 >= nticks;
@@ -1482,7 +1478,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
                 // (phase index PS_NRS_MAX = a spare state slot nobody reads)
                 if (DEFER && st == 0)
                     ps_bwd_epilogue_post<DESC>(a, e, rs0, n > 0 ? kprev.p : PS_NRS_MAX, kprev.t, pre_prev, dbacc, par ^ 1, n > 0);
-                if (!ZERO) ps_bwd_stage<CB, CPWB>(s0, bw, st * CB, acc0, acc1);
+                ps_bwd_stage<CB, CPWB>(s0, bw, st * CB, acc0, acc1);
             } else {
 #pragma unroll
                 for (int c = 0; c < CB; ++c) s0[c] = ps_ld_sc1(rn, noff + c * 1024);
@@ -1490,7 +1486,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
                     fv = ps_ld_flag(fl + q2.p * nnt);
                     ps_bwd_epilogue_pre(a, e, k0.p, k0.t, slot, pre);      // interleaved with this stage's MFMAs
                 }
-                if (!ZERO) ps_bwd_stage<CB, CPWB>(s1, bw, st * CB, acc0, acc1);
+                ps_bwd_stage<CB, CPWB>(s1, bw, st * CB, acc0, acc1);
             }
             // the next stage's operand loads (~60 clocks of issue each) and, in the last stage, the
             // product-independent half of the gate math go between this stage's MFMAs
@@ -1517,13 +1513,7 @@ __device__ __forceinline__ void ps_bwd_mfma_wave(const PsBwdArgs& a, const PsBwd
         if (wave == 0) tr.flush(0, n, lane);
         k0 = k1; k1 = k2; k2.next(nrs);
         if (++slot == PS_PF_R) slot = 0;
-    };
-    int n = 0;
-    const int nzero = a.skip_zero_pass ? min(nrs, nticks) : 0;
-#pragma unroll 1
-    for (; n < nzero; ++n) tick(n, std::true_type{});
-#pragma unroll 1
-    for (; n < nticks; ++n) tick(n, std::false_type{});
+    }
     // the last phase's product-dependent half (its rows go nowhere: no publication)
     if (DEFER) ps_bwd_epilogue_post<DESC>(a, e, rs0, kprev.p, kprev.t, pre_prev, dbacc, (nticks - 1) & 1);
 }
@@ -1864,11 +1854,6 @@ extern "C" int d2p_lstm_persist_set_bwd_desc(int on) {
     g_ps_bwd_desc = on ? 1 : 0;
     return D2P_OK;
 }
-static int g_ps_skip_zero_pass = 1;          // 0: pass 0 of a backward launch multiplies its zeros (A/B: d2p_lstm_persist_set_skip_zero_pass)
-extern "C" int d2p_lstm_persist_set_skip_zero_pass(int on) {
-    g_ps_skip_zero_pass = on ? 1 : 0;
-    return D2P_OK;
-}
 static int g_ps_bwd_defer_from = 1 << 20;    // backward: deferred form from this many phases per domain (d2p_lstm_persist_set_bwd_defer);
                                              // measured -4 % per phase at 5-7 phases in isolation, nothing in the step: off by default
 extern "C" int d2p_lstm_persist_set_bwd_defer(int from_phases) {
@@ -2105,7 +2090,6 @@ static int ps_bwd_setup(const PsBwdCall& q, int RT, int bid0, PsBwdArgs& a, hipS
     a.total_rs = (M + 15) / 16;
     const int nnt = U / 16;
     a.RT = RT;
-    a.skip_zero_pass = g_ps_skip_zero_pass;
     a.bid0 = bid0; a.gsz = nnt * RT;
     a.want_dh0 = q.dh0 ? 1 : 0;
     const size_t Mp = (size_t)a.total_rs * 16;

@@ -100,7 +100,6 @@ SIGNATURES = {
     'd2p_lstm_persist_set_trace': (c_int, [P, c_size_t, c_int]),
     'd2p_lstm_persist_set_wgs_per_cu': (c_int, [c_int, c_int]),
     'd2p_lstm_persist_set_cu_budget': (c_int, [c_int]),
-    'd2p_lstm_persist_set_skip_zero_pass': (c_int, [c_int]),
     'd2p_lstm_persist_pair_launches': (c_int, []),
     'd2p_lstm_persist_set_fwd_wide': (c_int, [c_int, c_int, c_int, c_int]),
     'd2p_lstm_persist_set_fwd_plan_cost': (c_int, [ctypes.c_double, ctypes.c_double]),

@@ -427,9 +427,6 @@ int d2p_lstm_persist_set_wgs_per_cu(int fwd, int bwd);
  * 256: seven row domains of 32 column tiles instead of eight -- leaves whole CUs to other queues: four-wave workgroups
  * (GEMMs, a collective's kernels) cannot become resident on a CU that holds a recurrence's workgroup. */
 int d2p_lstm_persist_set_cu_budget(int cus);
-/* Debugging switch (process-global, default 1): the first pass of a persistent backward launch multiplies dz[T], which
- * does not exist (zeros); 1 leaves that pass's MFMA chain out -- same results bit for bit. */
-int d2p_lstm_persist_set_skip_zero_pass(int on);
 /* The wide-tile forward kernel (round 4: 16 units per column tile -- 8 row domains at U = 512 --, one to three
  * sequences per launch, length-sorted where a descriptor brings rowmap / slab_steps, row domains that find all their
  * workgroups on one XCD exchange through its L2).  on: 1 (default) / 0 = every forward launch goes to the 8-unit-tile

@@ -1339,17 +1339,6 @@ def test_lstm_backward_over_rows_sorted_by_length(K, specs):
         scale = max(1.0, float(o['dz'].abs().double().sum(dim=0).max()))
         assert (o['db'].double() - o2['db'].double()).abs().max().item() <= 2e-6 * scale
         assert torch.equal(o2['db'], o3['db'])                       # deterministic
-    # round 6: the first pass of a launch multiplies dz[T], which does not exist -- its MFMA chain is left out
-    # (d2p_lstm_persist_set_skip_zero_pass); with the chain put back every array is bit-identical
-    from demo2program_amd.lib import load
-    load().d2p_lstm_persist_set_skip_zero_pass(0)
-    try:
-        d = run(True)
-    finally:
-        load().d2p_lstm_persist_set_skip_zero_pass(1)
-    for o2, o4 in zip(b, d):
-        for name in ('dz', 'dh0', 'dc0', 'db'):
-            assert torch.equal(o2[name], o4[name]), name
     assert K.lstm_persist_error(True) == 0
 
 
