@@ -199,16 +199,8 @@ static int g_rows_by_key = 1;             // d2p_gemm_set_option bit 7 switches 
 
 // K slices between workgroups for outputs of fewer than 128 tiles (1: none): enough slices to fill the chip, at least 512
 // rows of K per workgroup
-// (g_tnd_big_slices, d2p_gemm_tn_direct_set_slices -- an experiment of round 6: K slices also for the outputs that fill the
-//  chip by themselves, i.e. more, shorter-lived workgroups: a persistent recurrence of the other queue can only start when
-//  every workgroup of a running product has left its CU)
-static int g_tnd_big_slices = 1;
-extern "C" int d2p_gemm_tn_direct_set_slices(int ks) {
-    g_tnd_big_slices = ks >= 1 && ks <= 16 ? ks : 1;
-    return D2P_OK;
-}
 static int tn_direct_slices(long tiles, int K) {
-    if (tiles >= 128) return (K / g_tnd_big_slices >= 512) ? g_tnd_big_slices : 1;
+    if (tiles >= 128) return 1;
     int ks = (int)(256 / tiles);
     while (ks > 1 && K / ks < 512) --ks;
     return ks > 16 ? 16 : ks;

@@ -29,7 +29,6 @@ SIGNATURES = {
     'd2p_gemm_f32_batched': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_long, c_long, c_long, P, c_long, c_long,
                                      c_long, P, c_long, c_long, c_long, P, c_long, c_long, c_int, c_int, S]),
     'd2p_gemm_force_plan': (c_int, [c_int, c_int]),
-    'd2p_gemm_tn_direct_set_slices': (c_int, [c_int]),
     'd2p_gemm_f32_nn': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
     'd2p_gemm_f32_nt': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),
     'd2p_gemm_f32_tn': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, c_int, c_int, P, c_size_t, S]),

@@ -87,8 +87,6 @@ int d2p_gemm_set_option(int bk32);
  * falls back to the staged kernel of the same tile when the operands are not 16-byte aligned or K is not a
  * multiple of 32; -1 auto) and the split-K factor (0 auto) of the dense entry points. */
 int d2p_gemm_force_plan(int tile, int splits);
-/* Tuning experiment (round 6): K slices of the register-direct A^T B kernel for outputs of 128 tiles and more (default 1). */
-int d2p_gemm_tn_direct_set_slices(int ks);
 int d2p_gemm_f32_nn(int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                     float* C, long ldc, const float* bias, int act, int accumulate,
                     void* ws, size_t ws_bytes, d2p_stream_t stream);
