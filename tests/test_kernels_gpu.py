@@ -310,7 +310,8 @@ def test_conv_uint8_frames_equal_float_frames(K, N, H, W, Cin, Cout):
     close(dw, dwf, atol=1e-3, rtol=1e-5)
 
 
-@pytest.mark.parametrize('B,G,T,H,Cin', [(2, 3, 4, 20, 32), (3, 2, 5, 10, 48), (2, 5, 4, 5, 48), (9, 10, 20, 10, 48)])
+@pytest.mark.parametrize('B,G,T,H,Cin', [(2, 3, 4, 20, 32), (3, 2, 5, 10, 48), (2, 5, 4, 5, 48), (9, 10, 20, 10, 48),
+                                        (1, 2, 30, 20, 32)])      # (3 000 pixels per sequence: the weight gradient's offset table covers half a sequence)
 def test_wide_layers_forward_with_statistics_and_input_affine(K, B, G, T, H, Cin):
     """Round 6, conv_wide.hip: the 48-channel layers' forward pass (filter in LDS; conv3 32 -> 48 on 20x20, conv4 / conv5
     48 -> 48 on 10x10 / 5x5; models/ops.py:27-33) with the batch-norm folding of ConvBnFold -- statistics of its own
