@@ -740,7 +740,7 @@ struct WideWg {
     unsigned x_bytes, dy_bytes;  // buffer sizes (x: incl. the pad pixels when AFFINE)
 };
 
-template <int CIN, bool AFFINE>
+template <int CIN, bool AFFINE, bool TAIL>
 __global__ void __launch_bounds__(WWG_WAVES * 64)
 conv_wide_wgrad_kernel(WideGeom g, const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slabs,
                        WideWg dl) {
@@ -794,10 +794,15 @@ conv_wide_wgrad_kernel(WideGeom g, const float* __restrict__ x, const float* __r
         const unsigned xs = (unsigned)frame0 * frame_bytes;                     // (wave-uniform: scalar offsets)
         const unsigned ys = (unsigned)frame0 * (unsigned)(HoWo * WCO * 4);
         const unsigned padrel = pad_abs - xs;
+        // a plain launch's LAST block may hold fewer than fb frames: its pixels past the batch must read zeros on BOTH
+        // operands -- by offsets past the buffer in the VGPR offset (the scalar offset need not be part of the range check)
+        // (TAIL: a compile-time choice -- the test inside the loop cost the affine form 12 % when it was a run-time one)
+        const int lim = TAIL ? min(dl.fb, g.N - frame0) * HoWo : 0;
         float A[4][NA], B[4][WNB];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            const uint4 e = tab[ks * npix + tr * 16 + 4 * q + kk];
+            uint4 e = tab[ks * npix + tr * 16 + 4 * q + kk];
+            if (TAIL && tr * 16 + 4 * q + kk >= lim) e = uint4{WWG_SENT, WWG_SENT, WWG_SENT, WWG_SENT};
             unsigned off[3] = {e.x, e.y, e.z};
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
@@ -918,9 +923,9 @@ int launch_wide_wgrad(const ConvGeom& g, const float* x, const float* dy, float*
     float* slabs = (float*)ws;
     {
         D2pProfScope prof(st, D2P_PROF_CONV, 2.0 * d.P * KK * WCO);
-#define D2P_WIDE_WG(AF)                                                                                                  \
+#define D2P_WIDE_WG(AF, TL)                                                                                              \
     do {                                                                                                                 \
-        auto kern = conv_wide_wgrad_kernel<CIN, AF>;                                                                     \
+        auto kern = conv_wide_wgrad_kernel<CIN, AF, TL>;                                                                 \
         static size_t have = 0;                                                                                          \
         if (lds > have) {                                                                                                \
             hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -929,8 +934,9 @@ int launch_wide_wgrad(const ConvGeom& g, const float* x, const float* dy, float*
         }                                                                                                                \
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(WWG_WAVES * 64), lds, st, d, x, dy, slabs, dl);                      \
     } while (0)
-        if (dl.in_scale) D2P_WIDE_WG(true);
-        else D2P_WIDE_WG(false);
+        if (dl.in_scale) D2P_WIDE_WG(true, false);            // (sequences are whole blocks: no tail)
+        else if (!bn && g.N % dl.fb != 0) D2P_WIDE_WG(false, true);
+        else D2P_WIDE_WG(false, false);
 #undef D2P_WIDE_WG
         D2P_LAUNCH_CHECK("conv_wide_wgrad");
         EpiDense ep{dw, WCO, nullptr, 0, 0};
