@@ -21,7 +21,10 @@ Besides the contract fields the JSON line carries
   value_incl_h2d_prefetched -- the same step loop fed from HOST batches through the trainer's
                   prefetcher (the reference's step time spans fetch + feed + run, trainer.py:187-205)
   config4_vizdoom -- BASELINE config 4 (80x80x3 frames) timed in the same run: ms/step and the conv
-                  encoder's fraction of the fp32 MFMA peak (N = 1 only)
+                  encoder's fraction of the fp32 MFMA peak (N = 1 only); its headline numbers again at the TOP
+                  level (config4_ms_per_step, config4_value, config4_conv_frac, config4_conv_bn_ms,
+                  config4_traffic_ratio) and inside `config.also_measured_in_this_run`
+  config5_per_rank_vizdoom_k25 -- config 5's per-rank shape (k = 25, B = 16), 5 steps: config5_rank_ms_per_step / _value
   cpu_baseline -- the CPU oracle (torch-CPU restatement, NOT TF1) timed on this box's host
                   cores on the same batch (rank 0, N=1 only): forward + backward WITHOUT the
                   optimizer, on <= 16 threads.
