@@ -97,6 +97,46 @@ def build_library(force=False, verbose=False):
     return OUT
 
 
+def build_variant_library(tag, defines, source='lstm_persist.hip', verbose=False):
+    """An A/B copy of the library: `source` compiled with extra -D `defines`, every other object shared with the product
+    library -> csrc/libd2p_hip_<tag>.so (git-ignored; loaded through D2P_LIB_PATH by tools/ab_env.sh)."""
+    build_library()
+    out = os.path.join(CSRC, 'libd2p_hip_%s.so' % tag)
+    obj = os.path.join(OBJDIR, '%s.%s.%s.o' % (os.path.splitext(source)[0], tag, _stamp()))
+    cmd = [_hipcc()] + FLAGS + ['-D' + d for d in defines] + ['-c', source, '-o', obj]
+    if verbose:
+        print(' '.join(cmd), flush=True)
+    subprocess.run(cmd, cwd=CSRC, check=True)
+    objs = [obj if s == source else _obj(s) for s in SOURCES]
+    subprocess.run([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out], cwd=CSRC, check=True)
+    return out
+
+
+def build_stamps_library(verbose=False):
+    """A DIAGNOSTIC copy of the library for tools/lstm_launch_stamps.py: lstm_persist.hip compiled with -DD2P_PS_STAMPS
+    (launch-boundary time stamps in the persistent recurrences), every other object shared with the product library.
+    Loaded through D2P_LIB_PATH by that tool only; the product library's code is unchanged by the macro's absence."""
+    build_library()
+    out = os.path.join(CSRC, 'libd2p_hip_stamps.so')
+    src = os.path.join(CSRC, 'lstm_persist.hip')
+    obj = os.path.join(OBJDIR, 'lstm_persist.stamps.%s.o' % _stamp())
+    if _mtime(obj) < max(_mtime(src), _newest_header()):
+        cmd = [_hipcc()] + FLAGS + ['-DD2P_PS_STAMPS', '-c', 'lstm_persist.hip', '-o', obj]
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.run(cmd, cwd=CSRC, check=True)
+    if _mtime(out) < max(_mtime(obj), _mtime(OUT)):
+        objs = [obj if s == 'lstm_persist.hip' else _obj(s) for s in SOURCES]
+        subprocess.run([_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out], cwd=CSRC, check=True)
+    return out
+
+
 if __name__ == '__main__':
     import sys
-    print(build_library(force='--force' in sys.argv, verbose=True))
+    if '--stamps' in sys.argv:
+        print(build_stamps_library(verbose=True))
+    elif '--variant' in sys.argv:            # --variant TAG DEFINE [DEFINE ...]
+        i = sys.argv.index('--variant')
+        print(build_variant_library(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+    else:
+        print(build_library(force='--force' in sys.argv, verbose=True))

@@ -117,6 +117,56 @@ struct PsTrace {
     }
 };
 
+// ---- launch-level stamps (tools/lstm_launch_stamps.py; a DIAGNOSTIC build of this file with -DD2P_PS_STAMPS,
+// linked into its own library -- the product library never carries them: PS_STAMP expands to nothing) ------------
+// Wave 0 (role 0: the first MFMA wave) and wave 4 (role 1: the publish / prefetch wave) of EVERY workgroup leave the
+// 100 MHz s_memrealtime counter (one clock for the whole chip, unlike the shader clock of PsTrace) at the boundaries
+// of a launch: 0 entry, 1 tables / initial state in LDS (weights requested), 3 last tick done, 4 bias-gradient
+// exchange done, 5 final stores issued, 6 final stores out; 7 = geometry word.  Nothing inside the tick loops: a
+// stamp there changes hipcc's schedule of the loop (the backward launches ran 8 % slower with one).
+#ifdef D2P_PS_STAMPS
+#define PS_ST_K 8
+#define PS_ST_MAXB 512
+__device__ unsigned long long* g_ps_stamp_buf = nullptr;    // [slot][PS_ST_MAXB blocks][2 roles][PS_ST_K]
+__device__ int g_ps_stamp_slot = -1;
+static int g_ps_stamp_slots = 0, g_ps_stamp_next = 0;
+__global__ void ps_stamp_slot_kernel(unsigned long long* buf, int slot) {
+    g_ps_stamp_buf = buf;
+    g_ps_stamp_slot = slot;
+}
+static unsigned long long* g_ps_stamp_host_buf = nullptr;
+extern "C" int d2p_lstm_persist_set_stamps(void* buf, size_t bytes) {
+    g_ps_stamp_host_buf = (unsigned long long*)buf;
+    g_ps_stamp_slots = buf ? (int)(bytes / ((size_t)PS_ST_MAXB * 2 * PS_ST_K * sizeof(unsigned long long))) : 0;
+    g_ps_stamp_next = 0;
+    return D2P_OK;
+}
+extern "C" int d2p_lstm_persist_stamp_launches(void) { return g_ps_stamp_next; }
+// in stream order in front of a persistent launch: the slot its workgroups write (-1: none left / off)
+static void ps_stamp_before_launch(hipStream_t st) {
+    const int slot = (g_ps_stamp_host_buf && g_ps_stamp_next < g_ps_stamp_slots) ? g_ps_stamp_next++ : -1;
+    hipLaunchKernelGGL(ps_stamp_slot_kernel, dim3(1), dim3(1), 0, st, g_ps_stamp_host_buf, slot);
+}
+__device__ __forceinline__ void ps_stamp(int role, int k, unsigned long long v = 0ull) {
+    unsigned long long* b = g_ps_stamp_buf;
+    const int s = g_ps_stamp_slot;
+    if (b && s >= 0 && (threadIdx.x & 63) == 0 && blockIdx.x < PS_ST_MAXB)
+        b[(((long)s * PS_ST_MAXB + blockIdx.x) * 2 + role) * PS_ST_K + k] = k == 7 ? v : __builtin_amdgcn_s_memrealtime();
+}
+#define PS_STAMP(role, k) ps_stamp(role, k);
+#define PS_STAMP_W0(k) if (wave == 0) ps_stamp(0, k);
+#define PS_STAMP_ENTRY(geom) if (wave == 0 || wave == 4) { ps_stamp(wave >> 2, 0); ps_stamp(wave >> 2, 7, geom); }
+#define PS_STAMP_EXIT_W0 if (wave == 0) { ps_stamp(0, 5); ps_wait_vmcnt<0>(); ps_stamp(0, 6); }
+#define PS_STAMP_LAUNCH(st) ps_stamp_before_launch(st);
+#else   // (every macro expands to NOTHING -- not even an empty statement: an empty `if` in front of the tick loops changed
+        //  hipcc's code for the backward kernels, 54 012 -> 53 704 bytes for U = 512)
+#define PS_STAMP(role, k)
+#define PS_STAMP_W0(k)
+#define PS_STAMP_ENTRY(geom)
+#define PS_STAMP_EXIT_W0
+#define PS_STAMP_LAUNCH(st)
+#endif
+
 // ---- device helpers -------------------------------------------------------------------------
 __device__ __forceinline__ unsigned ps_ld_flag(const unsigned* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1106,6 +1156,8 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWLau
     unsigned* xccw = a.flags + PS_FLAG_WORDS + PS_TICKET_WORDS + rt * nnt;     // this domain's placement words
     const bool defer = nrs >= a.defer_from && a.lds_nb == 2;
     const unsigned my_xcc = (unsigned)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | ((4 - 1) << 11));   // HW_REG_XCC_ID[3:0]
+    PS_STAMP_ENTRY((unsigned long long)nrs | ((unsigned long long)T << 8) | ((unsigned long long)dom << 16) |
+                                     ((unsigned long long)nt << 24) | ((unsigned long long)my_xcc << 32) | ((unsigned long long)seq << 40))
 
     if (wave < 4) {
         // ---------------- MFMA waves ----------------
@@ -1153,10 +1205,12 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWLau
             if (e.un == 0) stl[p * 16 + e.rr] = len | (row << 16);
         }
         ps_barrier();                             // (stl rows of the other waves: the operand rows of step 0)
+        PS_STAMP_W0(1)
         if (defer) psw_mfma_wave<CPW, 2>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
         else if (nrs >= a.la_from && a.la_q == 2) psw_mfma_wave<CPW, 3>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
         else if (nrs >= a.la_from) psw_mfma_wave<CPW, 1>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
         else psw_mfma_wave<CPW, 0>(a, e, bv, hres, hres0, fl, nnt, rs0, nrs, nticks, lane_off, k_off, wave, lane);
+        PS_STAMP_W0(3)
         for (int q = 0; q < nrs; ++q) {
             const int vrow = (rs0 + q) * 16 + e.rr;
             const int row = stl[q * 16 + e.rr] >> 16;
@@ -1171,6 +1225,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWLau
                 }
             }
         }
+        PS_STAMP_EXIT_W0
     } else {
         // ---------------- publish + prefetch wave ----------------
         // prefetch: 4 DMA instructions per tick (one per gate): lane = (row r, quad q), 16 bytes = 4 units
@@ -1211,6 +1266,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWLau
         };
         for (int d = 0; d < PS_PF_D; ++d) issue();
         ps_wait_vmcnt<(PS_PF_D - 1) * 4>();         // tick 0's inputs have landed
+        PS_STAMP(1, 1)
         const __amdgpu_buffer_rsrc_t hres = ps_rsrc(a.hfrag, 2u * a.hfrag_bytes);
         PsTrace tr;
         tr.buf = (blockIdx.x == a.trace_block) ? a.trace : nullptr;
@@ -1259,7 +1315,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_fwdw_kernel(PsFwdWLau
             tr.flush(1, n, lane);
             if (pub) k.next(nrs);
         }
+        PS_STAMP(1, 3)
         ps_wait_vmcnt<0>();
+        PS_STAMP(1, 6)
     }
 }
 
@@ -1564,6 +1622,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
     const int nticks = nrs * J;
     unsigned* fbase = a.flags + (long)rt * PS_NRS_MAX * nnt;
     const bool defer = nrs >= a.defer_from && a.lds_nb == 2;
+    PS_STAMP_ENTRY((unsigned long long)nrs | ((unsigned long long)J << 8) | ((unsigned long long)rt << 16) |
+                                     ((unsigned long long)nt << 24) |
+                                     ((unsigned long long)(((int)blockIdx.x >= a0.gsz + a1.gsz) ? 2 : (((int)blockIdx.x >= a0.gsz) ? 1 : 0)) << 40))
 
     if (wave < 4) {
         // ---------------- MFMA waves ----------------
@@ -1603,11 +1664,13 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             if (e.un == 0) stl[p * 16 + e.rr] = min(len, 0xffff) | (row << 16);
         }
         float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+        PS_STAMP_W0(1)
         // slack between a publication and the phase that asks for it: nrs - 2 phases with look-ahead, nrs - 3 with the
         // deferred epilogue on top; a hand-off takes ~1.5 phases (as in the forward kernel: deferred from 5 phases)
         if (defer) ps_bwd_mfma_wave<CPW, DESC, true, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
         else if (nrs >= 2) ps_bwd_mfma_wave<CPW, DESC, true>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
         else ps_bwd_mfma_wave<CPW, DESC, false>(a, e, bw, dres, fl, nnt, rs0, nrs, nticks, lane_off, P, wave, lane, dbacc);
+        PS_STAMP_W0(3)
         if (a.db) {
             // this workgroup's 4 gates x 16 units: the four row lanes of a wave by two shuffles, the four waves
             // through LDS in wave order (P is free: the last tick's barrier B is behind every wave)
@@ -1640,6 +1703,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
                 }
             }
         }
+        PS_STAMP_W0(4)
         if (a.dc0)
             for (int qq = 0; qq < nrs; ++qq) {
                 const int vrow = (rs0 + qq) * 16 + e.rr;
@@ -1658,6 +1722,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
                         for (int gg = 0; gg < 4; ++gg) zr[(long)gg * U] = 0.f;
                     }
             }
+        PS_STAMP_EXIT_W0
     } else {
         // ---------------- publish + prefetch wave ----------------
         // prefetch: 8 DMA instructions per tick, lane = (row r, quad q): z gates i, j, f, o, c before the
@@ -1726,6 +1791,7 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
         };
         for (int d = 0; d < PS_PF_D; ++d) issue();
         ps_wait_vmcnt<(PS_PF_D - 1) * PS_BWD_NOP>();
+        PS_STAMP(1, 1)
         const __amdgpu_buffer_rsrc_t dres = ps_rsrc(a.dzfrag, 2u * a.dzfrag_bytes);
         const int KCx = U >> 2;
         PsTrace tr;
@@ -1761,7 +1827,9 @@ __global__ void __launch_bounds__(PS_THREADS) lstm_persist_bwd_kernel(PsBwdArgs 
             tr.flush(1, n, lane);
             if (pub) k.next(nrs);
         }
+        PS_STAMP(1, 3)
         ps_wait_vmcnt<0>();
+        PS_STAMP(1, 6)
         if (a.db) ps_barrier();                      // the MFMA waves' bias-gradient exchange
     }
 }
@@ -2165,6 +2233,7 @@ static int ps_bwd_launch(const PsBwdArgs& a0, const PsBwdArgs& a1, const PsBwdAr
     const bool desc = (a0.gsz == 0 || a0.use_desc) && (a1.gsz == 0 || a1.use_desc) && (a2.gsz == 0 || a2.use_desc);
     const size_t lds = (size_t)(nb * PS_BWD_P_FLOATS + (PS_NRS_MAX + 1) * 256 + 2 * PS_NRS_MAX * 16 + nb * 1024 +
                                 PS_PF_R * PS_BWD_SLOT) * sizeof(float);
+    PS_STAMP_LAUNCH(st)
     D2pProfScope prof(st, D2P_PROF_LSTM_STEP_BWD, flops);
 #define PS_BWD_LAUNCH(CPW)                                                                                              \
     {                                                                                                                   \
@@ -2454,6 +2523,7 @@ int d2p_lstm_persist_fwd_wide(int n, const PsFwdCall* q, hipStream_t st) {
     const int blocks = dom * nnt;
     ++g_psw_launches[n];
     if (any_sorted) ++g_psw_launches[0];
+    PS_STAMP_LAUNCH(st)
     D2pProfScope prof(st, D2P_PROF_LSTM_STEP_FWD, flops);
 #define PSW_LAUNCH(CPW)                                                                                                 \
     {                                                                                                                   \

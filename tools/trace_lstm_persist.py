@@ -57,6 +57,12 @@ def trace(which, M, U, T, masked, block):
 
 if __name__ == '__main__':
     build.build_library()
+    if len(sys.argv) > 1:
+        # which M T masked block[,block...]   e.g.  bwd 320 20 0 0,4   (block b of a 256-workgroup launch is in row domain b % 8)
+        which, M, T, masked = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) != 0
+        for b in sys.argv[5].split(','):
+            trace(which, M, 512, T, masked, int(b))
+        sys.exit(0)
     for which in ('fwd', 'bwd'):
         trace(which, 320, 512, 20, False, 0)
         trace(which, 320, 512, 20, False, 77)
