@@ -406,14 +406,15 @@ def config4_leg(steps=10, warmup=3, preset='vizdoom'):
     for b in batches:
         b['s_h'] = b['s_h'].astype(np.uint8)
     feeds = [tr.model.get_feed_dict(b) for b in batches]
-    for i in range(warmup):
-        tr.train_step(feeds[i % 2])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        tr.train_step(feeds[i % 2])
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / steps
+    with tr.step_stream():
+        for i in range(warmup):
+            tr.train_step(feeds[i % 2])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            tr.train_step(feeds[i % 2])
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
     res = {'workload': 'vizdoom full model, k=%d, %dx%dx%d uint8 frames, T=%d, batch=%d, inputs resident in HBM'
                        % (cfg.k, cfg.h, cfg.w, cfg.depth, cfg.max_demo_len, cfg.batch_size),
            'steps': steps, 'ms_per_step': round(dt * 1e3, 4), 'value': round(cfg.batch_size / dt, 2),
@@ -585,27 +586,29 @@ def main():
     torch.cuda.synchronize()
     log('feeds resident; warmup')
 
-    for i in range(args.warmup):
-        trainer.train_step(feeds[i % len(feeds)])
-    torch.cuda.synchronize()
-    log('warmup done; timing %d steps' % args.steps)
-    dp.barrier()
-    torch.cuda.synchronize()
-    waited0 = trainer.guard.waited
-    t0 = time.perf_counter()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    marks[0].record()
-    for i in range(args.steps):
-        loss = trainer.train_step(feeds[i % len(feeds)])
-        marks[i + 1].record()             # device-side step boundaries (no host sync inside the region)
-    host_enqueue = time.perf_counter() - t0   # host time to ENQUEUE the K steps (device may still be running)
-    # the step guard lets the host run at most StepGuard.DEPTH steps ahead: time it spent WAITING for the device is not
-    # enqueue work
-    host_enqueue -= trainer.guard.waited - waited0
-    torch.cuda.synchronize()
-    dp.barrier()
-    torch.cuda.synchronize()
-    elapsed = dp.max_over_ranks(time.perf_counter() - t0)
+    # (warm-up and timed region on the trainer's high-priority stream, as Trainer.train runs its loop: Trainer.step_stream)
+    with trainer.step_stream():
+        for i in range(args.warmup):
+            trainer.train_step(feeds[i % len(feeds)])
+        torch.cuda.synchronize()
+        log('warmup done; timing %d steps' % args.steps)
+        dp.barrier()
+        torch.cuda.synchronize()
+        waited0 = trainer.guard.waited
+        t0 = time.perf_counter()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        marks[0].record()
+        for i in range(args.steps):
+            loss = trainer.train_step(feeds[i % len(feeds)])
+            marks[i + 1].record()             # device-side step boundaries (no host sync inside the region)
+        host_enqueue = time.perf_counter() - t0   # host time to ENQUEUE the K steps (device may still be running)
+        # the step guard lets the host run at most StepGuard.DEPTH steps ahead: time it spent WAITING for the device is not
+        # enqueue work
+        host_enqueue -= trainer.guard.waited - waited0
+        torch.cuda.synchronize()
+        dp.barrier()
+        torch.cuda.synchronize()
+        elapsed = dp.max_over_ranks(time.perf_counter() - t0)
     final_loss = float(loss.item())
     log('timed region done: %.3f s' % elapsed)
     # a persistent LSTM launch that gave up a hand-off: the guarded step skipped it on the device and the trainer

@@ -103,7 +103,8 @@ def build_variant_library(tag, defines, source='lstm_persist.hip', verbose=False
     build_library()
     out = os.path.join(CSRC, 'libd2p_hip_%s.so' % tag)
     obj = os.path.join(OBJDIR, '%s.%s.%s.o' % (os.path.splitext(source)[0], tag, _stamp()))
-    cmd = [_hipcc()] + FLAGS + ['-D' + d for d in defines] + ['-c', source, '-o', obj]
+    # (an item that starts with '-' is a compiler flag, e.g. -mllvm -amdgpu-igrouplp-exact-solver; anything else a define)
+    cmd = [_hipcc()] + FLAGS + [d if d.startswith('-') else '-D' + d for d in defines] + ['-c', source, '-o', obj]
     if verbose:
         print(' '.join(cmd), flush=True)
     subprocess.run(cmd, cwd=CSRC, check=True)

@@ -38,6 +38,8 @@ SWITCHES = {
     'D2P_TOKEN_PROJECTION': ('1', "token-input decoders project the embedding table; '0' = project the gathered rows "
                              "(the form scheduled sampling takes)",
                              'tests/test_model_gpu.py::test_token_decoders_project_the_table_not_the_rows'),
+    'D2P_PRIORITY_STREAM': ('1', "`with Trainer.step_stream():` (Trainer.train, bench.py) runs the steps on a priority -1 stream of the "
+                            "trainer's own (eager schedule); '0' = on the caller's current stream", 'tests/test_model_gpu.py::test_step_on_the_priority_stream_equals_the_step_on_the_callers_stream'),
     # plumbing
     'D2P_LIB_PATH': (None, 'path of libd2p_hip.so (default: in-tree csrc/)', 'tests/test_abi.py'),
     'D2P_BUILD_JOBS': (None, 'parallel hipcc jobs of build.py', '-'),

@@ -9,6 +9,7 @@ One process per GPU; ``torch.distributed`` (backend "nccl" == RCCL) is used only
 all-reduce.
 """
 import argparse
+import contextlib
 import math
 import os
 import time
@@ -280,6 +281,9 @@ class Trainer(object):
         # beside them only delays their start (one rank, forced RCCL group: 5.20 vs 5.02 ms/step); no
         # multi-GPU box was available to show a gain at N > 1
         self.dp_overlap = flag('D2P_DP_OVERLAP')
+        # the training loop on a priority -1 stream of the trainer's own (step_stream)
+        self.priority_stream = flag('D2P_PRIORITY_STREAM')
+        self._prio = None
         # CUs the recurrences behind the split point are planned for while a collective runs beside them (round 6): a
         # four-wave workgroup -- a collective's kernel -- never becomes resident on a CU that holds a persistent
         # recurrence's workgroup, so a launch over all 256 CUs and the collective only take turns; 7 row domains of 32
@@ -342,6 +346,38 @@ class Trainer(object):
                                         shuffle=is_training, seed=seed + self.dp.rank, frames_dtype=np.uint8)
             return batch
         return dataset
+
+    @contextlib.contextmanager
+    def step_stream(self):
+        """`with trainer.step_stream():` -- the steps enqueued inside run on a HIGH-PRIORITY stream of the trainer's own
+        (D2P_PRIORITY_STREAM=1, the default; eager schedule only; `Trainer.train` and bench.py enter it around their
+        loops): the step's main queue then takes a CU the moment one frees, in front of the side queue's weight-gradient
+        workgroups -- a persistent recurrence needs ALL its workgroups resident before its first hand-off completes, and
+        its last ones entered 17-27 us late behind ~68 us workgroups of the other queue
+        (profiles/r06_launch_stamps_step.log).  2.605 -> 2.582 ms per step at config 2, 5.22 -> 5.18 at config 4; a
+        priority-0 stream of its own gains nothing (profiles/r06_stream_priority_ab*.log).  Ordered with the caller's
+        current stream at entry and exit -- ONCE per loop: the same two waits around every single step cost more than the
+        priority gains (2.60 -> 2.63 ms, profiles/r06_ab_priority_stream_bench.log), so `train_step` itself stays on
+        whatever stream is current."""
+        st = self._priority_stream()
+        cur = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        if st is None or cur == st:
+            yield cur
+            return
+        st.wait_stream(cur)
+        try:
+            with torch.cuda.stream(st):
+                yield st
+        finally:
+            cur.wait_stream(st)
+
+    def _priority_stream(self):
+        if not self.priority_stream or self.use_graph or not torch.cuda.is_available() \
+                or torch.cuda.is_current_stream_capturing():
+            return None
+        if self._prio is None:
+            self._prio = torch.cuda.Stream(priority=-1)
+        return self._prio
 
     def train_step(self, feed):
         """forward + backward + (all-reduce) + clip + Adam on a device-resident feed.
@@ -649,6 +685,13 @@ class Trainer(object):
         if self.dp.rank == 0 and os.path.isdir(self.train_dir):
             from .summary import SummaryWriter
             writer = SummaryWriter(self.train_dir)
+        with self.step_stream():
+            self._train_loop(source, max_steps, writer, ckpt_save_step)
+        self.settle()                          # (up to StepGuard.DEPTH trailing steps may still be skipped ones)
+        if writer is not None:
+            writer.close()
+
+    def _train_loop(self, source, max_steps, writer, ckpt_save_step):
         for s in range(max_steps):
             step, train_summary, loss, output, step_time = \
                 self.run_single_step(source, step=s, is_train=True)
@@ -673,9 +716,6 @@ class Trainer(object):
                 self.check_device_status()
                 if self.dp.rank == 0:
                     self.save_checkpoint(os.path.join(self.train_dir, 'model-%d.npz' % step))
-        self.settle()                          # (up to StepGuard.DEPTH trailing steps may still be skipped ones)
-        if writer is not None:
-            writer.close()
 
     def check_device_status(self):
         """The persistent LSTM kernels give up a hand-off after a bounded wait instead of hanging (a workgroup that was

@@ -1053,6 +1053,44 @@ def test_rccl_single_rank_self_test(monkeypatch):
         assert all(abs(a - b) <= 2e-5 * abs(b) for a, b in zip(other, plain)), (other, plain)
 
 
+def test_step_on_the_priority_stream_equals_the_step_on_the_callers_stream(monkeypatch):
+    """`with trainer.step_stream():` runs the steps on a priority -1 stream of the trainer's own (D2P_PRIORITY_STREAM=1,
+    default; Trainer.train and bench.py enter it around their loops), ordered with the caller's stream at entry and exit:
+    same kernels, same order within each queue -- the same losses and parameters bit for bit as on the caller's stream
+    ('0'), with the caller writing the parameters right before entry and reading them right after exit, unsynchronised."""
+    from demo2program_amd.trainer import Trainer
+    cfg, params, batch = small_case('karel', seed=43)
+
+    def run(on):
+        monkeypatch.setenv('D2P_PRIORITY_STREAM', on)
+        tr = Trainer(cfg, make_train_dir=False)
+        feed = tr.model.get_feed_dict(batch)
+        caller = torch.cuda.current_stream()
+        losses = []
+        for rep in range(2):
+            tr.model.params.load(params)               # on the caller's stream, right in front of the entry
+            tr.adam_step = tr.global_step = 0
+            tr.model.params.m.zero_()
+            tr.model.params.v.zero_()
+            with tr.step_stream() as st:
+                assert torch.cuda.current_stream() == st
+                if on == '1':
+                    assert st != caller and st.priority < 0
+                else:
+                    assert st == caller
+                for i in range(3):
+                    losses.append(tr.train_step(feed))
+            assert torch.cuda.current_stream() == caller
+            after = tr.model.params.flat.clone()       # on the caller's stream, right behind the exit
+        assert tr.settle() == 0
+        return [float(v.item()) for v in losses], after
+
+    la, pa = run('1')
+    lb, pb = run('0')
+    assert la == lb and la[:3] == la[3:]
+    assert torch.equal(pa, pb)
+
+
 def test_tf_checkpoint_export_import_round_trip(tmp_path):
     """tf_checkpoint.export_checkpoint writes parameters + moving statistics under the reference's
     variable names as a TF V2 bundle; Trainer.load_checkpoint / Evaler recognise such a prefix and
