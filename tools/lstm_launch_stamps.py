@@ -151,13 +151,15 @@ def main():
     for b in batches:
         b['s_h'] = b['s_h'].astype(np.uint8)
     feeds = [trainer.model.get_feed_dict(b) for b in batches]
-    for i in range(20):
-        trainer.train_step(feeds[i % 4])
+    with trainer.step_stream():              # (the loop's own high-priority stream, as Trainer.train / bench.py)
+        for i in range(20):
+            trainer.train_step(feeds[i % 4])
     torch.cuda.synchronize()
 
     def steps():
-        for i in range(args.steps):
-            trainer.train_step(feeds[i % 4])
+        with trainer.step_stream():
+            for i in range(args.steps):
+                trainer.train_step(feeds[i % 4])
     Ls = collect(steps, '%d training steps (%s)' % (args.steps, args.preset))
     per = len(Ls) // args.steps
     names = ['fwd encoder 1', 'fwd encoder 2', 'fwd decoders', 'bwd decoders', 'bwd encoder 2', 'bwd encoder 1']
