@@ -136,8 +136,13 @@ if __name__ == '__main__':
     import sys
     if '--stamps' in sys.argv:
         print(build_stamps_library(verbose=True))
-    elif '--variant' in sys.argv:            # --variant TAG DEFINE [DEFINE ...]
+    elif '--variant' in sys.argv:            # [--source gemm.hip] --variant TAG DEFINE|-flag [...]
+        src = 'lstm_persist.hip'
+        if '--source' in sys.argv:
+            j = sys.argv.index('--source')
+            src = sys.argv[j + 1]
+            del sys.argv[j:j + 2]
         i = sys.argv.index('--variant')
-        print(build_variant_library(sys.argv[i + 1], sys.argv[i + 2:], verbose=True))
+        print(build_variant_library(sys.argv[i + 1], sys.argv[i + 2:], source=src, verbose=True))
     else:
         print(build_library(force='--force' in sys.argv, verbose=True))
