@@ -194,6 +194,142 @@ gemm_tn_direct_kernel(const float* __restrict__ A, int lda, const int* __restric
         }
 }
 
+// The same product on a 128 x 64 output tile per wave (round 6): a second 16-byte load of A (rows m0 + 64 ..) feeds
+// sixteen more MFMAs with the SAME 16 bytes of B -- three loads per 32 MFMAs instead of two per 16 (21 flop per byte
+// instead of 16; 128 accumulator registers): 1024 x 2048 x 4480 in 160 us against 178 (117 TFLOP/s).  For outputs of at
+// least 256 such tiles only: a 512 x 2048 output has 128, and with K split between two workgroups per tile (the in-launch
+// ticket combine) the fill / tree / combine of half a K each ate the gain (94.1 against 93.3 us).  The LSTM kernel
+// gradients reach 256 tiles as [X | H]^T dZ (d2p_gemm_f32_tn_rows2).
+template <int KW, bool GATHER>
+__global__ void __launch_bounds__(64 * KW)
+gemm_tn_direct128_kernel(const float* __restrict__ A, int lda, const int* __restrict__ rowsA, const float* __restrict__ B,
+                         int ldb, const int* __restrict__ rowsB, float* __restrict__ C, long ldc, int M, int N, int K, int kps,
+                         int accumulate, float* __restrict__ partial, unsigned* __restrict__ tickets,
+                         const float* __restrict__ A2, int lda2, int msplit) {
+    // (output rows from msplit on come from a SECOND operand A2 -- column m - msplit of its rows -- through the same row
+    //  list: [X | H]^T dZ, the input and the recurrent half of an LSTM's kernel gradient, as one product of 256 tiles;
+    //  msplit is a multiple of 128, or >= M: no second operand)
+    extern __shared__ __attribute__((aligned(16))) float tnd_red[];      // [KW / 2][128 values][64 lanes]
+    const int lane = threadIdx.x & 63, c = lane & 15, kq = lane >> 4;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nbn = (N + 63) / 64;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int m0 = bm * 128, n0 = bn * 64;
+    const int kbeg = ((int)blockIdx.y * KW + w) * kps;
+    const int kend = kbeg + kps < K ? kbeg + kps : K;
+    const int ng = kend > kbeg ? (kend - kbeg) >> 2 : 0;                  // groups of four rows; a multiple of TND_D
+    const bool second = m0 >= msplit;
+    const float* Ab = second ? A2 : A;
+    const int ma = second ? m0 - msplit : m0, Ma = second ? M - msplit : (msplit < M ? msplit : M);
+    lda = second ? lda2 : lda;
+    const float* pa0 = Ab + (ma + 4 * c < Ma - 4 ? ma + 4 * c : Ma - 4);
+    const float* pa1 = Ab + (ma + 64 + 4 * c < Ma - 4 ? ma + 64 + 4 * c : Ma - 4);
+    const float* pb = B + (n0 + 4 * c < N - 4 ? n0 + 4 * c : N - 4);
+
+    tnd_f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = tnd_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (ng > 0) {
+        // (the ring of gemm_tn_direct_kernel with three data loads per slot)
+        constexpr int NL = GATHER ? 5 : 3;
+        tnd_f32x4 av0[TND_D], av1[TND_D], bv[TND_D];
+        int ia[TND_D], ib[TND_D];
+        const int* qia = rowsA + kbeg + kq;
+        const int* qib = rowsB + kbeg + kq;
+        auto load_idx = [&](int d, int g) {
+            const int gc = g < ng ? g : ng - 1;
+            if constexpr (GATHER) {
+                asm volatile("global_load_dword %0, %1, off" : "=v"(ia[d]) : "v"(qia + 4 * gc) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(ib[d]) : "v"(qib + 4 * gc) : "memory");
+            } else {
+                ia[d] = ib[d] = kbeg + 4 * gc + kq;
+            }
+        };
+        auto load_data = [&](int d) {
+            const long oa = (long)ia[d] * lda;
+            const float* qb = pb + (long)ib[d] * ldb;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(av0[d]) : "v"(pa0 + oa) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(av1[d]) : "v"(pa1 + oa) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bv[d]) : "v"(qb) : "memory");
+        };
+#pragma unroll
+        for (int d = 0; d < TND_D; ++d) load_idx(d, d);
+        if constexpr (GATHER) {
+#pragma unroll
+            for (int d = 0; d < TND_D; ++d) asm volatile("s_waitcnt vmcnt(0)" : "+v"(ia[d]), "+v"(ib[d]) :: "memory");
+        }
+#pragma unroll
+        for (int d = 0; d < TND_D; ++d) {
+            load_data(d);
+            load_idx(d, TND_D + d);
+        }
+        for (int g0 = 0; g0 < ng; g0 += TND_D) {
+#pragma unroll
+            for (int d = 0; d < TND_D; ++d) {
+                if constexpr (GATHER)
+                    asm volatile("s_waitcnt vmcnt(%5)" : "+v"(av0[d]), "+v"(av1[d]), "+v"(bv[d]), "+v"(ia[d]), "+v"(ib[d])
+                                 : "n"(NL * (TND_D - 1)) : "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(%3)" : "+v"(av0[d]), "+v"(av1[d]), "+v"(bv[d]) : "n"(NL * (TND_D - 1)) : "memory");
+                const tnd_f32x4 a4 = av0[d], a5 = av1[d], b4 = bv[d];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[i], b4[j], acc[i][j], 0, 0, 0);
+                        acc[4 + i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5[i], b4[j], acc[4 + i][j], 0, 0, 0);
+                    }
+                load_data(d);
+                load_idx(d, g0 + d + 2 * TND_D);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // the KW partial tiles: fixed-order tree through LDS (value e of lane l at [slot][e][l])
+#pragma unroll
+    for (int step = KW / 2; step >= 1; step >>= 1) {
+        if (w >= step && w < 2 * step) {
+            float* dst = tnd_red + (size_t)(w - step) * 8192;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[((i * 4 + j) * 4 + r) * 64 + lane] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (w < step) {
+            const float* src = tnd_red + (size_t)w * 8192;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i][j][r] += src[((i * 4 + j) * 4 + r) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    // lane (c, kq) holds, for MFMA (i, j) and register r: output row m0 + 64 (i / 4) + 4 (4 kq + r) + i % 4, column n0 + 4 c + j
+    const int col = n0 + 4 * c;
+    if (w != 0 || col >= N) return;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = m0 + 64 * (i >> 2) + 16 * kq + 4 * r + (i & 3);
+            if (row < M) {
+                float* dst = C + (long)row * ldc + col;
+                tnd_f32x4 o = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+                if (accumulate) o += *reinterpret_cast<const tnd_f32x4*>(dst);
+                *reinterpret_cast<tnd_f32x4*>(dst) = o;
+            }
+        }
+}
+
 static int g_gemm_tn_direct = 1;          // d2p_gemm_set_option bit 6 switches it off (A/B)
 static int g_rows_by_key = 1;             // d2p_gemm_set_option bit 7 switches it off (A/B, tests)
 
@@ -205,10 +341,40 @@ static int tn_direct_slices(long tiles, int K) {
     while (ks > 1 && K / ks < 512) --ks;
     return ks > 16 ? 16 : ks;
 }
+// the 128 x 64 tile form (gemm_tn_direct128_kernel): outputs of at least 256 tiles of 64 x 64 in whole 128 x 64 tiles, a K
+// long enough for two slices
+static int g_tn_direct_tall = 1;          // d2p_gemm_set_option bit 8 switches it off (A/B, tests)
+static bool tn_direct_tall(int M, int N, int K) {
+    return g_tn_direct_tall && M % 128 == 0 && N % 64 == 0 && (long)(M / 128) * (N / 64) >= 256 && (long)(M / 128) * (N / 64) <= 65535 &&
+           K >= 1024;
+}
 static size_t tn_direct_ws_bytes(int M, int N, int K) {
+    if (tn_direct_tall(M, N, K)) return 0;
     const long tiles = (long)ceil_div(M, 64) * ceil_div(N, 64);
     const int ks = tn_direct_slices(tiles, K);
     return ks > 1 ? (size_t)ks * tiles * 4096 * sizeof(float) : 0;
+}
+template <int KW, bool GATHER>
+static bool tn_direct_tall_launch(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
+                                  const int* rowsB, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
+                                  const float* A2 = nullptr, long lda2 = 0, int msplit = 0x7fffffff) {
+    const long tiles = (long)(M / 128) * (N / 64);
+    const int ks = 1;
+    unsigned* tickets = nullptr;
+    const int kps = (ceil_div(K, KW * ks) + 4 * TND_D - 1) / (4 * TND_D) * (4 * TND_D);
+    constexpr int lds = (KW / 2) * 8192 * (int)sizeof(float);       // 128 KB: never beside a recurrence's workgroup (see below)
+    static bool attr = false;
+    if (!attr) {
+        if (hipFuncSetAttribute((const void*)gemm_tn_direct128_kernel<KW, GATHER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                160 * 1024) != hipSuccess)
+            return false;
+        attr = true;
+    }
+    D2pProfScope prof(st, D2P_PROF_GEMM, 2.0 * M * N * K);
+    hipLaunchKernelGGL((gemm_tn_direct128_kernel<KW, GATHER>), dim3((unsigned)tiles, (unsigned)ks), dim3(64 * KW), lds, st, A,
+                       (int)lda, rowsA, B, (int)ldb, rowsB, C, ldc, M, N, K, kps, accumulate, (float*)ws, tickets, A2, (int)lda2,
+                       msplit);
+    return true;
 }
 // true: launched.  Shapes it takes: whole 16-byte pieces everywhere, K in whole ring rounds, enough tiles (x K slices) to
 // fill the chip
@@ -219,6 +385,9 @@ static bool tn_direct_launch_kw(int M, int N, int K, const float* A, long lda, c
     if (!vec_ok(A, lda) || !vec_ok(B, ldb) || !vec_ok(C, ldc)) return false;
     const long tiles = (long)ceil_div(M, 64) * ceil_div(N, 64);
     if (tiles < 16 || tiles > 65535 || lda > 0x7fffffffL || ldb > 0x7fffffffL) return false;
+    if (KW == 8 && tn_direct_tall(M, N, K) &&
+        tn_direct_tall_launch<KW, GATHER>(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate, ws, ws_bytes, st))
+        return true;
     const int ks = tn_direct_slices(tiles, K);
     if (tiles * ks < 128) return false;
     unsigned* tickets = nullptr;
@@ -264,6 +433,7 @@ extern "C" int d2p_gemm_set_option(int bk32) {
     g_gemm_tn_direct = (bk32 & 64) ? 0 : 1;    // bit 6: the A^T B products on the staged kernel (no register-direct form)
     g_rows_by_key = (bk32 & 128) ? 0 : 1;      // bit 7: the embedding gradient as a one-hot GEMM (no rows_by_key_kernel)
     g_gemm_fold = (bk32 & 32) ? 0 : 1;         // bit 5: split-K combine as a separate launch (round 2's form)
+    g_tn_direct_tall = (bk32 & 256) ? 0 : 1;   // bit 8: the large A^T B products on 64 x 64 tiles (no 128 x 64 form)
     g_gemm_dma_big = (bk32 & 8) ? 1 : 0;       // bit 3 (experiment): large dense GEMMs on the persistent LDS-DMA kernel
     g_gemm_dma_grid = bk32 >> 16;              // bits 16..: persistent grid of the LDS-DMA kernel (0 = automatic)
     return D2P_OK;
@@ -389,6 +559,29 @@ extern "C" int d2p_gemm_f32_tn_rows(int M, int N, int K, const float* A, long ld
     GatherXC bl{B, ldb, N, vec_ok(B, ldb), rowsB};
     EpiDense ep{C, ldc, nullptr, 0, accumulate};
     return d2p_launch_gemm(al, bl, ep, M, N, K, ws, ws_bytes, as_stream(stream), "gemm_tn_rows");
+}
+
+// C[:M0] (+)= A0^T B and C[M0 : M0 + M1] (+)= A1^T B over ONE pair of row lists: the two halves of an LSTM's kernel
+// gradient (dWx = X^T dZ, dWh = H^T dZ; they are adjacent row blocks of the same gradient tensor and read the same dZ rows).
+// 512 + 512 rows x 2048 columns are 256 tiles of 128 x 64: one launch of gemm_tn_direct128_kernel without a K split; any
+// other geometry (or d2p_gemm_set_option bit 8) runs the two products one after the other -- the same values bit for bit
+// (the same K partition between the waves, the same tree).
+extern "C" int d2p_gemm_f32_tn_rows2(int M0, int M1, int N, int K, const float* A0, long lda0, const float* A1, long lda1,
+                                     const int* rowsA, const float* B, long ldb, const int* rowsB, float* C, long ldc,
+                                     int accumulate, void* ws, size_t ws_bytes, d2p_stream_t stream) {
+    D2P_REQUIRE(M0 >= 0 && M1 >= 0, D2P_EINVAL, "gemm_tn_rows2: negative M");
+    if (M0 > 0 && M1 > 0 && N > 0 && K > 0 && g_gemm_tn_direct && M0 % 128 == 0 && tn_direct_tall(M0 + M1, N, K) && K % (4 * TND_D) == 0 && A0 && A1 && B && C && rowsA && rowsB &&
+        vec_ok(A0, lda0) && vec_ok(A1, lda1) && vec_ok(B, ldb) && vec_ok(C, ldc) && lda0 <= 0x7fffffffL && lda1 <= 0x7fffffffL &&
+        ldb <= 0x7fffffffL &&
+        tn_direct_tall_launch<8, true>(M0 + M1, N, K, A0, lda0, rowsA, B, ldb, rowsB, C, ldc, accumulate, ws, ws_bytes,
+                                       as_stream(stream), A1, lda1, M0)) {
+        D2P_LAUNCH_CHECK("gemm_tn_direct128");
+        return D2P_OK;
+    }
+    int rc = M0 > 0 ? d2p_gemm_f32_tn_rows(M0, N, K, A0, lda0, rowsA, B, ldb, rowsB, C, ldc, accumulate, ws, ws_bytes, stream) : D2P_OK;
+    if (rc) return rc;
+    return M1 > 0 ? d2p_gemm_f32_tn_rows(M1, N, K, A1, lda1, rowsA, B, ldb, rowsB, C + (long)M0 * ldc, ldc, accumulate, ws, ws_bytes,
+                                        stream) : D2P_OK;
 }
 
 // ---- column sum (bias gradients): two-stage, deterministic --------------------------

@@ -95,6 +95,14 @@ def gemm_tn_rows(M, N, K, A, lda, rowsA, B, ldb, rowsB, C, ldc, accumulate=False
                               1 if accumulate else 0, ws, wsb, current_stream())
 
 
+def gemm_tn_rows2(M0, M1, N, K, A0, lda0, A1, lda1, rowsA, B, ldb, rowsB, C, ldc, accumulate=False):
+    """C[:M0] (+)= A0[rowsA]^T B[rowsB], C[M0:M0+M1] (+)= A1[rowsA]^T B[rowsB]: the two halves of an LSTM's kernel gradient
+    as one product (d2p_gemm_f32_tn_rows2)."""
+    ws, wsb = SCRATCH.get(max(call.d2p_gemm_ws_bytes(M0 + M1, N, K), call.d2p_gemm_ws_bytes(max(M0, M1), N, K)))
+    call.d2p_gemm_f32_tn_rows2(M0, M1, N, K, _p(A0), lda0, _p(A1), lda1, _p(rowsA), _p(B), ldb, _p(rowsB), _p(C), ldc,
+                               1 if accumulate else 0, ws, wsb, current_stream())
+
+
 def gemm_batched(kind, nb1, nb0, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, bias=None, sbias=(0, 0), act=0,
                  accumulate=False):
     """nb1 x nb0 problems of one shape in one launch; sA / sB / sC / sbias = (stride over the first batch

@@ -194,6 +194,8 @@ class Model(object):
         self.fold_bn = True
         # the decoders' small gradient products grouped into one launch (an attribute, not a switch: tests compare)
         self.grouped_decoder_grads = True
+        # an encoder's two kernel-gradient halves as one product (an attribute, not a switch: tests compare)
+        self.paired_kernel_grads = True
         self.fused_loss = flag('D2P_FUSED_LOSS')
         # timing-only ablation (tools/step_ablation.py -> set_ablation): NEVER from the environment; Trainer.train and
         # Evaler refuse a model that carries one
@@ -1582,6 +1584,20 @@ class Model(object):
         dz_n = dz[:rows] if rows > 0 else dz[:0]
         # the rows inside their sequences, as K lists (d2p_gemm_f32_tn_rows): the others are zeros in dz
         kl = self._ctx.get('klists', {}).get(e.get('rowspace')) if rows > 0 else None
+        # both halves of the kernel gradient as ONE product [X | H]^T dZ (d2p_gemm_f32_tn_rows2: 256 tiles of 128 x 64 at
+        # I = U = 512; the same values as the two products below, bit for bit): the input half reads x through the K list,
+        # the recurrent half the staged states (hbuf[0] = h0) through the same list
+        pair = (part != 'h' and e.get('token_ids') is None and e['x'] is not None and kl is not None and kl[1] and n > 0
+                and e['name'] in self._ctx.get('h0_staged', ()) and e.get('hbuf') is not None and self.paired_kernel_grads)
+        if pair:
+            ev = self._ctx.get('h0_event')
+            if ev is not None and torch.cuda.current_stream() != self._ctx.get('h0_stream'):
+                torch.cuda.current_stream().wait_event(ev)
+            K.gemm_tn_rows2(I, U, 4 * U, kl[1], e['x'], e['x'].stride(0), e['hbuf'].view((T + 1) * M, U), U, kl[0],
+                            dz, 4 * U, kl[0], gk, 4 * U)
+            if not e.get('db_done'):
+                K.colsum(dz_n, out=gb, rows=rows)
+            return
         # dWx = X^T dZ ; db = colsum(dZ)
         if part == 'h':
             pass

@@ -14,7 +14,8 @@ from the environment -- `fused_encoder` (set from D2P_FUSED_ENCODER at construct
 four-launch form; tests/test_model_gpu.py::test_relation_networks_in_four_launches_equal_the_separate_launches) and
 `decoder_skip_past_len` (a training step's decoders stop at a row's length;
 ::test_training_step_decoders_skip_the_steps_past_a_rows_length); likewise `fold_bn` (batch norm folded into the conv launches)
-and `grouped_decoder_grads` (::test_decoder_small_gradient_products_grouped_equal_the_separate_launches).
+and `grouped_decoder_grads` (::test_decoder_small_gradient_products_grouped_equal_the_separate_launches), `paired_kernel_grads`
+(an encoder's two kernel-gradient halves as one product; ::test_encoder_kernel_gradient_halves_as_one_product).
 """
 import os
 

@@ -79,7 +79,8 @@ int d2p_gemm_f32_batched(int kind, int nb1, int nb0, int M, int N, int K, const 
  * K and combine through LDS, picked when the ordinary plan would fill fewer than 128 workgroups);
  * bit 2 keeps the select between global load and LDS store even when K is a multiple of the slab
  * depth (the dense loaders then need none); bit 6: the A^T B products stay on the staged kernel (no
- * gemm_tn_direct_kernel); bit 7: the embedding gradient stays a one-hot GEMM (no rows_by_key_kernel); bits 16 and up:
+ * gemm_tn_direct_kernel); bit 7: the embedding gradient stays a one-hot GEMM (no rows_by_key_kernel); bit 8: the large
+ * A^T B products stay on 64 x 64 tiles (no gemm_tn_direct128_kernel); bits 16 and up:
  * persistent grid size of the LDS-DMA kernel (0 = CUs x resident workgroups per CU). */
 int d2p_gemm_set_option(int bk32);
 /* Tuning experiments only: force the tile (0 64x64, 1 128x128, 2 128x32, 3 256x32, 4 128x64, 5-7 the K-split
@@ -116,6 +117,15 @@ int d2p_gemm_f32_rows(int kind, int M, int N, int K, const float* A, long lda, c
 int d2p_gemm_f32_tn_rows(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
                          const int* rowsB, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes,
                          d2p_stream_t stream);
+/* Round 6: C[:M0] (+)= A0^T B and C[M0 : M0 + M1] (+)= A1^T B through ONE pair of row lists -- the input and the
+ * recurrent half of an LSTM's kernel gradient, [X | H]^T dZ (tf.gradients of the `kernel` variable of
+ * tf.contrib.rnn.BasicLSTMCell, models/model_full.py:243-246: one [I + U, 4U] tensor).  M0 % 128 == 0 and (M0 + M1) x N
+ * = at least 256 tiles of 128 x 64 with K >= 1024: one launch of gemm_tn_direct128_kernel (a 128 x 64 output tile per wave: three
+ * 16-byte loads per 32 MFMAs); anything else, or d2p_gemm_set_option bit 8: the two d2p_gemm_f32_tn_rows products one
+ * after the other, the same values bit for bit.  ws >= d2p_gemm_ws_bytes(M0 + M1, N, K). */
+int d2p_gemm_f32_tn_rows2(int M0, int M1, int N, int K, const float* A0, long lda0, const float* A1, long lda1,
+                          const int* rowsA, const float* B, long ldb, const int* rowsB, float* C, long ldc, int accumulate,
+                          void* ws, size_t ws_bytes, d2p_stream_t stream);
 /* out[c] = sum_r X[r*ld + c]  (bias gradients).  ws >= d2p_colsum_ws_bytes. */
 size_t d2p_colsum_ws_bytes(int rows, int cols);
 int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float* out,

@@ -1376,6 +1376,40 @@ def test_gemm_tn_over_lists_of_k_rows(K, M, N, R, Kn):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M0,M1,N,R,Kn', [(512, 512, 2048, 6720, 4480),      # 256 tiles of 128 x 64: gemm_tn_direct128_kernel
+                                           (128, 384, 4096, 3000, 1024),      # the split inside the first tile row block
+                                           (128, 64, 256, 900, 384),          # any other geometry: two products
+                                           (512, 512, 2048, 6720, 1000)])     # K below the 128 x 64 form's
+def test_gemm_tn_rows2_two_operands_one_product(K, M0, M1, N, R, Kn):
+    """d2p_gemm_f32_tn_rows2: C[:M0] = A0[rows]^T B[rows'], C[M0:] = A1[rows]^T B[rows'] -- the input and the recurrent half of
+    an LSTM's kernel gradient as one product on 128 x 64 tiles.  Bit-identical to the two d2p_gemm_f32_tn_rows products on
+    64 x 64 tiles (same K partition between the waves, same tree), plain and accumulating; and against fp64."""
+    from demo2program_amd.lib import load
+    g = torch.Generator().manual_seed(M0 + N + Kn)
+    lda0 = M0 + 64                                   # (a row stride that is not the width: x is a view of wider rows)
+    A0 = (torch.rand(R, lda0, generator=g) * 2 - 1).cuda()
+    A1 = (torch.rand(R, M1, generator=g) * 2 - 1).cuda()
+    B = (torch.rand(R, N, generator=g) * 2 - 1).cuda()
+    rowsB = (torch.randperm(R - 5, generator=g)[:Kn].sort().values + 5).int().cuda()
+    rowsA = rowsB - 5
+    C0 = (torch.rand(M0 + M1, N, generator=g) * 2 - 1).cuda()
+    ref = torch.cat([A0[:, :M0], A1], 1).double().cpu()[rowsA.long().cpu()].t() @ B.double().cpu()[rowsB.long().cpu()]
+    for acc in (False, True):
+        got = C0.clone()
+        K.gemm_tn_rows2(M0, M1, N, Kn, A0, lda0, A1, M1, rowsA, B, N, rowsB, got, N, accumulate=acc)
+        want = C0.clone()
+        load().d2p_gemm_set_option(256)              # the separate products on 64 x 64 tiles
+        try:
+            K.gemm_tn_rows(M0, N, Kn, A0, lda0, rowsA, B, N, rowsB, want[:M0], N, accumulate=acc)
+            K.gemm_tn_rows(M1, N, Kn, A1, M1, rowsA, B, N, rowsB, want[M0:], N, accumulate=acc)
+        finally:
+            load().d2p_gemm_set_option(0)
+        assert torch.equal(got, want), (acc, float((got - want).abs().max()))
+        full = ref + (C0.double().cpu() if acc else 0)
+        assert (got.double().cpu() - full).abs().max().item() <= 2e-5 * max(1.0, float(Kn) ** 0.5)
+
+
+@pytest.mark.gpu
 def test_loss_backward_of_three_decoders_and_their_projection_in_one_launch(K):
     """d2p_xent_bwd_dhout_multi: dlogits of a softmax ('bvl' labels), a grouped softmax and a grouped sigmoid loss
     AND dhout = dlogits . proj^T of each, in one launch -- dlogits equal to the per-loss kernels' (1e-7), dhout

@@ -1568,6 +1568,28 @@ def test_decoder_small_gradient_products_grouped_equal_the_separate_launches(kin
     assert any('embedding' in n or n.endswith('lstm/kernel') for n in changed), changed      # (the other path really ran)
 
 
+def test_encoder_kernel_gradient_halves_as_one_product():
+    """Round 6: the two encoders' kernel gradients -- dWx = X^T dZ and dWh = H^T dZ, adjacent row blocks of one tensor, the
+    same dZ rows -- as ONE product [X | H]^T dZ (d2p_gemm_f32_tn_rows2, 128 x 64 tiles at U = 512): the same gradients bit for
+    bit as the two products (the oracle parity tests run with the paired form)."""
+    from demo2program_amd.config import make_config
+    from demo2program_amd.models.model_full import Model
+    from demo2program_amd.synthetic import make_batch
+    cfg = make_config('karel', batch_size=8, k=10)                       # U = 512: 256 tiles of 128 x 64
+    batch = make_batch(cfg, seed=13)
+    res = []
+    for paired in (False, True):
+        m = Model(cfg, seed=5)
+        m.paired_kernel_grads = paired
+        feed = m.get_feed_dict(batch)
+        loss = m.forward(feed, defer_loss=True)
+        m.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss.item()), m.params.grad.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1])
+
+
 def test_training_step_decoders_skip_the_steps_past_a_rows_length():
     """Round 5: in a training step (deferred logits) the action / perception decoders' forward recurrences run
     length-sorted and do not compute a row past its own length -- nothing reads those outputs there (the loss and its

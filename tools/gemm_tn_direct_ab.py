@@ -31,8 +31,8 @@ def main():
     lib = load()
     g = torch.Generator().manual_seed(1)
     R = 6720
-    for (M, N, Kn) in ((512, 2048, 4480), (512, 2048, 6400), (560, 2048, 4480), (48, 2048, 4480), (512, 2048, 1600),
-                       (512, 512, 3200), (1024, 2048, 4480), (500, 2048, 4480)):
+    for (M, N, Kn) in ((512, 2048, 4480), (512, 2048, 4448), (512, 2048, 4128), (512, 2048, 6400), (560, 2048, 4480), (48, 2048, 4480),
+                       (512, 2048, 1600), (512, 512, 3200), (1024, 2048, 4480), (256, 2048, 4480), (500, 2048, 4480)):
         lda = 1024 if M <= 1024 else M
         A = (torch.rand(R, lda, generator=g) - 0.5).cuda()
         B = (torch.rand(R, N, generator=g) - 0.5).cuda()
@@ -40,7 +40,7 @@ def main():
         rows2 = torch.randperm(R, generator=g)[:Kn].sort().values.int().cuda()
         ref = (A[rows.long(), :M].double().t() @ B[rows2.long()].double())
         line = '%4d x %4d x %4d:' % (M, N, Kn)
-        for opt, name in ((64, 'staged'), (0, 'direct')):
+        for opt, name in ((64, 'staged'), (256, 'direct 64x64'), (0, 'direct')):
             lib.d2p_gemm_set_option(opt)
             C = torch.full((M, N), float('nan'), device='cuda')
             K.gemm_tn_rows(M, N, Kn, A, lda, rows, B, N, rows2, C, N)
