@@ -1587,11 +1587,13 @@ class Model(object):
         # both halves of the kernel gradient as ONE product [X | H]^T dZ (d2p_gemm_f32_tn_rows2: 256 tiles of 128 x 64 at
         # I = U = 512; the same values as the two products below, bit for bit): the input half reads x through the K list,
         # the recurrent half the staged states (hbuf[0] = h0) through the same list
+        # (a recurrence without an initial state: hbuf[0] is the zero slab nothing ever writes -- its rows add exact zeros)
         pair = (part != 'h' and e.get('token_ids') is None and e['x'] is not None and kl is not None and kl[1] and n > 0
-                and e['name'] in self._ctx.get('h0_staged', ()) and e.get('hbuf') is not None and self.paired_kernel_grads)
+                and (e['name'] in self._ctx.get('h0_staged', ()) or e['h0'] is None) and e.get('hbuf') is not None
+                and self.paired_kernel_grads)
         if pair:
             ev = self._ctx.get('h0_event')
-            if ev is not None and torch.cuda.current_stream() != self._ctx.get('h0_stream'):
+            if e['h0'] is not None and ev is not None and torch.cuda.current_stream() != self._ctx.get('h0_stream'):
                 torch.cuda.current_stream().wait_event(ev)
             K.gemm_tn_rows2(I, U, 4 * U, kl[1], e['x'], e['x'].stride(0), e['hbuf'].view((T + 1) * M, U), U, kl[0],
                             dz, 4 * U, kl[0], gk, 4 * U)

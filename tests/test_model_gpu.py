@@ -1585,9 +1585,17 @@ def test_encoder_kernel_gradient_halves_as_one_product():
         loss = m.forward(feed, defer_loss=True)
         m.backward()
         torch.cuda.synchronize()
-        res.append((float(loss.item()), m.params.grad.clone()))
+        res.append((float(loss.item()), m.params.grad.clone(), m.params.to_numpy('g')))
     assert res[0][0] == res[1][0]
-    assert torch.equal(res[0][1], res[1][1])
+    g0, g1 = res[0][2], res[1][2]
+    for n in g0:
+        if n == 'demo_lstm/kernel':
+            # the first encoder has no initial state: its recurrent half reads the zero slab hbuf[0] through the input
+            # half's row list instead of a list without step 0 -- exact zeros more, another K partition between the waves
+            assert np.abs(g0[n] - g1[n]).max() <= 2e-5 * np.abs(g0[n]).max(), n
+            assert not np.array_equal(g0[n], g1[n]), n          # (the paired form really ran)
+        else:
+            assert np.array_equal(g0[n], g1[n]), n
 
 
 def test_training_step_decoders_skip_the_steps_past_a_rows_length():
