@@ -145,9 +145,10 @@ def roofline_leg(trainer, feeds, steps=2, keep_side=False):
     #  launches take BESIDE the other stream's work; the reported roofline always uses one stream)
     if not keep_side:
         trainer.model.use_side_stream = False
-    for i in range(steps):
-        trainer.train_step(feeds[i % len(feeds)])
-    torch.cuda.synchronize()
+    with trainer.step_stream():          # (the stream the timed region ran on)
+        for i in range(steps):
+            trainer.train_step(feeds[i % len(feeds)])
+        torch.cuda.synchronize()
     rows = []
     for fam, (name, bound, group) in PROF_FAMILIES.items():
         for tag in (0, 1):

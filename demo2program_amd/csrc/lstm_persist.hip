@@ -2391,15 +2391,17 @@ extern "C" int d2p_lstm_persist_wide_local_wgs(int reset) {
     }
     return (int)(v & 0x7fffffffu);
 }
-// us per step of a row domain with nrs phases (measured, tools/check_lstm_wide.py --sweep and the traces: a single
-// phase is the bare hand-off chain; two phases poll for their own rows with nothing fetched ahead; from three the next
-// rows are requested ahead; from defer_from the gate math rides in the next phase's chain), scaled by the two knobs
+// us per step of a row domain with nrs phases, as measured IN THE TRAINING STEP (tools/lstm_launch_stamps.py, round 6: the
+// tick loops of every domain of the three forward launches; a single phase is the bare hand-off chain, two phases poll for
+// their own rows with nothing fetched ahead, from three the next rows are requested ahead, from defer_from the gate math
+// rides in the next phase's chain), scaled by the two knobs.  Rounds 4-5 planned with a stand-alone sweep's 4.6 / 7.0 /
+// 2.83 n / 2.65 n: 8 % low for one phase, 13 % high for two -- the cuts of the sorted launches follow the table
+// (2.585 -> 2.573 ms per step, profiles/r06_ab_fwd_planner.log).
 static double psw_step_cost(int nrs) {
     const double ph = g_psw_cost_ph / 2.7, fl = g_psw_cost_fl / 4.6;
-    if (nrs <= 1) return 4.6 * fl;
-    if (nrs == 2) return 7.0 * ph;
-    if (nrs < g_psw_defer_from) return 2.83 * nrs * ph;
-    return 2.65 * nrs * ph;
+    static const double tab[PS_NRS_MAX + 1] = {5.0, 5.0, 6.2, 7.9, 10.6, 12.4, 14.7, 17.2, 19.6};
+    if (nrs <= 1) return tab[1] * fl;
+    return tab[nrs > PS_NRS_MAX ? PS_NRS_MAX : nrs] * ph * (nrs > PS_NRS_MAX ? (double)nrs / PS_NRS_MAX : 1.0);
 }
 static double psw_cost(int trs, int T, int RT) { return T * psw_step_cost((trs + RT - 1) / RT); }
 // row domains of a launch with n sequences: all of the chip's (num_cus / column tiles) domains, dealt out so that the
