@@ -1587,17 +1587,11 @@ class Model(object):
         # both halves of the kernel gradient as ONE product [X | H]^T dZ (d2p_gemm_f32_tn_rows2: 256 tiles of 128 x 64 at
         # I = U = 512; the same values as the two products below, bit for bit): the input half reads x through the K list,
         # the recurrent half the staged states (hbuf[0] = h0) through the same list
-        # (a recurrence without an initial state: hbuf[0] is the zero slab nothing ever writes -- its rows add exact zeros;
-        #  taken only where the pair really is one launch of 128 x 64 tiles, d2p_gemm_f32_tn_rows2's geometry: as two
-        #  products the recurrent half would multiply M more rows than its own list has)
-        one_launch = (I % 128 == 0 and U % 128 == 0 and ((I + U) // 128) * (4 * U // 64) >= 256 and kl is not None
-                      and kl[1] >= 1024 and kl[1] % 16 == 0)
         pair = (part != 'h' and e.get('token_ids') is None and e['x'] is not None and kl is not None and kl[1] and n > 0
-                and (e['name'] in self._ctx.get('h0_staged', ()) or (e['h0'] is None and one_launch))
-                and e.get('hbuf') is not None and self.paired_kernel_grads)
+                and e['name'] in self._ctx.get('h0_staged', ()) and e.get('hbuf') is not None and self.paired_kernel_grads)
         if pair:
             ev = self._ctx.get('h0_event')
-            if e['h0'] is not None and ev is not None and torch.cuda.current_stream() != self._ctx.get('h0_stream'):
+            if ev is not None and torch.cuda.current_stream() != self._ctx.get('h0_stream'):
                 torch.cuda.current_stream().wait_event(ev)
             K.gemm_tn_rows2(I, U, 4 * U, kl[1], e['x'], e['x'].stride(0), e['hbuf'].view((T + 1) * M, U), U, kl[0],
                             dz, 4 * U, kl[0], gk, 4 * U)
