@@ -59,12 +59,13 @@ def main():
     dp.broadcast_params(tr.model.params.flat)
     feeds = [tr.model.get_feed_dict(b) for b in rank_batches(cfg, rank)]
     losses = []
-    for step in range(N_STEPS):
-        if case == 'inject' and rank == 1 and step == 1:
-            torch.cuda.synchronize()
-            K.lstm_persist_inject_error()
-        losses.append(tr.train_step(feeds[step]))
-    failures = tr.settle()
+    with tr.step_stream():                     # (the loop on the trainer's high-priority stream, as Trainer.train runs it)
+        for step in range(N_STEPS):
+            if case == 'inject' and rank == 1 and step == 1:
+                torch.cuda.synchronize()
+                K.lstm_persist_inject_error()
+            losses.append(tr.train_step(feeds[step]))
+        failures = tr.settle()
     torch.cuda.synchronize()
     P = tr.model.params
     np.savez(os.path.join(outdir, 'rank%d.npz' % rank), flat=P.flat.cpu().numpy(), m=P.m.cpu().numpy(),
