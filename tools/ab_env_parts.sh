@@ -1,3 +1,6 @@
+#!/bin/bash
+# As tools/ab_env.sh, printing the instrumented pass's recurrent forward / backward ms per step as well:
+# tools/ab_env_parts.sh VAR A B [rounds] [steps]
 VAR=$1; A=$2; B=$3; ROUNDS=${4:-2}; STEPS=${5:-300}
 for r in $(seq 1 $ROUNDS); do
   for v in "$A" "$B"; do
