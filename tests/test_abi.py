@@ -35,6 +35,18 @@ def test_library_loads_and_exports_everything(d2p_lib):
     assert d2p_lib.d2p_last_error() is not None
 
 
+def test_product_library_carries_no_diagnostic_stamps(d2p_lib):
+    """tools/lstm_launch_stamps.py runs against a DIAGNOSTIC build of lstm_persist.hip (-DD2P_PS_STAMPS,
+    build.build_stamps_library): its two entry points exist there only -- the product library exports neither, and the
+    header declares neither."""
+    for name in ('d2p_lstm_persist_set_stamps', 'd2p_lstm_persist_stamp_launches'):
+        assert not hasattr(d2p_lib, name), name
+        assert name not in _header_prototypes()
+    src = open(os.path.join(ROOT, 'demo2program_amd', 'csrc', 'lstm_persist.hip')).read()
+    body = src[src.index('#ifdef D2P_PS_STAMPS'):src.index('#else   // (every macro expands to NOTHING')]
+    assert 'd2p_lstm_persist_set_stamps' in body and src.count('d2p_lstm_persist_set_stamps') == 1
+
+
 def test_workspace_queries_need_no_gpu(d2p_lib):
     assert d2p_lib.d2p_lstm_ws_bytes(320, 512) >= 3 * 320 * 512 * 4
     assert d2p_lib.d2p_gemm_ws_bytes(144, 16, 102400) > 0      # conv1 wgrad needs split-K
