@@ -205,10 +205,13 @@ __global__ void __launch_bounds__(64 * KW)
 gemm_tn_direct128_kernel(const float* __restrict__ A, int lda, const int* __restrict__ rowsA, const float* __restrict__ B,
                          int ldb, const int* __restrict__ rowsB, float* __restrict__ C, long ldc, int M, int N, int K, int kps,
                          int accumulate, float* __restrict__ partial, unsigned* __restrict__ tickets,
-                         const float* __restrict__ A2, int lda2, int msplit) {
+                         const float* __restrict__ A2, int lda2, int msplit, const float* __restrict__ B2, int ldb2,
+                         float* __restrict__ C2) {
     // (output rows from msplit on come from a SECOND operand A2 -- column m - msplit of its rows -- through the same row
     //  list: [X | H]^T dZ, the input and the recurrent half of an LSTM's kernel gradient, as one product of 256 tiles;
-    //  msplit is a multiple of 128, or >= M: no second operand)
+    //  msplit is a multiple of 128, or >= M: no second operand.  With B2 / C2 the rows from msplit on are a SECOND,
+    //  independent product A2^T B2 -> C2 of the same K through the same row lists: two 512 x 2048 kernel gradients -- the
+    //  action and the perception decoder's recurrent halves -- fill the chip as 2 x 128 tiles)
     extern __shared__ __attribute__((aligned(16))) float tnd_red[];      // [KW / 2][128 values][64 lanes]
     const int lane = threadIdx.x & 63, c = lane & 15, kq = lane >> 4;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -222,6 +225,10 @@ gemm_tn_direct128_kernel(const float* __restrict__ A, int lda, const int* __rest
     const float* Ab = second ? A2 : A;
     const int ma = second ? m0 - msplit : m0, Ma = second ? M - msplit : (msplit < M ? msplit : M);
     lda = second ? lda2 : lda;
+    if (second && B2) { B = B2; ldb = ldb2; }
+    // output rows: of C from m0 on, or (a second product) of C2 from ma on
+    float* Co = (second && C2) ? C2 : C;
+    const int mo = (second && C2) ? ma : m0, Mo = (second && C2) ? Ma : M;
     const float* pa0 = Ab + (ma + 4 * c < Ma - 4 ? ma + 4 * c : Ma - 4);
     const float* pa1 = Ab + (ma + 64 + 4 * c < Ma - 4 ? ma + 64 + 4 * c : Ma - 4);
     const float* pb = B + (n0 + 4 * c < N - 4 ? n0 + 4 * c : N - 4);
@@ -320,9 +327,9 @@ gemm_tn_direct128_kernel(const float* __restrict__ A, int lda, const int* __rest
     for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int row = m0 + 64 * (i >> 2) + 16 * kq + 4 * r + (i & 3);
-            if (row < M) {
-                float* dst = C + (long)row * ldc + col;
+            const int row = mo + 64 * (i >> 2) + 16 * kq + 4 * r + (i & 3);
+            if (row < Mo) {
+                float* dst = Co + (long)row * ldc + col;
                 tnd_f32x4 o = {acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
                 if (accumulate) o += *reinterpret_cast<const tnd_f32x4*>(dst);
                 *reinterpret_cast<tnd_f32x4*>(dst) = o;
@@ -357,7 +364,8 @@ static size_t tn_direct_ws_bytes(int M, int N, int K) {
 template <int KW, bool GATHER>
 static bool tn_direct_tall_launch(int M, int N, int K, const float* A, long lda, const int* rowsA, const float* B, long ldb,
                                   const int* rowsB, float* C, long ldc, int accumulate, void* ws, size_t ws_bytes, hipStream_t st,
-                                  const float* A2 = nullptr, long lda2 = 0, int msplit = 0x7fffffff) {
+                                  const float* A2 = nullptr, long lda2 = 0, int msplit = 0x7fffffff, const float* B2 = nullptr,
+                                  long ldb2 = 0, float* C2 = nullptr) {
     const long tiles = (long)(M / 128) * (N / 64);
     const int ks = 1;
     unsigned* tickets = nullptr;
@@ -373,7 +381,7 @@ static bool tn_direct_tall_launch(int M, int N, int K, const float* A, long lda,
     D2pProfScope prof(st, D2P_PROF_GEMM, 2.0 * M * N * K);
     hipLaunchKernelGGL((gemm_tn_direct128_kernel<KW, GATHER>), dim3((unsigned)tiles, (unsigned)ks), dim3(64 * KW), lds, st, A,
                        (int)lda, rowsA, B, (int)ldb, rowsB, C, ldc, M, N, K, kps, accumulate, (float*)ws, tickets, A2, (int)lda2,
-                       msplit);
+                       msplit, B2, (int)ldb2, C2);
     return true;
 }
 // true: launched.  Shapes it takes: whole 16-byte pieces everywhere, K in whole ring rounds, enough tiles (x K slices) to
@@ -582,6 +590,29 @@ extern "C" int d2p_gemm_f32_tn_rows2(int M0, int M1, int N, int K, const float* 
     if (rc) return rc;
     return M1 > 0 ? d2p_gemm_f32_tn_rows(M1, N, K, A1, lda1, rowsA, B, ldb, rowsB, C + (long)M0 * ldc, ldc, accumulate, ws, ws_bytes,
                                         stream) : D2P_OK;
+}
+
+// Two independent products of ONE shape through one pair of row lists, C0 (+)= A0^T B0 and C1 (+)= A1^T B1 (the recurrent
+// halves of the action and the perception decoder's kernel gradients: 512 x 2048 each, the same rows of their own dZ):
+// 2 x 128 tiles of 128 x 64 in one launch of gemm_tn_direct128_kernel; any other geometry, or d2p_gemm_set_option bit 8:
+// one after the other, the same values bit for bit.
+extern "C" int d2p_gemm_f32_tn_rows_x2(int M, int N, int K, const float* A0, long lda0, const float* B0, long ldb0, float* C0,
+                                       const float* A1, long lda1, const float* B1, long ldb1, float* C1, long ldc,
+                                       const int* rowsA, const int* rowsB, int accumulate, void* ws, size_t ws_bytes,
+                                       d2p_stream_t stream) {
+    D2P_REQUIRE(M >= 0, D2P_EINVAL, "gemm_tn_rows_x2: negative M");
+    if (M > 0 && N > 0 && K > 0 && g_gemm_tn_direct && M % 128 == 0 && tn_direct_tall(2 * M, N, K) && K % (4 * TND_D) == 0 &&
+        A0 && A1 && B0 && B1 && C0 && C1 && rowsA && rowsB && vec_ok(A0, lda0) && vec_ok(A1, lda1) && vec_ok(B0, ldb0) &&
+        vec_ok(B1, ldb1) && vec_ok(C0, ldc) && vec_ok(C1, ldc) && lda0 <= 0x7fffffffL && lda1 <= 0x7fffffffL &&
+        ldb0 <= 0x7fffffffL && ldb1 <= 0x7fffffffL &&
+        tn_direct_tall_launch<8, true>(2 * M, N, K, A0, lda0, rowsA, B0, ldb0, rowsB, C0, ldc, accumulate, ws, ws_bytes,
+                                       as_stream(stream), A1, lda1, M, B1, ldb1, C1)) {
+        D2P_LAUNCH_CHECK("gemm_tn_direct128");
+        return D2P_OK;
+    }
+    int rc = d2p_gemm_f32_tn_rows(M, N, K, A0, lda0, rowsA, B0, ldb0, rowsB, C0, ldc, accumulate, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return d2p_gemm_f32_tn_rows(M, N, K, A1, lda1, rowsA, B1, ldb1, rowsB, C1, ldc, accumulate, ws, ws_bytes, stream);
 }
 
 // ---- column sum (bias gradients): two-stage, deterministic --------------------------

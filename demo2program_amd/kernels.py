@@ -103,6 +103,14 @@ def gemm_tn_rows2(M0, M1, N, K, A0, lda0, A1, lda1, rowsA, B, ldb, rowsB, C, ldc
                                1 if accumulate else 0, ws, wsb, current_stream())
 
 
+def gemm_tn_rows_x2(M, N, K, A0, lda0, B0, ldb0, C0, A1, lda1, B1, ldb1, C1, ldc, rowsA, rowsB, accumulate=False):
+    """C0 (+)= A0[rowsA]^T B0[rowsB] and C1 (+)= A1[rowsA]^T B1[rowsB]: two products of one shape in one launch
+    (d2p_gemm_f32_tn_rows_x2)."""
+    ws, wsb = SCRATCH.get(call.d2p_gemm_ws_bytes(M, N, K))
+    call.d2p_gemm_f32_tn_rows_x2(M, N, K, _p(A0), lda0, _p(B0), ldb0, _p(C0), _p(A1), lda1, _p(B1), ldb1, _p(C1), ldc,
+                                 _p(rowsA), _p(rowsB), 1 if accumulate else 0, ws, wsb, current_stream())
+
+
 def gemm_batched(kind, nb1, nb0, M, N, K, A, lda, sA, B, ldb, sB, C, ldc, sC, bias=None, sbias=(0, 0), act=0,
                  accumulate=False):
     """nb1 x nb0 problems of one shape in one launch; sA / sB / sC / sbias = (stride over the first batch

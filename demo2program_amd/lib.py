@@ -26,6 +26,8 @@ SIGNATURES = {
     'd2p_gemm_set_option': (c_int, [c_int]),
     'd2p_gemm_f32_rows': (c_int, [c_int, c_int, c_int, c_int, P, c_long, P, c_long, P, c_long, P, P, P, c_size_t, S]),
     'd2p_gemm_f32_tn_rows': (c_int, [c_int, c_int, c_int, P, c_long, P, P, c_long, P, P, c_long, c_int, P, c_size_t, S]),
+    'd2p_gemm_f32_tn_rows_x2': (c_int, [c_int, c_int, c_int, P, c_long, P, c_long, P, P, c_long, P, c_long, P, c_long, P, P, c_int,
+                                P, c_size_t, S]),
     'd2p_gemm_f32_tn_rows2': (c_int, [c_int, c_int, c_int, c_int, P, c_long, P, c_long, P, P, c_long, P, P, c_long, c_int, P,
                               c_size_t, S]),
     'd2p_gemm_f32_batched': (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, P, c_long, c_long, c_long, P, c_long, c_long,

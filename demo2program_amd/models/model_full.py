@@ -1549,8 +1549,35 @@ class Model(object):
         K.per_fc_bn_bwd(k, P, c.batch_size * c.max_demo_len, p['per/fc/W'], p['per/fc/b'], p['per/fc/gamma'],
                         ctx['pe_mean'], ctx['pe_rstd'], self._bufs['per/Q'], feed['per_gram'], g['per/fc/W'], g['per/fc/b'],
                         g['per/fc/gamma'], g['per/fc/beta'])
-        for e, dz in ((dq, dz_of[2]), (da, dz_of[1]), (dp, dz_of[0])):
-            self._lstm_bwd_weights(e, dz, part='h')
+        # the recurrent halves: the action and the perception decoder's as ONE launch of two products (same shape, same
+        # row lists, their own states and dz: d2p_gemm_f32_tn_rows_x2), the program decoder's on its own
+        if not self._lstm_bwd_weights_h_pair(dq, dz_of[2], da, dz_of[1]):
+            self._lstm_bwd_weights(dq, dz_of[2], part='h')
+            self._lstm_bwd_weights(da, dz_of[1], part='h')
+        self._lstm_bwd_weights(dp, dz_of[0], part='h')
+        return True
+
+    def _lstm_bwd_weights_h_pair(self, e0, dz0, e1, dz1):
+        """part='h' of _lstm_bwd_weights for two recurrences of one geometry at once; False: not taken (nothing written)."""
+        if not self.paired_kernel_grads or self._abl('wgrad') or self._abl('wgrad:' + e0['name']) or self._abl('wgrad:' + e1['name']):
+            return False
+        staged = self._ctx.get('h0_staged', ())
+        kl = self._ctx.get('klists', {}).get(e0.get('rowspace'))
+        same = all(e0[k] == e1[k] for k in ('M', 'T', 'n', 'I')) and e0.get('rowspace') == e1.get('rowspace')
+        if not (same and kl is not None and kl[1] and e0['n'] > 0 and e0['name'] in staged and e1['name'] in staged
+                and e0.get('hbuf') is not None and e1.get('hbuf') is not None):
+            return False
+        g = self.params.g
+        U, M, T, n, I = self.num_lstm_cell_units, e0['M'], e0['T'], e0['n'], e0['I']
+        rows = n * M
+        for e, dz in ((e0, dz0), (e1, dz1)):
+            if not e.get('db_done'):
+                K.colsum(dz[:rows], out=g[e['name'] + '/bias'], rows=rows)
+        ev = self._ctx.get('h0_event')
+        if ev is not None and torch.cuda.current_stream() != self._ctx.get('h0_stream'):
+            torch.cuda.current_stream().wait_event(ev)
+        K.gemm_tn_rows_x2(U, 4 * U, kl[1], e0['hbuf'].view((T + 1) * M, U), U, dz0, 4 * U, g[e0['name'] + '/kernel'][I:],
+                          e1['hbuf'].view((T + 1) * M, U), U, dz1, 4 * U, g[e1['name'] + '/kernel'][I:], 4 * U, kl[0], kl[0])
         return True
 
     def _token_decoder_grads(self, e, dz, ids, rows):

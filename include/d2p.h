@@ -126,6 +126,14 @@ int d2p_gemm_f32_tn_rows(int M, int N, int K, const float* A, long lda, const in
 int d2p_gemm_f32_tn_rows2(int M0, int M1, int N, int K, const float* A0, long lda0, const float* A1, long lda1,
                           const int* rowsA, const float* B, long ldb, const int* rowsB, float* C, long ldc, int accumulate,
                           void* ws, size_t ws_bytes, d2p_stream_t stream);
+/* Round 6: two independent products of one shape through one pair of row lists, C0 (+)= A0^T B0 and C1 (+)= A1^T B1 -- the
+ * recurrent halves of the action and the perception decoder's kernel gradients (models/model_full.py:530-599: one decoder
+ * graph per demonstration index, all of them sharing these weights).  2 x (M / 128) x (N / 64) >= 256 tiles with M % 128 == 0,
+ * K >= 1024: one launch of gemm_tn_direct128_kernel; anything else, or d2p_gemm_set_option bit 8: one after the other, the
+ * same values bit for bit.  ws >= d2p_gemm_ws_bytes(M, N, K). */
+int d2p_gemm_f32_tn_rows_x2(int M, int N, int K, const float* A0, long lda0, const float* B0, long ldb0, float* C0,
+                            const float* A1, long lda1, const float* B1, long ldb1, float* C1, long ldc, const int* rowsA,
+                            const int* rowsB, int accumulate, void* ws, size_t ws_bytes, d2p_stream_t stream);
 /* out[c] = sum_r X[r*ld + c]  (bias gradients).  ws >= d2p_colsum_ws_bytes. */
 size_t d2p_colsum_ws_bytes(int rows, int cols);
 int d2p_colsum_f32(int rows, int cols, const float* X, long ld, float* out,

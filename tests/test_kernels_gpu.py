@@ -1410,6 +1410,37 @@ def test_gemm_tn_rows2_two_operands_one_product(K, M0, M1, N, R, Kn):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize('M,N,R,Kn', [(512, 2048, 6720, 4480),       # 2 x 128 tiles of 128 x 64: one launch
+                                       (128, 256, 900, 384)])         # any other geometry: one after the other
+def test_gemm_tn_rows_x2_two_products_one_launch(K, M, N, R, Kn):
+    """d2p_gemm_f32_tn_rows_x2: C0 = A0[rows]^T B0[rows'], C1 = A1[rows]^T B1[rows'] -- two independent products of one shape
+    through one pair of row lists (the action and the perception decoder's recurrent kernel-gradient halves) in ONE launch of
+    the 128 x 64-tile kernel.  Bit-identical to two d2p_gemm_f32_tn_rows products on 64 x 64 tiles, plain and accumulating."""
+    from demo2program_amd.lib import load
+    g = torch.Generator().manual_seed(M + N + Kn + 1)
+    A = [(torch.rand(R, M, generator=g) * 2 - 1).cuda() for _ in range(2)]
+    B = [(torch.rand(R, N, generator=g) * 2 - 1).cuda() for _ in range(2)]
+    rowsB = (torch.randperm(R - 5, generator=g)[:Kn].sort().values + 5).int().cuda()
+    rowsA = rowsB - 5
+    C0 = [(torch.rand(M, N, generator=g) * 2 - 1).cuda() for _ in range(2)]
+    for acc in (False, True):
+        got = [c.clone() for c in C0]
+        K.gemm_tn_rows_x2(M, N, Kn, A[0], M, B[0], N, got[0], A[1], M, B[1], N, got[1], N, rowsA, rowsB, accumulate=acc)
+        want = [c.clone() for c in C0]
+        load().d2p_gemm_set_option(256)
+        try:
+            for i in range(2):
+                K.gemm_tn_rows(M, N, Kn, A[i], M, rowsA, B[i], N, rowsB, want[i], N, accumulate=acc)
+        finally:
+            load().d2p_gemm_set_option(0)
+        for i in range(2):
+            assert torch.equal(got[i], want[i]), (acc, i, float((got[i] - want[i]).abs().max()))
+            ref = A[i].double().cpu()[rowsA.long().cpu()].t() @ B[i].double().cpu()[rowsB.long().cpu()]
+            full = ref + (C0[i].double().cpu() if acc else 0)
+            assert (got[i].double().cpu() - full).abs().max().item() <= 2e-5 * max(1.0, float(Kn) ** 0.5)
+
+
+@pytest.mark.gpu
 def test_loss_backward_of_three_decoders_and_their_projection_in_one_launch(K):
     """d2p_xent_bwd_dhout_multi: dlogits of a softmax ('bvl' labels), a grouped softmax and a grouped sigmoid loss
     AND dhout = dlogits . proj^T of each, in one launch -- dlogits equal to the per-loss kernels' (1e-7), dhout

@@ -1572,7 +1572,8 @@ def test_encoder_kernel_gradient_halves_as_one_product(monkeypatch):
     """Round 6: the second encoder's kernel gradient -- dWx = X^T dZ and dWh = H^T dZ, adjacent row blocks of one tensor, the
     same dZ rows through the same list (its states are staged behind their initial state) -- as ONE product [X | H]^T dZ
     (d2p_gemm_f32_tn_rows2, 128 x 64 tiles at I = U = 512): the same gradients bit for bit as the two products (the oracle
-    parity tests run with the paired form).  (The first encoder's input half is 48 / 432 rows wide: two products.)"""
+    parity tests run with the paired form).  (The first encoder's input half is 48 / 432 rows wide: two products.)  Likewise the
+    action and the perception decoder's recurrent halves: two products of one shape in one launch (d2p_gemm_f32_tn_rows_x2)."""
     from demo2program_amd.config import make_config
     from demo2program_amd.models.model_full import Model
     from demo2program_amd.synthetic import make_batch
@@ -1580,12 +1581,17 @@ def test_encoder_kernel_gradient_halves_as_one_product(monkeypatch):
     batch = make_batch(cfg, seed=13)
     from demo2program_amd import kernels as K
     res, calls = [], []
-    orig = K.gemm_tn_rows2
+    orig, orig_x2 = K.gemm_tn_rows2, K.gemm_tn_rows_x2
 
     def counted(*a, **kw):
         calls[-1] += 1
         return orig(*a, **kw)
+
+    def counted_x2(*a, **kw):
+        calls[-1] += 10
+        return orig_x2(*a, **kw)
     monkeypatch.setattr(K, 'gemm_tn_rows2', counted)
+    monkeypatch.setattr(K, 'gemm_tn_rows_x2', counted_x2)
     for paired in (False, True):
         m = Model(cfg, seed=5)
         m.paired_kernel_grads = paired
@@ -1595,7 +1601,7 @@ def test_encoder_kernel_gradient_halves_as_one_product(monkeypatch):
         m.backward()
         torch.cuda.synchronize()
         res.append((float(loss.item()), m.params.grad.clone()))
-    assert calls == [0, 1]                                               # (the paired form really ran: the second encoder)
+    assert calls == [0, 11]          # (the paired forms really ran: the second encoder's halves, the two decoders' recurrent halves)
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1])
 
