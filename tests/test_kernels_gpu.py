@@ -1379,7 +1379,8 @@ def test_gemm_tn_over_lists_of_k_rows(K, M, N, R, Kn):
 @pytest.mark.parametrize('M0,M1,N,R,Kn', [(512, 512, 2048, 6720, 4480),      # 256 tiles of 128 x 64: gemm_tn_direct128_kernel
                                            (128, 384, 4096, 3000, 1024),      # the split inside the first tile row block
                                            (128, 64, 256, 900, 384),          # any other geometry: two products
-                                           (512, 512, 2048, 6720, 1000)])     # K below the 128 x 64 form's
+                                           (512, 512, 2048, 6720, 1000),      # K below the 128 x 64 form's
+                                           (128, 0, 256, 900, 384)])          # no second operand
 def test_gemm_tn_rows2_two_operands_one_product(K, M0, M1, N, R, Kn):
     """d2p_gemm_f32_tn_rows2: C[:M0] = A0[rows]^T B[rows'], C[M0:] = A1[rows]^T B[rows'] -- the input and the recurrent half of
     an LSTM's kernel gradient as one product on 128 x 64 tiles.  Bit-identical to the two d2p_gemm_f32_tn_rows products on
@@ -1396,12 +1397,13 @@ def test_gemm_tn_rows2_two_operands_one_product(K, M0, M1, N, R, Kn):
     ref = torch.cat([A0[:, :M0], A1], 1).double().cpu()[rowsA.long().cpu()].t() @ B.double().cpu()[rowsB.long().cpu()]
     for acc in (False, True):
         got = C0.clone()
-        K.gemm_tn_rows2(M0, M1, N, Kn, A0, lda0, A1, M1, rowsA, B, N, rowsB, got, N, accumulate=acc)
+        K.gemm_tn_rows2(M0, M1, N, Kn, A0, lda0, A1, max(M1, 1), rowsA, B, N, rowsB, got, N, accumulate=acc)
         want = C0.clone()
         load().d2p_gemm_set_option(256)              # the separate products on 64 x 64 tiles
         try:
             K.gemm_tn_rows(M0, N, Kn, A0, lda0, rowsA, B, N, rowsB, want[:M0], N, accumulate=acc)
-            K.gemm_tn_rows(M1, N, Kn, A1, M1, rowsA, B, N, rowsB, want[M0:], N, accumulate=acc)
+            if M1:
+                K.gemm_tn_rows(M1, N, Kn, A1, M1, rowsA, B, N, rowsB, want[M0:], N, accumulate=acc)
         finally:
             load().d2p_gemm_set_option(0)
         assert torch.equal(got, want), (acc, float((got - want).abs().max()))
